@@ -1,0 +1,415 @@
+"""ctypes front end of the CPU oracle (oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; the product package ``constriction_amd`` never imports
+this module.  The oracle restates the reference's arithmetic (citations in oracle.c) and is
+pinned by tests/golden/reference_vectors.json.
+
+The shared library is (re)built on demand with the Makefile next to this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIBS: dict = {}
+
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def build(native: bool = False) -> Path:
+    """Compile oracle.c if the .so is missing or older than the source."""
+    name = "liboracle_native.so" if native else "liboracle.so"
+    so = _HERE / "_build" / name
+    src = _HERE / "oracle.c"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "native" if native else "all"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def load(native: bool = False):
+    key = bool(native)
+    if key in _LIBS:
+        return _LIBS[key]
+    try:
+        so = build(native)
+    except Exception:
+        if not native:
+            raise
+        so = build(False)
+    lib = C.CDLL(str(so))
+    d, i, u, z, vp = C.c_double, C.c_int, C.c_uint32, C.c_size_t, C.c_void_p
+    i32, i64, u64 = C.c_int32, C.c_int64, C.c_uint64
+    sig = {
+        "cst_oracle_exp": (d, [d]),
+        "cst_oracle_erf": (d, [d]),
+        "cst_oracle_gaussian_cdf": (d, [d, d, d]),
+        "cst_oracle_leaky_gaussian_lcp": (i, [i32, i32, i32, i, i, d, d, C.POINTER(u), C.POINTER(u)]),
+        "cst_oracle_leaky_gaussian_cdf_table": (i, [i32, i32, i, i, d, d, u32p]),
+        "cst_oracle_leaky_gaussian_quantile": (i, [u, i32, i32, i, i, d, d, C.POINTER(i32), C.POINTER(u), C.POINTER(u)]),
+        "cst_oracle_categorical_fast_cdf_f64": (i, [f64p, i, i, u32p]),
+        "cst_oracle_categorical_fast_cdf_f32": (i, [f32p, i, i, u32p]),
+        "cst_oracle_lookup_from_cdf": (None, [u32p, i, i, u16p]),
+        "cst_oracle_ans_new": (vp, [i, i]),
+        "cst_oracle_ans_free": (None, [vp]),
+        "cst_oracle_ans_clear": (None, [vp]),
+        "cst_oracle_ans_state": (u64, [vp]),
+        "cst_oracle_ans_bulk_len": (z, [vp]),
+        "cst_oracle_ans_is_empty": (i, [vp]),
+        "cst_oracle_ans_from_compressed": (vp, [i, i, u32p, z]),
+        "cst_oracle_ans_from_binary": (vp, [i, i, u32p, z]),
+        "cst_oracle_ans_num_words": (z, [vp]),
+        "cst_oracle_ans_num_valid_bits": (z, [vp]),
+        "cst_oracle_ans_get_compressed": (z, [vp, vp]),
+        "cst_oracle_ans_encode_cp": (None, [vp, u, u, i]),
+        "cst_oracle_ans_peek_quantile": (u, [vp, i]),
+        "cst_oracle_ans_decode_advance": (None, [vp, u, u, i]),
+        "cst_oracle_ans_seek": (i, [vp, z, u64]),
+        "cst_oracle_ans_encode_iid_table_reverse": (i64, [vp, i32p, z, i32, u32p, i, i]),
+        "cst_oracle_ans_decode_iid_table": (None, [vp, i32p, z, i32, u32p, i, i]),
+        "cst_oracle_ans_encode_gaussian_reverse": (i64, [vp, i32p, z, i32, i32, f64p, f64p, i, i, i]),
+        "cst_oracle_ans_decode_gaussian": (None, [vp, i32p, z, i32, i32, f64p, f64p, i, i, i]),
+        "cst_oracle_rc_encoder_new": (vp, [i, i]),
+        "cst_oracle_rc_encoder_free": (None, [vp]),
+        "cst_oracle_rc_encode_cp": (i, [vp, u, u, i]),
+        "cst_oracle_rc_get_compressed": (z, [vp, vp]),
+        "cst_oracle_rc_decoder_new": (vp, [i, i, u32p, z]),
+        "cst_oracle_rc_decoder_free": (None, [vp]),
+        "cst_oracle_rc_peek_quantile": (u, [vp, i]),
+        "cst_oracle_rc_decode_advance": (None, [vp, u, u, i]),
+        "cst_oracle_rc_maybe_exhausted": (i, [vp]),
+        "cst_oracle_ans_encode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, i, u32p, z, u32p, i32p, i]),
+        "cst_oracle_ans_decode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, vp, i, u32p, z, u32p, i32p, i]),
+        "cst_oracle_synth_symbols": (None, [u64, z, z, z, i32, i, u32p, i, i, i32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIBS[key] = lib
+    return lib
+
+
+# ---------------------------------------------------------------------------------------------
+# models: every model answers (left, prob) for a symbol and (symbol, left, prob) for a quantile
+# ---------------------------------------------------------------------------------------------
+
+class GaussianModel:
+    """LeakyQuantizer<f64,i32,u{prob_bits},P>(lo..=hi) x Gaussian(mean, std)
+    (src/stream/model/quantize.rs:284-308, 525-568)."""
+
+    def __init__(self, lo, hi, mean, std, P=24, prob_bits=32):
+        self.lo, self.hi, self.mean, self.std, self.P, self.prob_bits = int(lo), int(hi), float(mean), float(std), P, prob_bits
+
+    def lcp(self, sym):
+        lib = load()
+        l, p = C.c_uint32(), C.c_uint32()
+        rc = lib.cst_oracle_leaky_gaussian_lcp(int(sym), self.lo, self.hi, self.P, self.prob_bits, self.mean,
+                                               self.std, C.byref(l), C.byref(p))
+        if rc == 1:
+            raise KeyError("impossible symbol")
+        if rc == 2:
+            raise ArithmeticError("zero probability")
+        return l.value, p.value
+
+    def quantile(self, q):
+        lib = load()
+        s, l, p = C.c_int32(), C.c_uint32(), C.c_uint32()
+        lib.cst_oracle_leaky_gaussian_quantile(int(q), self.lo, self.hi, self.P, self.prob_bits, self.mean,
+                                               self.std, C.byref(s), C.byref(l), C.byref(p))
+        return s.value, l.value, p.value
+
+    def cdf_table(self):
+        n = self.hi - self.lo + 1
+        cdf = np.zeros(n + 1, dtype=np.uint32)
+        rc = load().cst_oracle_leaky_gaussian_cdf_table(self.lo, self.hi, self.P, self.prob_bits, self.mean,
+                                                        self.std, cdf)
+        if rc:
+            raise ArithmeticError("zero probability")
+        return cdf
+
+
+class TableModel:
+    """Tabulated model: symbols lo..lo+n-1, cdf[n+1] (contiguous.rs:673-700 encode,
+    lookup_contiguous.rs:564-605 decode)."""
+
+    def __init__(self, cdf, lo=0, P=24):
+        self.cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        self.lo, self.P = int(lo), P
+        self.n = len(self.cdf) - 1
+        self._mask = (1 << P) - 1 if P < 32 else 0xFFFFFFFF
+
+    def lcp(self, sym):
+        i = int(sym) - self.lo
+        if i < 0 or i >= self.n:
+            raise KeyError("impossible symbol")
+        return int(self.cdf[i]), (int(self.cdf[i + 1]) - int(self.cdf[i])) & 0xFFFFFFFF
+
+    def quantile(self, q):
+        i = int(np.searchsorted(self.cdf[: self.n], q, side="right")) - 1
+        return self.lo + i, int(self.cdf[i]), (int(self.cdf[i + 1]) - int(self.cdf[i])) & 0xFFFFFFFF
+
+
+def categorical_fast_cdf(probs, P=24):
+    """fast_quantized_cdf + trailing 2^P (categorical.rs:16-54, contiguous.rs:203-214)."""
+    probs = np.asarray(probs)
+    n = len(probs)
+    cdf = np.zeros(n + 1, dtype=np.uint32)
+    if probs.dtype == np.float32:
+        rc = load().cst_oracle_categorical_fast_cdf_f32(np.ascontiguousarray(probs), n, P, cdf)
+    else:
+        rc = load().cst_oracle_categorical_fast_cdf_f64(np.ascontiguousarray(probs, dtype=np.float64), n, P, cdf)
+    if rc:
+        raise ValueError("Probability distribution not normalizable")
+    return cdf
+
+
+def lookup_from_cdf(cdf, P):
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    lut = np.zeros(1 << P, dtype=np.uint16)
+    load().cst_oracle_lookup_from_cdf(cdf, len(cdf) - 1, P, lut)
+    return lut
+
+
+# ---------------------------------------------------------------------------------------------
+# coders
+# ---------------------------------------------------------------------------------------------
+
+class AnsCoder:
+    """stream::stack::AnsCoder<W,S> (src/stream/stack.rs) restated; single stream."""
+
+    def __init__(self, compressed=None, seal=False, W=32, S=64):
+        self.W, self.S = W, S
+        lib = load()
+        if compressed is None:
+            self._h = lib.cst_oracle_ans_new(W, S)
+        else:
+            words = np.ascontiguousarray(compressed, dtype=np.uint32)
+            if seal:
+                self._h = lib.cst_oracle_ans_from_binary(W, S, words, len(words))
+            else:
+                self._h = lib.cst_oracle_ans_from_compressed(W, S, words, len(words))
+                if not self._h:
+                    raise ValueError("Invalid compressed data: ANS compressed data never ends in a zero word.")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            load().cst_oracle_ans_free(h)
+
+    # model-generic per-symbol paths
+    def encode_reverse(self, symbols, models, P=24):
+        """models: one model (iid) or a list with one model per symbol."""
+        symbols = np.atleast_1d(np.asarray(symbols))
+        lib = load()
+        for t in range(len(symbols) - 1, -1, -1):
+            m = models[t] if isinstance(models, (list, tuple)) else models
+            l, p = m.lcp(symbols[t])
+            lib.cst_oracle_ans_encode_cp(self._h, l, p, P)
+
+    def decode(self, models, n=None, P=24):
+        lib = load()
+        if isinstance(models, (list, tuple)):
+            n = len(models)
+        out = np.zeros(n, dtype=np.int32)
+        for t in range(n):
+            m = models[t] if isinstance(models, (list, tuple)) else models
+            q = lib.cst_oracle_ans_peek_quantile(self._h, P)
+            s, l, p = m.quantile(q)
+            out[t] = s
+            lib.cst_oracle_ans_decode_advance(self._h, l, p, P)
+        return out
+
+    # fast whole-array paths (C loops)
+    def encode_iid_table_reverse(self, symbols, cdf, lo, P):
+        symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+        cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        rc = load().cst_oracle_ans_encode_iid_table_reverse(self._h, symbols, len(symbols), lo, cdf, len(cdf) - 1, P)
+        if rc:
+            raise KeyError(f"impossible symbol at index {rc - 1}")
+
+    def decode_iid_table(self, n, cdf, lo, P):
+        cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        out = np.zeros(n, dtype=np.int32)
+        load().cst_oracle_ans_decode_iid_table(self._h, out, n, lo, cdf, len(cdf) - 1, P)
+        return out
+
+    def encode_gaussian_reverse(self, symbols, lo, hi, means, stds, P=24, prob_bits=32):
+        symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+        means = np.ascontiguousarray(np.atleast_1d(means), dtype=np.float64)
+        stds = np.ascontiguousarray(np.atleast_1d(stds), dtype=np.float64)
+        iid = int(len(means) == 1 and len(symbols) != 1)
+        rc = load().cst_oracle_ans_encode_gaussian_reverse(self._h, symbols, len(symbols), lo, hi, means, stds, iid,
+                                                           P, prob_bits)
+        if rc:
+            raise KeyError(f"impossible symbol at index {rc - 1}")
+
+    def decode_gaussian(self, n, lo, hi, means, stds, P=24, prob_bits=32):
+        means = np.ascontiguousarray(np.atleast_1d(means), dtype=np.float64)
+        stds = np.ascontiguousarray(np.atleast_1d(stds), dtype=np.float64)
+        iid = int(len(means) == 1 and n != 1)
+        out = np.zeros(n, dtype=np.int32)
+        load().cst_oracle_ans_decode_gaussian(self._h, out, n, lo, hi, means, stds, iid, P, prob_bits)
+        return out
+
+    def get_compressed(self):
+        lib = load()
+        n = lib.cst_oracle_ans_get_compressed(self._h, None)
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            lib.cst_oracle_ans_get_compressed(self._h, out.ctypes.data)
+        return out
+
+    def num_words(self):
+        return load().cst_oracle_ans_num_words(self._h)
+
+    def num_bits(self):
+        return self.W * self.num_words()
+
+    def num_valid_bits(self):
+        return load().cst_oracle_ans_num_valid_bits(self._h)
+
+    def is_empty(self):
+        return bool(load().cst_oracle_ans_is_empty(self._h))
+
+    def pos(self):
+        lib = load()
+        return lib.cst_oracle_ans_bulk_len(self._h), lib.cst_oracle_ans_state(self._h)
+
+    def seek(self, pos, state):
+        if load().cst_oracle_ans_seek(self._h, pos, state):
+            raise ValueError("Tried to seek past end of stream.")
+
+    def clear(self):
+        load().cst_oracle_ans_clear(self._h)
+
+
+class RangeEncoder:
+    """stream::queue::RangeEncoder<W,S> (src/stream/queue.rs:612-705, seal 458-523)."""
+
+    def __init__(self, W=32, S=64):
+        self.W, self.S = W, S
+        self._h = load().cst_oracle_rc_encoder_new(W, S)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            load().cst_oracle_rc_encoder_free(h)
+
+    def encode(self, symbols, models, P=24):
+        symbols = np.atleast_1d(np.asarray(symbols))
+        lib = load()
+        for t in range(len(symbols)):
+            m = models[t] if isinstance(models, (list, tuple)) else models
+            l, p = m.lcp(symbols[t])
+            if lib.cst_oracle_rc_encode_cp(self._h, l, p, P):
+                raise KeyError("impossible symbol")
+
+    def get_compressed(self):
+        lib = load()
+        n = lib.cst_oracle_rc_get_compressed(self._h, None)
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            lib.cst_oracle_rc_get_compressed(self._h, out.ctypes.data)
+        return out
+
+    def num_words(self):
+        return load().cst_oracle_rc_get_compressed(self._h, None)
+
+    def num_bits(self):
+        return self.W * self.num_words()
+
+
+class RangeDecoder:
+    """stream::queue::RangeDecoder<W,S> (src/stream/queue.rs:847-868, 968-1033)."""
+
+    def __init__(self, compressed, W=32, S=64):
+        self.W, self.S = W, S
+        self._words = np.ascontiguousarray(compressed, dtype=np.uint32)
+        self._h = load().cst_oracle_rc_decoder_new(W, S, self._words, len(self._words))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            load().cst_oracle_rc_decoder_free(h)
+
+    def decode(self, models, n=None, P=24):
+        lib = load()
+        if isinstance(models, (list, tuple)):
+            n = len(models)
+        out = np.zeros(n, dtype=np.int32)
+        for t in range(n):
+            m = models[t] if isinstance(models, (list, tuple)) else models
+            q = lib.cst_oracle_rc_peek_quantile(self._h, P)
+            if q == 0xFFFFFFFF:
+                raise AssertionError("Tried to decode from compressed data that is invalid for the employed entropy model.")
+            s, l, p = m.quantile(q)
+            out[t] = s
+            lib.cst_oracle_rc_decode_advance(self._h, l, p, P)
+        return out
+
+    def maybe_exhausted(self):
+        return bool(load().cst_oracle_rc_maybe_exhausted(self._h))
+
+
+# ---------------------------------------------------------------------------------------------
+# batched drivers (CPU baseline) and the synthetic workload
+# ---------------------------------------------------------------------------------------------
+
+def synth_symbols(seed, stream_begin, n_streams, n_per_stream, lo, cdf, P, per_stream_tables=False):
+    """q = splitmix64(seed ^ stream).next() >> (64-P); sym = quantile(q)   (SURVEY.md 8d)."""
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    n_sym = (cdf.shape[-1]) - 1
+    out = np.zeros((n_streams, n_per_stream), dtype=np.int32)
+    load().cst_oracle_synth_symbols(seed, stream_begin, n_streams, n_per_stream, lo, n_sym, cdf.reshape(-1),
+                                    int(per_stream_tables), P, out.reshape(-1))
+    return out
+
+
+def slab_stride(n_per_stream, P, W=32, S=64):
+    """Upper bound on words per stream: at most one word per symbol, and at most
+    ceil(n*P/W) from the information content, plus the S/W state words."""
+    return min(n_per_stream, (n_per_stream * P + W - 1) // W) + S // W
+
+
+def ans_encode_batch(symbols, lo, cdf, P, W=32, S=64, stride=None, n_threads=1, native=False):
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    n_streams, n = symbols.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    per_stream = cdf.ndim == 2
+    n_sym = cdf.shape[-1] - 1
+    stride = stride or slab_stride(n, P, W, S)
+    words = np.zeros((n_streams, stride), dtype=np.uint32)
+    n_words = np.zeros(n_streams, dtype=np.uint32)
+    status = np.zeros(n_streams, dtype=np.int32)
+    load(native).cst_oracle_ans_encode_batch(W, S, P, symbols.reshape(-1), n_streams, n, lo, n_sym, cdf.reshape(-1),
+                                             int(per_stream), words.reshape(-1), stride, n_words, status, n_threads)
+    return words, n_words, status
+
+
+def ans_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64, lookup=None, n_threads=1, native=False):
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    n_streams, stride = words.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    per_stream = cdf.ndim == 2
+    n_sym = cdf.shape[-1] - 1
+    out = np.zeros((n_streams, n_per_stream), dtype=np.int32)
+    status = np.zeros(n_streams, dtype=np.int32)
+    lut_ptr = None
+    if lookup is not None:
+        lookup = np.ascontiguousarray(lookup, dtype=np.uint16)
+        lut_ptr = lookup.ctypes.data
+    load(native).cst_oracle_ans_decode_batch(W, S, P, out.reshape(-1), n_streams, n_per_stream, lo, n_sym,
+                                             cdf.reshape(-1), lut_ptr, int(per_stream), words.reshape(-1), stride,
+                                             np.ascontiguousarray(n_words, dtype=np.uint32), status, n_threads)
+    return out, status

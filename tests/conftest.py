@@ -1,0 +1,24 @@
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(ROOT / "tests" / "golden" / "reference_vectors.json") as f:
+        return json.load(f)
+
+
+def golden_vectors():
+    with open(ROOT / "tests" / "golden" / "reference_vectors.json") as f:
+        return json.load(f)["vectors"]
