@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI declared in include/constriction_amd.h.
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible the
+product path raises (BackendUnavailable).  Nothing here imports the test oracle."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libconstriction_amd.so"
+
+CST_OK = 0
+CST_ERR_INVALID_ARGUMENT = -1
+CST_ERR_HIP = -2
+CST_ERR_NO_DEVICE = -3
+CST_ERR_MODEL = -4
+CST_ERR_OUT_OF_MEMORY = -5
+
+STREAM_OK = 0
+STREAM_IMPOSSIBLE_SYMBOL = 1
+STREAM_CAPACITY = 2
+STREAM_INVALID_DATA = 3
+
+LAYOUT_STREAM_MAJOR = 0
+LAYOUT_SYMBOL_MAJOR = 1
+
+FLAG_NONE = 0
+FLAG_RAW_STATE = 1
+
+
+class BackendUnavailable(RuntimeError):
+    """The HIP extension (or a GPU) is missing.  The product path never falls back to the CPU."""
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class CoderConfig(C.Structure):
+    _fields_ = [("word_bits", C.c_int32), ("state_bits", C.c_int32), ("precision", C.c_int32)]
+
+
+_vp, _z, _i32, _u32, _f64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_double
+
+# name -> (restype, argtypes); one entry per symbol of include/constriction_amd.h
+SIGNATURES = {
+    "cst_abi_version": (_i32, []),
+    "cst_device_count": (_i32, []),
+    "cst_last_hip_error": (C.c_char_p, []),
+    "cst_ans_max_words": (_z, [_z, CoderConfig]),
+    "cst_range_max_words": (_z, [_z, CoderConfig]),
+    "cst_model_create_table": (_i32, [_i32, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "cst_model_create_gaussian": (_i32, [_i32, _i32, _i32, _f64, _f64, _vp, C.POINTER(_vp)]),
+    "cst_model_create_gaussian_per_stream": (_i32, [_i32, _i32, _i32, _vp, _vp, _z, _vp, C.POINTER(_vp)]),
+    "cst_model_destroy": (_i32, [_vp]),
+    "cst_model_precision": (_i32, [_vp]),
+    "cst_model_min_symbol": (_i32, [_vp]),
+    "cst_model_n_symbols": (_i32, [_vp]),
+    "cst_model_n_tables": (_z, [_vp]),
+    "cst_model_get_cdf": (_i32, [_vp, _z, _vp, _vp]),
+    "cst_ans_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, C.POINTER(C.c_uint64), _vp]),
+    "cst_ans_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_range_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp]),
+    "cst_range_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp]),
+    "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
+    "cst_debug_gaussian_lcp": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _z, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libconstriction_amd.so and types every entry point.  Does not need a GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise BackendUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -m constriction_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cst_abi_version() != 1:
+        raise BackendUnavailable("ABI version mismatch between _native.py and libconstriction_amd.so")
+    _lib = lib
+    return lib
+
+
+def lib():
+    """The library, after checking that a GPU is actually present."""
+    l = load_library()
+    n = l.cst_device_count()
+    if n < 1:
+        raise BackendUnavailable("no MI355X (gfx950) device visible; constriction_amd has no CPU fallback")
+    return l
+
+
+def check(status: int, what: str = ""):
+    if status == CST_OK:
+        return
+    l = load_library()
+    msg = {CST_ERR_INVALID_ARGUMENT: "invalid argument", CST_ERR_HIP: "HIP error: " + l.cst_last_hip_error().decode(),
+           CST_ERR_NO_DEVICE: "no device", CST_ERR_MODEL: "model cannot be built",
+           CST_ERR_OUT_OF_MEMORY: "out of memory"}.get(status, f"status {status}")
+    if status == CST_ERR_NO_DEVICE:
+        raise BackendUnavailable(f"{what}: {msg}")
+    if status == CST_ERR_MODEL:
+        raise ValueError(f"{what}: {msg}")
+    raise BackendError(f"{what}: {msg}")

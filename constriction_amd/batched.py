@@ -1,0 +1,200 @@
+"""Batched, device-resident front end: thousands of independent coders per call.
+
+This is the extension the reference has no counterpart for (it codes one stream per `AnsCoder`
+object, src/stream/stack.rs); every stream's compressed words are bit-identical to what one
+reference coder would produce for that stream alone.  PyTorch is used for device memory and
+streams only; all computation happens in the HIP library behind include/constriction_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+PRESETS = {"default": (32, 64, 24), "lookup": (32, 64, 12), "small": (16, 32, 12)}
+
+
+def _cfg(W, S, P):
+    return N.CoderConfig(W, S, P)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_cuda(t: torch.Tensor, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live in device memory (HBM)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}")
+    return t.contiguous()
+
+
+class Model:
+    """Device image of an entropy model with contiguous support (include/constriction_amd.h, cst_model)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.load_library().cst_model_destroy(h)
+            except Exception:
+                pass
+
+    @classmethod
+    def from_cdf(cls, cdf, min_symbol: int, precision: int) -> "Model":
+        """Any tabulated model: cdf[n+1] with cdf[0]=0 < ... < cdf[n]=2^P."""
+        cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        h = C.c_void_p()
+        N.check(N.lib().cst_model_create_table(precision, int(min_symbol), len(cdf) - 1, cdf.ctypes.data, C.byref(h)),
+                "cst_model_create_table")
+        return cls(h)
+
+    @classmethod
+    def quantized_gaussian(cls, min_symbol: int, max_symbol: int, mean: float, std: float, precision: int) -> "Model":
+        """LeakyQuantizer(min..=max) x Gaussian(mean, std), tabulated on the GPU in bit-exact f64."""
+        h = C.c_void_p()
+        N.check(N.lib().cst_model_create_gaussian(precision, int(min_symbol), int(max_symbol), float(mean), float(std),
+                                                  _stream_ptr(), C.byref(h)), "cst_model_create_gaussian")
+        return cls(h)
+
+    @classmethod
+    def quantized_gaussian_per_stream(cls, min_symbol, max_symbol, means: torch.Tensor, stds: torch.Tensor,
+                                      precision: int) -> "Model":
+        means = _require_cuda(means, torch.float64, "means")
+        stds = _require_cuda(stds, torch.float64, "stds")
+        if means.shape != stds.shape or means.dim() != 1:
+            raise ValueError("means and stds must be 1-d and of equal length (one entry per stream)")
+        h = C.c_void_p()
+        N.check(N.lib().cst_model_create_gaussian_per_stream(precision, int(min_symbol), int(max_symbol), _ptr(means),
+                                                             _ptr(stds), means.numel(), _stream_ptr(), C.byref(h)),
+                "cst_model_create_gaussian_per_stream")
+        return cls(h)
+
+    @property
+    def precision(self):
+        return N.load_library().cst_model_precision(self._h)
+
+    @property
+    def min_symbol(self):
+        return N.load_library().cst_model_min_symbol(self._h)
+
+    @property
+    def n_symbols(self):
+        return N.load_library().cst_model_n_symbols(self._h)
+
+    @property
+    def n_tables(self):
+        return N.load_library().cst_model_n_tables(self._h)
+
+    def cdf(self, index: int = 0) -> np.ndarray:
+        out = np.zeros(self.n_symbols + 1, dtype=np.uint32)
+        N.check(N.lib().cst_model_get_cdf(self._h, index, out.ctypes.data, _stream_ptr()), "cst_model_get_cdf")
+        return out
+
+
+@dataclass
+class EncodedBatch:
+    """Per-stream compressed words in fixed-stride slabs (stream s: words[s, :n_words[s]])."""
+    words: torch.Tensor      # uint32 as int32 storage? -> torch.int32 view of uint32 words [n_streams, stride]
+    n_words: torch.Tensor    # int32 [n_streams] (values are counts)
+    status: torch.Tensor     # int32 [n_streams]
+    config: tuple
+
+    @property
+    def stride(self):
+        return self.words.shape[1]
+
+    def total_words(self) -> int:
+        return int(self.n_words.to(torch.int64).sum().item())
+
+    def stream(self, s: int) -> np.ndarray:
+        n = int(self.n_words[s].item())
+        return self.words[s, :n].cpu().numpy().view(np.uint32)
+
+    def to_numpy(self):
+        return (self.words.cpu().numpy().view(np.uint32), self.n_words.cpu().numpy().view(np.uint32),
+                self.status.cpu().numpy())
+
+
+def max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
+    return N.load_library().cst_ans_max_words(n_per_stream, _cfg(*config))
+
+
+def _layout_shape(symbols: torch.Tensor, layout: str):
+    if symbols.dim() != 2:
+        raise ValueError("symbols must be 2-d")
+    if layout == "stream_major":
+        return symbols.shape[0], symbols.shape[1], N.LAYOUT_STREAM_MAJOR
+    if layout == "symbol_major":
+        return symbols.shape[1], symbols.shape[0], N.LAYOUT_SYMBOL_MAJOR
+    raise ValueError("layout must be 'stream_major' or 'symbol_major'")
+
+
+def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
+               stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895)."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    if out is None:
+        stride = stride or max_words(n_per, config)
+        dev = symbols.device
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
+                                         out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
+                                         _stream_ptr()), "cst_ans_encode_batch")
+    return out
+
+
+def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, config=None):
+    """One AnsCoder per stream: from_compressed + decode_iid_symbols (stack.rs:299-318, mod.rs:1016-1031).
+
+    `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout."""
+    if isinstance(encoded, EncodedBatch):
+        words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
+        stride = words.shape[1]
+    else:
+        words, n_words = encoded
+        stride = words.shape[1] if words.dim() == 2 else 0
+        config = config or (32, 64, 12)
+    n_streams = n_words.numel()
+    dev = words.device
+    if out is None:
+        shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
+        out = torch.empty(shape, dtype=torch.int32, device=dev)
+    lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
+    status = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
+                                         _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status), N.FLAG_NONE,
+                                         _stream_ptr()), "cst_ans_decode_batch")
+    return out, status
+
+
+def compact(encoded: EncodedBatch):
+    """Packs the slabs: returns (packed uint32 words as int32 tensor, offsets int64[n_streams+1])."""
+    n_streams = encoded.n_words.numel()
+    dev = encoded.words.device
+    offsets = torch.empty(n_streams + 1, dtype=torch.int64, device=dev)
+    total = C.c_uint64(0)
+    L = N.lib()
+    N.check(L.cst_compact_words(None, 0, _ptr(encoded.n_words), n_streams, _ptr(offsets), None, 0, C.byref(total),
+                                _stream_ptr()), "cst_compact_words(offsets)")
+    packed = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
+    N.check(L.cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
+                                _ptr(offsets), _ptr(packed), packed.numel(), None, _stream_ptr()), "cst_compact_words")
+    return packed[: total.value], offsets

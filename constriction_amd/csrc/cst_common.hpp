@@ -1,0 +1,82 @@
+// cst_common.hpp -- shared host/device declarations of the MI355X entropy-coding backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/constriction_amd.h"
+
+namespace cst {
+
+constexpr int kWave = 64;        // gfx950 wavefront
+constexpr int kBlock = 256;      // 4 waves = one per SIMD of a CU
+constexpr int kTileSyms = 32;    // symbols per stream staged per LDS tile (128 B rows)
+constexpr int kTileStride = 36;  // words per LDS tile row: 16-B aligned and conflict-free for b128
+
+// Encoder table entry (one per symbol of the support): left cumulative, probability and the
+// 64-bit reciprocal m = floor(2^64 / p) (p >= 2; m = 2^64-1 for p = 1) used for the exact
+// state / p of src/stream/stack.rs:1042-1043.  The high word of m is floor(2^32 / p), the
+// reciprocal the 32-bit-state preset uses.
+struct __attribute__((aligned(16))) EncEntry {
+    uint32_t c;
+    uint32_t p;
+    uint32_t m_lo;
+    uint32_t m_hi;
+};
+
+// Decoder lookup entry for quantile q (lookup_contiguous.rs:564-605 collapsed into one load):
+//   packed32: idx[0,8) | c[8,20) | p[20,32)      (P <= 12 and n_symbols <= 256)
+//   packed64: c[0,24) | p[24,48) | idx[48,64)    (P <= 16)
+__host__ __device__ inline uint32_t pack_dec32(uint32_t idx, uint32_t c, uint32_t p) { return idx | (c << 8) | (p << 20); }
+__host__ __device__ inline uint64_t pack_dec64(uint32_t idx, uint32_t c, uint32_t p) {
+    return (uint64_t)c | ((uint64_t)p << 24) | ((uint64_t)idx << 48);
+}
+
+enum DecMode : int {
+    kDecLut32 = 0,   // 2^P x u32 in LDS
+    kDecLut64 = 1,   // 2^P x u64 in LDS (P <= 13) or global
+    kDecBucket = 2,  // cdf[n+1] + bucket index, linear scan (any P)
+};
+
+} // namespace cst
+
+// The opaque model handle of the C ABI.
+struct cst_model {
+    int32_t precision = 0;
+    int32_t min_symbol = 0;
+    int32_t n_symbols = 0;
+    size_t n_tables = 1;     // 1 = shared, else one table per stream
+    int device = 0;
+    uint32_t* d_cdf = nullptr;        // [n_tables][n_symbols + 1]
+    // shared-table artefacts (n_tables == 1)
+    cst::EncEntry* d_enc = nullptr;   // [n_symbols]
+    uint32_t* d_dec32 = nullptr;      // [2^P] or null
+    uint64_t* d_dec64 = nullptr;      // [2^P] or null
+    uint16_t* d_bucket = nullptr;     // [2^bucket_bits + 1]
+    int32_t bucket_bits = 0;
+    // per-stream artefacts (n_tables > 1): 16-bit cdf rows, padded to a multiple of 8 entries
+    uint16_t* d_cdf16 = nullptr;      // [n_tables][cdf16_stride], only when precision <= 16... (2^P stored as 0)
+    int32_t cdf16_stride = 0;
+};
+
+namespace cst {
+
+// thread-local record of the last HIP failure (cst_last_hip_error)
+void set_hip_error(hipError_t e, const char* what);
+
+#define CST_HIP_TRY(expr)                                      \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) {                                \
+            ::cst::set_hip_error(_e, #expr);                   \
+            return CST_ERR_HIP;                                \
+        }                                                      \
+    } while (0)
+
+inline bool config_supported(cst_coder_config c) {
+    if (c.word_bits == 32 && c.state_bits == 64) return c.precision >= 1 && c.precision <= 24;
+    if (c.word_bits == 16 && c.state_bits == 32) return c.precision >= 1 && c.precision <= 16;
+    return false;
+}
+
+} // namespace cst

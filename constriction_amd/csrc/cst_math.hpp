@@ -1,0 +1,177 @@
+// cst_math.hpp -- bit-exact f64 special functions and the LeakyQuantizer arithmetic, for gfx950.
+//
+// The reference computes the quantized-Gaussian cumulative in f64 through third-party crates
+// (probability 0.20.3 -> special 0.10.3 -> libm 0.2.16, see Cargo.lock); the call sites are
+// src/stream/model/quantize.rs:546,558.  libm's `erf`/`exp` are the msun algorithms as arranged by
+// musl.  This header evaluates the same expression trees on the GPU.  It MUST be compiled with
+// -ffp-contract=off: every operation below has to round exactly once, in the order written
+// (v_fma_f64 fusion would change low bits and with them floor(free_weight * cdf)).
+// f64 add/mul/div on gfx950 are IEEE correctly rounded and keep subnormals, so the results are
+// identical to a scalar CPU evaluation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cst {
+
+__device__ __forceinline__ uint32_t f64_hi(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ double f64_clear_lo(double x) { return __hiloint2double(__double2hiint(x), 0); }
+__device__ __forceinline__ double f64_pow2(int n) { return __hiloint2double((0x3ff + n) << 20, 0); }
+
+// scalbn as musl writes it; only |n| < 2100 can occur.
+__device__ inline double scalbn_exact(double x, int n) {
+    double y = x;
+    if (n > 1023) {
+        y *= 0x1p1023; n -= 1023;
+        if (n > 1023) { y *= 0x1p1023; n -= 1023; if (n > 1023) n = 1023; }
+    } else if (n < -1022) {
+        y *= 0x1p-1022 * 0x1p53; n += 1022 - 53;
+        if (n < -1022) { y *= 0x1p-1022 * 0x1p53; n += 1022 - 53; if (n < -1022) n = -1022; }
+    }
+    return y * f64_pow2(n);
+}
+
+__device__ inline double exp_exact(double x) {
+    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                     invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                     P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                     P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    uint32_t hx = f64_hi(x);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4086232bu) {
+        if (x != x) return x;
+        if (x > 709.782712893383973096) return x * 0x1p1023;
+        if (x < -745.13321910194110842) return 0.0;
+    }
+    double hi, lo;
+    int k;
+    if (hx > 0x3fd62e42u) {
+        if (hx >= 0x3ff0a2b2u) k = (int)(invln2 * x + (sign ? -0.5 : 0.5));
+        else k = 1 - sign - sign;
+        hi = x - (double)k * ln2hi;
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x3e300000u) {
+        k = 0; hi = x; lo = 0.0;
+    } else {
+        return 1.0 + x;
+    }
+    const double xx = x * x;
+    const double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    const double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    return k == 0 ? y : scalbn_exact(y, k);
+}
+
+__device__ inline double erf_exact(double x) {
+    constexpr double erx = 8.45062911510467529297e-01, efx8 = 1.02703333676410069053e+00,
+        pp0 = 1.28379167095512558561e-01, pp1 = -3.25042107247001499370e-01, pp2 = -2.84817495755985104766e-02,
+        pp3 = -5.77027029648944159157e-03, pp4 = -2.37630166566501626084e-05,
+        qq1 = 3.97917223959155352819e-01, qq2 = 6.50222499887672944485e-02, qq3 = 5.08130628187576562776e-03,
+        qq4 = 1.32494738004321644526e-04, qq5 = -3.96022827877536812320e-06,
+        pa0 = -2.36211856075265944077e-03, pa1 = 4.14856118683748331666e-01, pa2 = -3.72207876035701323847e-01,
+        pa3 = 3.18346619901161753674e-01, pa4 = -1.10894694282396677476e-01, pa5 = 3.54783043256182359371e-02,
+        pa6 = -2.16637559486879084300e-03,
+        qa1 = 1.06420880400844228286e-01, qa2 = 5.40397917702171048937e-01, qa3 = 7.18286544141962662868e-02,
+        qa4 = 1.26171219808761642112e-01, qa5 = 1.36370839120290507362e-02, qa6 = 1.19844998467991074170e-02,
+        ra0 = -9.86494403484714822705e-03, ra1 = -6.93858572707181764372e-01, ra2 = -1.05586262253232909814e+01,
+        ra3 = -6.23753324503260060396e+01, ra4 = -1.62396669462573470355e+02, ra5 = -1.84605092906711035994e+02,
+        ra6 = -8.12874355063065934246e+01, ra7 = -9.81432934416914548592e+00,
+        sa1 = 1.96512716674392571292e+01, sa2 = 1.37657754143519042600e+02, sa3 = 4.34565877475229228821e+02,
+        sa4 = 6.45387271733267880336e+02, sa5 = 4.29008140027567833386e+02, sa6 = 1.08635005541779435134e+02,
+        sa7 = 6.57024977031928170135e+00, sa8 = -6.04244152148580987438e-02,
+        rb0 = -9.86494292470009928597e-03, rb1 = -7.99283237680523006574e-01, rb2 = -1.77579549177547519889e+01,
+        rb3 = -1.60636384855821916062e+02, rb4 = -6.37566443368389627722e+02, rb5 = -1.02509513161107724954e+03,
+        rb6 = -4.83519191608651397019e+02,
+        sb1 = 3.03380607434824582924e+01, sb2 = 3.25792512996573918826e+02, sb3 = 1.53672958608443695994e+03,
+        sb4 = 3.19985821950859553908e+03, sb5 = 2.55305040643316442583e+03, sb6 = 4.74528541206955367215e+02,
+        sb7 = -2.24409524465858183362e+01;
+
+    uint32_t ix = f64_hi(x);
+    const int sign = (int)(ix >> 31);
+    ix &= 0x7fffffffu;
+    if (ix >= 0x7ff00000u) return (double)(1 - 2 * sign) + 1.0 / x;
+    if (ix < 0x3feb0000u) { // |x| < 0.84375
+        if (ix < 0x3e300000u) return 0.125 * (8.0 * x + efx8 * x);
+        const double z = x * x;
+        const double r = pp0 + z * (pp1 + z * (pp2 + z * (pp3 + z * pp4)));
+        const double s = 1.0 + z * (qq1 + z * (qq2 + z * (qq3 + z * (qq4 + z * qq5))));
+        const double y = r / s;
+        return x + x * y;
+    }
+    double y;
+    if (ix < 0x40180000u) { // 0.84375 <= |x| < 6: y = 1 - erfc(|x|)
+        const double ax = fabs(x);
+        double erfc_val;
+        if (ix < 0x3ff40000u) { // |x| < 1.25
+            const double s = ax - 1.0;
+            const double P = pa0 + s * (pa1 + s * (pa2 + s * (pa3 + s * (pa4 + s * (pa5 + s * pa6)))));
+            const double Q = 1.0 + s * (qa1 + s * (qa2 + s * (qa3 + s * (qa4 + s * (qa5 + s * qa6)))));
+            erfc_val = 1.0 - erx - P / Q;
+        } else {
+            const double s = 1.0 / (ax * ax);
+            double R, Sv;
+            if (ix < 0x4006db6du) { // |x| < 1/.35
+                R = ra0 + s * (ra1 + s * (ra2 + s * (ra3 + s * (ra4 + s * (ra5 + s * (ra6 + s * ra7))))));
+                Sv = 1.0 + s * (sa1 + s * (sa2 + s * (sa3 + s * (sa4 + s * (sa5 + s * (sa6 + s * (sa7 + s * sa8)))))));
+            } else {
+                R = rb0 + s * (rb1 + s * (rb2 + s * (rb3 + s * (rb4 + s * (rb5 + s * rb6)))));
+                Sv = 1.0 + s * (sb1 + s * (sb2 + s * (sb3 + s * (sb4 + s * (sb5 + s * (sb6 + s * sb7))))));
+            }
+            const double z = f64_clear_lo(ax);
+            erfc_val = exp_exact(-z * z - 0.5625) * exp_exact((z - ax) * (z + ax) + R / Sv) / ax;
+        }
+        y = 1.0 - erfc_val;
+    } else {
+        y = 1.0 - 0x1p-1022;
+    }
+    return sign ? -y : y;
+}
+
+// probability::distribution::Gaussian::distribution (third-party; used at quantize.rs:546,558)
+__device__ __forceinline__ double gaussian_cdf_exact(double x, double mu, double sigma) {
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    return (1.0 + erf_exact((x - mu) / (sigma * sqrt2))) / 2.0;
+}
+
+// Rust `f64 as u32`
+__device__ __forceinline__ uint32_t f64_as_u32_sat(double v) {
+    if (!(v > 0.0)) return 0u;
+    if (v >= 4294967296.0) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+// LeakilyQuantizedDistribution::left_cumulative_and_probability, quantize.rs:525-568, for
+// Symbol=i32 and Probability=u{prob_bits}.  Returns false if sym is outside [lo, hi].
+// `left` and `prob` are wrapped to prob_bits bits; prob == 0 signals an invalid distribution.
+__device__ inline bool leaky_gaussian_lcp(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu,
+                                          double sigma, uint32_t& left, uint32_t& prob) {
+    if (sym < lo || sym > hi) return false;
+    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
+    const uint32_t max_prob = pmask >> (prob_bits - P);
+    const double free_weight = (double)(max_prob - ((uint32_t)hi - (uint32_t)lo)); // quantize.rs:297-301
+    const uint32_t slack = ((uint32_t)sym - (uint32_t)lo) & pmask;               // quantize.rs:475-486
+    uint32_t l, r;
+    if (sym == lo) l = 0u;
+    else l = (f64_as_u32_sat(free_weight * gaussian_cdf_exact((double)sym - 0.5, mu, sigma)) + slack) & pmask;
+    if (sym == hi) r = (P >= 32 ? 0u : (1u << P)) & pmask;
+    else r = (f64_as_u32_sat(free_weight * gaussian_cdf_exact((double)sym + 0.5, mu, sigma)) + slack + 1u) & pmask;
+    left = l;
+    prob = (r - l) & pmask;
+    return true;
+}
+
+// left cumulative of symbol index i in [0, n]  (i == n gives 2^P); used to tabulate a model and for
+// decode-side searches.  Bit-identical to the `left` of leaky_gaussian_lcp(lo + i).
+__device__ inline uint32_t leaky_gaussian_left(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
+                                               double sigma) {
+    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
+    if (i <= 0) return 0u;
+    if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+    const uint32_t max_prob = pmask >> (prob_bits - P);
+    const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
+    const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
+    return (f64_as_u32_sat(free_weight * gaussian_cdf_exact(x, mu, sigma)) + (uint32_t)i) & pmask;
+}
+
+} // namespace cst

@@ -1,0 +1,264 @@
+// cst_model.hip -- entropy-model tables: device construction (bit-exact f64) and host-side derivation
+// of the encoder / decoder images the coder kernels consume.
+#include <vector>
+#include <new>
+
+#include "cst_common.hpp"
+#include "cst_math.hpp"
+
+namespace cst {
+
+// cdf[table][i] = left cumulative of symbol index i (i = n gives 2^P); one thread per entry.
+// This is the tabulation of LeakilyQuantizedDistribution::left_cumulative_and_probability
+// (src/stream/model/quantize.rs:525-568) -- NOT of symbol_table() (SURVEY.md hazard 1).
+__global__ void gaussian_cdf_kernel(int P, int32_t lo, int32_t n, const double* __restrict__ means,
+                                    const double* __restrict__ stds, double mean0, double std0, size_t n_tables,
+                                    uint32_t* __restrict__ cdf) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)n + 1;
+    if (gid >= n_tables * per) return;
+    const size_t tbl = gid / per;
+    const int32_t i = (int32_t)(gid - tbl * per);
+    const double mu = means ? means[tbl] : mean0;
+    const double sd = stds ? stds[tbl] : std0;
+    cdf[gid] = leaky_gaussian_left(i, lo, n, P, 32, mu, sd);
+}
+
+// 16-bit per-stream cdf rows for the LDS-resident per-stream models (2^P stored as-is when it fits,
+// else wrapped to 0; consumers special-case the last entry).
+__global__ void cdf_to_u16_kernel(const uint32_t* __restrict__ cdf, size_t n_tables, int32_t n, int32_t stride16,
+                                  uint16_t* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_tables * (size_t)stride16) return;
+    const size_t tbl = gid / stride16;
+    const int32_t i = (int32_t)(gid - tbl * stride16);
+    out[gid] = (i <= n) ? (uint16_t)cdf[tbl * ((size_t)n + 1) + i] : (uint16_t)0xffff;
+}
+
+__global__ void debug_erf_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = erf_exact(x[i]);
+}
+
+__global__ void debug_lcp_kernel(int P, int prob_bits, int32_t lo, int32_t hi, const int32_t* __restrict__ sym,
+                                 const double* __restrict__ means, const double* __restrict__ stds,
+                                 uint32_t* __restrict__ left, uint32_t* __restrict__ prob, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t l = 0, p = 0;
+    if (!leaky_gaussian_lcp(sym[i], lo, hi, P, prob_bits, means[i], stds[i], l, p)) { l = 0xffffffffu; p = 0; }
+    left[i] = l; prob[i] = p;
+}
+
+static bool cdf_valid(const uint32_t* cdf, int n, int P) {
+    if (cdf[0] != 0u) return false;
+    if ((uint64_t)cdf[n] != ((uint64_t)1 << P)) return false;
+    for (int i = 0; i < n; ++i)
+        if (cdf[i + 1] <= cdf[i]) return false;
+    return true;
+}
+
+// Derive the encoder entries, decoder lookup and bucket index from a validated host cdf and
+// upload them.  (lookup_contiguous.rs:611-636 builds the same quantile -> index map.)
+static cst_status upload_shared_tables(cst_model* m, const uint32_t* cdf) {
+    const int n = m->n_symbols, P = m->precision;
+    std::vector<EncEntry> enc((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t p = cdf[i + 1] - cdf[i];
+        const unsigned __int128 one = (unsigned __int128)1 << 64;
+        const uint64_t mm = p == 1 ? ~0ull : (uint64_t)(one / p);
+        enc[i] = EncEntry{cdf[i], p, (uint32_t)mm, (uint32_t)(mm >> 32)};
+    }
+    CST_HIP_TRY(hipMalloc(&m->d_enc, sizeof(EncEntry) * (size_t)n));
+    CST_HIP_TRY(hipMemcpy(m->d_enc, enc.data(), sizeof(EncEntry) * (size_t)n, hipMemcpyHostToDevice));
+
+    if (P <= 16) {
+        const size_t total = (size_t)1 << P;
+        if (P <= 12 && n <= 256) {
+            std::vector<uint32_t> lut(total);
+            int i = 0;
+            for (size_t q = 0; q < total; ++q) {
+                while (cdf[i + 1] <= q) ++i;
+                lut[q] = pack_dec32((uint32_t)i, cdf[i], cdf[i + 1] - cdf[i]);
+            }
+            CST_HIP_TRY(hipMalloc(&m->d_dec32, 4 * total));
+            CST_HIP_TRY(hipMemcpy(m->d_dec32, lut.data(), 4 * total, hipMemcpyHostToDevice));
+        }
+        std::vector<uint64_t> lut(total);
+        int i = 0;
+        for (size_t q = 0; q < total; ++q) {
+            while (cdf[i + 1] <= q) ++i;
+            lut[q] = pack_dec64((uint32_t)i, cdf[i], cdf[i + 1] - cdf[i]);
+        }
+        CST_HIP_TRY(hipMalloc(&m->d_dec64, 8 * total));
+        CST_HIP_TRY(hipMemcpy(m->d_dec64, lut.data(), 8 * total, hipMemcpyHostToDevice));
+    }
+    // bucket index for the generic (any P) decoder
+    m->bucket_bits = P < 11 ? P : 11;
+    {
+        const size_t nb = (size_t)1 << m->bucket_bits;
+        const int shift = P - m->bucket_bits;
+        std::vector<uint16_t> b(nb);
+        int i = 0;
+        for (size_t k = 0; k < nb; ++k) {
+            const uint64_t q = (uint64_t)k << shift;
+            while (cdf[i + 1] <= q) ++i;
+            b[k] = (uint16_t)(i > 0xffff ? 0xffff : i);
+        }
+        CST_HIP_TRY(hipMalloc(&m->d_bucket, 2 * nb));
+        CST_HIP_TRY(hipMemcpy(m->d_bucket, b.data(), 2 * nb, hipMemcpyHostToDevice));
+    }
+    return CST_OK;
+}
+
+static cst_status check_model_args(int32_t P, int64_t n_symbols) {
+    if (P < 1 || P > 24) return CST_ERR_INVALID_ARGUMENT;
+    // LeakyQuantizer::new panics on < 2 symbols or more than 2^P (quantize.rs:292-301)
+    if (n_symbols < 2 || n_symbols > ((int64_t)1 << P) || n_symbols > 65536) return CST_ERR_MODEL;
+    return CST_OK;
+}
+
+} // namespace cst
+
+using namespace cst;
+
+extern "C" {
+
+cst_status cst_model_create_table(int32_t precision, int32_t min_symbol, int32_t n_symbols, const uint32_t* h_cdf,
+                                  cst_model** out) {
+    if (!out || !h_cdf) return CST_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (cst_status st = check_model_args(precision, n_symbols)) return st;
+    if ((int64_t)min_symbol + n_symbols - 1 > INT32_MAX) return CST_ERR_INVALID_ARGUMENT;
+    if (!cdf_valid(h_cdf, n_symbols, precision)) return CST_ERR_MODEL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CST_ERR_NO_DEVICE;
+    cst_model* m = new (std::nothrow) cst_model();
+    if (!m) return CST_ERR_OUT_OF_MEMORY;
+    m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n_symbols; m->n_tables = 1;
+    hipGetDevice(&m->device);
+    const size_t bytes = 4 * ((size_t)n_symbols + 1);
+    hipError_t e = hipMalloc(&m->d_cdf, bytes);
+    if (e == hipSuccess) e = hipMemcpy(m->d_cdf, h_cdf, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_hip_error(e, "model upload"); cst_model_destroy(m); return CST_ERR_HIP; }
+    if (cst_status st = upload_shared_tables(m, h_cdf)) { cst_model_destroy(m); return st; }
+    *out = m;
+    return CST_OK;
+}
+
+cst_status cst_model_create_gaussian(int32_t precision, int32_t min_symbol, int32_t max_symbol, double mean, double std,
+                                     void* stream, cst_model** out) {
+    if (!out) return CST_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (max_symbol <= min_symbol) return CST_ERR_MODEL; // degenerate support, quantize.rs:292-294
+    const int64_t n64 = (int64_t)max_symbol - min_symbol + 1;
+    if (cst_status st = check_model_args(precision, n64)) return st;
+    // `assert!(std > 0.0)` in the reference's constructor (pybindings/stream/model.rs:654-657)
+    if (!(std > 0.0) || !(mean == mean) || std > 1.7976931348623157e308 || mean > 1.7976931348623157e308 ||
+        mean < -1.7976931348623157e308)
+        return CST_ERR_MODEL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CST_ERR_NO_DEVICE;
+    const int n = (int)n64;
+    hipStream_t hs = (hipStream_t)stream;
+    cst_model* m = new (std::nothrow) cst_model();
+    if (!m) return CST_ERR_OUT_OF_MEMORY;
+    m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = 1;
+    hipGetDevice(&m->device);
+    std::vector<uint32_t> h((size_t)n + 1);
+    hipError_t e = hipMalloc(&m->d_cdf, 4 * ((size_t)n + 1));
+    if (e == hipSuccess) {
+        const int threads = 256, blocks = (n + 1 + threads - 1) / threads;
+        hipLaunchKernelGGL(gaussian_cdf_kernel, dim3(blocks), dim3(threads), 0, hs, precision, min_symbol, n,
+                           (const double*)nullptr, (const double*)nullptr, mean, std, (size_t)1, m->d_cdf);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), m->d_cdf, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs);
+    if (e != hipSuccess) { set_hip_error(e, "gaussian table"); cst_model_destroy(m); return CST_ERR_HIP; }
+    // "Invalid underlying continuous probability distribution" panic in the reference (quantize.rs:562-565)
+    if (!cdf_valid(h.data(), n, precision)) { cst_model_destroy(m); return CST_ERR_MODEL; }
+    if (cst_status st = upload_shared_tables(m, h.data())) { cst_model_destroy(m); return st; }
+    *out = m;
+    return CST_OK;
+}
+
+cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_symbol, int32_t max_symbol,
+                                                const double* d_means, const double* d_stds, size_t n_streams,
+                                                void* stream, cst_model** out) {
+    if (!out || !d_means || !d_stds || n_streams == 0) return CST_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (max_symbol <= min_symbol) return CST_ERR_MODEL;
+    const int64_t n64 = (int64_t)max_symbol - min_symbol + 1;
+    if (cst_status st = check_model_args(precision, n64)) return st;
+    if (precision > 16) return CST_ERR_INVALID_ARGUMENT; // per-stream tables are kept as 16-bit rows
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CST_ERR_NO_DEVICE;
+    const int n = (int)n64;
+    hipStream_t hs = (hipStream_t)stream;
+    cst_model* m = new (std::nothrow) cst_model();
+    if (!m) return CST_ERR_OUT_OF_MEMORY;
+    m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = n_streams;
+    hipGetDevice(&m->device);
+    m->cdf16_stride = ((n + 1) + 7) & ~7;
+    const size_t total = n_streams * ((size_t)n + 1);
+    hipError_t e = hipMalloc(&m->d_cdf, 4 * total);
+    if (e == hipSuccess) e = hipMalloc(&m->d_cdf16, 2 * n_streams * (size_t)m->cdf16_stride);
+    if (e == hipSuccess) {
+        const int threads = 256;
+        const size_t blocks = (total + threads - 1) / threads;
+        hipLaunchKernelGGL(gaussian_cdf_kernel, dim3((unsigned)blocks), dim3(threads), 0, hs, precision, min_symbol, n,
+                           d_means, d_stds, 0.0, 1.0, n_streams, m->d_cdf);
+        const size_t total16 = n_streams * (size_t)m->cdf16_stride;
+        hipLaunchKernelGGL(cdf_to_u16_kernel, dim3((unsigned)((total16 + threads - 1) / threads)), dim3(threads), 0, hs,
+                           (const uint32_t*)m->d_cdf, n_streams, n, m->cdf16_stride, m->d_cdf16);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { set_hip_error(e, "per-stream gaussian tables"); cst_model_destroy(m); return CST_ERR_HIP; }
+    *out = m;
+    return CST_OK;
+}
+
+cst_status cst_model_destroy(cst_model* m) {
+    if (!m) return CST_OK;
+    hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec32); hipFree(m->d_dec64); hipFree(m->d_bucket);
+    hipFree(m->d_cdf16);
+    delete m;
+    return CST_OK;
+}
+
+int32_t cst_model_precision(const cst_model* m) { return m ? m->precision : 0; }
+int32_t cst_model_min_symbol(const cst_model* m) { return m ? m->min_symbol : 0; }
+int32_t cst_model_n_symbols(const cst_model* m) { return m ? m->n_symbols : 0; }
+size_t cst_model_n_tables(const cst_model* m) { return m ? m->n_tables : 0; }
+
+cst_status cst_model_get_cdf(const cst_model* m, size_t index, uint32_t* h_cdf, void* stream) {
+    if (!m || !h_cdf || index >= m->n_tables) return CST_ERR_INVALID_ARGUMENT;
+    const size_t per = (size_t)m->n_symbols + 1;
+    CST_HIP_TRY(hipMemcpyAsync(h_cdf, m->d_cdf + index * per, 4 * per, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CST_OK;
+}
+
+cst_status cst_debug_erf(const double* d_x, double* d_out, size_t n, void* stream) {
+    if (!d_x || !d_out) return CST_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(debug_erf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_out,
+                       n);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+cst_status cst_debug_gaussian_lcp(int32_t precision, int32_t prob_bits, int32_t min_symbol, int32_t max_symbol,
+                                  const int32_t* d_symbols, const double* d_means, const double* d_stds,
+                                  uint32_t* d_left, uint32_t* d_prob, size_t n, void* stream) {
+    if (!d_symbols || !d_means || !d_stds || !d_left || !d_prob) return CST_ERR_INVALID_ARGUMENT;
+    if (precision < 1 || precision > prob_bits || (prob_bits != 16 && prob_bits != 32)) return CST_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(debug_lcp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, precision,
+                       prob_bits, min_symbol, max_symbol, d_symbols, d_means, d_stds, d_left, d_prob, n);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,239 @@
+/*
+ * constriction_amd.h -- C ABI of the MI355X-native batched entropy-coding backend.
+ *
+ * This is the drop-in boundary for constriction's stream-coder hot path.
+ * The reference has NO FFI surface for this path (only PyO3 bindings); each entry point below
+ * names the reference interface it replaces (paths relative to the reference checkout).  A Rust
+ * `extern "C"` block / ctypes stub binding exactly these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types.  `stream` is a hipStream_t passed as void*
+ *    (NULL = the default stream).  All `d_*` pointers are DEVICE pointers (HBM), all `h_*`
+ *    pointers are host pointers.  The library never frees caller memory.
+ *  - all batched calls are asynchronous on `stream`; results are valid after the caller
+ *    synchronises that stream.  Functions are re-entrant; no global mutable state.
+ *  - every function returns a cst_status (0 = ok, negative = call-level error).  Per-stream
+ *    outcomes go to the caller's `d_status` array (cst_stream_status), mirroring the
+ *    reference's per-coder Result values (src/lib.rs:313-316, 376-385).
+ *  - coder presets are given as (word_bits, state_bits, precision) = (W, S, P):
+ *      (32,64,24) DefaultAnsCoder + the Python API        src/stream/stack.rs:139
+ *      (32,64,12) benches/lookup.rs:32-34, BASELINE config C2/C3
+ *      (16,32,12) SmallAnsCoder                            src/stream/stack.rs:153
+ *    Supported: W=32,S=64,1<=P<=24 and W=16,S=32,1<=P<=16.  Compressed words are always
+ *    stored one per uint32_t slot (W=16 words occupy the low half).
+ */
+#ifndef CONSTRICTION_AMD_H
+#define CONSTRICTION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CST_ABI_VERSION 1
+
+typedef enum cst_status {
+    CST_OK = 0,
+    CST_ERR_INVALID_ARGUMENT = -1, /* bad sizes / NULL pointers / unsupported (W,S,P) */
+    CST_ERR_HIP = -2,              /* a HIP runtime call failed (see cst_last_hip_error) */
+    CST_ERR_NO_DEVICE = -3,        /* no gfx950 device visible: the product path has NO CPU fallback */
+    CST_ERR_MODEL = -4,            /* model cannot be built (support too large, sigma<=0, zero probability) */
+    CST_ERR_OUT_OF_MEMORY = -5
+} cst_status;
+
+/* per-stream result codes written to d_status[stream] */
+typedef enum cst_stream_status {
+    CST_STREAM_OK = 0,
+    CST_STREAM_IMPOSSIBLE_SYMBOL = 1, /* DefaultEncoderFrontendError::ImpossibleSymbol, src/lib.rs:376-385
+                                         (Python: KeyError, src/pybindings/stream/mod.rs:82-89) */
+    CST_STREAM_CAPACITY = 2,          /* output slab too small (reference: backend WriteError) */
+    CST_STREAM_INVALID_DATA = 3       /* trailing zero word (src/stream/stack.rs:299-318) or
+                                         range-decoder InvalidData (src/stream/queue.rs:989-993) */
+} cst_stream_status;
+
+/* memory layout of the int32 symbol matrix */
+typedef enum cst_layout {
+    CST_LAYOUT_STREAM_MAJOR = 0, /* symbols[stream][t]  (BASELINE config C2) */
+    CST_LAYOUT_SYMBOL_MAJOR = 1  /* symbols[t][stream]  (lane-coalesced without LDS staging) */
+} cst_layout;
+
+typedef struct cst_coder_config {
+    int32_t word_bits;  /* W */
+    int32_t state_bits; /* S */
+    int32_t precision;  /* P */
+} cst_coder_config;
+
+/* flags for the batched coder calls */
+#define CST_FLAG_NONE 0u
+/* encode: do not append the final state words (leave the state in d_state);
+ * decode: do not read the initial state from the end of each stream's words (take it from d_state).
+ * Used by the single-coder drop-in object to continue an existing coder
+ * (AnsCoder::encode_symbols_reverse on a non-empty coder, src/stream/stack.rs:784-849). */
+#define CST_FLAG_RAW_STATE 1u
+
+/* ------------------------------------------------------------------------------------------
+ * library / device
+ * ---------------------------------------------------------------------------------------- */
+
+/* ABI version of the loaded library (== CST_ABI_VERSION of the header it was built from). */
+int32_t cst_abi_version(void);
+
+/* Number of visible gfx950 devices, or a negative cst_status. */
+int32_t cst_device_count(void);
+
+/* Text of the most recent HIP error seen by the calling thread ("" if none). */
+const char *cst_last_hip_error(void);
+
+/* Upper bound on the words one stream can produce: min(n, ceil(n*P/W)) + S/W.
+ * (At most one word per symbol: src/stream/stack.rs:1035-1040; final state: stack.rs:891-895.) */
+size_t cst_ans_max_words(size_t n_symbols, cst_coder_config cfg);
+
+/* Same bound for the range coder: one word per symbol (queue.rs:671-702) + seal words (queue.rs:498-522). */
+size_t cst_range_max_words(size_t n_symbols, cst_coder_config cfg);
+
+/* ------------------------------------------------------------------------------------------
+ * entropy models (device-resident cumulative-frequency tables)
+ *
+ * A cst_model is the device image of one of the reference's entropy models restricted to a
+ * contiguous i32 support [min_symbol, min_symbol + n_symbols):
+ *   encode side  = EncoderModel::left_cumulative_and_probability as a table
+ *                  (ContiguousCategoricalEntropyModel, src/stream/model/categorical/contiguous.rs:673-700)
+ *   decode side  = DecoderModel::quantile_function as ContiguousLookupDecoderModel
+ *                  (src/stream/model/categorical/lookup_contiguous.rs:169-187, 564-605)
+ * cdf[0] = 0 < cdf[1] < ... < cdf[n] = 2^P.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct cst_model cst_model;
+
+/* One table shared by all streams, from a host cdf[n_symbols+1] (any tabulated model: the
+ * "fast" categorical tables of src/stream/model/categorical.rs:16-54, a LeakyQuantizer table, ...). */
+cst_status cst_model_create_table(int32_t precision, int32_t min_symbol, int32_t n_symbols,
+                                  const uint32_t *h_cdf, cst_model **out);
+
+/* One shared table = LeakyQuantizer<f64,i32,u{prob_bits},P>(min..=max) x Gaussian(mean,std),
+ * i.e. constriction.stream.model.QuantizedGaussian(min, max, mean, std)
+ * (src/stream/model/quantize.rs:284-308, 525-568; src/pybindings/stream/model.rs:649-660).
+ * The table is computed ON DEVICE in bit-exact f64.  prob_bits = 32 for W=32, 16 for W=16. */
+cst_status cst_model_create_gaussian(int32_t precision, int32_t min_symbol, int32_t max_symbol,
+                                     double mean, double std, void *stream, cst_model **out);
+
+/* One table PER STREAM (BASELINE config C3): stream s uses Gaussian(d_means[s], d_stds[s]).
+ * d_means/d_stds are device arrays of n_streams doubles. */
+cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_symbol, int32_t max_symbol,
+                                                const double *d_means, const double *d_stds,
+                                                size_t n_streams, void *stream, cst_model **out);
+
+cst_status cst_model_destroy(cst_model *model);
+
+/* Introspection (tests, and get_cdf for host-side tooling). */
+int32_t cst_model_precision(const cst_model *model);
+int32_t cst_model_min_symbol(const cst_model *model);
+int32_t cst_model_n_symbols(const cst_model *model);
+size_t cst_model_n_tables(const cst_model *model); /* 1 = shared, else n_streams */
+/* Copies table `index`'s cdf[n_symbols+1] to host (synchronises `stream`). */
+cst_status cst_model_get_cdf(const cst_model *model, size_t index, uint32_t *h_cdf, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * batched ANS coder: one independent AnsCoder<W,S> per stream
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces, for every stream s in [0, n_streams):
+ *     let mut coder = AnsCoder::new();                             src/stream/stack.rs:249
+ *     coder.encode_iid_symbols_reverse(symbols[s], &model)?;       src/stream/stack.rs:835-849
+ *     out[s] = coder.into_compressed();                            src/stream/stack.rs:891-895
+ * (Python: AnsCoder().encode_reverse(symbols, model); get_compressed(),
+ *  src/pybindings/stream/stack.rs:529-591, 411-429.)
+ *
+ * d_symbols   int32 [n_streams][n_per_stream] (or transposed, see layout)
+ * d_words     uint32 slabs: stream s writes d_words[s*stride_words ...], in emission order
+ * d_n_words   out: words written per stream
+ * d_state     uint64 [n_streams] in/out, only with CST_FLAG_RAW_STATE (else may be NULL)
+ * d_status    out: cst_stream_status per stream.  On IMPOSSIBLE_SYMBOL / CAPACITY the stream's
+ *             n_words is 0 and its slab content is unspecified.
+ */
+cst_status cst_ans_encode_batch(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                uint32_t *d_words, size_t stride_words, uint32_t *d_n_words,
+                                uint64_t *d_state, int32_t *d_status, uint32_t flags, void *stream);
+
+/* Replaces, for every stream s:
+ *     let mut coder = AnsCoder::from_compressed(words[s])?;        src/stream/stack.rs:299-318, 440-462
+ *     symbols[s] = coder.decode_iid_symbols(n_per_stream, &model)  src/stream/mod.rs:1016-1031, stack.rs:1070-1100
+ * (Python: AnsCoder(compressed).decode(model, n), src/pybindings/stream/stack.rs:217-241, 688-752.)
+ *
+ * The words of stream s are d_words[off(s) .. off(s) + d_n_words[s]) with
+ *     off(s) = d_offsets ? d_offsets[s] : s * stride_words
+ * so both the slab layout written by cst_ans_encode_batch and the packed layout written by
+ * cst_compact_words decode without a copy.  Decoding past the end of a stream is legal and
+ * deterministic, exactly as in the reference (stack.rs:1062-1065).
+ * With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
+ * count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).
+ */
+cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                const uint64_t *d_offsets, size_t stride_words, const uint32_t *d_n_words,
+                                int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
+                                uint32_t flags, void *stream);
+
+/* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one
+ * packed buffer (the concatenation of every stream's `into_compressed()` result).
+ * d_packed may be NULL to compute the offsets only.  packed_capacity is in words; if the total
+ * exceeds it nothing is copied and CST_ERR_INVALID_ARGUMENT is returned after the offsets are
+ * written (the call synchronises `stream` to read the total). */
+cst_status cst_compact_words(const uint32_t *d_words, size_t stride_words, const uint32_t *d_n_words,
+                             size_t n_streams, uint64_t *d_offsets, uint32_t *d_packed,
+                             size_t packed_capacity, uint64_t *h_total_words, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * per-symbol quantized Gaussians: the reference's flagship Python call
+ *     coder.encode_reverse(symbols, QuantizedGaussian(min, max), means, stds)
+ *     coder.decode(QuantizedGaussian(min, max), means, stds)
+ * (src/pybindings/stream/stack.rs:567-588, 733-751; src/pybindings/stream/model/internals.rs:188-249)
+ * d_means / d_stds have the same shape and layout as d_symbols (f64; f32 callers widen first,
+ * src/pybindings/mod.rs:211-216).  std <= 0 or a non-finite parameter yields
+ * CST_STREAM_IMPOSSIBLE_SYMBOL for that stream (the reference panics: pybindings/stream/model.rs:654-657).
+ * ---------------------------------------------------------------------------------------- */
+cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                         const int32_t *d_symbols, const double *d_means, const double *d_stds,
+                                         size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                         uint32_t *d_words, size_t stride_words, uint32_t *d_n_words,
+                                         uint64_t *d_state, int32_t *d_status, uint32_t flags, void *stream);
+
+cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                         const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                         const uint32_t *d_n_words, const double *d_means, const double *d_stds,
+                                         int32_t *d_symbols, size_t n_streams, size_t n_per_stream,
+                                         cst_layout layout, uint64_t *d_state, uint32_t *d_n_words_out,
+                                         int32_t *d_status, uint32_t flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * batched range coder (BASELINE config C4): one RangeEncoder / RangeDecoder per stream
+ *   encode: RangeEncoder::encode_iid_symbols + get_compressed   src/stream/queue.rs:612-705, 458-523
+ *   decode: RangeDecoder::from_compressed + decode_iid_symbols  src/stream/queue.rs:847-868, 968-1033
+ * Symbols are coded in forward order (a queue).  Same slab/offset conventions as the ANS calls.
+ * ---------------------------------------------------------------------------------------- */
+cst_status cst_range_encode_batch(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                  size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                  uint32_t *d_words, size_t stride_words, uint32_t *d_n_words,
+                                  int32_t *d_status, void *stream);
+
+cst_status cst_range_decode_batch(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                  const uint64_t *d_offsets, size_t stride_words, const uint32_t *d_n_words,
+                                  int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                  int32_t *d_status, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bit-exact f64 special functions on device (test hooks for the model kernels)
+ * out[i] = erf(x[i]) resp. Gaussian cdf, evaluated by the same device code the table kernels use.
+ * ---------------------------------------------------------------------------------------- */
+cst_status cst_debug_erf(const double *d_x, double *d_out, size_t n, void *stream);
+cst_status cst_debug_gaussian_lcp(int32_t precision, int32_t prob_bits, int32_t min_symbol, int32_t max_symbol,
+                                  const int32_t *d_symbols, const double *d_means, const double *d_stds,
+                                  uint32_t *d_left, uint32_t *d_prob, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONSTRICTION_AMD_H */
