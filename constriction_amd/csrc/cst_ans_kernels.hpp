@@ -2,14 +2,35 @@
 //
 // One independent AnsCoder<W,S> per LANE.  The recurrences are those of the reference's
 // AnsCoder::encode_symbol / decode_symbol (src/stream/stack.rs:1014-1048, 1070-1100); what is
-// new is everything around them: the shared cumulative-frequency tables live in LDS, the int32
-// symbol matrix is moved in wave-private LDS tiles (coalesced 128-B row segments in HBM, b128
-// transposing reads/writes in LDS), and the u64 division by the symbol's probability is an
-// exact multiply-high by a per-symbol reciprocal.
+// new is everything around them:
+//   * the shared cumulative-frequency tables live in LDS,
+//   * the int32 symbol matrix moves in wave-private LDS tiles (coalesced 128-B row segments in HBM,
+//     b128 transposing accesses in LDS),
+//   * compressed words travel through a per-lane LDS ring: the coder step itself is branch-free
+//     (one unconditional ring access + selects), and HBM is touched only at scheduled points with
+//     aligned 16-byte chunks per lane, issued one interval ahead of use,
+//   * the u64 division by the symbol's probability is an exact multiply-high by a per-symbol
+//     reciprocal plus one correction.
 #pragma once
 #include "cst_common.hpp"
 
 namespace cst {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kRingSlots = 32;            // words per lane in the LDS word ring
+constexpr int kRingWords = kRingSlots * kWave;
+constexpr int kAhead = 16;                // decode: words kept issued ahead of the read position
+constexpr int kMaxChunksPerPoint = 3;     // 16-byte chunks a lane may move per scheduled point
+
+// Words a coder can emit/consume in T consecutive steps is at most ceil(P*T/W)+1 (each step moves at
+// most P bits of information).  Scheduled points are placed every 4*G steps with G chosen so that this
+// bound is <= 7, which the ring geometry above is sized for.
+__host__ __device__ inline int groups_per_point(int W, int P) {
+    if (16 * P <= 6 * W) return 4;
+    if (8 * P <= 6 * W) return 2;
+    return 1;
+}
 
 // ------------------------------------------------------------------------------------------------
 // exact state / p
@@ -24,39 +45,31 @@ __device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint32_t m_lo, uint32_t 
     return (uint64_t)a1 * m_hi + ((t1 >> 32) + (t2 >> 32));       // v_mad_u64_u32
 }
 
-// AnsCoder state as a template on the state width.
 template <int S> struct StateT;
 template <> struct StateT<64> { using type = uint64_t; };
 template <> struct StateT<32> { using type = uint32_t; };
 
-// One encode step: (c, p, m) is the table entry of the symbol.
-// Returns true if a word has to be emitted (the word is returned in `word`).
+template <int W> __device__ __forceinline__ constexpr uint32_t word_mask() { return W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u); }
+
+// One branch-free encode step (stack.rs:1035-1045).  Returns 1 if `word` was emitted.
 template <int W, int S>
-__device__ __forceinline__ bool ans_encode_step(typename StateT<S>::type& state, const EncEntry e, int P,
-                                                uint32_t& word) {
+__device__ __forceinline__ uint32_t ans_encode_step(typename StateT<S>::type& state, const EncEntry e, int P,
+                                                    uint32_t& word) {
     using st_t = typename StateT<S>::type;
     st_t st = state;
-    // stack.rs:1035-1040: flush one word if the state would overflow
-    const bool emit = (uint32_t)(st >> (S - P)) >= e.p;
-    word = (uint32_t)st & (W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u));
-    if (emit) st = (st_t)(st >> (W % S));
-    // stack.rs:1042-1045: state = ((state / p) << P) | (c + state % p), with state / p obtained as
-    // mulhi(state, floor(2^S / p)) in {q-1, q} followed by one correction.
+    const bool emit = (uint32_t)(st >> (S - P)) >= e.p;     // would the state overflow?
+    word = (uint32_t)st & word_mask<W>();
+    st = emit ? (st_t)(st >> (W % S)) : st;
+    // state / p as mulhi(state, floor(2^S / p)) in {q-1, q} followed by one correction
     st_t q;
     if constexpr (S == 64) q = mulhi64(st, e.m_lo, e.m_hi);
     else q = __umulhi(st, e.m_hi);
-    uint32_t r = (uint32_t)st - (uint32_t)q * e.p; // exact: true remainder < 2p < 2^25
-    if (r >= e.p) { r -= e.p; q += 1; }
+    uint32_t r = (uint32_t)st - (uint32_t)q * e.p;          // exact: true remainder < 2p < 2^25
+    const bool fix = r >= e.p;
+    r = fix ? r - e.p : r;
+    q += fix ? 1 : 0;
     state = (st_t)((q << P) + (st_t)(e.c + r));
-    return emit;
-}
-
-// decode step arithmetic (stack.rs:1086-1088): state = (state >> P) * p + (q - c)
-template <int S>
-__device__ __forceinline__ void ans_decode_advance(typename StateT<S>::type& state, uint32_t quantile, uint32_t c,
-                                                   uint32_t p, int P) {
-    using st_t = typename StateT<S>::type;
-    state = (st_t)((st_t)(state >> P) * (st_t)p + (st_t)(quantile - c));
+    return emit ? 1u : 0u;
 }
 
 // number of W-bit words the state serialises to (bit_array_to_chunks_truncated, src/lib.rs:719-731)
@@ -109,6 +122,13 @@ struct AnsDecodeArgs {
 // wave-private symbol tiles: 64 stream rows x kTileSyms symbols, row stride kTileStride words
 // ------------------------------------------------------------------------------------------------
 
+// Orders this wave's LDS traffic for the compiler (the hardware executes one wave's DS ops in order).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // global -> registers.  VEC: lane l fetches the 16-B chunk (l & 7) of rows (l >> 3) + 8k, i.e. every
 // instruction reads eight full 128-B row segments.  !VEC: lane l fetches word (l & 31) of rows
 // (l >> 5) + 2k.  Rows past n_streams are skipped (registers zeroed).
@@ -121,7 +141,10 @@ __device__ __forceinline__ void tile_fetch(const int32_t* __restrict__ sym, size
         for (int k = 0; k < 8; ++k) {
             const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
             int4 v = make_int4(0, 0, 0, 0);
-            if (s < n_streams) v = *reinterpret_cast<const int4*>(sym + s * N + t0 + 4 * chunk);
+            if (s < n_streams) {
+                const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(sym + s * N + t0 + 4 * chunk));
+                v = make_int4(t.x, t.y, t.z, t.w);
+            }
             r[4 * k + 0] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
         }
     } else {
@@ -163,7 +186,10 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
             const int row = (lane >> 3) + 8 * k;
             const size_t s = s0 + (size_t)row;
             const int4 v = *reinterpret_cast<const int4*>(tile + row * kTileStride + 4 * chunk);
-            if (s < n_streams) *reinterpret_cast<int4*>(sym + s * N + t0 + 4 * chunk) = v;
+            if (s < n_streams) {
+                v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(sym + s * N + t0 + 4 * chunk));
+            }
         }
     } else {
         const int col = lane & 31;
@@ -181,56 +207,105 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
 // encode
 // ------------------------------------------------------------------------------------------------
 
+// Per-lane encoder: coder state + the LDS word ring in front of this stream's output slab.
+// Positions are counted in words from `base16`, the 16-byte aligned address at or below the slab start
+// (`shift` = slab start - base16, 0..3), so that every 4-aligned position group is one aligned 16-B chunk.
 template <int W, int S>
 struct EncLane {
     using st_t = typename StateT<S>::type;
     st_t state;
-    uint32_t len;       // words emitted so far
-    int32_t status;
-    uint32_t* out;      // this stream's slab
-    uint32_t cap;
+    uint32_t wr;        // words emitted so far (may exceed cap; then nothing more is stored)
+    uint32_t flushed;   // positions < flushed are in HBM (multiple of 4, or 0)
+    uint32_t bad;       // any symbol outside the model's support
+    uint32_t cap;       // slab capacity in words (0 for lanes without a stream)
+    uint32_t shift;
+    uint32_t* base16;
+    uint32_t* ring;     // this wave's ring [kRingSlots][kWave]
+    int lane;
 
-    __device__ __forceinline__ void step(int32_t sym, const EncEntry* table, int32_t min_symbol, int32_t n_symbols,
-                                         int P) {
-        const uint32_t idx = (uint32_t)sym - (uint32_t)min_symbol;
-        if (idx >= (uint32_t)n_symbols) {
-            if (status == CST_STREAM_OK) status = CST_STREAM_IMPOSSIBLE_SYMBOL; // src/lib.rs:376-385
-            return;
-        }
-        const EncEntry e = table[idx];
-        step_entry(e, P);
+    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(slab);
+        base16 = reinterpret_cast<uint32_t*>(addr & ~(uintptr_t)15);
+        shift = (uint32_t)((addr & 15) >> 2);
+        cap = capacity; ring = wave_ring; lane = lane_;
+        wr = 0; flushed = 0; bad = 0;
     }
 
-    __device__ __forceinline__ void step_entry(const EncEntry e, int P) {
-        if (status != CST_STREAM_OK) return;
+    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
+
+    // branch-free step with a prefetched table entry
+    __device__ __forceinline__ void step(const EncEntry e, int P) {
         uint32_t word;
-        if (ans_encode_step<W, S>(state, e, P, word)) {
-            if (len < cap) out[len] = word;
-            else status = CST_STREAM_CAPACITY;
-            ++len;
+        const uint32_t emit = ans_encode_step<W, S>(state, e, P, word);
+        *slot(wr + shift) = word;   // always written; only becomes part of the stream if wr advances
+        wr += emit;
+    }
+
+    // scheduled point: move complete aligned 16-B chunks from the ring to HBM
+    __device__ __forceinline__ void flush_chunks() {
+        const uint32_t end = wr + shift;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (flushed + 4 <= end) {
+                uint4 v;
+                v.x = *slot(flushed + 0); v.y = *slot(flushed + 1); v.z = *slot(flushed + 2); v.w = *slot(flushed + 3);
+                if (flushed >= shift && flushed + 4 - shift <= cap) {
+                    *reinterpret_cast<uint4*>(base16 + flushed) = v;
+                } else {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t pos = flushed + i;
+                        if (pos >= shift && pos - shift < cap) base16[pos] = w[i];
+                    }
+                }
+                flushed += 4;
+            }
         }
     }
 
-    // into_compressed: append the state's words, least significant first (stack.rs:891-895)
-    __device__ __forceinline__ void finish() {
-        if (status != CST_STREAM_OK) return;
-        const int k = state_word_count<W, S>(state);
-        if (len + (uint32_t)k > cap) { status = CST_STREAM_CAPACITY; return; }
-        for (int i = 0; i < k; ++i) {
-            out[len++] = (uint32_t)(state >> ((i * W) % S)) & (W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u));
+    // end of stream: everything still in the ring, then (unless raw) the state words, least significant
+    // first (into_compressed, stack.rs:891-895).  Returns the stream status.
+    __device__ __forceinline__ int32_t finish(bool append_state, uint32_t& n_words_out) {
+        // drain ring: whole chunks first, then the ragged tail
+        for (int guard = 0; guard < 8 && flushed + 4 <= wr + shift; ++guard) flush_chunks();
+        for (uint32_t pos = flushed; pos < wr + shift; ++pos)
+            if (pos >= shift && pos - shift < cap) base16[pos] = *slot(pos);
+        uint32_t len = wr;
+        if (append_state) {
+            const int k = state_word_count<W, S>(state);
+            for (int i = 0; i < k; ++i) {
+                const uint32_t w = (uint32_t)(state >> ((i * W) % S)) & word_mask<W>();
+                if (len < cap) base16[shift + len] = w;
+                ++len;
+            }
         }
+        n_words_out = len;
+        if (bad) return CST_STREAM_IMPOSSIBLE_SYMBOL;   // src/lib.rs:376-385
+        if (len > cap) return CST_STREAM_CAPACITY;
+        return CST_STREAM_OK;
     }
 };
 
+// symbol -> table index, clamped so that the lookup is always legal; out-of-support symbols set `bad`
+__device__ __forceinline__ uint32_t enc_index(int32_t sym, int32_t min_symbol, uint32_t n_symbols, uint32_t& bad) {
+    const uint32_t idx = (uint32_t)sym - (uint32_t)min_symbol;
+    const bool oob = idx >= n_symbols;
+    bad |= oob ? 1u : 0u;
+    return oob ? 0u : idx;
+}
+
 // LAYOUT 0: symbols[stream][t] staged through LDS tiles; LAYOUT 1: symbols[t][stream] read directly.
-template <int W, int S, int LAYOUT, bool VEC>
+template <int W, int S, int LAYOUT, bool VEC, int G>
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EncEntry* table = reinterpret_cast<EncEntry*>(smem);
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + table_bytes) + wave_in_block * (kWave * kTileStride);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + table_bytes) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + table_bytes + (size_t)(kBlock / kWave) * kRingWords * 4) +
+                    wave_in_block * (kWave * kTileStride);
 
     // stage the encoder table once per workgroup (16 B per lane per pass, coalesced)
     for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
@@ -238,24 +313,24 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t s0 = wave * kWave;
-    if (s0 >= a.n_streams) return; // whole wave idle (after the barrier)
+    if (s0 >= a.n_streams) return; // whole wave idle (after the only barrier)
     const size_t s = s0 + lane;
     const bool active = s < a.n_streams;
     const size_t N = a.n_per_stream;
     const int P = a.precision;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
 
     EncLane<W, S> L;
+    L.init(a.words + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
     L.state = (raw && active) ? (typename StateT<S>::type)a.state[s] : 0;
-    L.len = 0;
-    L.status = active ? CST_STREAM_OK : -1; // -1: lane has no stream, never computes
-    L.out = a.words + (active ? s : 0) * a.stride_words;
-    L.cap = (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words);
 
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
-        // lane-coalesced: every step reads 256 contiguous bytes per wave; keep 4 steps in flight
+        // lane-coalesced: every step reads 256 contiguous bytes per wave
         const int32_t* col = a.symbols + (active ? s : 0);
         size_t t = N;
+        int countdown = G;
         while (t >= 4) {
             t -= 4;
             int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -263,16 +338,16 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 v3 = col[(t + 3) * a.n_streams]; v2 = col[(t + 2) * a.n_streams];
                 v1 = col[(t + 1) * a.n_streams]; v0 = col[(t + 0) * a.n_streams];
             }
-            if (L.status == CST_STREAM_OK) {
-                L.step(v3, table, a.min_symbol, a.n_symbols, P);
-                L.step(v2, table, a.min_symbol, a.n_symbols, P);
-                L.step(v1, table, a.min_symbol, a.n_symbols, P);
-                L.step(v0, table, a.min_symbol, a.n_symbols, P);
-            }
+            const EncEntry e3 = table[enc_index(v3, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v2, a.min_symbol, nsym, L.bad)],
+                           e1 = table[enc_index(v1, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v0, a.min_symbol, nsym, L.bad)];
+            L.step(e3, P); L.step(e2, P); L.step(e1, P); L.step(e0, P);
+            if (--countdown == 0) { countdown = G; L.flush_chunks(); }
         }
         while (t > 0) {
             --t;
-            if (L.status == CST_STREAM_OK) L.step(col[t * a.n_streams], table, a.min_symbol, a.n_symbols, P);
+            const int32_t v = active ? col[t * a.n_streams] : 0;
+            L.step(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.flush_chunks();
         }
     } else {
         const int32_t* row = a.symbols + (active ? s : 0) * N;
@@ -280,92 +355,136 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
         // ragged top part [32*n_full, N): direct (uncoalesced) reads, at most 31 symbols per stream
         for (size_t t = N; t > n_full * kTileSyms;) {
             --t;
-            if (L.status == CST_STREAM_OK) L.step(row[t], table, a.min_symbol, a.n_symbols, P);
+            const int32_t v = active ? row[t] : 0;
+            L.step(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.flush_chunks();
         }
         if (n_full > 0) {
             int32_t r[kTileSyms];
             tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
             for (size_t tb = n_full; tb-- > 0;) {
+                wave_lds_fence();
                 tile_to_lds<VEC>(tile, lane, r);
+                wave_lds_fence();
                 if (tb > 0) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r); // prefetch
                 const int32_t* my = tile + lane * kTileStride;
-                // walk this lane's row backwards, 4 symbols per LDS read; the table lookups of a
-                // group are independent of the coder state and are issued ahead of the dependent chain
-#pragma unroll 2
+                // Walk this lane's row backwards, 4 symbols per LDS read.  The table entries of group j-1
+                // are fetched before the dependent chain of group j runs (they do not depend on the state).
+                int4 v = *reinterpret_cast<const int4*>(my + 4 * (kTileSyms / 4 - 1));
+                EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
+                         e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
+#pragma unroll
                 for (int j = kTileSyms / 4 - 1; j >= 0; --j) {
-                    const int4 v = *reinterpret_cast<const int4*>(my + 4 * j);
-                    const uint32_t i3 = (uint32_t)v.w - (uint32_t)a.min_symbol, i2 = (uint32_t)v.z - (uint32_t)a.min_symbol,
-                                   i1 = (uint32_t)v.y - (uint32_t)a.min_symbol, i0 = (uint32_t)v.x - (uint32_t)a.min_symbol;
-                    const uint32_t nsym = (uint32_t)a.n_symbols;
-                    const bool ok = i3 < nsym && i2 < nsym && i1 < nsym && i0 < nsym;
-                    if (__builtin_expect(ok, 1)) {
-                        const EncEntry e3 = table[i3], e2 = table[i2], e1 = table[i1], e0 = table[i0];
-                        L.step_entry(e3, P); L.step_entry(e2, P); L.step_entry(e1, P); L.step_entry(e0, P);
-                    } else if (L.status == CST_STREAM_OK) {
-                        L.step(v.w, table, a.min_symbol, a.n_symbols, P); L.step(v.z, table, a.min_symbol, a.n_symbols, P);
-                        L.step(v.y, table, a.min_symbol, a.n_symbols, P); L.step(v.x, table, a.min_symbol, a.n_symbols, P);
+                    EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
+                    if (j > 0) {
+                        v = *reinterpret_cast<const int4*>(my + 4 * (j - 1));
+                        n3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)];
+                        n1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
                     }
+                    L.step(e3, P); L.step(e2, P); L.step(e1, P); L.step(e0, P);
+                    e3 = n3; e2 = n2; e1 = n1; e0 = n0;
+                    if (j % G == 0) L.flush_chunks();   // static schedule: G divides the 8 groups of a tile
                 }
             }
         }
     }
 
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(!raw, n_words);
     if (!active) return;
-    if (raw) {
-        a.state[s] = (uint64_t)L.state;
-    } else {
-        L.finish();
-    }
-    a.status[s] = L.status;
-    a.n_words[s] = (L.status == CST_STREAM_OK) ? L.len : 0u;
+    if (raw) a.state[s] = (uint64_t)L.state;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
 
+// Per-lane decoder: coder state + the LDS word ring that runs ahead of the read position.
 template <int W, int S>
 struct DecLane {
     using st_t = typename StateT<S>::type;
     st_t state;
-    uint32_t len;          // words not yet consumed
-    const uint32_t* in;    // this stream's words
-    uint32_t next_word;    // in[len-1], prefetched
+    uint32_t rd;           // words not yet consumed (next word has stream index rd-1)
+    uint32_t shift;
+    uint32_t lo_issued;    // lowest position (multiple of 4) whose chunk has been requested
+    const uint32_t* base16;
+    uint32_t* ring;
+    int lane;
     int32_t status;
+    uint4 pend[kMaxChunksPerPoint];
+    int32_t pend_pos[kMaxChunksPerPoint];
 
-    // from_compressed + read_initial_state (stack.rs:299-318, 440-462)
-    __device__ __forceinline__ void init_from_words() {
-        state = 0;
-        if (len == 0) { next_word = 0; return; }
-        const uint32_t first = in[--len];
-        if (first == 0) { status = CST_STREAM_INVALID_DATA; next_word = 0; return; }
+    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
+
+    __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint32_t* wave_ring, int lane_) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
+        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
+        shift = (uint32_t)((addr & 15) >> 2);
+        ring = wave_ring; lane = lane_; rd = len; status = CST_STREAM_OK; state = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+    }
+
+    // from_compressed + read_initial_state (stack.rs:299-318, 440-462), straight from HBM
+    __device__ __forceinline__ void read_initial_state() {
+        if (rd == 0) return;
+        const uint32_t* in = base16 + shift;
+        const uint32_t first = in[--rd];
+        if (first == 0) { status = CST_STREAM_INVALID_DATA; rd = 0; return; }
         st_t st = first;
-        while (len > 0) {
-            st = (st_t)((st << (W % S)) | (st_t)in[--len]);
+        while (rd > 0) {
+            st = (st_t)((st << (W % S)) | (st_t)in[--rd]);
             if (st >= ((st_t)1 << (S - W))) break;
         }
         state = st;
-        next_word = len > 0 ? in[len - 1] : 0u;
     }
 
-    // stack.rs:1089-1097: refill one word if the state dropped below 2^(S-W) and words remain
-    __device__ __forceinline__ void refill() {
-        if (state < ((st_t)1 << (S - W)) && len > 0) {
-            state = (st_t)((state << (W % S)) | (st_t)next_word);
-            --len;
-            next_word = len > 0 ? in[len - 1] : 0u;
+    // fill the ring with the kAhead words below the read position (blocking; once per stream)
+    __device__ __forceinline__ void prime() {
+        const uint32_t top = rd + shift;
+        lo_issued = (top + 3) & ~3u;
+        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+        while (lo_issued > want_lo) {
+            lo_issued -= 4;
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            *slot(lo_issued + 0) = v.x; *slot(lo_issued + 1) = v.y; *slot(lo_issued + 2) = v.z; *slot(lo_issued + 3) = v.w;
+        }
+    }
+
+    // scheduled point: land the chunks requested at the previous point, request the next ones
+    __device__ __forceinline__ void advance_window() {
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (pend_pos[k] >= 0) {
+                const uint32_t p = (uint32_t)pend_pos[k];
+                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
+            }
+        }
+        const uint32_t top = rd + shift;
+        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (lo_issued > want_lo) {
+                lo_issued -= 4;
+                pend_pos[k] = (int32_t)lo_issued;
+                pend[k] = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            } else {
+                pend_pos[k] = -1;
+            }
         }
     }
 };
 
-template <int MODE> struct DecTables;
-
-// returns the symbol index for the current state and advances the state
+// One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
 template <int W, int S, int MODE>
-__device__ __forceinline__ uint32_t ans_decode_symbol(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
-                                                      const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
+__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
+                                                    const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
+    using st_t = typename StateT<S>::type;
     const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
-    const uint32_t q = (uint32_t)L.state & qmask; // stack.rs:1084
+    const uint32_t q = (uint32_t)L.state & qmask;
+    const uint32_t next_word = *L.slot(L.rd - 1u + L.shift);   // unconditional; ignored if no refill
     uint32_t idx, c, p;
     if constexpr (MODE == kDecLut32) {
         const uint32_t e = reinterpret_cast<const uint32_t*>(lut)[q];
@@ -381,12 +500,14 @@ __device__ __forceinline__ uint32_t ans_decode_symbol(DecLane<W, S>& L, const vo
         c = cdf[idx];
         p = nxt - c;
     }
-    ans_decode_advance<S>(L.state, q, c, p, P);
-    L.refill();
+    st_t st = (st_t)((st_t)(L.state >> P) * (st_t)p + (st_t)(q - c));
+    const bool refill = st < ((st_t)1 << (S - W)) && L.rd > 0;
+    L.state = refill ? (st_t)((st << (W % S)) | (st_t)next_word) : st;
+    L.rd -= refill ? 1u : 0u;
     return idx;
 }
 
-template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS>
+template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G>
 __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -425,7 +546,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         }
     }
     lds_off = (lds_off + 15) & ~(size_t)15;
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + lds_off) + wave_in_block * (kWave * kTileStride);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + lds_off + (size_t)(kBlock / kWave) * kRingWords * 4) +
+                    wave_in_block * (kWave * kTileStride);
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -438,49 +561,43 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const int bucket_shift = P - a.bucket_bits;
 
     DecLane<W, S> L;
-    L.status = active ? CST_STREAM_OK : -1;
-    L.len = active ? a.n_words[s] : 0u;
-    L.in = a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0);
-    if (raw) {
-        L.state = active ? (typename StateT<S>::type)a.state[s] : 0;
-        L.next_word = L.len > 0 ? L.in[L.len - 1] : 0u;
-    } else {
-        L.init_from_words();
-    }
-    const bool run = L.status == CST_STREAM_OK;
+    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    if (raw) L.state = active ? (typename StateT<S>::type)a.state[s] : 0;
+    else L.read_initial_state();
+    L.prime();
+    wave_lds_fence();
 
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
         int32_t* col = a.symbols + (active ? s : 0);
+        int countdown = 4 * G;
         for (size_t t = 0; t < N; ++t) {
-            if (run) {
-                const uint32_t idx = ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
-            }
+            const uint32_t idx = ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
+            if (--countdown == 0) { countdown = 4 * G; L.advance_window(); }
         }
     } else {
         int32_t* row = a.symbols + (active ? s : 0) * N;
         const size_t n_full = N / kTileSyms;
         int32_t* my = tile + lane * kTileStride;
         for (size_t tb = 0; tb < n_full; ++tb) {
-#pragma unroll 2
+#pragma unroll
             for (int j = 0; j < kTileSyms / 4; ++j) {
-                int4 v = make_int4(0, 0, 0, 0);
-                if (run) {
-                    v.x = a.min_symbol + (int32_t)ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                    v.y = a.min_symbol + (int32_t)ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                    v.z = a.min_symbol + (int32_t)ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                    v.w = a.min_symbol + (int32_t)ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                }
+                int4 v;
+                v.x = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.y = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.z = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.w = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
                 *reinterpret_cast<int4*>(my + 4 * j) = v;
+                if ((j + 1) % G == 0) L.advance_window();   // static schedule
             }
-            // rows of failed / absent streams hold zeros; they are written too (their content is unspecified)
+            wave_lds_fence();
             tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+            wave_lds_fence();
         }
         for (size_t t = n_full * kTileSyms; t < N; ++t) {
-            if (run) {
-                const uint32_t idx = ans_decode_symbol<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                row[t] = a.min_symbol + (int32_t)idx;
-            }
+            const uint32_t idx = ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            if (active) row[t] = a.min_symbol + (int32_t)idx;
+            L.advance_window();
         }
     }
 
@@ -488,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     a.status[s] = L.status;
     if (raw) {
         a.state[s] = (uint64_t)L.state;
-        if (a.n_words_out) a.n_words_out[s] = L.len;
+        if (a.n_words_out) a.n_words_out[s] = L.rd;
     }
 }
 

@@ -17,7 +17,8 @@ void set_hip_error(hipError_t e, const char* what) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static constexpr size_t kTileBytesPerBlock = (size_t)(kBlock / kWave) * kWave * kTileStride * sizeof(int32_t);
+static constexpr size_t kRingBytesPerBlock = (size_t)(kBlock / kWave) * kRingWords * sizeof(uint32_t);
+static constexpr size_t kTileBytesPerBlock = (size_t)(kBlock / kWave) * kWave * kTileStride * sizeof(int32_t) + kRingBytesPerBlock;
 static constexpr size_t kMaxLds = 160 * 1024;
 
 template <typename K, typename A>
@@ -35,38 +36,56 @@ static cst_status launch(K kernel, size_t n_streams, size_t lds_bytes, hipStream
 }
 
 // ---- encode dispatch ----
-template <int W, int S>
-static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
+template <int W, int S, int G>
+static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     if (table_bytes + kTileBytesPerBlock > kMaxLds) return CST_ERR_INVALID_ARGUMENT; // TODO(global-table path)
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
-        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false>, a.n_streams, table_bytes, hs, a);
+        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
-    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
-    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+}
+
+template <int W, int S>
+static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
+    switch (groups_per_point(W, a.precision)) {
+        case 4: return encode_dispatch_g<W, S, 4>(a, layout, hs);
+        case 2: return encode_dispatch_g<W, S, 2>(a, layout, hs);
+        default: return encode_dispatch_g<W, S, 1>(a, layout, hs);
+    }
 }
 
 // ---- decode dispatch ----
+template <int W, int S, int MODE, bool LDS, int G>
+static cst_status decode_dispatch3(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
+    const size_t lds = ((table_lds + 15) & ~(size_t)15) + kTileBytesPerBlock;
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR)
+        return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+    const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
+    if (vec) return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, MODE, LDS, G>, a.n_streams, lds, hs, a);
+    return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+}
+
 template <int W, int S, int MODE, bool LDS>
 static cst_status decode_dispatch2(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
-    if (layout == CST_LAYOUT_SYMBOL_MAJOR)
-        return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS>, a.n_streams, table_lds, hs, a);
-    const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
-    if (vec) return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, MODE, LDS>, a.n_streams, table_lds + kTileBytesPerBlock, hs, a);
-    return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, MODE, LDS>, a.n_streams, table_lds + kTileBytesPerBlock, hs, a);
+    switch (groups_per_point(W, a.precision)) {
+        case 4: return decode_dispatch3<W, S, MODE, LDS, 4>(a, layout, table_lds, hs);
+        case 2: return decode_dispatch3<W, S, MODE, LDS, 2>(a, layout, table_lds, hs);
+        default: return decode_dispatch3<W, S, MODE, LDS, 1>(a, layout, table_lds, hs);
+    }
 }
 
 template <int W, int S>
 static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const int P = a.precision;
-    // budget: keep two workgroups per CU resident when possible
-    const size_t lds_budget = 64 * 1024;
-    if (a.dec32 && ((size_t)4 << P) + 32 <= lds_budget)
+    const size_t lds_budget = kMaxLds - kTileBytesPerBlock - 1024;
+    if (a.dec32 && ((size_t)4 << P) <= lds_budget)
         return decode_dispatch2<W, S, kDecLut32, true>(a, layout, ((size_t)4 << P), hs);
-    if (a.dec64 && ((size_t)8 << P) + 32 <= lds_budget)
+    if (a.dec64 && ((size_t)8 << P) <= lds_budget)
         return decode_dispatch2<W, S, kDecLut64, true>(a, layout, ((size_t)8 << P), hs);
     const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
-    if (bucket_lds + 32 <= lds_budget) return decode_dispatch2<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
+    if (bucket_lds <= lds_budget) return decode_dispatch2<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
     if (a.dec64) return decode_dispatch2<W, S, kDecLut64, false>(a, layout, 0, hs);
     return decode_dispatch2<W, S, kDecBucket, false>(a, layout, 0, hs);
 }

@@ -1,0 +1,117 @@
+"""Multi-GPU: streams shard trivially (one process per GPU, contiguous blocks of streams, shared tables
+replicated); the only exchange step is the gather of the per-stream compressed words to one rank
+(BASELINE config C5).  RCCL has no allgatherv, so the gather is
+  (1) one small all_gather of (n_streams, total_words) per rank -> displacements, then
+  (2) grouped point-to-point send/recv of the packed words and of the per-stream lengths straight into
+      their final position on the destination (each peer uses its own xGMI link to the root).
+Works with the "nccl" (= RCCL) backend on device tensors and with "gloo" on host tensors (CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of streams owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def gather_packed(packed: torch.Tensor, offsets: torch.Tensor, dst: int = 0, group=None
+                  ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    """Gathers every rank's packed words (int32 storage of uint32 words) and per-stream offsets to `dst`.
+
+    packed  : [total_words_local]           offsets : int64 [n_streams_local + 1] (offsets[-1] == total)
+    Returns on dst (all_packed, all_offsets) in rank order with global offsets; None on the other ranks.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = offsets.device
+    n_local = offsets.numel() - 1
+    lengths = (offsets[1:] - offsets[:-1]).contiguous()
+    meta = torch.stack([torch.tensor(n_local, dtype=torch.int64, device=dev), offsets[-1].to(torch.int64)])
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = torch.stack(metas).cpu()
+    n_streams = metas[:, 0].tolist()
+    n_words = metas[:, 1].tolist()
+
+    if rank == dst:
+        all_packed = torch.empty(max(sum(n_words), 1), dtype=packed.dtype, device=dev)
+        all_len = torch.empty(sum(n_streams), dtype=torch.int64, device=dev)
+        ops, wpos, spos = [], 0, 0
+        for r in range(world):
+            pw, pl = all_packed[wpos: wpos + n_words[r]], all_len[spos: spos + n_streams[r]]
+            if r == rank:
+                pw.copy_(packed[: n_words[r]])
+                pl.copy_(lengths)
+            else:
+                if n_words[r]:
+                    ops.append(dist.P2POp(dist.irecv, pw, r, group))
+                if n_streams[r]:
+                    ops.append(dist.P2POp(dist.irecv, pl, r, group))
+            wpos += n_words[r]
+            spos += n_streams[r]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        all_off = torch.zeros(sum(n_streams) + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(all_len, 0, out=all_off[1:])
+        return all_packed[: sum(n_words)], all_off
+    ops = []
+    if n_words[rank]:
+        ops.append(dist.P2POp(dist.isend, packed[: n_words[rank]].contiguous(), dst, group))
+    if n_local:
+        ops.append(dist.P2POp(dist.isend, lengths, dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return None
+
+
+def scatter_packed(all_packed: Optional[torch.Tensor], all_offsets: Optional[torch.Tensor], n_local: int, src: int = 0,
+                   group=None, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inverse of gather_packed: `src` hands every rank the words of its block of streams
+    (blocks as in shard_range over the gathered stream order).  Returns (packed_local, offsets_local)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = torch.tensor([n_local], dtype=torch.int64, device=device)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    all_counts = [int(c.item()) for c in all_counts]
+    starts = [sum(all_counts[:r]) for r in range(world)]
+    if rank == src:
+        ops, mine = [], None
+        for r in range(world):
+            a, b = starts[r], starts[r] + all_counts[r]
+            off = all_offsets[a: b + 1]
+            lens = (off[1:] - off[:-1]).contiguous()
+            words = all_packed[int(off[0].item()): int(off[-1].item())].contiguous()
+            if r == rank:
+                mine = (words, lens)
+            else:
+                if all_counts[r]:
+                    ops.append(dist.P2POp(dist.isend, lens, r, group))
+                    if words.numel():
+                        ops.append(dist.P2POp(dist.isend, words, r, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        words, lens = mine
+    else:
+        lens = torch.empty(n_local, dtype=torch.int64, device=device)
+        if n_local:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, lens, src, group)]):
+                req.wait()
+        total = int(lens.sum().item()) if n_local else 0
+        words = torch.empty(max(total, 1), dtype=torch.int32, device=device)[:total]
+        if total:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, words, src, group)]):
+                req.wait()
+    off = torch.zeros(n_local + 1, dtype=torch.int64, device=lens.device)
+    torch.cumsum(lens, 0, out=off[1:])
+    return words, off
