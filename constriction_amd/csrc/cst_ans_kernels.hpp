@@ -52,6 +52,7 @@ template <> struct StateT<32> { using type = uint32_t; };
 template <int W> __device__ __forceinline__ constexpr uint32_t word_mask() { return W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u); }
 
 // One branch-free encode step (stack.rs:1035-1045).  Returns 1 if `word` was emitted.
+// Generic form (any supported W, S, P).
 template <int W, int S>
 __device__ __forceinline__ uint32_t ans_encode_step(typename StateT<S>::type& state, const EncEntry e, int P,
                                                     uint32_t& word) {
@@ -69,6 +70,32 @@ __device__ __forceinline__ uint32_t ans_encode_step(typename StateT<S>::type& st
     r = fix ? r - e.p : r;
     q += fix ? 1 : 0;
     state = (st_t)((q << P) + (st_t)(e.c + r));
+    return emit ? 1u : 0u;
+}
+
+// (W,S) = (32,64), 8 <= P <= 24, written on 32-bit halves to keep the dependent chain short (a lone
+// wave issues one VALU op per 4 cycles and a dependent one only every 8):
+//   new_state = st + c + q*(2^P - p)  with q = floor(st / p); the estimate q_est in {q-1, q} is fixed up by
+//   adding k = 2^P - p once more when the estimated remainder is >= p.  `p_shl` = p << (32-P), `k` = 2^P - p.
+__device__ __forceinline__ uint32_t ans_encode_step_32x64(uint32_t& lo, uint32_t& hi, const EncEntry e, uint32_t p_shl,
+                                                          uint32_t k, uint32_t& word) {
+    const bool emit = hi >= p_shl;                     // (state >> (64-P)) >= p
+    word = lo;
+    const uint32_t a0 = emit ? hi : lo;
+    const uint32_t a1 = emit ? 0u : hi;
+    // q_est = mulhi64(a1:a0, m)
+    const uint64_t t1 = (uint64_t)a1 * e.m_lo + (uint64_t)__umulhi(a0, e.m_lo);
+    const uint64_t t2 = (uint64_t)a0 * e.m_hi + (uint32_t)t1;
+    const uint64_t q = (uint64_t)a1 * e.m_hi + ((t1 >> 32) + (t2 >> 32));
+    const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+    // estimated remainder (exact modulo 2^32; the true value is < 2p)
+    const uint32_t r = a0 - q_lo * e.p;
+    // st + c + q_est * k  (independent of r)
+    const uint64_t base = (((uint64_t)a1 << 32) | a0) + e.c;
+    uint64_t t = (uint64_t)q_lo * k + base;
+    t += (uint64_t)__umul24(q_hi, k) << 32;            // q_hi < 2^(32-P) <= 2^24, k < 2^24
+    t += (r >= e.p) ? k : 0u;
+    lo = (uint32_t)t; hi = (uint32_t)(t >> 32);
     return emit ? 1u : 0u;
 }
 
@@ -233,10 +260,17 @@ struct EncLane {
 
     __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
 
-    // branch-free step with a prefetched table entry
+    // branch-free step with a prefetched table entry; FAST selects the 32-bit-halves form (needs P >= 8)
+    template <bool FAST>
     __device__ __forceinline__ void step(const EncEntry e, int P) {
-        uint32_t word;
-        const uint32_t emit = ans_encode_step<W, S>(state, e, P, word);
+        uint32_t word, emit;
+        if constexpr (W == 32 && S == 64 && FAST) {
+            uint32_t lo = (uint32_t)state, hi = (uint32_t)(state >> 32);
+            emit = ans_encode_step_32x64(lo, hi, e, e.p << (32 - P), (1u << P) - e.p, word);
+            state = ((uint64_t)hi << 32) | lo;
+        } else {
+            emit = ans_encode_step<W, S>(state, e, P, word);
+        }
         *slot(wr + shift) = word;   // always written; only becomes part of the stream if wr advances
         wr += emit;
     }
@@ -266,7 +300,7 @@ struct EncLane {
 
     // end of stream: everything still in the ring, then (unless raw) the state words, least significant
     // first (into_compressed, stack.rs:891-895).  Returns the stream status.
-    __device__ __forceinline__ int32_t finish(bool append_state, uint32_t& n_words_out) {
+    __device__ __forceinline__ int32_t finish(bool append_state, uint32_t n_symbols, uint32_t& n_words_out) {
         // drain ring: whole chunks first, then the ragged tail
         for (int guard = 0; guard < 8 && flushed + 4 <= wr + shift; ++guard) flush_chunks();
         for (uint32_t pos = flushed; pos < wr + shift; ++pos)
@@ -281,22 +315,22 @@ struct EncLane {
             }
         }
         n_words_out = len;
-        if (bad) return CST_STREAM_IMPOSSIBLE_SYMBOL;   // src/lib.rs:376-385
+        if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;   // src/lib.rs:376-385
         if (len > cap) return CST_STREAM_CAPACITY;
         return CST_STREAM_OK;
     }
 };
 
-// symbol -> table index, clamped so that the lookup is always legal; out-of-support symbols set `bad`
+// symbol -> table index, clamped so that the lookup is always legal.  `bad` accumulates the largest raw
+// index seen; the stream is flagged at the end if it ever reached n_symbols (2 ops per symbol).
 __device__ __forceinline__ uint32_t enc_index(int32_t sym, int32_t min_symbol, uint32_t n_symbols, uint32_t& bad) {
     const uint32_t idx = (uint32_t)sym - (uint32_t)min_symbol;
-    const bool oob = idx >= n_symbols;
-    bad |= oob ? 1u : 0u;
-    return oob ? 0u : idx;
+    bad = max(bad, idx);
+    return min(idx, n_symbols - 1u);
 }
 
 // LAYOUT 0: symbols[stream][t] staged through LDS tiles; LAYOUT 1: symbols[t][stream] read directly.
-template <int W, int S, int LAYOUT, bool VEC, int G>
+template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EncEntry* table = reinterpret_cast<EncEntry*>(smem);
@@ -340,13 +374,13 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
             }
             const EncEntry e3 = table[enc_index(v3, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v2, a.min_symbol, nsym, L.bad)],
                            e1 = table[enc_index(v1, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v0, a.min_symbol, nsym, L.bad)];
-            L.step(e3, P); L.step(e2, P); L.step(e1, P); L.step(e0, P);
+            L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
             if (--countdown == 0) { countdown = G; L.flush_chunks(); }
         }
         while (t > 0) {
             --t;
             const int32_t v = active ? col[t * a.n_streams] : 0;
-            L.step(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.template step<FAST>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
             L.flush_chunks();
         }
     } else {
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
         for (size_t t = N; t > n_full * kTileSyms;) {
             --t;
             const int32_t v = active ? row[t] : 0;
-            L.step(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.template step<FAST>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
             L.flush_chunks();
         }
         if (n_full > 0) {
@@ -381,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                         n3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)];
                         n1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
                     }
-                    L.step(e3, P); L.step(e2, P); L.step(e1, P); L.step(e0, P);
+                    L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
                     e3 = n3; e2 = n2; e1 = n1; e0 = n0;
                     if (j % G == 0) L.flush_chunks();   // static schedule: G divides the 8 groups of a tile
                 }
@@ -390,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
     }
 
     uint32_t n_words = 0;
-    const int32_t status = L.finish(!raw, n_words);
+    const int32_t status = L.finish(!raw, nsym, n_words);
     if (!active) return;
     if (raw) a.state[s] = (uint64_t)L.state;
     a.status[s] = status;
@@ -478,20 +512,30 @@ struct DecLane {
 };
 
 // One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
-template <int W, int S, int MODE>
+template <int W, int S, int MODE, bool FAST>
 __device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
                                                     const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
     using st_t = typename StateT<S>::type;
     const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
     const uint32_t q = (uint32_t)L.state & qmask;
-    const uint32_t next_word = *L.slot(L.rd - 1u + L.shift);   // unconditional; ignored if no refill
+    uint32_t next_word;
+    if constexpr (W == 32 && S == 64 && FAST) {
+        // Unconditional ring read, issued BEFORE the table lookup so that the lookup's own wait covers it.
+        // Inline asm: the optimiser would otherwise sink the load into a branch on `refill` and put the LDS
+        // latency back on the critical path (it is invisible to the compiler's lgkmcnt bookkeeping, hence the
+        // explicit s_waitcnt in the select block below).
+        const uint32_t ring_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)L.slot(L.rd - 1u + L.shift);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(next_word) : "v"(ring_addr) : "memory");
+    } else {
+        next_word = *L.slot(L.rd - 1u + L.shift);   // ignored if no refill
+    }
     uint32_t idx, c, p;
     if constexpr (MODE == kDecLut32) {
         const uint32_t e = reinterpret_cast<const uint32_t*>(lut)[q];
         idx = e & 0xffu; c = (e >> 8) & 0xfffu; p = e >> 20;
     } else if constexpr (MODE == kDecLut64) {
-        const uint64_t e = reinterpret_cast<const uint64_t*>(lut)[q];
-        c = (uint32_t)e & 0xffffffu; p = (uint32_t)(e >> 24) & 0xffffffu; idx = (uint32_t)(e >> 48);
+        const uint2 e = reinterpret_cast<const uint2*>(lut)[q];
+        p = e.x; c = e.y & 0xffffu; idx = e.y >> 16;
     } else {
         // bucket[q >> shift] = first index whose bin reaches into the bucket; scan forward
         idx = bucket[q >> bucket_shift];
@@ -500,14 +544,39 @@ __device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void
         c = cdf[idx];
         p = nxt - c;
     }
-    st_t st = (st_t)((st_t)(L.state >> P) * (st_t)p + (st_t)(q - c));
-    const bool refill = st < ((st_t)1 << (S - W)) && L.rd > 0;
-    L.state = refill ? (st_t)((st << (W % S)) | (st_t)next_word) : st;
-    L.rd -= refill ? 1u : 0u;
+    if constexpr (W == 32 && S == 64 && FAST) {
+        // 32-bit halves: (state >> P) * p + (q - c); the high product fits mul_u24 because P >= 8
+        const uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+        const uint32_t s_lo = __builtin_amdgcn_alignbit(hi, lo, P), s_hi = hi >> P;
+        const uint64_t t = (uint64_t)s_lo * p + (uint64_t)(q - c);
+        const uint32_t t_lo = (uint32_t)t;
+        const uint32_t t_hi = __umul24(s_hi, p) + (uint32_t)(t >> 32);
+        // refill <=> t < 2^32 and words remain <=> t_hi < min(rd, 1).  Hand-scheduled so that it stays one compare
+        // and three selects (2 wait states between the VALU write of vcc and its VALU readers).
+        uint32_t new_lo, new_hi, new_rd, have;
+        asm volatile(
+            "v_min_u32 %3, %4, 1\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_lt_u32 vcc, %5, %3\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %0, %6, %7, vcc\n\t"          // lo' = refill ? next_word : t_lo
+            "v_cndmask_b32 %1, %5, %6, vcc\n\t"          // hi' = refill ? t_lo : t_hi
+            "v_subbrev_co_u32 %2, vcc, 0, %4, vcc"        // rd' = rd - refill
+            : "=&v"(new_lo), "=&v"(new_hi), "=&v"(new_rd), "=&v"(have)
+            : "v"(L.rd), "v"(t_hi), "v"(t_lo), "v"(next_word)
+            : "vcc");
+        L.state = ((uint64_t)new_hi << 32) | new_lo;
+        L.rd = new_rd;
+    } else {
+        st_t st = (st_t)((st_t)(L.state >> P) * (st_t)p + (st_t)(q - c));
+        const bool refill = st < ((st_t)1 << (S - W)) && L.rd > 0;
+        L.state = refill ? (st_t)((st << (W % S)) | (st_t)next_word) : st;
+        L.rd -= refill ? 1u : 0u;
+    }
     return idx;
 }
 
-template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G>
+template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -571,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         int32_t* col = a.symbols + (active ? s : 0);
         int countdown = 4 * G;
         for (size_t t = 0; t < N; ++t) {
-            const uint32_t idx = ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
             if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
             if (--countdown == 0) { countdown = 4 * G; L.advance_window(); }
         }
@@ -583,10 +652,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
 #pragma unroll
             for (int j = 0; j < kTileSyms / 4; ++j) {
                 int4 v;
-                v.x = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.y = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.z = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.w = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.x = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.y = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.z = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.w = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
                 *reinterpret_cast<int4*>(my + 4 * j) = v;
                 if ((j + 1) % G == 0) L.advance_window();   // static schedule
             }
@@ -595,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
             wave_lds_fence();
         }
         for (size_t t = n_full * kTileSyms; t < N; ++t) {
-            const uint32_t idx = ans_decode_step<W, S, MODE>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
             if (active) row[t] = a.min_symbol + (int32_t)idx;
             L.advance_window();
         }

@@ -1,5 +1,6 @@
 // cst_api.hip -- C-ABI entry points (include/constriction_amd.h): argument checks, kernel selection, launches.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -36,43 +37,49 @@ static cst_status launch(K kernel, size_t n_streams, size_t lds_bytes, hipStream
 }
 
 // ---- encode dispatch ----
-template <int W, int S, int G>
+template <int W, int S, int G, bool FAST>
 static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     if (table_bytes + kTileBytesPerBlock > kMaxLds) return CST_ERR_INVALID_ARGUMENT; // TODO(global-table path)
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
-        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
-    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
-    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
 }
 
 template <int W, int S>
 static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
+    // FAST = the 32-bit-halves step of the (32,64) preset, valid for P >= 8
+    static const bool env_fast = getenv("CST_ENC_FAST") ? atoi(getenv("CST_ENC_FAST")) != 0 : false; // A/B knob: the compiler-scheduled 32-bit-halves form is currently slower
+    const bool fast = (W == 32) && a.precision >= 8 && env_fast;
     switch (groups_per_point(W, a.precision)) {
-        case 4: return encode_dispatch_g<W, S, 4>(a, layout, hs);
-        case 2: return encode_dispatch_g<W, S, 2>(a, layout, hs);
-        default: return encode_dispatch_g<W, S, 1>(a, layout, hs);
+        case 4: return fast ? encode_dispatch_g<W, S, 4, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 4, false>(a, layout, hs);
+        case 2: return fast ? encode_dispatch_g<W, S, 2, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 2, false>(a, layout, hs);
+        default: return encode_dispatch_g<W, S, 1, false>(a, layout, hs);
     }
 }
 
 // ---- decode dispatch ----
-template <int W, int S, int MODE, bool LDS, int G>
+template <int W, int S, int MODE, bool LDS, int G, bool FAST>
 static cst_status decode_dispatch3(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
     const size_t lds = ((table_lds + 15) & ~(size_t)15) + kTileBytesPerBlock;
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
-        return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+        return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G, FAST>, a.n_streams, lds, hs, a);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
-    if (vec) return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, MODE, LDS, G>, a.n_streams, lds, hs, a);
-    return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+    if (vec) return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, MODE, LDS, G, FAST>, a.n_streams, lds, hs, a);
+    return launch(ans_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, MODE, LDS, G, FAST>, a.n_streams, lds, hs, a);
 }
 
 template <int W, int S, int MODE, bool LDS>
 static cst_status decode_dispatch2(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
+    const bool fast = (W == 32) && a.precision >= 8;
     switch (groups_per_point(W, a.precision)) {
-        case 4: return decode_dispatch3<W, S, MODE, LDS, 4>(a, layout, table_lds, hs);
-        case 2: return decode_dispatch3<W, S, MODE, LDS, 2>(a, layout, table_lds, hs);
-        default: return decode_dispatch3<W, S, MODE, LDS, 1>(a, layout, table_lds, hs);
+        case 4: return fast ? decode_dispatch3<W, S, MODE, LDS, 4, W == 32>(a, layout, table_lds, hs)
+                            : decode_dispatch3<W, S, MODE, LDS, 4, false>(a, layout, table_lds, hs);
+        case 2: return fast ? decode_dispatch3<W, S, MODE, LDS, 2, W == 32>(a, layout, table_lds, hs)
+                            : decode_dispatch3<W, S, MODE, LDS, 2, false>(a, layout, table_lds, hs);
+        default: return decode_dispatch3<W, S, MODE, LDS, 1, false>(a, layout, table_lds, hs);
     }
 }
 
@@ -80,8 +87,6 @@ template <int W, int S>
 static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const int P = a.precision;
     const size_t lds_budget = kMaxLds - kTileBytesPerBlock - 1024;
-    if (a.dec32 && ((size_t)4 << P) <= lds_budget)
-        return decode_dispatch2<W, S, kDecLut32, true>(a, layout, ((size_t)4 << P), hs);
     if (a.dec64 && ((size_t)8 << P) <= lds_budget)
         return decode_dispatch2<W, S, kDecLut64, true>(a, layout, ((size_t)8 << P), hs);
     const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);

@@ -26,10 +26,11 @@ struct __attribute__((aligned(16))) EncEntry {
 
 // Decoder lookup entry for quantile q (lookup_contiguous.rs:564-605 collapsed into one load):
 //   packed32: idx[0,8) | c[8,20) | p[20,32)      (P <= 12 and n_symbols <= 256)
-//   packed64: c[0,24) | p[24,48) | idx[48,64)    (P <= 16)
+//   packed64: p[0,32) | c[32,48) | idx[48,64)    (P <= 16): p is a whole dword, c and idx are 16-bit halves
+//             (one SDWA subtract / add each on the decoder's critical path)
 __host__ __device__ inline uint32_t pack_dec32(uint32_t idx, uint32_t c, uint32_t p) { return idx | (c << 8) | (p << 20); }
 __host__ __device__ inline uint64_t pack_dec64(uint32_t idx, uint32_t c, uint32_t p) {
-    return (uint64_t)c | ((uint64_t)p << 24) | ((uint64_t)idx << 48);
+    return (uint64_t)p | ((uint64_t)c << 32) | ((uint64_t)idx << 48);
 }
 
 enum DecMode : int {
