@@ -198,3 +198,47 @@ def compact(encoded: EncodedBatch):
     N.check(L.cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
                                 _ptr(offsets), _ptr(packed), packed.numel(), None, _stream_ptr()), "cst_compact_words")
     return packed[: total.value], offsets
+
+
+def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
+    return N.load_library().cst_range_max_words(n_per_stream, _cfg(*config))
+
+
+def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
+                 stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One RangeEncoder per stream: encode_iid_symbols + get_compressed (queue.rs:612-705, 458-523)."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    if out is None:
+        stride = stride or range_max_words(n_per, config)
+        dev = symbols.device
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    N.check(N.lib().cst_range_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
+                                           out.words.shape[1], _ptr(out.n_words), _ptr(out.status), _stream_ptr()),
+            "cst_range_encode_batch")
+    return out
+
+
+def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, config=None):
+    """One RangeDecoder per stream: from_compressed + decode_iid_symbols (queue.rs:847-868, 968-1033)."""
+    if isinstance(encoded, EncodedBatch):
+        words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
+        stride = words.shape[1]
+    else:
+        words, n_words = encoded
+        stride = words.shape[1] if words.dim() == 2 else 0
+        config = config or (32, 64, 12)
+    n_streams = n_words.numel()
+    dev = words.device
+    if out is None:
+        shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
+        out = torch.empty(shape, dtype=torch.int32, device=dev)
+    lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
+    status = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
+                                           _ptr(out), n_streams, n_per_stream, lay, _ptr(status), _stream_ptr()),
+            "cst_range_decode_batch")
+    return out, status

@@ -231,19 +231,16 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode
+// per-lane word rings in LDS (layout [slot][lane]: every access is bank-conflict free)
 // ------------------------------------------------------------------------------------------------
 
-// Per-lane encoder: coder state + the LDS word ring in front of this stream's output slab.
-// Positions are counted in words from `base16`, the 16-byte aligned address at or below the slab start
-// (`shift` = slab start - base16, 0..3), so that every 4-aligned position group is one aligned 16-B chunk.
-template <int W, int S>
-struct EncLane {
-    using st_t = typename StateT<S>::type;
-    st_t state;
+// Output side.  Positions are counted in words from `base16`, the 16-byte aligned address at or below the
+// slab start (`shift` = slab start - base16, 0..3), so that every 4-aligned position group is one aligned
+// 16-B chunk of HBM.  A coder step writes its candidate word unconditionally and advances `wr` only if the
+// word was really emitted; complete chunks leave for HBM at scheduled points.
+struct RingWriter {
     uint32_t wr;        // words emitted so far (may exceed cap; then nothing more is stored)
     uint32_t flushed;   // positions < flushed are in HBM (multiple of 4, or 0)
-    uint32_t bad;       // any symbol outside the model's support
     uint32_t cap;       // slab capacity in words (0 for lanes without a stream)
     uint32_t shift;
     uint32_t* base16;
@@ -255,22 +252,12 @@ struct EncLane {
         base16 = reinterpret_cast<uint32_t*>(addr & ~(uintptr_t)15);
         shift = (uint32_t)((addr & 15) >> 2);
         cap = capacity; ring = wave_ring; lane = lane_;
-        wr = 0; flushed = 0; bad = 0;
+        wr = 0; flushed = 0;
     }
 
     __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
 
-    // branch-free step with a prefetched table entry; FAST selects the 32-bit-halves form (needs P >= 8)
-    template <bool FAST>
-    __device__ __forceinline__ void step(const EncEntry e, int P) {
-        uint32_t word, emit;
-        if constexpr (W == 32 && S == 64 && FAST) {
-            uint32_t lo = (uint32_t)state, hi = (uint32_t)(state >> 32);
-            emit = ans_encode_step_32x64(lo, hi, e, e.p << (32 - P), (1u << P) - e.p, word);
-            state = ((uint64_t)hi << 32) | lo;
-        } else {
-            emit = ans_encode_step<W, S>(state, e, P, word);
-        }
+    __device__ __forceinline__ void push(uint32_t word, uint32_t emit) {
         *slot(wr + shift) = word;   // always written; only becomes part of the stream if wr advances
         wr += emit;
     }
@@ -298,25 +285,132 @@ struct EncLane {
         }
     }
 
-    // end of stream: everything still in the ring, then (unless raw) the state words, least significant
-    // first (into_compressed, stack.rs:891-895).  Returns the stream status.
-    __device__ __forceinline__ int32_t finish(bool append_state, uint32_t n_symbols, uint32_t& n_words_out) {
-        // drain ring: whole chunks first, then the ragged tail
+    // rare slow path: make room for a burst (range coder carry resolution)
+    __device__ __forceinline__ void push_slow(uint32_t word) {
+        if (wr + shift - flushed >= (uint32_t)(kRingSlots - 4)) flush_chunks();
+        push(word, 1u);
+    }
+
+    // end of stream: everything still in the ring goes to HBM (whole chunks first, then the ragged tail)
+    __device__ __forceinline__ void drain() {
         for (int guard = 0; guard < 8 && flushed + 4 <= wr + shift; ++guard) flush_chunks();
         for (uint32_t pos = flushed; pos < wr + shift; ++pos)
             if (pos >= shift && pos - shift < cap) base16[pos] = *slot(pos);
-        uint32_t len = wr;
-        if (append_state) {
-            const int k = state_word_count<W, S>(state);
-            for (int i = 0; i < k; ++i) {
-                const uint32_t w = (uint32_t)(state >> ((i * W) % S)) & word_mask<W>();
-                if (len < cap) base16[shift + len] = w;
-                ++len;
+        flushed = wr + shift;
+    }
+
+    // append one word directly to HBM after drain()
+    __device__ __forceinline__ void append_direct(uint32_t word) {
+        if (wr < cap) base16[shift + wr] = word;
+        ++wr;
+    }
+};
+
+// Input side (stack semantics: words are consumed from the END of the stream's buffer).
+struct RingReader {
+    uint32_t rd;           // words not yet consumed (next word has stream index rd-1)
+    uint32_t shift;
+    uint32_t lo_issued;    // lowest position (multiple of 4) whose chunk has been requested
+    const uint32_t* base16;
+    uint32_t* ring;
+    int lane;
+    uint4 pend[kMaxChunksPerPoint];
+    int32_t pend_pos[kMaxChunksPerPoint];
+
+    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
+
+    __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint32_t* wave_ring, int lane_) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
+        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
+        shift = (uint32_t)((addr & 15) >> 2);
+        ring = wave_ring; lane = lane_; rd = len;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+    }
+
+    // direct HBM access to word `i` of the stream (initial-state words)
+    __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
+
+    // fill the ring with the kAhead words below the read position (blocking; once per stream)
+    __device__ __forceinline__ void prime() {
+        const uint32_t top = rd + shift;
+        lo_issued = (top + 3) & ~3u;
+        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+        while (lo_issued > want_lo) {
+            lo_issued -= 4;
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            *slot(lo_issued + 0) = v.x; *slot(lo_issued + 1) = v.y; *slot(lo_issued + 2) = v.z; *slot(lo_issued + 3) = v.w;
+        }
+    }
+
+    // scheduled point: land the chunks requested at the previous point, request the next ones
+    __device__ __forceinline__ void advance_window() {
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (pend_pos[k] >= 0) {
+                const uint32_t p = (uint32_t)pend_pos[k];
+                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
             }
         }
-        n_words_out = len;
+        const uint32_t top = rd + shift;
+        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (lo_issued > want_lo) {
+                lo_issued -= 4;
+                pend_pos[k] = (int32_t)lo_issued;
+                pend[k] = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            } else {
+                pend_pos[k] = -1;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+
+// Per-lane ANS encoder: coder state + the word ring in front of this stream's output slab.
+template <int W, int S>
+struct EncLane {
+    using st_t = typename StateT<S>::type;
+    st_t state;
+    uint32_t bad;       // largest raw table index seen (>= n_symbols <=> impossible symbol)
+    RingWriter out;
+
+    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        out.init(slab, capacity, wave_ring, lane_);
+        bad = 0; state = 0;
+    }
+
+    // branch-free step with a prefetched table entry; FAST selects the 32-bit-halves form (needs P >= 8)
+    template <bool FAST>
+    __device__ __forceinline__ void step(const EncEntry e, int P) {
+        uint32_t word, emit;
+        if constexpr (W == 32 && S == 64 && FAST) {
+            uint32_t lo = (uint32_t)state, hi = (uint32_t)(state >> 32);
+            emit = ans_encode_step_32x64(lo, hi, e, e.p << (32 - P), (1u << P) - e.p, word);
+            state = ((uint64_t)hi << 32) | lo;
+        } else {
+            emit = ans_encode_step<W, S>(state, e, P, word);
+        }
+        out.push(word, emit);
+    }
+
+    __device__ __forceinline__ void flush_chunks() { out.flush_chunks(); }
+
+    // end of stream: everything still in the ring, then (unless raw) the state words, least significant
+    // first (into_compressed, stack.rs:891-895).  Returns the stream status.
+    __device__ __forceinline__ int32_t finish(bool append_state, uint32_t n_symbols, uint32_t& n_words_out) {
+        out.drain();
+        if (append_state) {
+            const int k = state_word_count<W, S>(state);
+            for (int i = 0; i < k; ++i) out.append_direct((uint32_t)(state >> ((i * W) % S)) & word_mask<W>());
+        }
+        n_words_out = out.wr;
         if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;   // src/lib.rs:376-385
-        if (len > cap) return CST_STREAM_CAPACITY;
+        if (out.wr > out.cap) return CST_STREAM_CAPACITY;
         return CST_STREAM_OK;
     }
 };
@@ -435,101 +529,38 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
 // decode
 // ------------------------------------------------------------------------------------------------
 
-// Per-lane decoder: coder state + the LDS word ring that runs ahead of the read position.
+// Per-lane ANS decoder: coder state + the word ring that runs ahead of the read position.
 template <int W, int S>
 struct DecLane {
     using st_t = typename StateT<S>::type;
     st_t state;
-    uint32_t rd;           // words not yet consumed (next word has stream index rd-1)
-    uint32_t shift;
-    uint32_t lo_issued;    // lowest position (multiple of 4) whose chunk has been requested
-    const uint32_t* base16;
-    uint32_t* ring;
-    int lane;
     int32_t status;
-    uint4 pend[kMaxChunksPerPoint];
-    int32_t pend_pos[kMaxChunksPerPoint];
+    RingReader in;
 
-    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
-
-    __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint32_t* wave_ring, int lane_) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
-        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
-        shift = (uint32_t)((addr & 15) >> 2);
-        ring = wave_ring; lane = lane_; rd = len; status = CST_STREAM_OK; state = 0;
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+    __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
+        in.init(words, len, wave_ring, lane_);
+        status = CST_STREAM_OK; state = 0;
     }
 
     // from_compressed + read_initial_state (stack.rs:299-318, 440-462), straight from HBM
     __device__ __forceinline__ void read_initial_state() {
-        if (rd == 0) return;
-        const uint32_t* in = base16 + shift;
-        const uint32_t first = in[--rd];
-        if (first == 0) { status = CST_STREAM_INVALID_DATA; rd = 0; return; }
+        if (in.rd == 0) return;
+        const uint32_t first = in.word_direct(--in.rd);
+        if (first == 0) { status = CST_STREAM_INVALID_DATA; in.rd = 0; return; }
         st_t st = first;
-        while (rd > 0) {
-            st = (st_t)((st << (W % S)) | (st_t)in[--rd]);
+        while (in.rd > 0) {
+            st = (st_t)((st << (W % S)) | (st_t)in.word_direct(--in.rd));
             if (st >= ((st_t)1 << (S - W))) break;
         }
         state = st;
     }
-
-    // fill the ring with the kAhead words below the read position (blocking; once per stream)
-    __device__ __forceinline__ void prime() {
-        const uint32_t top = rd + shift;
-        lo_issued = (top + 3) & ~3u;
-        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
-        while (lo_issued > want_lo) {
-            lo_issued -= 4;
-            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
-            *slot(lo_issued + 0) = v.x; *slot(lo_issued + 1) = v.y; *slot(lo_issued + 2) = v.z; *slot(lo_issued + 3) = v.w;
-        }
-    }
-
-    // scheduled point: land the chunks requested at the previous point, request the next ones
-    __device__ __forceinline__ void advance_window() {
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
-            if (pend_pos[k] >= 0) {
-                const uint32_t p = (uint32_t)pend_pos[k];
-                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
-            }
-        }
-        const uint32_t top = rd + shift;
-        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
-            if (lo_issued > want_lo) {
-                lo_issued -= 4;
-                pend_pos[k] = (int32_t)lo_issued;
-                pend[k] = *reinterpret_cast<const uint4*>(base16 + lo_issued);
-            } else {
-                pend_pos[k] = -1;
-            }
-        }
-    }
 };
 
-// One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
-template <int W, int S, int MODE, bool FAST>
-__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
-                                                    const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
-    using st_t = typename StateT<S>::type;
-    const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
-    const uint32_t q = (uint32_t)L.state & qmask;
-    uint32_t next_word;
-    if constexpr (W == 32 && S == 64 && FAST) {
-        // Unconditional ring read, issued BEFORE the table lookup so that the lookup's own wait covers it.
-        // Inline asm: the optimiser would otherwise sink the load into a branch on `refill` and put the LDS
-        // latency back on the critical path (it is invisible to the compiler's lgkmcnt bookkeeping, hence the
-        // explicit s_waitcnt in the select block below).
-        const uint32_t ring_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)L.slot(L.rd - 1u + L.shift);
-        asm volatile("ds_read_b32 %0, %1" : "=v"(next_word) : "v"(ring_addr) : "memory");
-    } else {
-        next_word = *L.slot(L.rd - 1u + L.shift);   // ignored if no refill
-    }
-    uint32_t idx, c, p;
+// DecoderModel::quantile_function for a tabulated model (lookup_contiguous.rs:564-605): quantile -> (index, left
+// cumulative, probability), from the LDS/global image selected by MODE.
+template <int MODE>
+__device__ __forceinline__ void lookup_quantile(uint32_t q, const void* lut, const uint32_t* cdf, const uint16_t* bucket,
+                                                int bucket_shift, int n_symbols, uint32_t& idx, uint32_t& c, uint32_t& p) {
     if constexpr (MODE == kDecLut32) {
         const uint32_t e = reinterpret_cast<const uint32_t*>(lut)[q];
         idx = e & 0xffu; c = (e >> 8) & 0xfffu; p = e >> 20;
@@ -544,6 +575,28 @@ __device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void
         c = cdf[idx];
         p = nxt - c;
     }
+}
+
+// One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
+template <int W, int S, int MODE, bool FAST>
+__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
+                                                    const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
+    using st_t = typename StateT<S>::type;
+    const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
+    const uint32_t q = (uint32_t)L.state & qmask;
+    uint32_t next_word;
+    if constexpr (W == 32 && S == 64 && FAST) {
+        // Unconditional ring read, issued BEFORE the table lookup so that the lookup's own wait covers it.
+        // Inline asm: the optimiser would otherwise sink the load into a branch on `refill` and put the LDS
+        // latency back on the critical path (it is invisible to the compiler's lgkmcnt bookkeeping, hence the
+        // explicit s_waitcnt in the select block below).
+        const uint32_t ring_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)L.in.slot(L.in.rd - 1u + L.in.shift);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(next_word) : "v"(ring_addr) : "memory");
+    } else {
+        next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);   // ignored if no refill
+    }
+    uint32_t idx, c, p;
+    lookup_quantile<MODE>(q, lut, cdf, bucket, bucket_shift, n_symbols, idx, c, p);
     if constexpr (W == 32 && S == 64 && FAST) {
         // 32-bit halves: (state >> P) * p + (q - c); the high product fits mul_u24 because P >= 8
         const uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
@@ -563,17 +616,53 @@ __device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void
             "v_cndmask_b32 %1, %5, %6, vcc\n\t"          // hi' = refill ? t_lo : t_hi
             "v_subbrev_co_u32 %2, vcc, 0, %4, vcc"        // rd' = rd - refill
             : "=&v"(new_lo), "=&v"(new_hi), "=&v"(new_rd), "=&v"(have)
-            : "v"(L.rd), "v"(t_hi), "v"(t_lo), "v"(next_word)
+            : "v"(L.in.rd), "v"(t_hi), "v"(t_lo), "v"(next_word)
             : "vcc");
         L.state = ((uint64_t)new_hi << 32) | new_lo;
-        L.rd = new_rd;
+        L.in.rd = new_rd;
     } else {
         st_t st = (st_t)((st_t)(L.state >> P) * (st_t)p + (st_t)(q - c));
-        const bool refill = st < ((st_t)1 << (S - W)) && L.rd > 0;
+        const bool refill = st < ((st_t)1 << (S - W)) && L.in.rd > 0;
         L.state = refill ? (st_t)((st << (W % S)) | (st_t)next_word) : st;
-        L.rd -= refill ? 1u : 0u;
+        L.in.rd -= refill ? 1u : 0u;
     }
     return idx;
+}
+
+// Copies the decoder tables selected by MODE into LDS (if LUT_IN_LDS) and returns the bytes used.
+template <int MODE, bool LUT_IN_LDS>
+__device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int P, const uint32_t* dec32, const uint64_t* dec64,
+                                                       const uint32_t* g_cdf, const uint16_t* g_bucket, int bucket_bits,
+                                                       int n_symbols, const void*& lut, const uint32_t*& cdf,
+                                                       const uint16_t*& bucket) {
+    size_t lds_off = 0;
+    if constexpr (MODE == kDecLut32) {
+        if constexpr (LUT_IN_LDS) {
+            uint32_t* l = reinterpret_cast<uint32_t*>(smem);
+            const int n = 1 << P;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = dec32[i];
+            lut = l; lds_off = (size_t)n * 4;
+        } else lut = dec32;
+    } else if constexpr (MODE == kDecLut64) {
+        if constexpr (LUT_IN_LDS) {
+            uint64_t* l = reinterpret_cast<uint64_t*>(smem);
+            const int n = 1 << P;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = dec64[i];
+            lut = l; lds_off = (size_t)n * 8;
+        } else lut = dec64;
+    } else {
+        if constexpr (LUT_IN_LDS) {
+            uint32_t* c = reinterpret_cast<uint32_t*>(smem);
+            for (int i = threadIdx.x; i <= n_symbols; i += blockDim.x) c[i] = g_cdf[i];
+            lds_off = (((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15;
+            uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
+            const int nb = (1 << bucket_bits);
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];
+            lds_off += ((size_t)nb * 2 + 15) & ~(size_t)15;
+            cdf = c; bucket = b;
+        }
+    }
+    return lds_off;
 }
 
 template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G, bool FAST>
@@ -584,36 +673,11 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const int P = a.precision;
 
     // ---- stage tables in LDS ----
-    size_t lds_off = 0;
     const void* lut = nullptr;
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    if constexpr (MODE == kDecLut32) {
-        if constexpr (LUT_IN_LDS) {
-            uint32_t* l = reinterpret_cast<uint32_t*>(smem);
-            const int n = 1 << P;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = a.dec32[i];
-            lut = l; lds_off = (size_t)n * 4;
-        } else lut = a.dec32;
-    } else if constexpr (MODE == kDecLut64) {
-        if constexpr (LUT_IN_LDS) {
-            uint64_t* l = reinterpret_cast<uint64_t*>(smem);
-            const int n = 1 << P;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = a.dec64[i];
-            lut = l; lds_off = (size_t)n * 8;
-        } else lut = a.dec64;
-    } else {
-        if constexpr (LUT_IN_LDS) {
-            uint32_t* c = reinterpret_cast<uint32_t*>(smem);
-            for (int i = threadIdx.x; i <= a.n_symbols; i += blockDim.x) c[i] = a.cdf[i];
-            lds_off = (((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15;
-            uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
-            const int nb = (1 << a.bucket_bits);
-            for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = a.bucket[i];
-            lds_off += ((size_t)nb * 2 + 15) & ~(size_t)15;
-            cdf = c; bucket = b;
-        }
-    }
+    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec32, a.dec64, a.cdf, a.bucket, a.bucket_bits,
+                                                           a.n_symbols, lut, cdf, bucket);
     lds_off = (lds_off + 15) & ~(size_t)15;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
     int32_t* tile = reinterpret_cast<int32_t*>(smem + lds_off + (size_t)(kBlock / kWave) * kRingWords * 4) +
@@ -633,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
     if (raw) L.state = active ? (typename StateT<S>::type)a.state[s] : 0;
     else L.read_initial_state();
-    L.prime();
+    L.in.prime();
     wave_lds_fence();
 
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
@@ -642,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         for (size_t t = 0; t < N; ++t) {
             const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
             if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
-            if (--countdown == 0) { countdown = 4 * G; L.advance_window(); }
+            if (--countdown == 0) { countdown = 4 * G; L.in.advance_window(); }
         }
     } else {
         int32_t* row = a.symbols + (active ? s : 0) * N;
@@ -657,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 v.z = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
                 v.w = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
                 *reinterpret_cast<int4*>(my + 4 * j) = v;
-                if ((j + 1) % G == 0) L.advance_window();   // static schedule
+                if ((j + 1) % G == 0) L.in.advance_window();   // static schedule
             }
             wave_lds_fence();
             tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
@@ -666,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         for (size_t t = n_full * kTileSyms; t < N; ++t) {
             const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
             if (active) row[t] = a.min_symbol + (int32_t)idx;
-            L.advance_window();
+            L.in.advance_window();
         }
     }
 
@@ -674,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     a.status[s] = L.status;
     if (raw) {
         a.state[s] = (uint64_t)L.state;
-        if (a.n_words_out) a.n_words_out[s] = L.rd;
+        if (a.n_words_out) a.n_words_out[s] = L.in.rd;
     }
 }
 

@@ -1,0 +1,472 @@
+// cst_range.hip -- batched range coder (BASELINE config C4): one RangeEncoder / RangeDecoder per lane.
+//
+// Recurrences: RangeEncoder::encode_symbol (src/stream/queue.rs:612-705) with its lazy carry
+// (EncoderSituation::Inverted, queue.rs:126-142), seal_words (queue.rs:482-523), RangeDecoder::read_point
+// (queue.rs:847-868) and decode_symbol (queue.rs:968-1033).  Same data movement as the ANS kernels
+// (cst_ans_kernels.hpp): tables in LDS, LDS-tiled symbol matrix, per-lane LDS word rings; words are
+// written and read front to back (a queue).
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+// Forward-reading counterpart of RingReader (queue semantics).
+struct RingReaderFwd {
+    uint32_t pos;          // next stream index to read
+    uint32_t len;          // words in the stream
+    uint32_t shift;
+    uint32_t hi_issued;    // positions < hi_issued (multiple of 4) have been requested
+    const uint32_t* base16;
+    uint32_t* ring;
+    int lane;
+    uint4 pend[kMaxChunksPerPoint];
+    int32_t pend_pos[kMaxChunksPerPoint];
+
+    __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (kRingSlots - 1)) * kWave + lane); }
+
+    __device__ __forceinline__ void init(const uint32_t* in, uint32_t n, uint32_t* wave_ring, int lane_) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
+        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
+        shift = (uint32_t)((addr & 15) >> 2);
+        ring = wave_ring; lane = lane_; pos = 0; len = n;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+    }
+
+    __device__ __forceinline__ void prime() {
+        hi_issued = shift & ~3u;
+        const uint32_t end = len + shift;
+        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+        while (hi_issued < want_hi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + hi_issued);
+            *slot(hi_issued + 0) = v.x; *slot(hi_issued + 1) = v.y; *slot(hi_issued + 2) = v.z; *slot(hi_issued + 3) = v.w;
+            hi_issued += 4;
+        }
+    }
+
+    __device__ __forceinline__ void advance_window() {
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (pend_pos[k] >= 0) {
+                const uint32_t p = (uint32_t)pend_pos[k];
+                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
+            }
+        }
+        const uint32_t end = len + shift;
+        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (hi_issued < want_hi) {
+                pend_pos[k] = (int32_t)hi_issued;
+                pend[k] = *reinterpret_cast<const uint4*>(base16 + hi_issued);
+                hi_issued += 4;
+            } else {
+                pend_pos[k] = -1;
+            }
+        }
+    }
+
+    // next word if any (ring must cover it); does not advance
+    __device__ __forceinline__ uint32_t peek() const { return *slot(pos + shift); }
+    __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
+};
+
+template <int W, int S>
+struct RangeEncLane {
+    using st_t = typename StateT<S>::type;
+    st_t lower, range;
+    uint32_t inv_n, inv_first;   // EncoderSituation: inv_n == 0 <=> Normal
+    uint32_t bad;
+    RingWriter out;
+
+    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        out.init(slab, capacity, wave_ring, lane_);
+        lower = 0; range = (st_t)~(st_t)0;   // RangeCoderState::default, queue.rs:96-104
+        inv_n = 0; inv_first = 0; bad = 0;
+    }
+
+    // queue.rs:612-705
+    __device__ __forceinline__ void step(uint32_t c, uint32_t p, int P) {
+        const st_t scale = (st_t)(range >> P);
+        const st_t new_range = (st_t)(scale * (st_t)p);
+        const st_t new_lower = (st_t)(lower + scale * (st_t)c);
+        if (__builtin_expect(inv_n != 0, 0)) {
+            if ((st_t)(new_lower + new_range) > new_lower) {   // inverted -> normal
+                uint32_t first, cons;
+                if (new_lower < lower) { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
+                else { first = inv_first; cons = word_mask<W>(); }
+                out.push_slow(first);
+                for (uint32_t i = 1; i < inv_n; ++i) out.push_slow(cons);
+                inv_n = 0;
+            }
+        }
+        lower = new_lower; range = new_range;
+        const bool renorm = range < ((st_t)1 << (S - W));
+        const uint32_t lower_word = (uint32_t)(lower >> (S - W)) & word_mask<W>();
+        const st_t sh_lower = (st_t)(lower << (W % S)), sh_range = (st_t)(range << (W % S));
+        const bool no_wrap = (st_t)(sh_lower + sh_range) > sh_lower;
+        // common case: Normal -> Normal (emit lower_word) -- branch free through the ring
+        out.push(lower_word, (renorm && inv_n == 0 && no_wrap) ? 1u : 0u);
+        if (__builtin_expect(renorm && (inv_n != 0 || !no_wrap), 0)) {
+            if (inv_n != 0) inv_n += 1;                    // inverted -> inverted
+            else { inv_n = 1; inv_first = lower_word; }    // normal -> inverted
+        }
+        lower = renorm ? sh_lower : lower;
+        range = renorm ? sh_range : range;
+    }
+
+    // seal_words / iter_seal (queue.rs:458-523)
+    __device__ __forceinline__ int32_t finish(uint32_t n_symbols, uint32_t& n_words_out) {
+        out.drain();
+        if (range != (st_t)~(st_t)0) {
+            const st_t point = (st_t)(lower + (((st_t)1 << (S - W)) - 1));
+            if (inv_n != 0) {
+                uint32_t first, cons;
+                if (point >= lower) { first = inv_first; cons = word_mask<W>(); }
+                else { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
+                out.append_direct(first);
+                for (uint32_t i = 1; i < inv_n; ++i) out.append_direct(cons);
+            }
+            const uint32_t point_word = (uint32_t)(point >> (S - W)) & word_mask<W>();
+            const uint32_t upper_word = (uint32_t)((st_t)(lower + range) >> (S - W)) & word_mask<W>();
+            out.append_direct(point_word);
+            if (upper_word == point_word) out.append_direct(0u);
+        }
+        n_words_out = out.wr;
+        if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;
+        if (out.wr > out.cap) return CST_STREAM_CAPACITY;
+        return CST_STREAM_OK;
+    }
+};
+
+struct RangeEncodeArgs {
+    const int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    const EncEntry* enc;
+    int32_t n_symbols, min_symbol, precision;
+    uint32_t* words;
+    size_t stride_words;
+    uint32_t* n_words;
+    int32_t* status;
+};
+
+template <int W, int S, int LAYOUT, bool VEC, int G>
+__global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + table_bytes) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + table_bytes + (size_t)(kBlock / kWave) * kRingWords * 4) +
+                    wave_in_block * (kWave * kTileStride);
+    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+
+    RangeEncLane<W, S> L;
+    L.init(a.words + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+
+    auto code = [&](int32_t v) {
+        const EncEntry e = table[enc_index(v, a.min_symbol, nsym, L.bad)];
+        L.step(e.c, e.p, P);
+    };
+
+    if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
+        const int32_t* col = a.symbols + (active ? s : 0);
+        int countdown = 4 * G;
+        for (size_t t = 0; t < N; ++t) {
+            code(active ? col[t * a.n_streams] : 0);
+            if (--countdown == 0) { countdown = 4 * G; L.out.flush_chunks(); }
+        }
+    } else {
+        const int32_t* row = a.symbols + (active ? s : 0) * N;
+        const size_t n_full = N / kTileSyms;
+        if (n_full > 0) {
+            int32_t r[kTileSyms];
+            tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, 0, lane, r);
+            for (size_t tb = 0; tb < n_full; ++tb) {
+                wave_lds_fence();
+                tile_to_lds<VEC>(tile, lane, r);
+                wave_lds_fence();
+                if (tb + 1 < n_full) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb + 1) * kTileSyms, lane, r);
+                const int32_t* my = tile + lane * kTileStride;
+#pragma unroll
+                for (int j = 0; j < kTileSyms / 4; ++j) {
+                    const int4 v = *reinterpret_cast<const int4*>(my + 4 * j);
+                    code(v.x); code(v.y); code(v.z); code(v.w);
+                    if ((j + 1) % G == 0) L.out.flush_chunks();
+                }
+            }
+        }
+        for (size_t t = n_full * kTileSyms; t < N; ++t) {
+            code(active ? row[t] : 0);
+            L.out.flush_chunks();
+        }
+    }
+
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+struct RangeDecodeArgs {
+    const uint32_t* words;
+    const uint64_t* offsets;
+    size_t stride_words;
+    const uint32_t* n_words;
+    int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    const uint32_t* dec32;
+    const uint64_t* dec64;
+    const uint32_t* cdf;
+    const uint16_t* bucket;
+    int32_t bucket_bits;
+    int32_t n_symbols, min_symbol, precision;
+    int32_t* status;
+};
+
+template <int W, int S>
+struct RangeDecLane {
+    using st_t = typename StateT<S>::type;
+    st_t lower, range, point;
+    int32_t status;
+    RingReaderFwd in;
+
+    // from_compressed + read_point (queue.rs:776-790, 847-868)
+    __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
+        in.init(words, len, wave_ring, lane_);
+        lower = 0; range = (st_t)~(st_t)0; status = CST_STREAM_OK;
+        st_t pt = 0;
+        int num_read = 0;
+        while (in.pos < in.len) {
+            pt = (st_t)((pt << (W % S)) | (st_t)in.word_direct(in.pos++));
+            if (++num_read == S / W) break;
+        }
+        if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
+        point = pt;
+    }
+
+    // queue.rs:968-1033; returns the symbol index (0 after an InvalidData error)
+    template <int MODE>
+    __device__ __forceinline__ uint32_t step(const void* lut, const uint32_t* cdf, const uint16_t* bucket, int bucket_shift,
+                                             int n_symbols, int P) {
+        const st_t scale = (st_t)(range >> P);
+        const st_t x = (st_t)(point - lower);
+        // quantile = x / scale is < 2^(P+1): estimate in f64, then make it exact
+        uint32_t q = (uint32_t)((double)x / (double)scale);
+        st_t prod = (st_t)((st_t)q * scale);
+        if (prod > x) { --q; prod -= scale; }
+        else if ((st_t)(x - prod) >= scale) { ++q; prod += scale; }
+        const uint32_t next_word = in.peek();
+        if (q >= (1u << P)) {                      // DecoderFrontendError::InvalidData, queue.rs:989-993
+            if (status == CST_STREAM_OK) status = CST_STREAM_INVALID_DATA;
+            q = (1u << P) - 1u;                    // keep the lane on legal table indices; its output is unspecified
+        }
+        uint32_t idx, c, p;
+        lookup_quantile<MODE>(q, lut, cdf, bucket, bucket_shift, n_symbols, idx, c, p);
+        lower = (st_t)(lower + scale * (st_t)c);
+        range = (st_t)(scale * (st_t)p);
+        const bool renorm = range < ((st_t)1 << (S - W));
+        const bool have = in.pos < in.len;
+        const st_t sh_point = (st_t)((st_t)(point << (W % S)) | (st_t)(have ? next_word : 0u));
+        lower = renorm ? (st_t)(lower << (W % S)) : lower;
+        range = renorm ? (st_t)(range << (W % S)) : range;
+        point = renorm ? sh_point : point;
+        in.pos += (renorm && have) ? 1u : 0u;
+        return idx;
+    }
+};
+
+template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G>
+__global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    const void* lut = nullptr;
+    const uint32_t* cdf = a.cdf;
+    const uint16_t* bucket = a.bucket;
+    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec32, a.dec64, a.cdf, a.bucket, a.bucket_bits,
+                                                           a.n_symbols, lut, cdf, bucket);
+    lds_off = (lds_off + 15) & ~(size_t)15;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + lds_off + (size_t)(kBlock / kWave) * kRingWords * 4) +
+                    wave_in_block * (kWave * kTileStride);
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int bucket_shift = P - a.bucket_bits;
+
+    RangeDecLane<W, S> L;
+    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    L.in.prime();
+    wave_lds_fence();
+
+    if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
+        int32_t* col = a.symbols + (active ? s : 0);
+        int countdown = 4 * G;
+        for (size_t t = 0; t < N; ++t) {
+            const uint32_t idx = L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
+            if (--countdown == 0) { countdown = 4 * G; L.in.advance_window(); }
+        }
+    } else {
+        int32_t* row = a.symbols + (active ? s : 0) * N;
+        const size_t n_full = N / kTileSyms;
+        int32_t* my = tile + lane * kTileStride;
+        for (size_t tb = 0; tb < n_full; ++tb) {
+#pragma unroll
+            for (int j = 0; j < kTileSyms / 4; ++j) {
+                int4 v;
+                v.x = a.min_symbol + (int32_t)L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.y = a.min_symbol + (int32_t)L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.z = a.min_symbol + (int32_t)L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                v.w = a.min_symbol + (int32_t)L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                *reinterpret_cast<int4*>(my + 4 * j) = v;
+                if ((j + 1) % G == 0) L.in.advance_window();
+            }
+            wave_lds_fence();
+            tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+            wave_lds_fence();
+        }
+        for (size_t t = n_full * kTileSyms; t < N; ++t) {
+            const uint32_t idx = L.template step<MODE>(lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            if (active) row[t] = a.min_symbol + (int32_t)idx;
+            L.in.advance_window();
+        }
+    }
+    if (active) a.status[s] = L.status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static constexpr size_t kPerBlockLds = (size_t)(kBlock / kWave) * (kRingWords * sizeof(uint32_t) + kWave * kTileStride * sizeof(int32_t));
+static constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename K, typename A>
+static cst_status launch(K kernel, size_t n_streams, size_t lds_bytes, hipStream_t hs, const A& args) {
+    const size_t blocks = (n_streams + kBlock - 1) / kBlock;
+    if (blocks == 0) return CST_OK;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    if (lds_bytes > 64 * 1024)
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, hs, args);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+template <int W, int S, int G>
+static cst_status range_encode_g(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs) {
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
+    const size_t lds = table_bytes + kPerBlockLds;
+    if (lds > kMaxLds) return CST_ERR_INVALID_ARGUMENT;
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return launch(range_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G>, a.n_streams, lds, hs, a);
+    const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
+    if (vec) return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G>, a.n_streams, lds, hs, a);
+    return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G>, a.n_streams, lds, hs, a);
+}
+
+template <int W, int S>
+static cst_status range_encode_ws(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs) {
+    switch (groups_per_point(W, a.precision)) {
+        case 4: return range_encode_g<W, S, 4>(a, layout, hs);
+        case 2: return range_encode_g<W, S, 2>(a, layout, hs);
+        default: return range_encode_g<W, S, 1>(a, layout, hs);
+    }
+}
+
+template <int W, int S, int MODE, bool LDS, int G>
+static cst_status range_decode_g(const RangeDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
+    const size_t lds = ((table_lds + 15) & ~(size_t)15) + kPerBlockLds;
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return launch(range_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+    const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
+    if (vec) return launch(range_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, MODE, LDS, G>, a.n_streams, lds, hs, a);
+    return launch(range_decode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, MODE, LDS, G>, a.n_streams, lds, hs, a);
+}
+
+template <int W, int S, int MODE, bool LDS>
+static cst_status range_decode_m(const RangeDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
+    switch (groups_per_point(W, a.precision)) {
+        case 4: return range_decode_g<W, S, MODE, LDS, 4>(a, layout, table_lds, hs);
+        case 2: return range_decode_g<W, S, MODE, LDS, 2>(a, layout, table_lds, hs);
+        default: return range_decode_g<W, S, MODE, LDS, 1>(a, layout, table_lds, hs);
+    }
+}
+
+template <int W, int S>
+static cst_status range_decode_ws(const RangeDecodeArgs& a, cst_layout layout, hipStream_t hs) {
+    const int P = a.precision;
+    const size_t lds_budget = kMaxLds - kPerBlockLds - 1024;
+    if (a.dec64 && ((size_t)8 << P) <= lds_budget) return range_decode_m<W, S, kDecLut64, true>(a, layout, ((size_t)8 << P), hs);
+    const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
+    if (bucket_lds <= lds_budget) return range_decode_m<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
+    if (a.dec64) return range_decode_m<W, S, kDecLut64, false>(a, layout, 0, hs);
+    return range_decode_m<W, S, kDecBucket, false>(a, layout, 0, hs);
+}
+
+} // namespace cst
+
+using namespace cst;
+
+extern "C" {
+
+cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
+                                  size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
+                                  uint32_t* d_n_words, int32_t* d_status, void* stream) {
+    if (!model || !d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
+    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    RangeEncodeArgs a{};
+    a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
+    hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32) return range_encode_ws<32, 64>(a, layout, hs);
+    return range_encode_ws<16, 32>(a, layout, hs);
+}
+
+cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
+                                  const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                  int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                  int32_t* d_status, void* stream) {
+    if (!model || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
+    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    RangeDecodeArgs a{};
+    a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec32 = model->d_dec32; a.dec64 = model->d_dec64;
+    a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
+    a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
+    hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
+    return range_decode_ws<16, 32>(a, layout, hs);
+}
+
+} // extern "C"

@@ -7,8 +7,4 @@ cst_status cst_ans_encode_gaussian_batch(cst_coder_config, int32_t, int32_t, con
 cst_status cst_ans_decode_gaussian_batch(cst_coder_config, int32_t, int32_t, const uint32_t*, const uint64_t*, size_t,
                                          const uint32_t*, const double*, const double*, int32_t*, size_t, size_t,
                                          cst_layout, uint64_t*, uint32_t*, int32_t*, uint32_t, void*) { return CST_ERR_INVALID_ARGUMENT; }
-cst_status cst_range_encode_batch(const cst_model*, cst_coder_config, const int32_t*, size_t, size_t, cst_layout, uint32_t*,
-                                  size_t, uint32_t*, int32_t*, void*) { return CST_ERR_INVALID_ARGUMENT; }
-cst_status cst_range_decode_batch(const cst_model*, cst_coder_config, const uint32_t*, const uint64_t*, size_t,
-                                  const uint32_t*, int32_t*, size_t, size_t, cst_layout, int32_t*, void*) { return CST_ERR_INVALID_ARGUMENT; }
 }

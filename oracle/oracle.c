@@ -805,3 +805,45 @@ API void cst_oracle_synth_symbols(uint64_t seed, size_t stream_begin, size_t n_s
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Batched range coder drivers (config C4): one RangeEncoder / RangeDecoder per stream, shared table.
+ * ---------------------------------------------------------------------------------------- */
+API void cst_oracle_rc_encode_batch(int W, int S, int P, const int32_t *symbols, size_t n_streams, size_t n_per_stream,
+                                    int32_t lo, int n_sym, const uint32_t *cdf, uint32_t *words, size_t stride,
+                                    uint32_t *n_words, int32_t *status)
+{
+    for (size_t s = 0; s < n_streams; s++) {
+        orc_enc_t *e = cst_oracle_rc_encoder_new(W, S);
+        status[s] = 0;
+        for (size_t t = 0; t < n_per_stream; t++) {
+            int64_t i = (int64_t)symbols[s * n_per_stream + t] - lo;
+            if (i < 0 || i >= n_sym) { status[s] = 1; break; }
+            cst_oracle_rc_encode_cp(e, cdf[i], cdf[i + 1] - cdf[i], P);
+        }
+        size_t n = cst_oracle_rc_get_compressed(e, NULL);
+        if (status[s] == 0 && n > stride) status[s] = 2;
+        if (status[s] == 0) { cst_oracle_rc_get_compressed(e, words + s * stride); n_words[s] = (uint32_t)n; }
+        else n_words[s] = 0;
+        cst_oracle_rc_encoder_free(e);
+    }
+}
+
+API void cst_oracle_rc_decode_batch(int W, int S, int P, int32_t *decoded, size_t n_streams, size_t n_per_stream, int32_t lo,
+                                    int n_sym, const uint32_t *cdf, const uint32_t *words, size_t stride,
+                                    const uint32_t *n_words, int32_t *status)
+{
+    for (size_t s = 0; s < n_streams; s++) {
+        orc_dec_t *d = cst_oracle_rc_decoder_new(W, S, words + s * stride, n_words[s]);
+        status[s] = 0;
+        for (size_t t = 0; t < n_per_stream; t++) {
+            uint32_t q = cst_oracle_rc_peek_quantile(d, P);
+            if (q == 0xffffffffu) { status[s] = 3; break; }
+            int a = 0, b = n_sym - 1;
+            while (a < b) { int m = a + (b - a + 1) / 2; if (cdf[m] <= q) a = m; else b = m - 1; }
+            decoded[s * n_per_stream + t] = lo + a;
+            cst_oracle_rc_decode_advance(d, cdf[a], cdf[a + 1] - cdf[a], P);
+        }
+        cst_oracle_rc_decoder_free(d);
+    }
+}

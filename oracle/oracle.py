@@ -91,6 +91,8 @@ def load(native: bool = False):
         "cst_oracle_ans_encode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, i, u32p, z, u32p, i32p, i]),
         "cst_oracle_ans_decode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, vp, i, u32p, z, u32p, i32p, i]),
         "cst_oracle_synth_symbols": (None, [u64, z, z, z, i32, i, u32p, i, i, i32p]),
+        "cst_oracle_rc_encode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
+        "cst_oracle_rc_decode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -412,4 +414,32 @@ def ans_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64, looku
     load(native).cst_oracle_ans_decode_batch(W, S, P, out.reshape(-1), n_streams, n_per_stream, lo, n_sym,
                                              cdf.reshape(-1), lut_ptr, int(per_stream), words.reshape(-1), stride,
                                              np.ascontiguousarray(n_words, dtype=np.uint32), status, n_threads)
+    return out, status
+
+
+def range_max_words(n_per_stream, P, W=32, S=64):
+    return min(n_per_stream, (n_per_stream * P + W - 1) // W) + 2
+
+
+def rc_encode_batch(symbols, lo, cdf, P, W=32, S=64, stride=None):
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    n_streams, n = symbols.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    stride = stride or range_max_words(n, P, W, S)
+    words = np.zeros((n_streams, stride), dtype=np.uint32)
+    n_words = np.zeros(n_streams, dtype=np.uint32)
+    status = np.zeros(n_streams, dtype=np.int32)
+    load().cst_oracle_rc_encode_batch(W, S, P, symbols.reshape(-1), n_streams, n, lo, len(cdf) - 1, cdf, words.reshape(-1),
+                                      stride, n_words, status)
+    return words, n_words, status
+
+
+def rc_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64):
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    n_streams, stride = words.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    out = np.zeros((n_streams, n_per_stream), dtype=np.int32)
+    status = np.zeros(n_streams, dtype=np.int32)
+    load().cst_oracle_rc_decode_batch(W, S, P, out.reshape(-1), n_streams, n_per_stream, lo, len(cdf) - 1, cdf,
+                                      words.reshape(-1), stride, np.ascontiguousarray(n_words, dtype=np.uint32), status)
     return out, status

@@ -1,0 +1,105 @@
+"""GPU parity tests for the batched range coder (BASELINE config C4) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 12), (32, 64, 24), (16, 32, 12), (16, 32, 16)], ids=lambda c: "W%dS%dP%d" % c)
+@pytest.mark.parametrize("n_streams,n_per", [(1, 1), (1, 777), (64, 32), (65, 100), (300, 257), (129, 4096), (7, 0)])
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_range_roundtrip_parity(B, O, cfg, n_streams, n_per, layout):
+    W, S, P = cfg
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+    sym = O.synth_symbols(0xC0FFEE, 0, n_streams, n_per, -50, cdf, P)
+    want_words, want_n, want_status = O.rc_encode_batch(sym, -50, cdf, P, W, S)
+    enc = B.range_encode(dev(sym if layout == "stream_major" else sym.T), model, cfg, layout)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist()
+    assert n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    dec, dstatus = B.range_decode(enc, model, n_per, layout)
+    torch.cuda.synchronize()
+    got = dec.cpu().numpy()
+    assert (dstatus.cpu().numpy() == 0).all()
+    assert np.array_equal(got.T if layout == "symbol_major" else got, sym)
+
+
+def test_range_skewed_model_exercises_carry_paths(B, O):
+    """Very skewed tables make long runs of 0xFFFFFFFF / carries far more likely (lazy carry, queue.rs:126-142)."""
+    P = 12
+    cdf = np.array([0, 4093, 4094, 4095, 4096], dtype=np.uint32)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(3)
+    sym = rng.choice(4, size=(512, 3000), p=[0.97, 0.01, 0.01, 0.01]).astype(np.int32)
+    sym[:, :50] = 3  # push `lower` close to the top of the range
+    want_words, want_n, _ = O.rc_encode_batch(sym, 0, cdf, P)
+    enc = B.range_encode(dev(sym), model, (32, 64, P))
+    dec, st = B.range_decode(enc, model, 3000)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(512):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    assert np.array_equal(dec.cpu().numpy(), sym)
+
+
+def test_range_invalid_data(B, O):
+    """Random words decoded with a model whose last quantiles are unreachable give InvalidData
+    exactly where the oracle says (queue.rs:989-993)."""
+    P = 12
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+    rng = np.random.default_rng(8)
+    words = rng.integers(0, 2 ** 32, (200, 40), dtype=np.uint64).astype(np.uint32)
+    n_words = rng.integers(0, 41, 200).astype(np.uint32)
+    want, want_status = O.rc_decode_batch(words, n_words, 64, -50, cdf, P)
+    enc = B.EncodedBatch(dev(words.view(np.int32)), dev(n_words.view(np.int32)), torch.zeros(200, dtype=torch.int32, device="cuda"), (32, 64, P))
+    got, status = B.range_decode(enc, model, 64)
+    torch.cuda.synchronize()
+    assert status.cpu().numpy().tolist() == want_status.tolist()
+    ok = want_status == 0
+    assert np.array_equal(got.cpu().numpy()[ok], want[ok])
+
+
+def test_range_full_size_c4(B, O):
+    """Config C4 at full size: 65 536 x 4096 round trip + sampled bit-exactness."""
+    P, n_streams, n_per = 12, 65536, 4096
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+    base = O.synth_symbols(0xC0FFEE, 0, 256, n_per, -50, cdf, P)
+    dsym = dev(base).repeat(n_streams // 256, 1)
+    shift = torch.arange(n_streams, device="cuda") // 256
+    idx = (torch.arange(n_per, device="cuda")[None, :] + 7 * shift[:, None]) % n_per
+    dsym = torch.gather(dsym, 1, idx).contiguous()
+    enc = B.range_encode(dsym, model, (32, 64, P))
+    dec, status = B.range_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
+    assert torch.equal(dec, dsym)
+    sample = [0, 255, 256, 40000, 65535]
+    want_words, want_n, _ = O.rc_encode_batch(dsym[sample].cpu().numpy(), -50, cdf, P)
+    for k, s in enumerate(sample):
+        assert enc.stream(s).tolist() == want_words[k, : want_n[k]].tolist()
