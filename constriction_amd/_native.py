@@ -37,6 +37,12 @@ class BackendError(RuntimeError):
     pass
 
 
+class RangeState(C.Structure):
+    """cst_range_state"""
+    _fields_ = [("lower", C.c_uint64), ("range", C.c_uint64), ("point", C.c_uint64), ("inverted_n", C.c_uint32),
+                ("inverted_first", C.c_uint32), ("position", C.c_uint64)]
+
+
 class CoderConfig(C.Structure):
     _fields_ = [("word_bits", C.c_int32), ("state_bits", C.c_int32), ("precision", C.c_int32)]
 
@@ -64,8 +70,14 @@ SIGNATURES = {
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, C.POINTER(C.c_uint64), _vp]),
     "cst_ans_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
-    "cst_range_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp]),
-    "cst_range_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp]),
+    "cst_ans_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_range_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_range_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_range_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
     "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_gaussian_lcp": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _z, _vp]),
 }

@@ -216,8 +216,8 @@ def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layou
                            torch.empty(n_streams, dtype=torch.int32, device=dev),
                            torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
     N.check(N.lib().cst_range_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
-                                           out.words.shape[1], _ptr(out.n_words), _ptr(out.status), _stream_ptr()),
-            "cst_range_encode_batch")
+                                           out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
+                                           _stream_ptr()), "cst_range_encode_batch")
     return out
 
 
@@ -239,6 +239,6 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
     N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
-                                           _ptr(out), n_streams, n_per_stream, lay, _ptr(status), _stream_ptr()),
-            "cst_range_decode_batch")
+                                           _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
+                                           _stream_ptr()), "cst_range_decode_batch")
     return out, status

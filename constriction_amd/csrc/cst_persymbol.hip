@@ -1,0 +1,495 @@
+// cst_persymbol.hip -- coders driven by PER-SYMBOL entropy models (SURVEY.md 8f-1 and the single-coder drop-in).
+//
+//   * per-symbol quantized Gaussians: the reference's flagship call
+//       coder.encode_reverse(symbols, QuantizedGaussian(lo, hi), means, stds) / coder.decode(family, means, stds)
+//     (src/pybindings/stream/stack.rs:567-588, 733-751): every symbol gets its own
+//     LeakilyQuantizedDistribution (src/stream/model/quantize.rs:525-568), i.e. two bit-exact f64 erf on device
+//     per encoded symbol and a search over left cumulatives per decoded symbol;
+//   * explicit per-symbol models: (left, prob) pairs for encoding and cdf rows for decoding.
+//
+// Encoding is two passes: a fully parallel pass turns every symbol into a coder entry (c, p, 2^64/p), then one
+// LANE per stream runs the sequential recurrence over those entries.  Gaussian decoding uses one WAVE per stream:
+// 64 lanes evaluate 64 candidate left cumulatives at once (two erf rounds for a 201-symbol support).
+#include "cst_range_kernels.hpp"
+#include "cst_math.hpp"
+
+namespace cst {
+
+enum CoderKind : int { kAns = 0, kRange = 1 };
+
+__device__ __forceinline__ EncEntry make_entry(uint32_t c, uint32_t p) {
+    uint64_t m = 0;
+    if (p == 1) m = ~0ull;
+    else if (p > 1) {                      // floor(2^64 / p) without 128-bit arithmetic
+        const uint64_t q = (~0ull) / p;    // floor((2^64 - 1) / p)
+        const uint64_t r = (~0ull) - q * p;
+        m = q + ((r + 1 == p) ? 1 : 0);
+    }
+    return EncEntry{c, p, (uint32_t)m, (uint32_t)(m >> 32)};
+}
+
+__global__ void cp_entries_kernel(const uint32_t* __restrict__ left, const uint32_t* __restrict__ prob, size_t n, int P,
+                                  EncEntry* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = left[i], p = prob[i];
+    if ((uint64_t)c + p > ((uint64_t)1 << P)) p = 0;   // not a sub-interval of [0, 2^P): treat as impossible
+    out[i] = make_entry(c, p);
+}
+
+__global__ void gaussian_entries_kernel(int P, int32_t lo, int32_t hi, const int32_t* __restrict__ sym,
+                                        const double* __restrict__ mu, const double* __restrict__ sd, size_t n,
+                                        EncEntry* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = 0, p = 0;
+    const double m = mu[i], s = sd[i];
+    // `assert!(std > 0.0)` and finite parameters (pybindings/stream/model.rs:654-657); out-of-support symbols
+    // (quantize.rs:537-539) and degenerate distributions (quantize.rs:562-565) all end up with p = 0 = impossible
+    if (s > 0.0 && s <= 1.7976931348623157e308 && m == m && m <= 1.7976931348623157e308 && m >= -1.7976931348623157e308) {
+        if (!leaky_gaussian_lcp(sym[i], lo, hi, P, 32, m, s, c, p)) p = 0;
+    }
+    out[i] = make_entry(c, p);
+}
+
+struct EntriesEncodeArgs {
+    const EncEntry* entries;
+    size_t n_streams, n_per_stream;
+    int32_t layout, precision;
+    uint32_t* words;
+    size_t stride_words;
+    uint32_t* n_words;
+    uint64_t* state;            // ANS raw state
+    cst_range_state* rstate;    // range raw state
+    int32_t* status;
+    uint32_t flags;
+};
+
+// one lane per stream over precomputed entries; ANS walks backwards, the range coder forwards
+template <int W, int S, int KIND>
+__global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const int G4 = 4 * groups_per_point(W, P);
+    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    const EncEntry* my = a.entries + (active ? (a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N) : 0);
+    uint32_t* slab = a.words + (active ? s : 0) * a.stride_words;
+    const uint32_t cap = active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u;
+    uint32_t bad = 0, n_words = 0;
+    int32_t status;
+    int countdown = G4;
+
+    if constexpr (KIND == kAns) {
+        EncLane<W, S> L;
+        L.init(slab, cap, ring, lane);
+        if (raw && active) L.state = (typename StateT<S>::type)a.state[s];
+        for (size_t t = N; t-- > 0;) {
+            if (active) {
+                const EncEntry e = my[t * stride_t];
+                if (e.p == 0) bad = 1;
+                else if (!bad) L.template step<false>(e, P);
+            }
+            if (--countdown == 0) { countdown = G4; L.flush_chunks(); }
+        }
+        status = L.finish(!raw, 1u, n_words);
+        if (active && raw) a.state[s] = (uint64_t)L.state;
+    } else {
+        RangeEncLane<W, S> L;
+        L.init(slab, cap, ring, lane);
+        if (raw && active) {
+            const cst_range_state r = a.rstate[s];
+            L.lower = (typename StateT<S>::type)r.lower; L.range = (typename StateT<S>::type)r.range;
+            L.inv_n = r.inverted_n; L.inv_first = r.inverted_first;
+        }
+        for (size_t t = 0; t < N; ++t) {
+            if (active) {
+                const EncEntry e = my[t * stride_t];
+                if (e.p == 0) bad = 1;
+                else if (!bad) L.step(e.c, e.p, P);
+            }
+            if (--countdown == 0) { countdown = G4; L.out.flush_chunks(); }
+        }
+        if (raw) {
+            L.out.drain();
+            n_words = L.out.wr;
+            status = L.out.wr > L.out.cap ? CST_STREAM_CAPACITY : CST_STREAM_OK;
+            if (active) {
+                cst_range_state r = a.rstate[s];
+                r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.inverted_n = L.inv_n; r.inverted_first = L.inv_first;
+                a.rstate[s] = r;
+            }
+        } else {
+            status = L.finish(1u, n_words);
+        }
+    }
+    if (!active) return;
+    if (bad) status = CST_STREAM_IMPOSSIBLE_SYMBOL;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoding with per-symbol models
+// ------------------------------------------------------------------------------------------------
+
+struct PerSymbolDecodeArgs {
+    const uint32_t* words;
+    const uint64_t* offsets;
+    size_t stride_words;
+    const uint32_t* n_words;
+    int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    int32_t layout, precision;
+    int32_t min_symbol, n_symbols;
+    const double* means;        // Gaussian
+    const double* stds;
+    const uint32_t* cdf_rows;   // explicit rows
+    uint64_t* state;            // ANS raw
+    uint32_t* n_words_out;
+    cst_range_state* rstate;    // range raw
+    int32_t* status;
+    uint32_t flags;
+};
+
+// Uniform (per-wave or per-lane) coder front end reading words straight from HBM.
+template <int W, int S, int KIND> struct DirectDecoder;
+
+template <int W, int S>
+struct DirectDecoder<W, S, kAns> {
+    using st_t = typename StateT<S>::type;
+    st_t state; uint32_t rd; const uint32_t* in; int32_t status;
+    __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
+        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        rd = a.n_words[s]; status = CST_STREAM_OK; state = 0;
+        if (raw) { state = (st_t)a.state[s]; return; }
+        if (rd == 0) return;                                  // read_initial_state, stack.rs:440-462
+        const uint32_t first = in[--rd];
+        if (first == 0) { status = CST_STREAM_INVALID_DATA; rd = 0; return; }
+        st_t st = first;
+        while (rd > 0) { st = (st_t)((st << (W % S)) | (st_t)in[--rd]); if (st >= ((st_t)1 << (S - W))) break; }
+        state = st;
+    }
+    __device__ __forceinline__ uint32_t quantile(int P) { return (uint32_t)state & ((1u << P) - 1u); }
+    __device__ __forceinline__ void advance(uint32_t q, uint32_t c, uint32_t p, int P) {      // stack.rs:1086-1097
+        st_t st = (st_t)((st_t)(state >> P) * (st_t)p + (st_t)(q - c));
+        if (st < ((st_t)1 << (S - W)) && rd > 0) st = (st_t)((st << (W % S)) | (st_t)in[--rd]);
+        state = st;
+    }
+    __device__ __forceinline__ void finish(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
+        if (raw) { a.state[s] = (uint64_t)state; if (a.n_words_out) a.n_words_out[s] = rd; }
+    }
+};
+
+template <int W, int S>
+struct DirectDecoder<W, S, kRange> {
+    using st_t = typename StateT<S>::type;
+    RangeDecLane<W, S> L; uint32_t pos, len; const uint32_t* in; int32_t status;
+    __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
+        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        len = a.n_words[s]; pos = 0; L.status = CST_STREAM_OK;
+        L.lower = 0; L.range = (st_t)~(st_t)0;
+        if (raw) {
+            const cst_range_state r = a.rstate[s];
+            L.lower = (st_t)r.lower; L.range = (st_t)r.range; L.point = (st_t)r.point; pos = (uint32_t)r.position;
+        } else {                                              // read_point, queue.rs:847-868
+            st_t pt = 0; int num_read = 0;
+            while (pos < len) { pt = (st_t)((pt << (W % S)) | (st_t)in[pos++]); if (++num_read == S / W) break; }
+            if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
+            L.point = pt;
+        }
+        status = CST_STREAM_OK;
+    }
+    __device__ __forceinline__ uint32_t quantile(int P) { const uint32_t q = L.peek_quantile(P); status = L.status; return q; }
+    __device__ __forceinline__ void advance(uint32_t, uint32_t c, uint32_t p, int P) {
+        const bool have = pos < len;
+        pos += L.advance(c, p, P, have ? in[pos] : 0u, have) ? 1u : 0u;
+    }
+    __device__ __forceinline__ void finish(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
+        if (raw) {
+            cst_range_state r = a.rstate[s];
+            r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.point = (uint64_t)L.point; r.position = pos;
+            a.rstate[s] = r;
+        }
+    }
+};
+
+// Gaussian: one WAVE per stream.  Every lane carries the same coder state; the search for
+// quantile_function (semantics of quantize.rs:580-779: the unique symbol with left(sym) <= q < left(sym+1))
+// evaluates up to 64 candidate left cumulatives per round.
+template <int W, int S, int KIND>
+__global__ __launch_bounds__(kBlock) void decode_gaussian_wave_kernel(const PerSymbolDecodeArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s >= a.n_streams) return;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t n = (uint32_t)a.n_symbols;
+    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    const size_t e0 = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N;
+
+    DirectDecoder<W, S, KIND> D;
+    D.init(a, s, raw);
+    int32_t status = D.status;
+    for (size_t t = 0; t < N && status == CST_STREAM_OK; ++t) {
+        const double mu = a.means[e0 + t * stride_t], sd = a.stds[e0 + t * stride_t];
+        if (!(sd > 0.0 && sd <= 1.7976931348623157e308 && mu == mu && mu <= 1.7976931348623157e308 && mu >= -1.7976931348623157e308)) {
+            status = CST_STREAM_IMPOSSIBLE_SYMBOL;   // the reference panics on an invalid model (model.rs:654-657)
+            break;
+        }
+        const uint32_t q = D.quantile(P);
+        if (D.status != CST_STREAM_OK) { status = D.status; break; }
+        uint32_t base = 0, count = n;                 // invariant: left(base) <= q
+        while (count > 63) {
+            const uint32_t stride = (count + 63) / 64;
+            const uint32_t off = (uint32_t)lane * stride;
+            const bool valid = off < count;
+            const uint32_t val = valid ? leaky_gaussian_left((int32_t)(base + off), a.min_symbol, (int32_t)n, P, 32, mu, sd) : 0u;
+            const unsigned long long m = __ballot(valid && val <= q);
+            const uint32_t k = (uint32_t)__popcll(m);   // >= 1: lane 0 always qualifies
+            const uint32_t adv = (k - 1) * stride;
+            base += adv;
+            count = min(stride, count - adv);
+        }
+        const uint32_t val = ((uint32_t)lane <= count) ? leaky_gaussian_left((int32_t)(base + lane), a.min_symbol, (int32_t)n, P, 32, mu, sd) : 0u;
+        const unsigned long long m = __ballot((uint32_t)lane < count && val <= q);
+        const uint32_t k = (uint32_t)__popcll(m);
+        const uint32_t c = __shfl(val, (int)(k - 1), 64), nxt = __shfl(val, (int)k, 64);
+        const uint32_t p = nxt - c;
+        if (p == 0 || k == 0) { status = CST_STREAM_IMPOSSIBLE_SYMBOL; break; }   // degenerate distribution
+        if (lane == 0) a.symbols[e0 + t * stride_t] = a.min_symbol + (int32_t)(base + k - 1);
+        D.advance(q, c, p, P);
+    }
+    if (lane == 0) {
+        a.status[s] = status;
+        D.finish(a, s, raw);
+    }
+}
+
+// explicit cdf rows: one LANE per stream, bisection in the symbol's own row
+template <int W, int S, int KIND>
+__global__ __launch_bounds__(kBlock) void decode_rows_kernel(const PerSymbolDecodeArgs a) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_streams) return;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t n = (uint32_t)a.n_symbols;
+    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    const size_t e0 = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N;
+    DirectDecoder<W, S, KIND> D;
+    D.init(a, s, raw);
+    int32_t status = D.status;
+    for (size_t t = 0; t < N && status == CST_STREAM_OK; ++t) {
+        const size_t e = e0 + t * stride_t;
+        const uint32_t* row = a.cdf_rows + e * ((size_t)n + 1);
+        const uint32_t q = D.quantile(P);
+        if (D.status != CST_STREAM_OK) { status = D.status; break; }
+        uint32_t lo = 0, hi = n - 1;                 // largest i with row[i] <= q
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo + 1) / 2;
+            if (row[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t c = row[lo], p = row[lo + 1] - c;
+        if (p == 0 || c > q) { status = CST_STREAM_INVALID_DATA; break; }
+        a.symbols[e] = a.min_symbol + (int32_t)lo;
+        D.advance(q, c, p, P);
+    }
+    a.status[s] = status;
+    D.finish(a, s, raw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+static cst_status check_common(cst_coder_config cfg, cst_layout layout) {
+    if (!config_supported(cfg)) return CST_ERR_INVALID_ARGUMENT;
+    if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
+    return CST_OK;
+}
+
+template <int KIND>
+static cst_status launch_encode_entries(cst_coder_config cfg, const EntriesEncodeArgs& a, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    const size_t lds = (size_t)(kBlock / kWave) * kRingWords * sizeof(uint32_t);
+    if (cfg.word_bits == 32) hipLaunchKernelGGL((encode_entries_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    else hipLaunchKernelGGL((encode_entries_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+// pass 1 (entries) + pass 2 (sequential coder); `fill` launches the entry kernel into the temporary buffer
+template <int KIND, typename Fill>
+static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                  uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
+                                  cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, hipStream_t hs, Fill fill) {
+    if (cst_status st = check_common(cfg, layout)) return st;
+    if (!d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && (KIND == kAns ? (void*)d_state : (void*)d_rstate) == nullptr) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    const size_t n = n_streams * n_per_stream;
+    EncEntry* entries = nullptr;
+    if (n > 0) {
+        CST_HIP_TRY(hipMallocAsync((void**)&entries, n * sizeof(EncEntry), hs));
+        fill(entries, n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_hip_error(e, "entry kernel"); (void)hipFreeAsync(entries, hs); return CST_ERR_HIP; }
+    }
+    EntriesEncodeArgs a{};
+    a.entries = entries; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
+    a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.rstate = d_rstate;
+    a.status = d_status; a.flags = flags;
+    const cst_status st = launch_encode_entries<KIND>(cfg, a, hs);
+    if (entries) CST_HIP_TRY(hipFreeAsync(entries, hs));
+    return st;
+}
+
+template <int KIND>
+static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
+    if (a.n_streams == 0) return CST_OK;
+    if (gaussian) {
+        const size_t blocks = (a.n_streams * kWave + kBlock - 1) / kBlock;
+        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_wave_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        else hipLaunchKernelGGL((decode_gaussian_wave_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+    } else {
+        const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_rows_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        else hipLaunchKernelGGL((decode_rows_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+    }
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+static cst_status fill_decode_args(PerSymbolDecodeArgs& a, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                   size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                                   size_t n_per_stream, cst_layout layout, int32_t min_symbol, int64_t n_symbols, int32_t* d_status,
+                                   uint32_t flags) {
+    if (cst_status st = check_common(cfg, layout)) return st;
+    if (!d_n_words || !d_status || (n_per_stream > 0 && !d_symbols)) return CST_ERR_INVALID_ARGUMENT;
+    if (n_symbols < 2 || n_symbols > ((int64_t)1 << cfg.precision) || n_symbols > 65536) return CST_ERR_MODEL;
+    a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
+    a.min_symbol = min_symbol; a.n_symbols = (int32_t)n_symbols; a.status = d_status; a.flags = flags;
+    return CST_OK;
+}
+
+} // namespace cst
+
+using namespace cst;
+
+extern "C" {
+
+cst_status cst_ans_encode_cp_batch(cst_coder_config cfg, const uint32_t* d_left, const uint32_t* d_prob, size_t n_streams,
+                                   size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
+                                   uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags, void* stream) {
+    if (n_per_stream > 0 && (!d_left || !d_prob)) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    return encode_two_pass<kAns>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, nullptr,
+                                 d_status, flags, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(cp_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, d_left, d_prob, n, cfg.precision, out);
+    });
+}
+
+cst_status cst_range_encode_cp_batch(cst_coder_config cfg, const uint32_t* d_left, const uint32_t* d_prob, size_t n_streams,
+                                     size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
+                                     uint32_t* d_n_words, cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
+    if (n_per_stream > 0 && (!d_left || !d_prob)) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    return encode_two_pass<kRange>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, nullptr, d_rstate,
+                                   d_status, flags, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(cp_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, d_left, d_prob, n, cfg.precision, out);
+    });
+}
+
+cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                         const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream,
+                                         cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                         uint64_t* d_state, int32_t* d_status, uint32_t flags, void* stream) {
+    if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
+    hipStream_t hs = (hipStream_t)stream;
+    return encode_two_pass<kAns>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, nullptr,
+                                 d_status, flags, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
+                           max_symbol, d_symbols, d_means, d_stds, n, out);
+    });
+}
+
+cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                           const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                           cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
+    if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
+    hipStream_t hs = (hipStream_t)stream;
+    return encode_two_pass<kRange>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, nullptr, d_rstate,
+                                   d_status, flags, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
+                           max_symbol, d_symbols, d_means, d_stds, n, out);
+    });
+}
+
+cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
+                                         const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                         const double* d_means, const double* d_stds, int32_t* d_symbols, size_t n_streams,
+                                         size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
+                                         int32_t* d_status, uint32_t flags, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (max_symbol <= min_symbol) return CST_ERR_MODEL;
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+                                         min_symbol, (int64_t)max_symbol - min_symbol + 1, d_status, flags)) return st;
+    if (n_per_stream > 0 && (!d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
+    a.means = d_means; a.stds = d_stds; a.state = d_state; a.n_words_out = d_n_words_out;
+    return decode_per_symbol<kAns>(cfg, a, true, (hipStream_t)stream);
+}
+
+cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
+                                           const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                           const double* d_means, const double* d_stds, int32_t* d_symbols, size_t n_streams,
+                                           size_t n_per_stream, cst_layout layout, cst_range_state* d_rstate, int32_t* d_status,
+                                           uint32_t flags, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (max_symbol <= min_symbol) return CST_ERR_MODEL;
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+                                         min_symbol, (int64_t)max_symbol - min_symbol + 1, d_status, flags)) return st;
+    if (n_per_stream > 0 && (!d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
+    a.means = d_means; a.stds = d_stds; a.rstate = d_rstate;
+    return decode_per_symbol<kRange>(cfg, a, true, (hipStream_t)stream);
+}
+
+cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                                     const uint32_t* d_n_words, const uint32_t* d_cdf_rows, int32_t n_symbols, int32_t min_symbol,
+                                     int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout, uint64_t* d_state,
+                                     uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+                                         min_symbol, n_symbols, d_status, flags)) return st;
+    if (n_per_stream > 0 && !d_cdf_rows) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
+    a.cdf_rows = d_cdf_rows; a.state = d_state; a.n_words_out = d_n_words_out;
+    return decode_per_symbol<kAns>(cfg, a, false, (hipStream_t)stream);
+}
+
+cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                                       const uint32_t* d_n_words, const uint32_t* d_cdf_rows, int32_t n_symbols, int32_t min_symbol,
+                                       int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                       cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+                                         min_symbol, n_symbols, d_status, flags)) return st;
+    if (n_per_stream > 0 && !d_cdf_rows) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
+    a.cdf_rows = d_cdf_rows; a.rstate = d_rstate;
+    return decode_per_symbol<kRange>(cfg, a, false, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -1,142 +1,8 @@
-// cst_range.hip -- batched range coder (BASELINE config C4): one RangeEncoder / RangeDecoder per lane.
-//
-// Recurrences: RangeEncoder::encode_symbol (src/stream/queue.rs:612-705) with its lazy carry
-// (EncoderSituation::Inverted, queue.rs:126-142), seal_words (queue.rs:482-523), RangeDecoder::read_point
-// (queue.rs:847-868) and decode_symbol (queue.rs:968-1033).  Same data movement as the ANS kernels
-// (cst_ans_kernels.hpp): tables in LDS, LDS-tiled symbol matrix, per-lane LDS word rings; words are
-// written and read front to back (a queue).
-#include "cst_ans_kernels.hpp"
+// cst_range.hip -- batched range coder with a shared table (BASELINE config C4): kernels, launch, C ABI.
+// The per-lane state machines live in cst_range_kernels.hpp.
+#include "cst_range_kernels.hpp"
 
 namespace cst {
-
-// Forward-reading counterpart of RingReader (queue semantics).
-struct RingReaderFwd {
-    uint32_t pos;          // next stream index to read
-    uint32_t len;          // words in the stream
-    uint32_t shift;
-    uint32_t hi_issued;    // positions < hi_issued (multiple of 4) have been requested
-    const uint32_t* base16;
-    uint32_t* ring;
-    int lane;
-    uint4 pend[kMaxChunksPerPoint];
-    int32_t pend_pos[kMaxChunksPerPoint];
-
-    __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (kRingSlots - 1)) * kWave + lane); }
-
-    __device__ __forceinline__ void init(const uint32_t* in, uint32_t n, uint32_t* wave_ring, int lane_) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
-        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
-        shift = (uint32_t)((addr & 15) >> 2);
-        ring = wave_ring; lane = lane_; pos = 0; len = n;
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
-    }
-
-    __device__ __forceinline__ void prime() {
-        hi_issued = shift & ~3u;
-        const uint32_t end = len + shift;
-        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
-        while (hi_issued < want_hi) {
-            const uint4 v = *reinterpret_cast<const uint4*>(base16 + hi_issued);
-            *slot(hi_issued + 0) = v.x; *slot(hi_issued + 1) = v.y; *slot(hi_issued + 2) = v.z; *slot(hi_issued + 3) = v.w;
-            hi_issued += 4;
-        }
-    }
-
-    __device__ __forceinline__ void advance_window() {
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
-            if (pend_pos[k] >= 0) {
-                const uint32_t p = (uint32_t)pend_pos[k];
-                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
-            }
-        }
-        const uint32_t end = len + shift;
-        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
-#pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
-            if (hi_issued < want_hi) {
-                pend_pos[k] = (int32_t)hi_issued;
-                pend[k] = *reinterpret_cast<const uint4*>(base16 + hi_issued);
-                hi_issued += 4;
-            } else {
-                pend_pos[k] = -1;
-            }
-        }
-    }
-
-    // next word if any (ring must cover it); does not advance
-    __device__ __forceinline__ uint32_t peek() const { return *slot(pos + shift); }
-    __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
-};
-
-template <int W, int S>
-struct RangeEncLane {
-    using st_t = typename StateT<S>::type;
-    st_t lower, range;
-    uint32_t inv_n, inv_first;   // EncoderSituation: inv_n == 0 <=> Normal
-    uint32_t bad;
-    RingWriter out;
-
-    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
-        out.init(slab, capacity, wave_ring, lane_);
-        lower = 0; range = (st_t)~(st_t)0;   // RangeCoderState::default, queue.rs:96-104
-        inv_n = 0; inv_first = 0; bad = 0;
-    }
-
-    // queue.rs:612-705
-    __device__ __forceinline__ void step(uint32_t c, uint32_t p, int P) {
-        const st_t scale = (st_t)(range >> P);
-        const st_t new_range = (st_t)(scale * (st_t)p);
-        const st_t new_lower = (st_t)(lower + scale * (st_t)c);
-        if (__builtin_expect(inv_n != 0, 0)) {
-            if ((st_t)(new_lower + new_range) > new_lower) {   // inverted -> normal
-                uint32_t first, cons;
-                if (new_lower < lower) { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
-                else { first = inv_first; cons = word_mask<W>(); }
-                out.push_slow(first);
-                for (uint32_t i = 1; i < inv_n; ++i) out.push_slow(cons);
-                inv_n = 0;
-            }
-        }
-        lower = new_lower; range = new_range;
-        const bool renorm = range < ((st_t)1 << (S - W));
-        const uint32_t lower_word = (uint32_t)(lower >> (S - W)) & word_mask<W>();
-        const st_t sh_lower = (st_t)(lower << (W % S)), sh_range = (st_t)(range << (W % S));
-        const bool no_wrap = (st_t)(sh_lower + sh_range) > sh_lower;
-        // common case: Normal -> Normal (emit lower_word) -- branch free through the ring
-        out.push(lower_word, (renorm && inv_n == 0 && no_wrap) ? 1u : 0u);
-        if (__builtin_expect(renorm && (inv_n != 0 || !no_wrap), 0)) {
-            if (inv_n != 0) inv_n += 1;                    // inverted -> inverted
-            else { inv_n = 1; inv_first = lower_word; }    // normal -> inverted
-        }
-        lower = renorm ? sh_lower : lower;
-        range = renorm ? sh_range : range;
-    }
-
-    // seal_words / iter_seal (queue.rs:458-523)
-    __device__ __forceinline__ int32_t finish(uint32_t n_symbols, uint32_t& n_words_out) {
-        out.drain();
-        if (range != (st_t)~(st_t)0) {
-            const st_t point = (st_t)(lower + (((st_t)1 << (S - W)) - 1));
-            if (inv_n != 0) {
-                uint32_t first, cons;
-                if (point >= lower) { first = inv_first; cons = word_mask<W>(); }
-                else { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
-                out.append_direct(first);
-                for (uint32_t i = 1; i < inv_n; ++i) out.append_direct(cons);
-            }
-            const uint32_t point_word = (uint32_t)(point >> (S - W)) & word_mask<W>();
-            const uint32_t upper_word = (uint32_t)((st_t)(lower + range) >> (S - W)) & word_mask<W>();
-            out.append_direct(point_word);
-            if (upper_word == point_word) out.append_direct(0u);
-        }
-        n_words_out = out.wr;
-        if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;
-        if (out.wr > out.cap) return CST_STREAM_CAPACITY;
-        return CST_STREAM_OK;
-    }
-};
 
 struct RangeEncodeArgs {
     const int32_t* symbols;
@@ -147,6 +13,8 @@ struct RangeEncodeArgs {
     size_t stride_words;
     uint32_t* n_words;
     int32_t* status;
+    cst_range_state* rstate;
+    uint32_t flags;
 };
 
 template <int W, int S, int LAYOUT, bool VEC, int G>
@@ -174,6 +42,12 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
     RangeEncLane<W, S> L;
     L.init(a.words + (active ? s : 0) * a.stride_words,
            active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    if (raw && active) {
+        const cst_range_state r = a.rstate[s];
+        L.lower = (typename StateT<S>::type)r.lower; L.range = (typename StateT<S>::type)r.range;
+        L.inv_n = r.inverted_n; L.inv_first = r.inverted_first;
+    }
 
     auto code = [&](int32_t v) {
         const EncEntry e = table[enc_index(v, a.min_symbol, nsym, L.bad)];
@@ -214,8 +88,20 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
     }
 
     uint32_t n_words = 0;
-    const int32_t status = L.finish(nsym, n_words);
+    int32_t status;
+    if (raw) {
+        L.out.drain();
+        n_words = L.out.wr;
+        status = L.bad >= nsym ? CST_STREAM_IMPOSSIBLE_SYMBOL : (L.out.wr > L.out.cap ? CST_STREAM_CAPACITY : CST_STREAM_OK);
+    } else {
+        status = L.finish(nsym, n_words);
+    }
     if (!active) return;
+    if (raw) {
+        cst_range_state r = a.rstate[s];
+        r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.inverted_n = L.inv_n; r.inverted_first = L.inv_first;
+        a.rstate[s] = r;
+    }
     a.status[s] = status;
     a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
 }
@@ -236,58 +122,8 @@ struct RangeDecodeArgs {
     int32_t bucket_bits;
     int32_t n_symbols, min_symbol, precision;
     int32_t* status;
-};
-
-template <int W, int S>
-struct RangeDecLane {
-    using st_t = typename StateT<S>::type;
-    st_t lower, range, point;
-    int32_t status;
-    RingReaderFwd in;
-
-    // from_compressed + read_point (queue.rs:776-790, 847-868)
-    __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
-        in.init(words, len, wave_ring, lane_);
-        lower = 0; range = (st_t)~(st_t)0; status = CST_STREAM_OK;
-        st_t pt = 0;
-        int num_read = 0;
-        while (in.pos < in.len) {
-            pt = (st_t)((pt << (W % S)) | (st_t)in.word_direct(in.pos++));
-            if (++num_read == S / W) break;
-        }
-        if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
-        point = pt;
-    }
-
-    // queue.rs:968-1033; returns the symbol index (0 after an InvalidData error)
-    template <int MODE>
-    __device__ __forceinline__ uint32_t step(const void* lut, const uint32_t* cdf, const uint16_t* bucket, int bucket_shift,
-                                             int n_symbols, int P) {
-        const st_t scale = (st_t)(range >> P);
-        const st_t x = (st_t)(point - lower);
-        // quantile = x / scale is < 2^(P+1): estimate in f64, then make it exact
-        uint32_t q = (uint32_t)((double)x / (double)scale);
-        st_t prod = (st_t)((st_t)q * scale);
-        if (prod > x) { --q; prod -= scale; }
-        else if ((st_t)(x - prod) >= scale) { ++q; prod += scale; }
-        const uint32_t next_word = in.peek();
-        if (q >= (1u << P)) {                      // DecoderFrontendError::InvalidData, queue.rs:989-993
-            if (status == CST_STREAM_OK) status = CST_STREAM_INVALID_DATA;
-            q = (1u << P) - 1u;                    // keep the lane on legal table indices; its output is unspecified
-        }
-        uint32_t idx, c, p;
-        lookup_quantile<MODE>(q, lut, cdf, bucket, bucket_shift, n_symbols, idx, c, p);
-        lower = (st_t)(lower + scale * (st_t)c);
-        range = (st_t)(scale * (st_t)p);
-        const bool renorm = range < ((st_t)1 << (S - W));
-        const bool have = in.pos < in.len;
-        const st_t sh_point = (st_t)((st_t)(point << (W % S)) | (st_t)(have ? next_word : 0u));
-        lower = renorm ? (st_t)(lower << (W % S)) : lower;
-        range = renorm ? (st_t)(range << (W % S)) : range;
-        point = renorm ? sh_point : point;
-        in.pos += (renorm && have) ? 1u : 0u;
-        return idx;
-    }
+    cst_range_state* rstate;
+    uint32_t flags;
 };
 
 template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G>
@@ -317,6 +153,12 @@ __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeA
 
     RangeDecLane<W, S> L;
     L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    if (raw && active) {
+        const cst_range_state r = a.rstate[s];
+        L.lower = (typename StateT<S>::type)r.lower; L.range = (typename StateT<S>::type)r.range;
+        L.point = (typename StateT<S>::type)r.point; L.in.pos = (uint32_t)r.position;
+    }
     L.in.prime();
     wave_lds_fence();
 
@@ -353,7 +195,13 @@ __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeA
             L.in.advance_window();
         }
     }
-    if (active) a.status[s] = L.status;
+    if (!active) return;
+    a.status[s] = L.status;
+    if (raw) {
+        cst_range_state r = a.rstate[s];
+        r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.point = (uint64_t)L.point; r.position = L.in.pos;
+        a.rstate[s] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,8 +281,9 @@ extern "C" {
 
 cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
                                   size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
-                                  uint32_t* d_n_words, int32_t* d_status, void* stream) {
+                                  uint32_t* d_n_words, cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
@@ -444,6 +293,7 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
+    a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
     if (cfg.word_bits == 32) return range_encode_ws<32, 64>(a, layout, hs);
     return range_encode_ws<16, 32>(a, layout, hs);
@@ -452,8 +302,9 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
 cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
                                   const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
                                   int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
-                                  int32_t* d_status, void* stream) {
+                                  cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
@@ -464,6 +315,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec32 = model->d_dec32; a.dec64 = model->d_dec64;
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
+    a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
     if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
     return range_decode_ws<16, 32>(a, layout, hs);

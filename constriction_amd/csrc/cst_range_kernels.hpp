@@ -1,0 +1,206 @@
+// cst_range_kernels.hpp -- per-lane range coder state machines (shared by cst_range.hip and cst_persymbol.hip).
+//
+// Recurrences: RangeEncoder::encode_symbol (src/stream/queue.rs:612-705) with its lazy carry
+// (EncoderSituation::Inverted, queue.rs:126-142), seal_words (queue.rs:482-523), RangeDecoder::read_point
+// (queue.rs:847-868) and decode_symbol (queue.rs:968-1033).  Same data movement as the ANS kernels
+// (cst_ans_kernels.hpp): tables in LDS, LDS-tiled symbol matrix, per-lane LDS word rings; words are
+// written and read front to back (a queue).
+#pragma once
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+// Forward-reading counterpart of RingReader (queue semantics).
+struct RingReaderFwd {
+    uint32_t pos;          // next stream index to read
+    uint32_t len;          // words in the stream
+    uint32_t shift;
+    uint32_t hi_issued;    // positions < hi_issued (multiple of 4) have been requested
+    const uint32_t* base16;
+    uint32_t* ring;
+    int lane;
+    uint4 pend[kMaxChunksPerPoint];
+    int32_t pend_pos[kMaxChunksPerPoint];
+
+    __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (kRingSlots - 1)) * kWave + lane); }
+
+    __device__ __forceinline__ void init(const uint32_t* in, uint32_t n, uint32_t* wave_ring, int lane_) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
+        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
+        shift = (uint32_t)((addr & 15) >> 2);
+        ring = wave_ring; lane = lane_; pos = 0; len = n;
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+    }
+
+    __device__ __forceinline__ void prime() {
+        hi_issued = shift & ~3u;
+        const uint32_t end = len + shift;
+        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+        while (hi_issued < want_hi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + hi_issued);
+            *slot(hi_issued + 0) = v.x; *slot(hi_issued + 1) = v.y; *slot(hi_issued + 2) = v.z; *slot(hi_issued + 3) = v.w;
+            hi_issued += 4;
+        }
+    }
+
+    __device__ __forceinline__ void advance_window() {
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (pend_pos[k] >= 0) {
+                const uint32_t p = (uint32_t)pend_pos[k];
+                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
+            }
+        }
+        const uint32_t end = len + shift;
+        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (hi_issued < want_hi) {
+                pend_pos[k] = (int32_t)hi_issued;
+                pend[k] = *reinterpret_cast<const uint4*>(base16 + hi_issued);
+                hi_issued += 4;
+            } else {
+                pend_pos[k] = -1;
+            }
+        }
+    }
+
+    // next word if any (ring must cover it); does not advance
+    __device__ __forceinline__ uint32_t peek() const { return *slot(pos + shift); }
+    __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
+};
+
+template <int W, int S>
+struct RangeEncLane {
+    using st_t = typename StateT<S>::type;
+    st_t lower, range;
+    uint32_t inv_n, inv_first;   // EncoderSituation: inv_n == 0 <=> Normal
+    uint32_t bad;
+    RingWriter out;
+
+    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        out.init(slab, capacity, wave_ring, lane_);
+        lower = 0; range = (st_t)~(st_t)0;   // RangeCoderState::default, queue.rs:96-104
+        inv_n = 0; inv_first = 0; bad = 0;
+    }
+
+    // queue.rs:612-705
+    __device__ __forceinline__ void step(uint32_t c, uint32_t p, int P) {
+        const st_t scale = (st_t)(range >> P);
+        const st_t new_range = (st_t)(scale * (st_t)p);
+        const st_t new_lower = (st_t)(lower + scale * (st_t)c);
+        if (__builtin_expect(inv_n != 0, 0)) {
+            if ((st_t)(new_lower + new_range) > new_lower) {   // inverted -> normal
+                uint32_t first, cons;
+                if (new_lower < lower) { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
+                else { first = inv_first; cons = word_mask<W>(); }
+                out.push_slow(first);
+                for (uint32_t i = 1; i < inv_n; ++i) out.push_slow(cons);
+                inv_n = 0;
+            }
+        }
+        lower = new_lower; range = new_range;
+        const bool renorm = range < ((st_t)1 << (S - W));
+        const uint32_t lower_word = (uint32_t)(lower >> (S - W)) & word_mask<W>();
+        const st_t sh_lower = (st_t)(lower << (W % S)), sh_range = (st_t)(range << (W % S));
+        const bool no_wrap = (st_t)(sh_lower + sh_range) > sh_lower;
+        // common case: Normal -> Normal (emit lower_word) -- branch free through the ring
+        out.push(lower_word, (renorm && inv_n == 0 && no_wrap) ? 1u : 0u);
+        if (__builtin_expect(renorm && (inv_n != 0 || !no_wrap), 0)) {
+            if (inv_n != 0) inv_n += 1;                    // inverted -> inverted
+            else { inv_n = 1; inv_first = lower_word; }    // normal -> inverted
+        }
+        lower = renorm ? sh_lower : lower;
+        range = renorm ? sh_range : range;
+    }
+
+    // seal_words / iter_seal (queue.rs:458-523)
+    __device__ __forceinline__ int32_t finish(uint32_t n_symbols, uint32_t& n_words_out) {
+        out.drain();
+        if (range != (st_t)~(st_t)0) {
+            const st_t point = (st_t)(lower + (((st_t)1 << (S - W)) - 1));
+            if (inv_n != 0) {
+                uint32_t first, cons;
+                if (point >= lower) { first = inv_first; cons = word_mask<W>(); }
+                else { first = (inv_first + 1u) & word_mask<W>(); cons = 0u; }
+                out.append_direct(first);
+                for (uint32_t i = 1; i < inv_n; ++i) out.append_direct(cons);
+            }
+            const uint32_t point_word = (uint32_t)(point >> (S - W)) & word_mask<W>();
+            const uint32_t upper_word = (uint32_t)((st_t)(lower + range) >> (S - W)) & word_mask<W>();
+            out.append_direct(point_word);
+            if (upper_word == point_word) out.append_direct(0u);
+        }
+        n_words_out = out.wr;
+        if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;
+        if (out.wr > out.cap) return CST_STREAM_CAPACITY;
+        return CST_STREAM_OK;
+    }
+};
+
+template <int W, int S>
+struct RangeDecLane {
+    using st_t = typename StateT<S>::type;
+    st_t lower, range, point;
+    int32_t status;
+    RingReaderFwd in;
+
+    // from_compressed + read_point (queue.rs:776-790, 847-868)
+    __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
+        in.init(words, len, wave_ring, lane_);
+        lower = 0; range = (st_t)~(st_t)0; status = CST_STREAM_OK;
+        st_t pt = 0;
+        int num_read = 0;
+        while (in.pos < in.len) {
+            pt = (st_t)((pt << (W % S)) | (st_t)in.word_direct(in.pos++));
+            if (++num_read == S / W) break;
+        }
+        if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
+        point = pt;
+    }
+
+    // queue.rs:984-993: quantile = (point - lower) / (range >> P); flags InvalidData and clamps if it is >= 2^P
+    __device__ __forceinline__ uint32_t peek_quantile(int P) {
+        const st_t scale = (st_t)(range >> P);
+        const st_t x = (st_t)(point - lower);
+        // the quotient is < 2^(P+1): estimate in f64, then make it exact
+        uint32_t q = (uint32_t)((double)x / (double)scale);
+        const st_t prod = (st_t)((st_t)q * scale);
+        if (prod > x) --q;
+        else if ((st_t)(x - prod) >= scale) ++q;
+        if (q >= (1u << P)) {                      // DecoderFrontendError::InvalidData
+            if (status == CST_STREAM_OK) status = CST_STREAM_INVALID_DATA;
+            q = (1u << P) - 1u;                    // keep the lane on legal table indices; its output is unspecified
+        }
+        return q;
+    }
+
+    // queue.rs:998-1030 given the model's answer; `next_word` is the word at the read position (if `have`).
+    // Returns true if a word was consumed.
+    __device__ __forceinline__ bool advance(uint32_t c, uint32_t p, int P, uint32_t next_word, bool have) {
+        const st_t scale = (st_t)(range >> P);
+        lower = (st_t)(lower + scale * (st_t)c);
+        range = (st_t)(scale * (st_t)p);
+        const bool renorm = range < ((st_t)1 << (S - W));
+        const st_t sh_point = (st_t)((st_t)(point << (W % S)) | (st_t)(have ? next_word : 0u));
+        lower = renorm ? (st_t)(lower << (W % S)) : lower;
+        range = renorm ? (st_t)(range << (W % S)) : range;
+        point = renorm ? sh_point : point;
+        return renorm && have;
+    }
+
+    // queue.rs:968-1033 with a tabulated model; returns the symbol index
+    template <int MODE>
+    __device__ __forceinline__ uint32_t step(const void* lut, const uint32_t* cdf, const uint16_t* bucket, int bucket_shift,
+                                             int n_symbols, int P) {
+        const uint32_t q = peek_quantile(P);
+        const uint32_t next_word = in.peek();
+        uint32_t idx, c, p;
+        lookup_quantile<MODE>(q, lut, cdf, bucket, bucket_shift, n_symbols, idx, c, p);
+        in.pos += advance(c, p, P, next_word, in.pos < in.len) ? 1u : 0u;
+        return idx;
+    }
+};
+
+} // namespace cst

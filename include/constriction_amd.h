@@ -208,21 +208,77 @@ cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
                                          cst_layout layout, uint64_t *d_state, uint32_t *d_n_words_out,
                                          int32_t *d_status, uint32_t flags, void *stream);
 
+/* Per-symbol models given explicitly (any model family with per-symbol parameters, e.g.
+ * Categorical(perfect=False) with a probability matrix, src/pybindings/stream/model/internals.rs:188-249):
+ *   encode: d_left / d_prob hold EncoderModel::left_cumulative_and_probability of every symbol
+ *           (same shape/layout as the symbol matrix; prob == 0 marks an impossible symbol);
+ *   decode: d_cdf_rows holds one cdf[n_symbols+1] row per coded symbol, row index = element index of the
+ *           symbol matrix (s*n_per_stream + t, or t*n_streams + s for CST_LAYOUT_SYMBOL_MAJOR). */
+cst_status cst_ans_encode_cp_batch(cst_coder_config cfg, const uint32_t *d_left, const uint32_t *d_prob,
+                                   size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                   size_t stride_words, uint32_t *d_n_words, uint64_t *d_state, int32_t *d_status,
+                                   uint32_t flags, void *stream);
+
+cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_words, const uint64_t *d_offsets,
+                                     size_t stride_words, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
+                                     int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
+                                     size_t n_per_stream, cst_layout layout, uint64_t *d_state,
+                                     uint32_t *d_n_words_out, int32_t *d_status, uint32_t flags, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * batched range coder (BASELINE config C4): one RangeEncoder / RangeDecoder per stream
  *   encode: RangeEncoder::encode_iid_symbols + get_compressed   src/stream/queue.rs:612-705, 458-523
  *   decode: RangeDecoder::from_compressed + decode_iid_symbols  src/stream/queue.rs:847-868, 968-1033
  * Symbols are coded in forward order (a queue).  Same slab/offset conventions as the ANS calls.
  * ---------------------------------------------------------------------------------------- */
+/* Raw coder state of one range coder, for continuing a coder across calls (the single-coder drop-in):
+ * RangeCoderState{lower, range} + EncoderSituation (queue.rs:60-71, 126-142) on the encoder side,
+ * RangeCoderState + point + words consumed on the decoder side. */
+typedef struct cst_range_state {
+    uint64_t lower;
+    uint64_t range;
+    uint64_t point;        /* decoder only */
+    uint32_t inverted_n;   /* encoder only: 0 = EncoderSituation::Normal */
+    uint32_t inverted_first;
+    uint64_t position;     /* decoder only: words consumed so far */
+} cst_range_state;
+
+/* d_rstate (may be NULL unless CST_FLAG_RAW_STATE) is in/out with CST_FLAG_RAW_STATE: the encoder then starts
+ * from it and appends no seal words, the decoder does not re-read `point` and continues at ->position. */
 cst_status cst_range_encode_batch(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
                                   size_t n_streams, size_t n_per_stream, cst_layout layout,
                                   uint32_t *d_words, size_t stride_words, uint32_t *d_n_words,
-                                  int32_t *d_status, void *stream);
+                                  cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
 
 cst_status cst_range_decode_batch(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
                                   const uint64_t *d_offsets, size_t stride_words, const uint32_t *d_n_words,
                                   int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
-                                  int32_t *d_status, void *stream);
+                                  cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
+
+/* Per-symbol-model variants of the range coder (same argument meaning as the cst_ans_* twins). */
+cst_status cst_range_encode_cp_batch(cst_coder_config cfg, const uint32_t *d_left, const uint32_t *d_prob,
+                                     size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                     size_t stride_words, uint32_t *d_n_words, cst_range_state *d_rstate,
+                                     int32_t *d_status, uint32_t flags, void *stream);
+
+cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                           const int32_t *d_symbols, const double *d_means, const double *d_stds,
+                                           size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                           uint32_t *d_words, size_t stride_words, uint32_t *d_n_words,
+                                           cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
+
+cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                           const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                           const uint32_t *d_n_words, const double *d_means, const double *d_stds,
+                                           int32_t *d_symbols, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, cst_range_state *d_rstate, int32_t *d_status,
+                                           uint32_t flags, void *stream);
+
+cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_words, const uint64_t *d_offsets,
+                                       size_t stride_words, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
+                                       int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
+                                       size_t n_per_stream, cst_layout layout, cst_range_state *d_rstate,
+                                       int32_t *d_status, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * bit-exact f64 special functions on device (test hooks for the model kernels)
