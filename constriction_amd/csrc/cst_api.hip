@@ -211,8 +211,10 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
-    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT; // per-stream tables: see cst_ans_*_per_stream path
     if (n_streams == 0) return CST_OK;
+    if (model->per_stream)   // one table per stream (config C3)
+        return ans_encode_per_stream(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words,
+                                     d_state, d_status, flags, (hipStream_t)stream);
     AnsEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
@@ -232,8 +234,10 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
-    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
+    if (model->per_stream)
+        return ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream,
+                                     layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
     AnsDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec32 = model->d_dec32; a.dec64 = model->d_dec64;

@@ -46,7 +46,8 @@ struct cst_model {
     int32_t precision = 0;
     int32_t min_symbol = 0;
     int32_t n_symbols = 0;
-    size_t n_tables = 1;     // 1 = shared, else one table per stream
+    size_t n_tables = 1;     // number of tables
+    bool per_stream = false; // true: table s belongs to stream s (config C3); false: one table shared by all streams
     int device = 0;
     uint32_t* d_cdf = nullptr;        // [n_tables][n_symbols + 1]
     // shared-table artefacts (n_tables == 1)
@@ -55,9 +56,11 @@ struct cst_model {
     uint64_t* d_dec64 = nullptr;      // [2^P] or null
     uint16_t* d_bucket = nullptr;     // [2^bucket_bits + 1]
     int32_t bucket_bits = 0;
-    // per-stream artefacts (n_tables > 1): 16-bit cdf rows, padded to a multiple of 8 entries
-    uint16_t* d_cdf16 = nullptr;      // [n_tables][cdf16_stride], only when precision <= 16... (2^P stored as 0)
+    // per-stream artefacts (n_tables > 1): 16-bit cdf rows (row length = cdf16_stride, a power of two >= n+1;
+    // values are taken modulo 2^16, so 2^16 is stored as 0) and the reciprocal table floor(2^64 / p), p < 2^P
+    uint16_t* d_cdf16 = nullptr;      // [n_tables][cdf16_stride]
     int32_t cdf16_stride = 0;
+    uint64_t* d_recip = nullptr;      // [2^P]
 };
 
 namespace cst {
@@ -73,6 +76,15 @@ void set_hip_error(hipError_t e, const char* what);
             return CST_ERR_HIP;                                \
         }                                                      \
     } while (0)
+
+// per-stream-table coder launches (cst_ans_ps.hip)
+cst_status ans_encode_per_stream(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
+                                 size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
+                                 uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags, hipStream_t hs);
+cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                 size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                                 size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
+                                 int32_t* d_status, uint32_t flags, hipStream_t hs);
 
 inline bool config_supported(cst_coder_config c) {
     if (c.word_bits == 32 && c.state_bits == 64) return c.precision >= 1 && c.precision <= 24;

@@ -24,15 +24,23 @@ __global__ void gaussian_cdf_kernel(int P, int32_t lo, int32_t n, const double* 
     cdf[gid] = leaky_gaussian_left(i, lo, n, P, 32, mu, sd);
 }
 
-// 16-bit per-stream cdf rows for the LDS-resident per-stream models (2^P stored as-is when it fits,
-// else wrapped to 0; consumers special-case the last entry).
+// 16-bit per-stream cdf rows for the LDS-resident per-stream models (values modulo 2^16).  Also validates
+// every table: status[tbl] = 1 if some probability is zero (quantize.rs:562-565 panics) or a parameter is invalid.
 __global__ void cdf_to_u16_kernel(const uint32_t* __restrict__ cdf, size_t n_tables, int32_t n, int32_t stride16,
-                                  uint16_t* __restrict__ out) {
+                                  uint16_t* __restrict__ out, const double* __restrict__ means,
+                                  const double* __restrict__ stds, int32_t* __restrict__ bad) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_tables * (size_t)stride16) return;
     const size_t tbl = gid / stride16;
     const int32_t i = (int32_t)(gid - tbl * stride16);
-    out[gid] = (i <= n) ? (uint16_t)cdf[tbl * ((size_t)n + 1) + i] : (uint16_t)0xffff;
+    const uint32_t* row = cdf + tbl * ((size_t)n + 1);
+    out[gid] = (i <= n) ? (uint16_t)row[i] : (uint16_t)0xffff;
+    if (i < n && row[i + 1] <= row[i]) atomicOr(&bad[tbl], 1);
+    if (i == 0) {
+        const double m = means[tbl], s = stds[tbl];
+        if (!(s > 0.0 && s <= 1.7976931348623157e308 && m == m && m <= 1.7976931348623157e308 && m >= -1.7976931348623157e308))
+            atomicOr(&bad[tbl], 1);
+    }
 }
 
 __global__ void debug_erf_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
@@ -198,9 +206,10 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
     hipStream_t hs = (hipStream_t)stream;
     cst_model* m = new (std::nothrow) cst_model();
     if (!m) return CST_ERR_OUT_OF_MEMORY;
-    m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = n_streams;
+    m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = n_streams; m->per_stream = true;
     hipGetDevice(&m->device);
-    m->cdf16_stride = ((n + 1) + 7) & ~7;
+    m->cdf16_stride = 8;
+    while (m->cdf16_stride < n + 1) m->cdf16_stride <<= 1;   // power of two (rows are rotated per lane in LDS)
     const size_t total = n_streams * ((size_t)n + 1);
     hipError_t e = hipMalloc(&m->d_cdf, 4 * total);
     if (e == hipSuccess) e = hipMalloc(&m->d_cdf16, 2 * n_streams * (size_t)m->cdf16_stride);
@@ -210,9 +219,30 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
         hipLaunchKernelGGL(gaussian_cdf_kernel, dim3((unsigned)blocks), dim3(threads), 0, hs, precision, min_symbol, n,
                            d_means, d_stds, 0.0, 1.0, n_streams, m->d_cdf);
         const size_t total16 = n_streams * (size_t)m->cdf16_stride;
-        hipLaunchKernelGGL(cdf_to_u16_kernel, dim3((unsigned)((total16 + threads - 1) / threads)), dim3(threads), 0, hs,
-                           (const uint32_t*)m->d_cdf, n_streams, n, m->cdf16_stride, m->d_cdf16);
-        e = hipGetLastError();
+        int32_t* d_bad = nullptr;
+        e = hipMallocAsync((void**)&d_bad, 4 * n_streams, hs);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4 * n_streams, hs);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cdf_to_u16_kernel, dim3((unsigned)((total16 + threads - 1) / threads)), dim3(threads), 0, hs,
+                               (const uint32_t*)m->d_cdf, n_streams, n, m->cdf16_stride, m->d_cdf16, d_means, d_stds, d_bad);
+            e = hipGetLastError();
+        }
+        // any invalid table makes the whole model invalid (the reference panics when such a model is constructed)
+        if (e == hipSuccess) {
+            std::vector<int32_t> h_bad(n_streams);
+            e = hipMemcpyAsync(h_bad.data(), d_bad, 4 * n_streams, hipMemcpyDeviceToHost, hs);
+            if (e == hipSuccess) e = hipStreamSynchronize(hs);
+            if (e == hipSuccess) for (size_t i = 0; i < n_streams; ++i) if (h_bad[i]) { (void)hipFree(d_bad); cst_model_destroy(m); return CST_ERR_MODEL; }
+        }
+        if (d_bad) (void)hipFreeAsync(d_bad, hs);
+    }
+    if (e == hipSuccess) {   // reciprocal table floor(2^64 / p) for p in [1, 2^P)
+        const size_t np = (size_t)1 << precision;
+        std::vector<uint64_t> rec(np, 0);
+        rec[1] = ~0ull;
+        for (size_t p = 2; p < np; ++p) rec[p] = (uint64_t)((((unsigned __int128)1) << 64) / p);
+        e = hipMalloc(&m->d_recip, 8 * np);
+        if (e == hipSuccess) e = hipMemcpy(m->d_recip, rec.data(), 8 * np, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { set_hip_error(e, "per-stream gaussian tables"); cst_model_destroy(m); return CST_ERR_HIP; }
     *out = m;
@@ -222,7 +252,7 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
 cst_status cst_model_destroy(cst_model* m) {
     if (!m) return CST_OK;
     hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec32); hipFree(m->d_dec64); hipFree(m->d_bucket);
-    hipFree(m->d_cdf16);
+    hipFree(m->d_cdf16); hipFree(m->d_recip);
     delete m;
     return CST_OK;
 }

@@ -287,7 +287,7 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
-    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT;
+    if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     RangeEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
@@ -308,7 +308,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
     if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
-    if (model->n_tables != 1) return CST_ERR_INVALID_ARGUMENT;
+    if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     RangeDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
