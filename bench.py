@@ -60,31 +60,32 @@ def synth_symbols_device(seed, stream_begin, n_streams, n_per, lo, cdf_dev, prec
     return out
 
 
-def cpu_baseline(cdf, target_seconds=6.0):
-    """Times the CPU oracle (kind "port") on this box's host cores on a bounded sample of the workload."""
+def cpu_baseline(cdf, symbols_host, repeats=3):
+    """Times the CPU oracle (kind "port": the repo's C restatement of the reference arithmetic, -O3 -march=native,
+    one disjoint block of streams per thread) on this box's host cores, on the SAME symbols the GPU coded."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     lut = O.lookup_from_cdf(cdf, P)
 
-    def run(n_streams, threads):
-        sym = O.synth_symbols(SEED, 0, n_streams, N_PER, LO, cdf, P)
-        t0 = time.perf_counter()
-        words, n_words, status = O.ans_encode_batch(sym, LO, cdf, P, W, S, n_threads=threads, native=True)
-        t1 = time.perf_counter()
-        dec, dstatus = O.ans_decode_batch(words, n_words, N_PER, LO, cdf, P, W, S, lookup=lut, n_threads=threads, native=True)
-        t2 = time.perf_counter()
+    def run(sym, threads):
+        best = None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            words, n_words, status = O.ans_encode_batch(sym, LO, cdf, P, W, S, n_threads=threads, native=True)
+            t1 = time.perf_counter()
+            dec, dstatus = O.ans_decode_batch(words, n_words, N_PER, LO, cdf, P, W, S, lookup=lut, n_threads=threads, native=True)
+            t2 = time.perf_counter()
+            if best is None or (t2 - t0) < sum(best):
+                best = (t1 - t0, t2 - t1)
         assert np.array_equal(dec, sym) and not status.any() and not dstatus.any()
-        return sym.size, t1 - t0, t2 - t1
+        return sym.size, best[0], best[1]
 
-    n, te, td = run(max(cores, 64), cores)                      # probe
-    rate = n / (te + td)
-    n_streams = int(min(N_STREAMS, max(cores, rate * target_seconds / N_PER)))
-    n, te, td = run(n_streams, cores)
-    n1, te1, td1 = run(max(8, min(512, n_streams // max(cores, 1))), 1)
+    n, te, td = run(symbols_host, cores)
+    n1, te1, td1 = run(symbols_host[: max(64, min(1024, len(symbols_host)))], 1)
     return {
         "value": round(n / (te + td) / 1e6, 2), "unit": "Msymbols/s", "cores": cores, "kind": "port",
-        "sample": f"{n_streams} of {N_STREAMS} streams x {N_PER} symbols, same model/seed, {cores} threads "
-                  f"(encode {n / te / 1e6:.0f} + decode {n / td / 1e6:.0f} Msym/s); "
+        "sample": f"{len(symbols_host)} of {N_STREAMS} streams x {N_PER} symbols (the GPU's own input), {cores} threads, best of "
+                  f"{repeats} (encode {n / te / 1e6:.0f} + decode {n / td / 1e6:.0f} Msym/s); "
                   f"1 thread: {n1 / (te1 + td1) / 1e6:.1f} Msym/s "
                   f"({te1 / n1 * 1e9:.1f} ns/sym encode, {td1 / n1 * 1e9:.1f} ns/sym decode)",
         "single_thread_value": round(n1 / (te1 + td1) / 1e6, 2),
@@ -225,7 +226,7 @@ def main():
                          "decode_GBps": round(bytes_per_launch / (dec_ms * 1e-3) / 1e9, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cdf)
+            line["cpu_baseline"] = cpu_baseline(cdf, symbols.cpu().numpy())
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
