@@ -18,18 +18,20 @@ namespace cst {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kRingSlots = 32;            // words per lane in the LDS word ring
+constexpr int kRingSlots = 64;            // words per lane in the LDS word ring
 constexpr int kRingWords = kRingSlots * kWave;
-constexpr int kAhead = 16;                // decode: words kept issued ahead of the read position
-constexpr int kMaxChunksPerPoint = 3;     // 16-byte chunks a lane may move per scheduled point
+constexpr int kAhead = 28;                // decode: words kept issued ahead of the read position
+constexpr int kMaxChunksPerPoint = 5;     // 16-byte chunks a lane may move per scheduled point
 
 // Words a coder can emit/consume in T consecutive steps is at most ceil(P*T/W)+1 (each step moves at
-// most P bits of information).  Scheduled points are placed every 4*G steps with G chosen so that this
-// bound is <= 7, which the ring geometry above is sized for.
+// most P bits of information).  Scheduled points -- the ONLY places where a coder touches HBM for compressed
+// words -- are placed every 4*G steps with G as large as possible such that this bound is <= 13, which the ring
+// geometry above is sized for.  Everything a point waits for was issued a whole interval
+// earlier, so neither load latency nor store completion is exposed.
 __host__ __device__ inline int groups_per_point(int W, int P) {
-    if (16 * P <= 6 * W) return 4;
-    if (8 * P <= 6 * W) return 2;
-    return 1;
+    if (32 * P <= 12 * W) return 8;
+    if (16 * P <= 12 * W) return 4;
+    return 2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -133,8 +135,8 @@ struct AnsDecodeArgs {
     const uint32_t* n_words;
     int32_t* symbols;
     size_t n_streams, n_per_stream;
-    const uint32_t* dec32;    // DecMode-dependent tables
-    const uint64_t* dec64;
+    const uint32_t* dec_cp;   // DecMode-dependent tables
+    const uint16_t* dec_idx;
     const uint32_t* cdf;
     const uint16_t* bucket;
     int32_t bucket_bits;
@@ -208,13 +210,15 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
                                            int lane, const int32_t* tile) {
     if constexpr (VEC) {
         const int chunk = lane & 7;
+        // all eight LDS reads first (one wait), then the eight stores back to back
+        int4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const int4*>(tile + ((lane >> 3) + 8 * k) * kTileStride + 4 * chunk);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int row = (lane >> 3) + 8 * k;
-            const size_t s = s0 + (size_t)row;
-            const int4 v = *reinterpret_cast<const int4*>(tile + row * kTileStride + 4 * chunk);
+            const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
             if (s < n_streams) {
-                v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                v4i t; t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
                 __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(sym + s * N + t0 + 4 * chunk));
             }
         }
@@ -248,9 +252,9 @@ struct RingWriter {
     int lane;
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(slab);
-        base16 = reinterpret_cast<uint32_t*>(addr & ~(uintptr_t)15);
-        shift = (uint32_t)((addr & 15) >> 2);
+        // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
+        shift = (uint32_t)((reinterpret_cast<uintptr_t>(slab) & 15) >> 2);
+        base16 = slab - shift;
         cap = capacity; ring = wave_ring; lane = lane_;
         wr = 0; flushed = 0;
     }
@@ -320,9 +324,9 @@ struct RingReader {
     __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
 
     __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint32_t* wave_ring, int lane_) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
-        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
-        shift = (uint32_t)((addr & 15) >> 2);
+        // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
+        shift = (uint32_t)((reinterpret_cast<uintptr_t>(in) & 15) >> 2);
+        base16 = in - shift;
         ring = wave_ring; lane = lane_; rd = len;
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
@@ -495,6 +499,8 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 tile_to_lds<VEC>(tile, lane, r);
                 wave_lds_fence();
                 if (tb > 0) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r); // prefetch
+                L.flush_chunks();   // words of the previous tile: stores issued together with the loads, a whole tile
+                                    // before anything waits on vmcnt again
                 const int32_t* my = tile + lane * kTileStride;
                 // Walk this lane's row backwards, 4 symbols per LDS read.  The table entries of group j-1
                 // are fetched before the dependent chain of group j runs (they do not depend on the state).
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                     }
                     L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
                     e3 = n3; e2 = n2; e1 = n1; e0 = n0;
-                    if (j % G == 0) L.flush_chunks();   // static schedule: G divides the 8 groups of a tile
+                    if (j % G == 0 && j != 0) L.flush_chunks();   // static mid-tile points (G < 8 only)
                 }
             }
         }
@@ -556,17 +562,110 @@ struct DecLane {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Speculative decode step for (W,S) = (32,64), 8 <= P <= 13, LUT in LDS  
+//
+// The decoder's critical path is  state -> quantile -> LDS lookup -> multiply -> refill? -> state.  The LDS
+// round trip (~100 cycles here) dominates it, so BOTH possible next lookups are issued before the refill
+// decision is known:
+//   no refill: the next quantile is ((state >> P) mod 2^P) * p + (q - c)  mod 2^P      (3 ops after the entry arrives)
+//   refill   : the next quantile is the low P bits of the next compressed word         (known a step earlier)
+// and the entry that belongs to the actual outcome is selected when the data returns.  The refill test itself
+// (64-bit multiply-add, compare) runs in the shadow of the lookups.
+// ------------------------------------------------------------------------------------------------
+struct SpecDec {
+    uint32_t lo, hi;     // coder state
+    uint32_t q;          // quantile of the current state
+    uint32_t e;          // its table entry  c | p << 16
+    uint32_t nw;         // ring word at the read position (before the deferred select of the previous step)
+    uint32_t nw2;        // ring word below it (in flight until spec step's first wait)
+    uint64_t pred;       // did the previous step refill?
+    // LDS byte addresses
+    uint32_t cp_base, idx_base;
+};
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const lds_u32*)p; }
+
+__device__ __forceinline__ void spec_init(SpecDec& D, uint64_t state, const RingReader& in, const DecLut lut, uint32_t mask) {
+    D.lo = (uint32_t)state; D.hi = (uint32_t)(state >> 32);
+    D.q = D.lo & mask;
+    D.e = lut.cp[D.q];
+    D.nw = *in.slot(in.rd - 1u + in.shift);
+    D.nw2 = D.nw;
+    D.pred = 0;
+    D.cp_base = lds_addr(lut.cp); D.idx_base = lds_addr(lut.idx);
+}
+
+// One symbol.  All four LDS reads of a step are issued together by hand (inline asm, invisible to the compiler's
+// lgkmcnt bookkeeping) in the order  EB, EA, next-next word, symbol index : one wave's DS operations are served and
+// returned in order, each random access costing ~20 cycles of service time, so the two speculative table reads go
+// first and are waited for with lgkmcnt(2); the other two are only needed a step later.
+//   idx_out  : symbol index of this step -- IN FLIGHT on return; `settle_idx` (or the next step) orders its consumers
+//   idx_tie  : the previous step's idx_out, which is complete once this step's lgkmcnt(2) wait has passed
+__device__ __forceinline__ void spec_decode_step(SpecDec& D, RingReader& in, uint32_t mask, int P, uint32_t& idx_out,
+                                                 uint32_t& idx_tie) {
+    // deferred select of the previous step: next word = refill ? ring[rd-2] : ring[rd-1]; its data (nw2) is the
+    // second-youngest outstanding read
+    uint32_t nw;
+    asm volatile("s_waitcnt lgkmcnt(1)\n\tv_cndmask_b32 %0, %1, %2, %3" : "=v"(nw) : "v"(D.nw), "v"(D.nw2), "s"(D.pred) : "memory");
+    const uint32_t p = D.e >> 16;
+    const uint32_t rem = D.q - (D.e & 0xffffu);
+    // candidate A (no refill) and candidate B (refill: quantile = low bits of the next word)
+    const uint32_t qA = (__umul24((D.lo >> P) & mask, p) + rem) & mask;
+    const uint32_t qB = nw & mask;
+    uint32_t EA, EB, nw2;
+    asm volatile(
+        "ds_read_b32 %0, %4\n\t"
+        "ds_read_b32 %1, %5\n\t"
+        "ds_read_b32 %2, %6\n\t"
+        "ds_read_u16 %3, %7"
+        : "=&v"(EB), "=&v"(EA), "=&v"(nw2), "=&v"(idx_out)
+        : "v"(D.cp_base + 4u * qB), "v"(D.cp_base + 4u * qA), "v"(lds_addr(in.slot(in.rd - 2u + in.shift))),
+          "v"(D.idx_base + 2u * D.q)
+        : "memory");
+    // exact state update on 32-bit halves (stack.rs:1086-1088); the high product fits mul_u24 because P >= 8
+    const uint32_t s_lo = __builtin_amdgcn_alignbit(D.hi, D.lo, P), s_hi = D.hi >> P;
+    const uint64_t t = (uint64_t)s_lo * p + (uint64_t)rem;
+    const uint32_t t_lo = (uint32_t)t;
+    const uint32_t t_hi = __umul24(s_hi, p) + (uint32_t)(t >> 32);
+    // refill <=> t < 2^32 and words remain <=> t_hi < min(rd, 1)   (stack.rs:1089-1097)
+    uint32_t new_lo, new_hi, new_rd, new_q, have;
+    uint64_t pred;
+    asm volatile(
+        "v_min_u32 %4, %6, 1\n\t"
+        "v_cmp_lt_u32 vcc, %7, %4\n\t"
+        "s_mov_b64 %5, vcc\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %0, %8, %9, vcc\n\t"           // lo' = refill ? next_word : t_lo
+        "v_cndmask_b32 %1, %7, %8, vcc\n\t"           // hi' = refill ? t_lo : t_hi
+        "v_cndmask_b32 %3, %10, %11, vcc\n\t"         // q'  = refill ? qB : qA
+        "v_subbrev_co_u32 %2, vcc, 0, %6, vcc"          // rd' = rd - refill
+        : "=&v"(new_lo), "=&v"(new_hi), "=&v"(new_rd), "=&v"(new_q), "=&v"(have), "=&s"(pred)
+        : "v"(in.rd), "v"(t_hi), "v"(t_lo), "v"(nw), "v"(qA), "v"(qB)
+        : "vcc");
+    in.rd = new_rd;
+    // entry select once the two table reads are back (the two younger reads stay in flight)
+    uint32_t e_next;
+    asm volatile("s_waitcnt lgkmcnt(2)\n\tv_cndmask_b32 %0, %2, %3, %4"
+                 : "=v"(e_next), "+v"(idx_tie) : "v"(EA), "v"(EB), "s"(pred) : "memory");
+    D.lo = new_lo; D.hi = new_hi; D.q = new_q; D.e = e_next; D.nw = nw; D.nw2 = nw2; D.pred = pred;
+}
+
+// orders the consumers of in-flight symbol indices after their arrival
+__device__ __forceinline__ void settle_idx(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
+__device__ __forceinline__ void settle_idx4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
 // DecoderModel::quantile_function for a tabulated model (lookup_contiguous.rs:564-605): quantile -> (index, left
 // cumulative, probability), from the LDS/global image selected by MODE.
 template <int MODE>
-__device__ __forceinline__ void lookup_quantile(uint32_t q, const void* lut, const uint32_t* cdf, const uint16_t* bucket,
+__device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, const uint32_t* cdf, const uint16_t* bucket,
                                                 int bucket_shift, int n_symbols, uint32_t& idx, uint32_t& c, uint32_t& p) {
-    if constexpr (MODE == kDecLut32) {
-        const uint32_t e = reinterpret_cast<const uint32_t*>(lut)[q];
-        idx = e & 0xffu; c = (e >> 8) & 0xfffu; p = e >> 20;
-    } else if constexpr (MODE == kDecLut64) {
-        const uint2 e = reinterpret_cast<const uint2*>(lut)[q];
-        p = e.x; c = e.y & 0xffffu; idx = e.y >> 16;
+    if constexpr (MODE == kDecLutCP) {
+        const uint32_t e = lut.cp[q];
+        c = e & 0xffffu; p = e >> 16; idx = lut.idx[q];
     } else {
         // bucket[q >> shift] = first index whose bin reaches into the bucket; scan forward
         idx = bucket[q >> bucket_shift];
@@ -579,7 +678,7 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const void* lut, con
 
 // One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
 template <int W, int S, int MODE, bool FAST>
-__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void* lut, const uint32_t* cdf,
+__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const DecLut lut, const uint32_t* cdf,
                                                     const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
     using st_t = typename StateT<S>::type;
     const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
@@ -631,25 +730,21 @@ __device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const void
 
 // Copies the decoder tables selected by MODE into LDS (if LUT_IN_LDS) and returns the bytes used.
 template <int MODE, bool LUT_IN_LDS>
-__device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int P, const uint32_t* dec32, const uint64_t* dec64,
+__device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int P, const uint32_t* dec_cp, const uint16_t* dec_idx,
                                                        const uint32_t* g_cdf, const uint16_t* g_bucket, int bucket_bits,
-                                                       int n_symbols, const void*& lut, const uint32_t*& cdf,
+                                                       int n_symbols, DecLut& lut, const uint32_t*& cdf,
                                                        const uint16_t*& bucket) {
     size_t lds_off = 0;
-    if constexpr (MODE == kDecLut32) {
+    lut.cp = dec_cp; lut.idx = dec_idx;
+    if constexpr (MODE == kDecLutCP) {
         if constexpr (LUT_IN_LDS) {
             uint32_t* l = reinterpret_cast<uint32_t*>(smem);
             const int n = 1 << P;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = dec32[i];
-            lut = l; lds_off = (size_t)n * 4;
-        } else lut = dec32;
-    } else if constexpr (MODE == kDecLut64) {
-        if constexpr (LUT_IN_LDS) {
-            uint64_t* l = reinterpret_cast<uint64_t*>(smem);
-            const int n = 1 << P;
-            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = dec64[i];
-            lut = l; lds_off = (size_t)n * 8;
-        } else lut = dec64;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) l[i] = dec_cp[i];
+            uint16_t* x = reinterpret_cast<uint16_t*>(smem + (size_t)n * 4);
+            for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = dec_idx[i];
+            lut.cp = l; lut.idx = x; lds_off = (size_t)n * 6;
+        }
     } else {
         if constexpr (LUT_IN_LDS) {
             uint32_t* c = reinterpret_cast<uint32_t*>(smem);
@@ -673,10 +768,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const int P = a.precision;
 
     // ---- stage tables in LDS ----
-    const void* lut = nullptr;
+    DecLut lut{};
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec32, a.dec64, a.cdf, a.bucket, a.bucket_bits,
+    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                            a.n_symbols, lut, cdf, bucket);
     lds_off = (lds_off + 15) & ~(size_t)15;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
@@ -700,11 +795,45 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     L.in.prime();
     wave_lds_fence();
 
+    constexpr bool SPEC = FAST && W == 32 && S == 64 && MODE == kDecLutCP && LUT_IN_LDS;
+    [[maybe_unused]] SpecDec D;
+    [[maybe_unused]] const uint32_t qmask = (1u << P) - 1u;
+    if constexpr (SPEC) { spec_init(D, (uint64_t)L.state, L.in, lut, qmask); wave_lds_fence(); }
+    // one symbol (tails, symbol-major layout)
+    auto next_index = [&]() -> uint32_t {
+        if constexpr (SPEC) {
+            uint32_t idx, tie = 0;
+            spec_decode_step(D, L.in, qmask, P, idx, tie);
+            settle_idx(idx);
+            return idx;
+        } else {
+            return ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+        }
+    };
+    // four symbols
+    auto next_four = [&]() -> int4 {
+        int4 v;
+        if constexpr (SPEC) {
+            uint32_t i0, i1, i2, i3, tie = 0;
+            spec_decode_step(D, L.in, qmask, P, i0, tie);
+            spec_decode_step(D, L.in, qmask, P, i1, i0);
+            spec_decode_step(D, L.in, qmask, P, i2, i1);
+            spec_decode_step(D, L.in, qmask, P, i3, i2);
+            settle_idx4(i0, i1, i2, i3);
+            v.x = a.min_symbol + (int32_t)i0; v.y = a.min_symbol + (int32_t)i1;
+            v.z = a.min_symbol + (int32_t)i2; v.w = a.min_symbol + (int32_t)i3;
+        } else {
+            v.x = a.min_symbol + (int32_t)next_index(); v.y = a.min_symbol + (int32_t)next_index();
+            v.z = a.min_symbol + (int32_t)next_index(); v.w = a.min_symbol + (int32_t)next_index();
+        }
+        return v;
+    };
+
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
         int32_t* col = a.symbols + (active ? s : 0);
         int countdown = 4 * G;
         for (size_t t = 0; t < N; ++t) {
-            const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            const uint32_t idx = next_index();
             if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
             if (--countdown == 0) { countdown = 4 * G; L.in.advance_window(); }
         }
@@ -715,24 +844,25 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         for (size_t tb = 0; tb < n_full; ++tb) {
 #pragma unroll
             for (int j = 0; j < kTileSyms / 4; ++j) {
-                int4 v;
-                v.x = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.y = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.z = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-                v.w = a.min_symbol + (int32_t)ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+                const int4 v = next_four();
                 *reinterpret_cast<int4*>(my + 4 * j) = v;
+#ifndef CST_EXP_NO_ADVANCE
                 if ((j + 1) % G == 0) L.in.advance_window();   // static schedule
+#endif
             }
             wave_lds_fence();
+#ifndef CST_EXP_NO_TILE_STORE
             tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+#endif
             wave_lds_fence();
         }
         for (size_t t = n_full * kTileSyms; t < N; ++t) {
-            const uint32_t idx = ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+            const uint32_t idx = next_index();
             if (active) row[t] = a.min_symbol + (int32_t)idx;
             L.in.advance_window();
         }
     }
+    if constexpr (SPEC) L.state = ((uint64_t)D.hi << 32) | D.lo;
 
     if (!active) return;
     a.status[s] = L.status;

@@ -54,9 +54,9 @@ static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hip
     static const bool env_fast = getenv("CST_ENC_FAST") ? atoi(getenv("CST_ENC_FAST")) != 0 : false; // A/B knob: the compiler-scheduled 32-bit-halves form is currently slower
     const bool fast = (W == 32) && a.precision >= 8 && env_fast;
     switch (groups_per_point(W, a.precision)) {
+        case 8: return fast ? encode_dispatch_g<W, S, 8, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 8, false>(a, layout, hs);
         case 4: return fast ? encode_dispatch_g<W, S, 4, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 4, false>(a, layout, hs);
-        case 2: return fast ? encode_dispatch_g<W, S, 2, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 2, false>(a, layout, hs);
-        default: return encode_dispatch_g<W, S, 1, false>(a, layout, hs);
+        default: return encode_dispatch_g<W, S, 2, false>(a, layout, hs);
     }
 }
 
@@ -75,11 +75,11 @@ template <int W, int S, int MODE, bool LDS>
 static cst_status decode_dispatch2(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
     const bool fast = (W == 32) && a.precision >= 8;
     switch (groups_per_point(W, a.precision)) {
+        case 8: return fast ? decode_dispatch3<W, S, MODE, LDS, 8, W == 32>(a, layout, table_lds, hs)
+                            : decode_dispatch3<W, S, MODE, LDS, 8, false>(a, layout, table_lds, hs);
         case 4: return fast ? decode_dispatch3<W, S, MODE, LDS, 4, W == 32>(a, layout, table_lds, hs)
                             : decode_dispatch3<W, S, MODE, LDS, 4, false>(a, layout, table_lds, hs);
-        case 2: return fast ? decode_dispatch3<W, S, MODE, LDS, 2, W == 32>(a, layout, table_lds, hs)
-                            : decode_dispatch3<W, S, MODE, LDS, 2, false>(a, layout, table_lds, hs);
-        default: return decode_dispatch3<W, S, MODE, LDS, 1, false>(a, layout, table_lds, hs);
+        default: return decode_dispatch3<W, S, MODE, LDS, 2, false>(a, layout, table_lds, hs);
     }
 }
 
@@ -87,11 +87,11 @@ template <int W, int S>
 static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const int P = a.precision;
     const size_t lds_budget = kMaxLds - kTileBytesPerBlock - 1024;
-    if (a.dec64 && ((size_t)8 << P) <= lds_budget)
-        return decode_dispatch2<W, S, kDecLut64, true>(a, layout, ((size_t)8 << P), hs);
+    if (a.dec_cp && ((size_t)6 << P) <= lds_budget)
+        return decode_dispatch2<W, S, kDecLutCP, true>(a, layout, ((size_t)6 << P), hs);
     const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
     if (bucket_lds <= lds_budget) return decode_dispatch2<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
-    if (a.dec64) return decode_dispatch2<W, S, kDecLut64, false>(a, layout, 0, hs);
+    if (a.dec_cp) return decode_dispatch2<W, S, kDecLutCP, false>(a, layout, 0, hs);
     return decode_dispatch2<W, S, kDecBucket, false>(a, layout, 0, hs);
 }
 
@@ -240,7 +240,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
                                      layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
     AnsDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
-    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec32 = model->d_dec32; a.dec64 = model->d_dec64;
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags;

@@ -24,19 +24,20 @@ struct __attribute__((aligned(16))) EncEntry {
     uint32_t m_hi;
 };
 
-// Decoder lookup entry for quantile q (lookup_contiguous.rs:564-605 collapsed into one load):
-//   packed32: idx[0,8) | c[8,20) | p[20,32)      (P <= 12 and n_symbols <= 256)
-//   packed64: p[0,32) | c[32,48) | idx[48,64)    (P <= 16): p is a whole dword, c and idx are 16-bit halves
-//             (one SDWA subtract / add each on the decoder's critical path)
-__host__ __device__ inline uint32_t pack_dec32(uint32_t idx, uint32_t c, uint32_t p) { return idx | (c << 8) | (p << 20); }
-__host__ __device__ inline uint64_t pack_dec64(uint32_t idx, uint32_t c, uint32_t p) {
-    return (uint64_t)p | ((uint64_t)c << 32) | ((uint64_t)idx << 48);
-}
+// Decoder lookup for quantile q (lookup_contiguous.rs:564-605 collapsed into table reads), P <= 16:
+//   cp[q]  = c | p << 16   (u32: left cumulative and probability of the bin that holds q, both < 2^16; one random
+//                           32-bit LDS read -- 64-bit random reads cost ~35 cycles more on gfx950)
+//   idx[q] = symbol index  (u16, needed only for the output, off the coder's critical path)
+__host__ __device__ inline uint32_t pack_cp(uint32_t c, uint32_t p) { return (c & 0xffffu) | (p << 16); }
 
 enum DecMode : int {
-    kDecLut32 = 0,   // 2^P x u32 in LDS
-    kDecLut64 = 1,   // 2^P x u64 in LDS (P <= 13) or global
+    kDecLutCP = 1,   // cp[2^P] + idx[2^P] in LDS (P <= 14) or global
     kDecBucket = 2,  // cdf[n+1] + bucket index, linear scan (any P)
+};
+
+struct DecLut {      // pointers into LDS or global memory
+    const uint32_t* cp;
+    const uint16_t* idx;
 };
 
 } // namespace cst
@@ -52,8 +53,8 @@ struct cst_model {
     uint32_t* d_cdf = nullptr;        // [n_tables][n_symbols + 1]
     // shared-table artefacts (n_tables == 1)
     cst::EncEntry* d_enc = nullptr;   // [n_symbols]
-    uint32_t* d_dec32 = nullptr;      // [2^P] or null
-    uint64_t* d_dec64 = nullptr;      // [2^P] or null
+    uint32_t* d_dec_cp = nullptr;     // [2^P] or null (P <= 16)
+    uint16_t* d_dec_idx = nullptr;    // [2^P] or null
     uint16_t* d_bucket = nullptr;     // [2^bucket_bits + 1]
     int32_t bucket_bits = 0;
     // per-stream artefacts (n_tables > 1): 16-bit cdf rows (row length = cdf16_stride, a power of two >= n+1;

@@ -82,24 +82,18 @@ static cst_status upload_shared_tables(cst_model* m, const uint32_t* cdf) {
 
     if (P <= 16) {
         const size_t total = (size_t)1 << P;
-        if (P <= 12 && n <= 256) {
-            std::vector<uint32_t> lut(total);
-            int i = 0;
-            for (size_t q = 0; q < total; ++q) {
-                while (cdf[i + 1] <= q) ++i;
-                lut[q] = pack_dec32((uint32_t)i, cdf[i], cdf[i + 1] - cdf[i]);
-            }
-            CST_HIP_TRY(hipMalloc(&m->d_dec32, 4 * total));
-            CST_HIP_TRY(hipMemcpy(m->d_dec32, lut.data(), 4 * total, hipMemcpyHostToDevice));
-        }
-        std::vector<uint64_t> lut(total);
+        std::vector<uint32_t> cp(total);
+        std::vector<uint16_t> ix(total);
         int i = 0;
         for (size_t q = 0; q < total; ++q) {
             while (cdf[i + 1] <= q) ++i;
-            lut[q] = pack_dec64((uint32_t)i, cdf[i], cdf[i + 1] - cdf[i]);
+            cp[q] = pack_cp(cdf[i], cdf[i + 1] - cdf[i]);
+            ix[q] = (uint16_t)i;
         }
-        CST_HIP_TRY(hipMalloc(&m->d_dec64, 8 * total));
-        CST_HIP_TRY(hipMemcpy(m->d_dec64, lut.data(), 8 * total, hipMemcpyHostToDevice));
+        CST_HIP_TRY(hipMalloc(&m->d_dec_cp, 4 * total));
+        CST_HIP_TRY(hipMemcpy(m->d_dec_cp, cp.data(), 4 * total, hipMemcpyHostToDevice));
+        CST_HIP_TRY(hipMalloc(&m->d_dec_idx, 2 * total));
+        CST_HIP_TRY(hipMemcpy(m->d_dec_idx, ix.data(), 2 * total, hipMemcpyHostToDevice));
     }
     // bucket index for the generic (any P) decoder
     m->bucket_bits = P < 11 ? P : 11;
@@ -251,7 +245,7 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
 
 cst_status cst_model_destroy(cst_model* m) {
     if (!m) return CST_OK;
-    hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec32); hipFree(m->d_dec64); hipFree(m->d_bucket);
+    hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec_cp); hipFree(m->d_dec_idx); hipFree(m->d_bucket);
     hipFree(m->d_cdf16); hipFree(m->d_recip);
     delete m;
     return CST_OK;

@@ -115,8 +115,8 @@ struct RangeDecodeArgs {
     const uint32_t* n_words;
     int32_t* symbols;
     size_t n_streams, n_per_stream;
-    const uint32_t* dec32;
-    const uint64_t* dec64;
+    const uint32_t* dec_cp;
+    const uint16_t* dec_idx;
     const uint32_t* cdf;
     const uint16_t* bucket;
     int32_t bucket_bits;
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeA
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
     const int P = a.precision;
-    const void* lut = nullptr;
+    DecLut lut{};
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec32, a.dec64, a.cdf, a.bucket, a.bucket_bits,
+    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                            a.n_symbols, lut, cdf, bucket);
     lds_off = (lds_off + 15) & ~(size_t)15;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
@@ -238,9 +238,9 @@ static cst_status range_encode_g(const RangeEncodeArgs& a, cst_layout layout, hi
 template <int W, int S>
 static cst_status range_encode_ws(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     switch (groups_per_point(W, a.precision)) {
+        case 8: return range_encode_g<W, S, 8>(a, layout, hs);
         case 4: return range_encode_g<W, S, 4>(a, layout, hs);
-        case 2: return range_encode_g<W, S, 2>(a, layout, hs);
-        default: return range_encode_g<W, S, 1>(a, layout, hs);
+        default: return range_encode_g<W, S, 2>(a, layout, hs);
     }
 }
 
@@ -256,9 +256,9 @@ static cst_status range_decode_g(const RangeDecodeArgs& a, cst_layout layout, si
 template <int W, int S, int MODE, bool LDS>
 static cst_status range_decode_m(const RangeDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
     switch (groups_per_point(W, a.precision)) {
+        case 8: return range_decode_g<W, S, MODE, LDS, 8>(a, layout, table_lds, hs);
         case 4: return range_decode_g<W, S, MODE, LDS, 4>(a, layout, table_lds, hs);
-        case 2: return range_decode_g<W, S, MODE, LDS, 2>(a, layout, table_lds, hs);
-        default: return range_decode_g<W, S, MODE, LDS, 1>(a, layout, table_lds, hs);
+        default: return range_decode_g<W, S, MODE, LDS, 2>(a, layout, table_lds, hs);
     }
 }
 
@@ -266,10 +266,10 @@ template <int W, int S>
 static cst_status range_decode_ws(const RangeDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const int P = a.precision;
     const size_t lds_budget = kMaxLds - kPerBlockLds - 1024;
-    if (a.dec64 && ((size_t)8 << P) <= lds_budget) return range_decode_m<W, S, kDecLut64, true>(a, layout, ((size_t)8 << P), hs);
+    if (a.dec_cp && ((size_t)6 << P) <= lds_budget) return range_decode_m<W, S, kDecLutCP, true>(a, layout, ((size_t)6 << P), hs);
     const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
     if (bucket_lds <= lds_budget) return range_decode_m<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
-    if (a.dec64) return range_decode_m<W, S, kDecLut64, false>(a, layout, 0, hs);
+    if (a.dec_cp) return range_decode_m<W, S, kDecLutCP, false>(a, layout, 0, hs);
     return range_decode_m<W, S, kDecBucket, false>(a, layout, 0, hs);
 }
 
@@ -312,7 +312,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     if (n_streams == 0) return CST_OK;
     RangeDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
-    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec32 = model->d_dec32; a.dec64 = model->d_dec64;
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags;

@@ -25,9 +25,9 @@ struct RingReaderFwd {
     __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (kRingSlots - 1)) * kWave + lane); }
 
     __device__ __forceinline__ void init(const uint32_t* in, uint32_t n, uint32_t* wave_ring, int lane_) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
-        base16 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)15);
-        shift = (uint32_t)((addr & 15) >> 2);
+        // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
+        shift = (uint32_t)((reinterpret_cast<uintptr_t>(in) & 15) >> 2);
+        base16 = in - shift;
         ring = wave_ring; lane = lane_; pos = 0; len = n;
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
@@ -192,7 +192,7 @@ struct RangeDecLane {
 
     // queue.rs:968-1033 with a tabulated model; returns the symbol index
     template <int MODE>
-    __device__ __forceinline__ uint32_t step(const void* lut, const uint32_t* cdf, const uint16_t* bucket, int bucket_shift,
+    __device__ __forceinline__ uint32_t step(const DecLut lut, const uint32_t* cdf, const uint16_t* bucket, int bucket_shift,
                                              int n_symbols, int P) {
         const uint32_t q = peek_quantile(P);
         const uint32_t next_word = in.peek();
