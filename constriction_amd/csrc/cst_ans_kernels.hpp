@@ -101,6 +101,45 @@ __device__ __forceinline__ uint32_t ans_encode_step_32x64(uint32_t& lo, uint32_t
     return emit ? 1u : 0u;
 }
 
+// Hand-scheduled form of the same step (W,S) = (32,64), 8 <= P <= 24: 22 instructions, fixed scratch registers
+// v[120:134] so that every 64-bit operand of v_mad_u64_u32 is a register pair written in place (the compiler's
+// version spends ~10 v_mov per step assembling such pairs).  Also performs the ring write of the candidate word and
+// the emit-count update.  Hazards: two instructions separate every VALU write of vcc from its VALU reader.
+//   ring_addr : LDS byte address of this lane's ring slot for word index `wr`
+//   pshl = p << (32-P), k = 2^P - p, ck = c + k
+__device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t ring_addr,
+                                                    const EncEntry e, uint32_t pshl, uint32_t k, uint32_t ck) {
+    uint64_t sdummy;
+    asm volatile(
+        "v_cmp_ge_u32 vcc, %[hi], %[pshl]\n\t"                       // emit <=> (state >> (64-P)) >= p
+        "ds_write_b32 %[ra], %[lo]\n\t"                             // candidate word, always written
+        "v_mov_b32 v123, 0\n\t"
+        "v_cndmask_b32_e64 v120, %[lo], %[hi], vcc\n\t"             // a0 = emit ? hi : lo
+        "v_cndmask_b32_e64 v121, %[hi], 0, vcc\n\t"                 // a1 = emit ? 0 : hi          A = v[120:121]
+        "v_addc_co_u32 %[wr], vcc, 0, %[wr], vcc\n\t"               // wr += emit
+        "v_mul_hi_u32 v122, v120, %[m0]\n\t"                        // W = [hi32(a0*m0), 0]
+        "v_mov_b32 v127, 0\n\t"
+        "v_mad_u64_u32 v[124:125], vcc, v121, %[m0], v[122:123]\n\t" // U = a1*m0 + W
+        "v_mov_b32 v126, v124\n\t"                                  // X = [U_lo, 0]
+        "v_mad_u64_u32 v[128:129], vcc, v120, %[m1], v[126:127]\n\t" // V = a0*m1 + U_lo
+        "v_add_co_u32 v130, vcc, v125, v129\n\t"                    // S = U_hi + V_hi (33 bits)
+        "v_addc_co_u32 v131, vcc, 0, v123, vcc\n\t"
+        "v_mad_u64_u32 v[132:133], vcc, v121, %[m1], v[130:131]\n\t" // Q = a1*m1 + S = q_est in {q-1, q}
+        "v_mul_lo_u32 v134, v132, %[p]\n\t"
+        "v_sub_u32 v134, v120, v134\n\t"                            // estimated remainder (true value < 2p)
+        "v_cmp_ge_u32 vcc, v134, %[p]\n\t"                          // fix <=> q = q_est + 1
+        "v_mad_u64_u32 v[124:125], %[sd], v132, %[k], v[120:121]\n\t" // T = A + q_lo*k
+        "v_mad_u32_u24 v125, v133, %[k], v125\n\t"                  // T_hi += q_hi*k   (q_hi < 2^24, k < 2^24)
+        "v_cndmask_b32 v134, %[c], %[ck], vcc\n\t"                  // d = c + (fix ? k : 0)
+        "v_add_co_u32 %[lo], vcc, v124, v134\n\t"                   // state' = T + d
+        "v_addc_co_u32 %[hi], vcc, 0, v125, vcc"
+        : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [sd] "=&s"(sdummy)
+        : [ra] "v"(ring_addr), [pshl] "v"(pshl), [m0] "v"(e.m_lo), [m1] "v"(e.m_hi), [p] "v"(e.p), [k] "v"(k), [c] "v"(e.c),
+          [ck] "v"(ck)
+        : "vcc", "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
+          "v132", "v133", "v134");
+}
+
 // number of W-bit words the state serialises to (bit_array_to_chunks_truncated, src/lib.rs:719-731)
 template <int W, int S>
 __device__ __forceinline__ int state_word_count(typename StateT<S>::type st) {
@@ -166,15 +205,24 @@ __device__ __forceinline__ void tile_fetch(const int32_t* __restrict__ sym, size
                                            size_t t0, int lane, int32_t (&r)[kTileSyms]) {
     if constexpr (VEC) {
         const int chunk = lane & 7;
+        if (s0 + kWave <= n_streams) {   // wave-uniform common case: no per-row predication
+            const int32_t* src = sym + (s0 + (size_t)(lane >> 3)) * N + t0 + 4 * chunk;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
-            int4 v = make_int4(0, 0, 0, 0);
-            if (s < n_streams) {
-                const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(sym + s * N + t0 + 4 * chunk));
-                v = make_int4(t.x, t.y, t.z, t.w);
+            for (int k = 0; k < 8; ++k) {
+                const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + (size_t)(8 * k) * N));
+                r[4 * k + 0] = t.x; r[4 * k + 1] = t.y; r[4 * k + 2] = t.z; r[4 * k + 3] = t.w;
             }
-            r[4 * k + 0] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
+                int4 v = make_int4(0, 0, 0, 0);
+                if (s < n_streams) {
+                    const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(sym + s * N + t0 + 4 * chunk));
+                    v = make_int4(t.x, t.y, t.z, t.w);
+                }
+                r[4 * k + 0] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
+            }
         }
     } else {
         const int col = lane & 31;
@@ -214,12 +262,21 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
         int4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const int4*>(tile + ((lane >> 3) + 8 * k) * kTileStride + 4 * chunk);
+        if (s0 + kWave <= n_streams) {   // wave-uniform common case: no per-row predication
+            int32_t* dst = sym + (s0 + (size_t)(lane >> 3)) * N + t0 + 4 * chunk;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
-            if (s < n_streams) {
+            for (int k = 0; k < 8; ++k) {
                 v4i t; t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
-                __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(sym + s * N + t0 + 4 * chunk));
+                __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(dst + (size_t)(8 * k) * N));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t s = s0 + (size_t)((lane >> 3) + 8 * k);
+                if (s < n_streams) {
+                    v4i t; t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(sym + s * N + t0 + 4 * chunk));
+                }
             }
         }
     } else {
@@ -238,6 +295,9 @@ __device__ __forceinline__ void tile_store(int32_t* __restrict__ sym, size_t n_s
 // per-lane word rings in LDS (layout [slot][lane]: every access is bank-conflict free)
 // ------------------------------------------------------------------------------------------------
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const lds_u32*)p; }
+
 // Output side.  Positions are counted in words from `base16`, the 16-byte aligned address at or below the
 // slab start (`shift` = slab start - base16, 0..3), so that every 4-aligned position group is one aligned
 // 16-B chunk of HBM.  A coder step writes its candidate word unconditionally and advances `wr` only if the
@@ -250,8 +310,10 @@ struct RingWriter {
     uint32_t* base16;
     uint32_t* ring;     // this wave's ring [kRingSlots][kWave]
     int lane;
+    uint32_t lane_addr; // LDS byte address of ring[0][lane]
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        lane_addr = lds_addr(wave_ring + lane_);
         // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
         shift = (uint32_t)((reinterpret_cast<uintptr_t>(slab) & 15) >> 2);
         base16 = slab - shift;
@@ -272,8 +334,10 @@ struct RingWriter {
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (flushed + 4 <= end) {
+                // `flushed` is a multiple of 4 and so is the ring size: the four slots are base + i * kWave
+                const uint32_t* b = slot(flushed);
                 uint4 v;
-                v.x = *slot(flushed + 0); v.y = *slot(flushed + 1); v.z = *slot(flushed + 2); v.w = *slot(flushed + 3);
+                v.x = b[0]; v.y = b[kWave]; v.z = b[2 * kWave]; v.w = b[3 * kWave];
                 if (flushed >= shift && flushed + 4 - shift <= cap) {
                     *reinterpret_cast<uint4*>(base16 + flushed) = v;
                 } else {
@@ -329,7 +393,7 @@ struct RingReader {
         base16 = in - shift;
         ring = wave_ring; lane = lane_; rd = len;
 #pragma unroll
-        for (int k = 0; k < kMaxChunksPerPoint; ++k) pend_pos[k] = -1;
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) { pend_pos[k] = -1; pend[k] = make_uint4(0, 0, 0, 0); }
     }
 
     // direct HBM access to word `i` of the stream (initial-state words)
@@ -343,7 +407,8 @@ struct RingReader {
         while (lo_issued > want_lo) {
             lo_issued -= 4;
             const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
-            *slot(lo_issued + 0) = v.x; *slot(lo_issued + 1) = v.y; *slot(lo_issued + 2) = v.z; *slot(lo_issued + 3) = v.w;
+            uint32_t* b = slot(lo_issued);   // chunk positions are multiples of 4: slots are base + i * kWave
+            b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
         }
     }
 
@@ -352,14 +417,40 @@ struct RingReader {
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (pend_pos[k] >= 0) {
-                const uint32_t p = (uint32_t)pend_pos[k];
-                *slot(p + 0) = pend[k].x; *slot(p + 1) = pend[k].y; *slot(p + 2) = pend[k].z; *slot(p + 3) = pend[k].w;
+                uint32_t* b = slot((uint32_t)pend_pos[k]);
+                b[0] = pend[k].x; b[kWave] = pend[k].y; b[2 * kWave] = pend[k].z; b[3 * kWave] = pend[k].w;
             }
         }
         const uint32_t top = rd + shift;
         const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (lo_issued > want_lo) {
+                lo_issued -= 4;
+                pend_pos[k] = (int32_t)lo_issued;
+                pend[k] = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            } else {
+                pend_pos[k] = -1;
+            }
+        }
+    }
+
+    // Same point with a fixed shape: K chunk slots, the landing of ALL of them unconditional (slots without a
+    // request land in the lane's dump rows `dump[i * kWave]`).  With the conditional form the compiler cannot see
+    // that "no request" implies "nothing in flight" and protects the registers of pend[] with vmcnt(0) waits
+    // right behind the loads of the same point, which exposes a full HBM round trip per tile.
+    template <int K>
+    __device__ __forceinline__ void advance_window_fixed(uint32_t* dump) {
+        static_assert(K <= kMaxChunksPerPoint, "pend[] too small");
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t* b = pend_pos[k] >= 0 ? slot((uint32_t)pend_pos[k]) : dump;
+            b[0] = pend[k].x; b[kWave] = pend[k].y; b[2 * kWave] = pend[k].z; b[3 * kWave] = pend[k].w;
+        }
+        const uint32_t top = rd + shift;
+        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             if (lo_issued > want_lo) {
                 lo_issued -= 4;
                 pend_pos[k] = (int32_t)lo_issued;
@@ -394,8 +485,13 @@ struct EncLane {
         uint32_t word, emit;
         if constexpr (W == 32 && S == 64 && FAST) {
             uint32_t lo = (uint32_t)state, hi = (uint32_t)(state >> 32);
-            emit = ans_encode_step_32x64(lo, hi, e, e.p << (32 - P), (1u << P) - e.p, word);
+            const uint32_t k = (1u << P) - e.p;
+            // ring slot address as (pos << 8 & 0x3f00) | lane_addr: one v_add_lshl + one v_and_or (the kernel checks
+            // that the wave's ring is 16-KiB aligned)
+            const uint32_t ra = (((out.wr + out.shift) << 8) & (uint32_t)((kRingSlots - 1) * kWave * 4)) | out.lane_addr;
+            ans_encode_step_asm(lo, hi, out.wr, ra, e, e.p << (32 - P), k, e.c + k);
             state = ((uint64_t)hi << 32) | lo;
+            return;
         } else {
             emit = ans_encode_step<W, S>(state, e, P, word);
         }
@@ -431,13 +527,15 @@ __device__ __forceinline__ uint32_t enc_index(int32_t sym, int32_t min_symbol, u
 template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
+    // LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][encoder table][symbol tiles]
+    constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem + kRingBytes);
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + table_bytes) + wave_in_block * kRingWords;
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + table_bytes + (size_t)(kBlock / kWave) * kRingWords * 4) +
-                    wave_in_block * (kWave * kTileStride);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
+    if constexpr (FAST) { if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap(); }
 
     // stage the encoder table once per workgroup (16 B per lane per pass, coalesced)
     for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
@@ -502,21 +600,25 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 L.flush_chunks();   // words of the previous tile: stores issued together with the loads, a whole tile
                                     // before anything waits on vmcnt again
                 const int32_t* my = tile + lane * kTileStride;
-                // Walk this lane's row backwards, 4 symbols per LDS read.  The table entries of group j-1
-                // are fetched before the dependent chain of group j runs (they do not depend on the state).
-                int4 v = *reinterpret_cast<const int4*>(my + 4 * (kTileSyms / 4 - 1));
+                // Walk this lane's row backwards, 4 symbols per LDS read.  Software pipeline: the symbols of group
+                // j-2 are requested and the table entries of group j-1 are fetched before the dependent chain of
+                // group j runs (none of it depends on the state), so no LDS latency is exposed inside the tile.
+                constexpr int NG = kTileSyms / 4;
+                int4 v = *reinterpret_cast<const int4*>(my + 4 * (NG - 1));
+                int4 vn = *reinterpret_cast<const int4*>(my + 4 * (NG - 2));
                 EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
                          e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
 #pragma unroll
-                for (int j = kTileSyms / 4 - 1; j >= 0; --j) {
+                for (int j = NG - 1; j >= 0; --j) {
                     EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
+                    int4 vnn = vn;
+                    if (j > 1) vnn = *reinterpret_cast<const int4*>(my + 4 * (j - 2));
                     if (j > 0) {
-                        v = *reinterpret_cast<const int4*>(my + 4 * (j - 1));
-                        n3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)];
-                        n1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
+                        n3 = table[enc_index(vn.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(vn.z, a.min_symbol, nsym, L.bad)];
+                        n1 = table[enc_index(vn.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(vn.x, a.min_symbol, nsym, L.bad)];
                     }
                     L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
-                    e3 = n3; e2 = n2; e1 = n1; e0 = n0;
+                    e3 = n3; e2 = n2; e1 = n1; e0 = n0; vn = vnn;
                     if (j % G == 0 && j != 0) L.flush_chunks();   // static mid-tile points (G < 8 only)
                 }
             }
@@ -563,99 +665,92 @@ struct DecLane {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Speculative decode step for (W,S) = (32,64), 8 <= P <= 13, LUT in LDS  
+// Hand-scheduled decode of one 32-symbol tile for (W,S) = (32,64), 8 <= P <= 12, tables in LDS  
 //
-// The decoder's critical path is  state -> quantile -> LDS lookup -> multiply -> refill? -> state.  The LDS
-// round trip (~100 cycles here) dominates it, so BOTH possible next lookups are issued before the refill
-// decision is known:
-//   no refill: the next quantile is ((state >> P) mod 2^P) * p + (q - c)  mod 2^P      (3 ops after the entry arrives)
-//   refill   : the next quantile is the low P bits of the next compressed word         (known a step earlier)
-// and the entry that belongs to the actual outcome is selected when the data returns.  The refill test itself
-// (64-bit multiply-add, compare) runs in the shadow of the lookups.
+// A lone wave per SIMD (the C2 shape: 65536 streams = 1024 waves) issues one instruction of ANY kind every 4
+// cycles, dependent VALU results forward without extra latency, and an LDS round trip is ~60 cycles.  A decode
+// step is the serial chain   entry c|p -> N = (state >> P) * p + (q - c) -> refill? -> state' -> q' -> LDS lookup,
+// so its floor is  (chain instructions) * 4 + one LDS latency.  The whole tile is ONE asm statement so that
+//   * the chain is exactly 10 instructions from the arrival of an entry to the issue of the next lookup,
+//   * everything else of the step (symbol fetch, ring read of the next candidate word, the shifted state halves
+//     for the next step, the read-position update) is issued in the shadow of that lookup,
+//   * waits are counted by hand: lgkmcnt(2|3) at the top of a step = "the entry is back, the younger symbol and
+//     ring reads may still fly", lgkmcnt(0) in the slot between the refill compare and its first select,
+//   * the refill predicate lives in vcc for exactly one step; carries go to a scratch SGPR pair.
+// LDS image (stage_tile_tables):  cp[q] = c | p << 16 at lut+0,  sym[q] = decoded int32 symbol at lut+16384.
+// Registers v120..v142 are scratch of the statement (64-bit operands of v_mad_u64_u32 are real register pairs).
+//   v[120:121] N   v[122:123] [q-c, 0]   v124 p   v125,v126 (state >> P) halves   v127 lookup address
+//   v128 entry     v129 candidate word   v131 ring address   v132 min(rd,1)   v133 q   v134..v141 symbols   v142 spare
 // ------------------------------------------------------------------------------------------------
-struct SpecDec {
-    uint32_t lo, hi;     // coder state
-    uint32_t q;          // quantile of the current state
-    uint32_t e;          // its table entry  c | p << 16
-    uint32_t nw;         // ring word at the read position (before the deferred select of the previous step)
-    uint32_t nw2;        // ring word below it (in flight until spec step's first wait)
-    uint64_t pred;       // did the previous step refill?
-    // LDS byte addresses
-    uint32_t cp_base, idx_base;
-};
+constexpr uint32_t kTileLutBytes = 32768;    // cp[4096] + sym[4096]
+constexpr int kTileAsmChunks = 3;            // 32 symbols of <= 12 bits: at most 12 words = 3 chunks per tile
+constexpr uint32_t kTileDumpBytes = (kBlock / kWave) * 4 * kWave * 4;   // landing area of unused chunk slots
+constexpr uint32_t kTileSymOffset = 16384;
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const lds_u32*)p; }
+#define CST_DEC_STEP(TOPW, SYM, TAIL)                                                                               \
+    "s_waitcnt lgkmcnt(" #TOPW ")\n\t"                                                                              \
+    "v_sub_u32_sdwa v122, v133, v128 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"       \
+    "v_lshrrev_b32 v124, 16, v128\n\t"                                                                              \
+    "v_mad_u64_u32 v[120:121], %[sd], v125, v124, v[122:123]\n\t"                                                   \
+    "v_mad_u32_u24 v121, v126, v124, v121\n\t"                                                                      \
+    "v_cmp_lt_u32 vcc, v121, v132\n\t"                                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                      \
+    "v_cndmask_b32 %[lo], v120, v129, vcc\n\t"                                                                      \
+    "v_and_b32 v133, %[mask], %[lo]\n\t"                                                                            \
+    "v_lshl_add_u32 v127, v133, 2, %[lut]\n\t"                                                                      \
+    "ds_read_b32 v128, v127\n\t"                                                                                    \
+    "v_subbrev_co_u32 %[rd], %[sd], 0, %[rd], vcc\n\t"                                                              \
+    "v_add_lshl_u32 v131, %[rd], %[shm1], 8\n\t"                                                                    \
+    "v_and_or_b32 v131, v131, %[c3f00], %[lanebase]\n\t"                                                            \
+    "ds_read_b32 v129, v131\n\t"                                                                                    \
+    "ds_read_b32 " SYM ", v127 offset:16384\n\t"                                                                    \
+    "v_cndmask_b32 %[hi], v121, v120, vcc\n\t"                                                                      \
+    "v_min_u32 v132, 1, %[rd]\n\t"                                                                                  \
+    "v_alignbit_b32 v125, %[hi], %[lo], %[P]\n\t"                                                                   \
+    "v_lshrrev_b32 v126, %[P], %[hi]\n\t" TAIL
 
-__device__ __forceinline__ void spec_init(SpecDec& D, uint64_t state, const RingReader& in, const DecLut lut, uint32_t mask) {
-    D.lo = (uint32_t)state; D.hi = (uint32_t)(state >> 32);
-    D.q = D.lo & mask;
-    D.e = lut.cp[D.q];
-    D.nw = *in.slot(in.rd - 1u + in.shift);
-    D.nw2 = D.nw;
-    D.pred = 0;
-    D.cp_base = lds_addr(lut.cp); D.idx_base = lds_addr(lut.idx);
-}
+// steps 4k .. 4k+3: symbols 4k+1 .. 4k+4 are fetched (the first three complete quad Q0, the fourth opens quad Q1);
+// the finished quad leaves for the tile row (one 16-B LDS write) at the end of its last step
+#define CST_DEC_QUAD(TOPW0, A1, A2, A3, B0, WRITE)                                                                  \
+    CST_DEC_STEP(TOPW0, A1, "") CST_DEC_STEP(2, A2, "") CST_DEC_STEP(2, A3, "") CST_DEC_STEP(2, B0, WRITE)
 
-// One symbol.  All four LDS reads of a step are issued together by hand (inline asm, invisible to the compiler's
-// lgkmcnt bookkeeping) in the order  EB, EA, next-next word, symbol index : one wave's DS operations are served and
-// returned in order, each random access costing ~20 cycles of service time, so the two speculative table reads go
-// first and are waited for with lgkmcnt(2); the other two are only needed a step later.
-//   idx_out  : symbol index of this step -- IN FLIGHT on return; `settle_idx` (or the next step) orders its consumers
-//   idx_tie  : the previous step's idx_out, which is complete once this step's lgkmcnt(2) wait has passed
-__device__ __forceinline__ void spec_decode_step(SpecDec& D, RingReader& in, uint32_t mask, int P, uint32_t& idx_out,
-                                                 uint32_t& idx_tie) {
-    // deferred select of the previous step: next word = refill ? ring[rd-2] : ring[rd-1]; its data (nw2) is the
-    // second-youngest outstanding read
-    uint32_t nw;
-    asm volatile("s_waitcnt lgkmcnt(1)\n\tv_cndmask_b32 %0, %1, %2, %3" : "=v"(nw) : "v"(D.nw), "v"(D.nw2), "s"(D.pred) : "memory");
-    const uint32_t p = D.e >> 16;
-    const uint32_t rem = D.q - (D.e & 0xffffu);
-    // candidate A (no refill) and candidate B (refill: quantile = low bits of the next word)
-    const uint32_t qA = (__umul24((D.lo >> P) & mask, p) + rem) & mask;
-    const uint32_t qB = nw & mask;
-    uint32_t EA, EB, nw2;
+// Decodes symbols [0, 32) of the current tile into the lane's tile row (LDS).  On return every LDS operation of
+// the statement has completed.
+__device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t lut_addr, uint32_t mask,
+                                                  uint32_t P, uint32_t tile_row_addr, uint32_t shift_minus_1,
+                                                  uint32_t ring_lane_addr) {
+    uint64_t sd;
     asm volatile(
-        "ds_read_b32 %0, %4\n\t"
-        "ds_read_b32 %1, %5\n\t"
-        "ds_read_b32 %2, %6\n\t"
-        "ds_read_u16 %3, %7"
-        : "=&v"(EB), "=&v"(EA), "=&v"(nw2), "=&v"(idx_out)
-        : "v"(D.cp_base + 4u * qB), "v"(D.cp_base + 4u * qA), "v"(lds_addr(in.slot(in.rd - 2u + in.shift))),
-          "v"(D.idx_base + 2u * D.q)
-        : "memory");
-    // exact state update on 32-bit halves (stack.rs:1086-1088); the high product fits mul_u24 because P >= 8
-    const uint32_t s_lo = __builtin_amdgcn_alignbit(D.hi, D.lo, P), s_hi = D.hi >> P;
-    const uint64_t t = (uint64_t)s_lo * p + (uint64_t)rem;
-    const uint32_t t_lo = (uint32_t)t;
-    const uint32_t t_hi = __umul24(s_hi, p) + (uint32_t)(t >> 32);
-    // refill <=> t < 2^32 and words remain <=> t_hi < min(rd, 1)   (stack.rs:1089-1097)
-    uint32_t new_lo, new_hi, new_rd, new_q, have;
-    uint64_t pred;
-    asm volatile(
-        "v_min_u32 %4, %6, 1\n\t"
-        "v_cmp_lt_u32 vcc, %7, %4\n\t"
-        "s_mov_b64 %5, vcc\n\t"
-        "s_nop 0\n\t"
-        "v_cndmask_b32 %0, %8, %9, vcc\n\t"           // lo' = refill ? next_word : t_lo
-        "v_cndmask_b32 %1, %7, %8, vcc\n\t"           // hi' = refill ? t_lo : t_hi
-        "v_cndmask_b32 %3, %10, %11, vcc\n\t"         // q'  = refill ? qB : qA
-        "v_subbrev_co_u32 %2, vcc, 0, %6, vcc"          // rd' = rd - refill
-        : "=&v"(new_lo), "=&v"(new_hi), "=&v"(new_rd), "=&v"(new_q), "=&v"(have), "=&s"(pred)
-        : "v"(in.rd), "v"(t_hi), "v"(t_lo), "v"(nw), "v"(qA), "v"(qB)
-        : "vcc");
-    in.rd = new_rd;
-    // entry select once the two table reads are back (the two younger reads stay in flight)
-    uint32_t e_next;
-    asm volatile("s_waitcnt lgkmcnt(2)\n\tv_cndmask_b32 %0, %2, %3, %4"
-                 : "=v"(e_next), "+v"(idx_tie) : "v"(EA), "v"(EB), "s"(pred) : "memory");
-    D.lo = new_lo; D.hi = new_hi; D.q = new_q; D.e = e_next; D.nw = nw; D.nw2 = nw2; D.pred = pred;
-}
-
-// orders the consumers of in-flight symbol indices after their arrival
-__device__ __forceinline__ void settle_idx(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
-__device__ __forceinline__ void settle_idx4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+        // prologue: first lookup, candidate word, shifted state
+        "v_mov_b32 v123, 0\n\t"
+        "v_and_b32 v133, %[mask], %[lo]\n\t"
+        "v_lshl_add_u32 v127, v133, 2, %[lut]\n\t"
+        "ds_read_b32 v128, v127\n\t"
+        "ds_read_b32 v134, v127 offset:16384\n\t"
+        "v_add_lshl_u32 v131, %[rd], %[shm1], 8\n\t"
+        "v_and_or_b32 v131, v131, %[c3f00], %[lanebase]\n\t"
+        "ds_read_b32 v129, v131\n\t"
+        "v_min_u32 v132, 1, %[rd]\n\t"
+        "v_alignbit_b32 v125, %[hi], %[lo], %[P]\n\t"
+        "v_lshrrev_b32 v126, %[P], %[hi]\n\t"
+        CST_DEC_QUAD(2, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:0\n\t")
+        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:16\n\t")
+        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:32\n\t")
+        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:48\n\t")
+        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:64\n\t")
+        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:80\n\t")
+        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:96\n\t")
+        CST_DEC_QUAD(3, "v139", "v140", "v141", "v142", "ds_write_b128 %[tile], v[138:141] offset:112\n\t")
+        "s_waitcnt lgkmcnt(0)"
+        : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [sd] "=&s"(sd)
+        : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [c3f00] "s"(0x3f00u), [tile] "v"(tile_row_addr),
+          [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr)
+        : "vcc",
+#ifndef CST_EXP_NO_MEMCLOBBER
+          "memory",
+#endif
+          "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
+          "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142");
 }
 
 // DecoderModel::quantile_function for a tabulated model (lookup_contiguous.rs:564-605): quantile -> (index, left
@@ -665,7 +760,8 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
                                                 int bucket_shift, int n_symbols, uint32_t& idx, uint32_t& c, uint32_t& p) {
     if constexpr (MODE == kDecLutCP) {
         const uint32_t e = lut.cp[q];
-        c = e & 0xffffu; p = e >> 16; idx = lut.idx[q];
+        c = e & 0xffffu; p = e >> 16;
+        idx = lut.sym ? (uint32_t)(lut.sym[q] - lut.min_symbol) : (uint32_t)lut.idx[q];
     } else {
         // bucket[q >> shift] = first index whose bin reaches into the bucket; scan forward
         idx = bucket[q >> bucket_shift];
@@ -760,9 +856,28 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
     return lds_off;
 }
 
+// Is the hand-scheduled tile decoder used for this instantiation?  (host and kernel must agree: it changes the
+// LDS image of the tables).  G == 8 <=> P <= 12 for W = 32 (groups_per_point).
+constexpr bool decode_uses_tile_asm(int W, int S, int MODE, bool LUT_IN_LDS, int G, bool FAST) {
+    return FAST && W == 32 && S == 64 && MODE == kDecLutCP && LUT_IN_LDS && G == 8;
+}
+
+// LDS image for ans_decode_tile32: cp[2^P] at +0, decoded symbols (int32) at +kTileSymOffset
+__device__ __forceinline__ void stage_tile_tables(unsigned char* lds, int P, const uint32_t* dec_cp, const uint16_t* dec_idx,
+                                                  int32_t min_symbol, DecLut& lut) {
+    uint32_t* l = reinterpret_cast<uint32_t*>(lds);
+    int32_t* x = reinterpret_cast<int32_t*>(lds + kTileSymOffset);
+    const int n = 1 << P;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { l[i] = dec_cp[i]; x[i] = min_symbol + (int32_t)dec_idx[i]; }
+    lut.cp = l; lut.idx = nullptr; lut.sym = x; lut.min_symbol = min_symbol;
+}
+
+// LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][tables][symbol tiles]
 template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool TILE_ASM = decode_uses_tile_asm(W, S, MODE, LUT_IN_LDS, G, FAST);
+    constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
     const int P = a.precision;
@@ -771,12 +886,17 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     DecLut lut{};
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    size_t lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
-                                                           a.n_symbols, lut, cdf, bucket);
-    lds_off = (lds_off + 15) & ~(size_t)15;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + lds_off) + wave_in_block * kRingWords;
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + lds_off + (size_t)(kBlock / kWave) * kRingWords * 4) +
-                    wave_in_block * (kWave * kTileStride);
+    size_t lds_off;
+    if constexpr (TILE_ASM) {
+        stage_tile_tables(smem + kRingBytes, P, a.dec_cp, a.dec_idx, a.min_symbol, lut);
+        lds_off = kTileLutBytes;
+    } else {
+        lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem + kRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+                                                         a.n_symbols, lut, cdf, bucket);
+        lds_off = (lds_off + 15) & ~(size_t)15;
+    }
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRingBytes + lds_off) + wave_in_block * (kWave * kTileStride);
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -795,38 +915,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     L.in.prime();
     wave_lds_fence();
 
-    constexpr bool SPEC = FAST && W == 32 && S == 64 && MODE == kDecLutCP && LUT_IN_LDS;
-    [[maybe_unused]] SpecDec D;
-    [[maybe_unused]] const uint32_t qmask = (1u << P) - 1u;
-    if constexpr (SPEC) { spec_init(D, (uint64_t)L.state, L.in, lut, qmask); wave_lds_fence(); }
     // one symbol (tails, symbol-major layout)
     auto next_index = [&]() -> uint32_t {
-        if constexpr (SPEC) {
-            uint32_t idx, tie = 0;
-            spec_decode_step(D, L.in, qmask, P, idx, tie);
-            settle_idx(idx);
-            return idx;
-        } else {
-            return ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
-        }
-    };
-    // four symbols
-    auto next_four = [&]() -> int4 {
-        int4 v;
-        if constexpr (SPEC) {
-            uint32_t i0, i1, i2, i3, tie = 0;
-            spec_decode_step(D, L.in, qmask, P, i0, tie);
-            spec_decode_step(D, L.in, qmask, P, i1, i0);
-            spec_decode_step(D, L.in, qmask, P, i2, i1);
-            spec_decode_step(D, L.in, qmask, P, i3, i2);
-            settle_idx4(i0, i1, i2, i3);
-            v.x = a.min_symbol + (int32_t)i0; v.y = a.min_symbol + (int32_t)i1;
-            v.z = a.min_symbol + (int32_t)i2; v.w = a.min_symbol + (int32_t)i3;
-        } else {
-            v.x = a.min_symbol + (int32_t)next_index(); v.y = a.min_symbol + (int32_t)next_index();
-            v.z = a.min_symbol + (int32_t)next_index(); v.w = a.min_symbol + (int32_t)next_index();
-        }
-        return v;
+        return ans_decode_step<W, S, MODE, FAST>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
     };
 
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
@@ -841,20 +932,44 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         int32_t* row = a.symbols + (active ? s : 0) * N;
         const size_t n_full = N / kTileSyms;
         int32_t* my = tile + lane * kTileStride;
-        for (size_t tb = 0; tb < n_full; ++tb) {
-#pragma unroll
-            for (int j = 0; j < kTileSyms / 4; ++j) {
-                const int4 v = next_four();
-                *reinterpret_cast<int4*>(my + 4 * j) = v;
+        if constexpr (TILE_ASM) {
+            // the ring address is formed with v_and_or: this wave's ring must be 16-KiB aligned in LDS
+            if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap();
+            uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+            const uint32_t qmask = (1u << P) - 1u;
+            const uint32_t lut_addr = lds_addr(lut.cp), row_addr = lds_addr(my), lane_addr = lds_addr(ring + lane);
+            uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRingBytes + lds_off + (size_t)(kBlock / kWave) * kWave * kTileStride * 4) +
+                             wave_in_block * (4 * kWave) + lane;
+            // Settle every load of the prologue here: otherwise the compiler's wait-count bookkeeping merges
+            // "state still loading" (loop entry) with "window chunks in flight" (back edge) into a vmcnt(0) at the
+            // top of every tile, which would expose the HBM latency of the window loads once per tile.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            for (size_t tb = 0; tb < n_full; ++tb) {
+                ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, row_addr, L.in.shift - 1u, lane_addr);
 #ifndef CST_EXP_NO_ADVANCE
-                if ((j + 1) % G == 0) L.in.advance_window();   // static schedule
+                L.in.template advance_window_fixed<kTileAsmChunks>(dump);
 #endif
-            }
-            wave_lds_fence();
+                wave_lds_fence();
 #ifndef CST_EXP_NO_TILE_STORE
-            tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+                tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
 #endif
-            wave_lds_fence();
+                wave_lds_fence();
+            }
+            L.state = ((uint64_t)hi << 32) | lo;
+        } else {
+            for (size_t tb = 0; tb < n_full; ++tb) {
+#pragma unroll
+                for (int j = 0; j < kTileSyms / 4; ++j) {
+                    int4 v;
+                    v.x = a.min_symbol + (int32_t)next_index(); v.y = a.min_symbol + (int32_t)next_index();
+                    v.z = a.min_symbol + (int32_t)next_index(); v.w = a.min_symbol + (int32_t)next_index();
+                    *reinterpret_cast<int4*>(my + 4 * j) = v;
+                    if ((j + 1) % G == 0) L.in.advance_window();   // static schedule
+                }
+                wave_lds_fence();
+                tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+                wave_lds_fence();
+            }
         }
         for (size_t t = n_full * kTileSyms; t < N; ++t) {
             const uint32_t idx = next_index();
@@ -862,7 +977,6 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
             L.in.advance_window();
         }
     }
-    if constexpr (SPEC) L.state = ((uint64_t)D.hi << 32) | D.lo;
 
     if (!active) return;
     a.status[s] = L.status;

@@ -51,7 +51,7 @@ static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, h
 template <int W, int S>
 static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     // FAST = the 32-bit-halves step of the (32,64) preset, valid for P >= 8
-    static const bool env_fast = getenv("CST_ENC_FAST") ? atoi(getenv("CST_ENC_FAST")) != 0 : false; // A/B knob: the compiler-scheduled 32-bit-halves form is currently slower
+    static const bool env_fast = getenv("CST_ENC_FAST") ? atoi(getenv("CST_ENC_FAST")) != 0 : true; // A/B knob: hand-scheduled asm step vs the generic compiler-scheduled one
     const bool fast = (W == 32) && a.precision >= 8 && env_fast;
     switch (groups_per_point(W, a.precision)) {
         case 8: return fast ? encode_dispatch_g<W, S, 8, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 8, false>(a, layout, hs);
@@ -63,6 +63,7 @@ static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hip
 // ---- decode dispatch ----
 template <int W, int S, int MODE, bool LDS, int G, bool FAST>
 static cst_status decode_dispatch3(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
+    if (decode_uses_tile_asm(W, S, MODE, LDS, G, FAST)) table_lds = kTileLutBytes + kTileDumpBytes;   // (dump rows sit behind the tiles)
     const size_t lds = ((table_lds + 15) & ~(size_t)15) + kTileBytesPerBlock;
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
         return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G, FAST>, a.n_streams, lds, hs, a);

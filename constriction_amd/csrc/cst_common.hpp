@@ -36,8 +36,10 @@ enum DecMode : int {
 };
 
 struct DecLut {      // pointers into LDS or global memory
-    const uint32_t* cp;
-    const uint16_t* idx;
+    const uint32_t* cp;     // c | p << 16 per quantile
+    const uint16_t* idx;    // symbol index per quantile ...
+    const int32_t* sym;     // ... or, if non-null, the decoded symbol itself (idx + min_symbol)
+    int32_t min_symbol;
 };
 
 } // namespace cst
