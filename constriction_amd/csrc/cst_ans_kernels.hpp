@@ -140,6 +140,140 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
           "v132", "v133", "v134");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hand-scheduled encode of one 32-symbol tile for (W,S) = (32,64), 8 <= P <= 12  
+//
+// The encoder's table entries do not depend on the coder state, so the only serial chain is arithmetic and the
+// tile is bound by instruction issue (one instruction of any kind per 4 cycles for a lone wave).  One asm
+// statement per tile: 25 instructions per symbol for the step itself (same arithmetic as ans_encode_step_asm, the
+// zero halves of its register pairs set once per tile) plus 3.75 for the software pipeline around it:
+//   quad j (4 symbols, walked backwards):  request the symbols of quad j-2 (one 16-B LDS read of the lane's tile
+//   row), fetch the four 16-B table entries of quad j-1, then run the four steps of quad j.
+// LDS returns in order, so the hand-counted waits are: lgkmcnt(8) = "symbols of quad j-1 are back" (4 entry
+// reads and 4 ring writes are younger), lgkmcnt(9) = "entries of quad j are back".
+// A symbol outside the model's support reads a garbage entry (LDS never faults) and only corrupts its own stream,
+// which is reported through smin/smax (the caller turns them into CST_STREAM_IMPOSSIBLE_SYMBOL).
+//   v100..v111  three symbol quads     v112..v143  two sets of four entries {c, p, m_lo, m_hi}
+//   v[144:145] A   v[146:147] [w,0]   v[148:149] U/T   v[150:151] [U_lo,0]   v[152:153] V   v[154:155] sum
+//   v[156:157] Q   v158 r/d   v159 p << (32-P)   v160 k   v161 c+k   v162 ring address   v163 entry address
+// ------------------------------------------------------------------------------------------------
+#define CST_ENC_STEP(C, PP, M0, M1)                                                                                 \
+    "v_lshlrev_b32 v159, %[shP], " PP "\n\t"                                                                        \
+    "v_sub_u32 v160, %[twoP], " PP "\n\t"                                                                           \
+    "v_add_lshl_u32 v162, %[wr], %[shift], 8\n\t"                                                                   \
+    "v_cmp_ge_u32 vcc, %[hi], v159\n\t"                                                                             \
+    "v_and_or_b32 v162, v162, %[c3f00], %[lanebase]\n\t"                                                            \
+    "v_add_u32 v161, " C ", v160\n\t"                                                                               \
+    "v_cndmask_b32_e64 v144, %[lo], %[hi], vcc\n\t"                                                                 \
+    "v_cndmask_b32_e64 v145, %[hi], 0, vcc\n\t"                                                                     \
+    "ds_write_b32 v162, %[lo]\n\t"                                                                                  \
+    "v_addc_co_u32 %[wr], vcc, 0, %[wr], vcc\n\t"                                                                   \
+    "v_mul_hi_u32 v146, v144, " M0 "\n\t"                                                                           \
+    "v_mad_u64_u32 v[148:149], vcc, v145, " M0 ", v[146:147]\n\t"                                                   \
+    "v_mov_b32 v150, v148\n\t"                                                                                      \
+    "v_mad_u64_u32 v[152:153], vcc, v144, " M1 ", v[150:151]\n\t"                                                   \
+    "v_add_co_u32 v154, vcc, v149, v153\n\t"                                                                        \
+    "v_addc_co_u32 v155, vcc, 0, v147, vcc\n\t"                                                                     \
+    "v_mad_u64_u32 v[156:157], vcc, v145, " M1 ", v[154:155]\n\t"                                                   \
+    "v_mul_lo_u32 v158, v156, " PP "\n\t"                                                                           \
+    "v_sub_u32 v158, v144, v158\n\t"                                                                                \
+    "v_cmp_ge_u32 vcc, v158, " PP "\n\t"                                                                            \
+    "v_mad_u64_u32 v[148:149], %[sd], v156, v160, v[144:145]\n\t"                                                   \
+    "v_mad_u32_u24 v149, v157, v160, v149\n\t"                                                                      \
+    "v_cndmask_b32 v158, " C ", v161, vcc\n\t"                                                                      \
+    "v_add_co_u32 %[lo], vcc, v148, v158\n\t"                                                                       \
+    "v_addc_co_u32 %[hi], vcc, 0, v149, vcc\n\t"
+
+// entry sets (consumption order: symbol .w first)
+#define CST_ENC_STEPS_E0 CST_ENC_STEP("v112", "v113", "v114", "v115") CST_ENC_STEP("v116", "v117", "v118", "v119")  \
+                         CST_ENC_STEP("v120", "v121", "v122", "v123") CST_ENC_STEP("v124", "v125", "v126", "v127")
+#define CST_ENC_STEPS_E1 CST_ENC_STEP("v128", "v129", "v130", "v131") CST_ENC_STEP("v132", "v133", "v134", "v135")  \
+                         CST_ENC_STEP("v136", "v137", "v138", "v139") CST_ENC_STEP("v140", "v141", "v142", "v143")
+#define CST_ENC_FETCH1(SYM, E) "v_lshl_add_u32 v163, " SYM ", 4, %[tbl]\n\tds_read_b128 " E ", v163\n\t"
+// fetch the entries of symbols (X,Y,Z,W) of a quad into a set, .w first, and fold the quad into smin/smax
+#define CST_ENC_FETCH_E0(X, Y, Z, W)                                                                                \
+    CST_ENC_FETCH1(W, "v[112:115]") CST_ENC_FETCH1(Z, "v[116:119]") CST_ENC_FETCH1(Y, "v[120:123]") CST_ENC_FETCH1(X, "v[124:127]") \
+    CST_ENC_MINMAX(X, Y, Z, W)
+#define CST_ENC_FETCH_E1(X, Y, Z, W)                                                                                \
+    CST_ENC_FETCH1(W, "v[128:131]") CST_ENC_FETCH1(Z, "v[132:135]") CST_ENC_FETCH1(Y, "v[136:139]") CST_ENC_FETCH1(X, "v[140:143]") \
+    CST_ENC_MINMAX(X, Y, Z, W)
+#define CST_ENC_MINMAX(X, Y, Z, W)                                                                                  \
+    "v_max3_i32 %[smax], %[smax], " X ", " Y "\n\tv_max3_i32 %[smax], %[smax], " Z ", " W "\n\t"                     \
+    "v_min3_i32 %[smin], %[smin], " X ", " Y "\n\tv_min3_i32 %[smin], %[smin], " Z ", " W "\n\t"
+#define CST_ENC_S0 "v100", "v101", "v102", "v103"
+#define CST_ENC_S1 "v104", "v105", "v106", "v107"
+#define CST_ENC_S2 "v108", "v109", "v110", "v111"
+#define CST_ENC_FETCH_E0_(S) CST_ENC_FETCH_E0(S)
+#define CST_ENC_FETCH_E1_(S) CST_ENC_FETCH_E1(S)
+
+// Encodes symbols [31 .. 0] of the lane's tile row (LDS), last symbol first.  On return every LDS operation of the
+// statement has completed.  smin/smax accumulate the smallest/largest symbol seen.
+__device__ __forceinline__ void ans_encode_tile32(uint32_t& lo, uint32_t& hi, uint32_t& wr, int32_t& smin, int32_t& smax,
+                                                  uint32_t tile_row_addr, uint32_t table_addr_biased, uint32_t P,
+                                                  uint32_t shift, uint32_t ring_lane_addr) {
+    uint64_t sd;
+    asm volatile(
+        "v_mov_b32 v147, 0\n\t"
+        "v_mov_b32 v151, 0\n\t"
+        "ds_read_b128 v[100:103], %[tile] offset:112\n\t"      // quad 7 -> S0
+        "ds_read_b128 v[104:107], %[tile] offset:96\n\t"       // quad 6 -> S1
+        "s_waitcnt lgkmcnt(1)\n\t"
+        CST_ENC_FETCH_E0_(CST_ENC_S0)
+        // quad 7
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "ds_read_b128 v[108:111], %[tile] offset:80\n\t"       // quad 5 -> S2
+        CST_ENC_FETCH_E1_(CST_ENC_S1)
+        "s_waitcnt lgkmcnt(5)\n\t"
+        CST_ENC_STEPS_E0
+        // quad 6
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "ds_read_b128 v[100:103], %[tile] offset:64\n\t"       // quad 4 -> S0
+        CST_ENC_FETCH_E0_(CST_ENC_S2)
+        "s_waitcnt lgkmcnt(9)\n\t"
+        CST_ENC_STEPS_E1
+        // quad 5
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "ds_read_b128 v[104:107], %[tile] offset:48\n\t"       // quad 3 -> S1
+        CST_ENC_FETCH_E1_(CST_ENC_S0)
+        "s_waitcnt lgkmcnt(9)\n\t"
+        CST_ENC_STEPS_E0
+        // quad 4
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "ds_read_b128 v[108:111], %[tile] offset:32\n\t"       // quad 2 -> S2
+        CST_ENC_FETCH_E0_(CST_ENC_S1)
+        "s_waitcnt lgkmcnt(9)\n\t"
+        CST_ENC_STEPS_E1
+        // quad 3
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "ds_read_b128 v[100:103], %[tile] offset:16\n\t"       // quad 1 -> S0
+        CST_ENC_FETCH_E1_(CST_ENC_S2)
+        "s_waitcnt lgkmcnt(9)\n\t"
+        CST_ENC_STEPS_E0
+        // quad 2
+        "s_waitcnt lgkmcnt(8)\n\t"
+        "ds_read_b128 v[104:107], %[tile]\n\t"                 // quad 0 -> S1
+        CST_ENC_FETCH_E0_(CST_ENC_S0)
+        "s_waitcnt lgkmcnt(9)\n\t"
+        CST_ENC_STEPS_E1
+        // quad 1
+        "s_waitcnt lgkmcnt(8)\n\t"
+        CST_ENC_FETCH_E1_(CST_ENC_S1)
+        "s_waitcnt lgkmcnt(8)\n\t"
+        CST_ENC_STEPS_E0
+        // quad 0
+        "s_waitcnt lgkmcnt(4)\n\t"
+        CST_ENC_STEPS_E1
+        "s_waitcnt lgkmcnt(0)"
+        : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [smin] "+v"(smin), [smax] "+v"(smax), [sd] "=&s"(sd)
+        : [tile] "v"(tile_row_addr), [tbl] "s"(table_addr_biased), [shP] "s"(32u - P), [twoP] "s"(1u << P),
+          [c3f00] "s"(0x3f00u), [shift] "v"(shift), [lanebase] "v"(ring_lane_addr)
+        : "vcc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+          "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",
+          "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",
+          "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",
+          "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163");
+}
+
 // number of W-bit words the state serialises to (bit_array_to_chunks_truncated, src/lib.rs:719-731)
 template <int W, int S>
 __device__ __forceinline__ int state_word_count(typename StateT<S>::type st) {
@@ -335,9 +469,15 @@ struct RingWriter {
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (flushed + 4 <= end) {
                 // `flushed` is a multiple of 4 and so is the ring size: the four slots are base + i * kWave
+#ifdef CST_EXP_FLUSH_NOP
+                flushed += 4; continue;
+#endif
                 const uint32_t* b = slot(flushed);
                 uint4 v;
                 v.x = b[0]; v.y = b[kWave]; v.z = b[2 * kWave]; v.w = b[3 * kWave];
+#ifdef CST_EXP_FLUSH_NOSTORE
+                asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); flushed += 4; continue;
+#endif
                 if (flushed >= shift && flushed + 4 - shift <= cap) {
                     *reinterpret_cast<uint4*>(base16 + flushed) = v;
                 } else {
@@ -590,37 +730,54 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
             L.flush_chunks();
         }
         if (n_full > 0) {
+            constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8;
+            [[maybe_unused]] int32_t smin = a.min_symbol, smax = a.min_symbol;
             int32_t r[kTileSyms];
             tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
             for (size_t tb = n_full; tb-- > 0;) {
                 wave_lds_fence();
                 tile_to_lds<VEC>(tile, lane, r);
                 wave_lds_fence();
+#ifndef CST_EXP_NO_FETCH
                 if (tb > 0) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r); // prefetch
+#endif
+#ifndef CST_EXP_NO_FLUSH
                 L.flush_chunks();   // words of the previous tile: stores issued together with the loads, a whole tile
                                     // before anything waits on vmcnt again
+#endif
                 const int32_t* my = tile + lane * kTileStride;
-                // Walk this lane's row backwards, 4 symbols per LDS read.  Software pipeline: the symbols of group
-                // j-2 are requested and the table entries of group j-1 are fetched before the dependent chain of
-                // group j runs (none of it depends on the state), so no LDS latency is exposed inside the tile.
-                constexpr int NG = kTileSyms / 4;
-                int4 v = *reinterpret_cast<const int4*>(my + 4 * (NG - 1));
-                int4 vn = *reinterpret_cast<const int4*>(my + 4 * (NG - 2));
-                EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
-                         e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
+                if constexpr (TILE_ASM) {
+                    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
+                    ans_encode_tile32(lo, hi, L.out.wr, smin, smax, lds_addr(my), lds_addr(table) - 16u * (uint32_t)a.min_symbol,
+                                      (uint32_t)P, L.out.shift, L.out.lane_addr);
+                    L.state = ((uint64_t)hi << 32) | lo;
+                } else {
+                    // Walk this lane's row backwards, 4 symbols per LDS read.  Software pipeline: the symbols of group
+                    // j-2 are requested and the table entries of group j-1 are fetched before the dependent chain of
+                    // group j runs (none of it depends on the state), so no LDS latency is exposed inside the tile.
+                    constexpr int NG = kTileSyms / 4;
+                    int4 v = *reinterpret_cast<const int4*>(my + 4 * (NG - 1));
+                    int4 vn = *reinterpret_cast<const int4*>(my + 4 * (NG - 2));
+                    EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
+                             e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
 #pragma unroll
-                for (int j = NG - 1; j >= 0; --j) {
-                    EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
-                    int4 vnn = vn;
-                    if (j > 1) vnn = *reinterpret_cast<const int4*>(my + 4 * (j - 2));
-                    if (j > 0) {
-                        n3 = table[enc_index(vn.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(vn.z, a.min_symbol, nsym, L.bad)];
-                        n1 = table[enc_index(vn.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(vn.x, a.min_symbol, nsym, L.bad)];
+                    for (int j = NG - 1; j >= 0; --j) {
+                        EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
+                        int4 vnn = vn;
+                        if (j > 1) vnn = *reinterpret_cast<const int4*>(my + 4 * (j - 2));
+                        if (j > 0) {
+                            n3 = table[enc_index(vn.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(vn.z, a.min_symbol, nsym, L.bad)];
+                            n1 = table[enc_index(vn.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(vn.x, a.min_symbol, nsym, L.bad)];
+                        }
+                        L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
+                        e3 = n3; e2 = n2; e1 = n1; e0 = n0; vn = vnn;
+                        if (j % G == 0 && j != 0) L.flush_chunks();   // static mid-tile points (G < 8 only)
                     }
-                    L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
-                    e3 = n3; e2 = n2; e1 = n1; e0 = n0; vn = vnn;
-                    if (j % G == 0 && j != 0) L.flush_chunks();   // static mid-tile points (G < 8 only)
                 }
+            }
+            if constexpr (TILE_ASM) {
+                // fold the extremes into `bad` (largest raw table index): a symbol below min_symbol wraps to a huge index
+                L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
             }
         }
     }
@@ -711,7 +868,8 @@ constexpr uint32_t kTileSymOffset = 16384;
 
 // steps 4k .. 4k+3: symbols 4k+1 .. 4k+4 are fetched (the first three complete quad Q0, the fourth opens quad Q1);
 // the finished quad leaves for the tile row (one 16-B LDS write) at the end of its last step
-#define CST_DEC_QUAD(TOPW0, A1, A2, A3, B0, WRITE)                                                                  \
+#define CST_DEC_QUAD(TOPW0, A1, A2, A3, B0, WRITE) CST_DEC_QUAD_(TOPW0, A1, A2, A3, B0, WRITE)
+#define CST_DEC_QUAD_(TOPW0, A1, A2, A3, B0, WRITE)                                                                 \
     CST_DEC_STEP(TOPW0, A1, "") CST_DEC_STEP(2, A2, "") CST_DEC_STEP(2, A3, "") CST_DEC_STEP(2, B0, WRITE)
 
 // Decodes symbols [0, 32) of the current tile into the lane's tile row (LDS).  On return every LDS operation of
@@ -733,14 +891,16 @@ __device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, ui
         "v_min_u32 v132, 1, %[rd]\n\t"
         "v_alignbit_b32 v125, %[hi], %[lo], %[P]\n\t"
         "v_lshrrev_b32 v126, %[P], %[hi]\n\t"
-        CST_DEC_QUAD(2, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:0\n\t")
-        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:16\n\t")
-        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:32\n\t")
-        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:48\n\t")
-        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:64\n\t")
-        CST_DEC_QUAD(3, "v139", "v140", "v141", "v134", "ds_write_b128 %[tile], v[138:141] offset:80\n\t")
-        CST_DEC_QUAD(3, "v135", "v136", "v137", "v138", "ds_write_b128 %[tile], v[134:137] offset:96\n\t")
-        CST_DEC_QUAD(3, "v139", "v140", "v141", "v142", "ds_write_b128 %[tile], v[138:141] offset:112\n\t")
+#define CST_DEC_WR(REGS, OFF) "ds_write_b128 %[tile], " REGS " offset:" #OFF "\n\t"
+#define CST_DEC_W1 3
+        CST_DEC_QUAD(2, "v135", "v136", "v137", "v138", CST_DEC_WR("v[134:137]", 0))
+        CST_DEC_QUAD(CST_DEC_W1, "v139", "v140", "v141", "v134", CST_DEC_WR("v[138:141]", 16))
+        CST_DEC_QUAD(CST_DEC_W1, "v135", "v136", "v137", "v138", CST_DEC_WR("v[134:137]", 32))
+        CST_DEC_QUAD(CST_DEC_W1, "v139", "v140", "v141", "v134", CST_DEC_WR("v[138:141]", 48))
+        CST_DEC_QUAD(CST_DEC_W1, "v135", "v136", "v137", "v138", CST_DEC_WR("v[134:137]", 64))
+        CST_DEC_QUAD(CST_DEC_W1, "v139", "v140", "v141", "v134", CST_DEC_WR("v[138:141]", 80))
+        CST_DEC_QUAD(CST_DEC_W1, "v135", "v136", "v137", "v138", CST_DEC_WR("v[134:137]", 96))
+        CST_DEC_QUAD(CST_DEC_W1, "v139", "v140", "v141", "v142", CST_DEC_WR("v[138:141]", 112))
         "s_waitcnt lgkmcnt(0)"
         : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [sd] "=&s"(sd)
         : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [c3f00] "s"(0x3f00u), [tile] "v"(tile_row_addr),
