@@ -515,6 +515,8 @@ struct RingWriter {
 };
 
 // Input side (stack semantics: words are consumed from the END of the stream's buffer).
+// SLOTS words of ring per lane; AHEAD = words kept requested below the read position.
+template <int SLOTS = kRingSlots, int AHEAD = kAhead>
 struct RingReader {
     uint32_t rd;           // words not yet consumed (next word has stream index rd-1)
     uint32_t shift;
@@ -525,7 +527,7 @@ struct RingReader {
     uint4 pend[kMaxChunksPerPoint];
     int32_t pend_pos[kMaxChunksPerPoint];
 
-    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
+    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (SLOTS - 1)) * kWave + lane); }
 
     __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint32_t* wave_ring, int lane_) {
         // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
@@ -543,11 +545,23 @@ struct RingReader {
     __device__ __forceinline__ void prime() {
         const uint32_t top = rd + shift;
         lo_issued = (top + 3) & ~3u;
-        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+        const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
         while (lo_issued > want_lo) {
             lo_issued -= 4;
             const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
             uint32_t* b = slot(lo_issued);   // chunk positions are multiples of 4: slots are base + i * kWave
+            b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
+        }
+    }
+
+    // blocking top-up of the window from wherever it stands (used once, between the first tile and the main loop)
+    __device__ __forceinline__ void refill_blocking() {
+        const uint32_t top = rd + shift;
+        const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
+        while (lo_issued > want_lo) {
+            lo_issued -= 4;
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            uint32_t* b = slot(lo_issued);
             b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
         }
     }
@@ -562,7 +576,7 @@ struct RingReader {
             }
         }
         const uint32_t top = rd + shift;
-        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+        const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (lo_issued > want_lo) {
@@ -588,7 +602,7 @@ struct RingReader {
             b[0] = pend[k].x; b[kWave] = pend[k].y; b[2 * kWave] = pend[k].z; b[3 * kWave] = pend[k].w;
         }
         const uint32_t top = rd + shift;
-        const uint32_t want_lo = top > (uint32_t)kAhead ? top - kAhead : 0u;
+        const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (lo_issued > want_lo) {
@@ -795,12 +809,12 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
 // ------------------------------------------------------------------------------------------------
 
 // Per-lane ANS decoder: coder state + the word ring that runs ahead of the read position.
-template <int W, int S>
+template <int W, int S, int SLOTS = kRingSlots, int AHEAD = kAhead>
 struct DecLane {
     using st_t = typename StateT<S>::type;
     st_t state;
     int32_t status;
-    RingReader in;
+    RingReader<SLOTS, AHEAD> in;
 
     __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
         in.init(words, len, wave_ring, lane_);
@@ -876,7 +890,7 @@ constexpr uint32_t kTileSymOffset = 16384;
 // the statement has completed.
 __device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t lut_addr, uint32_t mask,
                                                   uint32_t P, uint32_t tile_row_addr, uint32_t shift_minus_1,
-                                                  uint32_t ring_lane_addr) {
+                                                  uint32_t ring_lane_addr, uint32_t ring_mask) {
     uint64_t sd;
     asm volatile(
         // prologue: first lookup, candidate word, shifted state
@@ -903,7 +917,7 @@ __device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, ui
         CST_DEC_QUAD(CST_DEC_W1, "v139", "v140", "v141", "v142", CST_DEC_WR("v[138:141]", 112))
         "s_waitcnt lgkmcnt(0)"
         : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [sd] "=&s"(sd)
-        : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [c3f00] "s"(0x3f00u), [tile] "v"(tile_row_addr),
+        : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [c3f00] "s"(ring_mask), [tile] "v"(tile_row_addr),
           [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr)
         : "vcc",
 #ifndef CST_EXP_NO_MEMCLOBBER
@@ -911,6 +925,29 @@ __device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, ui
 #endif
           "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
           "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142");
+}
+
+// Main loop of the same decoder: tiles 1 .. n_tiles of a FULL wave in one asm statement (generated, with its wait
+// counts, by scripts/gen_decode_loop.py).  Per iteration it
+//   * requests up to kDecChunks 16-B chunks of compressed words (exec-masked global loads relative to `words_base`)
+//     at the top and lands them in the ring at the bottom (vmcnt(8): the eight stores of the iteration are younger),
+//   * decodes 32 symbols exactly like ans_decode_tile32 into the lane's row of the CURRENT tile buffer,
+//   * streams the PREVIOUS tile buffer to HBM in the idle issue slots of the steps: quad k reads rows
+//     (lane >> 3) + 8k, chunk (lane & 7) (one 16-B LDS read) and stores it at store_base + goff[k] (128-B row
+//     segments, eight rows per instruction), then swaps the buffers and advances store_base by 128 B.
+// The decode chain leaves ~6 idle issue slots per symbol (it waits on the LDS lookup), so this work is free.
+// The compiler sees no vector-memory instruction in the loop, hence no conservative vmcnt(0) of its own.
+constexpr int kDecRingSlots = 32;            // ring words per lane for this decoder (8 KiB per wave, 8-KiB aligned)
+constexpr int kDecAhead = 24;                // two tiles of at most 12 words each
+constexpr uint32_t kDecRingMask = (kDecRingSlots - 1) * kWave * 4;
+
+__device__ __forceinline__ void ans_decode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued,
+                                                      uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev,
+                                                      uint32_t lut_addr, uint32_t mask, uint32_t P, uint32_t ring_mask,
+                                                      const void* words_base, uint64_t store_base, uint32_t n_tiles,
+                                                      uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                      uint32_t words_off, const uint32_t (&goff)[8]) {
+#include "cst_decode_loop.inc"
 }
 
 // DecoderModel::quantile_function for a tabulated model (lookup_contiguous.rs:564-605): quantile -> (index, left
@@ -933,8 +970,8 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
 }
 
 // One branch-free decode step (stack.rs:1084-1097): returns the symbol index.
-template <int W, int S, int MODE, bool FAST>
-__device__ __forceinline__ uint32_t ans_decode_step(DecLane<W, S>& L, const DecLut lut, const uint32_t* cdf,
+template <int W, int S, int MODE, bool FAST, class LANE>
+__device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, const uint32_t* cdf,
                                                     const uint16_t* bucket, int bucket_shift, int n_symbols, int P) {
     using st_t = typename StateT<S>::type;
     const uint32_t qmask = (P >= 32) ? 0xffffffffu : ((1u << P) - 1u);
@@ -1032,12 +1069,21 @@ __device__ __forceinline__ void stage_tile_tables(unsigned char* lds, int P, con
     lut.cp = l; lut.idx = nullptr; lut.sym = x; lut.min_symbol = min_symbol;
 }
 
-// LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][tables][symbol tiles]
+// LDS bytes of a decode workgroup that uses the hand-scheduled tile decoder:
+// [rings 4 x 8 KiB][cp + sym tables 32 KiB][two symbol tiles per wave][dump rows]
+constexpr size_t kDecTileAsmLdsBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4 + kTileLutBytes +
+                                       2 * (size_t)(kBlock / kWave) * kWave * kTileStride * 4 + kTileDumpBytes;
+
+// LDS layout: [word rings: one per wave, aligned to their size][tables][symbol tiles][dump rows (tile asm only)]
 template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool TILE_ASM = decode_uses_tile_asm(W, S, MODE, LUT_IN_LDS, G, FAST);
-    constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
+    constexpr int SLOTS = TILE_ASM ? kDecRingSlots : kRingSlots;
+    constexpr int AHEAD = TILE_ASM ? kDecAhead : kAhead;
+    constexpr size_t kWaveRingWords = (size_t)SLOTS * kWave;
+    constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kWaveRingWords * 4;
+    constexpr size_t kTileWords = (size_t)kWave * kTileStride;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
     const int P = a.precision;
@@ -1055,8 +1101,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                                                          a.n_symbols, lut, cdf, bucket);
         lds_off = (lds_off + 15) & ~(size_t)15;
     }
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRingBytes + lds_off) + wave_in_block * (kWave * kTileStride);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kWaveRingWords;
+    // tile asm: two tile buffers per wave (A, B), the B buffers behind all A buffers
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRingBytes + lds_off) + wave_in_block * kTileWords;
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1068,7 +1115,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     const int bucket_shift = P - a.bucket_bits;
 
-    DecLane<W, S> L;
+    DecLane<W, S, SLOTS, AHEAD> L;
     L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
     if (raw) L.state = active ? (typename StateT<S>::type)a.state[s] : 0;
     else L.read_initial_state();
@@ -1093,26 +1140,57 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         const size_t n_full = N / kTileSyms;
         int32_t* my = tile + lane * kTileStride;
         if constexpr (TILE_ASM) {
-            // the ring address is formed with v_and_or: this wave's ring must be 16-KiB aligned in LDS
-            if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap();
+            // the ring address is formed with v_and_or: this wave's ring must be aligned to its size
+            if ((lds_addr(ring) & (uint32_t)(kWaveRingWords * 4 - 1)) != 0) __builtin_trap();
             uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
             const uint32_t qmask = (1u << P) - 1u;
-            const uint32_t lut_addr = lds_addr(lut.cp), row_addr = lds_addr(my), lane_addr = lds_addr(ring + lane);
-            uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRingBytes + lds_off + (size_t)(kBlock / kWave) * kWave * kTileStride * 4) +
+            const uint32_t lut_addr = lds_addr(lut.cp), lane_addr = lds_addr(ring + lane);
+            int32_t* tile_b = tile + (kBlock / kWave) * kTileWords;
+            uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRingBytes + lds_off + 2 * (size_t)(kBlock / kWave) * kTileWords * 4) +
                              wave_in_block * (4 * kWave) + lane;
             // Settle every load of the prologue here: otherwise the compiler's wait-count bookkeeping merges
             // "state still loading" (loop entry) with "window chunks in flight" (back edge) into a vmcnt(0) at the
             // top of every tile, which would expose the HBM latency of the window loads once per tile.
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            for (size_t tb = 0; tb < n_full; ++tb) {
-                ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, row_addr, L.in.shift - 1u, lane_addr);
-#ifndef CST_EXP_NO_ADVANCE
-                L.in.template advance_window_fixed<kTileAsmChunks>(dump);
-#endif
+
+            // The main-loop statement addresses HBM as uniform base + 32-bit lane offset: it needs a full wave, at
+            // least two tiles, rows of < 2^24 symbols and this wave's compressed words within 2 GiB of a.words.
+            const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+            const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+            const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
+            const bool use_loop = (s0 + kWave <= a.n_streams) && n_full >= 2 && N < (1u << 24) && !__any(!off_ok);
+            size_t tb = 0;
+            if (use_loop) {
+                ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, lds_addr(my), L.in.shift - 1u, lane_addr, kDecRingMask);
+                L.in.refill_blocking();
                 wave_lds_fence();
-#ifndef CST_EXP_NO_TILE_STORE
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                uint32_t goff[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+                const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+                // current = B (tile 1), previous = A (tile 0)
+                uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+                uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+                // wave-uniform store base in SGPRs (s0 is derived from threadIdx, so the compiler cannot know)
+                const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+                // (readfirstlane returns int: go through uint32_t or the low half sign-extends into the high one)
+                const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                ans_decode_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                      kDecRingMask, words_base, store_base,
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
+                // the last tile is still in LDS (buffer A if it has an even index)
+                wave_lds_fence();
+                tile_store<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                wave_lds_fence();
+                tb = n_full;
+            }
+            for (; tb < n_full; ++tb) {
+                ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, lds_addr(my), L.in.shift - 1u, lane_addr, kDecRingMask);
+                L.in.template advance_window_fixed<kTileAsmChunks>(dump);
+                wave_lds_fence();
                 tile_store<VEC>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
-#endif
                 wave_lds_fence();
             }
             L.state = ((uint64_t)hi << 32) | lo;

@@ -63,8 +63,8 @@ static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hip
 // ---- decode dispatch ----
 template <int W, int S, int MODE, bool LDS, int G, bool FAST>
 static cst_status decode_dispatch3(const AnsDecodeArgs& a, cst_layout layout, size_t table_lds, hipStream_t hs) {
-    if (decode_uses_tile_asm(W, S, MODE, LDS, G, FAST)) table_lds = kTileLutBytes + kTileDumpBytes;   // (dump rows sit behind the tiles)
-    const size_t lds = ((table_lds + 15) & ~(size_t)15) + kTileBytesPerBlock;
+    const size_t lds = decode_uses_tile_asm(W, S, MODE, LDS, G, FAST) ? kDecTileAsmLdsBytes
+                                                                      : ((table_lds + 15) & ~(size_t)15) + kTileBytesPerBlock;
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
         return launch(ans_decode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, MODE, LDS, G, FAST>, a.n_streams, lds, hs, a);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generates constriction_amd/csrc/cst_decode_loop.inc: the hand-scheduled gfx950 main loop of the (32,64) ANS
+decoder (one asm statement that decodes tiles 1..n-1 of a wave's 64 streams).
+
+Why a generator: the statement is ~800 instructions of straight-line code per loop iteration whose s_waitcnt
+operands depend on how many LDS / vector-memory operations were issued after the one being waited for.  This
+script keeps that book (one wave's LDS operations complete in order, and so do its vector-memory operations) and
+emits the counts, so that moving an instruction cannot silently break a wait.
+
+Run:  python scripts/gen_decode_loop.py   (rewrites the .inc; the .inc is checked in)
+"""
+from pathlib import Path
+
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop.inc"
+
+K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
+AHEAD_M1 = 23         # kDecAhead - 1  (want_lo = max(rd + shift - kDecAhead, 0) = sat_sub(rd + (shift-1), kDecAhead-1))
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.lds = []      # tags of LDS ops in issue order
+        self.vm = []       # tags of vector-memory ops in issue order
+
+    def i(self, text, comment=None):
+        self.lines.append((text, comment))
+
+    def ds(self, text, tag, comment=None):
+        self.lds.append(tag)
+        self.i(text, comment)
+
+    def vmem(self, text, tag, comment=None):
+        self.vm.append(tag)
+        self.i(text, comment)
+
+    def wait_lds(self, tag, comment=None):
+        """wait until the LDS op `tag` (and everything older) has completed"""
+        idx = max(k for k, t in enumerate(self.lds) if t == tag)
+        younger = len(self.lds) - 1 - idx
+        assert younger <= 15, (tag, younger)
+        self.i(f"s_waitcnt lgkmcnt({younger})", comment)
+        self.lds = self.lds[idx + 1:]
+
+    def wait_lds_all(self, comment=None):
+        self.i("s_waitcnt lgkmcnt(0)", comment)
+        self.lds = []
+
+    def wait_vm(self, tag, comment=None):
+        idx = max(k for k, t in enumerate(self.vm) if t == tag)
+        younger = len(self.vm) - 1 - idx
+        assert younger <= 63
+        self.i(f"s_waitcnt vmcnt({younger})", comment)
+        self.vm = self.vm[idx + 1:]
+
+
+import os
+NO_STORE = bool(os.environ.get("GEN_NO_STORE"))
+NO_LOAD = bool(os.environ.get("GEN_NO_LOAD"))
+
+
+def gen():
+    a = Asm()
+    # ---- fixed registers ------------------------------------------------------------------------------
+    N0, N1 = "v120", "v121"          # v[120:121] = N
+    D = "v122"                       # v[122:123] = [q - c, 0]
+    PR, T0, T1, LA, CP, WD, RA, R1, Q = "v124", "v125", "v126", "v127", "v128", "v129", "v131", "v132", "v133"
+    SYM = [f"v{134 + k}" for k in range(8)] + ["v142"]   # two quads + spare
+    X = "v[144:147]"                 # (register tuples must start at an even register on gfx950)
+    PEND = [(f"v[{148 + 4 * k}:{151 + 4 * k}]", [f"v{148 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
+    LAND = [f"v{160 + k}" for k in range(K_CHUNKS)]
+    WANT, TMP, TADDR, TOFF = "v163", "v164", "v165", "v166"
+    clobbers = [f"v{r}" for r in range(120, 167)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "memory"]
+    SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
+
+    a.i("v_mov_b32 v123, 0")
+    a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
+    a.i("s_mov_b32 s82, %[ntiles]")
+    a.i("1:", None)
+
+    # ---- window: request the chunks this tile's successor may need (landed at the end of this iteration) ----
+    a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
+    a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kDecAhead, 0)")
+    for k in range(K_CHUNKS):
+        a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
+        a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+        a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
+        a.i(f"v_lshlrev_b32 {TADDR}, 8, %[lo_issued]")
+        a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+        a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+        a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
+        a.i("s_and_saveexec_b64 s[86:87], vcc")
+        if NO_LOAD:
+            a.vm.append(f"chunk{k}")
+        else:
+            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+        a.i("s_mov_b64 exec, s[86:87]")
+
+    # ---- first lookup of the tile ----
+    a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
+    a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
+    a.ds(f"ds_read_b32 {CP}, {LA}", "cp")
+    a.ds(f"ds_read_b32 {SYM[0]}, {LA} offset:16384", "sym0")
+    a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+    a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+    a.ds(f"ds_read_b32 {WD}, {RA}", "w")
+    a.i(f"v_min_u32 {R1}, 1, %[rd]")
+    a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+    a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+
+    for j in range(32):
+        quad, pos = divmod(j, 4)
+        # symbol j+1 goes to: quad registers alternate between SYM[0:4] and SYM[4:8]; symbol 32 to the spare
+        nxt = j + 1
+        sym_reg = SYM[8] if nxt == 32 else SYM[(nxt // 4 % 2) * 4 + nxt % 4]
+        a.wait_lds("cp", f"---- step {j}: entry is back")
+        a.i(f"v_sub_u32_sdwa {D}, {Q}, {CP} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "q - c")
+        a.i(f"v_lshrrev_b32 {PR}, 16, {CP}", "p")
+        a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
+        a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+        a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
+        a.wait_lds_all("candidate word (and everything older) is back")
+        a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
+        a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
+        a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
+        a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
+        a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
+        a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+        a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+        a.ds(f"ds_read_b32 {WD}, {RA}", "w")
+        a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
+        if pos == 1:
+            a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
+        a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
+        a.i(f"v_min_u32 {R1}, 1, %[rd]")
+        a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+        a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        if pos == 2:
+            # x was issued in step pos 1 and is covered by this step's lgkmcnt(0)
+            if NO_STORE:
+                a.vm.append(f"store{quad}")
+            else:
+                a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] nt", f"store{quad}")
+        if pos == 3:
+            base = (quad % 2) * 4
+            a.ds(f"ds_write_b128 %[rowcur], v[{134 + base}:{137 + base}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
+
+    a.wait_lds_all("---- end of tile")
+    a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
+    for k in range(K_CHUNKS):
+        r = PEND[k][1]
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+    a.i("v_swap_b32 %[rowcur], %[rowprev]")
+    a.i("v_swap_b32 %[trcur], %[trprev]")
+    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_addc_u32 s81, s81, 0")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.wait_lds_all("landed chunks visible to the next tile")
+    a.i("s_cbranch_scc1 1b")
+    return a, clobbers
+
+
+def main():
+    a, clobbers = gen()
+    out = []
+    out.append("// GENERATED by scripts/gen_decode_loop.py -- do not edit by hand (edit the generator and re-run it).")
+    out.append("// Main loop of the hand-scheduled (32,64) ANS decoder: see ans_decode_tiles_loop in cst_ans_kernels.hpp.")
+    out.append("asm volatile(")
+    for text, comment in a.lines:
+        sep = "\\n" if text.endswith(":") else "\\n\\t"
+        line = f'    "{text}{sep}"'
+        if comment:
+            line = f"{line:<118}// {comment}"
+        out.append(line)
+    out.append('    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),')
+    out.append('      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)')
+    out.append('    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),')
+    out.append('      [ntiles] "s"(n_tiles), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),')
+    out.append('      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)))
+    out.append("    : " + ", ".join(f'"{c}"' for c in clobbers) + ");")
+    OUT.write_text("\n".join(out) + "\n")
+    n_instr = sum(1 for t, _ in a.lines if not t.endswith(":"))
+    print(f"wrote {OUT} ({n_instr} instructions per iteration incl. loop control)")
+
+
+if __name__ == "__main__":
+    main()
