@@ -189,7 +189,11 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
                          CST_ENC_STEP("v120", "v121", "v122", "v123") CST_ENC_STEP("v124", "v125", "v126", "v127")
 #define CST_ENC_STEPS_E1 CST_ENC_STEP("v128", "v129", "v130", "v131") CST_ENC_STEP("v132", "v133", "v134", "v135")  \
                          CST_ENC_STEP("v136", "v137", "v138", "v139") CST_ENC_STEP("v140", "v141", "v142", "v143")
+#ifdef CST_EXP_ENC_SAMEENTRY
+#define CST_ENC_FETCH1(SYM, E) "v_lshl_add_u32 v163, v147, 4, %[tbl]\n\tds_read_b128 " E ", v163\n\t"
+#else
 #define CST_ENC_FETCH1(SYM, E) "v_lshl_add_u32 v163, " SYM ", 4, %[tbl]\n\tds_read_b128 " E ", v163\n\t"
+#endif
 // fetch the entries of symbols (X,Y,Z,W) of a quad into a set, .w first, and fold the quad into smin/smax
 #define CST_ENC_FETCH_E0(X, Y, Z, W)                                                                                \
     CST_ENC_FETCH1(W, "v[112:115]") CST_ENC_FETCH1(Z, "v[116:119]") CST_ENC_FETCH1(Y, "v[120:123]") CST_ENC_FETCH1(X, "v[124:127]") \

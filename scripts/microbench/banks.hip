@@ -24,15 +24,19 @@ template <int KIND> __device__ __forceinline__ void body() {
     if constexpr (KIND == 13) asm volatile("v_mul_hi_u32 v10, v10, v21" ::: CLOBS);
     if constexpr (KIND == 14) asm volatile("v_mul_hi_u32 v9, v9, v24\n\tv_mul_hi_u32 v10, v10, v24\n\tv_mul_hi_u32 v11, v11, v24" ::: CLOBS);
     if constexpr (KIND == 15) asm volatile("v_xor_b32 v9, v9, v24\n\ts_nop 0\n\tv_xor_b32 v10, v10, v24\n\ts_nop 0" ::: CLOBS);
-    if constexpr (KIND == 16) asm volatile("v_xor_b32 v9, v9, v24\n\ts_add_u32 s20, s20, 1\n\tv_xor_b32 v10, v10, v24\n\ts_add_u32 s21, s21, 1" ::: CLOBS, "s20", "s21");
-    if constexpr (KIND == 17) asm volatile("v_xor_b32 v10, v10, v21\n\ts_add_u32 s20, s20, 1" ::: CLOBS, "s20", "s21");  // dep valu + salu filler
-    if constexpr (KIND == 18) asm volatile("v_xor_b32 v10, v10, v21\n\tds_read_b32 v15, v26" ::: CLOBS);                // dep valu + lds filler
+    // 8 instructions per body so that the s_nop the compiler puts between asm statements is amortised
+    if constexpr (KIND == 16) asm volatile("v_xor_b32 v9, v10, v24\n\tv_xor_b32 v9, v11, v24\n\tv_xor_b32 v9, v10, v24\n\tv_xor_b32 v9, v11, v24\n\tv_xor_b32 v9, v10, v24\n\tv_xor_b32 v9, v11, v24\n\tv_xor_b32 v9, v10, v24\n\tv_xor_b32 v9, v11, v24" ::: CLOBS);  // WAW only
+    if constexpr (KIND == 17) asm volatile("v_xor_b32 v9, v10, v24\n\tv_xor_b32 v12, v9, v24\n\tv_xor_b32 v13, v12, v24\n\tv_xor_b32 v14, v13, v24\n\tv_xor_b32 v15, v14, v24\n\tv_xor_b32 v16, v15, v24\n\tv_xor_b32 v17, v16, v24\n\tv_xor_b32 v10, v17, v24" ::: CLOBS);  // RAW chain, distinct dst
+    if constexpr (KIND == 18) asm volatile("v_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24\n\tv_xor_b32 v9, v9, v24" ::: CLOBS);  // RAW + same dst
+    if constexpr (KIND == 19) asm volatile("v_mad_u64_u32 v[10:11], s[20:21], v24, v25, v[12:13]\n\tv_mad_u32_u24 v11, v24, v25, v11\n\tv_mad_u64_u32 v[14:15], s[20:21], v24, v25, v[10:11]\n\tv_mad_u32_u24 v15, v24, v25, v15\n\tv_mad_u64_u32 v[10:11], s[20:21], v24, v25, v[14:15]\n\tv_mad_u32_u24 v11, v24, v25, v11\n\tv_mad_u64_u32 v[14:15], s[20:21], v24, v25, v[10:11]\n\tv_mad_u32_u24 v15, v24, v25, v15" ::: CLOBS, "s20", "s21");  // mad64 then mad24 into its high half
+    if constexpr (KIND == 20) asm volatile("v_mad_u64_u32 v[10:11], s[20:21], v24, v25, v[12:13]\n\tv_mad_u32_u24 v16, v24, v25, v11\n\tv_mad_u64_u32 v[14:15], s[20:21], v24, v25, v[10:11]\n\tv_mad_u32_u24 v17, v24, v25, v15\n\tv_mad_u64_u32 v[10:11], s[20:21], v24, v25, v[14:15]\n\tv_mad_u32_u24 v16, v24, v25, v11\n\tv_mad_u64_u32 v[14:15], s[20:21], v24, v25, v[10:11]\n\tv_mad_u32_u24 v17, v24, v25, v15" ::: CLOBS, "s20", "s21");  // same, separate dst
+    if constexpr (KIND == 21) asm volatile("v_xor_b32 v9, v10, v24\n\tv_xor_b32 v12, v9, v9\n\tv_xor_b32 v13, v12, v12\n\tv_xor_b32 v14, v13, v13\n\tv_xor_b32 v15, v14, v14\n\tv_xor_b32 v16, v15, v15\n\tv_xor_b32 v17, v16, v16\n\tv_xor_b32 v10, v17, v17" ::: CLOBS);  // RAW chain, both sources
 }
 static const char* kNames[] = {"dep xor (banks differ)", "dep xor (same bank srcs)", "3 indep xor", "2 chains", "2 chains one clash",
     "dep ping-pong", "dep ring of 3", "dep mad_u64_u32", "3 indep mad_u64_u32", "add_co+addc", "cmp+cndmask (vcc)",
-    "cmp+1 filler+cndmask", "cmp+2 filler+cndmask", "dep mul_hi", "3 indep mul_hi", "2 chains + s_nop each", "2 chains + s_add each",
-    "dep xor + s_add", "dep xor + ds_read"};
-static const int kInstr[] = {1, 1, 3, 2, 2, 2, 3, 1, 3, 2, 2, 3, 4, 1, 3, 4, 4, 2, 2};
+    "cmp+1 filler+cndmask", "cmp+2 filler+cndmask", "dep mul_hi", "3 indep mul_hi", "2 chains + s_nop each", "8x WAW only",
+    "8x RAW chain distinct dst", "8x RAW same dst", "4x mad64+mad24 hi (same dst)", "4x mad64+mad24 (other dst)", "8x RAW chain both srcs"};
+static const int kInstr[] = {1, 1, 3, 2, 2, 2, 3, 1, 3, 2, 2, 3, 4, 1, 3, 4, 8, 8, 8, 8, 8, 8};
 
 template <int KIND> __global__ __launch_bounds__(256) void k(uint64_t* out) {
     __shared__ uint32_t lds[1024];
@@ -59,6 +63,6 @@ template <int KIND> void run() {
 }
 int main() { setvbuf(stdout, NULL, _IONBF, 0);
     run<0>(); run<1>(); run<2>(); run<3>(); run<4>(); run<5>(); run<6>(); run<7>(); run<8>(); run<9>(); run<10>(); run<11>(); run<12>();
-    run<13>(); run<14>(); run<15>(); run<16>(); run<17>(); run<18>();
+    run<13>(); run<14>(); run<15>(); run<16>(); run<17>(); run<18>(); run<19>(); run<20>(); run<21>();
     return 0;
 }

@@ -256,6 +256,49 @@ def test_large_alphabet_lut64(B, O):
     assert np.array_equal(dec.cpu().numpy(), sym)
 
 
+@pytest.mark.parametrize("P", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("kind", ["rare", "common", "mixed"])
+def test_hand_scheduled_tiles_extremes(B, O, P, kind):
+    """The whole-tile encoder/decoder of the (32,64) preset (P <= 12) at the extremes of the word rate: every symbol
+    the rarest one (P bits each: the window and ring schedules run at their worst case, 12 words per 32-symbol tile
+    at P = 12), every symbol the most probable one (almost no words), and a mix that switches rate between streams
+    and inside a stream.  Full waves take the main-loop statement, the last partial wave the per-tile path."""
+    lo, hi = -20, 20
+    gm = O.GaussianModel(lo, hi, 0.3, 2.5, P, 32)
+    cdf = gm.cdf_table()
+    model = B.Model.quantized_gaussian(lo, hi, 0.3, 2.5, P)
+    probs = np.diff(cdf.astype(np.int64))
+    rare, common = int(np.argmin(probs)) + lo, int(np.argmax(probs)) + lo
+    n_streams, n_per = 64 * 3 + 5, 32 * 9 + 7
+    rng = np.random.default_rng(P * 31 + len(kind))
+    if kind == "rare":
+        sym = np.full((n_streams, n_per), rare, dtype=np.int32)
+    elif kind == "common":
+        sym = np.full((n_streams, n_per), common, dtype=np.int32)
+    else:
+        sym = O.synth_symbols(77, 0, n_streams, n_per, lo, cdf, P)
+        sym[::3] = rare
+        sym[1::3, : n_per // 2] = common
+        sym[1::3, n_per // 2:] = rare
+        sym[:, rng.integers(0, n_per, 40)] = hi
+    want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdf, P)
+    assert (want_status == 0).all()
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    dec, dstatus = B.ans_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    # same streams from the packed buffer: every 16-byte alignment of a stream start occurs
+    packed, offsets = B.compact(enc)
+    dec2, _ = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P))
+    torch.cuda.synchronize()
+    assert np.array_equal(dec2.cpu().numpy(), sym)
+
+
 def test_full_size_c2_properties(B, O):
     """BASELINE config C2 at full size (65 536 x 4096): round trip is the identity, and a sample of
     streams is bit-identical to the oracle."""
