@@ -189,11 +189,7 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
                          CST_ENC_STEP("v120", "v121", "v122", "v123") CST_ENC_STEP("v124", "v125", "v126", "v127")
 #define CST_ENC_STEPS_E1 CST_ENC_STEP("v128", "v129", "v130", "v131") CST_ENC_STEP("v132", "v133", "v134", "v135")  \
                          CST_ENC_STEP("v136", "v137", "v138", "v139") CST_ENC_STEP("v140", "v141", "v142", "v143")
-#ifdef CST_EXP_ENC_SAMEENTRY
-#define CST_ENC_FETCH1(SYM, E) "v_lshl_add_u32 v163, v147, 4, %[tbl]\n\tds_read_b128 " E ", v163\n\t"
-#else
 #define CST_ENC_FETCH1(SYM, E) "v_lshl_add_u32 v163, " SYM ", 4, %[tbl]\n\tds_read_b128 " E ", v163\n\t"
-#endif
 // fetch the entries of symbols (X,Y,Z,W) of a quad into a set, .w first, and fold the quad into smin/smax
 #define CST_ENC_FETCH_E0(X, Y, Z, W)                                                                                \
     CST_ENC_FETCH1(W, "v[112:115]") CST_ENC_FETCH1(Z, "v[116:119]") CST_ENC_FETCH1(Y, "v[120:123]") CST_ENC_FETCH1(X, "v[124:127]") \
@@ -276,6 +272,20 @@ __device__ __forceinline__ void ans_encode_tile32(uint32_t& lo, uint32_t& hi, ui
           "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",
           "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",
           "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163");
+}
+
+// All full tiles of a FULL wave in one asm statement (generated, with its wait counts, by scripts/gen_encode_loop.py):
+// ans_encode_tile32's steps plus, per tile, the chunk flush of the word ring (16-byte aligned slabs only), the LDS
+// staging of the tile's symbols and the request of the symbols two tiles further down (two register sets: under
+// load an HBM round trip outlasts one tile).  Nothing in it is visible to the compiler's wait-count pass.
+//   symbols_base : address of the last full tile of stream s0 (uniform);  goff[k] : byte offset of row (lane>>3)+8k,
+//   chunk (lane&7) from it;  words_base + slab_off : the lane's slab (16-byte aligned);  cap : slab capacity (% 4 == 0)
+__device__ __forceinline__ void ans_encode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                      int32_t& smax, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                      uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
+                                                      uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                      uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop.inc"
 }
 
 // number of W-bit words the state serialises to (bit_array_to_chunks_truncated, src/lib.rs:719-731)
@@ -473,15 +483,9 @@ struct RingWriter {
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (flushed + 4 <= end) {
                 // `flushed` is a multiple of 4 and so is the ring size: the four slots are base + i * kWave
-#ifdef CST_EXP_FLUSH_NOP
-                flushed += 4; continue;
-#endif
                 const uint32_t* b = slot(flushed);
                 uint4 v;
                 v.x = b[0]; v.y = b[kWave]; v.z = b[2 * kWave]; v.w = b[3 * kWave];
-#ifdef CST_EXP_FLUSH_NOSTORE
-                asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); flushed += 4; continue;
-#endif
                 if (flushed >= shift && flushed + 4 - shift <= cap) {
                     *reinterpret_cast<uint4*>(base16 + flushed) = v;
                 } else {
@@ -495,6 +499,23 @@ struct RingWriter {
                 flushed += 4;
             }
         }
+    }
+
+    // The same point for 16-byte aligned slabs (shift == 0, cap % 4 == 0) and at most K whole chunks pending: all
+    // ring reads first (one LDS wait instead of one per chunk), no ragged-chunk cases, exec-masked stores only.
+    template <int K>
+    __device__ __forceinline__ void flush_chunks_aligned() {
+        const uint32_t n = min((wr - flushed) >> 2, (uint32_t)K);
+        uint4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t* b = slot(flushed + 4 * k);
+            v[k].x = b[0]; v[k].y = b[kWave]; v[k].z = b[2 * kWave]; v[k].w = b[3 * kWave];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((uint32_t)k < n && flushed + 4 * k + 4 <= cap) *reinterpret_cast<uint4*>(base16 + flushed + 4 * k) = v[k];
+        flushed += 4 * n;
     }
 
     // rare slow path: make room for a burst (range coder carry resolution)
@@ -750,19 +771,49 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
         if (n_full > 0) {
             constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8;
             [[maybe_unused]] int32_t smin = a.min_symbol, smax = a.min_symbol;
-            int32_t r[kTileSyms];
-            tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
-            for (size_t tb = n_full; tb-- > 0;) {
+            // wave-uniform: every slab of this wave 16-byte aligned and a whole number of chunks long
+            const bool aligned_slabs = !__any(L.out.shift != 0 || (L.out.cap & 3u) != 0);
+            // ---- main loop as one asm statement (full wave, aligned slabs, 32-bit offsets) ----
+            bool done = false;
+            if constexpr (TILE_ASM) {
+                const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) -
+                                                     reinterpret_cast<const unsigned char*>(a.words));
+                const bool off_ok = slab_off + 4ull * L.out.cap < 0x100000000ull;
+                if (aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok)) {
+                    uint32_t goff[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+                    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
+                    // wave-uniform base in SGPRs (readfirstlane returns int: go through uint32_t)
+                    const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
+                    const uint32_t tr_addr = lds_addr(tile) + (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+                    ans_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, lds_addr(tile + lane * kTileStride), tr_addr,
+                                          L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
+                                          lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+                    L.state = ((uint64_t)hi << 32) | lo;
+                    done = true;
+                }
+            }
+            // Symbol tiles are prefetched TWO tiles ahead into two register sets: under full load an HBM round trip is
+            // longer than the ~2.4 us one tile takes, and a single tile of lead left ~35 cycles per symbol of vmcnt wait.
+            int32_t rA[kTileSyms], rB[kTileSyms];
+            if (!done) {
+                tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, rA);
+                if (n_full >= 2) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 2) * kTileSyms, lane, rB);
+            }
+            auto tile_body = [&](size_t tb, int32_t (&r)[kTileSyms]) {
                 wave_lds_fence();
                 tile_to_lds<VEC>(tile, lane, r);
                 wave_lds_fence();
-#ifndef CST_EXP_NO_FETCH
-                if (tb > 0) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r); // prefetch
-#endif
-#ifndef CST_EXP_NO_FLUSH
-                L.flush_chunks();   // words of the previous tile: stores issued together with the loads, a whole tile
-                                    // before anything waits on vmcnt again
-#endif
+                // words of the previous tile first (stores), then the prefetch (loads): everything younger than the
+                // OTHER register set's loads is then a store, so waiting for that set never waits for these loads
+                if (TILE_ASM && aligned_slabs) L.out.template flush_chunks_aligned<3>();   // <= 3 + 12 words pending
+                else L.flush_chunks();
+                if (tb >= 2) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb - 2) * kTileSyms, lane, r);
                 const int32_t* my = tile + lane * kTileStride;
                 if constexpr (TILE_ASM) {
                     uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
@@ -792,6 +843,11 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                         if (j % G == 0 && j != 0) L.flush_chunks();   // static mid-tile points (G < 8 only)
                     }
                 }
+            };
+            for (size_t tb = done ? 0 : n_full; tb > 0;) {
+                tile_body(--tb, rA);
+                if (tb == 0) break;
+                tile_body(--tb, rB);
             }
             if constexpr (TILE_ASM) {
                 // fold the extremes into `bad` (largest raw table index): a symbol below min_symbol wraps to a huge index
@@ -923,11 +979,7 @@ __device__ __forceinline__ void ans_decode_tile32(uint32_t& lo, uint32_t& hi, ui
         : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [sd] "=&s"(sd)
         : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [c3f00] "s"(ring_mask), [tile] "v"(tile_row_addr),
           [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr)
-        : "vcc",
-#ifndef CST_EXP_NO_MEMCLOBBER
-          "memory",
-#endif
-          "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
+        : "vcc", "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
           "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142");
 }
 

@@ -86,7 +86,9 @@ int32_t cst_device_count(void);
 /* Text of the most recent HIP error seen by the calling thread ("" if none). */
 const char *cst_last_hip_error(void);
 
-/* Upper bound on the words one stream can produce: min(n, ceil(n*P/W)) + S/W.
+/* Upper bound on the words one stream can produce, min(n, ceil(n*P/W)) + S/W, rounded up to a whole number of
+ * 16-byte units so that slabs laid out at this stride from a 16-byte aligned base are all 16-byte aligned (the
+ * kernels then move whole aligned chunks).  Any other stride remains legal.
  * (At most one word per symbol: src/stream/stack.rs:1035-1040; final state: stack.rs:891-895.) */
 size_t cst_ans_max_words(size_t n_symbols, cst_coder_config cfg);
 

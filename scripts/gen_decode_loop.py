@@ -17,41 +17,9 @@ K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits =
 AHEAD_M1 = 23         # kDecAhead - 1  (want_lo = max(rd + shift - kDecAhead, 0) = sat_sub(rd + (shift-1), kDecAhead-1))
 
 
-class Asm:
-    def __init__(self):
-        self.lines = []
-        self.lds = []      # tags of LDS ops in issue order
-        self.vm = []       # tags of vector-memory ops in issue order
-
-    def i(self, text, comment=None):
-        self.lines.append((text, comment))
-
-    def ds(self, text, tag, comment=None):
-        self.lds.append(tag)
-        self.i(text, comment)
-
-    def vmem(self, text, tag, comment=None):
-        self.vm.append(tag)
-        self.i(text, comment)
-
-    def wait_lds(self, tag, comment=None):
-        """wait until the LDS op `tag` (and everything older) has completed"""
-        idx = max(k for k, t in enumerate(self.lds) if t == tag)
-        younger = len(self.lds) - 1 - idx
-        assert younger <= 15, (tag, younger)
-        self.i(f"s_waitcnt lgkmcnt({younger})", comment)
-        self.lds = self.lds[idx + 1:]
-
-    def wait_lds_all(self, comment=None):
-        self.i("s_waitcnt lgkmcnt(0)", comment)
-        self.lds = []
-
-    def wait_vm(self, tag, comment=None):
-        idx = max(k for k, t in enumerate(self.vm) if t == tag)
-        younger = len(self.vm) - 1 - idx
-        assert younger <= 63
-        self.i(f"s_waitcnt vmcnt({younger})", comment)
-        self.vm = self.vm[idx + 1:]
+import sys
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from asmgen import Asm  # noqa: E402
 
 
 import os
@@ -164,25 +132,16 @@ def gen():
 
 def main():
     a, clobbers = gen()
-    out = []
-    out.append("// GENERATED by scripts/gen_decode_loop.py -- do not edit by hand (edit the generator and re-run it).")
-    out.append("// Main loop of the hand-scheduled (32,64) ANS decoder: see ans_decode_tiles_loop in cst_ans_kernels.hpp.")
-    out.append("asm volatile(")
-    for text, comment in a.lines:
-        sep = "\\n" if text.endswith(":") else "\\n\\t"
-        line = f'    "{text}{sep}"'
-        if comment:
-            line = f"{line:<118}// {comment}"
-        out.append(line)
-    out.append('    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),')
-    out.append('      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)')
-    out.append('    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),')
-    out.append('      [ntiles] "s"(n_tiles), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),')
-    out.append('      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)))
-    out.append("    : " + ", ".join(f'"{c}"' for c in clobbers) + ");")
-    OUT.write_text("\n".join(out) + "\n")
-    n_instr = sum(1 for t, _ in a.lines if not t.endswith(":"))
-    print(f"wrote {OUT} ({n_instr} instructions per iteration incl. loop control)")
+    header = ["// GENERATED by scripts/gen_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Main loop of the hand-scheduled (32,64) ANS decoder: see ans_decode_tiles_loop in cst_ans_kernels.hpp."]
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
+           '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
+           '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
+           '      [ntiles] "s"(n_tiles), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),',
+           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
+    OUT.write_text(a.render(header, ops))
+    print(f"wrote {OUT} ({a.n_instr()} instructions per iteration incl. loop control)")
 
 
 if __name__ == "__main__":
