@@ -779,7 +779,9 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) -
                                                      reinterpret_cast<const unsigned char*>(a.words));
                 const bool off_ok = slab_off + 4ull * L.out.cap < 0x100000000ull;
-                if (aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok)) {
+                // the statement writes whole 64-byte groups: slabs 64-byte aligned and a whole number of groups long
+                const bool groups_ok = (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 && (L.out.cap & 15u) == 0 && L.out.shift == 0;
+                if (aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok || !groups_ok)) {
                     uint32_t goff[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);

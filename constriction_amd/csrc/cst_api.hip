@@ -196,7 +196,7 @@ size_t cst_ans_max_words(size_t n, cst_coder_config c) {
     if (c.word_bits <= 0) return 0;
     const size_t by_bits = (n * (size_t)c.precision + (size_t)c.word_bits - 1) / (size_t)c.word_bits;
     const size_t bound = (n < by_bits ? n : by_bits) + (size_t)(c.state_bits / c.word_bits);
-    const size_t unit = (size_t)(128 / c.word_bits) > 0 ? (size_t)(128 / c.word_bits) : 1;   // words per 16 bytes
+    const size_t unit = (size_t)(512 / c.word_bits) > 0 ? (size_t)(512 / c.word_bits) : 1;   // words per 64 bytes
     return (bound + unit - 1) / unit * unit;
 }
 

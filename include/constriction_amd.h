@@ -87,8 +87,8 @@ int32_t cst_device_count(void);
 const char *cst_last_hip_error(void);
 
 /* Upper bound on the words one stream can produce, min(n, ceil(n*P/W)) + S/W, rounded up to a whole number of
- * 16-byte units so that slabs laid out at this stride from a 16-byte aligned base are all 16-byte aligned (the
- * kernels then move whole aligned chunks).  Any other stride remains legal.
+ * 64-byte units so that slabs laid out at this stride from a 64-byte aligned base are all 64-byte aligned (the
+ * encoder then writes whole aligned 64-byte groups).  Any other stride remains legal.
  * (At most one word per symbol: src/stream/stack.rs:1035-1040; final state: stack.rs:891-895.) */
 size_t cst_ans_max_words(size_t n_symbols, cst_coder_config cfg);
 

@@ -34,10 +34,10 @@ E = [[quad_regs(176 + 4 * i) for i in range(4)], [quad_regs(192 + 4 * i) for i i
 E_T = [[f"v[{176 + 4 * i}:{179 + 4 * i}]" for i in range(4)], [f"v[{192 + 4 * i}:{195 + 4 * i}]" for i in range(4)]]
 A0, A1, W0, W1, U0, U1, X0, X1, V0, V1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(208, 222))
 RR, PSHL, KK, CK, RA, EA = (f"v{r}" for r in range(222, 228))
-FD = [(f"v[{228 + 4 * k}:{229 + 4 * k}]", f"v[{230 + 4 * k}:{231 + 4 * k}]", f"v[{228 + 4 * k}:{231 + 4 * k}]") for k in range(3)]
-NCH, LIM, FADDR, FOFF = "v240", "v241", "v242", "v243"
+FD = [(f"v[{228 + 4 * k}:{229 + 4 * k}]", f"v[{230 + 4 * k}:{231 + 4 * k}]", f"v[{228 + 4 * k}:{231 + 4 * k}]") for k in range(4)]
+NCH, LIM, FADDR, FOFF = "v244", "v245", "v246", "v247"
 SD, SAVE = "s[84:85]", "s[86:87]"
-CLOBBERS = [f"v{r}" for r in range(100, 244)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 248)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "memory"]
 
 
 def step(a, c, p, m0, m1):
@@ -86,8 +86,10 @@ def steps(a, eset):
 
 def half(a, name):
     a.i(f"// ---- tile using symbol set {name}".replace("//", ";"))
-    # 1. ring reads of the chunks that may be complete
-    for k in range(3):
+    # 1. ring reads of the 64-byte group (4 chunks) that may be complete.  Words leave for HBM 64 bytes at a time:
+    #    16-byte stores reach DRAM as partial bursts (measured 1.6x write amplification), and at most 15 + 12 words are
+    #    ever pending, so one group per tile is enough and the 64-slot ring holds the backlog.
+    for k in range(4):
         a.i(f"v_add_lshl_u32 {FADDR}, %[flushed], {4 * k}, 8")
         a.i(f"v_and_or_b32 {FADDR}, {FADDR}, %[c3f00], %[lanebase]")
         a.ds(f"ds_read2st64_b32 {FD[k][0]}, {FADDR} offset1:1", "fl")
@@ -98,19 +100,18 @@ def half(a, name):
         a.ds(f"ds_write_b128 %[tr], {R[name][k]} offset:{1152 * k}", "tl")
     # 3. chunk stores, then the symbol loads of tile - 2 (stores first: see the module docstring)
     a.i(f"v_sub_u32 {NCH}, %[wr], %[flushed]")
-    a.i(f"v_lshrrev_b32 {NCH}, 2, {NCH}")
-    a.i(f"v_min_u32 {NCH}, 3, {NCH}", "whole chunks pending (<= 3 + 12 words)")
-    a.i(f"v_sub_u32_e64 {LIM}, %[cap], %[flushed] clamp")
-    a.i(f"v_lshrrev_b32 {LIM}, 2, {LIM}")
-    a.i(f"v_min_u32 {LIM}, {NCH}, {LIM}", "... of which inside the slab")
+    a.i(f"v_lshrrev_b32 {NCH}, 4, {NCH}", "whole 16-word groups pending: 0 or 1")
+    a.i(f"v_add_u32 {LIM}, 16, %[flushed]")
     a.i(f"v_lshl_add_u32 {FOFF}, %[flushed], 2, %[slaboff]")
+    a.i(f"v_cmp_le_u32 vcc, {LIM}, %[cap]", "group inside the slab (cap % 16 == 0 on this path)")
+    a.i(f"v_cmp_ne_u32 {SAVE}, 0, {NCH}")
+    a.i(f"s_and_b64 vcc, vcc, {SAVE}")
     a.wait_lds("fl")
-    for k in range(3):
-        a.i(f"v_cmp_lt_u32 vcc, {k}, {LIM}")
-        a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+    a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+    for k in range(4):
         a.vmem(f"global_store_dwordx4 {FOFF}, {FD[k][2]}, %[wbase] offset:{16 * k}", "st")
-        a.i(f"s_mov_b64 exec, {SAVE}")
-    a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 2, %[flushed]")
+    a.i(f"s_mov_b64 exec, {SAVE}")
+    a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 4, %[flushed]")
     for k in range(8):
         a.vmem(f"global_load_dwordx4 {R[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
     advance_base(a)

@@ -45,9 +45,9 @@ def test_abi_version_and_bounds(lib):
     from constriction_amd._native import CoderConfig
     assert lib.cst_abi_version() == 1
     # config C2: ceil(4096*12/32) + 2 = 1538
-    assert lib.cst_ans_max_words(4096, CoderConfig(32, 64, 12)) == 1540     # 1538 rounded up to 16 bytes
-    assert lib.cst_ans_max_words(5, CoderConfig(32, 64, 24)) == 8         # 4 + 2 rounded up
-    assert lib.cst_ans_max_words(0, CoderConfig(16, 32, 12)) == 8         # 2 rounded up (8 x 16-bit words)
+    assert lib.cst_ans_max_words(4096, CoderConfig(32, 64, 12)) == 1552     # 1538 rounded up to 64 bytes
+    assert lib.cst_ans_max_words(5, CoderConfig(32, 64, 24)) == 16        # 4 + 2 rounded up
+    assert lib.cst_ans_max_words(0, CoderConfig(16, 32, 12)) == 32        # 2 rounded up (32 x 16-bit words)
 
 
 def test_no_gpu_means_loud_failure(lib):
