@@ -196,6 +196,25 @@ def test_impossible_symbol_and_capacity(B, O):
         assert words2[s, : n_words2[s]].tolist() == w2[s, : n2[s]].tolist()
 
 
+def test_capacity_overflow_in_main_loop(B, O):
+    """Slabs that are 64-byte aligned but too small: the encoder's main-loop statement must drop the words past the
+    capacity, report CAPACITY for exactly the streams the oracle reports it for, and leave the others bit-exact."""
+    P = 12
+    model, cdf = make_model(B, O, P)
+    sym = O.synth_symbols(21, 0, 192, 1024, -50, cdf, P)
+    sym[::2, ::3] = -50                                  # every other stream needs many more words
+    _, full_n, _ = O.ans_encode_batch(sym, -50, cdf, P)
+    stride = (int(full_n[1::2].max()) + 15) // 16 * 16   # multiple of 16 words: the aligned path; fits the odd streams
+    w2, n2, st2 = O.ans_encode_batch(sym, -50, cdf, P, stride=stride)
+    assert 2 in st2.tolist() and 0 in st2.tolist()
+    enc = B.ans_encode(dev(sym), model, (32, 64, 12), stride=stride)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == st2.tolist() and n_words.tolist() == n2.tolist()
+    for s in np.nonzero(status == 0)[0]:
+        assert words[s, : n_words[s]].tolist() == w2[s, : n2[s]].tolist()
+
+
 def test_decode_invalid_and_past_end(B, O):
     """Trailing zero word -> INVALID_DATA (stack.rs:299-318); decoding past the end is legal and
     deterministic (stack.rs:1062-1065)."""
