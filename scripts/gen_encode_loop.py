@@ -51,12 +51,12 @@ def step(a, c, p, m0, m1):
     a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
     a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
     a.i(f"v_addc_co_u32 %[wr], vcc, 0, %[wr], vcc")
+    # q_est = floor(A * m / 2^64) = a1*m1 + floor((a1*m0 + a0*m1 + hi32(a0*m0)) / 2^32), the middle sum taken to 65 bits
     a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
-    a.i(f"v_mad_u64_u32 v[212:213], vcc, {A1}, {m0}, v[210:211]")
-    a.i(f"v_mov_b32 {X0}, {U0}")
-    a.i(f"v_mad_u64_u32 v[216:217], vcc, {A0}, {m1}, v[214:215]")
-    a.i(f"v_add_co_u32 {SM0}, vcc, {U1}, {V1}")
-    a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc")
+    a.i(f"v_mad_u64_u32 v[212:213], vcc, {A1}, {m0}, v[210:211]", "U = a1*m0 + hi32(a0*m0)   (< 2^64)")
+    a.i(f"v_mad_u64_u32 v[216:217], vcc, {A0}, {m1}, v[212:213]", "T = a0*m1 + U, carry -> vcc")
+    a.i(f"v_mov_b32 {SM0}, {V1}")
+    a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc", "[T_hi, carry]")
     a.i(f"v_mad_u64_u32 v[220:221], vcc, {A1}, {m1}, v[218:219]", "q_est in {q - 1, q}")
     a.i(f"v_mul_lo_u32 {RR}, {Q0}, {p}")
     a.i(f"v_sub_u32 {RR}, {A0}, {RR}")
