@@ -275,13 +275,15 @@ __device__ __forceinline__ void ans_encode_tile32(uint32_t& lo, uint32_t& hi, ui
 }
 
 // All full tiles of a FULL wave in one asm statement (generated, with its wait counts, by scripts/gen_encode_loop.py):
-// ans_encode_tile32's steps plus, per tile, the chunk flush of the word ring (16-byte aligned slabs only), the LDS
-// staging of the tile's symbols and the request of the symbols two tiles further down (two register sets: under
-// load an HBM round trip outlasts one tile).  Nothing in it is visible to the compiler's wait-count pass.
+// ans_encode_tile32's steps as ONE quad pipeline that runs on across tile boundaries (two LDS tile buffers), plus,
+// per tile, the flush of a 64-byte word group from the ring (64-byte aligned slabs only), the LDS staging of the
+// next tile's symbols and the request of the symbols three tiles further down (two register sets: under load an
+// HBM round trip outlasts one tile).  Nothing in it is visible to the compiler's wait-count pass.
+//   tile_row_addr[b] : the lane's own row in tile buffer b;  tile_tr_addr[b] : its transposed staging address
 //   symbols_base : address of the last full tile of stream s0 (uniform);  goff[k] : byte offset of row (lane>>3)+8k,
 //   chunk (lane&7) from it;  words_base + slab_off : the lane's slab (16-byte aligned);  cap : slab capacity (% 4 == 0)
 __device__ __forceinline__ void ans_encode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
-                                                      int32_t& smax, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                      int32_t& smax, const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
                                                       uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
                                                       uint32_t table_addr_biased, uint32_t P, const void* words_base,
                                                       uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
@@ -781,7 +783,8 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 const bool off_ok = slab_off + 4ull * L.out.cap < 0x100000000ull;
                 // the statement writes whole 64-byte groups: slabs 64-byte aligned and a whole number of groups long
                 const bool groups_ok = (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 && (L.out.cap & 15u) == 0 && L.out.shift == 0;
-                if (aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok || !groups_ok)) {
+                if ((a.flags & CST_KFLAG_TWO_TILES) && aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) &&
+                    !__any(!off_ok || !groups_ok)) {
                     uint32_t goff[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
@@ -790,9 +793,12 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                     const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                                   (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
                     uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
-                    const uint32_t tr_addr = lds_addr(tile) + (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+                    const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+                    int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);   // second buffer behind all first ones
+                    const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+                    const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
                     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-                    ans_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, lds_addr(tile + lane * kTileStride), tr_addr,
+                    ans_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr,
                                           L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
                                           lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);

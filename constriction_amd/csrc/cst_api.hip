@@ -39,13 +39,20 @@ static cst_status launch(K kernel, size_t n_streams, size_t lds_bytes, hipStream
 // ---- encode dispatch ----
 template <int W, int S, int G, bool FAST>
 static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
-    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
+    size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     if (table_bytes + kTileBytesPerBlock > kMaxLds) return CST_ERR_INVALID_ARGUMENT; // TODO(global-table path)
+    // the main-loop statement of the (32,64), P <= 12 encoder alternates between two tile buffers per wave; without
+    // room for the second one the kernel is told so (flag) and stays on the per-tile path
+    constexpr size_t kSecondTiles = (size_t)(kBlock / kWave) * kWave * kTileStride * sizeof(int32_t);
+    const bool second = FAST && W == 32 && S == 64 && G == 8 && table_bytes + kTileBytesPerBlock + kSecondTiles <= kMaxLds;
+    AnsEncodeArgs args = a;
+    args.flags = (a.flags & ~CST_KFLAG_TWO_TILES) | (second ? CST_KFLAG_TWO_TILES : 0u);
+    if (second) table_bytes += kSecondTiles;
     if (layout == CST_LAYOUT_SYMBOL_MAJOR)
-        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+        return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, args);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
-    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
-    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, a);
+    if (vec) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, args);
+    return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G, FAST>, a.n_streams, table_bytes + kTileBytesPerBlock, hs, args);
 }
 
 template <int W, int S>

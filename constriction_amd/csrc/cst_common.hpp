@@ -35,6 +35,9 @@ enum DecMode : int {
     kDecBucket = 2,  // cdf[n+1] + bucket index, linear scan (any P)
 };
 
+// kernel-internal launch flag (never part of the ABI): the workgroup's LDS holds a second symbol tile per wave
+constexpr uint32_t CST_KFLAG_TWO_TILES = 0x80000000u;
+
 struct DecLut {      // pointers into LDS or global memory
     const uint32_t* cp;     // c | p << 16 per quantile
     const uint16_t* idx;    // symbol index per quantile ...

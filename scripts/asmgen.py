@@ -2,7 +2,12 @@
 
 It records instructions and keeps the book the hardware's s_waitcnt counters imply: one wave's LDS operations complete
 in issue order, and so do its vector-memory operations, so "wait until operation X is done" is
-s_waitcnt <cnt>(number of operations of that kind issued after X)."""
+s_waitcnt <cnt>(number of operations of that kind issued after X).
+
+Loops: the body is generated once, with the queues as the code before the loop leaves them.  `verify_loop` replays the
+body from the queues a full pass leaves behind and checks that every emitted operand is still <= the exact one (a
+smaller operand only waits longer) and reports what each wait additionally retires in the steady state."""
+import re
 
 
 class Asm:
@@ -10,40 +15,76 @@ class Asm:
         self.lines = []
         self.lds = []      # tags of LDS ops in issue order (oldest first)
         self.vm = []       # tags of vector-memory ops in issue order
+        self.events = []   # ("lds"|"vm", tag) issues and ("wait_lds"|"wait_vm", tag, operand) waits, in program order
 
     def i(self, text, comment=None):
         self.lines.append((text, comment))
 
     def ds(self, text, tag, comment=None):
         self.lds.append(tag)
+        self.events.append(("lds", tag))
         self.i(text, comment)
 
     def vmem(self, text, tag, comment=None):
         self.vm.append(tag)
+        self.events.append(("vm", tag))
         self.i(text, comment)
 
-    def _wait(self, queue, tag, limit):
+    @staticmethod
+    def _younger(queue, tag):
         idx = max(k for k, t in enumerate(queue) if t == tag)
-        younger = len(queue) - 1 - idx
-        assert younger <= limit, (tag, younger)
-        return younger, queue[idx + 1:]
+        return len(queue) - 1 - idx
 
     def wait_lds(self, tag, comment=None):
         """wait until the youngest LDS op tagged `tag` (and everything older) has completed"""
-        n, self.lds = self._wait(self.lds, tag, 15)
+        n = self._younger(self.lds, tag)
+        assert n <= 15, (tag, n)
+        self.lds = self.lds[len(self.lds) - n:] if n else []
+        self.events.append(("wait_lds", tag, n))
         self.i(f"s_waitcnt lgkmcnt({n})", comment)
 
     def wait_lds_all(self, comment=None):
-        self.i("s_waitcnt lgkmcnt(0)", comment)
         self.lds = []
+        self.events.append(("wait_lds", None, 0))
+        self.i("s_waitcnt lgkmcnt(0)", comment)
 
     def wait_vm(self, tag, comment=None):
-        n, self.vm = self._wait(self.vm, tag, 63)
+        n = self._younger(self.vm, tag)
+        assert n <= 63, (tag, n)
+        self.vm = self.vm[len(self.vm) - n:] if n else []
+        self.events.append(("wait_vm", tag, n))
         self.i(f"s_waitcnt vmcnt({n})", comment)
 
     def wait_vm_all(self, comment=None):
-        self.i("s_waitcnt vmcnt(0)", comment)
         self.vm = []
+        self.events.append(("wait_vm", None, 0))
+        self.i("s_waitcnt vmcnt(0)", comment)
+
+    def verify_loop(self, first_event, lds_entry, vm_entry, passes=2):
+        """Replay events[first_event:] `passes` times starting from the given queues (the state at the back edge)."""
+        notes = set()
+        lds, vm = list(lds_entry), list(vm_entry)
+        for _ in range(passes):
+            for ev in self.events[first_event:]:
+                if ev[0] == "lds":
+                    lds.append(ev[1])
+                elif ev[0] == "vm":
+                    vm.append(ev[1])
+                else:
+                    kind, tag, n = ev
+                    q = lds if kind == "wait_lds" else vm
+                    if tag is not None and tag in q:     # (not in q: an earlier, stricter wait already retired it)
+                        exact = self._younger(q, tag)
+                        assert n <= exact, (kind, tag, n, exact)
+                        extra = q[len(q) - exact: len(q) - n]
+                        if extra:
+                            notes.add(f"{kind}({tag}) also retires {sorted(set(extra))} in the steady state")
+                    keep = q[len(q) - n:] if n else []
+                    if kind == "wait_lds":
+                        lds = keep
+                    else:
+                        vm = keep
+        return lds, vm, sorted(notes)
 
     def render(self, header_lines, operand_lines):
         out = list(header_lines)
@@ -58,4 +99,4 @@ class Asm:
         return "\n".join(out) + "\n"
 
     def n_instr(self):
-        return sum(1 for t, _ in self.lines if not t.endswith(":"))
+        return sum(1 for t, _ in self.lines if not t.endswith(":") and not t.startswith(";"))
