@@ -7,6 +7,7 @@ s_waitcnt <cnt>(number of operations of that kind issued after X).
 Loops: the body is generated once, with the queues as the code before the loop leaves them.  `verify_loop` replays the
 body from the queues a full pass leaves behind and checks that every emitted operand is still <= the exact one (a
 smaller operand only waits longer) and reports what each wait additionally retires in the steady state."""
+import os
 import re
 
 
@@ -41,6 +42,8 @@ class Asm:
         assert n <= 15, (tag, n)
         self.lds = self.lds[len(self.lds) - n:] if n else []
         self.events.append(("wait_lds", tag, n))
+        if os.environ.get("GEN_NO_LGKM"):          # timing experiment only: results are wrong
+            return
         self.i(f"s_waitcnt lgkmcnt({n})", comment)
 
     def wait_lds_all(self, comment=None):

@@ -114,8 +114,13 @@ def load_set(a, name):
     advance_base(a)
 
 
+import os
+
+
 def stage_set(a, name, buf):
     a.wait_vm(f"ld{name}", f"symbols in set {name} have arrived")
+    if os.environ.get("GEN_NO_VMWAIT") and len(a.lines) > 100:      # timing experiment only: results are wrong
+        a.lines.pop()
     for k in range(8):
         a.ds(f"ds_write_b128 {TR[buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
