@@ -61,10 +61,13 @@ def model_args(model, params, n_expected=None):
     """Classifies an (model, *params) call.  Returns one of
        ("table", device_model)                         concrete model, iid symbols
        ("gaussian", lo, hi, means, stds)               QuantizedGaussian family with per-symbol parameters
-       ("rows", cdf_rows)                              Categorical family with a probability matrix
+       ("rows", cdf_rows, min_symbol)                  one tabulated cdf row per symbol position (Categorical family with
+                                                       a probability matrix; CustomModel / ScipyModel with parameters)
     """
     if not isinstance(model, M.Model):
         raise TypeError("model must be a constriction_amd.stream.model.Model")
+    if isinstance(model, M.CustomModel) and len(params) > 0:
+        return ("rows", model.cdf_rows(params), model.min_symbol)
     if len(params) == 0:
         if not model.is_concrete():
             raise ValueError("This model family needs its parameters to be passed to `encode`/`decode`.")
@@ -81,5 +84,5 @@ def model_args(model, params, n_expected=None):
     if isinstance(model, M.Categorical):
         if len(params) != 1:
             raise ValueError("Wrong number of model parameters: Categorical expects one rank-2 array of probabilities.")
-        return ("rows", M.Categorical.cdf_rows(params[0]))
+        return ("rows", M.Categorical.cdf_rows(params[0]), 0)
     raise TypeError("unsupported model family")

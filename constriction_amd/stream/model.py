@@ -145,3 +145,73 @@ class Categorical(Model):
         if m.dtype not in (np.float32, np.float64):
             raise TypeError("probabilities must have dtype float32 or float64")
         return np.stack([fast_quantized_cdf(row, PRECISION) for row in m]) if len(m) else np.zeros((0, m.shape[1] + 1), np.uint32)
+
+
+def leaky_cdf_table(cdf, min_symbol: int, max_symbol: int, params=(), precision: int = PRECISION) -> np.ndarray:
+    """`LeakilyQuantizedDistribution::left_cumulative_and_probability` for every symbol of the support with an
+    arbitrary continuous CDF (src/stream/model/quantize.rs:525-568): L[0] = 0,
+    L[i] = trunc_sat(free_weight * cdf(sym_i - 0.5)) + i, L[n] = 2^P, in f64 like the reference (the CDF is a Python
+    callable there too: src/pybindings/stream/model/internals.rs:283-398).  Evaluated on the host; the table then
+    goes to the GPU like any other tabulated model."""
+    lo, hi = int(min_symbol), int(max_symbol)
+    n = hi - lo + 1
+    free_weight = float(((1 << precision) - 1) - (hi - lo))
+    out = np.empty(n + 1, dtype=np.uint32)
+    out[0] = 0
+    for i in range(1, n):
+        x = float(cdf(float(lo + i) - 0.5, *params)) * free_weight
+        # Rust `as u32`: truncate toward zero, saturate, NaN -> 0
+        v = 0 if not x > 0.0 else (0xFFFFFFFF if x >= 4294967295.0 else int(x))
+        out[i] = (v + i) & 0xFFFFFFFF
+    out[n] = 1 << precision
+    if np.any(np.diff(out.astype(np.int64)) <= 0):
+        raise ValueError("Invalid model: the cumulative distribution function is not monotonically increasing "
+                         "on the support (quantize.rs:560-566).")
+    return out
+
+
+class CustomModel(Model):
+    """constriction.stream.model.CustomModel(cdf, approximate_inverse_cdf, min_symbol_inclusive, max_symbol_inclusive)
+    (src/pybindings/stream/model.rs:264-318): LeakyQuantizer<f64,i32,u32,24> over a user-provided CDF.  Usable as a
+    concrete model (no parameters at encode/decode time) or as a family whose parameters (any number of rank-1
+    float arrays) are forwarded to `cdf(x, *params_i)`.  `approximate_inverse_cdf` is only a search hint in the
+    reference (quantize.rs:204-214) and cannot change results; it is accepted and ignored."""
+
+    def __init__(self, cdf, approximate_inverse_cdf, min_symbol_inclusive, max_symbol_inclusive):
+        lo, hi = int(min_symbol_inclusive), int(max_symbol_inclusive)
+        if not hi > lo:
+            raise ValueError("The support must contain at least two symbols.")
+        if hi - lo + 1 > (1 << PRECISION):
+            raise ValueError("The support is too large to assign a nonzero probability to each element.")
+        self.cdf, self.approximate_inverse_cdf = cdf, approximate_inverse_cdf
+        self.min_symbol, self.max_symbol = lo, hi
+        self._dev = None
+
+    def is_concrete(self):
+        return True      # (decided per call: with parameters it acts as a family, see _single.model_args)
+
+    def _device_model(self):
+        if self._dev is None:
+            from .. import batched
+            self._dev = batched.Model.from_cdf(leaky_cdf_table(self.cdf, self.min_symbol, self.max_symbol), self.min_symbol,
+                                               PRECISION)
+        return self._dev
+
+    def cdf_rows(self, params) -> np.ndarray:
+        """one tabulated row per symbol position for the family form"""
+        arrays = [_as_float_params(p, "model parameter") for p in params]
+        if any(len(a) != len(arrays[0]) for a in arrays):
+            raise ValueError("Model parameters have unequal lengths.")
+        n = self.max_symbol - self.min_symbol + 1
+        if len(arrays[0]) == 0:
+            return np.zeros((0, n + 1), np.uint32)
+        return np.stack([leaky_cdf_table(self.cdf, self.min_symbol, self.max_symbol, tuple(float(a[t]) for a in arrays))
+                         for t in range(len(arrays[0]))])
+
+
+class ScipyModel(CustomModel):
+    """constriction.stream.model.ScipyModel(scipy_model, min_symbol_inclusive, max_symbol_inclusive)
+    (src/pybindings/stream/model.rs:320-349): CustomModel(scipy_model.cdf, scipy_model.ppf, min, max)."""
+
+    def __init__(self, scipy_model, min_symbol_inclusive, max_symbol_inclusive):
+        super().__init__(scipy_model.cdf, scipy_model.ppf, min_symbol_inclusive, max_symbol_inclusive)

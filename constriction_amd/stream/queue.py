@@ -114,7 +114,7 @@ class RangeEncoder:
                                                    S.ptr(d_status), N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
-            idx = sym.astype(np.int64)
+            idx = sym.astype(np.int64) - kind[2]
             ok = (idx >= 0) & (idx < rows.shape[1] - 1)
             safe = np.where(ok, idx, 0)
             ar = np.arange(n)
@@ -215,7 +215,7 @@ class RangeDecoder:
             rows = kind[1]
             d_rows = S.dev(rows.view(np.int32))
             st = L.cst_range_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(nwin, 1), S.ptr(d_n), S.ptr(d_rows),
-                                               rows.shape[1] - 1, 0, S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, S.ptr(d_rs),
+                                               rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, S.ptr(d_rs),
                                                S.ptr(d_status), N.FLAG_RAW_STATE, sp)
         N.check(st, "range decode")
         torch.cuda.current_stream().synchronize()

@@ -136,7 +136,7 @@ class AnsCoder:
                                                  S.ptr(d_status), N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
-            idx = sym.astype(np.int64)
+            idx = sym.astype(np.int64) - kind[2]
             ok = (idx >= 0) & (idx < rows.shape[1] - 1)
             safe = np.where(ok, idx, 0)
             ar = np.arange(n)
@@ -192,7 +192,7 @@ class AnsCoder:
             rows = kind[1]
             d_rows = S.dev(rows.view(np.int32))
             st = L.cst_ans_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(tail, 1), S.ptr(d_n), S.ptr(d_rows),
-                                             rows.shape[1] - 1, 0, S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR,
+                                             rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR,
                                              S.ptr(d_state), S.ptr(d_n_out), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
         N.check(st, "ans decode")
         torch.cuda.current_stream().synchronize()

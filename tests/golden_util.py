@@ -29,4 +29,23 @@ def models_for(step, P, backend, prob_bits=32):
         return [backend.TableModel(backend.categorical_fast_cdf(r, P), 0, P) for r in rows], len(rows)
     if kind == "table":
         return backend.TableModel(np.asarray(m["cdf"], dtype=np.uint32), m["lo"], P), n
+    if kind in ("scipy_norm", "scipy_norm_family"):
+        import scipy.stats
+        if kind == "scipy_norm":
+            return backend.TableModel(leaky_table(scipy.stats.norm(m["loc"], m["scale"]).cdf, m["lo"], m["hi"], P), m["lo"], P), n
+        return [backend.TableModel(leaky_table(lambda x, a=a, b=b: scipy.stats.norm.cdf(x, a, b), m["lo"], m["hi"], P), m["lo"], P)
+                for a, b in zip(m["locs"], m["scales"])], len(m["locs"])
     raise ValueError(kind)
+
+
+def leaky_table(cdf, lo, hi, P):
+    """LeakyQuantizer over an arbitrary CDF (src/stream/model/quantize.rs:525-568), tabulated:
+    L[0] = 0, L[i] = trunc_sat(fw * cdf(lo + i - 0.5)) + i, L[n] = 2^P with fw = f64((2^P - 1) - (hi - lo))."""
+    n = hi - lo + 1
+    fw = float(((1 << P) - 1) - (hi - lo))
+    out = np.zeros(n + 1, dtype=np.uint32)
+    for i in range(1, n):
+        x = fw * float(cdf(lo + i - 0.5))
+        out[i] = (min(max(int(x), 0), 0xFFFFFFFF) if x == x else 0) + i
+    out[n] = 1 << P
+    return out

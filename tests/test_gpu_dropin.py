@@ -35,6 +35,14 @@ def _call_args(constriction, step):
         return mod.Categorical(np.array(m["probs"], dtype=_dtype(m["dtype"])), perfect=False), ()
     if m["kind"] == "categorical_fast_rows":
         return mod.Categorical(perfect=False), (np.array(m["probs"], dtype=_dtype(m["dtype"])),)
+    if m["kind"] == "scipy_norm":            # tests/python/test_constriction.py:233-235
+        import scipy.stats
+        model_py = scipy.stats.norm(m["loc"], m["scale"])
+        return mod.CustomModel(model_py.cdf, model_py.ppf, m["lo"], m["hi"]), ()
+    if m["kind"] == "scipy_norm_family":     # tests/python/test_constriction.py:241-244
+        import scipy.stats
+        model = mod.CustomModel(lambda x, loc, scale: scipy.stats.norm.cdf(x, loc, scale), scipy.stats.norm.ppf, m["lo"], m["hi"])
+        return model, (np.array(m["locs"], dtype=np.float64), np.array(m["scales"], dtype=np.float64))
     raise ValueError(m["kind"])
 
 
