@@ -89,6 +89,36 @@ def test_gaussian_model_table(B, O, lo, hi, mean, std, P):
     assert (m.precision, m.min_symbol, m.n_symbols, m.n_tables) == (P, lo, hi - lo + 1, 1)
 
 
+@pytest.mark.parametrize("std", [1e-40, 0.0001, 0.1, 3.5, 123.45, 1234.56])
+def test_leakily_quantized_normal_invariants(B, O, std):
+    """The reference's `leakily_quantized_normal` grid (src/stream/model/quantize.rs:906-935 with test_entropy_model,
+    src/stream/model.rs:960-989): LeakyQuantizer<_,_,u32,24>(-127..=127) x 6 sigmas x 9 means.  For every model the
+    device table must equal the oracle's bit for bit, be strictly increasing from 0 to 2^24 (every probability >= 1,
+    cumulative sums to 2^24), and decoding a batch of quantiles at the left end, the last quantile and the middle of
+    every bin must return that bin's symbol (quantile_function inverts left_cumulative_and_probability)."""
+    lo, hi, P = -127, 127, 24
+    n = hi - lo + 1
+    for mean in [-300.6, -127.5, -100.2, -4.5, 0.0, 50.3, 127.5, 180.2, 2000.0]:
+        m = B.Model.quantized_gaussian(lo, hi, mean, std, P)
+        cdf = m.cdf().astype(np.int64)
+        assert cdf.tolist() == O.GaussianModel(lo, hi, mean, std, P, 32).cdf_table().tolist()
+        assert cdf[0] == 0 and cdf[-1] == 1 << P and (np.diff(cdf) >= 1).all()
+        # quantile -> symbol through the decoder: a one-symbol stream whose state IS the quantile (state < 2^24 decodes
+        # with q = state and no refill); three probes per bin, one stream each
+        left, prob = cdf[:-1], np.diff(cdf)
+        q = np.concatenate([left, left + prob - 1, left + prob // 2]).astype(np.uint32)
+        words = q.reshape(-1, 1).copy()
+        keep = q != 0                                   # compressed data never ends in a zero word; q = 0 <=> empty stream
+        n_words = keep.astype(np.uint32)
+        enc = B.EncodedBatch(dev(words.view(np.int32)), dev(n_words.view(np.int32)),
+                             torch.zeros(len(q), dtype=torch.int32, device="cuda"), (32, 64, P))
+        got, status = B.ans_decode(enc, m, 1)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all()
+        want = np.concatenate([np.arange(n), np.arange(n), np.arange(n)]) + lo
+        assert np.array_equal(got.cpu().numpy()[:, 0], want)
+
+
 def test_model_errors(B):
     with pytest.raises(ValueError):
         B.Model.quantized_gaussian(-50, 50, 0.0, 0.0, 12)      # std <= 0 (reference: assert!)
