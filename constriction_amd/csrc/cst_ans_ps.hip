@@ -7,8 +7,9 @@
 // (row[i], row[i+1]-row[i]) and the reciprocal floor(2^64/p), which comes from a small table indexed by p
 // (shared by all streams, L1/L2 resident).  Decoding finds the largest i with row[i] <= q by a 4-ary search
 // (3 probes per round, ceil(log4 n) rounds, branch free).
-// Symbols are read/written directly (16 B per lane per 4 steps); compressed words go through the same per-lane
-// LDS rings as the shared-table kernels.
+// The encoder reads stream-major symbols through wave-private LDS tiles like the shared-table kernels (128-byte row
+// segments per access); the decoder writes 16 B per lane per 4 steps (see there); compressed words go through the
+// same per-lane LDS rings.
 #include "cst_ans_kernels.hpp"
 
 namespace cst {
@@ -40,16 +41,25 @@ struct LaneRow {
     __device__ __forceinline__ uint32_t at(uint32_t i) const { return row[(i + rot) & mask]; }
 };
 
-__device__ __forceinline__ void stage_rows(uint16_t* lds_rows, const PsArgs& a, size_t block_s0) {
+// `pad`: entries behind cdf[n] become 0xFFFF, a sentinel above every quantile when P <= 15 (the decoder's search
+// then needs no bounds checks)
+__device__ __forceinline__ void stage_rows(uint16_t* lds_rows, const PsArgs& a, size_t block_s0, bool pad = false) {
     const uint32_t L = (uint32_t)a.L, mask = L - 1;
     const uint32_t total = blockDim.x * L;
+    const int shift = __builtin_ctz(L);
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const uint32_t j = idx / L, e = idx & mask;
+        const uint32_t j = idx >> shift, e = idx & mask;
         const size_t s = block_s0 + j;
-        const uint16_t v = s < a.n_streams ? a.cdf16[s * L + e] : (uint16_t)0;
+        uint16_t v = s < a.n_streams ? a.cdf16[s * L + e] : (uint16_t)0;
+        if (pad && e > (uint32_t)a.n_symbols) v = 0xFFFFu;
         lds_rows[j * L + ((e + 2u * (j & 63u)) & mask)] = v;
     }
 }
+
+// Bucket index of the per-stream decoder: kPsBuckets + 1 entries per stream, start[b] = the symbol index whose bin
+// holds quantile b * 2^(P - log2 kPsBuckets); row stride kPsIdxStride entries (an odd number of dwords: lock-step
+// accesses of the 64 lanes fall on distinct banks).
+constexpr int kPsBucketBits = 6, kPsBuckets = 1 << kPsBucketBits, kPsIdxStride = 66;
 
 template <int W, int S>
 __global__ void ans_encode_ps_kernel(const PsArgs a) {
@@ -89,15 +99,38 @@ __global__ void ans_encode_ps_kernel(const PsArgs a) {
     int countdown = G4;
     size_t t = N;
     if (vec) {
-        while (t >= 4) {
-            t -= 4;
-            int4 v = make_int4(a.min_symbol, a.min_symbol, a.min_symbol, a.min_symbol);
-            if (active) v = *reinterpret_cast<const int4*>(my + t);
-            const EncEntry e3 = entry_of(v.w), e2 = entry_of(v.z), e1 = entry_of(v.y), e0 = entry_of(v.x);
-            L.template step<false>(e3, P); L.template step<false>(e2, P); L.template step<false>(e1, P); L.template step<false>(e0, P);
-            countdown -= 4;
-            if (countdown <= 0) { countdown = G4; L.flush_chunks(); }
+        // ragged top part [32 * n_full, N) directly, then full tiles through LDS (last tile first)
+        const size_t n_full = N / kTileSyms;
+        const size_t s0 = block_s0 + (size_t)(threadIdx.x >> 6) * kWave;
+        int32_t* tile = reinterpret_cast<int32_t*>(smem + (size_t)blockDim.x * a.L * 2 + (size_t)(blockDim.x / kWave) * kRingWords * 4) +
+                        (threadIdx.x >> 6) * (kWave * kTileStride);
+        while (t > n_full * kTileSyms) {
+            --t;
+            const int32_t v = active ? my[t] : a.min_symbol;
+            L.template step<false>(entry_of(v), P);
+            if (--countdown <= 0) { countdown = G4; L.flush_chunks(); }
         }
+        if (n_full > 0 && s0 < a.n_streams) {
+            int32_t r[kTileSyms];
+            tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
+            const int32_t* row = tile + lane * kTileStride;
+            for (size_t tb = n_full; tb-- > 0;) {
+                wave_lds_fence();
+                tile_to_lds<true>(tile, lane, r);
+                wave_lds_fence();
+                if (tb > 0) tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r);
+#pragma unroll
+                for (int j = kTileSyms / 4 - 1; j >= 0; --j) {
+                    int4 v = *reinterpret_cast<const int4*>(row + 4 * j);
+                    if (!active) v = make_int4(a.min_symbol, a.min_symbol, a.min_symbol, a.min_symbol);
+                    const EncEntry e3 = entry_of(v.w), e2 = entry_of(v.z), e1 = entry_of(v.y), e0 = entry_of(v.x);
+                    L.template step<false>(e3, P); L.template step<false>(e2, P); L.template step<false>(e1, P); L.template step<false>(e0, P);
+                    countdown -= 4;
+                    if (countdown <= 0) { countdown = G4; L.flush_chunks(); }
+                }
+            }
+        }
+        t = 0;
     }
     while (t > 0) {
         --t;
@@ -122,7 +155,7 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     const size_t block_s0 = (size_t)blockIdx.x * blockDim.x;
     uint16_t* rows = reinterpret_cast<uint16_t*>(smem);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + (size_t)blockDim.x * a.L * 2) + (threadIdx.x >> 6) * kRingWords;
-    stage_rows(rows, a, block_s0);
+    stage_rows(rows, a, block_s0, a.precision >= kPsBucketBits && a.precision <= 15);
     __syncthreads();
 
     const size_t s = block_s0 + threadIdx.x;
@@ -142,17 +175,52 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     L.in.prime();
     wave_lds_fence();
 
+    // P in [6, 15]: bucket index + sentinel-padded rows (see stage_rows); otherwise the plain bounded 4-ary search
+    const bool indexed = P >= kPsBucketBits && P <= 15;
+    uint16_t* bidx = reinterpret_cast<uint16_t*>(smem + (size_t)blockDim.x * a.L * 2 + (size_t)(blockDim.x / kWave) * kRingWords * 4) +
+                     (size_t)threadIdx.x * kPsIdxStride;
+    if (indexed) {
+        // this lane's own row -> its bucket index (one pass over the row)
+        uint32_t i = 0;
+        const uint32_t w = 1u << (P - kPsBucketBits);
+        for (uint32_t b = 0; b < (uint32_t)kPsBuckets; ++b) {
+            const uint32_t q0 = b * w;
+            while (i + 1 < n && R.at(i + 1) <= q0) ++i;
+            bidx[b] = (uint16_t)i;
+        }
+        bidx[kPsBuckets] = (uint16_t)(n - 1);
+        wave_lds_fence();
+    }
+
     auto decode_one = [&]() -> int32_t {
         const uint32_t q = (uint32_t)L.state & qmask;
         const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
-        // largest i in [0, n) with row[i] <= q: 4-ary search, wave-uniform trip count
-        uint32_t lo = 0, size = n;
-        while (size > 1) {
-            const uint32_t step = (size + 3) >> 2;
-            const uint32_t p1 = lo + step, p2 = p1 + step, p3 = p2 + step;
-            const uint32_t v1 = p1 < n ? R.at(p1) : 0x10000u, v2 = p2 < n ? R.at(p2) : 0x10000u, v3 = p3 < n ? R.at(p3) : 0x10000u;
-            lo += ((v1 <= q ? 1u : 0u) + (v2 <= q ? 1u : 0u) + (v3 <= q ? 1u : 0u)) * step;
-            size = step;
+        uint32_t lo;
+        if (indexed) {
+            // the answer lies in [start[b], start[b+1]]; everything behind start[b+1] (including the padding) is > q,
+            // so the 4-ary refinement needs no bounds checks and a lane that is done is not disturbed by extra rounds
+            const uint32_t b = q >> (P - kPsBucketBits);
+            lo = bidx[b];
+            uint32_t size = (uint32_t)bidx[b + 1] - lo + 1u;
+            while (__any(size > 1)) {
+                const uint32_t step = (size + 3) >> 2;
+                // (probes clamped to index n, whose entry 2^P is itself above every quantile: the row may be exactly
+                // n + 1 entries long, and an index behind it would wrap around to the row's small first entries)
+                const uint32_t v1 = R.at(min(lo + step, n)), v2 = R.at(min(lo + 2 * step, n)), v3 = R.at(min(lo + 3 * step, n));
+                lo += ((v1 <= q ? 1u : 0u) + (v2 <= q ? 1u : 0u) + (v3 <= q ? 1u : 0u)) * step;
+                size = step;
+            }
+        } else {
+            // largest i in [0, n) with row[i] <= q: 4-ary search, wave-uniform trip count
+            lo = 0;
+            uint32_t size = n;
+            while (size > 1) {
+                const uint32_t step = (size + 3) >> 2;
+                const uint32_t p1 = lo + step, p2 = p1 + step, p3 = p2 + step;
+                const uint32_t v1 = p1 < n ? R.at(p1) : 0x10000u, v2 = p2 < n ? R.at(p2) : 0x10000u, v3 = p3 < n ? R.at(p3) : 0x10000u;
+                lo += ((v1 <= q ? 1u : 0u) + (v2 <= q ? 1u : 0u) + (v3 <= q ? 1u : 0u)) * step;
+                size = step;
+            }
         }
         const uint32_t c = R.at(lo);
         const uint32_t p = (R.at(lo + 1) - c) & 0xffffu;
@@ -166,6 +234,9 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
     int32_t* my = a.symbols_out + (active ? (a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N) : 0);
     const bool vec = a.layout == CST_LAYOUT_STREAM_MAJOR && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0);
+    // Symbols leave 16 bytes per lane: staging them through an LDS tile (as the encoder does) was measured 1.7x
+    // SLOWER here -- the 9 KiB tile per wave costs a wave of occupancy (3 -> 2 per CU at L = 256) and this kernel is
+    // bound by the latency of its table search, not by HBM.
     int countdown = G4;
     size_t t = 0;
     if (vec) {
@@ -190,19 +261,20 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     }
 }
 
-// threads per block such that rows + rings fit in the 160 KiB of LDS of one CU
-static int pick_block(int L, size_t& lds) {
+// threads per block such that rows + rings + symbol tiles fit in the 160 KiB of LDS of one CU
+static int pick_block(int L, bool with_tiles, size_t& lds) {
     for (int threads = 256; threads >= 64; threads -= 64) {
-        lds = (size_t)threads * L * 2 + (size_t)(threads / kWave) * kRingWords * sizeof(uint32_t);
+        lds = (size_t)threads * L * 2 + (size_t)(threads / kWave) * (kRingWords + (with_tiles ? kWave * kTileStride : 0)) * sizeof(uint32_t) +
+              (with_tiles ? 0 : (size_t)threads * kPsIdxStride * 2);   // encoder: symbol tiles; decoder: bucket index
         if (lds <= 160 * 1024) return threads;
     }
     return 0;
 }
 
 template <typename K>
-static cst_status launch_ps(K kernel, const PsArgs& a, hipStream_t hs) {
+static cst_status launch_ps(K kernel, const PsArgs& a, bool with_tiles, hipStream_t hs) {
     size_t lds = 0;
-    const int threads = pick_block(a.L, lds);
+    const int threads = pick_block(a.L, with_tiles, lds);
     if (threads == 0) return CST_ERR_INVALID_ARGUMENT;   // support too large for LDS-resident per-stream tables
     const size_t blocks = (a.n_streams + threads - 1) / threads;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
@@ -222,8 +294,8 @@ cst_status ans_encode_per_stream(const cst_model* model, cst_coder_config cfg, c
     a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
     a.cdf16 = model->d_cdf16; a.L = model->cdf16_stride; a.recip = model->d_recip; a.words_out = d_words;
     a.stride_words = stride_words; a.n_words_out_enc = d_n_words; a.state = d_state; a.status = d_status; a.flags = flags;
-    if (cfg.word_bits == 32) return launch_ps(ans_encode_ps_kernel<32, 64>, a, hs);
-    return launch_ps(ans_encode_ps_kernel<16, 32>, a, hs);
+    if (cfg.word_bits == 32) return launch_ps(ans_encode_ps_kernel<32, 64>, a, true, hs);
+    return launch_ps(ans_encode_ps_kernel<16, 32>, a, true, hs);
 }
 
 cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
@@ -237,8 +309,8 @@ cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, c
     a.cdf16 = model->d_cdf16; a.L = model->cdf16_stride; a.words_in = d_words; a.offsets = d_offsets;
     a.stride_words = stride_words; a.n_words_in = d_n_words; a.n_words_left = d_n_words_out; a.state = d_state;
     a.status = d_status; a.flags = flags;
-    if (cfg.word_bits == 32) return launch_ps(ans_decode_ps_kernel<32, 64>, a, hs);
-    return launch_ps(ans_decode_ps_kernel<16, 32>, a, hs);
+    if (cfg.word_bits == 32) return launch_ps(ans_decode_ps_kernel<32, 64>, a, false, hs);
+    return launch_ps(ans_decode_ps_kernel<16, 32>, a, false, hs);
 }
 
 } // namespace cst
