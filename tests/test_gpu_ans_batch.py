@@ -2,6 +2,8 @@
 against the CPU oracle on the same seeded inputs -- bit-exact words, symbols, counts and status."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -346,6 +348,41 @@ def test_hand_scheduled_tiles_extremes(B, O, P, kind):
     dec2, _ = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P))
     torch.cuda.synchronize()
     assert np.array_equal(dec2.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CST_STRESS_SEEDS", "12"))))
+def test_random_shapes_and_models(B, O, seed):
+    """Randomised sweep over what selects a kernel variant: precision (hand-scheduled statements for P <= 12, generic
+    steps above), alphabet size (encoder table / decoder lookup footprints), batch shape (full waves, partial last wave,
+    fewer than two tiles, ragged tails), slab stride (aligned default vs arbitrary), packed vs slab decoding."""
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.choice([8, 9, 10, 11, 12, 12, 12, 16, 24]))
+    n_sym = int(rng.integers(2, min(300, (1 << P) - 1)))
+    lo = int(rng.integers(-500, 500))
+    probs = rng.dirichlet(np.ones(n_sym) * rng.choice([0.05, 0.3, 3.0]))
+    cdf = O.categorical_fast_cdf(probs, P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    n_streams = int(rng.choice([1, 63, 64, 65, 128, 200, 257, 1000, 2500]))
+    n_per = int(rng.choice([0, 1, 31, 32, 33, 63, 64, 65, 100, 256, 500, 701]))
+    sym = O.synth_symbols(seed, 0, n_streams, n_per, lo, cdf, P)
+    stride = None
+    if rng.random() < 0.4 and n_per > 0:
+        stride = B.max_words(n_per, (32, 64, P)) + int(rng.integers(1, 7))      # not a multiple of 16 words
+    want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdf, P, stride=stride) if stride else O.ans_encode_batch(sym, lo, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P), stride=stride)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    dec, dstatus = B.ans_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    if n_per > 0:
+        packed, offsets = B.compact(enc)
+        dec2, _ = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P))
+        torch.cuda.synchronize()
+        assert np.array_equal(dec2.cpu().numpy(), sym)
 
 
 def test_full_size_c2_properties(B, O):
