@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="streams per GPU (default: BASELINE config C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1 only: also time the RCCL gather of the packed words to rank 0 (reported as gather_ms, never "
+                         "part of `value`; off by default so that the scaling run has no collective at all on its data path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -187,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     compact_ms = e0.elapsed_time(e1)
     gather_ms = None
-    if dist is not None:
+    if dist is not None and args.gather:
         from constriction_amd import dist as D
         sync_all()
         g0 = time.perf_counter()
