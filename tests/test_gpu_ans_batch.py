@@ -385,6 +385,31 @@ def test_random_shapes_and_models(B, O, seed):
         assert np.array_equal(dec2.cpu().numpy(), sym)
 
 
+@pytest.mark.parametrize("P", [1, 2, 4, 7])
+@pytest.mark.parametrize("cfg_ws", [(32, 64), (16, 32)])
+def test_small_precisions(B, O, P, cfg_ws):
+    """Precisions below 8 bits stay on the generic steps (the 32-bit-halves forms need P >= 8): tiny alphabets,
+    including the 1-bit two-symbol model."""
+    W, S = cfg_ws
+    n_sym = min(1 << P, 5)
+    rng = np.random.default_rng(P)
+    cuts = np.sort(rng.choice(np.arange(1, 1 << P), n_sym - 1, replace=False))
+    cdf = np.concatenate(([0], cuts, [1 << P])).astype(np.uint32)      # any strictly increasing table is a valid model
+    model = B.Model.from_cdf(cdf, -1, P)
+    sym = O.synth_symbols(4, 0, 130, 257, -1, cdf, P)
+    want_words, want_n, want_status = O.ans_encode_batch(sym, -1, cdf, P, W, S)
+    enc = B.ans_encode(dev(sym), model, (W, S, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    mask = (1 << W) - 1
+    for s in range(130):
+        assert (words[s, : n_words[s]] & mask).tolist() == want_words[s, : want_n[s]].tolist()
+    dec, dstatus = B.ans_decode(enc, model, 257)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
 def test_full_size_c2_properties(B, O):
     """BASELINE config C2 at full size (65 536 x 4096): round trip is the identity, and a sample of
     streams is bit-identical to the oracle."""
