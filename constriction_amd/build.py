@@ -29,7 +29,8 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "constriction_amd.h"]
+    deps = (list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) +
+            [PKG.parent / "include" / "constriction_amd.h"])
     return any(d.stat().st_mtime > t for d in deps)
 
 
