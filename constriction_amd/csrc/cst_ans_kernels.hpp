@@ -725,12 +725,21 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
         c = e & 0xffffu; p = e >> 16;
         idx = lut.sym ? (uint32_t)(lut.sym[q] - lut.min_symbol) : (uint32_t)lut.idx[q];
     } else {
-        // bucket[q >> shift] = first index whose bin reaches into the bucket; scan forward
+        // bucket[q >> shift] = first index whose bin reaches into the bucket.  Probe the next three boundaries at once
+        // (cdf[n] = 2^P lies above every quantile, so clamped probes never count) and advance by the number of
+        // boundaries at or below q; a wave-uniform loop repeats only while some lane had to advance by all three.
         idx = bucket[q >> bucket_shift];
-        uint32_t nxt = cdf[idx + 1];
-        while (nxt <= q && (int)idx + 1 < n_symbols) { ++idx; nxt = cdf[idx + 1]; }
-        c = cdf[idx];
-        p = nxt - c;
+        const uint32_t n = (uint32_t)n_symbols;
+        uint32_t c0, c1, c2, c3, cnt;
+        for (;;) {
+            c0 = cdf[idx]; c1 = cdf[min(idx + 1, n)]; c2 = cdf[min(idx + 2, n)]; c3 = cdf[min(idx + 3, n)];
+            cnt = (c1 <= q ? 1u : 0u) + (c2 <= q ? 1u : 0u) + (c3 <= q ? 1u : 0u);
+            if (!__any(cnt == 3)) break;
+            idx += cnt;                      // (lanes with cnt < 3 are already in place: their next round counts 0)
+        }
+        idx += cnt;
+        c = cnt == 0 ? c0 : (cnt == 1 ? c1 : c2);
+        p = (cnt == 0 ? c1 : (cnt == 1 ? c2 : c3)) - c;
     }
 }
 
