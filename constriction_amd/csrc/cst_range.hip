@@ -73,9 +73,8 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
                 wave_lds_fence();
                 if (tb + 1 < n_full) tile_fetch<VEC>(a.symbols, a.n_streams, N, s0, (tb + 1) * kTileSyms, lane, r);
                 const int32_t* my = tile + lane * kTileStride;
-                // The step has (rare, divergent) carry branches which the compiler will not move loads across: fetch the
-                // symbols and table entries of quad j+1 explicitly before quad j is coded, or every symbol pays an LDS
-                // round trip (measured: 300 of 715 cycles per symbol waiting).
+                // Quads run the branch-free step_inline; a quad in which some lane leaves a long Inverted run is rolled
+                // back and repeated with the general step (rare).  Entries of quad j+1 are fetched before quad j is coded.
                 auto entry = [&](int32_t v) { return table[enc_index(v, a.min_symbol, nsym, L.bad)]; };
                 int4 v = *reinterpret_cast<const int4*>(my);
                 EncEntry e0 = entry(v.x), e1 = entry(v.y), e2 = entry(v.z), e3 = entry(v.w);
@@ -86,7 +85,15 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
                         v = *reinterpret_cast<const int4*>(my + 4 * (j + 1));
                         n0 = entry(v.x); n1 = entry(v.y); n2 = entry(v.z); n3 = entry(v.w);
                     }
-                    L.step(e0.c, e0.p, P); L.step(e1.c, e1.p, P); L.step(e2.c, e2.p, P); L.step(e3.c, e3.p, P);
+                    const auto lower0 = L.lower, range0 = L.range;
+                    const uint32_t wr0 = L.out.wr, inv_n0 = L.inv_n, inv_first0 = L.inv_first;
+                    bool slow = false;
+                    L.step_inline(e0.c, e0.p, P, slow); L.step_inline(e1.c, e1.p, P, slow);
+                    L.step_inline(e2.c, e2.p, P, slow); L.step_inline(e3.c, e3.p, P, slow);
+                    if (__any(slow)) {
+                        L.lower = lower0; L.range = range0; L.out.wr = wr0; L.inv_n = inv_n0; L.inv_first = inv_first0;
+                        L.step(e0.c, e0.p, P); L.step(e1.c, e1.p, P); L.step(e2.c, e2.p, P); L.step(e3.c, e3.p, P);
+                    }
                     e0 = n0; e1 = n1; e2 = n2; e3 = n3;
                     if ((j + 1) % G == 0) L.out.flush_chunks();
                 }

@@ -115,6 +115,35 @@ struct RangeEncLane {
         range = renorm ? sh_range : range;
     }
 
+    // The same step, branch free, for every case except one: leaving an Inverted run of TWO OR MORE held-back words
+    // (then `slow` is set and the caller repeats the quad with step()).  An Inverted situation as such is common
+    // (the interval straddles a word boundary with probability range / 2^32 at a renormalisation); a run longer than
+    // one word needs a second renormalisation inside it and is rare.  Two candidate words per step go to the ring
+    // unconditionally -- the resolved first word of a run and the regular word -- and `wr` advances by what was
+    // really emitted.  queue.rs:612-705.
+    __device__ __forceinline__ void step_inline(uint32_t c, uint32_t p, int P, bool& slow) {
+        const st_t scale = (st_t)(range >> P);
+        const st_t new_range = (st_t)(scale * (st_t)p);
+        const st_t new_lower = (st_t)(lower + scale * (st_t)c);
+        // leaving the Inverted situation?
+        const bool resolve = inv_n != 0 && (st_t)(new_lower + new_range) > new_lower;
+        slow |= resolve && inv_n >= 2u;
+        const uint32_t first = (inv_first + (new_lower < lower ? 1u : 0u)) & word_mask<W>();
+        out.push(first, resolve ? 1u : 0u);
+        const uint32_t n_inv = resolve ? 0u : inv_n;
+        // renormalisation
+        const bool renorm = new_range < ((st_t)1 << (S - W));
+        const uint32_t lower_word = (uint32_t)(new_lower >> (S - W)) & word_mask<W>();
+        const st_t sh_lower = (st_t)(new_lower << (W % S)), sh_range = (st_t)(new_range << (W % S));
+        const bool no_wrap = (st_t)(sh_lower + sh_range) > sh_lower;
+        out.push(lower_word, (renorm && n_inv == 0 && no_wrap) ? 1u : 0u);
+        const bool enter = renorm && n_inv == 0 && !no_wrap;
+        inv_first = enter ? lower_word : inv_first;
+        inv_n = enter ? 1u : ((renorm && n_inv != 0) ? n_inv + 1u : n_inv);
+        lower = renorm ? sh_lower : new_lower;
+        range = renorm ? sh_range : new_range;
+    }
+
     // seal_words / iter_seal (queue.rs:458-523)
     __device__ __forceinline__ int32_t finish(uint32_t n_symbols, uint32_t& n_words_out) {
         out.drain();
