@@ -731,13 +731,13 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
         idx = bucket[q >> bucket_shift];
         const uint32_t n = (uint32_t)n_symbols;
         uint32_t c0, c1, c2, c3, cnt;
-        for (;;) {
+        for (uint32_t guard = 0;; guard += 3) {      // (the guard only bounds the loop should a table ever be corrupt)
             c0 = cdf[idx]; c1 = cdf[min(idx + 1, n)]; c2 = cdf[min(idx + 2, n)]; c3 = cdf[min(idx + 3, n)];
             cnt = (c1 <= q ? 1u : 0u) + (c2 <= q ? 1u : 0u) + (c3 <= q ? 1u : 0u);
-            if (!__any(cnt == 3)) break;
-            idx += cnt;                      // (lanes with cnt < 3 are already in place: their next round counts 0)
+            if (guard > n || !__any(cnt == 3)) break;
+            idx = min(idx + cnt, n - 1u);    // (lanes with cnt < 3 are already in place: their next round counts 0)
         }
-        idx += cnt;
+        idx = min(idx + cnt, n - 1u);
         c = cnt == 0 ? c0 : (cnt == 1 ? c1 : c2);
         p = (cnt == 0 ? c1 : (cnt == 1 ? c2 : c3)) - c;
     }
