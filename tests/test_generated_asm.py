@@ -1,0 +1,49 @@
+"""The generated main-loop statements (constriction_amd/csrc/cst_{encode,decode}_loop.inc) must be exactly what
+scripts/gen_{encode,decode}_loop.py emit: the generators keep the s_waitcnt book, a hand edit of the .inc would not."""
+import importlib.util
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _load(name):
+    sys.path.insert(0, str(ROOT / "scripts"))
+    spec = importlib.util.spec_from_file_location(name, ROOT / "scripts" / f"{name}.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _regenerate(mod, tmp_path, name):
+    mod.OUT = tmp_path / name
+    mod.main()
+    return (tmp_path / name).read_text()
+
+
+def test_encode_loop_is_in_sync(tmp_path, monkeypatch):
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):
+        monkeypatch.delenv(var, raising=False)
+    text = _regenerate(_load("gen_encode_loop"), tmp_path, "cst_encode_loop.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop.inc").read_text()
+
+
+def test_decode_loop_is_in_sync(tmp_path, monkeypatch):
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):
+        monkeypatch.delenv(var, raising=False)
+    text = _regenerate(_load("gen_decode_loop"), tmp_path, "cst_decode_loop.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop.inc").read_text()
+
+
+def test_wait_bookkeeping_rejects_unreachable_counts():
+    """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
+    asmgen = _load("asmgen")
+    a = asmgen.Asm()
+    a.ds("ds_read_b32 v0, v1", "first")
+    for k in range(16):
+        a.ds(f"ds_read_b32 v{2 + k}, v1", "later")
+    try:
+        a.wait_lds("first")
+    except AssertionError:
+        return
+    raise AssertionError("lgkmcnt operand > 15 must be rejected")
