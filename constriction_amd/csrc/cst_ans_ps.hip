@@ -2,8 +2,9 @@
 // its own quantized-Gaussian table (learned-image-compression latents: one (mean, std) per channel / tile).
 //
 // Each lane's cumulative table (n+1 entries of 16 bits, row length L = 2^k) is held in LDS for the whole
-// kernel.  Row r of a wave is stored ROTATED by 2*lane entries, so that the lock-step accesses of the search
-// (all lanes probe the same index in the first rounds) fall on distinct banks.  Encoding needs (c, p) =
+// kernel, TRANSPOSED per wave: entry e of lane l lives at [e][l] (like the word rings).  The bank of an access then
+// depends on the lane only, whatever index the lane probes: two lanes per bank instead of the ~6-way conflicts random
+// per-lane indices cause in a row-per-lane layout (PMC: 200 of 1100 cycles per decoded symbol were bank conflicts).  Encoding needs (c, p) =
 // (row[i], row[i+1]-row[i]) and the reciprocal floor(2^64/p), which comes from a small table indexed by p
 // (shared by all streams, L1/L2 resident).  Decoding finds the largest i with row[i] <= q by a 4-ary search
 // (3 probes per round, ceil(log4 n) rounds, branch free).
@@ -34,11 +35,10 @@ struct PsArgs {
     uint32_t flags;
 };
 
-// rotated row accessor
+// this lane's column of its wave's transposed table: entry i at base[i * kWave]
 struct LaneRow {
-    const uint16_t* row;   // this lane's row in LDS
-    uint32_t rot, mask;
-    __device__ __forceinline__ uint32_t at(uint32_t i) const { return row[(i + rot) & mask]; }
+    const uint16_t* base;  // &table_of_wave[0][lane]
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return base[i * kWave]; }
 };
 
 // `pad`: entries behind cdf[n] become 0xFFFF, a sentinel above every quantile when P <= 15 (the decoder's search
@@ -52,13 +52,12 @@ __device__ __forceinline__ void stage_rows(uint16_t* lds_rows, const PsArgs& a, 
         const size_t s = block_s0 + j;
         uint16_t v = s < a.n_streams ? a.cdf16[s * L + e] : (uint16_t)0;
         if (pad && e > (uint32_t)a.n_symbols) v = 0xFFFFu;
-        lds_rows[j * L + ((e + 2u * (j & 63u)) & mask)] = v;
+        lds_rows[((size_t)(j >> 6) * L + e) * kWave + (j & 63u)] = v;      // [wave][entry][lane]
     }
 }
 
 // Bucket index of the per-stream decoder: kPsBuckets + 1 entries per stream, start[b] = the symbol index whose bin
-// holds quantile b * 2^(P - log2 kPsBuckets); row stride kPsIdxStride entries (an odd number of dwords: lock-step
-// accesses of the 64 lanes fall on distinct banks).
+// holds quantile b * 2^(P - log2 kPsBuckets); kPsIdxStride entries per lane, stored [bucket][lane] like the tables.
 constexpr int kPsBucketBits = 6, kPsBuckets = 1 << kPsBucketBits, kPsIdxStride = 66;
 
 template <int W, int S>
@@ -78,7 +77,7 @@ __global__ void ans_encode_ps_kernel(const PsArgs a) {
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     const uint32_t nsym = (uint32_t)a.n_symbols;
     const int G4 = 4 * groups_per_point(W, P);
-    LaneRow R{rows + (size_t)threadIdx.x * a.L, 2u * (uint32_t)lane, (uint32_t)a.L - 1u};
+    LaneRow R{rows + (size_t)(threadIdx.x >> 6) * a.L * kWave + lane};
 
     EncLane<W, S> L;
     L.init(a.words_out + (active ? s : 0) * a.stride_words,
@@ -166,7 +165,7 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     const uint32_t n = (uint32_t)a.n_symbols;
     const int G4 = 4 * groups_per_point(W, P);
     const uint32_t qmask = (1u << P) - 1u;
-    LaneRow R{rows + (size_t)threadIdx.x * a.L, 2u * (uint32_t)lane, (uint32_t)a.L - 1u};
+    LaneRow R{rows + (size_t)(threadIdx.x >> 6) * a.L * kWave + lane};
 
     DecLane<W, S> L;
     L.init(a.words_in + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words_in[s] : 0u, ring, lane);
@@ -178,7 +177,7 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     // P in [6, 15]: bucket index + sentinel-padded rows (see stage_rows); otherwise the plain bounded 4-ary search
     const bool indexed = P >= kPsBucketBits && P <= 15;
     uint16_t* bidx = reinterpret_cast<uint16_t*>(smem + (size_t)blockDim.x * a.L * 2 + (size_t)(blockDim.x / kWave) * kRingWords * 4) +
-                     (size_t)threadIdx.x * kPsIdxStride;
+                     (size_t)(threadIdx.x >> 6) * kPsIdxStride * kWave + lane;     // [wave][bucket][lane]
     if (indexed) {
         // this lane's own row -> its bucket index (one pass over the row)
         uint32_t i = 0;
@@ -186,9 +185,9 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
         for (uint32_t b = 0; b < (uint32_t)kPsBuckets; ++b) {
             const uint32_t q0 = b * w;
             while (i + 1 < n && R.at(i + 1) <= q0) ++i;
-            bidx[b] = (uint16_t)i;
+            bidx[b * kWave] = (uint16_t)i;
         }
-        bidx[kPsBuckets] = (uint16_t)(n - 1);
+        bidx[kPsBuckets * kWave] = (uint16_t)(n - 1);
         wave_lds_fence();
     }
 
@@ -200,8 +199,8 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
             // the answer lies in [start[b], start[b+1]]; everything behind start[b+1] (including the padding) is > q,
             // so the 4-ary refinement needs no bounds checks and a lane that is done is not disturbed by extra rounds
             const uint32_t b = q >> (P - kPsBucketBits);
-            lo = bidx[b];
-            uint32_t size = (uint32_t)bidx[b + 1] - lo + 1u;
+            lo = bidx[b * kWave];
+            uint32_t size = (uint32_t)bidx[(b + 1) * kWave] - lo + 1u;
             while (__any(size > 1)) {
                 const uint32_t step = (size + 3) >> 2;
                 // (probes clamped to index n, whose entry 2^P is itself above every quantile: the row may be exactly
