@@ -517,21 +517,28 @@ __device__ __forceinline__ uint32_t enc_index(int32_t sym, int32_t min_symbol, u
 }
 
 // LAYOUT 0: symbols[stream][t] staged through LDS tiles; LAYOUT 1: symbols[t][stream] read directly.
-template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST>
+// GLOBAL_TABLE: the encoder entries stay in HBM / L2 (alphabets too large for LDS: more than ~3800 symbols)
+template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST, bool GLOBAL_TABLE = false>
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][encoder table][symbol tiles]
     constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
-    EncEntry* table = reinterpret_cast<EncEntry*>(smem + kRingBytes);
-    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
+    const EncEntry* table;
+    const size_t table_bytes = GLOBAL_TABLE ? 0 : ((((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
     int32_t* tile = reinterpret_cast<int32_t*>(smem + kRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
     if constexpr (FAST) { if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap(); }
 
-    // stage the encoder table once per workgroup (16 B per lane per pass, coalesced)
-    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
+    if constexpr (GLOBAL_TABLE) {
+        table = a.enc;
+    } else {
+        // stage the encoder table once per workgroup (16 B per lane per pass, coalesced)
+        EncEntry* t = reinterpret_cast<EncEntry*>(smem + kRingBytes);
+        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = a.enc[i];
+        table = t;
+    }
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
             L.flush_chunks();
         }
         if (n_full > 0) {
-            constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8;
+            constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE;
             [[maybe_unused]] int32_t smin = a.min_symbol, smax = a.min_symbol;
             // wave-uniform: every slab of this wave 16-byte aligned and a whole number of chunks long
             const bool aligned_slabs = !__any(L.out.shift != 0 || (L.out.cap & 3u) != 0);

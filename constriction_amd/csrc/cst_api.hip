@@ -40,7 +40,14 @@ static cst_status launch(K kernel, size_t n_streams, size_t lds_bytes, hipStream
 template <int W, int S, int G, bool FAST>
 static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
-    if (table_bytes + kTileBytesPerBlock > kMaxLds) return CST_ERR_INVALID_ARGUMENT; // TODO(global-table path)
+    const bool vec0 = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
+    if (table_bytes + kTileBytesPerBlock > kMaxLds) {
+        // alphabet too large for an LDS-resident table: entries are read from HBM / L2 (generic steps)
+        if (layout == CST_LAYOUT_SYMBOL_MAJOR)
+            return launch(ans_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G, false, true>, a.n_streams, kTileBytesPerBlock, hs, a);
+        if (vec0) return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G, false, true>, a.n_streams, kTileBytesPerBlock, hs, a);
+        return launch(ans_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G, false, true>, a.n_streams, kTileBytesPerBlock, hs, a);
+    }
     // the main-loop statement of the (32,64), P <= 12 encoder alternates between two tile buffers per wave; without
     // room for the second one the kernel is told so (flag) and stays on the per-tile path
     constexpr size_t kSecondTiles = (size_t)(kBlock / kWave) * kWave * kTileStride * sizeof(int32_t);

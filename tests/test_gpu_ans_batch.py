@@ -410,6 +410,29 @@ def test_small_precisions(B, O, P, cfg_ws):
     assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
 
 
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 16), (16, 32, 16)], ids=lambda c: "W%dS%dP%d" % c)
+def test_alphabet_too_large_for_lds(B, O, cfg):
+    """More than ~3800 symbols: the 16-byte encoder entries no longer fit next to the rings and tiles in LDS and stay in
+    HBM / L2; the decoder uses its bucket index (P = 24) or the global lookup tables (P = 16)."""
+    W, S, P = cfg
+    n_sym = 6000
+    rng = np.random.default_rng(P)
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(n_sym) * 0.2), P)
+    model = B.Model.from_cdf(cdf, -3000, P)
+    sym = O.synth_symbols(8, 0, 150, 200, -3000, cdf, P)
+    want_words, want_n, want_status = O.ans_encode_batch(sym, -3000, cdf, P, W, S)
+    enc = B.ans_encode(dev(sym), model, cfg)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    mask = (1 << W) - 1
+    for s in range(150):
+        assert (words[s, : n_words[s]] & mask).tolist() == want_words[s, : want_n[s]].tolist()
+    dec, dstatus = B.ans_decode(enc, model, 200)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
 def test_full_size_c2_properties(B, O):
     """BASELINE config C2 at full size (65 536 x 4096): round trip is the identity, and a sample of
     streams is bit-identical to the oracle."""
