@@ -17,17 +17,24 @@ struct RangeEncodeArgs {
     uint32_t flags;
 };
 
-template <int W, int S, int LAYOUT, bool VEC, int G>
+// GLOBAL_TABLE: the encoder entries stay in HBM / L2 (alphabets too large for LDS)
+template <int W, int S, int LAYOUT, bool VEC, int G, bool GLOBAL_TABLE = false>
 __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
-    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
+    const EncEntry* table;
+    const size_t table_bytes = GLOBAL_TABLE ? 0 : ((((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + table_bytes) + wave_in_block * kRingWords;
     int32_t* tile = reinterpret_cast<int32_t*>(smem + table_bytes + (size_t)(kBlock / kWave) * kRingWords * 4) +
                     wave_in_block * (kWave * kTileStride);
-    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
+    if constexpr (GLOBAL_TABLE) {
+        table = a.enc;
+    } else {
+        EncEntry* t = reinterpret_cast<EncEntry*>(smem);
+        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = a.enc[i];
+        table = t;
+    }
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -246,9 +253,13 @@ template <int W, int S, int G>
 static cst_status range_encode_g(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15;
     const size_t lds = table_bytes + kPerBlockLds;
-    if (lds > kMaxLds) return CST_ERR_INVALID_ARGUMENT;
-    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return launch(range_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G>, a.n_streams, lds, hs, a);
     const bool vec = (a.n_per_stream % 4 == 0) && aligned16(a.symbols);
+    if (lds > kMaxLds) {   // alphabet too large for an LDS-resident table: entries are read from HBM / L2
+        if (layout == CST_LAYOUT_SYMBOL_MAJOR) return launch(range_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G, true>, a.n_streams, kPerBlockLds, hs, a);
+        if (vec) return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G, true>, a.n_streams, kPerBlockLds, hs, a);
+        return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G, true>, a.n_streams, kPerBlockLds, hs, a);
+    }
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return launch(range_encode_kernel<W, S, CST_LAYOUT_SYMBOL_MAJOR, false, G>, a.n_streams, lds, hs, a);
     if (vec) return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, true, G>, a.n_streams, lds, hs, a);
     return launch(range_encode_kernel<W, S, CST_LAYOUT_STREAM_MAJOR, false, G>, a.n_streams, lds, hs, a);
 }

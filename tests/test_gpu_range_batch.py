@@ -103,3 +103,22 @@ def test_range_full_size_c4(B, O):
     want_words, want_n, _ = O.rc_encode_batch(dsym[sample].cpu().numpy(), -50, cdf, P)
     for k, s in enumerate(sample):
         assert enc.stream(s).tolist() == want_words[k, : want_n[k]].tolist()
+
+
+def test_range_alphabet_too_large_for_lds(B, O):
+    """6000 symbols at P = 24: the encoder entries are read from HBM / L2, the decoder uses its bucket index."""
+    P = 24
+    rng = np.random.default_rng(77)
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(6000) * 0.2), P)
+    model = B.Model.from_cdf(cdf, -3000, P)
+    sym = O.synth_symbols(9, 0, 150, 200, -3000, cdf, P)
+    want_words, want_n, want_status = O.rc_encode_batch(sym, -3000, cdf, P)
+    enc = B.range_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    for s in range(150):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    dec, dstatus = B.range_decode(enc, model, 200)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
