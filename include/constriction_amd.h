@@ -122,7 +122,9 @@ cst_status cst_model_create_gaussian(int32_t precision, int32_t min_symbol, int3
                                      double mean, double std, void *stream, cst_model **out);
 
 /* One table PER STREAM (BASELINE config C3): stream s uses Gaussian(d_means[s], d_stds[s]).
- * d_means/d_stds are device arrays of n_streams doubles. */
+ * d_means/d_stds are device arrays of n_streams doubles.  Per-stream tables are coded from LDS: precision <= 16 and
+ * a support of at most 1023 symbols (larger ones make the coding calls return CST_ERR_INVALID_ARGUMENT; shared
+ * tables have no such limit). */
 cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_symbol, int32_t max_symbol,
                                                 const double *d_means, const double *d_stds,
                                                 size_t n_streams, void *stream, cst_model **out);
