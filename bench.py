@@ -213,10 +213,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 state / u32 words / i32 symbols", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"C2: {n_streams} streams/GPU x {N_PER} int32 symbols (stream-major), shared "
                                    f"12-bit QuantizedGaussian({LO},{HI},{MEAN},{STD}), AnsCoder (W,S,P)=({W},{S},{P}), "
-                                   "encode into slabs + decode", "streams_per_gpu": n_streams, "symbols_per_stream": N_PER,
+                                   "encode into slabs + decode; u64 coder state, u32 words, i32 symbols", "streams_per_gpu": n_streams, "symbols_per_stream": N_PER,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "bit_exact": ok,
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4),
