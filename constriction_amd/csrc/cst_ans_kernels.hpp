@@ -264,6 +264,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(
 // slab start (`shift` = slab start - base16, 0..3), so that every 4-aligned position group is one aligned
 // 16-B chunk of HBM.  A coder step writes its candidate word unconditionally and advances `wr` only if the
 // word was really emitted; complete chunks leave for HBM at scheduled points.
+template <int SLOTS = kRingSlots>
 struct RingWriter {
     uint32_t wr;        // words emitted so far (may exceed cap; then nothing more is stored)
     uint32_t flushed;   // positions < flushed are in HBM (multiple of 4, or 0)
@@ -283,7 +284,7 @@ struct RingWriter {
         wr = 0; flushed = 0;
     }
 
-    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (kRingSlots - 1)) * kWave + lane); }
+    __device__ __forceinline__ uint32_t* slot(uint32_t pos) const { return ring + ((pos & (SLOTS - 1)) * kWave + lane); }
 
     __device__ __forceinline__ void push(uint32_t word, uint32_t emit) {
         *slot(wr + shift) = word;   // always written; only becomes part of the stream if wr advances
@@ -334,7 +335,7 @@ struct RingWriter {
 
     // rare slow path: make room for a burst (range coder carry resolution)
     __device__ __forceinline__ void push_slow(uint32_t word) {
-        if (wr + shift - flushed >= (uint32_t)(kRingSlots - 4)) flush_chunks();
+        if (wr + shift - flushed >= (uint32_t)(SLOTS - 4)) flush_chunks();
         push(word, 1u);
     }
 
@@ -460,12 +461,12 @@ struct RingReader {
 // ------------------------------------------------------------------------------------------------
 
 // Per-lane ANS encoder: coder state + the word ring in front of this stream's output slab.
-template <int W, int S>
+template <int W, int S, int SLOTS = kRingSlots>
 struct EncLane {
     using st_t = typename StateT<S>::type;
     st_t state;
     uint32_t bad;       // largest raw table index seen (>= n_symbols <=> impossible symbol)
-    RingWriter out;
+    RingWriter<SLOTS> out;
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
         out.init(slab, capacity, wave_ring, lane_);
@@ -481,7 +482,7 @@ struct EncLane {
             const uint32_t k = (1u << P) - e.p;
             // ring slot address as (pos << 8 & 0x3f00) | lane_addr: one v_add_lshl + one v_and_or (the kernel checks
             // that the wave's ring is 16-KiB aligned)
-            const uint32_t ra = (((out.wr + out.shift) << 8) & (uint32_t)((kRingSlots - 1) * kWave * 4)) | out.lane_addr;
+            const uint32_t ra = (((out.wr + out.shift) << 8) & (uint32_t)((SLOTS - 1) * kWave * 4)) | out.lane_addr;
             ans_encode_step_asm(lo, hi, out.wr, ra, e, e.p << (32 - P), k, e.c + k);
             state = ((uint64_t)hi << 32) | lo;
             return;

@@ -1,0 +1,315 @@
+// cst_ans_pt.hip -- batched ANS with ONE MODEL PER STREAM (BASELINE config C3), compact tables.
+//
+// Every lane codes its stream with its own quantized-Gaussian table (learned-image-compression latents: one (mean, std)
+// per channel / tile).  What limits this shape is LDS: 256 full rows of a 255-symbol support do not fit next to the word
+// rings and symbol tiles of four waves, and a workgroup of fewer waves leaves SIMDs idle.  The tables are therefore
+// kept COMPACT (cst::PtMeta, built once per model by cst_model.hip): such a distribution is mostly runs of unit
+// probabilities, which need no table at all.  A workgroup of 256 streams then needs ~30-45 KB for its rows and runs four
+// waves per CU with rings and tiles like the shared-table coder.
+//
+//   encode  (stack.rs:1014-1048)   16-bit cumulatives of the symbols a..b between the unit runs at both ends, indexed by
+//           symbol: i -> t = clamp(i, a, b), one 32-bit LDS read (c[t], c[t+1]) at a 2-byte aligned address,
+//           c = c[t] + (i - t), p = c[t+1] - c[t]; m = floor(2^64 / p) from a reciprocal table shared by the workgroup.
+//   decode  (stack.rs:1070-1100)   entries  c << 20 | (p-1) << 8 | index  sorted by c, every run of unit probabilities
+//           folded into ONE entry; quantile q -> l1[q >> (P-7)] = first candidate, ONE 16-byte LDS read of four
+//           consecutive entries: the answer is the last of the first three that is <= q << 20 | 0xffffe, provided the
+//           fourth is larger; otherwise the lane continues from the fourth in a wave-uniform loop (buckets that hold
+//           more than three bins: the narrow bins next to the unit runs).
+// Shapes this file does not take (P > 12 or P < 8, more than 256 symbols, the 16-bit word preset, symbol-major
+// matrices, blocks whose rows do not fit in LDS) stay on the full-row kernels of cst_ans_ps.hip.
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+constexpr int kPtRingSlots = 32;                       // P <= 12: at most 12 words per 32-symbol tile (+ <= 15 pending)
+constexpr int kPtAhead = 24;
+constexpr size_t kPtRingBytes = (size_t)(kBlock / kWave) * kPtRingSlots * kWave * 4;          // 32 KiB
+constexpr size_t kPtTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;           // 36 KiB
+constexpr size_t kPtDumpBytes = (size_t)(kBlock / kWave) * 4 * kWave * 4;                     // decoder: landing rows
+constexpr size_t kPtL1Bytes = (size_t)kBlock * kPtBuckets;                                    // 32 KiB
+
+struct PtArgs {
+    const int32_t* symbols_in;
+    int32_t* symbols_out;
+    size_t n_streams, n_per_stream;
+    int32_t precision, n_symbols, min_symbol;
+    const PtMeta* meta;
+    const uint16_t* rows_enc;
+    const uint32_t* rows_dec;
+    const uint8_t* l1;
+    const uint32_t* block_base;    // of the rows in use
+    const uint64_t* recip;
+    uint32_t* words_out;
+    const uint32_t* words_in;
+    const uint64_t* offsets;
+    size_t stride_words;
+    uint32_t* n_words_out_enc;
+    const uint32_t* n_words_in;
+    uint32_t* n_words_left;
+    uint64_t* state;
+    int32_t* status;
+    uint32_t flags;
+};
+
+// copies this block's rows into LDS (coalesced, 4 bytes per lane)
+__device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* src, uint32_t n_words) {
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) rows_l[i] = src[i];
+}
+
+// LDS layout: [word rings, 8 KiB per wave][reciprocals 8 B x 2^P][symbol tiles][rows]
+__global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kPtRingSlots * kWave);
+    uint64_t* recip = reinterpret_cast<uint64_t*>(smem + kPtRingBytes);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kPtRingBytes + ((size_t)8 << P)) + wave_in_block * (kWave * kTileStride);
+    uint32_t* rows_l = reinterpret_cast<uint32_t*>(smem + kPtRingBytes + ((size_t)8 << P) + kPtTileBytes);
+    if ((lds_addr(ring) & (uint32_t)(kPtRingSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // step<true> forms ring addresses with and/or
+
+    for (int i = threadIdx.x; i < (1 << P); i += blockDim.x) recip[i] = a.recip[i];
+    {   // 16-bit rows; blocks start at even entries (cst_model.hip), so the copy moves whole words
+        const uint32_t bb = a.block_base[blockIdx.x], be = a.block_base[blockIdx.x + 1];
+        pt_stage_rows(rows_l, reinterpret_cast<const uint32_t*>(a.rows_enc + bb), (be - bb + 1) / 2);
+    }
+    __syncthreads();
+
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)wave_in_block * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
+    const uint32_t A = mt.a, B = (uint32_t)mt.a + mt.m - 1u;
+    // cumulatives of symbol index t (A <= t <= B) and of t + 1: the 32-bit word at row_addr + 2 * (t - A)
+    const uint32_t row_addr = lds_addr(rows_l) + 2u * mt.enc_off;
+
+    EncLane<32, 64, kPtRingSlots> L;
+    L.init(a.words_out + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    if (raw && active) L.state = a.state[s];
+
+    auto entry_of = [&](int32_t sym) {
+        const uint32_t i = enc_index(sym, a.min_symbol, nsym, L.bad);
+        const uint32_t t = min(max(i, A), B);
+        // (gfx950 LDS serves a 32-bit read at a 2-byte aligned address: scripts/microbench/lds_unaligned.hip)
+        const uint32_t e = *reinterpret_cast<const lds_u32*>((uintptr_t)(row_addr + 2u * (t - A)));
+        const uint32_t p = (e >> 16) - (e & 0xffffu);
+        const uint64_t m = recip[p];
+        return EncEntry{(e & 0xffffu) + (i - t), p, (uint32_t)m, (uint32_t)(m >> 32)};
+    };
+
+    const int32_t* my = a.symbols_in + (active ? s : 0) * N;
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_in) & 15) == 0);
+    const size_t n_full = vec ? N / kTileSyms : 0;
+    // ragged top part [32 * n_full, N): direct reads
+    for (size_t t = N; t > n_full * kTileSyms;) {
+        --t;
+        const int32_t v = active ? my[t] : a.min_symbol;
+        L.template step<true>(entry_of(v), P);
+        L.flush_chunks();
+    }
+    if (n_full > 0) {
+        int32_t r[kTileSyms];
+        tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
+        const int32_t* row = tile + lane * kTileStride;
+        for (size_t tb = n_full; tb-- > 0;) {
+            wave_lds_fence();
+            tile_to_lds<true>(tile, lane, r);
+            wave_lds_fence();
+            L.flush_chunks();                                   // words of the previous tile (stores before the loads)
+            if (tb > 0) tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (tb - 1) * kTileSyms, lane, r);
+            // the entries of quad j-1 are looked up before the steps of quad j run (nothing of it depends on the state)
+            int4 v = *reinterpret_cast<const int4*>(row + 4 * (kTileSyms / 4 - 1));
+            if (!active) v = make_int4(a.min_symbol, a.min_symbol, a.min_symbol, a.min_symbol);
+            EncEntry e3 = entry_of(v.w), e2 = entry_of(v.z), e1 = entry_of(v.y), e0 = entry_of(v.x);
+#pragma unroll
+            for (int j = kTileSyms / 4 - 1; j >= 0; --j) {
+                EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
+                if (j > 0) {
+                    int4 vn = *reinterpret_cast<const int4*>(row + 4 * (j - 1));
+                    if (!active) vn = make_int4(a.min_symbol, a.min_symbol, a.min_symbol, a.min_symbol);
+                    n3 = entry_of(vn.w); n2 = entry_of(vn.z); n1 = entry_of(vn.y); n0 = entry_of(vn.x);
+                }
+                L.template step<true>(e3, P); L.template step<true>(e2, P); L.template step<true>(e1, P); L.template step<true>(e0, P);
+                e3 = n3; e2 = n2; e1 = n1; e0 = n0;
+            }
+        }
+    }
+
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(!raw, nsym, n_words);
+    if (!active) return;
+    if (raw) a.state[s] = (uint64_t)L.state;
+    a.status[s] = status;
+    a.n_words_out_enc[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// LDS layout: [word rings, 8 KiB per wave][bucket index 128 B per stream][symbol tiles][dump rows][rows]
+__global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kPtRingSlots * kWave);
+    uint8_t* l1_l = smem + kPtRingBytes;
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kPtRingBytes + kPtL1Bytes) + wave_in_block * (kWave * kTileStride);
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kPtRingBytes + kPtL1Bytes + kPtTileBytes) + wave_in_block * (4 * kWave) + lane;
+    uint32_t* rows_l = reinterpret_cast<uint32_t*>(smem + kPtRingBytes + kPtL1Bytes + kPtTileBytes + kPtDumpBytes);
+
+    const size_t block_s0 = (size_t)blockIdx.x * kBlock;
+    {   // bucket index of the block's streams: 32 KiB, contiguous in HBM
+        const size_t have = a.n_streams - block_s0 < (size_t)kBlock ? (a.n_streams - block_s0) * kPtBuckets : kPtL1Bytes;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.l1 + block_s0 * kPtBuckets);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(l1_l);
+        for (uint32_t i = threadIdx.x; i < kPtL1Bytes / 4; i += blockDim.x) dst[i] = (size_t)i * 4 < have ? src[i] : 0u;
+    }
+    {
+        const uint32_t bb = a.block_base[blockIdx.x], be = a.block_base[blockIdx.x + 1];
+        pt_stage_rows(rows_l, a.rows_dec + bb, be - bb);
+    }
+    __syncthreads();
+
+    const size_t s0 = block_s0 + (size_t)wave_in_block * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t qmask = (1u << P) - 1u;
+    const int bshift = P - kPtBucketBits;
+    const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
+    const uint32_t row_addr = lds_addr(rows_l + mt.dec_off);
+    const uint8_t* l1p = l1_l + (size_t)threadIdx.x * kPtBuckets;
+
+    DecLane<32, 64, kPtRingSlots, kPtAhead> L;
+    L.init(a.words_in + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words_in[s] : 0u, ring, lane);
+    if (raw) L.state = active ? a.state[s] : 0;
+    else L.read_initial_state();
+    L.in.prime();
+    wave_lds_fence();
+    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+
+    auto decode_one = [&]() -> int32_t {
+        const uint32_t q = lo & qmask;
+        // candidate word for the refill, requested before the table search so that the search's waits cover it
+        const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
+        uint32_t r0 = l1p[q >> bshift];
+        const uint32_t qk = (q << 20) | 0xffffeu;
+        uint32_t e;
+        for (int guard = 0;; ++guard) {
+            // one 16-byte read at a 4-byte aligned address (gfx950 LDS serves it: scripts/microbench/lds_unaligned.hip);
+            // the wait sits in the same statement because the compiler's lgkmcnt book cannot see this read
+            v4u x;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(row_addr + 4u * r0) : "memory");
+            e = x.y <= qk ? x.y : x.x;
+            e = x.z <= qk ? x.z : e;
+            const bool more = x.w <= qk;                 // the bin lies behind the third candidate
+            if (!__any(more) || guard > 96) break;
+            r0 += more ? 3u : 0u;
+        }
+        const uint32_t pm1 = (e >> 8) & 0xfffu;
+        const bool run = pm1 == kPtRunMark;               // a run of unit probabilities: symbol index + (q - c), (c, p) = (q, 1)
+        const uint32_t d = q - (e >> 20);
+        const uint32_t p = run ? 1u : pm1 + 1u;
+        const uint32_t qc = run ? 0u : d;
+        const uint32_t idx = (e & 0xffu) + (run ? d : 0u);
+        // (state >> P) * p + (q - c) on 32-bit halves (P >= 8: the high product fits v_mul_u32_u24)
+        const uint32_t s_lo = __builtin_amdgcn_alignbit(hi, lo, P), s_hi = hi >> P;
+        const uint64_t t = (uint64_t)s_lo * p + (uint64_t)qc;
+        const uint32_t t_lo = (uint32_t)t;
+        const uint32_t t_hi = __umul24(s_hi, p) + (uint32_t)(t >> 32);
+        const bool refill = t_hi == 0u && L.in.rd > 0u;                // stack.rs:1089-1097
+        lo = refill ? next_word : t_lo;
+        hi = refill ? t_lo : t_hi;
+        L.in.rd -= refill ? 1u : 0u;
+        return a.min_symbol + (int32_t)idx;
+    };
+
+    int32_t* row = a.symbols_out + (active ? s : 0) * N;
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0);
+    const size_t n_full = vec ? N / kTileSyms : 0;
+    int32_t* my = tile + lane * kTileStride;
+    for (size_t tb = 0; tb < n_full; ++tb) {
+#pragma unroll
+        for (int j = 0; j < kTileSyms / 4; ++j) {
+            int4 v;
+            v.x = decode_one(); v.y = decode_one(); v.z = decode_one(); v.w = decode_one();
+            *reinterpret_cast<int4*>(my + 4 * j) = v;
+        }
+        L.in.template advance_window_fixed<3>(dump);
+        wave_lds_fence();
+        tile_store<true>(a.symbols_out, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        wave_lds_fence();
+    }
+    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        const int32_t v = decode_one();
+        if (active) row[t] = v;
+        L.in.advance_window();
+    }
+    if (!active) return;
+    a.status[s] = L.status;
+    if (raw) {
+        a.state[s] = ((uint64_t)hi << 32) | lo;
+        if (a.n_words_left) a.n_words_left[s] = L.in.rd;
+    }
+}
+
+static size_t pt_lds_bytes(const cst_model* m, bool encode) {
+    return encode ? kPtRingBytes + ((size_t)8 << m->precision) + kPtTileBytes + 2 * ((size_t)m->pt_max_enc + 4)
+                  : kPtRingBytes + kPtL1Bytes + kPtTileBytes + kPtDumpBytes + 4 * ((size_t)m->pt_max_dec + 4);
+}
+
+bool pt_usable(const cst_model* m, cst_coder_config cfg, cst_layout layout, size_t n_per_stream) {
+    (void)n_per_stream;
+    if (!m->pt_ok || cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR) return false;
+    if (m->precision < 8 || m->precision > 12) return false;
+    return pt_lds_bytes(m, true) <= 160 * 1024 && pt_lds_bytes(m, false) <= 160 * 1024;
+}
+
+template <typename K>
+static cst_status pt_launch(K kernel, const PtArgs& a, size_t lds, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    if (lds > 64 * 1024)
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                         uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status,
+                         uint32_t flags, hipStream_t hs) {
+    (void)cfg;
+    if (model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+    PtArgs a{};
+    a.symbols_in = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
+    a.meta = model->d_pt_meta; a.rows_enc = model->d_pt_enc; a.block_base = model->d_pt_block_base; a.recip = model->d_recip;
+    a.words_out = d_words; a.stride_words = stride_words; a.n_words_out_enc = d_n_words; a.state = d_state; a.status = d_status;
+    a.flags = flags;
+    return pt_launch(ans_encode_pt_kernel, a, pt_lds_bytes(model, true), hs);
+}
+
+cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                         size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                         uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, hipStream_t hs) {
+    (void)cfg;
+    if (model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+    PtArgs a{};
+    a.symbols_out = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
+    a.meta = model->d_pt_meta; a.rows_dec = model->d_pt_dec; a.l1 = model->d_pt_l1;
+    a.block_base = model->d_pt_block_base + (n_streams + kBlock - 1) / kBlock + 1;
+    a.words_in = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words_in = d_n_words;
+    a.n_words_left = d_n_words_out; a.state = d_state; a.status = d_status; a.flags = flags;
+    return pt_launch(ans_decode_pt_kernel, a, pt_lds_bytes(model, false), hs);
+}
+
+} // namespace cst

@@ -65,8 +65,7 @@ static cst_status encode_dispatch_g(const AnsEncodeArgs& a, cst_layout layout, h
 template <int W, int S>
 static cst_status encode_dispatch(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     // FAST = the 32-bit-halves step of the (32,64) preset, valid for P >= 8
-    static const bool env_fast = getenv("CST_ENC_FAST") ? atoi(getenv("CST_ENC_FAST")) != 0 : true; // A/B knob: hand-scheduled asm step vs the generic compiler-scheduled one
-    const bool fast = (W == 32) && a.precision >= 8 && env_fast;
+    const bool fast = (W == 32) && a.precision >= 8;
     switch (groups_per_point(W, a.precision)) {
         case 8: return fast ? encode_dispatch_g<W, S, 8, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 8, false>(a, layout, hs);
         case 4: return fast ? encode_dispatch_g<W, S, 4, W == 32>(a, layout, hs) : encode_dispatch_g<W, S, 4, false>(a, layout, hs);
@@ -229,7 +228,10 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
-    if (model->per_stream)   // one table per stream (config C3)
+    if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))   // one table per stream (config C3), compact rows
+        return ans_encode_pt(model, cfg, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, d_state, d_status,
+                             flags, (hipStream_t)stream);
+    if (model->per_stream)   // ... full rows (any supported shape)
         return ans_encode_per_stream(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words,
                                      d_state, d_status, flags, (hipStream_t)stream);
     AnsEncodeArgs a{};
@@ -252,6 +254,9 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
+    if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))
+        return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, d_state,
+                             d_n_words_out, d_status, flags, (hipStream_t)stream);
     if (model->per_stream)
         return ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream,
                                      layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);

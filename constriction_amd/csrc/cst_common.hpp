@@ -45,6 +45,29 @@ struct DecLut {      // pointers into LDS or global memory
     int32_t min_symbol;
 };
 
+// Per-stream tables in their compact form (cst_ans_pt.hip).  A quantized distribution over a support much wider than
+// its scale (the learned-compression case: support -127..127, std 0.5..16) consists mostly of runs of unit
+// probabilities: the leaky quantizer gives every symbol at least 1/2^P (quantize.rs:525-568).
+//   encoder row (16-bit cumulatives c[a..b+1], indexed by symbol):
+//       a = last index of the leading run of unit probabilities (0 if p[0] > 1), b = first index of the trailing run
+//       (n-1 if p[n-1] > 1); a symbol i < a has (c, p) = (c[a] - (a - i), 1), a symbol i > b has (c[b] + (i - b), 1).
+//   decoder row (32-bit entries sorted by c, searched by quantile): one entry per symbol,
+//       c << 20 | (p - 1) << 8 | index,  except that every maximal run of >= 2 unit probabilities is ONE entry
+//       c << 20 | 0xfff << 8 | first index  (quantile q of the run is symbol index + (q - c), with (c, p) = (q, 1));
+//       kPtRowPad sentinels 0xffffffff behind the row.  P <= 12, n <= 256.
+// Rows of different lengths lie back to back, blocks of kBlock streams are contiguous.
+struct PtMeta {
+    uint32_t enc_off;   // first 16-bit entry of the encoder row, relative to its block
+    uint32_t dec_off;   // first 32-bit entry of the decoder row, relative to its block
+    uint16_t a;         // first symbol index held by the encoder row
+    uint16_t m;         // symbols held by the encoder row (it has m + 1 entries)
+    uint16_t m_dec;     // entries of the decoder row (sentinels not counted)
+    uint16_t pad;
+};
+constexpr int kPtBucketBits = 7, kPtBuckets = 1 << kPtBucketBits;
+constexpr int kPtRowPad = 3;          // sentinel entries behind every decoder row
+constexpr uint32_t kPtRunMark = 0xfffu;
+
 } // namespace cst
 
 // The opaque model handle of the C ABI.
@@ -67,6 +90,14 @@ struct cst_model {
     uint16_t* d_cdf16 = nullptr;      // [n_tables][cdf16_stride]
     int32_t cdf16_stride = 0;
     uint64_t* d_recip = nullptr;      // [2^P]
+    // per-stream TRIMMED PACKED rows (cst_ans_pt.hip; built when P <= 12 and n <= 256): see cst::PtMeta
+    bool pt_ok = false;
+    cst::PtMeta* d_pt_meta = nullptr;     // [n_tables]
+    uint16_t* d_pt_enc = nullptr;         // encoder rows of all blocks, back to back
+    uint32_t* d_pt_dec = nullptr;         // decoder rows
+    uint8_t* d_pt_l1 = nullptr;           // [n_tables][kPtBuckets] quantile bucket -> first candidate (position in the decoder row)
+    uint32_t* d_pt_block_base = nullptr;  // [2][n_blocks + 1] first encoder / decoder row entry of every block of kBlock tables
+    uint32_t pt_max_enc = 0, pt_max_dec = 0;   // largest block (entries): sizes the LDS image of a workgroup
 };
 
 namespace cst {
@@ -91,6 +122,16 @@ cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, c
                                  size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
                                  size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
                                  int32_t* d_status, uint32_t flags, hipStream_t hs);
+
+// trimmed-packed-row coder launches (cst_ans_pt.hip); return CST_ERR_INVALID_ARGUMENT if the shape is not theirs
+bool pt_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, size_t n_per_stream);
+cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
+                         size_t n_per_stream, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
+                         int32_t* d_status, uint32_t flags, hipStream_t hs);
+cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                         size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                         size_t n_per_stream, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags,
+                         hipStream_t hs);
 
 inline bool config_supported(cst_coder_config c) {
     if (c.word_bits == 32 && c.state_bits == 64) return c.precision >= 1 && c.precision <= 24;

@@ -43,6 +43,122 @@ __global__ void cdf_to_u16_kernel(const uint32_t* __restrict__ cdf, size_t n_tab
     }
 }
 
+// ---- compact per-stream rows (cst::PtMeta, cst_ans_pt.hip) ----
+
+// pass 1, one thread per table: the unit runs at both ends -> (a, m); entries of the run-length decoder row -> m_dec
+__global__ void pt_measure_kernel(const uint32_t* __restrict__ cdf, size_t n_tables, int32_t n, PtMeta* __restrict__ meta) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tables) return;
+    const uint32_t* row = cdf + s * ((size_t)n + 1);
+    int r = 0;                                   // leading run: p[0..r) == 1
+    while (r < n && row[r + 1] - row[r] == 1u) ++r;
+    int t = 0;                                   // trailing run: p[n-t..n) == 1
+    while (t < n && row[n - t] - row[n - t - 1] == 1u) ++t;
+    int a = r > 0 ? r - 1 : 0;
+    const int b = t > 0 ? n - t : n - 1;
+    if (a > b) a = b;                            // the runs overlap (every probability is 1): one entry is enough
+    int cnt = 0;
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        if (row[i + 1] - row[i] == 1u) while (j < n && row[j + 1] - row[j] == 1u) ++j;
+        cnt += (j - i >= 2) ? 1 : (j - i);
+        i = j;
+    }
+    PtMeta mt{};
+    mt.a = (uint16_t)a; mt.m = (uint16_t)(b - a + 1); mt.m_dec = (uint16_t)cnt;
+    meta[s] = mt;
+}
+
+// pass 2, one workgroup per block of kBlock tables: row offsets inside the block, block sizes
+__global__ __launch_bounds__(256) void pt_offsets_kernel(PtMeta* __restrict__ meta, size_t n_tables, uint32_t* __restrict__ enc_size,
+                                                          uint32_t* __restrict__ dec_size) {
+    __shared__ uint32_t se[256], sd[256];
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t le = s < n_tables ? (uint32_t)meta[s].m + 1u : 0u;
+    const uint32_t ld = s < n_tables ? (uint32_t)meta[s].m_dec + kPtRowPad : 0u;
+    se[threadIdx.x] = le; sd[threadIdx.x] = ld;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t ve = threadIdx.x >= (unsigned)d ? se[threadIdx.x - d] : 0u, vd = threadIdx.x >= (unsigned)d ? sd[threadIdx.x - d] : 0u;
+        __syncthreads();
+        se[threadIdx.x] += ve; sd[threadIdx.x] += vd;
+        __syncthreads();
+    }
+    if (s < n_tables) { meta[s].enc_off = se[threadIdx.x] - le; meta[s].dec_off = sd[threadIdx.x] - ld; }
+    if (threadIdx.x == 255) { enc_size[blockIdx.x] = se[255]; dec_size[blockIdx.x] = sd[255]; }
+}
+
+// pass 3, one thread per table: the rows and the quantile bucket index of the decoder
+__global__ void pt_fill_kernel(const uint32_t* __restrict__ cdf, size_t n_tables, int32_t n, int P, const PtMeta* __restrict__ meta,
+                               const uint32_t* __restrict__ enc_base, const uint32_t* __restrict__ dec_base, uint16_t* __restrict__ enc,
+                               uint32_t* __restrict__ dec, uint8_t* __restrict__ l1) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tables) return;
+    const uint32_t* row = cdf + s * ((size_t)n + 1);
+    const PtMeta mt = meta[s];
+    uint16_t* e = enc + (size_t)enc_base[s / kBlock] + mt.enc_off;
+    for (uint32_t j = 0; j <= mt.m; ++j) e[j] = (uint16_t)row[mt.a + j];
+    // decoder row and, alongside, the bucket index: bucket k = quantiles [k * w, (k + 1) * w) -> position of the entry
+    // that holds k * w
+    uint32_t* d = dec + (size_t)dec_base[s / kBlock] + mt.dec_off;
+    uint8_t* b = l1 + s * kPtBuckets;
+    const int shift = P - kPtBucketBits;
+    uint32_t pos = 0, k = 0;
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        const uint32_t c = row[i], p = row[i + 1] - c;
+        if (p == 1u) while (j < n && row[j + 1] - row[j] == 1u) ++j;
+        if (j - i >= 2) {
+            d[pos] = (c << 20) | (kPtRunMark << 8) | (uint32_t)i;
+        } else {
+            j = i + 1;
+            d[pos] = (c << 20) | ((p - 1u) << 8) | (uint32_t)i;
+        }
+        const uint32_t c_end = row[j];                        // quantiles [c, c_end) belong to this entry
+        while (k < (uint32_t)kPtBuckets && (k << shift) < c_end) b[k++] = (uint8_t)pos;
+        ++pos;
+        i = j;
+    }
+    for (uint32_t j = 0; j < (uint32_t)kPtRowPad; ++j) d[pos + j] = 0xffffffffu;
+}
+
+// Builds the compact image of a per-stream model (8 <= P <= 12, n <= 256).  Failure to allocate only leaves pt_ok
+// false: the coder then uses the full-row kernels of cst_ans_ps.hip.
+static void build_pt_image(cst_model* m, hipStream_t hs) {
+    const int n = m->n_symbols, P = m->precision;
+    if (P > 12 || P < 8 || n > 256 || m->n_tables > 0x7fffffffull / 520) return;
+    const size_t nt = m->n_tables, n_blocks = (nt + kBlock - 1) / kBlock;
+    uint32_t* d_size = nullptr;
+    std::vector<uint32_t> h_size(2 * n_blocks), h_base(2 * (n_blocks + 1), 0);
+    bool ok = hipMalloc(&m->d_pt_meta, sizeof(PtMeta) * nt) == hipSuccess && hipMalloc(&d_size, 8 * n_blocks) == hipSuccess &&
+              hipMalloc(&m->d_pt_block_base, 8 * (n_blocks + 1)) == hipSuccess && hipMalloc(&m->d_pt_l1, nt * kPtBuckets) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(pt_measure_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, hs, (const uint32_t*)m->d_cdf, nt, n, m->d_pt_meta);
+        hipLaunchKernelGGL(pt_offsets_kernel, dim3((unsigned)n_blocks), dim3(256), 0, hs, m->d_pt_meta, nt, d_size, d_size + n_blocks);
+        ok = hipMemcpyAsync(h_size.data(), d_size, 8 * n_blocks, hipMemcpyDeviceToHost, hs) == hipSuccess &&
+             hipStreamSynchronize(hs) == hipSuccess;
+    }
+    uint32_t* eb = h_base.data(), *db = h_base.data() + n_blocks + 1;
+    if (ok) {
+        for (size_t k = 0; k < n_blocks; ++k) {
+            eb[k + 1] = eb[k] + ((h_size[k] + 1u) & ~1u);   // blocks of 16-bit rows start on a word
+            db[k + 1] = db[k] + h_size[n_blocks + k];
+            if (h_size[k] > m->pt_max_enc) m->pt_max_enc = h_size[k];
+            if (h_size[n_blocks + k] > m->pt_max_dec) m->pt_max_dec = h_size[n_blocks + k];
+        }
+        ok = hipMalloc(&m->d_pt_enc, 2 * ((size_t)eb[n_blocks] + 8)) == hipSuccess && hipMalloc(&m->d_pt_dec, 4 * ((size_t)db[n_blocks] + 4)) == hipSuccess &&
+             hipMemcpyAsync(m->d_pt_block_base, h_base.data(), 8 * (n_blocks + 1), hipMemcpyHostToDevice, hs) == hipSuccess;
+    }
+    if (ok) {
+        hipLaunchKernelGGL(pt_fill_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, hs, (const uint32_t*)m->d_cdf, nt, n, P,
+                           (const PtMeta*)m->d_pt_meta, (const uint32_t*)m->d_pt_block_base, (const uint32_t*)(m->d_pt_block_base + n_blocks + 1),
+                           m->d_pt_enc, m->d_pt_dec, m->d_pt_l1);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(hs) == hipSuccess;   // h_base must outlive the copy
+    }
+    if (d_size) (void)hipFree(d_size);
+    m->pt_ok = ok;
+}
+
 __global__ void debug_erf_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = erf_exact(x[i]);
@@ -239,6 +355,7 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
         if (e == hipSuccess) e = hipMemcpy(m->d_recip, rec.data(), 8 * np, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { set_hip_error(e, "per-stream gaussian tables"); cst_model_destroy(m); return CST_ERR_HIP; }
+    build_pt_image(m, hs);
     *out = m;
     return CST_OK;
 }
@@ -247,6 +364,7 @@ cst_status cst_model_destroy(cst_model* m) {
     if (!m) return CST_OK;
     hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec_cp); hipFree(m->d_dec_idx); hipFree(m->d_bucket);
     hipFree(m->d_cdf16); hipFree(m->d_recip);
+    hipFree(m->d_pt_meta); hipFree(m->d_pt_enc); hipFree(m->d_pt_dec); hipFree(m->d_pt_l1); hipFree(m->d_pt_block_base);
     delete m;
     return CST_OK;
 }

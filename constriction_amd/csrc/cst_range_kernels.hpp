@@ -77,7 +77,7 @@ struct RangeEncLane {
     st_t lower, range;
     uint32_t inv_n, inv_first;   // EncoderSituation: inv_n == 0 <=> Normal
     uint32_t bad;
-    RingWriter out;
+    RingWriter<> out;
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
         out.init(slab, capacity, wave_ring, lane_);
