@@ -53,6 +53,17 @@ struct PtArgs {
     uint32_t flags;
 };
 
+// Main loop of the decoder for P = 12: all full tiles of a FULL wave in one asm statement (generated, with its wait
+// counts, by scripts/gen_pt_decode_loop.py).
+__device__ __forceinline__ void pt_decode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
+                                                     uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
+                                                     uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
+                                                     uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                     uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                     const uint32_t (&goff)[8]) {
+#include "cst_pt_decode_loop.inc"
+}
+
 // copies this block's rows into LDS (coalesced, 4 bytes per lane)
 __device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* src, uint32_t n_words) {
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) rows_l[i] = src[i];
@@ -163,11 +174,19 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     uint32_t* rows_l = reinterpret_cast<uint32_t*>(smem + kPtRingBytes + kPtL1Bytes + kPtTileBytes + kPtDumpBytes);
 
     const size_t block_s0 = (size_t)blockIdx.x * kBlock;
-    {   // bucket index of the block's streams: 32 KiB, contiguous in HBM
+    const int bshift = P - kPtBucketBits;
+    {   // Bucket index of the block's streams (32 KiB, contiguous in HBM), interleaved in LDS in groups of G = 2^bshift
+        // lanes: bucket k of lane j at  (j / G) * 128 * G + k * G + j % G,  so that a lane's address for quantile q is
+        // (q & bucket_mask) | lane_base -- one v_and_or from the coder state.
         const size_t have = a.n_streams - block_s0 < (size_t)kBlock ? (a.n_streams - block_s0) * kPtBuckets : kPtL1Bytes;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.l1 + block_s0 * kPtBuckets);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(l1_l);
-        for (uint32_t i = threadIdx.x; i < kPtL1Bytes / 4; i += blockDim.x) dst[i] = (size_t)i * 4 < have ? src[i] : 0u;
+        for (uint32_t i = threadIdx.x; i < kPtL1Bytes / 4; i += blockDim.x) {
+            const uint32_t w = (size_t)i * 4 < have ? src[i] : 0u;
+            const uint32_t j = (4 * i) / kPtBuckets, k = (4 * i) % kPtBuckets;
+            uint8_t* d = l1_l + (((j >> bshift) * kPtBuckets) << bshift) + (j & ((1u << bshift) - 1u));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[(k + b) << bshift] = (uint8_t)(w >> (8 * b));
+        }
     }
     {
         const uint32_t bb = a.block_base[blockIdx.x], be = a.block_base[blockIdx.x + 1];
@@ -182,10 +201,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     const size_t N = a.n_per_stream;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     const uint32_t qmask = (1u << P) - 1u;
-    const int bshift = P - kPtBucketBits;
+    const uint32_t bucket_mask = (uint32_t)(kPtBuckets - 1) << bshift;
     const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
     const uint32_t row_addr = lds_addr(rows_l + mt.dec_off);
-    const uint8_t* l1p = l1_l + (size_t)threadIdx.x * kPtBuckets;
+    const uint8_t* l1p = l1_l + (((threadIdx.x >> bshift) * kPtBuckets) << bshift) + (threadIdx.x & ((1u << bshift) - 1u));
 
     DecLane<32, 64, kPtRingSlots, kPtAhead> L;
     L.init(a.words_in + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words_in[s] : 0u, ring, lane);
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
         const uint32_t q = lo & qmask;
         // candidate word for the refill, requested before the table search so that the search's waits cover it
         const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
-        uint32_t r0 = l1p[q >> bshift];
+        uint32_t r0 = l1p[q & bucket_mask];
         const uint32_t qk = (q << 20) | 0xffffeu;
         uint32_t e;
         for (int guard = 0;; ++guard) {
@@ -235,7 +254,32 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0);
     const size_t n_full = vec ? N / kTileSyms : 0;
     int32_t* my = tile + lane * kTileStride;
-    for (size_t tb = 0; tb < n_full; ++tb) {
+    size_t tb = 0;
+    if (P == 12 && n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24)) {
+        // The main-loop statement addresses HBM as uniform base + 32-bit lane offset: it needs a full wave, rows of
+        // < 2^24 symbols and this wave's compressed words within 2 GiB of a.words_in.
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words_in) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
+        if ((lds_addr(ring) & (uint32_t)(kPtRingSlots * kWave * 4 - 1)) != 0 || (lds_addr(l1_l) & (uint32_t)((kPtBuckets << bshift) - 1)) != 0) __builtin_trap();
+        if (!__any(!off_ok)) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols_out + s0 * N);
+            // wave-uniform store base in SGPRs (readfirstlane returns int: go through uint32_t)
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            pt_decode_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kPtRingSlots - 1) * kWave * 4), (uint32_t)P,
+                                 a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                 lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                 lds_addr(my), lds_addr(tile) + tr_off, goff);
+            tb = n_full;
+        }
+    }
+    for (; tb < n_full; ++tb) {
 #pragma unroll
         for (int j = 0; j < kTileSyms / 4; ++j) {
             int4 v;

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generates constriction_amd/csrc/cst_pt_decode_loop.inc: the hand-scheduled gfx950 main loop of the ANS decoder
+with ONE TABLE PER STREAM in its compact form (cst_ans_pt.hip, BASELINE config C3), (W,S,P) = (32,64,12).
+
+One asm statement decodes all full 32-symbol tiles of a wave's 64 streams.  Per symbol the serial chain is
+    q -> bucket index (ds_read_u8) -> four packed entries (one ds_read_b128 at a 4-byte aligned address)
+      -> last of the first three entries <= q << 20 | 0xffffe   [the fourth decides whether the lane must look further:
+         rare, handled by a wave-uniform loop that is branched around]
+      -> (c, p, index) -> N = (state >> P) * p + (q - c) -> refill? -> state' -> q'
+i.e. two dependent LDS round trips and 20 issue slots; everything else of a step (ring read of the next candidate
+word, shifted state halves, read-position update, symbol index -> symbol) is issued in the shadow of the bucket read.
+Per tile: up to three 16-byte chunks of compressed words are requested at the top and landed in the lane's LDS ring
+at the bottom (exactly as in gen_decode_loop.py); the tile of decoded symbols leaves for HBM at the end of the tile
+(eight transposing 16-byte LDS reads + eight 128-byte-row-segment stores per lane; a second tile buffer that would
+hide this costs 36 KiB of LDS the rows need).
+
+Run:  python scripts/gen_pt_decode_loop.py   (rewrites the .inc; the .inc is checked in)
+"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from asmgen import Asm  # noqa: E402
+
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_pt_decode_loop.inc"
+
+K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
+AHEAD_M1 = 23         # kPtAhead - 1
+
+N0, N1 = "v100", "v101"            # v[100:101] = N
+DD = "v102"                        # v[102:103] = [q - c (0 for a run), 0]
+PR, T0, T1, TT, R0, WD, RA, R1, QK, RA2 = (f"v{r}" for r in range(104, 114))
+X = ["v116", "v117", "v118", "v119"]
+X_T = "v[116:119]"
+E, PM1, D, IDXA, TS, IDX = (f"v{r}" for r in range(120, 126))
+SYM = [f"v{128 + k}" for k in range(8)]
+XO = [(f"v[{136 + 4 * k}:{139 + 4 * k}]") for k in range(4)]
+PEND = [(f"v[{152 + 4 * k}:{155 + 4 * k}]", [f"v{152 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
+LAND = [f"v{164 + k}" for k in range(K_CHUNKS)]
+WANT, TMP, TADDR, TOFF = "v167", "v168", "v169", "v170"
+SD, SAVE, M2, MORE, RUN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]"
+CLOBBERS = [f"v{r}" for r in range(100, 171)] + [f"s{r}" for r in range(80, 94)] + ["vcc", "scc", "memory"]
+
+
+def wait_if_pending(a, tag, comment=None):
+    if tag in a.lds:
+        a.wait_lds(tag, comment)
+
+
+def tail(a, sym_reg, first=False):
+    """everything of a step that is off the chain; issued behind the bucket read of the NEXT step"""
+    if not first:
+        a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc", "rd -= refill")
+    a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+    a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+    a.ds(f"ds_read_b32 {WD}, {RA}", "w", "candidate word of the next refill")
+    if not first:
+        a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
+    a.i(f"v_min_u32 {R1}, 1, %[rd]")
+    a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+    a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+    a.i(f"v_lshl_or_b32 {QK}, %[lo], 20, %[fffe]", "search key: every entry of a bin <= q compares <=")
+    if not first:
+        a.i(f"v_cndmask_b32_e64 {IDXA}, 0, {D}, {RUN}", "inside a run: index + (q - c)")
+        a.i(f"v_add3_u32 {sym_reg}, {IDX}, {IDXA}, %[minsym]", "decoded symbol")
+
+
+def step(a, j):
+    quad, pos = divmod(j, 4)
+    sym_reg = SYM[(quad % 2) * 4 + pos]
+    a.wait_lds("l1", f"---- step {j}: first candidate is back")
+    a.i(f"v_lshl_add_u32 {RA2}, {R0}, 2, %[rowaddr]")
+    a.ds(f"ds_read_b128 {X_T}, {RA2}", "x", "four consecutive entries (4-byte aligned address)")
+    if pos == 0 and j > 0:
+        base = ((quad - 1) % 2) * 4
+        a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+    a.wait_lds("x")
+    a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
+    a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
+    a.i(f"v_cmp_le_u32_e64 {MORE}, {X[3]}, {QK}", "fourth candidate <= q: the bin lies further on")
+    a.i(f"v_cndmask_b32 {E}, {X[0]}, {X[1]}, vcc")
+    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[2]}, {M2}")
+    a.i(f"s_cmp_lg_u64 {MORE}, 0")
+    a.i("s_cbranch_scc0 4f")
+    # wave-uniform continuation for the lanes in MORE (the others re-read their four entries and keep E)
+    a.i("3:")
+    a.i(f"v_cndmask_b32_e64 {TS}, 0, 12, {MORE}")
+    a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fourth candidate")
+    a.i(f"ds_read_b128 {X_T}, {RA2}")
+    a.i("s_waitcnt lgkmcnt(0)")
+    a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
+    a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
+    a.i(f"v_cndmask_b32 {TS}, {X[0]}, {X[1]}, vcc")
+    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[2]}, {M2}")
+    a.i(f"v_cndmask_b32_e64 {E}, {E}, {TS}, {MORE}")
+    a.i(f"v_cmp_le_u32_e64 {M2}, {X[3]}, {QK}")
+    a.i(f"s_and_b64 {MORE}, {MORE}, {M2}")
+    a.i(f"s_cmp_lg_u64 {MORE}, 0")
+    a.i("s_cbranch_scc1 3b")
+    a.i("4:")
+    a.i(f"v_sub_u32 {D}, {QK}, {E}")
+    a.i(f"v_bfe_u32 {PM1}, {E}, 8, 12", "p - 1, or the run mark")
+    a.i(f"v_lshrrev_b32 {D}, 20, {D}", "q - c")
+    a.i(f"v_cmp_eq_u32_e64 {RUN}, {PM1}, %[fff]", "run of unit probabilities: (c, p) = (q, 1)")
+    a.i(f"v_add_u32 {PR}, 1, {PM1}")
+    a.i(f"v_cndmask_b32_e64 {DD}, {D}, 0, {RUN}")
+    a.i(f"v_cndmask_b32_e64 {PR}, {PR}, 1, {RUN}")
+    a.i(f"v_mad_u64_u32 v[100:101], {SD}, {T0}, {PR}, v[102:103]", "N = (state >> P) * p + (q - c)")
+    a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+    a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
+    wait_if_pending(a, "w", "candidate word is back")      # (older than the entries: normally retired with them)
+    a.i(f"v_and_b32 {IDX}, 0xff, {E}", "(one instruction between a VALU write of vcc and its VALU reader)")
+    a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
+    a.i(f"v_and_or_b32 {TT}, %[lo], %[bmask], %[l1base]", "bucket of the next quantile (index interleaved by lane)")
+    a.ds(f"ds_read_u8 {R0}, {TT}", "l1", "<- end of the serial chain")
+    tail(a, sym_reg)
+
+
+def gen():
+    a = Asm()
+    a.i("v_mov_b32 v103, 0")
+    a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the current tile, bumped by 128 B per iteration")
+    a.i("s_mov_b32 s82, %[ntiles]")
+    # first bucket read and the off-chain values of step 0
+    a.i(f"v_and_or_b32 {TT}, %[lo], %[bmask], %[l1base]")
+    a.ds(f"ds_read_u8 {R0}, {TT}", "l1")
+    tail(a, None, first=True)
+    a.i("1:")
+    first = len(a.events)
+    lds_entry, vm_entry = list(a.lds), list(a.vm)
+
+    # ---- window: request the chunks this tile's successor may need (landed at the end of this iteration) ----
+    a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
+    a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kPtAhead, 0)")
+    for k in range(K_CHUNKS):
+        a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
+        a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+        a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
+        a.i(f"v_lshlrev_b32 {TADDR}, 8, %[lo_issued]")
+        a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+        a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+        a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
+        a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+        a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+        a.i(f"s_mov_b64 exec, {SAVE}")
+
+    for j in range(32):
+        step(a, j)
+
+    # ---- end of tile: last quad -> tile row, tile -> HBM, chunks -> ring ----
+    a.ds(f"ds_write_b128 %[rowcur], v[132:135] offset:112", "tile", "symbols 28..31")
+    a.wait_lds("tile")
+    for half in range(2):
+        for k in range(4):
+            a.ds(f"ds_read_b128 {XO[k]}, %[trcur] offset:{1152 * (4 * half + k)}", "xo", f"rows (lane>>3)+{8 * (4 * half + k)}")
+        a.wait_lds("xo")
+        for k in range(4):
+            a.vmem(f"global_store_dwordx4 %[goff{4 * half + k}], {XO[k]}, s[80:81] nt", "store")
+    a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
+    for k in range(K_CHUNKS):
+        r = PEND[k][1]
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_addc_u32 s81, s81, 0")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.wait_lds("land", "landed chunks visible to the next tile; the bucket and ring reads of its first step are older")
+    a.i("s_cbranch_scc1 1b")
+    # the back edge must leave the queues as the loop entry found them (modulo completed operations)
+    lds_end, vm_end, notes = a.verify_loop(first, list(a.lds), list(a.vm), passes=1)
+    assert lds_end == a.lds and vm_end == a.vm, (lds_end, a.lds, vm_end, a.vm)
+    assert [t for t in lds_entry if t not in ("l1", "w")] == [] and a.lds == [], (lds_entry, a.lds)
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    return a, notes
+
+
+def main():
+    a, notes = gen()
+    header = ["// GENERATED by scripts/gen_pt_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Main loop of the hand-scheduled per-stream-table ANS decoder: see pt_decode_tiles_loop in cst_ans_pt.hip."]
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued)',
+           '    : [bmask] "s"(bucket_mask), [cmask] "s"(ring_mask), [P] "s"(P), [fffe] "s"(0xffffeu), [fff] "s"(0xfffu), [minsym] "s"(min_symbol),',
+           '      [wbase] "s"(words_base), [gbase] "s"(store_base), [ntiles] "s"(n_tiles),',
+           '      [l1base] "v"(l1_lane_addr), [rowaddr] "v"(row_addr), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr),',
+           '      [dump] "v"(dump_addr), [woff] "v"(words_off), [rowcur] "v"(tile_row_addr), [trcur] "v"(tile_tr_addr),',
+           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
+    OUT.write_text(a.render(header, ops))
+    print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+
+
+if __name__ == "__main__":
+    main()
