@@ -8,13 +8,13 @@
 // waves per CU with rings and tiles like the shared-table coder.
 //
 //   encode  (stack.rs:1014-1048)   16-bit cumulatives of the symbols a..b between the unit runs at both ends, indexed by
-//           symbol: i -> t = clamp(i, a, b), one 32-bit LDS read (c[t], c[t+1]) at a 2-byte aligned address,
+//           symbol: i -> t = clamp(i, a, b), two 16-bit LDS reads (c[t], c[t+1]),
 //           c = c[t] + (i - t), p = c[t+1] - c[t]; m = floor(2^64 / p) from a reciprocal table shared by the workgroup.
 //   decode  (stack.rs:1070-1100)   entries  c << 20 | (p-1) << 8 | index  sorted by c, every run of unit probabilities
-//           folded into ONE entry; quantile q -> l1[q >> (P-7)] = first candidate, ONE 16-byte LDS read of four
-//           consecutive entries: the answer is the last of the first three that is <= q << 20 | 0xffffe, provided the
-//           fourth is larger; otherwise the lane continues from the fourth in a wave-uniform loop (buckets that hold
-//           more than three bins: the narrow bins next to the unit runs).
+//           folded into ONE entry; quantile q -> l1[q >> (P-7)] = the aligned pair of entries that holds the first
+//           candidate, six consecutive entries from there (two aligned LDS reads): the answer is the last of the first
+//           five that is <= q << 20 | 0xffffe, provided the sixth is larger; otherwise the lane continues four entries
+//           further in a wave-uniform loop (buckets that hold more than four bins: the narrow bins next to the unit runs).
 // Shapes this file does not take (P > 12 or P < 8, more than 256 symbols, the 16-bit word preset, symbol-major
 // matrices, blocks whose rows do not fit in LDS) stay on the full-row kernels of cst_ans_ps.hip.
 #include "cst_ans_kernels.hpp"
@@ -64,6 +64,18 @@ __device__ __forceinline__ void pt_decode_tiles_loop(uint32_t& lo, uint32_t& hi,
 #include "cst_pt_decode_loop.inc"
 }
 
+// Main loop of the encoder: all full tiles of a FULL wave in one asm statement (generated, with its wait counts, by
+// scripts/gen_pt_encode_loop.py).  sym_lo / sym_hi = first / last symbol index held by the lane's row,
+// row_addr_biased = LDS address of the row word of index 0 (row address - 2 * sym_lo).
+__device__ __forceinline__ void pt_encode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                     int32_t& smax, uint32_t tile_row_addr, uint32_t tile_tr_addr, uint32_t ring_lane_addr,
+                                                     uint32_t cap, uint32_t slab_off, uint32_t sym_lo, uint32_t sym_hi,
+                                                     uint32_t row_addr_biased, uint32_t recip_addr, int32_t min_symbol, uint32_t P,
+                                                     uint32_t ring_mask, const void* words_base, uint64_t symbols_base, uint32_t n_tiles,
+                                                     const uint32_t (&goff)[8]) {
+#include "cst_pt_encode_loop.inc"
+}
+
 // copies this block's rows into LDS (coalesced, 4 bytes per lane)
 __device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* src, uint32_t n_words) {
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) rows_l[i] = src[i];
@@ -98,7 +110,8 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
     const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
     const uint32_t A = mt.a, B = (uint32_t)mt.a + mt.m - 1u;
     // cumulatives of symbol index t (A <= t <= B) and of t + 1: the 32-bit word at row_addr + 2 * (t - A)
-    const uint32_t row_addr = lds_addr(rows_l) + 2u * mt.enc_off;
+    const uint16_t* rows16 = reinterpret_cast<const uint16_t*>(rows_l) + mt.enc_off;
+    const uint32_t row_addr = lds_addr(rows16);
 
     EncLane<32, 64, kPtRingSlots> L;
     L.init(a.words_out + (active ? s : 0) * a.stride_words,
@@ -108,8 +121,9 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
     auto entry_of = [&](int32_t sym) {
         const uint32_t i = enc_index(sym, a.min_symbol, nsym, L.bad);
         const uint32_t t = min(max(i, A), B);
-        // (gfx950 LDS serves a 32-bit read at a 2-byte aligned address: scripts/microbench/lds_unaligned.hip)
-        const uint32_t e = *reinterpret_cast<const lds_u32*>((uintptr_t)(row_addr + 2u * (t - A)));
+        // (two 16-bit reads: gfx950 LDS serves a misaligned 32-bit read, but 5x slower -- scripts/microbench/lds_tput.hip)
+        const uint16_t* cp = rows16 + (t - A);
+        const uint32_t e = (uint32_t)cp[0] | ((uint32_t)cp[1] << 16);
         const uint32_t p = (e >> 16) - (e & 0xffffu);
         const uint64_t m = recip[p];
         return EncEntry{(e & 0xffffu) + (i - t), p, (uint32_t)m, (uint32_t)(m >> 32)};
@@ -125,7 +139,35 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
         L.template step<true>(entry_of(v), P);
         L.flush_chunks();
     }
-    if (n_full > 0) {
+    bool done = false;
+    if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24)) {
+        // ---- main loop as one asm statement (full wave, 64-byte aligned slabs of whole 64-byte groups, 32-bit offsets) ----
+        const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words_out));
+        const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                        (L.out.cap & 15u) == 0 && L.out.shift == 0;
+        if (!__any(!ok)) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols_in + s0 * N + (n_full - 1) * kTileSyms);
+            // wave-uniform base in SGPRs (readfirstlane returns int: go through uint32_t)
+            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
+            int32_t smin = a.min_symbol, smax = a.min_symbol;
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            pt_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, lds_addr(tile + lane * kTileStride), lds_addr(tile) + tr_off,
+                                 L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A, lds_addr(recip), a.min_symbol,
+                                 (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out, symbols_base,
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            L.state = ((uint64_t)hi << 32) | lo;
+            // fold the extremes into `bad` (largest raw table index): a symbol below min_symbol wraps to a huge index
+            L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+            done = true;
+        }
+    }
+    if (n_full > 0 && !done) {
         int32_t r[kTileSyms];
         tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
         const int32_t* row = tile + lane * kTileStride;
@@ -203,7 +245,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     const uint32_t qmask = (1u << P) - 1u;
     const uint32_t bucket_mask = (uint32_t)(kPtBuckets - 1) << bshift;
     const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
-    const uint32_t row_addr = lds_addr(rows_l + mt.dec_off);
+    const uint32_t* rowp = rows_l + mt.dec_off;                 // 8-byte aligned
+    const uint32_t row_addr = lds_addr(rowp);
     const uint8_t* l1p = l1_l + (((threadIdx.x >> bshift) * kPtBuckets) << bshift) + (threadIdx.x & ((1u << bshift) - 1u));
 
     DecLane<32, 64, kPtRingSlots, kPtAhead> L;
@@ -222,15 +265,16 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
         const uint32_t qk = (q << 20) | 0xffffeu;
         uint32_t e;
         for (int guard = 0;; ++guard) {
-            // one 16-byte read at a 4-byte aligned address (gfx950 LDS serves it: scripts/microbench/lds_unaligned.hip);
-            // the wait sits in the same statement because the compiler's lgkmcnt book cannot see this read
-            v4u x;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(row_addr + 4u * r0) : "memory");
-            e = x.y <= qk ? x.y : x.x;
-            e = x.z <= qk ? x.z : e;
-            const bool more = x.w <= qk;                 // the bin lies behind the third candidate
-            if (!__any(more) || guard > 96) break;
-            r0 += more ? 3u : 0u;
+            // six entries from the 8-byte aligned pair that holds the first candidate (r0 = half its position)
+            const uint2* pr = reinterpret_cast<const uint2*>(rowp) + r0;
+            const uint2 x01 = pr[0], x23 = pr[1], x45 = pr[2];
+            e = x01.y <= qk ? x01.y : x01.x;
+            e = x23.x <= qk ? x23.x : e;
+            e = x23.y <= qk ? x23.y : e;
+            e = x45.x <= qk ? x45.x : e;
+            const bool more = x45.y <= qk;               // the bin lies behind the fifth entry
+            if (!__any(more) || guard > 64) break;
+            r0 += more ? 2u : 0u;
         }
         const uint32_t pm1 = (e >> 8) & 0xfffu;
         const bool run = pm1 == kPtRunMark;               // a run of unit probabilities: symbol index + (q - c), (c, p) = (q, 1)

@@ -36,9 +36,12 @@ class Asm:
         idx = max(k for k, t in enumerate(queue) if t == tag)
         return len(queue) - 1 - idx
 
-    def wait_lds(self, tag, comment=None):
-        """wait until the youngest LDS op tagged `tag` (and everything older) has completed"""
+    def wait_lds(self, tag, comment=None, cap=False):
+        """wait until the youngest LDS op tagged `tag` (and everything older) has completed; `cap`: the counter only
+        reaches 15 -- wait for more than asked instead of failing"""
         n = self._younger(self.lds, tag)
+        if cap:
+            n = min(n, 15)
         assert n <= 15, (tag, n)
         self.lds = self.lds[len(self.lds) - n:] if n else []
         self.events.append(("wait_lds", tag, n))

@@ -3,11 +3,12 @@
 with ONE TABLE PER STREAM in its compact form (cst_ans_pt.hip, BASELINE config C3), (W,S,P) = (32,64,12).
 
 One asm statement decodes all full 32-symbol tiles of a wave's 64 streams.  Per symbol the serial chain is
-    q -> bucket index (ds_read_u8) -> four packed entries (one ds_read_b128 at a 4-byte aligned address)
-      -> last of the first three entries <= q << 20 | 0xffffe   [the fourth decides whether the lane must look further:
-         rare, handled by a wave-uniform loop that is branched around]
+    q -> bucket index (ds_read_u8) -> six packed entries (ds_read2_b64 + ds_read_b64 from the 8-byte aligned pair that
+         holds the first candidate: a misaligned LDS read costs 5x, scripts/microbench/lds_tput.hip)
+      -> last of the first five entries <= q << 20 | 0xffffe   [the sixth decides whether the lane must look further:
+         0.2 extra rounds per wave step on the C3 tables, a wave-uniform loop that is branched around]
       -> (c, p, index) -> N = (state >> P) * p + (q - c) -> refill? -> state' -> q'
-i.e. two dependent LDS round trips and 20 issue slots; everything else of a step (ring read of the next candidate
+i.e. two dependent LDS round trips and 24 issue slots; everything else of a step (ring read of the next candidate
 word, shifted state halves, read-position update, symbol index -> symbol) is issued in the shadow of the bucket read.
 Per tile: up to three 16-byte chunks of compressed words are requested at the top and landed in the lane's LDS ring
 at the bottom (exactly as in gen_decode_loop.py); the tile of decoded symbols leaves for HBM at the end of the tile
@@ -30,16 +31,16 @@ AHEAD_M1 = 23         # kPtAhead - 1
 N0, N1 = "v100", "v101"            # v[100:101] = N
 DD = "v102"                        # v[102:103] = [q - c (0 for a run), 0]
 PR, T0, T1, TT, R0, WD, RA, R1, QK, RA2 = (f"v{r}" for r in range(104, 114))
-X = ["v116", "v117", "v118", "v119"]
-X_T = "v[116:119]"
+X = ["v116", "v117", "v118", "v119", "v126", "v127"]
+X_T, X45_T = "v[116:119]", "v[126:127]"
 E, PM1, D, IDXA, TS, IDX = (f"v{r}" for r in range(120, 126))
 SYM = [f"v{128 + k}" for k in range(8)]
 XO = [(f"v[{136 + 4 * k}:{139 + 4 * k}]") for k in range(4)]
 PEND = [(f"v[{152 + 4 * k}:{155 + 4 * k}]", [f"v{152 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
 LAND = [f"v{164 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v167", "v168", "v169", "v170"
-SD, SAVE, M2, MORE, RUN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]"
-CLOBBERS = [f"v{r}" for r in range(100, 171)] + [f"s{r}" for r in range(80, 94)] + ["vcc", "scc", "memory"]
+SD, SAVE, M2, MORE, RUN, M3, M4 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[76:77]", "s[78:79]"
+CLOBBERS = [f"v{r}" for r in range(100, 171)] + [f"s{r}" for r in range(76, 94)] + ["vcc", "scc", "memory"]
 
 
 def wait_if_pending(a, tag, comment=None):
@@ -69,31 +70,39 @@ def step(a, j):
     quad, pos = divmod(j, 4)
     sym_reg = SYM[(quad % 2) * 4 + pos]
     a.wait_lds("l1", f"---- step {j}: first candidate is back")
-    a.i(f"v_lshl_add_u32 {RA2}, {R0}, 2, %[rowaddr]")
-    a.ds(f"ds_read_b128 {X_T}, {RA2}", "x", "four consecutive entries (4-byte aligned address)")
+    a.i(f"v_lshl_add_u32 {RA2}, {R0}, 3, %[rowaddr]")
+    a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "six consecutive entries from the aligned pair that holds the first candidate")
+    a.ds(f"ds_read_b64 {X45_T}, {RA2} offset:16", "x")
     if pos == 0 and j > 0:
         base = ((quad - 1) % 2) * 4
         a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
     a.wait_lds("x")
     a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
     a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
-    a.i(f"v_cmp_le_u32_e64 {MORE}, {X[3]}, {QK}", "fourth candidate <= q: the bin lies further on")
+    a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
     a.i(f"v_cndmask_b32 {E}, {X[0]}, {X[1]}, vcc")
+    a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
     a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[2]}, {M2}")
+    a.i(f"v_cmp_le_u32_e64 {MORE}, {X[5]}, {QK}", "sixth entry <= q: the bin lies further on")
+    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[3]}, {M3}")
     a.i(f"s_cmp_lg_u64 {MORE}, 0")
+    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[4]}, {M4}")
     a.i("s_cbranch_scc0 4f")
-    # wave-uniform continuation for the lanes in MORE (the others re-read their four entries and keep E)
+    # wave-uniform continuation for the lanes in MORE (the others re-read their six entries and keep E)
     a.i("3:")
-    a.i(f"v_cndmask_b32_e64 {TS}, 0, 12, {MORE}")
-    a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fourth candidate")
-    a.i(f"ds_read_b128 {X_T}, {RA2}")
+    a.i(f"v_cndmask_b32_e64 {TS}, 0, 16, {MORE}")
+    a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fifth entry (8-byte aligned)")
+    a.i(f"ds_read2_b64 {X_T}, {RA2} offset1:1")
+    a.i(f"ds_read_b64 {X45_T}, {RA2} offset:16")
     a.i("s_waitcnt lgkmcnt(0)")
-    a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
-    a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
-    a.i(f"v_cndmask_b32 {TS}, {X[0]}, {X[1]}, vcc")
-    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[2]}, {M2}")
+    a.i(f"v_cmp_le_u32 vcc, {X[2]}, {QK}", "(the first two are known to be <= q)")
+    a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
+    a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
+    a.i(f"v_cndmask_b32 {TS}, {X[1]}, {X[2]}, vcc")
+    a.i(f"v_cmp_le_u32_e64 {M2}, {X[5]}, {QK}")
+    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[3]}, {M3}")
+    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[4]}, {M4}")
     a.i(f"v_cndmask_b32_e64 {E}, {E}, {TS}, {MORE}")
-    a.i(f"v_cmp_le_u32_e64 {M2}, {X[3]}, {QK}")
     a.i(f"s_and_b64 {MORE}, {MORE}, {M2}")
     a.i(f"s_cmp_lg_u64 {MORE}, 0")
     a.i("s_cbranch_scc1 3b")

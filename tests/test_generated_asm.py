@@ -35,6 +35,15 @@ def test_decode_loop_is_in_sync(tmp_path, monkeypatch):
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop.inc").read_text()
 
 
+def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
+    """the per-stream-table (C3) main loops"""
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):
+        monkeypatch.delenv(var, raising=False)
+    for name in ("pt_encode", "pt_decode"):
+        text = _regenerate(_load(f"gen_{name}_loop"), tmp_path, f"cst_{name}_loop.inc")
+        assert text == (ROOT / "constriction_amd" / "csrc" / f"cst_{name}_loop.inc").read_text()
+
+
 def test_wait_bookkeeping_rejects_unreachable_counts():
     """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
     asmgen = _load("asmgen")

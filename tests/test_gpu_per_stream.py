@@ -63,6 +63,50 @@ def test_per_stream_tables_roundtrip_parity(B, O, cfg, lo, hi, n_streams, n_per,
     assert np.array_equal(got.T if layout == "symbol_major" else got, sym)
 
 
+@pytest.mark.parametrize("case", ["narrow", "wide", "flat", "mixed", "two_symbols"])
+@pytest.mark.parametrize("n_streams,n_per", [(64, 96), (130, 100), (256, 32), (257, 4096 + 3)])
+def test_compact_rows_extremes(B, O, case, n_streams, n_per):
+    """The compact per-stream tables (cst_ans_pt.hip) at their limits: rows of a single bin, rows without any run of
+    unit probabilities, every probability equal to 1 (n = 2^P), both in one workgroup; full waves take the generated
+    main loops, the ragged last wave and the 3 extra symbols the compiler-scheduled paths."""
+    P, cfg = 12, (32, 64, 12)
+    rng = np.random.default_rng(n_streams * 7 + n_per)
+    lo, hi = -127, 127
+    if case == "narrow":
+        mu, sigma = rng.uniform(-100, 100, n_streams), np.full(n_streams, 1e-3)
+    elif case == "wide":
+        mu, sigma = rng.uniform(-10, 10, n_streams), np.full(n_streams, 1e4)      # nearly uniform: no unit runs at all
+    elif case == "flat":
+        lo, hi, P, cfg = 0, 255, 8, (32, 64, 8)                                    # n = 2^P: every probability is 1
+        mu, sigma = rng.uniform(0, 255, n_streams), rng.uniform(0.5, 300, n_streams)
+    elif case == "two_symbols":
+        lo, hi = 0, 1
+        mu, sigma = rng.uniform(-1, 2, n_streams), rng.uniform(0.1, 3, n_streams)
+    else:
+        mu = rng.uniform(-200, 200, n_streams)
+        sigma = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n_streams))
+    model = B.Model.quantized_gaussian_per_stream(lo, hi, dev(mu), dev(sigma), P)
+    cdfs = oracle_tables(O, lo, hi, mu, sigma, P)
+    sym = O.synth_symbols(0xC0FFEE, 0, n_streams, n_per, lo, cdfs, P, per_stream_tables=True)
+    # force the tails too: first / last symbols of the support and the ones next to them
+    sym[:, :4] = np.array([lo, hi, lo + 1, hi - 1])[: sym[:, :4].shape[1]] if hi - lo > 2 else sym[:, :4]
+    want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdfs, P, 32, 64)
+    enc = B.ans_encode(dev(sym), model, cfg)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and (want_status == 0).all()
+    assert n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    dec, dstatus = B.ans_decode(enc, model, n_per)
+    # and from the packed layout (unaligned streams)
+    packed, offsets = B.compact(enc)
+    dec2, _ = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=cfg)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all()
+    assert np.array_equal(dec.cpu().numpy(), sym) and np.array_equal(dec2.cpu().numpy(), sym)
+
+
 def test_per_stream_errors(B, O):
     mu, sigma = c3_params(70)
     model = B.Model.quantized_gaussian_per_stream(-127, 127, dev(mu), dev(sigma), 12)
