@@ -6,22 +6,27 @@
 One "step" = one pass of the hot path over one batch that is already resident in HBM:
 ANS-encode 65 536 independent 4096-symbol streams (int32, stream-major) with one shared 12-bit
 QuantizedGaussian(-50, 50, 3.2, 9.6) table into per-stream slabs, then ANS-decode them back
-(BASELINE.json configs[1], SURVEY.md 8d "C2").  With N > 1 every rank (one process per GPU,
-launched by torch.distributed.run) owns its own 65 536 streams (weak scaling, no data-path
-collective); the RCCL gather of the packed words to rank 0 is timed separately and reported as
-`gather_ms` (it is not part of `value`).
+(BASELINE.json configs[1], SURVEY.md 8d "C2").  With N > 1 every rank (one process per GPU) owns its own
+65 536 streams (weak scaling, no data-path collective).  `python bench.py --gpus N` starts its own ranks
+(re-executes itself under torch.distributed.run on 127.0.0.1) unless a launcher already did.
 
 Rank 0 prints ONE JSON line.  `value` = symbols all ranks processed / max-over-ranks time of the K
 timed steps (barrier + synchronize on both sides).  `roofline` is measured live with HIP events on
 the launch stream around the dominant kernel; `cpu_baseline` times the CPU oracle ("port": the
 repo's C restatement of the reference arithmetic, the Rust crate cannot be built here) on the
-host cores of the same box, on a bounded sample of the same workload.
+host cores of the same box.  The `configs` block carries, on the same clock, every other single-GPU
+configuration of BASELINE.json (the 16-bit-word and 24-bit presets of C2, C3 = one table per stream, C4 = range
+coder at P = 12 / 24, the C5 shard of 131 072 streams per GPU with compaction and -- N > 1 -- the RCCL gather of
+the packed words to rank 0): encode_ms / decode_ms / achieved fraction of the HBM roofline / bit_exact, where
+bit_exact compares EVERY stream's words with the CPU oracle's and the decoded symbols with the input.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -34,12 +39,13 @@ SEED = 0xC0FFEE
 LO, HI, MEAN, STD, P = -50, 50, 3.2, 9.6, 12
 W, S = 32, 64
 N_STREAMS, N_PER = 65536, 4096
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+C5_STREAMS = 131072       # per GPU: 1 048 576 streams over 8 GPUs
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def synth_symbols_device(seed, stream_begin, n_streams, n_per, lo, cdf_dev, precision, chunk=4096):
     """SURVEY.md 8(d) recipe on the GPU: q = splitmix64(seed ^ stream).next() >> (64-P); sym = quantile(q).
-    Bit-identical to oracle.synth_symbols (checked in tests)."""
+    Bit-identical to oracle.synth_symbols (tests/test_gpu_ans_batch.py::test_bench_symbols_match_the_oracle)."""
     dev = cdf_dev.device
     out = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
     G = -7046029254386353131           # 0x9E3779B97F4A7C15 as int64
@@ -58,6 +64,49 @@ def synth_symbols_device(seed, stream_begin, n_streams, n_per, lo, cdf_dev, prec
         idx = torch.searchsorted(inner, q, right=True)  # largest i with cdf[i] <= q
         out[a:b] = (idx + lo).to(torch.int32)
     return out
+
+
+def _blocks(n, parts):
+    step = max(1, (n + parts - 1) // parts)
+    return [(a, min(a + step, n)) for a in range(0, n, step)]
+
+
+def cpu_words_match(kind, sym_host, gpu_words, gpu_n_words, lo, cdf, precision, w_bits, s_bits):
+    """Encodes EVERY stream with the CPU oracle (one block of streams per host thread; the C code runs without the
+    GIL) and compares word counts and words with the GPU's slabs.  cdf: [n+1] shared or [n_streams][n+1]."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    per_stream = cdf.ndim == 2
+
+    def work(ab):
+        a, b = ab
+        c = cdf[a:b] if per_stream else cdf
+        if kind == "ans":
+            words, n_words, status = O.ans_encode_batch(sym_host[a:b], lo, c, precision, w_bits, s_bits)
+        else:
+            words, n_words, status = O.rc_encode_batch(sym_host[a:b], lo, c, precision, w_bits, s_bits)
+        if status.any() or not np.array_equal(n_words, gpu_n_words[a:b]):
+            return False
+        width = min(words.shape[1], gpu_words.shape[1])
+        if int(n_words.max(initial=0)) > width:
+            return False
+        mask = np.arange(width, dtype=np.uint32)[None, :] < n_words[:, None]
+        return bool(np.array_equal(np.where(mask, words[:, :width], 0), np.where(mask, gpu_words[a:b, :width], 0)))
+
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        return all(pool.map(work, _blocks(len(sym_host), 4 * cores)))
+
+
+def cpu_tables(lo, hi, mu, sigma, precision):
+    """one quantized-Gaussian cdf per stream from the oracle (host threads)"""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+
+    def work(ab):
+        return np.stack([O.GaussianModel(lo, hi, float(m), float(s), precision, 32).cdf_table() for m, s in zip(mu[ab[0]:ab[1]], sigma[ab[0]:ab[1]])])
+
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        return np.concatenate(list(pool.map(work, _blocks(len(mu), 2 * cores))))
 
 
 def cpu_baseline(cdf, symbols_host, repeats=3):
@@ -92,31 +141,151 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
     }
 
 
+def event_ms(fn, reps):
+    """average duration of fn() in ms, HIP events on torch's current stream (the launch stream of the library calls)"""
+    fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        fn()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    return float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
+
+
+def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO):
+    """One entry of the `configs` block: kernel times of encode and decode (HIP events), achieved fraction of the HBM
+    roofline (algorithmic bytes 4 B / symbol + 4 B / word per direction), bit-exactness of every stream."""
+    n_streams, n_per = symbols.shape
+    enc_fn = B.ans_encode if coder == "ans" else B.range_encode
+    dec_fn = B.ans_decode if coder == "ans" else B.range_decode
+    enc = enc_fn(symbols, model, cfg)
+    decoded = torch.empty_like(symbols)
+    enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc), reps)
+    dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded), reps)
+    total_words = enc.total_words()
+    n_sym = n_streams * n_per
+    byts = 4 * n_sym + 4 * total_words
+    entry = {
+        "workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
+        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
+        "Msymbols_per_s": round(n_sym / (enc_ms + dec_ms) / 1e3, 1), "words_per_stream": round(total_words / n_streams, 2),
+        "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+    }
+    if check:
+        ok = bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
+        if ok and cdf_host is not None:
+            words, n_words, _ = enc.to_numpy()
+            ok = cpu_words_match(coder, symbols.cpu().numpy(), words, n_words, lo, cdf_host, cfg[2], cfg[0], cfg[1])
+            entry["bit_exact_scope"] = f"all {n_streams} streams: words and counts vs CPU oracle, decoded symbols vs input"
+        entry["bit_exact"] = ok
+    return entry, enc
+
+
+def other_configs(B, rank, world, dist, args, reps=5):
+    """Every other single-GPU configuration of BASELINE.json, same clock, same checks (see the module docstring)."""
+    out = []
+    check = not args.no_check
+    from oracle import oracle as O
+
+    def gaussian(precision, lo=LO, hi=HI):
+        m = B.Model.quantized_gaussian(lo, hi, MEAN, STD, precision)
+        cdf = m.cdf()
+        if check:
+            assert cdf.tolist() == O.GaussianModel(lo, hi, MEAN, STD, precision, 32).cdf_table().tolist(), "device table != oracle"
+        return m, cdf
+
+    m12, cdf12 = gaussian(12)
+    cdf12_dev = torch.from_numpy(cdf12.astype(np.int64)).cuda()
+    sym12 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, cdf12_dev, 12)
+    if world == 1:
+        e, _ = run_config(B, "C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
+        out.append(e)
+        m24, cdf24 = gaussian(24)
+        sym24 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, torch.from_numpy(cdf24.astype(np.int64)).cuda(), 24)
+        e, _ = run_config(B, "C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        out.append(e)
+        e, _ = run_config(B, "C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        out.append(e)
+        e, _ = run_config(B, "C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        out.append(e)
+        del sym24, m24
+        # C3: one (mean, std) per stream, support -127..127
+        rng = np.random.default_rng(SEED)
+        mu = -10 + 20 * rng.random(N_STREAMS)
+        sigma = np.exp(np.log(0.5) + rng.random(N_STREAMS) * np.log(32))
+        mu_d, sigma_d = torch.from_numpy(mu).cuda(), torch.from_numpy(sigma).cuda()
+        m3 = B.Model.quantized_gaussian_per_stream(-127, 127, mu_d, sigma_d, 12)
+        g = torch.Generator(device="cuda").manual_seed(1234)
+        z = torch.randn((N_STREAMS, N_PER), generator=g, device="cuda", dtype=torch.float32)
+        sym3 = torch.clamp(torch.round(z * sigma_d.float()[:, None] + mu_d.float()[:, None]), -127, 127).to(torch.int32)
+        del z
+        cdfs = cpu_tables(-127, 127, mu, sigma, 12) if check else None
+        e, _ = run_config(B, "C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
+        out.append(e)
+        del sym3, m3, cdfs
+    del sym12
+    torch.cuda.empty_cache()
+    # C5 shard: 131 072 streams per GPU, compaction, gather of the packed words to rank 0
+    n5 = args.c5_streams
+    sym5 = synth_symbols_device(SEED, rank * n5, n5, N_PER, LO, cdf12_dev, 12)
+    e, enc5 = run_config(B, f"C5 shard: {n5} streams/GPU x {world} GPU(s)", "ans", (32, 64, 12), m12, sym5, reps, check and world == 1, cdf12)
+    packed, offsets = B.compact(enc5)
+    e["compact_ms"] = round(event_ms(lambda: B.compact(enc5, out=(packed, offsets)), reps), 4)
+    if dist is not None and not args.no_gather:
+        from constriction_amd import dist as D
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = D.gather_packed(packed[: int(offsets[-1].item())], offsets, dst=0)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        e["gather_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        if rank == 0:
+            e["gathered_words"] = int(res[0].numel())
+            e["gather_GBps"] = round(4 * res[0].numel() * (world - 1) / world / (e["gather_ms"] * 1e-3) / 1e9, 1)
+    out.append(e)
+    return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=N_STREAMS, help="streams per GPU (default: BASELINE config C2)")
+    ap.add_argument("--streams", type=int, default=N_STREAMS, help="streams per GPU of the headline step (default: BASELINE config C2)")
+    ap.add_argument("--c5-streams", type=int, default=C5_STREAMS, help="streams per GPU of the C5 shard entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1 only: also time the RCCL gather of the packed words to rank 0 (reported as gather_ms, never "
-                         "part of `value`; off by default so that the scaling run has no collective at all on its data path)")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` block")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of the C5 shard's packed words")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start our own ranks: one process per GPU on this node, rendezvous on 127.0.0.1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, **kw)
 
     from constriction_amd import batched as B
 
@@ -172,31 +341,22 @@ def main():
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
 
     ok = True
+    scope = "not checked"
     if not args.no_check:
         ok = bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
-        if rank == 0:
-            from oracle import oracle as O
-            sample = [0, 1, n_streams // 2, n_streams - 1]
-            host = symbols[sample].cpu().numpy()
-            ww, wn, _ = O.ans_encode_batch(host, LO, cdf, P, W, S)
-            for k, s in enumerate(sample):
-                ok = ok and enc.stream(s).tolist() == ww[k, : wn[k]].tolist()
+        scope = "decoded symbols vs input on every rank"
+        if rank == 0 and ok:
+            words, n_words, _ = enc.to_numpy()
+            ok = cpu_words_match("ans", symbols.cpu().numpy(), words, n_words, LO, cdf, P, W, S)
+            scope = f"all {n_streams} streams of rank 0: words and counts vs CPU oracle; decoded symbols vs input on every rank"
+            del words
 
-    # ---- compaction and (N > 1) gather of the packed words to rank 0, timed separately ----
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
     packed, offsets = B.compact(enc)
-    e1.record()
-    torch.cuda.synchronize()
-    compact_ms = e0.elapsed_time(e1)
-    gather_ms = None
-    if dist is not None and args.gather:
-        from constriction_amd import dist as D
-        sync_all()
-        g0 = time.perf_counter()
-        D.gather_packed(packed, offsets, dst=0)
-        sync_all()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+    compact_ms = event_ms(lambda: B.compact(enc, out=(packed, offsets)), 5)
+
+    configs = None
+    if not args.no_configs:
+        configs = other_configs(B, rank, world, dist, args)
 
     if rank == 0:
         traffic = None
@@ -218,9 +378,8 @@ def main():
                                    f"12-bit QuantizedGaussian({LO},{HI},{MEAN},{STD}), AnsCoder (W,S,P)=({W},{S},{P}), "
                                    "encode into slabs + decode; u64 coder state, u32 words, i32 symbols", "streams_per_gpu": n_streams, "symbols_per_stream": N_PER,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
-            "bit_exact": ok,
+            "bit_exact": ok, "bit_exact_scope": scope,
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4),
-            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "words_per_stream": round(total_words / n_streams, 2),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -228,6 +387,9 @@ def main():
                          "encode_GBps": round(bytes_per_launch / (enc_ms * 1e-3) / 1e9, 1),
                          "decode_GBps": round(bytes_per_launch / (dec_ms * 1e-3) / 1e9, 1)},
         }
+        if configs is not None:
+            line["configs"] = configs
+            ok = ok and all(c.get("bit_exact", True) for c in configs)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cdf, symbols.cpu().numpy())
         print(json.dumps(line), flush=True)

@@ -70,7 +70,8 @@ SIGNATURES = {
     "cst_model_get_cdf": (_i32, [_vp, _z, _vp, _vp]),
     "cst_ans_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
-    "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, C.POINTER(C.c_uint64), _vp]),
+    "cst_compact_scratch_bytes": (_z, [_z]),
+    "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
     "cst_ans_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
@@ -102,7 +103,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.cst_abi_version() != 1:
+    if lib.cst_abi_version() != 2:
         raise BackendUnavailable("ABI version mismatch between _native.py and libconstriction_amd.so")
     _lib = lib
     return lib

@@ -185,19 +185,36 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     return out, status
 
 
-def compact(encoded: EncodedBatch):
-    """Packs the slabs: returns (packed uint32 words as int32 tensor, offsets int64[n_streams+1])."""
+_scratch = {}
+
+
+def _compact_scratch(device, n_streams):
+    need = N.load_library().cst_compact_scratch_bytes(n_streams)
+    t = _scratch.get(device)
+    if t is None or t.numel() < need:
+        t = torch.empty(max(need, 4096), dtype=torch.uint8, device=device)
+        _scratch[device] = t
+    return t
+
+
+def compact(encoded: EncodedBatch, capacity: Optional[int] = None, out=None):
+    """Packs the slabs: returns (packed uint32 words as int32 tensor, offsets int64[n_streams+1]); offsets[-1] = total words.
+
+    One asynchronous kernel (single-pass scan fused with the gather), no host synchronisation: `packed` has `capacity`
+    words (default: the upper bound n_streams * stride, so that nothing can overflow) of which the first offsets[-1]
+    are valid.  `out=(packed, offsets)` reuses buffers of an earlier call."""
     n_streams = encoded.n_words.numel()
     dev = encoded.words.device
-    offsets = torch.empty(n_streams + 1, dtype=torch.int64, device=dev)
-    total = C.c_uint64(0)
-    L = N.lib()
-    N.check(L.cst_compact_words(None, 0, _ptr(encoded.n_words), n_streams, _ptr(offsets), None, 0, C.byref(total),
-                                _stream_ptr()), "cst_compact_words(offsets)")
-    packed = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
-    N.check(L.cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
-                                _ptr(offsets), _ptr(packed), packed.numel(), None, _stream_ptr()), "cst_compact_words")
-    return packed[: total.value], offsets
+    if out is not None:
+        packed, offsets = out
+    else:
+        capacity = capacity if capacity is not None else n_streams * encoded.words.shape[1]
+        packed = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(n_streams + 1, dtype=torch.int64, device=dev)
+    N.check(N.lib().cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
+                                      _ptr(offsets), _ptr(packed), packed.numel(), _ptr(_compact_scratch(dev, n_streams)),
+                                      _stream_ptr()), "cst_compact_words")
+    return packed, offsets
 
 
 def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
@@ -242,3 +259,85 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
                                            _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
                                            _stream_ptr()), "cst_range_decode_batch")
     return out, status
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-symbol quantized Gaussians: the reference's flagship call for many streams at once
+#     coder.encode_reverse(symbols, QuantizedGaussian(lo, hi), means, stds) / coder.decode(family, means, stds)
+# (src/pybindings/stream/stack.rs:567-588, 733-751): every symbol has its own (mean, std); `means` / `stds` are float64
+# tensors of the shape and layout of the symbol matrix (float32 callers widen first, src/pybindings/mod.rs:211-216).
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _gaussian_args(symbols_shape, means, stds):
+    means = _require_cuda(means, torch.float64, "means")
+    stds = _require_cuda(stds, torch.float64, "stds")
+    if tuple(means.shape) != tuple(symbols_shape) or tuple(stds.shape) != tuple(symbols_shape):
+        raise ValueError("means and stds must have the shape of the symbol matrix")
+    return means, stds
+
+
+def _encode_gaussian(fn_name, max_words_fn, symbols, min_symbol, max_symbol, means, stds, config, layout, stride, out):
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    means, stds = _gaussian_args(symbols.shape, means, stds)
+    if out is None:
+        stride = stride or max_words_fn(n_per, config)
+        dev = symbols.device
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    N.check(getattr(N.lib(), fn_name)(_cfg(*config), int(min_symbol), int(max_symbol), _ptr(symbols), _ptr(means), _ptr(stds),
+                                      n_streams, n_per, lay, _ptr(out.words), out.words.shape[1], _ptr(out.n_words), None,
+                                      _ptr(out.status), N.FLAG_NONE, _stream_ptr()), fn_name)
+    return out
+
+
+def ans_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32, 64, 24), layout="stream_major",
+                        stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One AnsCoder per stream: encode_reverse(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed."""
+    return _encode_gaussian("cst_ans_encode_gaussian_batch", max_words, symbols, min_symbol, max_symbol, means, stds, config,
+                            layout, stride, out)
+
+
+def range_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32, 64, 24), layout="stream_major",
+                          stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One RangeEncoder per stream: encode(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed
+    (src/pybindings/stream/queue.rs:343-410)."""
+    return _encode_gaussian("cst_range_encode_gaussian_batch", range_max_words, symbols, min_symbol, max_symbol, means, stds,
+                            config, layout, stride, out)
+
+
+def _decode_gaussian(fn_name, ans, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config):
+    if isinstance(encoded, EncodedBatch):
+        words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
+        stride = words.shape[1]
+    else:
+        words, n_words = encoded
+        stride = words.shape[1] if words.dim() == 2 else 0
+        config = config or (32, 64, 24)
+    if means.dim() != 2:
+        raise ValueError("means must be 2-d")
+    n_streams, n_per, lay = _layout_shape(means, layout)
+    if n_streams != n_words.numel():
+        raise ValueError("means / stds do not match the number of streams")
+    means, stds = _gaussian_args(means.shape, means, stds)
+    dev = words.device
+    if out is None:
+        out = torch.empty(tuple(means.shape), dtype=torch.int32, device=dev)
+    status = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    args = [_cfg(*config), int(min_symbol), int(max_symbol), _ptr(words), _ptr(offsets), stride, _ptr(n_words), _ptr(means), _ptr(stds),
+            _ptr(out), n_streams, n_per, lay, None]
+    if ans:
+        args.append(None)          # d_n_words_out
+    N.check(getattr(N.lib(), fn_name)(*args, _ptr(status), N.FLAG_NONE, _stream_ptr()), fn_name)
+    return out, status
+
+
+def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
+    """One AnsCoder per stream: AnsCoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
+    return _decode_gaussian("cst_ans_decode_gaussian_batch", True, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)
+
+
+def range_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
+    """One RangeDecoder per stream: RangeDecoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
+    return _decode_gaussian("cst_range_decode_gaussian_batch", False, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)

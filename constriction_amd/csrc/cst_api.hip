@@ -109,83 +109,83 @@ static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hip
     return decode_dispatch2<W, S, kDecBucket, false>(a, layout, 0, hs);
 }
 
-// ---- compaction ----
-constexpr int kScanItems = 4; // per thread
+// ---- compaction: single-pass exclusive scan (decoupled look-back) fused with the gather ----
+// One workgroup per kCompactStreams streams.  A workgroup takes a ticket (so that every predecessor it may wait for is
+// already running), scans its counts, publishes its aggregate in ONE 8-byte agent-scope store {flag, value} (no ordering
+// between flag and payload to get wrong: MI355X_MICROARCH.md, inter-workgroup visibility), looks back over its
+// predecessors 64 at a time, publishes its inclusive prefix, writes the offsets and copies its streams' words.
+constexpr int kCompactStreams = kBlock;
+constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagInclusive = 2ull << 62, kFlagMask = 3ull << 62;
 
-__global__ __launch_bounds__(kBlock) void scan_local_kernel(const uint32_t* __restrict__ n_words, size_t n,
-                                                             uint64_t* __restrict__ offsets, uint64_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restrict__ words, size_t stride, const uint32_t* __restrict__ n_words,
+                                                          size_t n_streams, uint64_t* __restrict__ offsets, uint32_t* __restrict__ packed,
+                                                          size_t capacity, uint32_t* __restrict__ ticket, uint64_t* __restrict__ status) {
     __shared__ uint64_t wave_sums[kBlock / kWave];
-    const size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
-    uint64_t v[kScanItems], sum = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? n_words[base + i] : 0; sum += v[i]; }
-    // inclusive scan of `sum` across the wave, then across the 4 waves
-    uint64_t incl = sum;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint64_t s_off[kCompactStreams];
+    __shared__ uint32_t s_len[kCompactStreams];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_bid;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t s = (size_t)bid * kCompactStreams + threadIdx.x;
+    const uint32_t len = s < n_streams ? n_words[s] : 0u;
+    uint64_t incl = len;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
     }
-    if (lane == 63) wave_sums[threadIdx.x >> 6] = incl;
+    if (lane == 63) wave_sums[wave] = incl;
     __syncthreads();
-    uint64_t wave_off = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wave_sums[w];
-    uint64_t excl = wave_off + incl - sum;
+    uint64_t wave_off = 0, total = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { if (base + i < n) offsets[base + i] = excl; excl += v[i]; }
-    if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = wave_off + incl;
-}
-
-// one workgroup: exclusive scan of the block sums in place; total -> offsets[n]
-__global__ __launch_bounds__(kBlock) void scan_blocks_kernel(uint64_t* __restrict__ block_sums, size_t n_blocks,
-                                                              uint64_t* __restrict__ total_out) {
-    __shared__ uint64_t wave_sums[kBlock / kWave];
-    __shared__ uint64_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    for (size_t start = 0; start < n_blocks; start += kBlock) {
-        const size_t i = start + threadIdx.x;
-        const uint64_t v = i < n_blocks ? block_sums[i] : 0;
-        uint64_t incl = v;
+    for (int w = 0; w < kBlock / kWave; ++w) { if (w < wave) wave_off += wave_sums[w]; total += wave_sums[w]; }
+    if (wave == 0) {
+        uint64_t prefix = 0;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(&status[bid], kFlagAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t base = (int64_t)bid - 1;; base -= 64) {
+                const int64_t i = base - lane;
+                uint64_t st = kFlagInclusive;                       // lanes before block 0: an empty inclusive prefix
+                if (i >= 0) {
+                    do { st = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st & kFlagMask) == 0);
+                }
+                // nearest predecessor (lowest lane) that already knows its inclusive prefix: sum up to and including it;
+                // without one in this window all 64 aggregates count and the look-back goes on
+                const uint64_t incl_mask = __ballot((st & kFlagMask) == kFlagInclusive);
+                const int stop = incl_mask ? __ffsll((long long)incl_mask) - 1 : 63;
+                uint64_t v = lane <= stop ? (st & ~kFlagMask) : 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                prefix += v;
+                if (incl_mask != 0) break;
+            }
         }
-        if (lane == 63) wave_sums[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint64_t off = carry_s;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wave_sums[w];
-        if (i < n_blocks) block_sums[i] = off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) carry_s = off + incl;
-        __syncthreads();
+        if (lane == 0) {
+            __hip_atomic_store(&status[bid], kFlagInclusive | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
     }
-    if (threadIdx.x == 0) *total_out = carry_s;
-}
-
-__global__ __launch_bounds__(kBlock) void scan_add_kernel(uint64_t* __restrict__ offsets, size_t n,
-                                                           const uint64_t* __restrict__ block_sums) {
-    const size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kScanItems;
-    const uint64_t add = block_sums[blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i)
-        if (base + i < n) offsets[base + i] += add;
-}
-
-// one wave per stream: copy its words from the slab to the packed buffer (256-B coalesced chunks)
-__global__ __launch_bounds__(kBlock) void gather_kernel(const uint32_t* __restrict__ words, size_t stride,
-                                                         const uint32_t* __restrict__ n_words, const uint64_t* __restrict__ offsets,
-                                                         size_t n_streams, uint32_t* __restrict__ packed) {
-    const size_t s = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (s >= n_streams) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t n = n_words[s];
-    const uint32_t* src = words + s * stride;
-    uint32_t* dst = packed + offsets[s];
-    for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    __syncthreads();
+    const uint64_t off = s_prefix + wave_off + incl - len;
+    if (s < n_streams) offsets[s] = off;
+    if (s + 1 == n_streams) offsets[n_streams] = off + len;
+    s_off[threadIdx.x] = off; s_len[threadIdx.x] = len;
+    __syncthreads();
+    if (!packed) return;
+    // gather: one wave per stream, 256-byte coalesced pieces
+    for (int k = wave; k < kCompactStreams; k += kBlock / kWave) {
+        const size_t sk = (size_t)bid * kCompactStreams + k;
+        if (sk >= n_streams) break;
+        const uint32_t n = s_len[k];
+        const uint64_t o = s_off[k];
+        if (o + n > capacity) continue;
+        const uint32_t* src = words + sk * stride;
+        uint32_t* dst = packed + o;
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
 }
 
 } // namespace cst
@@ -271,40 +271,28 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     return decode_dispatch<16, 32>(a, layout, hs);
 }
 
+size_t cst_compact_scratch_bytes(size_t n_streams) {
+    const size_t n_blocks = (n_streams + kCompactStreams - 1) / kCompactStreams;
+    return 16 + 8 * (n_blocks > 0 ? n_blocks : 1);
+}
+
 cst_status cst_compact_words(const uint32_t* d_words, size_t stride_words, const uint32_t* d_n_words, size_t n_streams,
-                             uint64_t* d_offsets, uint32_t* d_packed, size_t packed_capacity, uint64_t* h_total_words,
-                             void* stream) {
-    if (!d_n_words || !d_offsets) return CST_ERR_INVALID_ARGUMENT;
-    if (d_packed && !d_words) return CST_ERR_INVALID_ARGUMENT;
+                             uint64_t* d_offsets, uint32_t* d_packed, size_t packed_capacity, void* d_scratch, void* stream) {
+    if (!d_offsets) return CST_ERR_INVALID_ARGUMENT;
     hipStream_t hs = (hipStream_t)stream;
-    const size_t per_block = (size_t)kBlock * kScanItems;
-    const size_t n_blocks = (n_streams + per_block - 1) / per_block;
-    uint64_t total = 0;
     if (n_streams == 0) {
         CST_HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, hs));
-    } else {
-        uint64_t* block_sums = nullptr;
-        CST_HIP_TRY(hipMallocAsync((void**)&block_sums, 8 * n_blocks, hs));
-        hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, hs, d_n_words, n_streams, d_offsets,
-                           block_sums);
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(kBlock), 0, hs, block_sums, n_blocks, d_offsets + n_streams);
-        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, hs, d_offsets, n_streams,
-                           (const uint64_t*)block_sums);
-        CST_HIP_TRY(hipGetLastError());
-        CST_HIP_TRY(hipFreeAsync(block_sums, hs));
+        return CST_OK;
     }
-    if (h_total_words || d_packed) {
-        CST_HIP_TRY(hipMemcpyAsync(&total, d_offsets + n_streams, 8, hipMemcpyDeviceToHost, hs));
-        CST_HIP_TRY(hipStreamSynchronize(hs));
-        if (h_total_words) *h_total_words = total;
-    }
-    if (d_packed && n_streams > 0) {
-        if (total > packed_capacity) return CST_ERR_INVALID_ARGUMENT;
-        const size_t blocks = (n_streams * kWave + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, hs, d_words, stride_words, d_n_words,
-                           (const uint64_t*)d_offsets, n_streams, d_packed);
-        CST_HIP_TRY(hipGetLastError());
-    }
+    if (!d_n_words || !d_scratch || (d_packed && !d_words)) return CST_ERR_INVALID_ARGUMENT;
+    const size_t n_blocks = (n_streams + kCompactStreams - 1) / kCompactStreams;
+    if (n_blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipMemsetAsync(d_scratch, 0, cst_compact_scratch_bytes(n_streams), hs));
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(d_scratch);
+    uint64_t* status = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(d_scratch) + 16);
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, hs, d_words, stride_words, d_n_words, n_streams,
+                       d_offsets, d_packed, packed_capacity, ticket, status);
+    CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
 

@@ -8,8 +8,9 @@
 //   * explicit per-symbol models: (left, prob) pairs for encoding and cdf rows for decoding.
 //
 // Encoding is two passes: a fully parallel pass turns every symbol into a coder entry (c, p, 2^64/p), then one
-// LANE per stream runs the sequential recurrence over those entries.  Gaussian decoding uses one WAVE per stream:
-// 64 lanes evaluate 64 candidate left cumulatives at once (two erf rounds for a 201-symbol support).
+// LANE per stream runs the sequential recurrence over those entries.  Decoding uses one WAVE per stream:
+// 64 lanes evaluate 64 candidate left cumulatives at once (two erf rounds / two coalesced row reads for a 201-symbol
+// support).
 #include "cst_range_kernels.hpp"
 #include "cst_math.hpp"
 
@@ -219,11 +220,32 @@ struct DirectDecoder<W, S, kRange> {
     }
 };
 
-// Gaussian: one WAVE per stream.  Every lane carries the same coder state; the search for
-// quantile_function (semantics of quantize.rs:580-779: the unique symbol with left(sym) <= q < left(sym+1))
-// evaluates up to 64 candidate left cumulatives per round.
-template <int W, int S, int KIND>
-__global__ __launch_bounds__(kBlock) void decode_gaussian_wave_kernel(const PerSymbolDecodeArgs a) {
+// One WAVE per stream.  Every lane carries the same coder state; the search for quantile_function (semantics of
+// quantize.rs:580-779 / lookup_contiguous.rs:564-605: the unique symbol with left(sym) <= q < left(sym+1)) evaluates up
+// to 64 candidate left cumulatives per round: two rounds for a 201-symbol support.  MODEL supplies left(element, i).
+struct GaussianLeft {
+    static constexpr int32_t kBadModel = CST_STREAM_IMPOSSIBLE_SYMBOL;   // degenerate distribution (quantize.rs:562-565)
+    const PerSymbolDecodeArgs& a;
+    double mu, sd;
+    __device__ __forceinline__ bool load(size_t e) {
+        mu = a.means[e]; sd = a.stds[e];
+        // the reference panics on an invalid model (pybindings/stream/model.rs:654-657)
+        return sd > 0.0 && sd <= 1.7976931348623157e308 && mu == mu && mu <= 1.7976931348623157e308 && mu >= -1.7976931348623157e308;
+    }
+    __device__ __forceinline__ uint32_t left(uint32_t i) const {
+        return leaky_gaussian_left((int32_t)i, a.min_symbol, a.n_symbols, a.precision, 32, mu, sd);
+    }
+};
+struct RowLeft {                       // explicit cdf rows [n + 1] per coded symbol: 64 coalesced entries per round
+    static constexpr int32_t kBadModel = CST_STREAM_INVALID_DATA;          // a row that is not a cdf for this quantile
+    const PerSymbolDecodeArgs& a;
+    const uint32_t* row;
+    __device__ __forceinline__ bool load(size_t e) { row = a.cdf_rows + e * ((size_t)a.n_symbols + 1); return true; }
+    __device__ __forceinline__ uint32_t left(uint32_t i) const { return row[i]; }
+};
+
+template <int W, int S, int KIND, class MODEL>
+__global__ __launch_bounds__(kBlock) void decode_wave_kernel(const PerSymbolDecodeArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (s >= a.n_streams) return;
@@ -236,13 +258,10 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_wave_kernel(const PerS
 
     DirectDecoder<W, S, KIND> D;
     D.init(a, s, raw);
+    MODEL M{a};
     int32_t status = D.status;
     for (size_t t = 0; t < N && status == CST_STREAM_OK; ++t) {
-        const double mu = a.means[e0 + t * stride_t], sd = a.stds[e0 + t * stride_t];
-        if (!(sd > 0.0 && sd <= 1.7976931348623157e308 && mu == mu && mu <= 1.7976931348623157e308 && mu >= -1.7976931348623157e308)) {
-            status = CST_STREAM_IMPOSSIBLE_SYMBOL;   // the reference panics on an invalid model (model.rs:654-657)
-            break;
-        }
+        if (!M.load(e0 + t * stride_t)) { status = CST_STREAM_IMPOSSIBLE_SYMBOL; break; }
         const uint32_t q = D.quantile(P);
         if (D.status != CST_STREAM_OK) { status = D.status; break; }
         uint32_t base = 0, count = n;                 // invariant: left(base) <= q
@@ -250,19 +269,19 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_wave_kernel(const PerS
             const uint32_t stride = (count + 63) / 64;
             const uint32_t off = (uint32_t)lane * stride;
             const bool valid = off < count;
-            const uint32_t val = valid ? leaky_gaussian_left((int32_t)(base + off), a.min_symbol, (int32_t)n, P, 32, mu, sd) : 0u;
+            const uint32_t val = valid ? M.left(base + off) : 0u;
             const unsigned long long m = __ballot(valid && val <= q);
-            const uint32_t k = (uint32_t)__popcll(m);   // >= 1: lane 0 always qualifies
+            const uint32_t k = max((uint32_t)__popcll(m), 1u);   // (lane 0 always qualifies for a valid table)
             const uint32_t adv = (k - 1) * stride;
             base += adv;
             count = min(stride, count - adv);
         }
-        const uint32_t val = ((uint32_t)lane <= count) ? leaky_gaussian_left((int32_t)(base + lane), a.min_symbol, (int32_t)n, P, 32, mu, sd) : 0u;
+        const uint32_t val = ((uint32_t)lane <= count) ? M.left(base + lane) : 0u;
         const unsigned long long m = __ballot((uint32_t)lane < count && val <= q);
         const uint32_t k = (uint32_t)__popcll(m);
-        const uint32_t c = __shfl(val, (int)(k - 1), 64), nxt = __shfl(val, (int)k, 64);
+        const uint32_t c = __shfl(val, (int)(k > 0 ? k - 1 : 0), 64), nxt = __shfl(val, (int)min(k, 63u), 64);
         const uint32_t p = nxt - c;
-        if (p == 0 || k == 0) { status = CST_STREAM_IMPOSSIBLE_SYMBOL; break; }   // degenerate distribution
+        if (p == 0 || k == 0 || c > q || (uint64_t)c + p > ((uint64_t)1 << P)) { status = MODEL::kBadModel; break; }
         if (lane == 0) a.symbols[e0 + t * stride_t] = a.min_symbol + (int32_t)(base + k - 1);
         D.advance(q, c, p, P);
     }
@@ -270,39 +289,6 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_wave_kernel(const PerS
         a.status[s] = status;
         D.finish(a, s, raw);
     }
-}
-
-// explicit cdf rows: one LANE per stream, bisection in the symbol's own row
-template <int W, int S, int KIND>
-__global__ __launch_bounds__(kBlock) void decode_rows_kernel(const PerSymbolDecodeArgs a) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_streams) return;
-    const size_t N = a.n_per_stream;
-    const int P = a.precision;
-    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
-    const uint32_t n = (uint32_t)a.n_symbols;
-    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
-    const size_t e0 = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N;
-    DirectDecoder<W, S, KIND> D;
-    D.init(a, s, raw);
-    int32_t status = D.status;
-    for (size_t t = 0; t < N && status == CST_STREAM_OK; ++t) {
-        const size_t e = e0 + t * stride_t;
-        const uint32_t* row = a.cdf_rows + e * ((size_t)n + 1);
-        const uint32_t q = D.quantile(P);
-        if (D.status != CST_STREAM_OK) { status = D.status; break; }
-        uint32_t lo = 0, hi = n - 1;                 // largest i with row[i] <= q
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo + 1) / 2;
-            if (row[mid] <= q) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t c = row[lo], p = row[lo + 1] - c;
-        if (p == 0 || c > q) { status = CST_STREAM_INVALID_DATA; break; }
-        a.symbols[e] = a.min_symbol + (int32_t)lo;
-        D.advance(q, c, p, P);
-    }
-    a.status[s] = status;
-    D.finish(a, s, raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,14 +340,14 @@ static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t
 template <int KIND>
 static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
     if (a.n_streams == 0) return CST_OK;
+    const size_t blocks = (a.n_streams * kWave + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
     if (gaussian) {
-        const size_t blocks = (a.n_streams * kWave + kBlock - 1) / kBlock;
-        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_wave_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
-        else hipLaunchKernelGGL((decode_gaussian_wave_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_wave_kernel<32, 64, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        else hipLaunchKernelGGL((decode_wave_kernel<16, 32, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
     } else {
-        const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_rows_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
-        else hipLaunchKernelGGL((decode_rows_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_wave_kernel<32, 64, KIND, RowLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
+        else hipLaunchKernelGGL((decode_wave_kernel<16, 32, KIND, RowLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
     }
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
@@ -373,7 +359,8 @@ static cst_status fill_decode_args(PerSymbolDecodeArgs& a, cst_coder_config cfg,
                                    uint32_t flags) {
     if (cst_status st = check_common(cfg, layout)) return st;
     if (!d_n_words || !d_status || (n_per_stream > 0 && !d_symbols)) return CST_ERR_INVALID_ARGUMENT;
-    if (n_symbols < 2 || n_symbols > ((int64_t)1 << cfg.precision) || n_symbols > 65536) return CST_ERR_MODEL;
+    // (the same support limit as the encoding entry points: per-symbol models hold no tables, any n <= 2^P works)
+    if (n_symbols < 2 || n_symbols > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
     a.min_symbol = min_symbol; a.n_symbols = (int32_t)n_symbols; a.status = d_status; a.flags = flags;

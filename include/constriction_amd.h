@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CST_ABI_VERSION 1
+#define CST_ABI_VERSION 2
 
 typedef enum cst_status {
     CST_OK = 0,
@@ -181,14 +181,20 @@ cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, co
                                 uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
                                 uint32_t flags, void *stream);
 
-/* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one
- * packed buffer (the concatenation of every stream's `into_compressed()` result).
- * d_packed may be NULL to compute the offsets only.  packed_capacity is in words; if the total
- * exceeds it nothing is copied and CST_ERR_INVALID_ARGUMENT is returned after the offsets are
- * written (the call synchronises `stream` to read the total). */
+/* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
+ * concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled
+ * look-back, fused with the copy), fully asynchronous on `stream`: no host synchronisation, no allocation.
+ *   d_offsets        out: offsets[s] = first word of stream s in the packed buffer; offsets[n_streams] = total words
+ *   d_packed         may be NULL to compute the offsets only
+ *   packed_capacity  words available at d_packed (an upper bound such as n_streams * stride_words always suffices);
+ *                    a stream that would end beyond it is not copied -- the caller sees offsets[n_streams] > capacity
+ *   d_scratch        cst_compact_scratch_bytes(n_streams) bytes of device memory, contents irrelevant on entry
+ * (The reference has no counterpart: its coders each own a Vec<u32>; this is the container layout of
+ *  src/pybindings/stream/stack.rs:149-166 -- little-endian u32 words, one offset per message.) */
+size_t cst_compact_scratch_bytes(size_t n_streams);
 cst_status cst_compact_words(const uint32_t *d_words, size_t stride_words, const uint32_t *d_n_words,
                              size_t n_streams, uint64_t *d_offsets, uint32_t *d_packed,
-                             size_t packed_capacity, uint64_t *h_total_words, void *stream);
+                             size_t packed_capacity, void *d_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * per-symbol quantized Gaussians: the reference's flagship Python call

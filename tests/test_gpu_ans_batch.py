@@ -457,3 +457,54 @@ def test_full_size_c2_properties(B, O):
         assert enc.stream(s).tolist() == want_words[k, : want_n[k]].tolist()
     avg = enc.total_words() / n_streams
     assert 650 < avg < 740  # ~692 words per stream
+
+
+# ------------------------------------------------------------------ compaction (single-pass scan + gather)
+
+@pytest.mark.parametrize("n_streams,n_per", [(0, 8), (1, 40), (255, 33), (256, 64), (257, 100), (5000, 37), (70001, 24)])
+def test_compact_offsets_and_words(B, O, n_streams, n_per):
+    """cst_compact_words: offsets = exclusive prefix sum of the word counts (look-back over up to 274 workgroups),
+    packed = concatenation of the streams' words; asynchronous, total on device."""
+    P = 12
+    cdf = O.GaussianModel(-20, 20, 1.5, 4.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, -20, P)
+    sym = O.synth_symbols(7, 0, n_streams, n_per, -20, cdf, P)
+    if n_streams > 3:
+        sym[3, :] = -20                              # a very cheap stream: one or two words
+    enc = B.ans_encode(dev(sym), model, (32, 64, P)) if n_streams else None
+    if n_streams == 0:
+        from constriction_amd.batched import EncodedBatch
+        enc = EncodedBatch(torch.empty((0, 16), dtype=torch.int32, device="cuda"), torch.empty(0, dtype=torch.int32, device="cuda"),
+                           torch.empty(0, dtype=torch.int32, device="cuda"), (32, 64, P))
+    packed, offsets = B.compact(enc)
+    torch.cuda.synchronize()
+    words, n_words, _ = enc.to_numpy()
+    off = offsets.cpu().numpy()
+    want = np.concatenate([[0], np.cumsum(n_words.astype(np.int64))])
+    assert off.tolist() == want.tolist()
+    pk = packed.cpu().numpy().view(np.uint32)
+    flat = np.concatenate([words[s, : n_words[s]] for s in range(n_streams)] + [np.zeros(0, np.uint32)])
+    assert np.array_equal(pk[: off[-1]], flat)
+    if n_streams > 10:
+        # a packed buffer that is too small: streams that do not fit are skipped, the total still tells
+        cap = int(off[n_streams // 2]) + 1
+        small, off2 = B.compact(enc, capacity=cap)
+        small.fill_(-1)
+        small, off2 = B.compact(enc, out=(small, off2))
+        torch.cuda.synchronize()
+        assert off2.cpu().numpy().tolist() == want.tolist() and int(off2[-1]) > cap
+        sm = small.cpu().numpy().view(np.uint32)
+        assert np.array_equal(sm[: off[n_streams // 2]], flat[: off[n_streams // 2]])
+
+
+def test_bench_symbols_match_the_oracle(B, O):
+    """bench.py's device-side workload generator is the SURVEY 8(d) recipe of oracle.synth_symbols, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", str(__import__("pathlib").Path(__file__).resolve().parent.parent / "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for P, begin, n_streams, n_per in [(12, 0, 300, 257), (12, 65536 * 3 + 5, 64, 4096), (24, 17, 100, 100)]:
+        cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+        got = bench.synth_symbols_device(0xC0FFEE, begin, n_streams, n_per, -50, torch.from_numpy(cdf.astype(np.int64)).cuda(), P, chunk=128)
+        want = O.synth_symbols(0xC0FFEE, begin, n_streams, n_per, -50, cdf, P)
+        assert np.array_equal(got.cpu().numpy(), want)

@@ -1,0 +1,100 @@
+"""GPU parity tests of the BATCHED per-symbol-parameter API (constriction_amd.batched.*_gaussian): the reference's
+flagship call `encode_reverse(symbols, QuantizedGaussian(lo, hi), means, stds)` / `decode(family, means, stds)`
+(src/pybindings/stream/stack.rs:567-588, 733-751; queue.rs:343-410, 598-661) for many independent coders at once,
+against one CPU oracle coder per stream."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def workload(n_streams, n_per, lo, hi, seed):
+    rng = np.random.default_rng(seed)
+    mu = rng.uniform(lo * 0.6, hi * 0.6, (n_streams, n_per))
+    sd = np.exp(rng.uniform(np.log(0.3), np.log(40.0), (n_streams, n_per)))
+    sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), lo, hi).astype(np.int32)
+    sym[:, :2] = np.array([lo, hi])[: min(2, n_per)] if n_per >= 2 else sym[:, :2]     # the ends of the support too
+    return sym, mu, sd
+
+
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+@pytest.mark.parametrize("n_streams,n_per", [(1, 300), (65, 40), (1000, 21)])
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_gaussian_per_symbol_batch_parity(B, O, coder, cfg, n_streams, n_per, layout):
+    W, S, P = cfg
+    lo, hi = (-100, 100) if P == 24 else (-60, 60)
+    sym, mu, sd = workload(n_streams, n_per, lo, hi, n_streams * 13 + n_per + P)
+    # one oracle coder per stream
+    want = []
+    for s in range(n_streams):
+        if coder == "ans":
+            c = O.AnsCoder(W=W, S=S)
+            c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], P, 32 if W == 32 else 16)
+        else:
+            c = O.RangeEncoder(W=W, S=S)
+            c.encode(sym[s], [O.GaussianModel(lo, hi, m, d, P, 32 if W == 32 else 16) for m, d in zip(mu[s], sd[s])], P)
+        want.append(c.get_compressed())
+    t = (lambda a: a.T) if layout == "symbol_major" else (lambda a: a)
+    enc_fn = B.ans_encode_gaussian if coder == "ans" else B.range_encode_gaussian
+    dec_fn = B.ans_decode_gaussian if coder == "ans" else B.range_decode_gaussian
+    enc = enc_fn(dev(t(sym)), lo, hi, dev(t(mu)), dev(t(sd)), cfg, layout)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want[s].tolist(), f"stream {s}"
+    dec, dstatus = dec_fn(enc, lo, hi, dev(t(mu)), dev(t(sd)), layout)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all()
+    assert np.array_equal(t(dec.cpu().numpy()), sym)
+    if coder == "ans":
+        packed, offsets = B.compact(enc)
+        dec2, _ = B.ans_decode_gaussian((packed, enc.n_words), lo, hi, dev(t(mu)), dev(t(sd)), layout, offsets=offsets, config=cfg)
+        torch.cuda.synchronize()
+        assert np.array_equal(t(dec2.cpu().numpy()), sym)
+
+
+def test_gaussian_per_symbol_batch_errors(B, O):
+    lo, hi, cfg = -30, 30, (32, 64, 24)
+    sym, mu, sd = workload(70, 25, lo, hi, 5)
+    sym[9, 3] = hi + 1                                  # impossible symbol -> that stream only
+    sd[11, 7] = 0.0                                     # invalid model -> that stream only (the reference panics)
+    enc = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu), dev(sd), cfg)
+    torch.cuda.synchronize()
+    st = enc.status.cpu().numpy()
+    assert st[9] == 1 and st[11] == 1 and (np.delete(st, [9, 11]) == 0).all()
+    with pytest.raises(ValueError):
+        B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu[:, :5]), dev(sd), cfg)
+    # supports wider than 65536 symbols work in both directions (P = 24)
+    lo2, hi2 = -40000, 40000
+    sym2, mu2, sd2 = workload(3, 50, lo2, hi2, 11)
+    sd2 *= 300
+    sym2 = np.clip(np.rint(mu2 + sd2 * np.random.default_rng(1).standard_normal(sym2.shape)), lo2, hi2).astype(np.int32)
+    enc2 = B.ans_encode_gaussian(dev(sym2), lo2, hi2, dev(mu2), dev(sd2), cfg)
+    dec2, st2 = B.ans_decode_gaussian(enc2, lo2, hi2, dev(mu2), dev(sd2))
+    torch.cuda.synchronize()
+    assert (enc2.status.cpu().numpy() == 0).all() and (st2.cpu().numpy() == 0).all()
+    assert np.array_equal(dec2.cpu().numpy(), sym2)
+    c = O.AnsCoder()
+    c.encode_gaussian_reverse(sym2[1], lo2, hi2, mu2[1], sd2[1], 24, 32)
+    assert enc2.stream(1).tolist() == c.get_compressed().tolist()
