@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` block")
+    ap.add_argument("--graph", action="store_true", help="replay the timed step as a HIP graph instead of launching eagerly")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of the C5 shard's packed words")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     args = ap.parse_args()
@@ -298,9 +299,27 @@ def main():
     decoded = torch.empty_like(symbols)
     torch.cuda.synchronize()
 
-    def step():
+    def eager_step():
         B.ans_encode(symbols, model, (W, S, P), out=enc)
         B.ans_decode(enc, model, N_PER, out=decoded)
+
+    # One step = two kernel launches of ~0.3 ms.  Eager launches pipeline (the host is two launches ahead of the GPU);
+    # replaying the step as a HIP graph was measured SLOWER (0.65 vs 0.59 ms per step: ~60 us of fixed cost per replay
+    # with nothing to amortise it over), so it is opt-in.
+    step, launch_mode = eager_step, "eager"
+    if args.graph:
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager_step()
+            graph.replay()
+            torch.cuda.synchronize()
+            step, launch_mode = graph.replay, "hipGraph replay of (encode, decode)"
+        except Exception as exc:      # noqa: BLE001
+            launch_mode = f"eager (graph capture failed: {type(exc).__name__})"
+            torch.cuda.synchronize()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -378,7 +397,7 @@ def main():
                                    f"12-bit QuantizedGaussian({LO},{HI},{MEAN},{STD}), AnsCoder (W,S,P)=({W},{S},{P}), "
                                    "encode into slabs + decode; u64 coder state, u32 words, i32 symbols", "streams_per_gpu": n_streams, "symbols_per_stream": N_PER,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
-            "bit_exact": ok, "bit_exact_scope": scope,
+            "bit_exact": ok, "bit_exact_scope": scope, "launch": launch_mode,
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4),
             "words_per_stream": round(total_words / n_streams, 2),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,

@@ -114,12 +114,16 @@ static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hip
 // already running), scans its counts, publishes its aggregate in ONE 8-byte agent-scope store {flag, value} (no ordering
 // between flag and payload to get wrong: MI355X_MICROARCH.md, inter-workgroup visibility), looks back over its
 // predecessors 64 at a time, publishes its inclusive prefix, writes the offsets and copies its streams' words.
-constexpr int kCompactStreams = kBlock;
+constexpr int kCompactStreams = kBlock;          // streams per workgroup (scanned by its first kBlock threads)
+constexpr int kCompactThreads = 1024;            // 16 waves copy: the gather is latency bound, it needs loads in flight
 constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagInclusive = 2ull << 62, kFlagMask = 3ull << 62;
 
-__global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restrict__ words, size_t stride, const uint32_t* __restrict__ n_words,
-                                                          size_t n_streams, uint64_t* __restrict__ offsets, uint32_t* __restrict__ packed,
-                                                          size_t capacity, uint32_t* __restrict__ ticket, uint64_t* __restrict__ status) {
+typedef uint32_t cv4u __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) cv4u_unaligned { cv4u v; };
+
+__global__ __launch_bounds__(kCompactThreads) void compact_kernel(const uint32_t* __restrict__ words, size_t stride, const uint32_t* __restrict__ n_words,
+                                                                  size_t n_streams, uint64_t* __restrict__ offsets, uint32_t* __restrict__ packed,
+                                                                  size_t capacity, uint32_t* __restrict__ ticket, uint64_t* __restrict__ status) {
     __shared__ uint64_t wave_sums[kBlock / kWave];
     __shared__ uint64_t s_off[kCompactStreams];
     __shared__ uint32_t s_len[kCompactStreams];
@@ -129,15 +133,16 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restr
     __syncthreads();
     const uint32_t bid = s_bid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool scanner = threadIdx.x < kCompactStreams;
     const size_t s = (size_t)bid * kCompactStreams + threadIdx.x;
-    const uint32_t len = s < n_streams ? n_words[s] : 0u;
+    const uint32_t len = scanner && s < n_streams ? n_words[s] : 0u;
     uint64_t incl = len;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
     }
-    if (lane == 63) wave_sums[wave] = incl;
+    if (scanner && lane == 63) wave_sums[wave] = incl;
     __syncthreads();
     uint64_t wave_off = 0, total = 0;
 #pragma unroll
@@ -169,14 +174,18 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restr
         }
     }
     __syncthreads();
-    const uint64_t off = s_prefix + wave_off + incl - len;
-    if (s < n_streams) offsets[s] = off;
-    if (s + 1 == n_streams) offsets[n_streams] = off + len;
-    s_off[threadIdx.x] = off; s_len[threadIdx.x] = len;
+    if (scanner) {
+        const uint64_t off = s_prefix + wave_off + incl - len;
+        if (s < n_streams) offsets[s] = off;
+        if (s + 1 == n_streams) offsets[n_streams] = off + len;
+        s_off[threadIdx.x] = off; s_len[threadIdx.x] = len;
+    }
     __syncthreads();
     if (!packed) return;
-    // gather: one wave per stream, 256-byte coalesced pieces
-    for (int k = wave; k < kCompactStreams; k += kBlock / kWave) {
+    // Gather: one wave per stream at a time.  The head of a stream goes word by word up to the first 16-byte boundary
+    // of the packed buffer, the body in aligned 16-byte stores fed by (in general misaligned) 16-byte loads, four
+    // independent ones per lane before the first store, the tail word by word.
+    for (int k = wave; k < kCompactStreams; k += kCompactThreads / kWave) {
         const size_t sk = (size_t)bid * kCompactStreams + k;
         if (sk >= n_streams) break;
         const uint32_t n = s_len[k];
@@ -184,7 +193,20 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const uint32_t* __restr
         if (o + n > capacity) continue;
         const uint32_t* src = words + sk * stride;
         uint32_t* dst = packed + o;
-        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+        const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3u)) & 3u));
+        if ((uint32_t)lane < head) dst[lane] = src[lane];
+        const uint32_t n4 = (n - head) >> 2;                       // whole 16-byte pieces
+        const cv4u_unaligned* s4 = reinterpret_cast<const cv4u_unaligned*>(src + head);
+        cv4u* d4 = reinterpret_cast<cv4u*>(dst + head);
+        for (uint32_t i = lane; i < n4; i += 4 * 64) {
+            cv4u v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + 64 * u < n4) v[u] = s4[i + 64 * u].v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + 64 * u < n4) __builtin_nontemporal_store(v[u], d4 + i + 64 * u);
+        }
+        const uint32_t done = head + 4 * n4;
+        if (done + (uint32_t)lane < n) dst[done + lane] = src[done + lane];
     }
 }
 
@@ -290,7 +312,7 @@ cst_status cst_compact_words(const uint32_t* d_words, size_t stride_words, const
     CST_HIP_TRY(hipMemsetAsync(d_scratch, 0, cst_compact_scratch_bytes(n_streams), hs));
     uint32_t* ticket = reinterpret_cast<uint32_t*>(d_scratch);
     uint64_t* status = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(d_scratch) + 16);
-    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, hs, d_words, stride_words, d_n_words, n_streams,
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_blocks), dim3(kCompactThreads), 0, hs, d_words, stride_words, d_n_words, n_streams,
                        d_offsets, d_packed, packed_capacity, ticket, status);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
