@@ -248,6 +248,42 @@ def other_configs(B, rank, world, dist, args, reps=5):
     return out
 
 
+def plumbing(args, rank, world, dist):
+    """The multi-rank skeleton of this script on host tensors (see --plumbing): every rank owns streams
+    [rank * n, (rank + 1) * n) whose "compressed words" are a function of the global stream id, packs them, gathers them
+    to rank 0 with the product's gather and reports like the real run."""
+    from constriction_amd import dist as D
+    n = args.streams
+    sid = np.arange(rank * n, (rank + 1) * n, dtype=np.int64)
+    lens = (7 * sid + 3) % 11                                          # some streams are empty
+    words = np.concatenate([np.arange(l, dtype=np.int64) + 1000 * s for s, l in zip(sid, lens)] + [np.zeros(0, np.int64)])
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
+    packed = torch.from_numpy(words.astype(np.int32))
+    t0 = time.perf_counter()
+    res = D.gather_packed(packed, offsets, dst=0) if dist is not None else (packed, offsets)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = True
+    if rank == 0:
+        all_sid = np.arange(0, world * n, dtype=np.int64)
+        all_len = (7 * all_sid + 3) % 11
+        want = np.concatenate([np.arange(l, dtype=np.int64) + 1000 * s for s, l in zip(all_sid, all_len)] + [np.zeros(0, np.int64)])
+        ok = np.array_equal(res[0].numpy().astype(np.int64), want.astype(np.int32).astype(np.int64)) and \
+            res[1].numpy().tolist() == np.concatenate([[0], np.cumsum(all_len)]).tolist()
+        print(json.dumps({"plumbing": "ok" if ok else "FAILED", "n_gpus": world, "streams_per_rank": n, "gathered_words": int(res[0].numel()),
+                          "gather_ms": round(elapsed * 1e3, 3), "backend": args.backend if dist is not None else None}), flush=True)
+    else:
+        ok = res is None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("plumbing check FAILED")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -267,6 +303,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the timed step as a HIP graph instead of launching eagerly")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of the C5 shard's packed words")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="no GPU work: run only the multi-rank plumbing of this script (self-launch, rendezvous, stream sharding, "
+                         "variable-length gather of per-stream words to rank 0, max-over-ranks timing) on host tensors -- "
+                         "what tests/test_dist_cpu.py drives with --backend gloo in the CPU-only build container")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -280,13 +320,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    if not args.plumbing:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
         dist.init_process_group(args.backend, **kw)
+    if args.plumbing:
+        return plumbing(args, rank, world, dist)
 
     from constriction_amd import batched as B
 

@@ -72,3 +72,24 @@ def test_gather_scatter_world2(n_total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` re-executes itself under torch.distributed.run (127.0.0.1) and runs its own sharding /
+    gather / reporting path; here on host tensors over gloo (--plumbing), on the GPU box over RCCL."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--plumbing", "--backend", "gloo", "--streams", "777"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["plumbing"] == "ok" and out["n_gpus"] == world and out["streams_per_rank"] == 777
+    want = sum((7 * s + 3) % 11 for s in range(world * 777))
+    assert out["gathered_words"] == want
