@@ -1006,4 +1006,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     }
 }
 
+// small-footprint kernels for batches of more than one wave per SIMD (cst_ans_small.hip)
+bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
+bool small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
+cst_status ans_encode_small(const AnsEncodeArgs& a, hipStream_t hs);
+cst_status ans_decode_small(const AnsDecodeArgs& a, hipStream_t hs);
+
 } // namespace cst

@@ -262,6 +262,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.status = d_status;
     a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
+    if (small_encode_usable(a, cfg, layout, model->cu_count)) return ans_encode_small(a, hs);   // more than one wave per SIMD
     if (cfg.word_bits == 32) return encode_dispatch<32, 64>(a, layout, hs);
     return encode_dispatch<16, 32>(a, layout, hs);
 }
@@ -289,6 +290,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
+    if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
     if (cfg.word_bits == 32) return decode_dispatch<32, 64>(a, layout, hs);
     return decode_dispatch<16, 32>(a, layout, hs);
 }

@@ -78,6 +78,7 @@ struct cst_model {
     size_t n_tables = 1;     // number of tables
     bool per_stream = false; // true: table s belongs to stream s (config C3); false: one table shared by all streams
     int device = 0;
+    int cu_count = 256;      // compute units of that device (a batch of more than cu_count * 256 streams has more than one wave per SIMD)
     uint32_t* d_cdf = nullptr;        // [n_tables][n_symbols + 1]
     // shared-table artefacts (n_tables == 1)
     cst::EncEntry* d_enc = nullptr;   // [n_symbols]

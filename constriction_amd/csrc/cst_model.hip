@@ -255,7 +255,7 @@ cst_status cst_model_create_table(int32_t precision, int32_t min_symbol, int32_t
     cst_model* m = new (std::nothrow) cst_model();
     if (!m) return CST_ERR_OUT_OF_MEMORY;
     m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n_symbols; m->n_tables = 1;
-    hipGetDevice(&m->device);
+    hipGetDevice(&m->device); (void)hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, m->device);
     const size_t bytes = 4 * ((size_t)n_symbols + 1);
     hipError_t e = hipMalloc(&m->d_cdf, bytes);
     if (e == hipSuccess) e = hipMemcpy(m->d_cdf, h_cdf, bytes, hipMemcpyHostToDevice);
@@ -283,7 +283,7 @@ cst_status cst_model_create_gaussian(int32_t precision, int32_t min_symbol, int3
     cst_model* m = new (std::nothrow) cst_model();
     if (!m) return CST_ERR_OUT_OF_MEMORY;
     m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = 1;
-    hipGetDevice(&m->device);
+    hipGetDevice(&m->device); (void)hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, m->device);
     std::vector<uint32_t> h((size_t)n + 1);
     hipError_t e = hipMalloc(&m->d_cdf, 4 * ((size_t)n + 1));
     if (e == hipSuccess) {
@@ -318,7 +318,7 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
     cst_model* m = new (std::nothrow) cst_model();
     if (!m) return CST_ERR_OUT_OF_MEMORY;
     m->precision = precision; m->min_symbol = min_symbol; m->n_symbols = n; m->n_tables = n_streams; m->per_stream = true;
-    hipGetDevice(&m->device);
+    hipGetDevice(&m->device); (void)hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, m->device);
     m->cdf16_stride = 8;
     while (m->cdf16_stride < n + 1) m->cdf16_stride <<= 1;   // power of two (rows are rotated per lane in LDS)
     const size_t total = n_streams * ((size_t)n + 1);

@@ -24,7 +24,14 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_encode_loop.inc"
+CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
+OUT = CSRC / "cst_encode_loop.inc"
+OUT_SINGLE = CSRC / "cst_encode_loop_1buf.inc"
+# SINGLE: ONE tile buffer per wave and a 32-slot word ring (cst_encode_loop_1buf.inc): 17 KiB of LDS per wave instead of
+# 34, so that two workgroups share a CU when a batch has more than one wave per SIMD.  The next tile is staged between
+# the last read of the current tile (quad 0's symbols, requested in quad 2) and the first read of the next one (its
+# quad 7, requested in quad 1) -- one wave's LDS operations execute in order.
+SINGLE = False
 
 
 def regs(base, n=4):
@@ -80,7 +87,7 @@ def step(a, c, p, m0, m1):
 
 
 def read_syms(a, g, buf, quad):
-    a.ds(f"ds_read_b128 {S_T[g % 4]}, {ROW[buf]} offset:{16 * quad}", f"S{g}")
+    a.ds(f"ds_read_b128 {S_T[g % 4]}, {ROW[0 if SINGLE else buf]} offset:{16 * quad}", f"S{g}")
 
 
 def fetch_entries(a, g):
@@ -122,7 +129,7 @@ def stage_set(a, name, buf):
     if os.environ.get("GEN_NO_VMWAIT") and len(a.lines) > 100:      # timing experiment only: results are wrong
         a.lines.pop()
     for k in range(8):
-        a.ds(f"ds_write_b128 {TR[buf]}, {R[name][k]} offset:{1152 * k}", "tl")
+        a.ds(f"ds_write_b128 {TR[0 if SINGLE else buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
 
 def half(a, h, g0):
@@ -133,12 +140,15 @@ def half(a, h, g0):
         g, quad = g0 + j, 7 - j
         # the pipeline runs on into the next tile: quads "-1" and "-2" are quads 7 and 6 of the other buffer
         if f"S{g + 1}" in a.lds:        # (quad 4: already retired by the wait in front of the tile staging)
-            a.wait_lds(f"S{g + 1}", f"quad {quad}: symbols of the next quad are back")
+            a.wait_lds(f"S{g + 1}", f"quad {quad}: symbols of the next quad are back", cap=True)
         far = quad - 2
         read_syms(a, g + 2, h if far >= 0 else 1 - h, far if far >= 0 else far + 8)
+        if SINGLE and quad == 2:
+            stage_set(a, other, 1 - h)
+            load_set(a, other)
         fetch_entries(a, g + 1)
         if f"E{g}" in a.lds:
-            a.wait_lds(f"E{g}", f"entries of quad {quad} are back")
+            a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
         if quad in (7, 6):
             # ring reads of the 64-byte group (4 chunks, two per quad: lgkmcnt counts only to 15) that may be complete.
             # Words leave for HBM 64 bytes at a time: 16-byte stores reach DRAM as partial bursts (measured 1.6x write
@@ -163,15 +173,16 @@ def half(a, h, g0):
             a.i(f"v_cmp_le_u32 vcc, {LIM}, %[cap]", "group inside the slab (cap % 16 == 0 on this path)")
             a.i(f"v_cmp_ne_u32 {SAVE}, 0, {NCH}")
             a.i(f"s_and_b64 vcc, vcc, {SAVE}")
-            a.wait_lds("fl")
+            a.wait_lds("fl", cap=True)
             a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
             for k in range(4):
                 a.vmem(f"global_store_dwordx4 {FOFF}, {FD[k][2]}, %[wbase] offset:{16 * k}", "st")
             a.i(f"s_mov_b64 exec, {SAVE}")
             a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 4, %[flushed]")
-            a.wait_lds(f"E{g + 1}", "(early: keeps the eight tile writes below within lgkmcnt's range of 15)")
-            stage_set(a, other, 1 - h)
-            load_set(a, other)
+            if not SINGLE:
+                a.wait_lds(f"E{g + 1}", "(early: keeps the eight tile writes below within lgkmcnt's range of 15)")
+                stage_set(a, other, 1 - h)
+                load_set(a, other)
 
 
 def gen():
@@ -211,21 +222,33 @@ def gen():
     return a, notes
 
 
-def main():
+def emit(out, single):
+    global SINGLE
+    SINGLE = single
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (32,64) ANS encoder: see ans_encode_tiles_loop in cst_ans_kernels.hpp."]
-    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
-           '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),',
-           '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
-           '      [tbl] "s"(table_addr_biased), [shP] "s"(32u - P), [twoP] "s"(1u << P), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
-           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
-           "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-    OUT.write_text(a.render(header, ops))
-    print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
+    if single:
+        header[1] = "// Main loop of the hand-scheduled (32,64) ANS encoder, ONE tile buffer and a 32-slot ring per wave: see cst_ans_small.hip."
+        ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
+               '    : [row0] "v"(tile_row_addr), [tr0] "v"(tile_tr_addr),']
+    else:
+        ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
+               '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),']
+    ops += ['      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
+            '      [tbl] "s"(table_addr_biased), [shP] "s"(32u - P), [twoP] "s"(1u << P), [c3f00] "s"(' + ("ring_mask" if single else "0x3f00u") + '), [wbase] "s"(words_base),',
+            '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
+
+
+def main():
+    emit(OUT, False)
+    emit(OUT_SINGLE, True)
 
 
 if __name__ == "__main__":

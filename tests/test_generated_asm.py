@@ -35,6 +35,18 @@ def test_decode_loop_is_in_sync(tmp_path, monkeypatch):
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop.inc").read_text()
 
 
+def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
+    """the loops of cst_ans_small.hip (batches of more than one wave per SIMD)"""
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):
+        monkeypatch.delenv(var, raising=False)
+    mod = _load("gen_encode_loop")
+    mod.OUT, mod.OUT_SINGLE = tmp_path / "a.inc", tmp_path / "b.inc"
+    mod.main()
+    assert (tmp_path / "b.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_1buf.inc").read_text()
+    text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small.inc").read_text()
+
+
 def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
     """the per-stream-table (C3) main loops"""
     for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):

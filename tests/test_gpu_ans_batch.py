@@ -508,3 +508,37 @@ def test_bench_symbols_match_the_oracle(B, O):
         got = bench.synth_symbols_device(0xC0FFEE, begin, n_streams, n_per, -50, torch.from_numpy(cdf.astype(np.int64)).cuda(), P, chunk=128)
         want = O.synth_symbols(0xC0FFEE, begin, n_streams, n_per, -50, cdf, P)
         assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------ more than one wave per SIMD: small-footprint kernels
+
+@pytest.mark.parametrize("P,n_sym", [(12, 101), (8, 40), (12, 256)])
+@pytest.mark.parametrize("n_per,stride_extra", [(96, 0), (100, 0), (64, 5)])
+def test_more_than_one_wave_per_simd(B, O, P, n_sym, n_per, stride_extra):
+    """Batches of more than 256 streams per CU take cst_ans_small.hip (two waves per SIMD): full waves through the
+    generated main loops, the partial last wave, the ragged top symbols and unaligned slabs through the compiler-scheduled
+    paths; words of every stream against the oracle, decode from slabs and from the packed layout."""
+    n_streams = 65536 + 64 * 3 + 17
+    lo = -n_sym // 2
+    rng = np.random.default_rng(P * 1000 + n_sym + n_per)
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(n_sym) * 0.7), P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(11, 0, n_streams, n_per, lo, cdf, P)
+    sym[65600, 5] = lo + n_sym                                   # one impossible symbol in a full wave of the last workgroups
+    sym[n_streams - 3, 0] = lo - 1                               # and one in the partial wave
+    stride = B.max_words(n_per, (32, 64, P)) + stride_extra
+    want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdf, P, stride=stride)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P), stride=stride)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and status[65600] == 1 and status[n_streams - 3] == 1
+    assert n_words.tolist() == want_n.tolist()
+    mask = np.arange(stride, dtype=np.uint32)[None, :] < n_words[:, None]
+    assert np.array_equal(np.where(mask, words, 0), np.where(mask, want_words, 0))
+    dec, dstatus = B.ans_decode(enc, model, n_per)
+    packed, offsets = B.compact(enc)
+    dec2, _ = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P))
+    torch.cuda.synchronize()
+    good = status == 0
+    assert (dstatus.cpu().numpy()[good] == 0).all()
+    assert np.array_equal(dec.cpu().numpy()[good], sym[good]) and np.array_equal(dec2.cpu().numpy()[good], sym[good])
