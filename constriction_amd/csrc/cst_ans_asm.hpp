@@ -54,8 +54,8 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
 // Hand-scheduled encode of one 32-symbol tile for (W,S) = (32,64), 8 <= P <= 12  
 //
 // The encoder's table entries do not depend on the coder state, so the only serial chain is arithmetic and the
-// tile is bound by instruction issue (one instruction of any kind per 4 cycles for a lone wave).  One asm
-// statement per tile: 25 instructions per symbol for the step itself (same arithmetic as ans_encode_step_asm, the
+// tile is bound by instruction issue (one instruction of any kind per ~4.7 cycles for a lone wave).  One asm
+// statement per tile: 23 instructions per symbol for the step itself (PACKED table entries, see CST_ENC_STEP; the
 // zero halves of its register pairs set once per tile) plus 3.75 for the software pipeline around it:
 //   quad j (4 symbols, walked backwards):  request the symbols of quad j-2 (one 16-B LDS read of the lane's tile
 //   row), fetch the four 16-B table entries of quad j-1, then run the four steps of quad j.
@@ -63,17 +63,18 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
 // reads and 4 ring writes are younger), lgkmcnt(9) = "entries of quad j are back".
 // A symbol outside the model's support reads a garbage entry (LDS never faults) and only corrupts its own stream,
 // which is reported through smin/smax (the caller turns them into CST_STREAM_IMPOSSIBLE_SYMBOL).
-//   v100..v111  three symbol quads     v112..v143  two sets of four entries {c, p, m_lo, m_hi}
-//   v[144:145] A   v[146:147] [w,0]   v[148:149] U/T   v[150:151] [U_lo,0]   v[152:153] V   v[154:155] sum
-//   v[156:157] Q   v158 r/d   v159 p << (32-P)   v160 k   v161 c+k   v162 ring address   v163 entry address
+//   v100..v111  three symbol quads     v112..v143  two sets of four packed entries
+//   v[144:145] A   v[146:147] [w,0]   v[148:149] U / q_est << P   v[150:151] [U_lo,0]   v[152:153] V   v[154:155] sum
+//   v[156:157] Q   v158 r   v160 k = 2^P - p   v161 c (+ k)   v162 ring address   v163 entry address
 // ------------------------------------------------------------------------------------------------
-#define CST_ENC_STEP(C, PP, M0, M1)                                                                                 \
-    "v_lshlrev_b32 v159, %[shP], " PP "\n\t"                                                                        \
-    "v_sub_u32 v160, %[twoP], " PP "\n\t"                                                                           \
+#define CST_ENC_SDWA " dst_sel:DWORD dst_unused:UNUSED_PAD "
+// (E0, E1, M0, M1) = packed table entry { c | (c + 2^P - p) << 16,  p | p << (32 - P),  floor(2^64 / p) }: see
+// scripts/gen_encode_loop.py step() for the arithmetic -- 22 VALU instructions + the ring write
+#define CST_ENC_STEP(E0, E1, M0, M1)                                                                                \
+    "v_cmp_ge_u32_sdwa vcc, %[hi], " E1 " src0_sel:WORD_1 src1_sel:WORD_1\n\t"                                      \
+    "v_sub_u32_sdwa v160, %[twoP], " E1 CST_ENC_SDWA "src0_sel:DWORD src1_sel:WORD_0\n\t"                            \
     "v_add_lshl_u32 v162, %[wr], %[shift], 8\n\t"                                                                   \
-    "v_cmp_ge_u32 vcc, %[hi], v159\n\t"                                                                             \
     "v_and_or_b32 v162, v162, %[c3f00], %[lanebase]\n\t"                                                            \
-    "v_add_u32 v161, " C ", v160\n\t"                                                                               \
     "v_cndmask_b32_e64 v144, %[lo], %[hi], vcc\n\t"                                                                 \
     "v_cndmask_b32_e64 v145, %[hi], 0, vcc\n\t"                                                                     \
     "ds_write_b32 v162, %[lo]\n\t"                                                                                  \
@@ -85,13 +86,13 @@ __device__ __forceinline__ void ans_encode_step_asm(uint32_t& lo, uint32_t& hi, 
     "v_add_co_u32 v154, vcc, v149, v153\n\t"                                                                        \
     "v_addc_co_u32 v155, vcc, 0, v147, vcc\n\t"                                                                     \
     "v_mad_u64_u32 v[156:157], vcc, v145, " M1 ", v[154:155]\n\t"                                                   \
-    "v_mul_lo_u32 v158, v156, " PP "\n\t"                                                                           \
+    "v_mul_u32_u24_sdwa v158, v156, " E1 CST_ENC_SDWA "src0_sel:DWORD src1_sel:WORD_0\n\t"                           \
     "v_sub_u32 v158, v144, v158\n\t"                                                                                \
-    "v_cmp_ge_u32 vcc, v158, " PP "\n\t"                                                                            \
+    "v_cmp_ge_u32_sdwa vcc, v158, " E1 " src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                        \
     "v_mad_u64_u32 v[148:149], %[sd], v156, v160, v[144:145]\n\t"                                                   \
     "v_mad_u32_u24 v149, v157, v160, v149\n\t"                                                                      \
-    "v_cndmask_b32 v158, " C ", v161, vcc\n\t"                                                                      \
-    "v_add_co_u32 %[lo], vcc, v148, v158\n\t"                                                                       \
+    "v_cndmask_b32_sdwa v161, " E0 ", " E0 ", vcc" CST_ENC_SDWA "src0_sel:WORD_0 src1_sel:WORD_1\n\t"                  \
+    "v_add_co_u32 %[lo], vcc, v148, v161\n\t"                                                                       \
     "v_addc_co_u32 %[hi], vcc, 0, v149, vcc\n\t"
 
 // entry sets (consumption order: symbol .w first)
@@ -175,7 +176,7 @@ __device__ __forceinline__ void ans_encode_tile32(uint32_t& lo, uint32_t& hi, ui
         CST_ENC_STEPS_E1
         "s_waitcnt lgkmcnt(0)"
         : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [smin] "+v"(smin), [smax] "+v"(smax), [sd] "=&s"(sd)
-        : [tile] "v"(tile_row_addr), [tbl] "s"(table_addr_biased), [shP] "s"(32u - P), [twoP] "s"(1u << P),
+        : [tile] "v"(tile_row_addr), [tbl] "s"(table_addr_biased), [twoP] "v"(1u << P),
           [c3f00] "s"(0x3f00u), [shift] "v"(shift), [lanebase] "v"(ring_lane_addr)
         : "vcc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
           "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",

@@ -517,11 +517,22 @@ __device__ __forceinline__ uint32_t enc_index(int32_t sym, int32_t min_symbol, u
     return min(idx, n_symbols - 1u);
 }
 
+// The hand-scheduled tile / loop statements of the (32,64), P <= 12 encoder read PACKED table entries
+//     { c | (c + 2^P - p) << 16,  p | p << (32 - P),  m_lo,  m_hi }          (8 <= P <= 12: the high half of the second
+// word is p << (16 - P), what (state >> 48) is compared with; every operand the step derives from c and p is then a
+// half-word select: scripts/gen_encode_loop.py step()).
+__device__ __forceinline__ EncEntry pack_entry(const EncEntry e, int P) {
+    return EncEntry{e.c | ((e.c + (1u << P) - e.p) << 16), e.p | (e.p << (32 - P)), e.m_lo, e.m_hi};
+}
+__device__ __forceinline__ EncEntry unpack_entry(const EncEntry e) { return EncEntry{e.c & 0xffffu, e.p & 0xffffu, e.m_lo, e.m_hi}; }
+
 // LAYOUT 0: symbols[stream][t] staged through LDS tiles; LAYOUT 1: symbols[t][stream] read directly.
 // GLOBAL_TABLE: the encoder entries stay in HBM / L2 (alphabets too large for LDS: more than ~3800 symbols)
 template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST, bool GLOBAL_TABLE = false>
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // packed LDS entries <=> this instantiation has the hand-scheduled tile statements
+    constexpr bool PACKED = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE && LAYOUT == CST_LAYOUT_STREAM_MAJOR;
     // LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][encoder table][symbol tiles]
     constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
     const EncEntry* table;
@@ -537,10 +548,11 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
     } else {
         // stage the encoder table once per workgroup (16 B per lane per pass, coalesced)
         EncEntry* t = reinterpret_cast<EncEntry*>(smem + kRingBytes);
-        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = a.enc[i];
+        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = PACKED ? pack_entry(a.enc[i], a.precision) : a.enc[i];
         table = t;
     }
     __syncthreads();
+    auto entry = [&](uint32_t idx) { const EncEntry e = table[idx]; return PACKED ? unpack_entry(e) : e; };   // for the C++ paths
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t s0 = wave * kWave;
@@ -569,15 +581,15 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                 v3 = col[(t + 3) * a.n_streams]; v2 = col[(t + 2) * a.n_streams];
                 v1 = col[(t + 1) * a.n_streams]; v0 = col[(t + 0) * a.n_streams];
             }
-            const EncEntry e3 = table[enc_index(v3, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v2, a.min_symbol, nsym, L.bad)],
-                           e1 = table[enc_index(v1, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v0, a.min_symbol, nsym, L.bad)];
+            const EncEntry e3 = entry(enc_index(v3, a.min_symbol, nsym, L.bad)), e2 = entry(enc_index(v2, a.min_symbol, nsym, L.bad)),
+                           e1 = entry(enc_index(v1, a.min_symbol, nsym, L.bad)), e0 = entry(enc_index(v0, a.min_symbol, nsym, L.bad));
             L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
             if (--countdown == 0) { countdown = G; L.flush_chunks(); }
         }
         while (t > 0) {
             --t;
             const int32_t v = active ? col[t * a.n_streams] : 0;
-            L.template step<FAST>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.template step<FAST>(entry(enc_index(v, a.min_symbol, nsym, L.bad)), P);
             L.flush_chunks();
         }
     } else {
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
         for (size_t t = N; t > n_full * kTileSyms;) {
             --t;
             const int32_t v = active ? row[t] : 0;
-            L.template step<FAST>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+            L.template step<FAST>(entry(enc_index(v, a.min_symbol, nsym, L.bad)), P);
             L.flush_chunks();
         }
         if (n_full > 0) {
@@ -655,16 +667,16 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
                     constexpr int NG = kTileSyms / 4;
                     int4 v = *reinterpret_cast<const int4*>(my + 4 * (NG - 1));
                     int4 vn = *reinterpret_cast<const int4*>(my + 4 * (NG - 2));
-                    EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
-                             e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
+                    EncEntry e3 = entry(enc_index(v.w, a.min_symbol, nsym, L.bad)), e2 = entry(enc_index(v.z, a.min_symbol, nsym, L.bad)),
+                             e1 = entry(enc_index(v.y, a.min_symbol, nsym, L.bad)), e0 = entry(enc_index(v.x, a.min_symbol, nsym, L.bad));
 #pragma unroll
                     for (int j = NG - 1; j >= 0; --j) {
                         EncEntry n3 = e3, n2 = e2, n1 = e1, n0 = e0;
                         int4 vnn = vn;
                         if (j > 1) vnn = *reinterpret_cast<const int4*>(my + 4 * (j - 2));
                         if (j > 0) {
-                            n3 = table[enc_index(vn.w, a.min_symbol, nsym, L.bad)]; n2 = table[enc_index(vn.z, a.min_symbol, nsym, L.bad)];
-                            n1 = table[enc_index(vn.y, a.min_symbol, nsym, L.bad)]; n0 = table[enc_index(vn.x, a.min_symbol, nsym, L.bad)];
+                            n3 = entry(enc_index(vn.w, a.min_symbol, nsym, L.bad)); n2 = entry(enc_index(vn.z, a.min_symbol, nsym, L.bad));
+                            n1 = entry(enc_index(vn.y, a.min_symbol, nsym, L.bad)); n0 = entry(enc_index(vn.x, a.min_symbol, nsym, L.bad));
                         }
                         L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
                         e3 = n3; e2 = n2; e1 = n1; e0 = n0; vn = vnn;

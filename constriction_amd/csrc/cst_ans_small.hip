@@ -55,8 +55,9 @@ __global__ __launch_bounds__(kBlock, 2) void ans_encode_small_kernel(const AnsEn
     EncEntry* table = reinterpret_cast<EncEntry*>(smem + kWaves * kSmWaveRingBytes);
     int32_t* tile = reinterpret_cast<int32_t*>(smem + kWaves * kSmWaveRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
     if ((lds_addr(ring) & (uint32_t)(kSmWaveRingBytes - 1)) != 0) __builtin_trap();
-    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
+    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = pack_entry(a.enc[i], P);   // (see cst_ans_kernels.hpp)
     __syncthreads();
+    auto entry = [&](uint32_t idx) { return unpack_entry(table[idx]); };                                  // for the C++ paths
 
     const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)wave_in_block * kWave;
     if (s0 >= a.n_streams) return;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kBlock, 2) void ans_encode_small_kernel(const AnsEn
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
         const int32_t v = active ? my[t] : a.min_symbol;
-        L.template step<true>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+        L.template step<true>(entry(enc_index(v, a.min_symbol, nsym, L.bad)), P);
         L.flush_chunks();
     }
     bool done = false;
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(kBlock, 2) void ans_encode_small_kernel(const AnsEn
             for (int j = kTileSyms / 4 - 1; j >= 0; --j) {
                 int4 v = *reinterpret_cast<const int4*>(row + 4 * j);
                 if (!active) v = make_int4(a.min_symbol, a.min_symbol, a.min_symbol, a.min_symbol);
-                const EncEntry e3 = table[enc_index(v.w, a.min_symbol, nsym, L.bad)], e2 = table[enc_index(v.z, a.min_symbol, nsym, L.bad)],
-                               e1 = table[enc_index(v.y, a.min_symbol, nsym, L.bad)], e0 = table[enc_index(v.x, a.min_symbol, nsym, L.bad)];
+                const EncEntry e3 = entry(enc_index(v.w, a.min_symbol, nsym, L.bad)), e2 = entry(enc_index(v.z, a.min_symbol, nsym, L.bad)),
+                               e1 = entry(enc_index(v.y, a.min_symbol, nsym, L.bad)), e0 = entry(enc_index(v.x, a.min_symbol, nsym, L.bad));
                 L.template step<true>(e3, P); L.template step<true>(e2, P); L.template step<true>(e1, P); L.template step<true>(e0, P);
             }
         }

@@ -5,7 +5,8 @@ encoder -- ONE asm statement that encodes all full 32-symbol tiles of a wave's 6
 The steps run as one continuous software pipeline of quads (4 symbols) that does not drain at tile boundaries:
     quad g:  request the symbols of quad g-2 (one 16-B LDS read of the lane's tile row),
              fetch the four 16-B table entries of quad g-1,
-             fold quad g's symbols into smin/smax, run its four 24-instruction coder steps.
+             fold quad g's symbols into smin/smax, run its four 23-instruction coder steps (packed table entries:
+             see step()).
 Two LDS tile buffers alternate, so quads 1 and 0 of a tile already read the NEXT tile's row.  Everything else is
 hung into fixed places of a tile ("half": the loop body holds two, one per register set of prefetched symbols):
     before quad 6 : read the 64-byte group of compressed words that may be complete in the lane's LDS ring;
@@ -58,13 +59,23 @@ ROW = ["%[row0]", "%[row1]"]          # the lane's own row in tile buffer 0 / 1
 TR = ["%[tr0]", "%[tr1]"]             # transposed write address in tile buffer 0 / 1
 
 
-def step(a, c, p, m0, m1):
-    a.i(f"v_lshlrev_b32 {PSHL}, %[shP], {p}", "p << (32 - P)")
-    a.i(f"v_sub_u32 {KK}, %[twoP], {p}", "k = 2^P - p")
+SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD"
+
+
+def step(a, e0, e1, m0, m1):
+    """One coder step (stack.rs:1035-1045) on a PACKED table entry  e0 = c | (c + 2^P - p) << 16,  e1 = p | p << (32 - P),
+    (m0, m1) = floor(2^64 / p): the operands derived from c and p are SDWA half-word selects.
+        emit  <=>  (state >> (64 - P)) >= p  <=>  (hi >> 16) >= p << (16 - P)    (P <= 12)
+        A = emit ? state >> 32 : state;  q_est = mulhi64(A, m) in {q - 1, q};  r_est = A - q_est * p  (< 2p < 2^13: its low 16 bits
+        follow from the low 24 bits of q_est alone, one v_mul_u32_u24);  fix <=> r_est >= p
+        state' = (q << P) + c + r = A + q_est * (2^P - p) + (fix ? c + 2^P - p : c)
+    22 VALU instructions + the ring write.  What bounds a lone wave is the DEPENDENT chain (a dependent VALU instruction
+    issues every ~8 cycles, an independent one every ~4.7: scripts/microbench/occupancy.hip): emit -> A -> mul_hi -> U -> T ->
+    carry -> Q -> r -> fix -> select -> add -> carry, 13 levels; A + q_est * k runs beside the remainder test."""
+    a.i(f"v_cmp_ge_u32_sdwa vcc, %[hi], {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
+    a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
     a.i(f"v_lshlrev_b32 {RA}, 8, %[wr]")
-    a.i(f"v_cmp_ge_u32 vcc, %[hi], {PSHL}", "emit <=> (state >> (64 - P)) >= p")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
-    a.i(f"v_add_u32 {CK}, {c}, {KK}")
     a.i(f"v_cndmask_b32_e64 {A0}, %[lo], %[hi], vcc")
     a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
     a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
@@ -76,13 +87,13 @@ def step(a, c, p, m0, m1):
     a.i(f"v_mov_b32 {SM0}, {T1}")
     a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc", "[T_hi, carry]")
     a.i(f"v_mad_u64_u32 {Q_T}, vcc, {A1}, {m1}, {SM_T}", "q_est in {q - 1, q}")
-    a.i(f"v_mul_lo_u32 {RR}, {Q0}, {p}")
-    a.i(f"v_sub_u32 {RR}, {A0}, {RR}")
-    a.i(f"v_cmp_ge_u32 vcc, {RR}, {p}", "fix <=> q = q_est + 1")
-    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}")
-    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}")
-    a.i(f"v_cndmask_b32 {RR}, {c}, {CK}, vcc")
-    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {RR}")
+    a.i(f"v_mul_u32_u24_sdwa {RR}, {Q0}, {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "low 24 bits of q_est times p")
+    a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est modulo 2^24")
+    a.i(f"v_cmp_ge_u32_sdwa vcc, {RR}, {e1} src0_sel:WORD_0 src1_sel:WORD_0", "fix <=> q = q_est + 1")
+    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}", "A + q_lo * k")
+    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}", "      + (q_hi * k) << 32")
+    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + k")
+    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {CK}")
     a.i(f"v_addc_co_u32 %[hi], vcc, 0, {U1}, vcc")
 
 
@@ -236,7 +247,7 @@ def emit(out, single):
         ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
                '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),']
     ops += ['      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
-            '      [tbl] "s"(table_addr_biased), [shP] "s"(32u - P), [twoP] "s"(1u << P), [c3f00] "s"(' + ("ring_mask" if single else "0x3f00u") + '), [wbase] "s"(words_base),',
+            '      [tbl] "s"(table_addr_biased), [twoP] "v"(1u << P), [c3f00] "s"(' + ("ring_mask" if single else "0x3f00u") + '), [wbase] "s"(words_base),',
             '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
             '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
             "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
