@@ -81,8 +81,6 @@ def model_args(model, params, n_expected=None):
         if len(means) != len(stds):
             raise ValueError("Model parameters have unequal lengths.")
         return ("gaussian", model.min_symbol, model.max_symbol, means, stds)
-    if isinstance(model, M.Categorical):
-        if len(params) != 1:
-            raise ValueError("Wrong number of model parameters: Categorical expects one rank-2 array of probabilities.")
-        return ("rows", M.Categorical.cdf_rows(params[0]), 0)
+    if hasattr(model, "family_rows"):      # tabulated families: one cdf row per symbol position
+        return ("rows", model.family_rows(params), model.min_symbol)
     raise TypeError("unsupported model family")

@@ -4,7 +4,17 @@ Mirrors src/pybindings/stream/model.rs: every model fixes PRECISION = 24 bits, S
 (src/pybindings/stream/model/internals.rs:26-39).  A model is either *concrete* (all parameters given to the
 constructor; usable for i.i.d. symbols) or a *family* (parameters passed per symbol to encode/decode).
 The cumulative tables of concrete models are built on the GPU (Gaussian, bit-exact f64) or on the host
-(categorical "fast" quantisation, a handful of floats) and live in HBM as a `cst_model`.
+(categorical quantisations, leaky quantisation of other continuous families: a handful of floats) and live in HBM as a
+`cst_model`.
+
+What pins which family (tests/golden/reference_vectors.json holds the reference's own vectors):
+  QuantizedGaussian, Categorical(perfect=False / lazy=True), CustomModel, ScipyModel   -- golden vectors
+  Uniform                                                                             -- integer arithmetic only (uniform.rs)
+  Categorical(perfect=True), Bernoulli                                                -- restated from categorical.rs:56-177;
+        the reference holds no vector for them, and the result depends on libm's log1p to the last bit
+  QuantizedLaplace, QuantizedCauchy, Binomial                                         -- leaky quantisation is exact, but the
+        continuous CDF lives in the un-vendored `probability` crate and no vector pins it: tables can differ from the
+        reference's by one unit in rare entries (documented in DESIGN.md as UNPINNED)
 """
 from __future__ import annotations
 
@@ -58,6 +68,89 @@ def fast_quantized_cdf(probabilities: np.ndarray, precision: int = PRECISION) ->
     return cdf
 
 
+_warned = set()
+
+
+def _warn_once(key, text):
+    """the reference prints its deprecation warnings once per process (pybindings/stream/model.rs:505-525, 998-1010)"""
+    if key not in _warned:
+        _warned.add(key)
+        print(text)
+
+
+def perfect_quantized_cdf(probabilities: np.ndarray, precision: int = PRECISION) -> np.ndarray:
+    """`perfectly_quantized_probabilities` + cumulation (src/stream/model/categorical.rs:56-177, contiguous.rs:301-313):
+    start from weight 1 + trunc(p * (2^P - n) / sum p) per symbol, hand the remaining weight to the symbols with the
+    largest win, then move single units from the cheapest seller to the best buyer while that lowers the cross entropy.
+    f64 throughout (f32 inputs are widened: `F: Into<f64>`); ties resolve like Rust's stable sort / max_by (last
+    maximum) / min_by (first minimum)."""
+    import math
+    p = np.asarray(probabilities)
+    if p.dtype not in (np.float32, np.float64):
+        p = p.astype(np.float64)
+    if p.ndim != 1:
+        raise ValueError("probabilities must be rank 1")
+    err = ValueError("Probability distribution not normalizable (the array of probabilities\n"
+                     "might be empty, contain negative values or NaNs, or sum to infinity).")
+    n = p.shape[0]
+    if n < 2 or n > 0xFFFFFFFF:
+        raise err
+    probs = [float(x) for x in p]
+    norm = 0.0
+    for x in probs:                      # Iterator::sum over f64
+        norm += x
+    if not math.isfinite(norm) or not norm >= 2.2250738585072014e-308:
+        raise err
+    remaining = (1 << precision) - n
+    if remaining < 0:
+        raise err
+    scale = float(remaining) / norm
+    inf = math.inf
+    weight, win, loss = [0] * n, [0.0] * n, [0.0] * n
+    for i, x in enumerate(probs):
+        if x < 0.0:
+            raise err
+        v = x * scale
+        free = 0 if not v > 0.0 else (0xFFFFFFFF if v >= 4294967295.0 else int(v))
+        remaining -= free
+        if remaining < 0:
+            raise err
+        weight[i] = free + 1
+        win[i] = x * math.log1p(1.0 / weight[i])
+        loss[i] = inf if weight[i] == 1 else -x * math.log1p(-1.0 / weight[i])
+    order = list(range(n))               # `slots` in their current order
+    while remaining != 0:
+        order.sort(key=lambda k: -win[k])                 # stable, descending by win
+        batch = min(remaining, n)
+        for k in order[:batch]:
+            weight[k] += 1
+            win[k] = probs[k] * math.log1p(1.0 / weight[k])
+            loss[k] = -probs[k] * math.log1p(-1.0 / weight[k])
+        remaining -= batch
+    while True:
+        buyer = order[0]
+        for k in order:                                   # max_by: the last of several maxima
+            if win[k] >= win[buyer]:
+                buyer = k
+        seller = order[0]
+        for k in order:                                   # min_by: the first of several minima
+            if loss[k] < loss[seller]:
+                seller = k
+        if buyer == seller or win[buyer] <= loss[seller]:
+            break
+        weight[seller] -= 1
+        win[seller] = -inf
+        loss[seller] = inf if weight[seller] == 1 else -probs[seller] * math.log1p(-1.0 / weight[seller])
+        weight[buyer] += 1
+        loss[buyer] = inf
+        win[buyer] = probs[buyer] * math.log1p(1.0 / weight[buyer])
+    cdf = np.zeros(n + 1, dtype=np.uint32)
+    cdf[1:] = np.cumsum(np.array(weight, dtype=np.uint64)).astype(np.uint32)
+    if int(cdf[n]) != (1 << precision):
+        raise err
+    return cdf
+
+
 class Model:
     """Base class (constriction.stream.model.Model)."""
     _n_params = 0
@@ -87,6 +180,11 @@ class QuantizedGaussian(Model):
         self.std = None if std is None else float(std)
         if self.std is not None and not self.std > 0.0:
             raise ValueError("Invalid model parameter: `std` must be positive.")   # model.rs:654-657 (assert!)
+        if self.mean is not None and hi - lo + 1 > 65536:
+            # a concrete model is a device-resident table (16-bit symbol indices); with per-symbol (mean, std) arrays the
+            # same family works for any support up to 2^24 symbols
+            raise ValueError("A concrete QuantizedGaussian is tabulated on the device: its support may hold at most 65536 "
+                             "symbols.  Pass `mean` and `std` as per-symbol arrays to encode/decode for wider supports.")
         self._dev = None
 
     def is_concrete(self):
@@ -103,27 +201,37 @@ class QuantizedGaussian(Model):
 
 class Categorical(Model):
     """constriction.stream.model.Categorical(probabilities=None, lazy=None, perfect=None)
-    (src/pybindings/stream/model.rs:455-578).  Only the `perfect=False` quantisation is on the hot path
-    (lazy and non-lazy fast tables are identical, tests/python/test_lazy_f32.py); `perfect=True` is not
-    implemented."""
+    (src/pybindings/stream/model.rs:455-578).  `perfect=False` and `lazy=True` give the "fast" quantisation (their tables
+    are identical, tests/python/test_lazy_f32.py); `perfect=True` -- still the reference's default when neither flag is
+    given, with the same one-time warning -- the cross-entropy-optimal one (perfect_quantized_cdf)."""
     _n_params = 1
 
     def __init__(self, probabilities=None, lazy: Optional[bool] = None, perfect: Optional[bool] = None):
         if lazy and perfect:
             raise ValueError("Both arguments `lazy` and `perfect` cannot be set to `True` at the same time.\n"
                              "Lazy categorical entropy models cannot perfectly quantize probabilities.")
-        if perfect or (perfect is None and lazy is None):
-            raise NotImplementedError(
-                "Categorical(perfect=True) (also the reference's legacy default when neither `perfect` nor `lazy` "
-                "is given) is outside the accelerated hot path; pass perfect=False.")
+        if perfect is None and lazy is None:
+            _warn_once("categorical", "WARNING: Neither argument `perfect` nor `lazy` were specified for `Categorical` entropy model.\n"
+                       "         In this case, `perfect` currently defaults to `True` for backward compatibility, but\n"
+                       "         this default will change to `perfect=False` in constriction version 0.5.\n"
+                       "         To suppress this warning, explicitly set:\n"
+                       "         - `perfect=False`: recommended for most new use cases; or\n"
+                       "         - `perfect=True`: if you need backward compatibility with constriction <= 0.3.5.")
+            perfect = True
+        self.perfect = bool(perfect)
         self.probabilities = None
         self._dev = None
         if probabilities is not None:
             p = np.asarray(probabilities)
             if p.dtype not in (np.float32, np.float64):
                 raise TypeError("probabilities must have dtype float32 or float64")
+            if p.ndim != 1:
+                raise ValueError("probabilities must be a rank-1 array")
             self.probabilities = np.ascontiguousarray(p)
-            self.cdf = fast_quantized_cdf(self.probabilities, PRECISION)
+            self.cdf = self._quantize(self.probabilities)
+
+    def _quantize(self, row):
+        return perfect_quantized_cdf(row, PRECISION) if self.perfect else fast_quantized_cdf(row, PRECISION)
 
     def is_concrete(self):
         return self.probabilities is not None
@@ -136,15 +244,118 @@ class Categorical(Model):
             self._dev = batched.Model.from_cdf(self.cdf, 0, PRECISION)
         return self._dev
 
-    @staticmethod
-    def cdf_rows(prob_matrix) -> np.ndarray:
-        """One fast-quantised cdf row per symbol for the family form (rank-2 probabilities)."""
-        m = np.asarray(prob_matrix)
+    min_symbol = 0
+
+    def family_rows(self, params) -> np.ndarray:
+        """One quantised cdf row per symbol for the family form (a rank-2 array of probabilities)."""
+        if len(params) != 1:
+            raise ValueError("Wrong number of model parameters: Categorical expects one rank-2 array of probabilities.")
+        m = np.asarray(params[0])
         if m.ndim != 2:
             raise ValueError("expected a rank-2 array of probabilities (one row per symbol)")
         if m.dtype not in (np.float32, np.float64):
             raise TypeError("probabilities must have dtype float32 or float64")
-        return np.stack([fast_quantized_cdf(row, PRECISION) for row in m]) if len(m) else np.zeros((0, m.shape[1] + 1), np.uint32)
+        return np.stack([self._quantize(row) for row in m]) if len(m) else np.zeros((0, m.shape[1] + 1), np.uint32)
+
+    @staticmethod
+    def cdf_rows(prob_matrix) -> np.ndarray:
+        """fast-quantised rows (kept for callers of the round-1 interface)"""
+        return Categorical(perfect=False).family_rows((prob_matrix,))
+
+
+class Bernoulli(Model):
+    """constriction.stream.model.Bernoulli(p=None, perfect=None) (src/pybindings/stream/model.rs:968-1055): the categorical
+    model over {0, 1} with probabilities [1 - p, p], in f64; `perfect` as for `Categorical` (default True, one-time warning)."""
+    _n_params = 1
+    min_symbol = 0
+
+    def __init__(self, p=None, perfect: Optional[bool] = None):
+        if perfect is None:
+            _warn_once("bernoulli", "WARNING: Argument `perfect` was not specified for `Bernoulli` distribution.\n"
+                       "         It currently defaults to `perfect=True` for backward compatibility, but this default\n"
+                       "         will change to `perfect=False` in constriction version 0.5. To suppress this warning,\n"
+                       "         explicitly set `perfect=False` (recommended for most new use cases) or explicitly set\n"
+                       "         `perfect=True` (if you need backward compatibility with constriction <= 0.3.5).")
+            perfect = True
+        self.perfect = bool(perfect)
+        self.p = None if p is None else float(p)
+        self._dev = None
+        if self.p is not None:
+            self.cdf = self._row(self.p)
+
+    def _row(self, p):
+        try:
+            row = np.array([1.0 - p, p], dtype=np.float64)
+            return perfect_quantized_cdf(row, PRECISION) if self.perfect else fast_quantized_cdf(row, PRECISION)
+        except ValueError:
+            raise ValueError("`p` must be >= 0.0 and <= 1.0.") from None
+
+    def is_concrete(self):
+        return self.p is not None
+
+    def _device_model(self):
+        if not self.is_concrete():
+            return super()._device_model()
+        if self._dev is None:
+            from .. import batched
+            self._dev = batched.Model.from_cdf(self.cdf, 0, PRECISION)
+        return self._dev
+
+    def family_rows(self, params):
+        if len(params) != 1:
+            raise ValueError("Wrong number of model parameters: Bernoulli expects one array `p`.")
+        ps = _as_float_params(params[0], "p")
+        return np.stack([self._row(float(x)) for x in ps]) if len(ps) else np.zeros((0, 3), np.uint32)
+
+
+class Uniform(Model):
+    """constriction.stream.model.Uniform(size=None) (src/pybindings/stream/model.rs:562-600, src/stream/model/uniform.rs):
+    every symbol of {0, ..., size-1} has probability floor(2^24 / size), the last one takes the remainder too.  Integer
+    arithmetic only.  As a table: size <= 65536 (concrete) / <= 4096 (per-symbol sizes)."""
+    _n_params = 1
+    min_symbol = 0
+
+    def __init__(self, size=None):
+        self.size = None if size is None else int(size)
+        self._dev = None
+        if self.size is not None:
+            self.cdf = self._row(self.size, 65536)
+
+    @staticmethod
+    def _row(size, limit, width=None):
+        if size < 2:
+            raise ValueError("`size` must be at least 2.")          # uniform.rs:114 (assert!)
+        if size > (1 << PRECISION):
+            raise ValueError("`size` must be smaller than 2**24.")
+        if size > limit:
+            raise ValueError(f"Uniform models over more than {limit} symbols are not supported by this backend in this form.")
+        per_bin = (1 << PRECISION) // size
+        width = size if width is None else width
+        row = np.full(width + 1, 1 << PRECISION, dtype=np.uint32)       # (padding rows repeat 2^24: never selected)
+        row[:size] = np.arange(size, dtype=np.uint64) * per_bin
+        return row
+
+    def is_concrete(self):
+        return self.size is not None
+
+    def _device_model(self):
+        if not self.is_concrete():
+            return super()._device_model()
+        if self._dev is None:
+            from .. import batched
+            self._dev = batched.Model.from_cdf(self.cdf, 0, PRECISION)
+        return self._dev
+
+    def family_rows(self, params):
+        if len(params) != 1:
+            raise ValueError("Wrong number of model parameters: Uniform expects one array `size`.")
+        sizes = np.asarray(params[0])
+        if sizes.dtype != np.int32 or sizes.ndim != 1:
+            raise TypeError("`size` must be a rank-1 numpy array with dtype int32")
+        if len(sizes) == 0:
+            return np.zeros((0, 3), np.uint32)
+        width = int(sizes.max())
+        return np.stack([self._row(int(z), 4096, width) for z in sizes])
 
 
 def leaky_cdf_table(cdf, min_symbol: int, max_symbol: int, params=(), precision: int = PRECISION) -> np.ndarray:
@@ -183,6 +394,8 @@ class CustomModel(Model):
             raise ValueError("The support must contain at least two symbols.")
         if hi - lo + 1 > (1 << PRECISION):
             raise ValueError("The support is too large to assign a nonzero probability to each element.")
+        if hi - lo + 1 > 65536:
+            raise ValueError("This backend tabulates CustomModel / ScipyModel: the support may hold at most 65536 symbols.")
         self.cdf, self.approximate_inverse_cdf = cdf, approximate_inverse_cdf
         self.min_symbol, self.max_symbol = lo, hi
         self._dev = None
@@ -215,3 +428,148 @@ class ScipyModel(CustomModel):
 
     def __init__(self, scipy_model, min_symbol_inclusive, max_symbol_inclusive):
         super().__init__(scipy_model.cdf, scipy_model.ppf, min_symbol_inclusive, max_symbol_inclusive)
+
+
+class _LeakyFamily(Model):
+    """A continuous two-parameter family under the LeakyQuantizer<f64,i32,u32,24> (quantize.rs:284-308, 525-568), tabulated
+    on the host.  Subclasses give `_cdf(x, a, b)`."""
+    _n_params = 2
+    _names = ("a", "b")
+
+    def __init__(self, min_symbol_inclusive, max_symbol_inclusive, a=None, b=None):
+        lo, hi = int(min_symbol_inclusive), int(max_symbol_inclusive)
+        if not hi > lo:
+            raise ValueError("The support must contain at least two symbols.")
+        if hi - lo + 1 > 65536:
+            raise ValueError("This backend tabulates this model family: the support may hold at most 65536 symbols.")
+        if (a is None) != (b is None):
+            raise ValueError(f"Either none or both of `{self._names[0]}` and `{self._names[1]}` must be specified.")
+        self.min_symbol, self.max_symbol = lo, hi
+        self.a = None if a is None else float(a)
+        self.b = None if b is None else float(b)
+        if self.b is not None:
+            self._check(self.a, self.b)
+        self._dev = None
+
+    def _check(self, a, b):
+        if not b > 0.0:
+            raise ValueError(f"Invalid model parameter: `{self._names[1]}` must be positive.")
+
+    def is_concrete(self):
+        return self.a is not None
+
+    def _device_model(self):
+        if not self.is_concrete():
+            return super()._device_model()
+        if self._dev is None:
+            from .. import batched
+            self._dev = batched.Model.from_cdf(leaky_cdf_table(self._cdf, self.min_symbol, self.max_symbol, (self.a, self.b)),
+                                               self.min_symbol, PRECISION)
+        return self._dev
+
+    def family_rows(self, params):
+        if len(params) != 2:
+            raise ValueError(f"Wrong number of model parameters: expected ({self._names[0]}, {self._names[1]}).")
+        a, b = _as_float_params(params[0], self._names[0]), _as_float_params(params[1], self._names[1])
+        if len(a) != len(b):
+            raise ValueError("Model parameters have unequal lengths.")
+        n = self.max_symbol - self.min_symbol + 1
+        rows = []
+        for x, y in zip(a, b):
+            self._check(float(x), float(y))
+            rows.append(leaky_cdf_table(self._cdf, self.min_symbol, self.max_symbol, (float(x), float(y))))
+        return np.stack(rows) if rows else np.zeros((0, n + 1), np.uint32)
+
+
+class QuantizedLaplace(_LeakyFamily):
+    """constriction.stream.model.QuantizedLaplace(min_symbol_inclusive, max_symbol_inclusive, mean=None, scale=None)
+    (src/pybindings/stream/model.rs:736-800).  CDF of the `probability` crate's Laplace (UNPINNED: no reference vector):
+    x <= mean: exp((x - mean) / scale) / 2, else 1 - exp(-(x - mean) / scale) / 2."""
+    _names = ("mean", "scale")
+
+    def __init__(self, min_symbol_inclusive, max_symbol_inclusive, mean=None, scale=None):
+        super().__init__(min_symbol_inclusive, max_symbol_inclusive, mean, scale)
+
+    @staticmethod
+    def _cdf(x, mean, scale):
+        import math
+        if x <= mean:
+            return 0.5 * math.exp((x - mean) / scale)
+        return 1.0 - 0.5 * math.exp(-(x - mean) / scale)
+
+
+class QuantizedCauchy(_LeakyFamily):
+    """constriction.stream.model.QuantizedCauchy(min_symbol_inclusive, max_symbol_inclusive, loc=None, scale=None)
+    (src/pybindings/stream/model.rs:836-900).  CDF atan((x - loc) / scale) / pi + 1/2 (UNPINNED: no reference vector)."""
+    _names = ("loc", "scale")
+
+    def __init__(self, min_symbol_inclusive, max_symbol_inclusive, loc=None, scale=None):
+        super().__init__(min_symbol_inclusive, max_symbol_inclusive, loc, scale)
+
+    @staticmethod
+    def _cdf(x, loc, scale):
+        import math
+        return math.atan((x - loc) / scale) / math.pi + 0.5
+
+
+class Binomial(Model):
+    """constriction.stream.model.Binomial(n=None, p=None) (src/pybindings/stream/model.rs:903-966): LeakyQuantizer over
+    {0, ..., n} applied to the Binomial(n, p) CDF (UNPINNED: the reference evaluates it through the `probability` crate's
+    regularised incomplete beta function; here through scipy.stats.binom).  Forms: Binomial(n, p), Binomial(n) with `p` per
+    symbol, Binomial() with `n` and `p` per symbol."""
+    _n_params = 2
+    min_symbol = 0
+
+    def __init__(self, n=None, p=None):
+        if n is None and p is not None:
+            raise ValueError("Either none or both of `n` and `p` must be specified, or only `n`.")
+        self.n = None if n is None else int(n)
+        self.p = None if p is None else float(p)
+        if self.n is not None and self.n > 65535:
+            raise ValueError("This backend tabulates this model family: `n` may be at most 65535.")
+        self._dev = None
+
+    @staticmethod
+    def _row(n, p, width=None):
+        from scipy.stats import binom
+        if n < 1:
+            raise ValueError("`n` must be at least 1.")
+        if not 0.0 <= p <= 1.0:
+            raise ValueError("`p` must be >= 0.0 and <= 1.0.")
+        row = leaky_cdf_table(lambda x: float(binom.cdf(x, n, p)), 0, n)
+        if width is not None and width > n:
+            row = np.concatenate([row, np.full(width - n, 1 << PRECISION, dtype=np.uint32)])
+        return row
+
+    def is_concrete(self):
+        return self.n is not None and self.p is not None
+
+    def _device_model(self):
+        if not self.is_concrete():
+            return super()._device_model()
+        if self._dev is None:
+            from .. import batched
+            self._dev = batched.Model.from_cdf(self._row(self.n, self.p), 0, PRECISION)
+        return self._dev
+
+    def family_rows(self, params):
+        if self.n is None:
+            if len(params) != 2:
+                raise ValueError("Wrong number of model parameters: Binomial() expects (n, p).")
+            ns = np.asarray(params[0])
+            if ns.dtype != np.int32 or ns.ndim != 1:
+                raise TypeError("`n` must be a rank-1 numpy array with dtype int32")
+            ps = _as_float_params(params[1], "p")
+        else:
+            if len(params) != 1:
+                raise ValueError("Wrong number of model parameters: Binomial(n) expects (p,).")
+            ps = _as_float_params(params[0], "p")
+            ns = np.full(len(ps), self.n, dtype=np.int32)
+        if len(ns) != len(ps):
+            raise ValueError("Model parameters have unequal lengths.")
+        if len(ns) == 0:
+            return np.zeros((0, 3), np.uint32)
+        if int(ns.max()) > 4096:
+            raise ValueError("per-symbol Binomial models are tabulated: `n` may be at most 4096 in this form.")
+        width = int(ns.max())
+        return np.stack([self._row(int(a), float(b), width) for a, b in zip(ns, ps)])

@@ -1,0 +1,95 @@
+"""CPU-only: host-side model quantisations of the drop-in module (constriction_amd.stream.model) -- no GPU, no oracle.
+Properties are the reference's own test properties (src/stream/model/categorical/contiguous.rs:700-830,
+src/stream/model/uniform.rs); see the module docstring for what pins which family."""
+import math
+
+import numpy as np
+import pytest
+
+from constriction_amd.stream import model as M
+
+
+def cross_entropy(probs, cdf):
+    w = np.diff(cdf.astype(np.int64)) / float(cdf[-1])
+    p = np.asarray(probs, dtype=np.float64)
+    p = p / p.sum()
+    return float(-(p[p > 0] * np.log2(w[p > 0])).sum())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_perfect_quantisation_properties(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 7, 50, 300]))
+    probs = rng.dirichlet(np.ones(n) * rng.choice([0.05, 0.5, 5.0]))
+    if seed % 3 == 0:
+        probs[rng.integers(n)] = 0.0                  # zero-probability symbols still get weight 1
+    for P in (12, 24):
+        if n >= (1 << P):
+            continue
+        perfect = M.perfect_quantized_cdf(probs, P)
+        fast = M.fast_quantized_cdf(probs, P)
+        assert perfect[0] == 0 and int(perfect[-1]) == 1 << P
+        assert (np.diff(perfect.astype(np.int64)) >= 1).all()
+        # contiguous.rs:754-780: the perfect quantisation is never worse than the fast one
+        assert cross_entropy(probs, perfect) <= cross_entropy(probs, fast) + 1e-12
+        # local optimality: moving one unit between any two symbols does not lower the cross entropy
+        w = np.diff(perfect.astype(np.int64))
+        p = probs / probs.sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            win = p * np.log1p(1.0 / w)
+            loss = np.where(w > 1, -p * np.log1p(-1.0 / np.maximum(w, 2)), np.inf)
+        assert win.max() <= loss.min() + 1e-15 or np.argmax(win) == np.argmin(loss)
+
+
+def test_perfect_quantisation_small_cases():
+    assert M.perfect_quantized_cdf(np.array([0.5, 0.5]), 24).tolist() == [0, 1 << 23, 1 << 24]
+    assert M.perfect_quantized_cdf(np.array([1.0, 0.0]), 8).tolist() == [0, 255, 256]
+    assert M.perfect_quantized_cdf(np.array([0.25, 0.5, 0.25], dtype=np.float32), 12).tolist() == [0, 1024, 3072, 4096]
+    for bad in ([1.0], [], [0.5, -0.1], [float("nan"), 0.5], [float("inf"), 1.0], [0.0, 0.0]):
+        with pytest.raises(ValueError):
+            M.perfect_quantized_cdf(np.array(bad, dtype=np.float64), 24)
+
+
+def test_uniform_table_is_uniform_rs():
+    """uniform.rs:120-137: probability_per_bin = 2^24 / size (integer), the last symbol takes the rest"""
+    for size in (2, 3, 10, 1000, 65536):
+        cdf = M.Uniform(size).cdf.astype(np.int64)
+        per = (1 << 24) // size
+        assert cdf[0] == 0 and cdf[-1] == 1 << 24 and len(cdf) == size + 1
+        assert (np.diff(cdf)[:-1] == per).all() and cdf[-1] - cdf[-2] == (1 << 24) - (size - 1) * per
+    for bad in (0, 1, (1 << 24) + 1):
+        with pytest.raises(ValueError):
+            M.Uniform(bad)
+    rows = M.Uniform().family_rows((np.array([2, 5, 3], dtype=np.int32),))
+    assert rows.shape == (3, 6) and rows[0].tolist() == [0, 1 << 23, 1 << 24, 1 << 24, 1 << 24, 1 << 24]
+
+
+def test_leaky_families_tables():
+    for model in (M.QuantizedLaplace(-20, 20, 1.5, 3.0), M.QuantizedCauchy(-20, 20, -2.0, 1.5)):
+        cdf = M.leaky_cdf_table(model._cdf, -20, 20, (model.a, model.b)).astype(np.int64)
+        assert cdf[0] == 0 and cdf[-1] == 1 << 24 and (np.diff(cdf) >= 1).all()
+        # quantize.rs:525-568: left(i) = trunc(free_weight * cdf(sym - 0.5)) + i
+        fw = float((1 << 24) - 1 - 40)
+        i = 17
+        assert cdf[i] == int(fw * model._cdf(-20 + i - 0.5, model.a, model.b)) + i
+    row = M.Binomial._row(20, 0.3).astype(np.int64)
+    assert row[0] == 0 and row[-1] == 1 << 24 and (np.diff(row) >= 1).all() and np.argmax(np.diff(row)) == 6
+    with pytest.raises(ValueError):
+        M.QuantizedLaplace(-5, 5, 0.0, 0.0)
+    with pytest.raises(ValueError):
+        M.QuantizedCauchy(3, 3, 0.0, 1.0)
+    assert math.isclose(M.QuantizedLaplace._cdf(1.5, 1.5, 3.0), 0.5) and math.isclose(M.QuantizedCauchy._cdf(-2.0, -2.0, 1.5), 0.5)
+
+
+def test_categorical_flags_like_the_reference(capsys):
+    with pytest.raises(ValueError):
+        M.Categorical(np.array([0.5, 0.5]), lazy=True, perfect=True)
+    M._warned.discard("categorical")
+    m = M.Categorical(np.array([0.1, 0.6, 0.3]))               # legacy default: perfect, with a warning (printed once)
+    M.Categorical(np.array([0.1, 0.6, 0.3]))
+    out = capsys.readouterr().out
+    assert out.count("WARNING: Neither argument `perfect` nor `lazy`") == 1 and m.perfect
+    assert M.Categorical(np.array([0.1, 0.6, 0.3]), lazy=True).cdf.tolist() == M.Categorical(np.array([0.1, 0.6, 0.3]), perfect=False).cdf.tolist()
+    assert M.Bernoulli(0.25, perfect=False).cdf.tolist() == M.fast_quantized_cdf(np.array([0.75, 0.25])).tolist()
+    with pytest.raises(ValueError):
+        M.Bernoulli(1.5, perfect=True)       # (the fast quantisation does not look at signs: categorical.rs:16-54)
