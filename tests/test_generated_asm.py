@@ -17,6 +17,8 @@ def _load(name):
 
 def _regenerate(mod, tmp_path, name):
     mod.OUT = tmp_path / name
+    if hasattr(mod, "OUT_SINGLE"):          # (never rewrite a checked-in file: its mtime triggers a rebuild of the library)
+        mod.OUT_SINGLE = tmp_path / ("single_" + name)
     mod.main()
     return (tmp_path / name).read_text()
 
