@@ -244,6 +244,20 @@ def other_configs(B, rank, world, dist, args, reps=5):
         if rank == 0:
             e["gathered_words"] = int(res[0].numel())
             e["gather_GBps"] = round(4 * res[0].numel() * (world - 1) / world / (e["gather_ms"] * 1e-3) / 1e9, 1)
+        # the same exchange through the C ABI's own RCCL communicator (what a non-Python caller uses); never fatal
+        try:
+            comm = D.RcclComm()
+            comm.gather_packed(packed, offsets, dst=0)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res2 = comm.gather_packed(packed, offsets, dst=0)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            e["gather_c_abi_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            if rank == 0:
+                e["gather_c_abi_matches"] = bool(torch.equal(res2[0], res[0]) and torch.equal(res2[1], res[1]))
+            comm.close()
+        except Exception as exc:      # noqa: BLE001
+            e["gather_c_abi_error"] = f"{type(exc).__name__}: {exc}"[:200]
     out.append(e)
     return out
 

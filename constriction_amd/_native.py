@@ -72,6 +72,11 @@ SIGNATURES = {
     "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_compact_scratch_bytes": (_z, [_z]),
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
+    "cst_rccl_get_unique_id": (_i32, [_vp]),
+    "cst_rccl_comm_init": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "cst_rccl_comm_destroy": (_i32, [_vp]),
+    "cst_gather_sizes_rccl": (_i32, [_vp, _i32, _i32, _vp, _z, _vp, _vp]),
+    "cst_gather_rccl": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cst_ans_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),

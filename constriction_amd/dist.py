@@ -115,3 +115,59 @@ def scatter_packed(all_packed: Optional[torch.Tensor], all_offsets: Optional[tor
     off = torch.zeros(n_local + 1, dtype=torch.int64, device=lens.device)
     torch.cumsum(lens, 0, out=off[1:])
     return words, off
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same gather through the C ABI (cst_gather_sizes_rccl + cst_gather_rccl: what a Rust / C caller of the library uses)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class RcclComm:
+    """An RCCL communicator owned by the coder library (include/constriction_amd.h, "multi-GPU").  The 128-byte unique id
+    is created on rank 0 and handed to the other ranks through torch.distributed's existing process group."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import numpy as np
+        from . import _native as N
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        lib = N.lib()
+        idbuf = np.zeros(128, dtype=np.uint8)
+        if self.rank == 0:
+            N.check(lib.cst_rccl_get_unique_id(idbuf.ctypes.data), "cst_rccl_get_unique_id")
+        if self.world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.from_numpy(idbuf).to(dev)
+            dist.broadcast(t, src=0, group=group)
+            idbuf = t.cpu().numpy().copy()
+        h = C.c_void_p()
+        N.check(lib.cst_rccl_comm_init(idbuf.ctypes.data, self.world, self.rank, C.byref(h)), "cst_rccl_comm_init")
+        self._h = h
+
+    def close(self):
+        from . import _native as N
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.load_library().cst_rccl_comm_destroy(h)
+
+    def gather_packed(self, packed: torch.Tensor, offsets: torch.Tensor, dst: int = 0):
+        """packed: int32 storage of uint32 words (device), offsets: int64 [n_streams_local + 1] (device) as returned by
+        batched.compact.  Returns (all_packed, all_offsets) on dst, None elsewhere."""
+        import ctypes as C
+        from . import _native as N
+        lib = N.lib()
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n_local = offsets.numel() - 1
+        d_sizes = torch.zeros(2 * self.world, dtype=torch.int64, device=offsets.device)
+        N.check(lib.cst_gather_sizes_rccl(self._h, self.world, self.rank, C.c_void_p(offsets.data_ptr()), n_local,
+                                          C.c_void_p(d_sizes.data_ptr()), sp), "cst_gather_sizes_rccl")
+        h_sizes = d_sizes.cpu().numpy().astype("uint64")                       # (synchronises the stream)
+        all_packed = all_off = None
+        if self.rank == dst:
+            all_packed = torch.empty(max(int(h_sizes[1::2].sum()), 1), dtype=torch.int32, device=offsets.device)
+            all_off = torch.empty(int(h_sizes[0::2].sum()) + 1, dtype=torch.int64, device=offsets.device)
+        N.check(lib.cst_gather_rccl(self._h, self.world, self.rank, dst, C.c_void_p(packed.data_ptr()), C.c_void_p(offsets.data_ptr()),
+                                    h_sizes.ctypes.data, C.c_void_p(all_packed.data_ptr()) if all_packed is not None else None,
+                                    C.c_void_p(all_off.data_ptr()) if all_off is not None else None, sp), "cst_gather_rccl")
+        if self.rank == dst:
+            return all_packed[: int(h_sizes[1::2].sum())], all_off
+        return None

@@ -197,6 +197,30 @@ cst_status cst_compact_words(const uint32_t *d_words, size_t stride_words, const
                              size_t packed_capacity, void *d_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * multi-GPU: gather of the packed compressed words of every rank to one root over RCCL / xGMI (BASELINE config C5).
+ * One process per GPU; streams shard in contiguous blocks and no collective touches the coding path; this is the only
+ * exchange step.  The library opens librccl at first use (no link-time dependency); `comm` is an ncclComm_t -- the
+ * caller's own, or one made with the two helpers below from an id that rank 0 creates and the caller's launcher
+ * distributes (128 bytes).  (No reference counterpart: its coders are single-threaded host objects.)
+ * ---------------------------------------------------------------------------------------- */
+cst_status cst_rccl_get_unique_id(void *h_id /* 128 bytes out */);
+cst_status cst_rccl_comm_init(const void *h_id, int32_t n_ranks, int32_t rank, void **out_comm); /* on the current device */
+cst_status cst_rccl_comm_destroy(void *comm);
+
+/* Step 1 (every rank, asynchronous on `stream`): d_sizes[2 * n_ranks] (device, uint64) receives (n_streams, total_words)
+ * of every rank, in rank order; d_offsets is the rank's own offsets[n_streams_local + 1] from cst_compact_words. */
+cst_status cst_gather_sizes_rccl(void *comm, int32_t n_ranks, int32_t rank, const uint64_t *d_offsets,
+                                 size_t n_streams_local, uint64_t *d_sizes, void *stream);
+
+/* Step 2 (every rank): h_sizes = host copy of d_sizes.  Root: d_all_packed (capacity >= sum of words) receives the packed
+ * words of all ranks in rank order, d_all_offsets[sum of streams + 1] their global offsets; other ranks pass NULL for
+ * both.  Grouped point-to-point transfers straight into their final positions; the root's call returns after its
+ * stream has been synchronised, the other ranks' calls are asynchronous on `stream`. */
+cst_status cst_gather_rccl(void *comm, int32_t n_ranks, int32_t rank, int32_t root, const uint32_t *d_packed,
+                           const uint64_t *d_offsets, const uint64_t *h_sizes, uint32_t *d_all_packed,
+                           uint64_t *d_all_offsets, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * per-symbol quantized Gaussians: the reference's flagship Python call
  *     coder.encode_reverse(symbols, QuantizedGaussian(min, max), means, stds)
  *     coder.decode(QuantizedGaussian(min, max), means, stds)

@@ -542,3 +542,33 @@ def test_more_than_one_wave_per_simd(B, O, P, n_sym, n_per, stride_extra):
     good = status == 0
     assert (dstatus.cpu().numpy()[good] == 0).all()
     assert np.array_equal(dec.cpu().numpy()[good], sym[good]) and np.array_equal(dec2.cpu().numpy()[good], sym[good])
+
+
+def test_rccl_gather_through_the_c_abi_single_rank(B, O):
+    """cst_rccl_* / cst_gather_sizes_rccl / cst_gather_rccl with a communicator of ONE rank (the only world size a
+    single-GPU box offers): ids, sizes all-gather, the root's own copy and the offset re-basing."""
+    import os
+    import torch.distributed as dist
+    from constriction_amd import dist as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        P = 12
+        cdf = O.GaussianModel(-20, 20, 1.5, 4.0, P, 32).cdf_table()
+        model = B.Model.from_cdf(cdf, -20, P)
+        sym = O.synth_symbols(3, 0, 700, 50, -20, cdf, P)
+        enc = B.ans_encode(dev(sym), model, (32, 64, P))
+        packed, offsets = B.compact(enc)
+        comm = D.RcclComm()
+        all_packed, all_off = comm.gather_packed(packed, offsets, dst=0)
+        torch.cuda.synchronize()
+        total = int(offsets[-1])
+        assert torch.equal(all_off, offsets) and torch.equal(all_packed, packed[:total])
+        comm.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
