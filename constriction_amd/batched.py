@@ -341,3 +341,52 @@ def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="st
 def range_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
     """One RangeDecoder per stream: RangeDecoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
     return _decode_gaussian("cst_range_decode_gaussian_batch", False, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checkpointed streams (the reference's Pos / Seek jump tables, src/stream/stack.rs:1107-1139): one long stream decodes
+# on as many lanes as it has chunks
+# ---------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class Checkpoints:
+    interval: int
+    pos: torch.Tensor        # int32 [n_streams, n_chunks]: words in the bulk in front of chunk j (AnsCoder.pos()[0])
+    state: torch.Tensor      # int64 [n_streams, n_chunks]: coder state there (AnsCoder.pos()[1])
+
+
+def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, config=(32, 64, 24), layout="stream_major",
+                            stride: Optional[int] = None):
+    """ans_encode + a checkpoint in front of every `interval` symbols.  Returns (EncodedBatch, Checkpoints); the words are
+    those of ans_encode."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    stride = stride or max_words(n_per, config)
+    dev = symbols.device
+    out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                       torch.empty(n_streams, dtype=torch.int32, device=dev),
+                       torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    n_chunks = (n_per + interval - 1) // interval
+    ck = Checkpoints(int(interval), torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
+                     torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
+    N.check(N.lib().cst_ans_encode_batch_ckpt(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), stride,
+                                              _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status),
+                                              _stream_ptr()), "cst_ans_encode_batch_ckpt")
+    return out, ck
+
+
+def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None):
+    """Decodes every chunk on its own lane (AnsCoder.seek(pos, state) + `interval` symbols per chunk).
+    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
+    n_streams = encoded.n_words.numel()
+    dev = encoded.words.device
+    n_chunks = checkpoints.pos.shape[1]
+    if out is None:
+        out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
+    status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
+    L = N.lib()
+    scratch = torch.empty(L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval), dtype=torch.uint8, device=dev)
+    N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
+                                        checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
+                                        n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()), "cst_ans_decode_batch_ckpt")
+    return out, status

@@ -1,0 +1,151 @@
+// cst_ans_ckpt.hip -- checkpointed ANS streams: the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139,
+// docs of `AnsCoder::pos` / `seek`, test :1456-1548) for the batched coder.
+//
+// An ANS stream decodes strictly in order, so ONE long stream (BASELINE config C1: 10^6 symbols) occupies one lane of
+// the GPU however many there are.  The reference's answer is a jump table: while encoding, note (pos, state) = (words
+// in the bulk, coder state) every K symbols; `seek(pos, state)` later resumes decoding right there.  Here the encoder
+// records such a checkpoint in front of every chunk of K symbols and the decoder treats every (stream, chunk) pair as
+// an independent coder: chunk j of stream s is AnsCoder::seek(pos[s][j], state[s][j]) followed by K decoded symbols.
+// The compressed words are EXACTLY those of the plain encoder (checkpoints are side information), and decoding the
+// chunks is the ordinary batched decode of n_streams * n_chunks "virtual streams" of K symbols (stream-major: chunk j
+// of stream s is row s * n_chunks + j of the symbol matrix viewed as [n_streams * n_chunks][K]) with
+// CST_FLAG_RAW_STATE -- every decode kernel of the library applies unchanged, including the hand-scheduled ones.
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+struct CkptEncodeArgs {
+    const int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    int32_t layout;
+    const EncEntry* enc;
+    int32_t n_symbols, min_symbol, precision;
+    uint32_t* words;
+    size_t stride_words;
+    uint32_t* n_words;
+    size_t interval, n_chunks;
+    uint32_t* ckpt_pos;
+    uint64_t* ckpt_state;
+    int32_t* status;
+    int32_t table_in_lds;
+};
+
+// One lane per stream, generic steps (any supported preset).  Meant for FEW LONG streams: symbols are read straight
+// from HBM (a batch of many short streams is better served by cst_ans_encode_batch and has lanes enough without
+// checkpoints).
+template <int W, int S>
+__global__ __launch_bounds__(kBlock) void ans_encode_ckpt_kernel(const CkptEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
+    const EncEntry* table = a.enc;
+    if (a.table_in_lds) {
+        EncEntry* t = reinterpret_cast<EncEntry*>(smem + (size_t)(kBlock / kWave) * kRingWords * 4);
+        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = a.enc[i];
+        table = t;
+    }
+    __syncthreads();
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    const int32_t* my = a.symbols + (active ? (a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N) : 0);
+
+    EncLane<W, S> L;
+    L.init(a.words + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    int countdown = 4 * groups_per_point(W, P);
+    size_t next_ckpt = a.n_chunks;            // checkpoint j is taken once symbol j * interval has been encoded
+    for (size_t t = N; t-- > 0;) {
+        const int32_t v = active ? my[t * stride_t] : a.min_symbol;
+        L.template step<false>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P);
+        if (--countdown == 0) { countdown = 4 * groups_per_point(W, P); L.flush_chunks(); }
+        if (next_ckpt > 0 && t == (next_ckpt - 1) * a.interval) {
+            --next_ckpt;
+            if (active) {
+                a.ckpt_pos[s * a.n_chunks + next_ckpt] = L.out.wr;              // AnsCoder::pos(): (bulk.len(), state)
+                a.ckpt_state[s * a.n_chunks + next_ckpt] = (uint64_t)L.state;
+            }
+        }
+    }
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(true, nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// offsets of the virtual streams: every chunk of stream s reads stream s's words
+__global__ void ckpt_offsets_kernel(const uint64_t* __restrict__ offsets, size_t stride_words, size_t n_streams, size_t n_chunks,
+                                    uint64_t* __restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    const size_t s = v / n_chunks;
+    out[v] = offsets ? offsets[s] : s * stride_words;
+}
+
+} // namespace cst
+
+using namespace cst;
+
+extern "C" {
+
+cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
+                                     size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
+                                     uint32_t* d_n_words, size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
+                                     int32_t* d_status, void* stream) {
+    if (!model || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+    CkptEncodeArgs a{};
+    a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision; a.words = d_words;
+    a.stride_words = stride_words; a.n_words = d_n_words; a.interval = ckpt_interval;
+    a.n_chunks = (n_per_stream + ckpt_interval - 1) / ckpt_interval; a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.status = d_status;
+    const size_t ring_bytes = (size_t)(kBlock / kWave) * kRingWords * 4, table_bytes = (size_t)model->n_symbols * sizeof(EncEntry);
+    a.table_in_lds = ring_bytes + table_bytes <= 150 * 1024;
+    const size_t lds = ring_bytes + (a.table_in_lds ? table_bytes : 0);
+    const size_t blocks = (n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32) {
+        if (lds > 64 * 1024) CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_ckpt_kernel<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ans_encode_ckpt_kernel<32, 64>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    } else {
+        if (lds > 64 * 1024) CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_ckpt_kernel<16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ans_encode_ckpt_kernel<16, 32>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    }
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval) {
+    if (ckpt_interval == 0) return 0;
+    return 16 * n_streams * ((n_per_stream + ckpt_interval - 1) / ckpt_interval) + 16;
+}
+
+cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                     size_t stride_words, size_t ckpt_interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
+                                     int32_t* d_symbols, size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status,
+                                     void* stream) {
+    if (!model || !d_ckpt_pos || !d_ckpt_state || !d_scratch || !d_status || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;      // whole chunks only: rows of the virtual matrix
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
+    hipStream_t hs = (hipStream_t)stream;
+    uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
+    uint64_t* v_state = v_offsets + n_virtual;
+    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);
+    CST_HIP_TRY(hipGetLastError());
+    CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));   // (the raw decode updates its state array)
+    return cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR,
+                                v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+}
+
+} // extern "C"

@@ -773,11 +773,9 @@ __device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, c
     uint32_t next_word;
     if constexpr (W == 32 && S == 64 && FAST) {
         // Unconditional ring read, issued BEFORE the table lookup so that the lookup's own wait covers it.
-        // Inline asm: the optimiser would otherwise sink the load into a branch on `refill` and put the LDS
-        // latency back on the critical path (it is invisible to the compiler's lgkmcnt bookkeeping, hence the
-        // explicit s_waitcnt in the select block below).
-        const uint32_t ring_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)L.in.slot(L.in.rd - 1u + L.in.shift);
-        asm volatile("ds_read_b32 %0, %1" : "=v"(next_word) : "v"(ring_addr) : "memory");
+        // volatile: the load stays HERE (the optimiser would otherwise sink it into a branch on `refill` and put the LDS
+        // latency back on the critical path) and stays visible to the compiler's lgkmcnt bookkeeping
+        next_word = *reinterpret_cast<const volatile uint32_t*>(L.in.slot(L.in.rd - 1u + L.in.shift));
     } else {
         next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);   // ignored if no refill
     }
@@ -795,7 +793,6 @@ __device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, c
         uint32_t new_lo, new_hi, new_rd, have;
         asm volatile(
             "v_min_u32 %3, %4, 1\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
             "v_cmp_lt_u32 vcc, %5, %3\n\t"
             "s_nop 1\n\t"
             "v_cndmask_b32 %0, %6, %7, vcc\n\t"          // lo' = refill ? next_word : t_lo

@@ -18,6 +18,12 @@ void set_hip_error(hipError_t e, const char* what) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// a model's tables live on the device it was built on: coding calls must run there (one process may drive several GPUs)
+static inline bool on_model_device(const cst_model* m) {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess && dev == m->device;
+}
+
 static constexpr size_t kRingBytesPerBlock = (size_t)(kBlock / kWave) * kRingWords * sizeof(uint32_t);
 static constexpr size_t kTileBytesPerBlock = (size_t)(kBlock / kWave) * kWave * kTileStride * sizeof(int32_t) + kRingBytesPerBlock;
 static constexpr size_t kMaxLds = 160 * 1024;
@@ -250,6 +256,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))   // one table per stream (config C3), compact rows
         return ans_encode_pt(model, cfg, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, d_state, d_status,
                              flags, (hipStream_t)stream);
@@ -277,6 +284,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))
         return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, d_state,
                              d_n_words_out, d_status, flags, (hipStream_t)stream);

@@ -172,6 +172,10 @@ cst_status cst_ans_encode_batch(const cst_model *model, cst_coder_config cfg, co
  * so both the slab layout written by cst_ans_encode_batch and the packed layout written by
  * cst_compact_words decode without a copy.  Decoding past the end of a stream is legal and
  * deterministic, exactly as in the reference (stack.rs:1062-1065).
+ * The caller vouches for the metadata: [off(s), off(s) + d_n_words[s]) must lie inside the buffer behind d_words (the
+ * kernels read whole aligned 16-byte chunks: up to 12 bytes before the first and after the last word of a stream are
+ * touched, never interpreted; buffers from cst_ans_encode_batch / cst_compact_words via hipMalloc satisfy this).
+ * The model must have been created on the current device (CST_ERR_INVALID_ARGUMENT otherwise).
  * With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
  * count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).
  */
@@ -180,6 +184,26 @@ cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, co
                                 int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                 uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
                                 uint32_t flags, void *stream);
+
+/* Checkpointed streams -- the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139; test :1456-1548) for the
+ * batched coder.  The encoder notes, in front of every chunk of `ckpt_interval` symbols, what `AnsCoder::pos()` returns
+ * there: d_ckpt_pos[s][j] = words in the bulk, d_ckpt_state[s][j] = coder state once symbols [j * interval, n) are
+ * encoded (n_chunks = ceil(n_per_stream / interval) entries per stream).  The compressed words are exactly those of
+ * cst_ans_encode_batch.  The decoder then treats every (stream, chunk) as an independent coder --
+ * `AnsCoder::seek(pos, state)` + interval decoded symbols -- so that ONE long stream (BASELINE config C1) spreads over
+ * n_chunks lanes: it is the ordinary batched decode of n_streams * n_chunks virtual streams (stream-major symbols,
+ * shared-table models, n_per_stream a multiple of the interval; d_status has n_streams * n_chunks entries;
+ * d_scratch: cst_ckpt_scratch_bytes(...) bytes, contents irrelevant). */
+cst_status cst_ans_encode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                     size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                     size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
+                                     uint32_t *d_ckpt_pos, uint64_t *d_ckpt_state, int32_t *d_status, void *stream);
+size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval);
+cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                     const uint64_t *d_offsets, size_t stride_words, size_t ckpt_interval,
+                                     const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_state, int32_t *d_symbols,
+                                     size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
+                                     void *stream);
 
 /* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
  * concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled

@@ -1,0 +1,80 @@
+"""GPU tests of checkpointed streams (cst_ans_encode_batch_ckpt / cst_ans_decode_batch_ckpt): the reference's Pos / Seek
+jump tables (src/stream/stack.rs:1107-1139, its test :1456-1548) for the batched coder, and BASELINE config C1 (ONE stream
+of 10^6 symbols, QuantizedGaussian(-50, 50, 3.2, 9.6), P = 24) decoded on a thousand lanes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+@pytest.mark.parametrize("n_streams,n_per,interval", [(1, 96, 32), (3, 120, 40), (70, 64, 64), (5, 100, 1), (2, 90, 100)])
+def test_checkpoints_are_pos_and_state_of_the_reference_coder(B, O, cfg, n_streams, n_per, interval):
+    W, S, P = cfg
+    cdf = O.GaussianModel(-30, 30, 1.5, 6.0, P, 32 if W == 32 else 16).cdf_table()
+    model = B.Model.from_cdf(cdf, -30, P)
+    sym = O.synth_symbols(21, 0, n_streams, n_per, -30, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, -30, cdf, P, W, S)
+    enc, ck = B.ans_encode_checkpointed(dev(sym), model, interval, cfg)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    pos, state = ck.pos.cpu().numpy(), ck.state.cpu().numpy().view(np.uint64)
+    n_chunks = (n_per + interval - 1) // interval
+    assert pos.shape == (n_streams, n_chunks)
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+        for j in range(n_chunks):
+            c = O.AnsCoder(W=W, S=S)                       # AnsCoder::pos() after encoding symbols [j * K, n) in reverse
+            c.encode_iid_table_reverse(sym[s, j * interval:], cdf, -30, P)
+            p, st = c.pos()
+            assert (int(pos[s, j]), int(state[s, j])) == (p, st), (s, j)
+    if n_per % interval == 0:
+        dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per)
+        torch.cuda.synchronize()
+        assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+def test_config_c1_one_stream_of_a_million_symbols(B, O):
+    """BASELINE config C1 on the GPU: words identical to the CPU coder's, decoded on 1000 lanes through the checkpoints
+    and (slowly, on one lane) without them."""
+    lo, hi, mean, std, P, n = -50, 50, 3.2, 9.6, 24, 1_000_000
+    model = B.Model.quantized_gaussian(lo, hi, mean, std, P)
+    cdf = O.GaussianModel(lo, hi, mean, std, P, 32).cdf_table()
+    assert model.cdf().tolist() == cdf.tolist()
+    sym = O.synth_symbols(0xC0FFEE, 0, 1, n, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    enc, ck = B.ans_encode_checkpointed(dev(sym), model, 1000, (32, 64, P))
+    torch.cuda.synchronize()
+    assert int(enc.status[0]) == 0 and int(enc.n_words[0]) == int(want_n[0])
+    assert np.array_equal(enc.stream(0), want_words[0, : want_n[0]])
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n)
+    e1.record()
+    dec1, st1 = B.ans_decode(enc, model, n)
+    e2.record()
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    assert int(st1[0]) == 0 and np.array_equal(dec1.cpu().numpy(), sym)
+    print(f"C1 decode: {e0.elapsed_time(e1):.2f} ms on 1000 lanes (checkpoints), {e1.elapsed_time(e2):.2f} ms on one lane")
+    assert e0.elapsed_time(e1) * 20 < e1.elapsed_time(e2)
