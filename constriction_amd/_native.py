@@ -5,13 +5,10 @@ product path raises (BackendUnavailable).  Nothing here imports the test oracle.
 from __future__ import annotations
 
 import ctypes as C
-import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "lib" / "libconstriction_amd.so"
-if os.environ.get("CST_LIB_PATH"):   # developer knob: A/B an experimental build of the same ABI
-    LIB_PATH = Path(os.environ["CST_LIB_PATH"])
 
 CST_OK = 0
 CST_ERR_INVALID_ARGUMENT = -1

@@ -572,3 +572,41 @@ def test_rccl_gather_through_the_c_abi_single_rank(B, O):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_golden_vectors_through_the_batched_abi(B, O, golden):
+    """Every ANS golden vector with one i.i.d. table model per step -- in particular R3, the reference's (16,32,12)
+    lookup-decoder example (src/stream/model/categorical/lookup_contiguous.rs:278-290), which the single-coder drop-in
+    (fixed to the (32,64,24) preset like the reference's Python API) cannot express -- through ans_decode / ans_encode of
+    the batched API, replicated over a wave and a half of identical streams."""
+    from golden_util import models_for
+    n_rep = 96
+    done = 0
+    for vec in golden["vectors"]:
+        if vec["coder"] != "ans" or len(vec["steps"]) != 1:
+            continue
+        step = vec["steps"][0]
+        if step["model"]["kind"] not in ("categorical_fast", "table") and not (step["model"]["kind"] == "gaussian" and "means" not in step["model"]):
+            continue
+        W, S, P = vec["W"], vec["S"], vec["P"]
+        m, n = models_for(step, P, O, 32 if W == 32 else 16)
+        cdf = m.cdf_table() if hasattr(m, "cdf_table") else m.cdf
+        lo = m.lo
+        model = B.Model.from_cdf(np.asarray(cdf, dtype=np.uint32), lo, P)
+        if step["op"] == "decode":
+            words = np.asarray(vec["init"]["compressed"], dtype=np.uint32)
+            enc_words = dev(np.tile(words.view(np.int32), (n_rep, 1)))
+            n_words = dev(np.full(n_rep, len(words), dtype=np.int32))
+            expect = np.atleast_1d(np.asarray(step["expect"], dtype=np.int32))
+            dec, st = B.ans_decode((enc_words, n_words), model, len(expect), config=(W, S, P))
+            torch.cuda.synchronize()
+            assert (st.cpu().numpy() == 0).all()
+            assert (dec.cpu().numpy() == expect[None, :]).all(), vec["id"]
+        else:
+            sym = np.asarray(step["symbols"], dtype=np.int32)
+            enc = B.ans_encode(dev(np.tile(sym, (n_rep, 1))), model, (W, S, P))
+            torch.cuda.synchronize()
+            for s in (0, 63, 64, n_rep - 1):
+                assert enc.stream(s).tolist() == vec["expect_compressed"], vec["id"]
+        done += 1
+    assert done >= 3
