@@ -59,6 +59,9 @@ SIGNATURES = {
     "cst_model_create_table": (_i32, [_i32, _i32, _i32, _vp, C.POINTER(_vp)]),
     "cst_model_create_gaussian": (_i32, [_i32, _i32, _i32, _f64, _f64, _vp, C.POINTER(_vp)]),
     "cst_model_create_gaussian_per_stream": (_i32, [_i32, _i32, _i32, _vp, _vp, _z, _vp, C.POINTER(_vp)]),
+    "cst_model_create_table_noncontiguous": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),
+    "cst_symbols_to_indices": (_i32, [_vp, _vp, _z, _vp, _vp]),
+    "cst_indices_to_symbols": (_i32, [_vp, _vp, _z, _vp, _vp]),
     "cst_model_destroy": (_i32, [_vp]),
     "cst_model_precision": (_i32, [_vp]),
     "cst_model_min_symbol": (_i32, [_vp]),

@@ -63,6 +63,34 @@ class Model:
         return cls(h)
 
     @classmethod
+    def from_cdf_noncontiguous(cls, symbols, cdf, precision: int) -> "Model":
+        """A tabulated model over arbitrary distinct int32 symbols (symbols[i] has left cumulative cdf[i]):
+        NonContiguousCategorical{Encoder,Decoder}Model / NonContiguousLookupDecoderModel of the reference."""
+        cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+        symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+        if len(symbols) != len(cdf) - 1:
+            raise ValueError("one symbol per table entry")
+        h = C.c_void_p()
+        N.check(N.lib().cst_model_create_table_noncontiguous(precision, len(symbols), symbols.ctypes.data, cdf.ctypes.data, C.byref(h)),
+                "cst_model_create_table_noncontiguous")
+        m = cls(h)
+        m.noncontiguous = True
+        return m
+
+    def symbols_to_indices(self, symbols: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        symbols = _require_cuda(symbols, torch.int32, "symbols")
+        out = torch.empty_like(symbols) if out is None else out
+        N.check(N.lib().cst_symbols_to_indices(self._h, _ptr(symbols), symbols.numel(), _ptr(out), _stream_ptr()), "cst_symbols_to_indices")
+        return out
+
+    def indices_to_symbols(self, indices: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(indices) if out is None else out
+        N.check(N.lib().cst_indices_to_symbols(self._h, _ptr(indices), indices.numel(), _ptr(out), _stream_ptr()), "cst_indices_to_symbols")
+        return out
+
+    noncontiguous = False
+
+    @classmethod
     def quantized_gaussian(cls, min_symbol: int, max_symbol: int, mean: float, std: float, precision: int) -> "Model":
         """LeakyQuantizer(min..=max) x Gaussian(mean, std), tabulated on the GPU in bit-exact f64."""
         h = C.c_void_p()
@@ -147,6 +175,8 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
                stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
     """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895)."""
     symbols = _require_cuda(symbols, torch.int32, "symbols")
+    if model.noncontiguous:
+        symbols = model.symbols_to_indices(symbols)
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         stride = stride or max_words(n_per, config)
@@ -182,6 +212,8 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
                                          _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status), N.FLAG_NONE,
                                          _stream_ptr()), "cst_ans_decode_batch")
+    if model.noncontiguous:
+        model.indices_to_symbols(out, out=out)
     return out, status
 
 

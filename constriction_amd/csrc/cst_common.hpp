@@ -91,6 +91,11 @@ struct cst_model {
     uint16_t* d_cdf16 = nullptr;      // [n_tables][cdf16_stride]
     int32_t cdf16_stride = 0;
     uint64_t* d_recip = nullptr;      // [2^P]
+    // non-contiguous alphabets (symbol remapping, lookup_noncontiguous.rs / non_contiguous.rs): symbol of index i, and the
+    // symbols sorted with the index each one stands for
+    int32_t* d_symbol_of_index = nullptr;   // [n_symbols] or null (contiguous model)
+    int32_t* d_sorted_symbols = nullptr;    // [n_symbols]
+    int32_t* d_sorted_index = nullptr;      // [n_symbols]
     // per-stream TRIMMED PACKED rows (cst_ans_pt.hip; built when P <= 12 and n <= 256): see cst::PtMeta
     bool pt_ok = false;
     cst::PtMeta* d_pt_meta = nullptr;     // [n_tables]

@@ -1,5 +1,6 @@
 // cst_model.hip -- entropy-model tables: device construction (bit-exact f64) and host-side derivation
 // of the encoder / decoder images the coder kernels consume.
+#include <algorithm>
 #include <vector>
 #include <new>
 
@@ -158,6 +159,28 @@ static void build_pt_image(cst_model* m, hipStream_t hs) {
     }
     if (d_size) (void)hipFree(d_size);
     m->pt_ok = ok;
+}
+
+// ---- non-contiguous alphabets: symbol <-> index ----
+__global__ void symbols_to_indices_kernel(const int32_t* __restrict__ sorted, const int32_t* __restrict__ sorted_index, int32_t n,
+                                          const int32_t* __restrict__ in, int32_t* __restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t v = in[i];
+    int32_t lo = 0, hi = n;                        // first position with sorted[pos] >= v
+    while (lo < hi) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[i] = (lo < n && sorted[lo] == v) ? sorted_index[lo] : n;     // n = no such symbol: the coder reports it as impossible
+}
+
+__global__ void indices_to_symbols_kernel(const int32_t* __restrict__ symbol_of_index, int32_t n, const int32_t* __restrict__ in,
+                                          int32_t* __restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t k = (uint32_t)in[i];
+    out[i] = k < (uint32_t)n ? symbol_of_index[k] : 0;
 }
 
 __global__ void debug_erf_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
@@ -361,10 +384,56 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
     return CST_OK;
 }
 
+cst_status cst_model_create_table_noncontiguous(int32_t precision, int32_t n_symbols, const int32_t* h_symbols, const uint32_t* h_cdf,
+                                               cst_model** out) {
+    if (!out || !h_symbols || !h_cdf) return CST_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (n_symbols < 2) return CST_ERR_MODEL;
+    std::vector<int32_t> order((size_t)n_symbols);
+    for (int32_t i = 0; i < n_symbols; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return h_symbols[a] < h_symbols[b]; });
+    std::vector<int32_t> sorted((size_t)n_symbols);
+    for (int32_t i = 0; i < n_symbols; ++i) {
+        sorted[(size_t)i] = h_symbols[order[(size_t)i]];
+        if (i > 0 && sorted[(size_t)i] == sorted[(size_t)i - 1]) return CST_ERR_MODEL;     // symbols must be distinct (non_contiguous.rs: HashMap insert)
+    }
+    cst_model* m = nullptr;
+    if (cst_status st = cst_model_create_table(precision, 0, n_symbols, h_cdf, &m)) return st;   // the model proper works on indices 0..n-1
+    const size_t bytes = 4 * (size_t)n_symbols;
+    hipError_t e = hipMalloc(&m->d_symbol_of_index, bytes);
+    if (e == hipSuccess) e = hipMalloc(&m->d_sorted_symbols, bytes);
+    if (e == hipSuccess) e = hipMalloc(&m->d_sorted_index, bytes);
+    if (e == hipSuccess) e = hipMemcpy(m->d_symbol_of_index, h_symbols, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_sorted_symbols, sorted.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_sorted_index, order.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_hip_error(e, "non-contiguous alphabet"); cst_model_destroy(m); return CST_ERR_HIP; }
+    *out = m;
+    return CST_OK;
+}
+
+cst_status cst_symbols_to_indices(const cst_model* m, const int32_t* d_symbols, size_t count, int32_t* d_indices, void* stream) {
+    if (!m || !m->d_sorted_symbols || (count > 0 && (!d_symbols || !d_indices))) return CST_ERR_INVALID_ARGUMENT;
+    if (count == 0) return CST_OK;
+    hipLaunchKernelGGL(symbols_to_indices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)m->d_sorted_symbols, (const int32_t*)m->d_sorted_index, m->n_symbols, d_symbols, d_indices, count);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+cst_status cst_indices_to_symbols(const cst_model* m, const int32_t* d_indices, size_t count, int32_t* d_symbols, void* stream) {
+    if (!m || !m->d_symbol_of_index || (count > 0 && (!d_symbols || !d_indices))) return CST_ERR_INVALID_ARGUMENT;
+    if (count == 0) return CST_OK;
+    hipLaunchKernelGGL(indices_to_symbols_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const int32_t*)m->d_symbol_of_index, m->n_symbols, d_indices, d_symbols, count);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 cst_status cst_model_destroy(cst_model* m) {
     if (!m) return CST_OK;
     hipFree(m->d_cdf); hipFree(m->d_enc); hipFree(m->d_dec_cp); hipFree(m->d_dec_idx); hipFree(m->d_bucket);
     hipFree(m->d_cdf16); hipFree(m->d_recip);
+    hipFree(m->d_symbol_of_index); hipFree(m->d_sorted_symbols); hipFree(m->d_sorted_index);
     hipFree(m->d_pt_meta); hipFree(m->d_pt_enc); hipFree(m->d_pt_dec); hipFree(m->d_pt_l1); hipFree(m->d_pt_block_base);
     delete m;
     return CST_OK;

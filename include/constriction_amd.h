@@ -129,6 +129,19 @@ cst_status cst_model_create_gaussian_per_stream(int32_t precision, int32_t min_s
                                                 const double *d_means, const double *d_stds,
                                                 size_t n_streams, void *stream, cst_model **out);
 
+/* A tabulated model over an ARBITRARY alphabet of distinct i32 symbols (NonContiguousCategoricalEncoderModel /
+ * NonContiguousLookupDecoderModel, src/stream/model/categorical/{non_contiguous,lookup_noncontiguous}.rs:429-470, 602-646):
+ * h_symbols[i] is the symbol with left cumulative h_cdf[i].  The model proper works on the indices 0..n-1; the two
+ * kernels below translate (in place if wanted): encode = cst_symbols_to_indices + cst_ans_encode_batch (a symbol that is
+ * not in the alphabet becomes index n, which the coder reports as CST_STREAM_IMPOSSIBLE_SYMBOL), decode =
+ * cst_ans_decode_batch + cst_indices_to_symbols. */
+cst_status cst_model_create_table_noncontiguous(int32_t precision, int32_t n_symbols, const int32_t *h_symbols,
+                                               const uint32_t *h_cdf, cst_model **out);
+cst_status cst_symbols_to_indices(const cst_model *model, const int32_t *d_symbols, size_t count, int32_t *d_indices,
+                                  void *stream);
+cst_status cst_indices_to_symbols(const cst_model *model, const int32_t *d_indices, size_t count, int32_t *d_symbols,
+                                  void *stream);
+
 cst_status cst_model_destroy(cst_model *model);
 
 /* Introspection (tests, and get_cdf for host-side tooling). */

@@ -610,3 +610,36 @@ def test_golden_vectors_through_the_batched_abi(B, O, golden):
                 assert enc.stream(s).tolist() == vec["expect_compressed"], vec["id"]
         done += 1
     assert done >= 3
+
+
+def test_noncontiguous_alphabet(B, O):
+    """NonContiguousCategoricalEncoderModel / NonContiguousLookupDecoderModel (the reference's test:
+    src/stream/model/categorical/lookup_noncontiguous.rs:703-760): symbols 'a','x','c','y' with probabilities 3, 18, 1, 42 of
+    2^6, then a larger alphabet of scattered symbols; words = those of the contiguous coder on the symbols' indices."""
+    for P, symbols, probs in [(6, [ord(ch) for ch in "axcy"], [3, 18, 1, 42]),
+                              (12, [7, -100000, 2**31 - 1, 0, -5, 12345, -(2**31), 99], [1, 1000, 7, 500, 88, 2000, 1, 499])]:
+        cdf = np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+        assert int(cdf[-1]) == 1 << P
+        model = B.Model.from_cdf_noncontiguous(symbols, cdf, P)
+        rng = np.random.default_rng(P)
+        idx = rng.choice(len(symbols), size=(130, 77), p=np.array(probs) / float(1 << P)).astype(np.int32)
+        sym = np.asarray(symbols, dtype=np.int64)[idx].astype(np.int32)
+        if P == 6:
+            sym[0, :9] = [ord(ch) for ch in "axcxcyaac"]                 # the reference test's message
+            idx[0, :9] = ["axcy".index(ch) for ch in "axcxcyaac"]
+        want_words, want_n, _ = O.ans_encode_batch(idx, 0, cdf, P)
+        enc = B.ans_encode(dev(sym), model, (32, 64, P))
+        torch.cuda.synchronize()
+        words, n_words, status = enc.to_numpy()
+        assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+        for s in range(len(sym)):
+            assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+        dec, dst = B.ans_decode(enc, model, sym.shape[1])
+        torch.cuda.synchronize()
+        assert (dst.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+        bad = sym.copy()
+        bad[5, 3] = 424242                                               # not in the alphabet
+        st = B.ans_encode(dev(bad), model, (32, 64, P)).status.cpu().numpy()
+        assert st[5] == 1 and (np.delete(st, 5) == 0).all()
+    with pytest.raises(ValueError):
+        B.Model.from_cdf_noncontiguous([1, 2, 1], np.array([0, 10, 20, 64], dtype=np.uint32), 6)   # duplicate symbol
