@@ -6,6 +6,7 @@ code), so the files are compiled to objects in parallel and only the stale ones 
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -44,9 +45,26 @@ def needs_build() -> bool:
     return _stale(LIB, list(CSRC.glob("*.hip")) + _headers() + [Path(__file__)])
 
 
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(src: Path) -> list:
+    """the files a translation unit really includes (quoted includes, transitively): touching one generated .inc
+    recompiles only the kernels built from it"""
+    seen, todo = {}, [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not f.exists():
+            continue
+        seen[f] = True
+        for name in _INCLUDE.findall(f.read_text()):
+            todo.append((f.parent / name).resolve())
+    return list(seen)
+
+
 def _compile(src: Path, force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
-    if force or _stale(obj, [src, Path(__file__)] + _headers()):
+    if force or _stale(obj, _deps(src) + [Path(__file__)]):
         res = subprocess.run([_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n" + res.stdout + res.stderr)

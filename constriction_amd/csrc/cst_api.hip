@@ -244,7 +244,9 @@ size_t cst_ans_max_words(size_t n, cst_coder_config c) {
 size_t cst_range_max_words(size_t n, cst_coder_config c) {
     if (c.word_bits <= 0) return 0;
     const size_t by_bits = (n * (size_t)c.precision + (size_t)c.word_bits - 1) / (size_t)c.word_bits;
-    return (n < by_bits ? n : by_bits) + 2;
+    const size_t bound = (n < by_bits ? n : by_bits) + 2;
+    const size_t unit = (size_t)(512 / c.word_bits) > 0 ? (size_t)(512 / c.word_bits) : 1;   // words per 64 bytes
+    return (bound + unit - 1) / unit * unit;
 }
 
 cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,

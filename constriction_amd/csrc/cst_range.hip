@@ -4,18 +4,6 @@
 
 namespace cst {
 
-struct RangeEncodeArgs {
-    const int32_t* symbols;
-    size_t n_streams, n_per_stream;
-    const EncEntry* enc;
-    int32_t n_symbols, min_symbol, precision;
-    uint32_t* words;
-    size_t stride_words;
-    uint32_t* n_words;
-    int32_t* status;
-    cst_range_state* rstate;
-    uint32_t flags;
-};
 
 // GLOBAL_TABLE: the encoder entries stay in HBM / L2 (alphabets too large for LDS)
 template <int W, int S, int LAYOUT, bool VEC, int G, bool GLOBAL_TABLE = false>
@@ -133,23 +121,6 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
 
 // ------------------------------------------------------------------------------------------------
 
-struct RangeDecodeArgs {
-    const uint32_t* words;
-    const uint64_t* offsets;
-    size_t stride_words;
-    const uint32_t* n_words;
-    int32_t* symbols;
-    size_t n_streams, n_per_stream;
-    const uint32_t* dec_cp;
-    const uint16_t* dec_idx;
-    const uint32_t* cdf;
-    const uint16_t* bucket;
-    int32_t bucket_bits;
-    int32_t n_symbols, min_symbol, precision;
-    int32_t* status;
-    cst_range_state* rstate;
-    uint32_t flags;
-};
 
 template <int W, int S, int LAYOUT, bool VEC, int MODE, bool LUT_IN_LDS, int G>
 __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeArgs a) {
@@ -324,6 +295,7 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32 && range_encode_fast_usable(a, layout)) return range_encode_fast(a, hs);
     if (cfg.word_bits == 32) return range_encode_ws<32, 64>(a, layout, hs);
     return range_encode_ws<16, 32>(a, layout, hs);
 }

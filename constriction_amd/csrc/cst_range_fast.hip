@@ -1,0 +1,216 @@
+// cst_range_fast.hip -- the hand-scheduled (32,64) range coder kernels (BASELINE config C4), 8 <= P <= 24, stream-major.
+//
+// Encoder: the lazy carry of RangeEncoder::encode_symbol (src/stream/queue.rs:612-705, EncoderSituation :126-142) in its
+// "held word" form.  The reference holds back the words of an Inverted situation until it knows whether a carry
+// reaches them (first + 1, then zeros -- or first, then 0xffffffff): that IS addition with carry on the number the
+// emitted words spell, a carry out of `lower + scale * c` can only happen while words are held back (in the Normal
+// situation lower + range does not wrap), and a word entering an Inverted run is never 0xffffffff.  So a lane keeps the
+// most recent word in a register, adds carries to it and hands it to the ring when the next word is produced; no
+// situation is tracked.  A carry that must travel further than the held word (a run of two or more held words) is
+// handled by RangeEncHeld::carry_back on words in the ring or already in HBM; the asm main loop only flags it and the
+// wave repeats its streams with the C++ step.  scripts/gen_range_encode_loop.py has the instruction-level account.
+#include "cst_range_kernels.hpp"
+
+namespace cst {
+
+struct CumProb { uint32_t c, p; };
+
+struct RangeEncHeld {
+    uint64_t lower, range;
+    uint32_t lw;          // the held word: stream position out.wr, not yet final
+    uint32_t bad;
+    RingWriter<> out;     // out.wr = final words (-1 until the first word exists)
+
+    __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
+        out.init(slab, capacity, wave_ring, lane_);
+        out.wr = 0xffffffffu;
+        lower = 0; range = ~0ull; lw = 0; bad = 0;   // RangeCoderState::default, queue.rs:96-104
+    }
+
+    // + 1 on the number spelled by the final words (the held word overflowed)
+    __device__ __noinline__ void carry_back() {
+        for (int64_t i = (int64_t)(int32_t)out.wr - 1; i >= 0; --i) {
+            const uint32_t pos = (uint32_t)i + out.shift;
+            uint32_t w;
+            if (pos >= out.flushed) {
+                w = *out.slot(pos) + 1u;
+                *out.slot(pos) = w;
+            } else {
+                if ((uint32_t)i >= out.cap) break;                       // never stored: the stream ends as CST_STREAM_CAPACITY
+                __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the lane's own store of this word has landed
+                w = __hip_atomic_load(out.base16 + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                __hip_atomic_store(out.base16 + pos, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (w != 0) break;
+        }
+    }
+
+    __device__ __forceinline__ void step(uint32_t c, uint32_t p, int P) {
+        const uint64_t scale = range >> P;
+        uint64_t nr = scale * p;
+        uint64_t nl = lower + scale * c;
+        if (__builtin_expect(nl < lower, 0)) {
+            if (++lw == 0) carry_back();
+        }
+        const bool renorm = nr < (1ull << 32);
+        out.push(lw, renorm ? 1u : 0u);
+        if (renorm) { lw = (uint32_t)(nl >> 32); nl <<= 32; nr <<= 32; }
+        lower = nl; range = nr;
+    }
+
+    __device__ __forceinline__ void flush() {
+        if ((int32_t)out.wr >= 4) out.flush_chunks();
+    }
+
+    // seal_words / iter_seal (queue.rs:458-523)
+    __device__ __forceinline__ int32_t finish(uint32_t n_symbols, uint32_t& n_words_out) {
+        if (range != ~0ull) {
+            const uint64_t point = lower + 0xffffffffull;
+            if (point < lower) {
+                if (++lw == 0) carry_back();
+            }
+            if ((int32_t)out.wr >= 0) out.push(lw, 1u); else out.wr = 0;
+            out.drain();
+            const uint32_t point_word = (uint32_t)(point >> 32);
+            const uint32_t upper_word = (uint32_t)((lower + range) >> 32);
+            out.append_direct(point_word);
+            if (upper_word == point_word) out.append_direct(0u);
+        } else {
+            out.wr = 0;
+        }
+        n_words_out = out.wr;
+        if (bad >= n_symbols) return CST_STREAM_IMPOSSIBLE_SYMBOL;
+        if (out.wr > out.cap) return CST_STREAM_CAPACITY;
+        return CST_STREAM_OK;
+    }
+};
+
+template <int FLUSHES>
+__device__ __forceinline__ void range_encode_tiles_loop(uint32_t& lo0, uint32_t& lo1, uint32_t& rg0, uint32_t& rg1, uint32_t& lw,
+                                                        uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax, uint32_t& slow,
+                                                        const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
+                                                        uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
+                                                        uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                        uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
+    if constexpr (FLUSHES == 1) {
+#include "cst_range_encode_loop.inc"
+    } else {
+#include "cst_range_encode_loop_2f.inc"
+    }
+}
+
+constexpr size_t kFastRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
+constexpr size_t kFastTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;
+
+template <int FLUSHES>
+__global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
+    CumProb* table = reinterpret_cast<CumProb*>(smem + kFastRingBytes);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kFastRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
+    if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = CumProb{a.enc[i].c, a.enc[i].p};
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t n_full = N / kTileSyms;
+    uint32_t* slab = a.words + (active ? s : 0) * a.stride_words;
+    const uint32_t cap = active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u;
+
+    RangeEncHeld L;
+    L.init(slab, cap, ring, lane);
+    bool done = false;
+    {
+        const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
+        const bool ok = slab_off + 4ull * cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                        (cap & 15u) == 0 && L.out.shift == 0;
+        if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!ok)) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+            uint32_t lo0 = 0, lo1 = 0, rg0 = 0xffffffffu, rg1 = 0xffffffffu, lw = 0, wr = 0xffffffffu, flushed = 0, slow = 0;
+            int32_t smin = a.min_symbol, smax = a.min_symbol;
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            range_encode_tiles_loop<FLUSHES>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, row_addr, tr_addr, L.out.lane_addr, cap,
+                                             (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
+                                             symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            if (__builtin_amdgcn_readfirstlane(slow) == 0) {
+                L.lower = ((uint64_t)lo1 << 32) | lo0; L.range = ((uint64_t)rg1 << 32) | rg0; L.lw = lw;
+                L.out.wr = wr; L.out.flushed = flushed;
+                // a symbol below min_symbol wraps to a huge index
+                L.bad = max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol);
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        // partial waves, odd slabs, and streams whose carry had to travel: tile by tile with the C++ step
+        int32_t r[kTileSyms];
+        for (size_t tb = 0; tb < n_full; ++tb) {
+            tile_fetch<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, r);
+            wave_lds_fence();
+            tile_to_lds<true>(tile, lane, r);
+            wave_lds_fence();
+            const int32_t* my = tile + lane * kTileStride;
+#pragma unroll 8
+            for (int j = 0; j < kTileSyms; ++j) {
+                const CumProb e = table[enc_index(my[j], a.min_symbol, nsym, L.bad)];
+                L.step(e.c, e.p, P);
+                if ((j & 7) == 7) L.flush();
+            }
+        }
+    }
+    const int32_t* row = a.symbols + (active ? s : 0) * N;
+    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        const CumProb e = table[enc_index(active ? row[t] : 0, a.min_symbol, nsym, L.bad)];
+        L.step(e.c, e.p, P);
+        L.flush();
+    }
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout) {
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    return layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 24 && !(a.flags & CST_FLAG_RAW_STATE) &&
+           a.n_per_stream >= (size_t)kTileSyms && a.n_per_stream % 4 == 0 && a.n_per_stream < (1u << 24) &&
+           (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.words) & 63) == 0 &&
+           a.stride_words % 16 == 0 && a.n_streams * a.stride_words * 4 < 0x100000000ull &&
+           kFastRingBytes + table_bytes + 2 * kFastTileBytes <= 160 * 1024;
+}
+
+cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs) {
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    const size_t lds = kFastRingBytes + table_bytes + 2 * kFastTileBytes;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 16 ? go(range_encode_fast_kernel<1>) : go(range_encode_fast_kernel<2>);
+}
+
+} // namespace cst

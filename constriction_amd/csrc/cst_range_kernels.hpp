@@ -10,6 +10,41 @@
 
 namespace cst {
 
+struct RangeEncodeArgs {
+    const int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    const EncEntry* enc;
+    int32_t n_symbols, min_symbol, precision;
+    uint32_t* words;
+    size_t stride_words;
+    uint32_t* n_words;
+    int32_t* status;
+    cst_range_state* rstate;
+    uint32_t flags;
+};
+
+struct RangeDecodeArgs {
+    const uint32_t* words;
+    const uint64_t* offsets;
+    size_t stride_words;
+    const uint32_t* n_words;
+    int32_t* symbols;
+    size_t n_streams, n_per_stream;
+    const uint32_t* dec_cp;
+    const uint16_t* dec_idx;
+    const uint32_t* cdf;
+    const uint16_t* bucket;
+    int32_t bucket_bits;
+    int32_t n_symbols, min_symbol, precision;
+    int32_t* status;
+    cst_range_state* rstate;
+    uint32_t flags;
+};
+
+// cst_range_fast.hip: the hand-scheduled (32,64) kernels; `*_usable` says whether a call qualifies
+bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
+cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs);
+
 // Forward-reading counterpart of RingReader (queue semantics).
 struct RingReaderFwd {
     uint32_t pos;          // next stream index to read

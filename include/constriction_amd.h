@@ -92,7 +92,8 @@ const char *cst_last_hip_error(void);
  * (At most one word per symbol: src/stream/stack.rs:1035-1040; final state: stack.rs:891-895.) */
 size_t cst_ans_max_words(size_t n_symbols, cst_coder_config cfg);
 
-/* Same bound for the range coder: one word per symbol (queue.rs:671-702) + seal words (queue.rs:498-522). */
+/* Same bound for the range coder: one word per symbol (queue.rs:671-702) + seal words (queue.rs:498-522), rounded
+ * up to 64-byte units in the same way (the hand-scheduled encoder needs 64-byte aligned slabs). */
 size_t cst_range_max_words(size_t n_symbols, cst_coder_config cfg);
 
 /* ------------------------------------------------------------------------------------------

@@ -58,6 +58,16 @@ def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
         assert text == (ROOT / "constriction_amd" / "csrc" / f"cst_{name}_loop.inc").read_text()
 
 
+def test_range_loops_are_in_sync(tmp_path, monkeypatch):
+    """the range encoder's main loops (one / two word groups per tile)"""
+    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+    mod = _load("gen_range_encode_loop")
+    mod.OUT = {1: tmp_path / "r1.inc", 2: tmp_path / "r2.inc"}
+    mod.main()
+    assert (tmp_path / "r1.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_encode_loop.inc").read_text()
+    assert (tmp_path / "r2.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_encode_loop_2f.inc").read_text()
+
+
 def test_wait_bookkeeping_rejects_unreachable_counts():
     """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
     asmgen = _load("asmgen")

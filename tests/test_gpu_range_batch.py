@@ -122,3 +122,60 @@ def test_range_alphabet_too_large_for_lds(B, O):
     dec, dstatus = B.range_decode(enc, model, 200)
     torch.cuda.synchronize()
     assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+def _straddling_streams(cdf, P, n_streams, n_per, seed, stay):
+    """Symbols chosen by following the encoder's interval (queue.rs:612-705 in Python integers): while the interval
+    straddles a word boundary, the symbol whose bin contains the boundary is taken with probability `stay` -- Inverted
+    situations of many held-back words (queue.rs:126-142), far beyond what model-distributed data ever produces --
+    and another one otherwise (resolution with or without a carry)."""
+    rng = np.random.default_rng(seed)
+    n = len(cdf) - 1
+    top = 1 << 64
+    out = np.zeros((n_streams, n_per), dtype=np.int32)
+    longest = 0
+    for s in range(n_streams):
+        lower, rng_ = 0, top - 1
+        held = 0
+        for t in range(n_per):
+            scale = rng_ >> P
+            pick = None
+            if lower + rng_ >= top and rng.random() < stay:
+                for i in range(n):
+                    if lower + scale * int(cdf[i]) < top <= lower + scale * int(cdf[i + 1]):
+                        pick = i
+            if pick is None:
+                pick = int(rng.integers(0, n))
+            out[s, t] = pick
+            lower = lower + scale * int(cdf[pick])
+            rng_ = scale * int(cdf[pick + 1] - cdf[pick])
+            if lower >= top:
+                lower -= top
+            if lower + rng_ < top:
+                held = 0
+            if rng_ < (1 << 32):
+                lower = (lower << 32) % top
+                rng_ <<= 32
+                held = held + 1 if lower + rng_ >= top else 0
+                longest = max(longest, held)
+    return out, longest
+
+
+@pytest.mark.parametrize("P", [12, 24])
+def test_range_long_inverted_runs(B, O, P):
+    """Carries that travel through many held-back words, some of which have already left the LDS ring for HBM."""
+    probs = np.array([1, 3, 1 << (P - 2), (1 << P) - 8 - (1 << (P - 2)), 2, 2], dtype=np.int64)
+    cdf = np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+    model = B.Model.from_cdf(cdf, 0, P)
+    sym, longest = _straddling_streams(cdf, P, 192, 640, 5 + P, 0.995)
+    assert longest >= 24          # (the fixture does what it is for: runs longer than a 64-byte group)
+    sym[100:] = np.where(np.random.default_rng(1).random(sym[100:].shape) < 0.5, sym[100:], 3)
+    want_words, want_n, _ = O.rc_encode_batch(sym, 0, cdf, P)
+    enc = B.range_encode(dev(sym), model, (32, 64, P))
+    dec, st = B.range_decode(enc, model, sym.shape[1])
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(len(sym)):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    assert np.array_equal(dec.cpu().numpy(), sym)
