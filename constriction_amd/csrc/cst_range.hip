@@ -318,6 +318,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, hs);
     if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
     return range_decode_ws<16, 32>(a, layout, hs);
 }

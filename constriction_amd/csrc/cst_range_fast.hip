@@ -190,6 +190,166 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
     a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder, P <= 12 (scripts/gen_range_decode_loop.py): state x = point - lower, f64 quotient estimate checked through
+// the symbol it selects.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRdSlots = kDecRingSlots, kRdAhead = kDecAhead;
+constexpr size_t kRdRingBytes = (size_t)(kBlock / kWave) * kRdSlots * kWave * 4;
+
+template <bool ENDS>
+__device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& x1, uint32_t& rg0, uint32_t& rg1, uint32_t& pos,
+                                                        uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
+                                                        uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
+                                                        uint32_t lut_addr, uint32_t qmax, uint32_t P, uint32_t ring_mask,
+                                                        const void* words_base, uint64_t store_base, uint32_t goff_stride, uint32_t lens,
+                                                        uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
+                                                        uint32_t goff0) {
+    if constexpr (ENDS) {
+#include "cst_range_decode_loop_ends.inc"
+    } else {
+#include "cst_range_decode_loop.inc"
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    const size_t n_q = (size_t)1 << P;
+    constexpr size_t kTileWords = (size_t)kWave * kTileStride;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kRdSlots * kWave);
+    // LDS image as for the ANS decoder (stage_tile_tables): cp[q] = c | p << 16 at +0, the decoded symbol at +16384
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem + kRdRingBytes);
+    int32_t* symt = reinterpret_cast<int32_t*>(smem + kRdRingBytes + kTileSymOffset);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRdRingBytes + kTileLutBytes) + wave_in_block * kTileWords;
+    int32_t* tile_b = tile + (kBlock / kWave) * kTileWords;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRdRingBytes + kTileLutBytes + 2 * (size_t)(kBlock / kWave) * kTileWords * 4) +
+                     wave_in_block * (4 * kWave) + lane;
+    if ((lds_addr(ring) & (uint32_t)(kRdSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {
+        lut[q] = a.dec_cp[q];
+        symt[q] = a.min_symbol + (int32_t)a.dec_idx[q];
+    }
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const size_t n_full = N / kTileSyms;
+    const uint32_t* my_words = a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0);
+    const uint32_t my_len = active ? a.n_words[s] : 0u;
+
+    RangeDecLane<32, 64, kRdSlots, kRdAhead> L;
+    L.init(my_words, my_len, ring, lane);
+    L.in.prime();
+    wave_lds_fence();
+
+    // the exact step (queue.rs:968-1033); returns the symbol
+    auto step = [&]() -> int32_t {
+        const uint32_t q = L.peek_quantile(P);
+        const uint32_t cp = lut[q];
+        const int32_t sym = symt[q];
+        const uint32_t w = L.in.peek();
+        L.in.pos += L.advance(cp & 0xffffu, cp >> 16, P, w, L.in.pos < L.in.len) ? 1u : 0u;
+        return sym;
+    };
+
+    size_t tb = 0;
+    {
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)my_len + 8) < 0x80000000ull;
+        if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statements keep their own book from here
+            const uint32_t shift = L.in.shift;
+            uint32_t x0 = (uint32_t)L.point, x1 = (uint32_t)(L.point >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
+            uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
+            const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            uint32_t row_cur = lds_addr(tile + lane * kTileStride), row_prev = lds_addr(tile_b + lane * kTileStride);
+            uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
+            uint32_t tiles = (uint32_t)n_full, ginc = 0, bad = 0, bad2 = 0;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint32_t goff_stride = (uint32_t)(8 * N * 4);
+            const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
+            range_decode_tiles_loop<false>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lds_addr(lut),
+                                           qmax, (uint32_t)P, ring_mask, words_base, store_base, goff_stride, lens, endr,
+                                           lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+            tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
+            if (tiles > 0) {
+                const uint32_t done = (uint32_t)n_full - tiles;
+                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
+                range_decode_tiles_loop<true>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
+                                              lds_addr(lut), qmax, (uint32_t)P, ring_mask, words_base, base2, goff_stride, lens,
+                                              endr, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+            }
+            if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
+                // the last tile is still in LDS (buffer A if it has an even index)
+                wave_lds_fence();
+                tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                wave_lds_fence();
+                L.lower = 0; L.point = ((uint64_t)x1 << 32) | x0; L.range = ((uint64_t)rg1 << 32) | rg0;
+                L.in.pos = pos - shift; L.in.hi_issued = hi_issued;
+                tb = n_full;
+            } else {
+                // a quantile estimate failed its check, or the data are invalid: the wave's streams again, exactly
+                L.init(my_words, my_len, ring, lane);
+                L.in.prime();
+                wave_lds_fence();
+            }
+        }
+    }
+    int32_t* my = tile + lane * kTileStride;
+    for (; tb < n_full; ++tb) {
+#pragma unroll 1
+        for (int j = 0; j < kTileSyms / 4; ++j) {
+            int4 v;
+            v.x = step(); v.y = step(); v.z = step(); v.w = step();
+            *reinterpret_cast<int4*>(my + 4 * j) = v;
+            if (j & 1) L.in.advance_window();
+        }
+        wave_lds_fence();
+        tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        wave_lds_fence();
+    }
+    int32_t* row = a.symbols + (active ? s : 0) * N;
+    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        const int32_t sym = step();
+        if (active) row[t] = sym;
+        L.in.advance_window();
+    }
+    if (!active) return;
+    a.status[s] = L.status;
+}
+
+static size_t range_decode_fast_lds(int) {
+    return kRdRingBytes + kTileLutBytes + 2 * kFastTileBytes + (size_t)(kBlock / kWave) * 4 * kWave * 4;
+}
+
+bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout) {
+    return layout == CST_LAYOUT_STREAM_MAJOR && a.dec_cp && a.dec_idx && a.precision >= 8 && a.precision <= 12 &&
+           !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 &&
+           range_decode_fast_lds(a.precision) <= 160 * 1024;
+}
+
+cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs) {
+    const size_t lds = range_decode_fast_lds(a.precision);
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(range_decode_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(range_decode_fast_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
     return layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 24 && !(a.flags & CST_FLAG_RAW_STATE) &&

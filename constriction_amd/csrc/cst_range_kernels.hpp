@@ -44,8 +44,11 @@ struct RangeDecodeArgs {
 // cst_range_fast.hip: the hand-scheduled (32,64) kernels; `*_usable` says whether a call qualifies
 bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
 cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs);
+bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout);
+cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs);
 
 // Forward-reading counterpart of RingReader (queue semantics).
+template <int SLOTS = kRingSlots, int AHEAD = kAhead>
 struct RingReaderFwd {
     uint32_t pos;          // next stream index to read
     uint32_t len;          // words in the stream
@@ -57,7 +60,7 @@ struct RingReaderFwd {
     uint4 pend[kMaxChunksPerPoint];
     int32_t pend_pos[kMaxChunksPerPoint];
 
-    __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (kRingSlots - 1)) * kWave + lane); }
+    __device__ __forceinline__ uint32_t* slot(uint32_t p) const { return ring + ((p & (SLOTS - 1)) * kWave + lane); }
 
     __device__ __forceinline__ void init(const uint32_t* in, uint32_t n, uint32_t* wave_ring, int lane_) {
         // pointer arithmetic (not an integer round trip) so that the accesses stay global_*, not flat_*
@@ -70,8 +73,13 @@ struct RingReaderFwd {
 
     __device__ __forceinline__ void prime() {
         hi_issued = shift & ~3u;
+        fill_blocking();
+    }
+
+    // everything the window wants, now (no chunk may be pending)
+    __device__ __forceinline__ void fill_blocking() {
         const uint32_t end = len + shift;
-        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+        const uint32_t want_hi = min(pos + shift + (uint32_t)AHEAD, end);
         while (hi_issued < want_hi) {
             const uint4 v = *reinterpret_cast<const uint4*>(base16 + hi_issued);
             *slot(hi_issued + 0) = v.x; *slot(hi_issued + 1) = v.y; *slot(hi_issued + 2) = v.z; *slot(hi_issued + 3) = v.w;
@@ -88,7 +96,7 @@ struct RingReaderFwd {
             }
         }
         const uint32_t end = len + shift;
-        const uint32_t want_hi = min(pos + shift + (uint32_t)kAhead, end);
+        const uint32_t want_hi = min(pos + shift + (uint32_t)AHEAD, end);
 #pragma unroll
         for (int k = 0; k < kMaxChunksPerPoint; ++k) {
             if (hi_issued < want_hi) {
@@ -203,12 +211,12 @@ struct RangeEncLane {
     }
 };
 
-template <int W, int S>
+template <int W, int S, int SLOTS = kRingSlots, int AHEAD = kAhead>
 struct RangeDecLane {
     using st_t = typename StateT<S>::type;
     st_t lower, range, point;
     int32_t status;
-    RingReaderFwd in;
+    RingReaderFwd<SLOTS, AHEAD> in;
 
     // from_compressed + read_point (queue.rs:776-790, 847-868)
     __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Generates constriction_amd/csrc/cst_range_decode_loop{,_ends}.inc: the hand-scheduled gfx950 main loop of the (32,64)
+range decoder, P <= 12 (quantile table in LDS) -- one asm statement that decodes full 32-symbol tiles of a wave's 64
+streams.  Skeleton as gen_decode_loop.py (ANS): compressed words are requested in 16-byte chunks at the top of a tile
+and land in the lane's LDS ring at its end, the decoded symbols go to the lane's row of an LDS tile, and the PREVIOUS
+tile is streamed to HBM (transposed reads, 8 rows x 128 B per store) in the shadow of the steps' table lookups.
+
+The step (RangeDecoder::decode_symbol, queue.rs:968-1033) on the state  x = point - lower  (the decoder never needs
+`lower` or `point` on their own: x' = x - scale * c, and a renormalisation is x' = x' << 32 | word):
+    scale = range >> P;  quantile = x / scale;  (sym, c, p) = table[quantile];  rem = x - scale * c;  nr = scale * p
+    renorm <=> nr < 2^32:  range = nr << 32, x = rem << 32 | next word;  else  range = nr, x = rem
+The division is an ESTIMATE: x * (1 / scale) in f64 from v_rcp_f64 (measured: only 2^-24.4 accurate,
+scripts/microbench/rcp_f64_error.hip) + one Newton step, PLUS 2^-30, truncated: never below the true quotient and
+above it only if the true quotient is within 2^-29 below an integer.  (The bias must go this way: an encoder's sealed
+point sits at the very bottom of the final interval, so x / scale of a stream's last symbols is routinely an exact
+integer -- the first quantile of its bin.)  Instead of correcting the quotient the step checks the SYMBOL it led to:
+rem = x - scale * c < nr  <=>  the quantile's bin is the right one (a bin too far gives a negative, i.e. huge, rem; a
+quantile of 2^P or more -- invalid data, queue.rs:989-993 -- fails the check too, through the clamped lookup).  A
+failed check raises a sticky flag and the caller repeats the wave's streams with the exact C++ step; on valid data
+that takes a 2^-29 * n_symbols / 2^P coincidence per symbol.
+
+Two variants: the main one assumes every lane has its next 13 words (it leaves the loop at the top of a tile as soon
+as one has not); `_ends` also handles the end of the compressed data (reads past it deliver zeros, queue.rs:1020-1024)
+and decodes what the main one left.
+
+Run:  python scripts/gen_range_decode_loop.py   (rewrites the .inc files; they are checked in)
+"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from asmgen import Asm  # noqa: E402
+
+CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
+OUT = {False: CSRC / "cst_range_decode_loop.inc", True: CSRC / "cst_range_decode_loop_ends.inc"}
+
+K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
+AHEAD = 24            # kDecAhead
+
+
+def tup(base, n=2):
+    return f"v[{base}:{base + n - 1}]"
+
+
+X0, X1, RG0, RG1, SC0, SC1 = (f"v{r}" for r in range(120, 126))
+PC0, PC1, NR0, NR1, REM0, REM1 = (f"v{r}" for r in range(126, 132))
+PC_T, NR_T, REM_T = tup(126), tup(128), tup(130)
+FS, FS0, FX, FX0, RC, EST, C2P32, DELTA, NE = (tup(132 + 2 * i) for i in range(9))      # f64 pairs v132 .. v149
+Q, LA, C, PR, WD, RA, CP, POS, HI = (f"v{r}" for r in range(150, 159))
+SYM = [f"v{160 + k}" for k in range(8)]                                                  # two quads
+XT = tup(172, 4)
+PEND = [(tup(176 + 4 * k, 4), [f"v{176 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
+LAND = [f"v{188 + k}" for k in range(K_CHUNKS)]
+WANT, TMP, TADDR, TOFF = "v191", "v192", "v193", "v194"
+GOFF = [f"v{196 + k}" for k in range(8)]
+CLOBBERS = [f"v{r}" for r in range(120, 204)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "memory"]
+SD, SAVE, BAD, CHK, HV, REN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
+
+
+def quotient_lookup(a, nxt_sym):
+    """from (x, range) to the requests for the next step's table entry and symbol"""
+    a.i(f"v_alignbit_b32 {SC0}, {RG1}, {RG0}, %[P]", "scale = range >> P")
+    a.i(f"v_lshrrev_b32 {SC1}, %[P], {RG1}")
+    a.i(f"v_cvt_f64_u32 {FS}, {SC1}")
+    a.i(f"v_cvt_f64_u32 {FS0}, {SC0}")
+    a.i(f"v_cvt_f64_u32 {FX}, {X1}")
+    a.i(f"v_cvt_f64_u32 {FX0}, {X0}")
+    a.i(f"v_fma_f64 {FS}, {FS}, {C2P32}, {FS0}", "scale as f64 (exact below 2^53)")
+    a.i(f"v_rcp_f64 {RC}, {FS}", "2^-24 accurate ...")
+    a.i(f"v_fma_f64 {FX}, {FX}, {C2P32}, {FX0}", "x as f64  (also the wait state gfx950 needs between a transcendental and its reader)")
+    a.i(f"v_fma_f64 {NE}, -{FS}, {RC}, 1.0")
+    a.i(f"v_fma_f64 {RC}, {RC}, {NE}, {RC}", "... one Newton step: 2^-48")
+    a.i(f"v_fma_f64 {EST}, {FX}, {RC}, {DELTA}", "x / scale + 2^-30: never below the true quotient")
+    a.i(f"v_cvt_u32_f64 {Q}, {EST}")
+    a.i(f"v_min_u32 {Q}, %[qmax], {Q}", "(a quantile >= 2^P is invalid data: the clamped lookup fails the check)")
+    a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
+    a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next c | p << 16  <- end of the serial chain (a random 64-bit read costs ~35 cycles more)")
+    a.ds(f"ds_read_b32 {nxt_sym}, {LA} offset:16384", "sym")
+
+
+def word_request(a):
+    a.i(f"v_lshlrev_b32 {RA}, 8, {POS}")
+    a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+    a.ds(f"ds_read_b32 {WD}, {RA}", "w", "the word a renormalisation would take")
+
+
+def gen(ends):
+    a = Asm()
+    a.i(f"v_mov_b32 {X0}, %[x0]"); a.i(f"v_mov_b32 {X1}, %[x1]"); a.i(f"v_mov_b32 {RG0}, %[rg0]"); a.i(f"v_mov_b32 {RG1}, %[rg1]")
+    a.i(f"v_mov_b32 {POS}, %[pos]"); a.i(f"v_mov_b32 {HI}, %[hi_issued]")
+    a.i("v_mov_b32 v144, 0"); a.i("v_mov_b32 v145, 0x41f00000", "2^32")
+    a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, 0x3e100000", "+2^-30")
+    a.i(f"v_mov_b32 {GOFF[0]}, %[goff0]")
+    for k in range(1, 8):
+        a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+    a.i(f"s_mov_b64 {BAD}, 0")
+    a.i("s_mov_b64 s[80:81], %[gbase]", "where the PREVIOUS tile goes (first tile of all: onto itself, rewritten one tile later)")
+    a.i("v_readfirstlane_b32 s82, %[tiles]", "tiles left")
+    a.i("v_readfirstlane_b32 s83, %[ginc]", "0 in front of the very first tile, then 128 B")
+    # the first lookup: every tile's last step issues the next tile's
+    quotient_lookup(a, SYM[0])
+    a.i("1:", None)
+    if not ends:
+        a.i(f"v_add_u32 {TMP}, 13, {POS}")
+        a.i(f"v_cmp_gt_u32 vcc, {TMP}, %[lens]", "a lane that may run out of words inside this tile?")
+        a.i("s_cbranch_vccnz 2f", "-> the rest goes to the statement that knows about the end of the data")
+    word_request(a)       # (after the previous tile's chunks have landed)
+
+    # ---- window: request the chunks the NEXT tile may need (landed at the end of this iteration) ----
+    a.i(f"v_add_u32 {WANT}, {AHEAD}, {POS}")
+    a.i(f"v_min_u32 {WANT}, {WANT}, %[endr]", "want_hi = min(pos + kDecAhead, end rounded up to a chunk)")
+    for k in range(K_CHUNKS):
+        a.i(f"v_cmp_lt_u32 vcc, {HI}, {WANT}", f"chunk slot {k}: needed?")
+        a.i(f"v_lshlrev_b32 {TADDR}, 8, {HI}")
+        a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+        a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+        a.i(f"v_lshl_add_u32 {TOFF}, {HI}, 2, %[woff]")
+        a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+        a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+        a.i(f"s_mov_b64 exec, {SAVE}")
+        a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+        a.i(f"v_add_u32 {HI}, {HI}, {TMP}")
+
+    for j in range(32):
+        quad, pos = divmod(j, 4)
+        nxt = j + 1
+        sym_reg = SYM[(nxt // 4 % 2) * 4 + nxt % 4]        # (step 31: symbol 0 of the next tile)
+        if "cp" in a.lds:                                  # (step 0 of a later tile: the wait at the end of the previous one covered it)
+            a.wait_lds("cp", f"---- step {j}: (c, p) is back")
+        else:
+            a.i(f"; ---- step {j}")
+        a.i(f"v_and_b32 {C}, 0xffff, {CP}")
+        a.i(f"v_lshrrev_b32 {PR}, 16, {CP}")
+        a.i(f"v_mad_u64_u32 {PC_T}, {SD}, {SC0}, {C}, 0", "scale * c")
+        a.i(f"v_mad_u64_u32 {NR_T}, {SD}, {SC0}, {PR}, 0", "nr = scale * p")
+        a.i(f"v_mad_u32_u24 {PC1}, {SC1}, {C}, {PC1}")
+        a.i(f"v_mad_u32_u24 {NR1}, {SC1}, {PR}, {NR1}")
+        a.i(f"v_sub_co_u32 {REM0}, vcc, {X0}, {PC0}", "rem = x - scale * c")
+        a.i(f"v_subb_co_u32 {REM1}, vcc, {X1}, {PC1}, vcc")
+        a.i(f"v_cmp_eq_u32 vcc, 0, {NR1}", "renorm <=> nr < 2^32")
+        if ends:
+            a.i(f"v_cmp_lt_u32 {HV}, {POS}, %[lens]", "is there a word left?")
+        a.i(f"v_cmp_ge_u64 {CHK}, {REM_T}, {NR_T}", "rem >= nr: not this quantile's bin")
+        a.wait_lds_all("candidate word (and everything older) is back")
+        if ends:
+            a.i(f"v_cndmask_b32_e64 {WD}, 0, {WD}, {HV}", "past the end: zeros (queue.rs:1020-1024)")
+            a.i(f"s_and_b64 {REN}, vcc, {HV}")
+        a.i(f"v_cndmask_b32_e32 {RG1}, {NR1}, {NR0}, vcc", "range = renorm ? nr << 32 : nr")
+        a.i(f"v_cndmask_b32_e64 {RG0}, {NR0}, 0, vcc")
+        a.i(f"v_cndmask_b32_e32 {X1}, {REM1}, {REM0}, vcc", "x = renorm ? rem << 32 | word : rem")
+        a.i(f"v_cndmask_b32_e32 {X0}, {REM0}, {WD}, vcc")
+        quotient_lookup(a, sym_reg)
+        a.i(f"s_or_b64 {BAD}, {BAD}, {CHK}", "(sticky: the caller repeats the streams with the exact step)")
+        a.i(f"v_addc_co_u32_e64 {POS}, {SD}, 0, {POS}, {REN if ends else 'vcc'}", "a renormalisation took the word")
+        if j < 31:
+            word_request(a)
+        if pos == 1:
+            a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
+        if pos == 2:
+            # XT was read in step pos 1 and is covered by this step's lgkmcnt(0)
+            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] nt", f"store{quad}")
+        if pos == 3:
+            base = 160 + (quad % 2) * 4
+            a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
+
+    a.wait_lds_all("---- end of tile")
+    a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
+    for k in range(K_CHUNKS):
+        r = PEND[k][1]
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+    a.i("v_swap_b32 %[rowcur], %[rowprev]")
+    a.i("v_swap_b32 %[trcur], %[trprev]")
+    a.i("s_add_u32 s80, s80, s83")
+    a.i("s_addc_u32 s81, s81, 0")
+    a.i("s_movk_i32 s83, 0x80")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.wait_lds_all("landed chunks visible to the next tile")
+    a.i("s_cbranch_scc1 1b")
+    a.i("2:", None)
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all()
+    a.i(f"v_mov_b32 %[x0], {X0}"); a.i(f"v_mov_b32 %[x1], {X1}"); a.i(f"v_mov_b32 %[rg0], {RG0}"); a.i(f"v_mov_b32 %[rg1], {RG1}")
+    a.i(f"v_mov_b32 %[pos], {POS}"); a.i(f"v_mov_b32 %[hi_issued], {HI}")
+    a.i("v_mov_b32 %[tiles], s82"); a.i("v_mov_b32 %[ginc], s83")
+    a.i("s_or_b32 s88, s88, s89"); a.i("v_mov_b32 %[bad], s88")
+    return a
+
+
+def main():
+    for ends in (False, True):
+        a = gen(ends)
+        header = ["// GENERATED by scripts/gen_range_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
+                  "// Main loop of the hand-scheduled (32,64) range decoder" + (", end-of-data aware" if ends else "") + ": see cst_range_fast.hip."]
+        ops = ['    : [x0] "+v"(x0), [x1] "+v"(x1), [rg0] "+v"(rg0), [rg1] "+v"(rg1), [pos] "+v"(pos), [hi_issued] "+v"(hi_issued),',
+               '      [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev), [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev), [tiles] "+v"(tiles), [ginc] "+v"(ginc),',
+               '      [bad] "=v"(bad)',
+               '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base),',
+               '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
+               '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)',
+               "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
+        OUT[ends].write_text(a.render(header, ops))
+        print(f"wrote {OUT[ends]} ({a.n_instr()} instructions incl. loop control)")
+
+
+if __name__ == "__main__":
+    main()

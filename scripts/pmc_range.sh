@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage (GPU box, repo root): scripts/pmc_range.sh <tag> [ans]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
+# usage (GPU box, repo root): scripts/pmc_range.sh <tag> [range|ans|range_dec|ans_dec]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
 set -u
 tag=${1:-rng}; which=${2:-range}
+case $which in *_dec) pat=decode;; *) pat=encode;; esac
 export TMPDIR=/tmp
 R=$PWD
 cat > /tmp/rrun.py <<PY
@@ -13,10 +14,17 @@ P = 12
 m = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
 cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
 sym = bench.synth_symbols_device(0xC0FFEE, 0, 65536, 4096, -50, cdf, P)
-f = B.range_encode if "$which" == "range" else B.ans_encode
+which = "$which"
+f = B.range_encode if which.startswith("range") else B.ans_encode
 enc = f(sym, m, (32, 64, P))
-for _ in range(3):
-    f(sym, m, (32, 64, P), out=enc)
+if which.endswith("_dec"):
+    g = B.range_decode if which.startswith("range") else B.ans_decode
+    out = torch.empty_like(sym)
+    for _ in range(3):
+        g(enc, m, 4096, out=out)
+else:
+    for _ in range(3):
+        f(sym, m, (32, 64, P), out=enc)
 torch.cuda.synchronize()
 PY
 d=gpurun_out/${tag}
@@ -30,5 +38,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $R/$d/p$i -o pmc -- python /tmp/rrun.py > /dev/null 2> $d/err$i.log
   find $d/p$i -mindepth 2 -name "*.csv" -exec mv {} $d/p$i/ \;
-  for f in $d/p$i/*counter_collection.csv; do [ -f "$f" ] && python scripts/pmc_summary.py $f | grep -A12 "encode" ; done
+  for f in $d/p$i/*counter_collection.csv; do [ -f "$f" ] && python scripts/pmc_summary.py $f | grep -A12 "$pat" ; done
 done

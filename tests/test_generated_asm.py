@@ -68,6 +68,16 @@ def test_range_loops_are_in_sync(tmp_path, monkeypatch):
     assert (tmp_path / "r2.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_encode_loop_2f.inc").read_text()
 
 
+def test_range_decode_loops_are_in_sync(tmp_path, monkeypatch):
+    """the range decoder's main loops (plain / end-of-data aware)"""
+    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+    mod = _load("gen_range_decode_loop")
+    mod.OUT = {False: tmp_path / "d.inc", True: tmp_path / "e.inc"}
+    mod.main()
+    assert (tmp_path / "d.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_decode_loop.inc").read_text()
+    assert (tmp_path / "e.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_decode_loop_ends.inc").read_text()
+
+
 def test_wait_bookkeeping_rejects_unreachable_counts():
     """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
     asmgen = _load("asmgen")
