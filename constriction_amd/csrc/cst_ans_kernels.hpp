@@ -76,8 +76,8 @@ __device__ __forceinline__ uint32_t ans_encode_step(typename StateT<S>::type& st
     return emit ? 1u : 0u;
 }
 
-// (W,S) = (32,64), 8 <= P <= 24, written on 32-bit halves to keep the dependent chain short (a lone
-// wave issues one VALU op per 4 cycles and a dependent one only every 8):
+// (W,S) = (32,64), 8 <= P <= 24, written on 32-bit halves (what the compiler makes of the 64-bit form is twice as
+// many instructions, and a lone wave pays ~4 cycles for every one of them):
 //   new_state = st + c + q*(2^P - p)  with q = floor(st / p); the estimate q_est in {q-1, q} is fixed up by
 //   adding k = 2^P - p once more when the estimated remainder is >= p.  `p_shl` = p << (32-P), `k` = 2^P - p.
 __device__ __forceinline__ uint32_t ans_encode_step_32x64(uint32_t& lo, uint32_t& hi, const EncEntry e, uint32_t p_shl,

@@ -69,9 +69,8 @@ def step(a, e0, e1, m0, m1):
         A = emit ? state >> 32 : state;  q_est = mulhi64(A, m) in {q - 1, q};  r_est = A - q_est * p  (< 2p < 2^13: its low 16 bits
         follow from the low 24 bits of q_est alone, one v_mul_u32_u24);  fix <=> r_est >= p
         state' = (q << P) + c + r = A + q_est * (2^P - p) + (fix ? c + 2^P - p : c)
-    22 VALU instructions + the ring write.  What bounds a lone wave is the DEPENDENT chain (a dependent VALU instruction
-    issues every ~8 cycles, an independent one every ~4.7: scripts/microbench/occupancy.hip): emit -> A -> mul_hi -> U -> T ->
-    carry -> Q -> r -> fix -> select -> add -> carry, 13 levels; A + q_est * k runs beside the remainder test."""
+    22 VALU instructions + the ring write.  A lone wave executes one instruction after another, dependent or not
+    (4.0 cycles of issue + 0.3-1 of operand fetch each: DESIGN.md 3.8), so what counts is the NUMBER of instructions."""
     a.i(f"v_cmp_ge_u32_sdwa vcc, %[hi], {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
     a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
     a.i(f"v_lshlrev_b32 {RA}, 8, %[wr]")
