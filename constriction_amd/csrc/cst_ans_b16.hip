@@ -1,0 +1,143 @@
+// cst_ans_b16.hip -- the hand-scheduled (32,64) ANS decoder for 12 < P <= 24 (DefaultAnsCoder's PRECISION = 24),
+// shared table of at most 256 symbols, stream-major.  At this precision there is no table of 2^P quantiles: the lookup
+// (lookup_contiguous.rs:564-605, contiguous.rs:628-665) is ONE 16-byte LDS read of a bucket entry (DecLut::b16,
+// cst_common.hpp); scripts/gen_decode_loop_b16.py has the instruction-level account.  The step itself is
+// AnsCoder::decode_symbol, stack.rs:1084-1097.
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+__device__ __forceinline__ void ans_decode_b16_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur,
+                                                          uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr,
+                                                          uint32_t cdf_addr, uint32_t mask, uint32_t P, uint32_t bucket_shift,
+                                                          int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
+                                                          uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
+                                                          uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0) {
+#include "cst_decode_loop_b16.inc"
+}
+
+constexpr size_t kB16RingBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4;
+constexpr size_t kB16TileWords = (size_t)kWave * kTileStride;
+
+static size_t b16_table_bytes(int n_symbols, int bucket_bits) {
+    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits);
+}
+static size_t b16_lds_bytes(int n_symbols, int bucket_bits) {
+    return kB16RingBytes + b16_table_bytes(n_symbols, bucket_bits) + 2 * (size_t)(kBlock / kWave) * kB16TileWords * 4 + kTileDumpBytes;
+}
+
+// LDS layout: [word rings, 8 KiB per wave][cdf][bucket entries][symbol tiles A][symbol tiles B][dump rows]
+__global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    DecLut lut{};
+    const uint32_t* cdf = a.cdf;
+    const uint16_t* bucket = a.bucket;
+    const size_t lds_off = stage_decoder_tables<kDecBucket, true>(smem + kB16RingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+                                                                  a.n_symbols, lut, cdf, bucket);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kDecRingSlots * kWave);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kB16RingBytes + lds_off) + wave_in_block * kB16TileWords;
+    int32_t* tile_b = tile + (kBlock / kWave) * kB16TileWords;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kB16RingBytes + lds_off + 2 * (size_t)(kBlock / kWave) * kB16TileWords * 4) +
+                     wave_in_block * (4 * kWave) + lane;
+    if ((lds_addr(ring) & (uint32_t)(kDecRingSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const size_t n_full = N / kTileSyms;
+    const int bucket_shift = P - a.bucket_bits;
+
+    DecLane<32, 64, kDecRingSlots, kDecAhead> L;
+    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    L.read_initial_state();
+    L.in.prime();
+    wave_lds_fence();
+
+    auto next_symbol = [&]() -> int32_t {
+        return a.min_symbol + (int32_t)ans_decode_step<32, 64, kDecBucket, true>(L, lut, cdf, bucket, bucket_shift, a.n_symbols, P);
+    };
+    // one tile with the compiler-scheduled step into `dst` (the lane's tile row); the window is topped up every half tile
+    auto tile_cxx = [&](int32_t* dst) {
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                int4 v;
+                v.x = next_symbol(); v.y = next_symbol(); v.z = next_symbol(); v.w = next_symbol();
+                *reinterpret_cast<int4*>(dst + 16 * h + 4 * j) = v;
+            }
+            L.in.refill_blocking();
+            wave_lds_fence();
+        }
+    };
+
+    int32_t* my = tile + lane * kTileStride;
+    size_t tb = 0;
+    {
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
+        if (s0 + kWave <= a.n_streams && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+            tile_cxx(my);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            // current = B (tile 1), previous = A (tile 0)
+            uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+            uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
+            ans_decode_b16_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
+                                      (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
+                                      words_base, store_base, (uint32_t)(8 * N * 4), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
+                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+            L.state = ((uint64_t)hi << 32) | lo;
+            // the last tile is still in LDS (buffer A if it has an even index)
+            wave_lds_fence();
+            tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+            wave_lds_fence();
+            tb = n_full;
+        }
+    }
+    for (; tb < n_full; ++tb) {
+        tile_cxx(my);
+        tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        wave_lds_fence();
+    }
+    int32_t* row = a.symbols + (active ? s : 0) * N;
+    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        const int32_t sym = next_symbol();
+        if (active) row[t] = sym;
+        L.in.refill_blocking();
+        wave_lds_fence();
+    }
+    if (!active) return;
+    a.status[s] = L.status;
+}
+
+bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    return cfg.word_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision > 12 && a.precision <= 24 &&
+           bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && b16_lds_bytes(a.n_symbols, a.bucket_bits) <= 160 * 1024;
+}
+
+cst_status ans_decode_b16(const AnsDecodeArgs& a, hipStream_t hs) {
+    const size_t lds = b16_lds_bytes(a.n_symbols, a.bucket_bits);
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ans_decode_b16_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+} // namespace cst

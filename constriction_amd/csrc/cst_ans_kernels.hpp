@@ -745,6 +745,23 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
         c = e & 0xffffu; p = e >> 16;
         idx = lut.sym ? (uint32_t)(lut.sym[q] - lut.min_symbol) : (uint32_t)lut.idx[q];
     } else {
+        if (lut.b16) {
+            const uint4 e = lut.b16[q >> bucket_shift];
+            const uint32_t c0 = e.x & 0xffffffu, i0 = e.x >> 24;
+            const uint32_t k = (q >= e.y ? 1u : 0u) + (q >= e.z ? 1u : 0u);
+            c = k == 0 ? c0 : (k == 1 ? e.y : e.z);
+            uint32_t nxt = k == 0 ? e.y : (k == 1 ? e.z : e.w);
+            idx = i0 + k;
+            if (__any(q >= e.w)) {          // more than three symbols begin inside this bucket below q (the far tails): walk
+                if (q >= e.w) {
+                    idx = i0 + 3u;
+                    while (cdf[idx + 1u] <= q) ++idx;     // (cdf[n] = 2^P lies above every quantile)
+                    c = cdf[idx]; nxt = cdf[idx + 1u];
+                }
+            }
+            p = nxt - c;
+            return;
+        }
         // bucket[q >> shift] = first index whose bin reaches into the bucket.  Probe the next three boundaries at once
         // (cdf[n] = 2^P lies above every quantile, so clamped probes never count) and advance by the number of
         // boundaries at or below q; a wave-uniform loop repeats only while some lane had to advance by all three.
@@ -834,11 +851,22 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
             uint32_t* c = reinterpret_cast<uint32_t*>(smem);
             for (int i = threadIdx.x; i <= n_symbols; i += blockDim.x) c[i] = g_cdf[i];
             lds_off = (((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15;
-            uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
             const int nb = (1 << bucket_bits);
-            for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];
-            lds_off += ((size_t)nb * 2 + 15) & ~(size_t)15;
-            cdf = c; bucket = b;
+            if (bucket16_usable(n_symbols, P)) {
+                uint4* b = reinterpret_cast<uint4*>(smem + lds_off);
+                const uint32_t n = (uint32_t)n_symbols;
+                for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+                    const uint32_t i0 = g_bucket[i];
+                    b[i] = make_uint4(g_cdf[i0] | (i0 << 24), g_cdf[min(i0 + 1u, n)], g_cdf[min(i0 + 2u, n)], g_cdf[min(i0 + 3u, n)]);
+                }
+                lds_off += (size_t)nb * 16;
+                lut.b16 = b; cdf = c;
+            } else {
+                uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
+                for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];
+                lds_off += ((size_t)nb * 2 + 15) & ~(size_t)15;
+                cdf = c; bucket = b;
+            }
         }
     }
     return lds_off;
@@ -1020,5 +1048,8 @@ bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layou
 bool small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_small(const AnsEncodeArgs& a, hipStream_t hs);
 cst_status ans_decode_small(const AnsDecodeArgs& a, hipStream_t hs);
+// the hand-scheduled decoder for 12 < P <= 24 (cst_ans_b16.hip)
+bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
+cst_status ans_decode_b16(const AnsDecodeArgs& a, hipStream_t hs);
 
 } // namespace cst

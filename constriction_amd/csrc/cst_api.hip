@@ -109,7 +109,8 @@ static cst_status decode_dispatch(const AnsDecodeArgs& a, cst_layout layout, hip
     const size_t lds_budget = kMaxLds - kTileBytesPerBlock - 1024;
     if (a.dec_cp && ((size_t)6 << P) <= lds_budget)
         return decode_dispatch2<W, S, kDecLutCP, true>(a, layout, ((size_t)6 << P), hs);
-    const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
+    const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) +
+                              (bucket16_usable(a.n_symbols, P) ? ((size_t)16 << a.bucket_bits) : ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15));
     if (bucket_lds <= lds_budget) return decode_dispatch2<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
     if (a.dec_cp) return decode_dispatch2<W, S, kDecLutCP, false>(a, layout, 0, hs);
     return decode_dispatch2<W, S, kDecBucket, false>(a, layout, 0, hs);
@@ -301,6 +302,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     a.status = d_status; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
+    if (b16_decode_usable(a, cfg, layout)) return ans_decode_b16(a, hs);                        // 12 < P <= 24
     if (cfg.word_bits == 32) return decode_dispatch<32, 64>(a, layout, hs);
     return decode_dispatch<16, 32>(a, layout, hs);
 }

@@ -267,7 +267,8 @@ static cst_status range_decode_ws(const RangeDecodeArgs& a, cst_layout layout, h
     const int P = a.precision;
     const size_t lds_budget = kMaxLds - kPerBlockLds - 1024;
     if (a.dec_cp && ((size_t)6 << P) <= lds_budget) return range_decode_m<W, S, kDecLutCP, true>(a, layout, ((size_t)6 << P), hs);
-    const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15);
+    const size_t bucket_lds = ((((size_t)a.n_symbols + 1) * 4 + 15) & ~(size_t)15) +
+                              (bucket16_usable(a.n_symbols, P) ? ((size_t)16 << a.bucket_bits) : ((((size_t)2 << a.bucket_bits) + 15) & ~(size_t)15));
     if (bucket_lds <= lds_budget) return range_decode_m<W, S, kDecBucket, true>(a, layout, bucket_lds, hs);
     if (a.dec_cp) return range_decode_m<W, S, kDecLutCP, false>(a, layout, 0, hs);
     return range_decode_m<W, S, kDecBucket, false>(a, layout, 0, hs);

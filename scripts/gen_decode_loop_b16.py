@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Generates constriction_amd/csrc/cst_decode_loop_b16.inc: the hand-scheduled gfx950 main loop of the (32,64) ANS
+decoder for 12 < P <= 24 (DefaultAnsCoder's PRECISION = 24), alphabets of at most 256 symbols.
+
+There is no table of 2^P quantiles at this precision.  The lookup (lookup_contiguous.rs:564-605 / contiguous.rs:628-665)
+is ONE 16-byte LDS read of a bucket entry (cst_common.hpp, DecLut::b16), bucket = quantile >> (P - 11):
+    { cdf[i0] | i0 << 24, cdf[i0+1], cdf[i0+2], cdf[i0+3] }      i0 = the symbol that holds the bucket's first quantile
+    k = (q >= e1) + (q >= e2);  c = (c0, e1, e2)[k];  next = (e1, e2, e3)[k];  p = next - c;  symbol index = i0 + k
+and a quantile >= e3 (more than three symbols begin in its bucket below it: the far tails of a distribution, 2^-11 of
+the probability mass per such bucket) takes a wave-uniform walk over the cdf table (an out-of-line block at the end of
+the statement, entered through one s_cbranch per step).
+
+Everything else is gen_decode_loop.py's skeleton (the step of stack.rs:1084-1097 on 32-bit halves, the word ring, the
+symbol tile streamed out one tile later), except that a tile of up to 24 words is handled as two half tiles of at most
+12: the window requests / landings of gen_decode_loop.py run at steps 0 and 16, so the ring stays at 32 slots and the
+workgroup's LDS image at 142 KiB.
+
+Run:  python scripts/gen_decode_loop_b16.py   (rewrites the .inc; the .inc is checked in)
+"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from asmgen import Asm  # noqa: E402
+
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc"
+
+K_CHUNKS = 3          # window chunks requested per HALF tile (16 symbols * 24 bits = 12 words = 3 chunks)
+AHEAD_M1 = 23         # kDecAhead - 1
+
+
+def tup(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+def gen():
+    a = Asm()
+    N0, N1, D = "v120", "v121", "v122"          # v[120:121] = N, v[122:123] = [q - c, 0]
+    PR, T0, T1, LA, WD, RA, R1, Q = "v124", "v125", "v126", "v127", "v129", "v131", "v132", "v133"
+    SYM = [f"v{134 + k}" for k in range(8)]      # two quads
+    X = tup(144)
+    E0, E1, E2, E3 = (f"v{148 + k}" for k in range(4))
+    E_T = tup(148)
+    C, NXT, IDX, TMPA = "v152", "v153", "v154", "v155"
+    PAIR0, PAIR1, PAIR_T = "v156", "v157", tup(156, 2)
+    PEND = [(tup(160 + 4 * k), [f"v{160 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
+    LAND = [f"v{172 + k}" for k in range(K_CHUNKS)]
+    WANT, TMP, TADDR, TOFF = "v175", "v176", "v177", "v178"
+    GOFF = [f"v{180 + k}" for k in range(8)]
+    clobbers = [f"v{r}" for r in range(120, 188)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
+    SD, SAVE, V1, V2 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]"
+    RET, XSAVE, FLAGGED = "s[70:71]", "s[72:73]", "s[74:75]"
+
+    def window_requests():
+        a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
+        a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kDecAhead, 0)")
+        for k in range(K_CHUNKS):
+            a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
+            a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+            a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
+            a.i(f"v_lshlrev_b32 {TADDR}, 8, %[lo_issued]")
+            a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+            a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+            a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
+            a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+            a.i(f"s_mov_b64 exec, {SAVE}")
+
+    def window_landing(comment):
+        a.wait_lds_all(comment)
+        a.wait_vm(f"chunk{K_CHUNKS - 1}", "(this half tile's stores are younger than the chunk loads)")
+        for k in range(K_CHUNKS):
+            r = PEND[k][1]
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+
+    def lookup():
+        a.i(f"v_and_b32 {Q}, %[mask], %[lo]", "quantile")
+        a.i(f"v_lshrrev_b32 {LA}, %[bsh], {Q}")
+        a.i(f"v_lshl_add_u32 {LA}, {LA}, 4, %[lut]")
+        a.ds(f"ds_read_b128 {E_T}, {LA}", "e", "bucket entry  <- end of the serial chain")
+
+    def word_request():
+        a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+        a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+        a.ds(f"ds_read_b32 {WD}, {RA}", "w")
+
+    a.i("v_mov_b32 v123, 0")
+    a.i(f"v_mov_b32 {GOFF[0]}, %[goff0]")
+    for k in range(1, 8):
+        a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+    a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
+    a.i("s_mov_b32 s82, %[ntiles]")
+    a.i("1:", None)
+
+    for j in range(32):
+        quad, pos = divmod(j, 4)
+        if j in (0, 16):
+            # ---- window: request the chunks the next half tile may need, then this half tile's first lookup ----
+            window_requests()
+            lookup()
+            word_request()
+            a.i(f"v_min_u32 {R1}, 1, %[rd]")
+            a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+            a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        a.wait_lds("e", f"---- step {j}: the bucket entry is back")
+        a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
+        a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
+        a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
+        a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
+        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+        a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
+        a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
+        a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
+        a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
+        a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare)")
+        a.i(f"2{j:02d}:", None)
+        a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
+        a.i(f"v_sub_u32 {D}, {Q}, {C}", "q - c")
+        a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
+        a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+        a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
+        a.wait_lds_all("candidate word (and everything older) is back")
+        a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
+        last_of_half = j in (15, 31)
+        if not last_of_half:
+            lookup()
+        a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
+        if not last_of_half:
+            word_request()
+        a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
+        if pos == 1:
+            a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
+        a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
+        if not last_of_half:
+            a.i(f"v_min_u32 {R1}, 1, %[rd]")
+            a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+            a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        if pos == 2:
+            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {X}, s[80:81] nt", f"store{quad}")
+        if pos == 3:
+            base = 134 + (quad % 2) * 4
+            a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
+        if j == 15:
+            window_landing("---- middle of the tile: the first half's chunks land")
+            a.wait_lds_all("landed chunks visible")
+
+    window_landing("---- end of tile")
+    a.i("v_swap_b32 %[rowcur], %[rowprev]")
+    a.i("v_swap_b32 %[trcur], %[trprev]")
+    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_addc_u32 s81, s81, 0")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.wait_lds_all("landed chunks visible to the next tile")
+    a.i("s_cbranch_scc1 1b")
+    a.i("s_branch 3f")
+
+    # ---- out of line: the walk (entered with the lanes to walk in vcc; Q, E0 as in the step) ----
+    for j in range(32):
+        a.i(f"1{j:02d}:", None)
+        a.i(f"s_call_b64 {RET}, 4f")
+        a.i(f"s_branch 2{j:02d}b")
+    a.i("4:", None)
+    a.i(f"s_mov_b64 {XSAVE}, exec")
+    a.i(f"s_mov_b64 {FLAGGED}, vcc")
+    a.i("s_mov_b64 exec, vcc")
+    a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+    a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+    a.i("5:", None)
+    a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+    a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
+    a.i("s_waitcnt lgkmcnt(0)")
+    a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
+    a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
+    a.i("s_and_b64 exec, exec, vcc")
+    a.i("s_cbranch_execnz 5b")
+    a.i(f"s_mov_b64 exec, {FLAGGED}")
+    a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+    a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
+    a.i("s_waitcnt lgkmcnt(0)")
+    a.i(f"v_mov_b32 {C}, {PAIR0}")
+    a.i(f"v_mov_b32 {NXT}, {PAIR1}")
+    a.i(f"s_mov_b64 exec, {XSAVE}")
+    a.i(f"s_setpc_b64 {RET}")
+    a.i("3:", None)
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    return a, clobbers
+
+
+def main():
+    a, clobbers = gen()
+    header = ["// GENERATED by scripts/gen_decode_loop_b16.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Main loop of the hand-scheduled (32,64) ANS decoder for 12 < P <= 24 (bucket entries): see cst_ans_b16.hip."]
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
+           '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
+           '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "s"(min_symbol),',
+           '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)',
+           "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
+    OUT.write_text(a.render(header, ops))
+    print(f"wrote {OUT} ({a.n_instr()} instructions per iteration incl. loop control)")
+
+
+if __name__ == "__main__":
+    main()

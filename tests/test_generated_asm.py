@@ -78,6 +78,13 @@ def test_range_decode_loops_are_in_sync(tmp_path, monkeypatch):
     assert (tmp_path / "e.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_decode_loop_ends.inc").read_text()
 
 
+def test_b16_decode_loop_is_in_sync(tmp_path, monkeypatch):
+    """the ANS decoder's main loop for 12 < P <= 24 (bucket entries)"""
+    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+    text = _regenerate(_load("gen_decode_loop_b16"), tmp_path, "cst_decode_loop_b16.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
+
+
 def test_wait_bookkeeping_rejects_unreachable_counts():
     """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
     asmgen = _load("asmgen")

@@ -643,3 +643,42 @@ def test_noncontiguous_alphabet(B, O):
         assert st[5] == 1 and (np.delete(st, 5) == 0).all()
     with pytest.raises(ValueError):
         B.Model.from_cdf_noncontiguous([1, 2, 1], np.array([0, 10, 20, 64], dtype=np.uint32), 6)   # duplicate symbol
+
+
+@pytest.mark.parametrize("P", [13, 16, 20, 24])
+def test_bucket_entry_decoder_walks_the_tails(B, O, P):
+    """12 < P <= 24 (cst_ans_b16.hip): one 16-byte bucket entry resolves three symbols, the rest is a walk over the cdf
+    table.  256 symbols, 100 + 155 of them with probability 1 / 2^P crowded into the first and last bucket, and data drawn
+    UNIFORMLY over the alphabet so that most quantiles lie beyond their bucket's third symbol; full and partial waves,
+    slabs and the packed layout, tails of every length mod 4."""
+    n = 256
+    probs = np.ones(n, dtype=np.int64)
+    probs[100] = (1 << P) - (n - 1) - 500
+    probs[37] += 300; probs[200] += 200
+    cdf = np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+    assert int(cdf[-1]) == 1 << P
+    model = B.Model.from_cdf(cdf, -7, P)
+    rng = np.random.default_rng(P)
+    for n_streams, n_per in ((192, 640), (70, 96), (64, 64), (3, 100)):
+        sym = (rng.integers(0, n, (n_streams, n_per)) - 7).astype(np.int32)
+        sym[:, ::3] = 93                                       # (and the bulk symbol in between)
+        want_words, want_n, _ = O.ans_encode_batch(sym, -7, cdf, P)
+        enc = B.ans_encode(dev(sym), model, (32, 64, P))
+        torch.cuda.synchronize()
+        words, n_words, status = enc.to_numpy()
+        assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+        for s in range(n_streams):
+            assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+        dec, st = B.ans_decode(enc, model, n_per)
+        torch.cuda.synchronize()
+        assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+        packed, offsets = B.compact(enc)
+        dec2, st2 = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P))
+        torch.cuda.synchronize()
+        assert (st2.cpu().numpy() == 0).all() and np.array_equal(dec2.cpu().numpy(), sym)
+        # decoding more symbols than were encoded reads past the data exactly like the reference (stack.rs:1090-1096)
+        want_more, want_st = O.ans_decode_batch(want_words, want_n, n_per + 36, -7, cdf, P)
+        more, st3 = B.ans_decode(enc, model, n_per + 36)
+        torch.cuda.synchronize()
+        assert st3.cpu().numpy().tolist() == want_st.tolist()
+        assert np.array_equal(more.cpu().numpy(), want_more)
