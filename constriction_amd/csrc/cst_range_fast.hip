@@ -197,21 +197,36 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
 constexpr int kRdSlots = kDecRingSlots, kRdAhead = kDecAhead;
 constexpr size_t kRdRingBytes = (size_t)(kBlock / kWave) * kRdSlots * kWave * 4;
 
-template <bool ENDS>
+template <bool ENDS, bool B16>
 __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& x1, uint32_t& rg0, uint32_t& rg1, uint32_t& pos,
                                                         uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
                                                         uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
                                                         uint32_t lut_addr, uint32_t qmax, uint32_t P, uint32_t ring_mask,
-                                                        const void* words_base, uint64_t store_base, uint32_t goff_stride, uint32_t lens,
-                                                        uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
-                                                        uint32_t goff0) {
-    if constexpr (ENDS) {
-#include "cst_range_decode_loop_ends.inc"
+                                                        const void* words_base, uint32_t delta_hi, uint64_t store_base, uint32_t goff_stride,
+                                                        uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                        uint32_t words_off, uint32_t goff0, uint32_t bucket_shift, uint32_t cdf_addr,
+                                                        int32_t min_symbol) {
+    if constexpr (B16) {
+        if constexpr (ENDS) {
+#include "cst_range_decode_loop_b16_ends.inc"
+        } else {
+#include "cst_range_decode_loop_b16.inc"
+        }
     } else {
+        if constexpr (ENDS) {
+#include "cst_range_decode_loop_ends.inc"
+        } else {
 #include "cst_range_decode_loop.inc"
+        }
     }
 }
 
+static size_t b16_tables_bytes(int n_symbols, int bucket_bits) {
+    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits);
+}
+
+// B16: 12 < P <= 24, at most 256 symbols: the lookup is one 16-byte bucket entry (DecLut::b16) instead of the quantile table
+template <bool B16>
 __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -220,18 +235,28 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     const size_t n_q = (size_t)1 << P;
     constexpr size_t kTileWords = (size_t)kWave * kTileStride;
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kRdSlots * kWave);
-    // LDS image as for the ANS decoder (stage_tile_tables): cp[q] = c | p << 16 at +0, the decoded symbol at +16384
+    // LDS image: P <= 12 as for the ANS decoder (stage_tile_tables): cp[q] = c | p << 16 at +0, the decoded symbol at +16384;
+    // B16: cdf, then the bucket entries (stage_decoder_tables)
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem + kRdRingBytes);
     int32_t* symt = reinterpret_cast<int32_t*>(smem + kRdRingBytes + kTileSymOffset);
-    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRdRingBytes + kTileLutBytes) + wave_in_block * kTileWords;
+    DecLut blut{};
+    const uint32_t* cdf = a.cdf;
+    const uint16_t* bucket = a.bucket;
+    size_t table_bytes = kTileLutBytes;
+    if constexpr (B16) {
+        table_bytes = stage_decoder_tables<kDecBucket, true>(smem + kRdRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+                                                             a.n_symbols, blut, cdf, bucket);
+    } else {
+        for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {
+            lut[q] = a.dec_cp[q];
+            symt[q] = a.min_symbol + (int32_t)a.dec_idx[q];
+        }
+    }
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kRdRingBytes + table_bytes) + wave_in_block * kTileWords;
     int32_t* tile_b = tile + (kBlock / kWave) * kTileWords;
-    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRdRingBytes + kTileLutBytes + 2 * (size_t)(kBlock / kWave) * kTileWords * 4) +
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRdRingBytes + table_bytes + 2 * (size_t)(kBlock / kWave) * kTileWords * 4) +
                      wave_in_block * (4 * kWave) + lane;
     if ((lds_addr(ring) & (uint32_t)(kRdSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
-    for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {
-        lut[q] = a.dec_cp[q];
-        symt[q] = a.min_symbol + (int32_t)a.dec_idx[q];
-    }
     __syncthreads();
 
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -241,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     const bool active = s < a.n_streams;
     const size_t N = a.n_per_stream;
     const size_t n_full = N / kTileSyms;
+    const int bucket_shift = P - a.bucket_bits;
     const uint32_t* my_words = a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0);
     const uint32_t my_len = active ? a.n_words[s] : 0u;
 
@@ -252,10 +278,19 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     // the exact step (queue.rs:968-1033); returns the symbol
     auto step = [&]() -> int32_t {
         const uint32_t q = L.peek_quantile(P);
-        const uint32_t cp = lut[q];
-        const int32_t sym = symt[q];
+        uint32_t c, p;
+        int32_t sym;
+        if constexpr (B16) {
+            uint32_t idx;
+            lookup_quantile<kDecBucket>(q, blut, cdf, bucket, bucket_shift, a.n_symbols, idx, c, p);
+            sym = a.min_symbol + (int32_t)idx;
+        } else {
+            const uint32_t cp = lut[q];
+            c = cp & 0xffffu; p = cp >> 16;
+            sym = symt[q];
+        }
         const uint32_t w = L.in.peek();
-        L.in.pos += L.advance(cp & 0xffffu, cp >> 16, P, w, L.in.pos < L.in.len) ? 1u : 0u;
+        L.in.pos += L.advance(c, p, P, w, L.in.pos < L.in.len) ? 1u : 0u;
         return sym;
     };
 
@@ -280,16 +315,22 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
             const uint32_t goff_stride = (uint32_t)(8 * N * 4);
             const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
-            range_decode_tiles_loop<false>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lds_addr(lut),
-                                           qmax, (uint32_t)P, ring_mask, words_base, store_base, goff_stride, lens, endr,
-                                           lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+            // the estimate's error is 2^(P - 48.5): the bias on top of it (high word of the f64)
+            const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22
+            const uint32_t lut_addr = B16 ? lds_addr(blut.b16) : lds_addr(lut);
+            const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
+            range_decode_tiles_loop<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
+                                                qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
+                                                lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, (uint32_t)bucket_shift, cdf_addr,
+                                                a.min_symbol);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
                 const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
-                range_decode_tiles_loop<true>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
-                                              lds_addr(lut), qmax, (uint32_t)P, ring_mask, words_base, base2, goff_stride, lens,
-                                              endr, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+                range_decode_tiles_loop<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
+                                                   lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
+                                                   lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, (uint32_t)bucket_shift,
+                                                   cdf_addr, a.min_symbol);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
                 // the last tile is still in LDS (buffer A if it has an even index)
@@ -314,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             int4 v;
             v.x = step(); v.y = step(); v.z = step(); v.w = step();
             *reinterpret_cast<int4*>(my + 4 * j) = v;
-            if (j & 1) L.in.advance_window();
+            L.in.advance_window();
         }
         wave_lds_fence();
         tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
@@ -330,24 +371,29 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     a.status[s] = L.status;
 }
 
-static size_t range_decode_fast_lds(int) {
-    return kRdRingBytes + kTileLutBytes + 2 * kFastTileBytes + (size_t)(kBlock / kWave) * 4 * kWave * 4;
+static size_t range_decode_fast_lds(const RangeDecodeArgs& a) {
+    const size_t tables = a.precision <= 12 ? (size_t)kTileLutBytes : b16_tables_bytes(a.n_symbols, a.bucket_bits);
+    return kRdRingBytes + tables + 2 * kFastTileBytes + (size_t)(kBlock / kWave) * 4 * kWave * 4;
 }
 
 bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout) {
-    return layout == CST_LAYOUT_STREAM_MAJOR && a.dec_cp && a.dec_idx && a.precision >= 8 && a.precision <= 12 &&
-           !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 &&
-           range_decode_fast_lds(a.precision) <= 160 * 1024;
+    const bool table = a.precision >= 8 && a.precision <= 12 && a.dec_cp && a.dec_idx;
+    const bool entries = a.precision > 12 && a.precision <= 24 && bucket16_usable(a.n_symbols, a.precision) && a.cdf && a.bucket;
+    return layout == CST_LAYOUT_STREAM_MAJOR && (table || entries) && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && range_decode_fast_lds(a) <= 160 * 1024;
 }
 
 cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs) {
-    const size_t lds = range_decode_fast_lds(a.precision);
+    const size_t lds = range_decode_fast_lds(a);
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(range_decode_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(range_decode_fast_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
-    CST_HIP_TRY(hipGetLastError());
-    return CST_OK;
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 12 ? go(range_decode_fast_kernel<false>) : go(range_decode_fast_kernel<true>);
 }
 
 bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout) {

@@ -32,7 +32,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
-OUT = {False: CSRC / "cst_range_decode_loop.inc", True: CSRC / "cst_range_decode_loop_ends.inc"}
+OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
+       (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD = 24            # kDecAhead
@@ -53,8 +54,12 @@ PEND = [(tup(176 + 4 * k, 4), [f"v{176 + 4 * k + j}" for j in range(4)]) for k i
 LAND = [f"v{188 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v191", "v192", "v193", "v194"
 GOFF = [f"v{196 + k}" for k in range(8)]
-CLOBBERS = [f"v{r}" for r in range(120, 204)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "memory"]
+E0, E1, E2, E3, NXT, IDX, TMPA = (f"v{r}" for r in (204, 205, 206, 207, 208, 209, 210))        # bucket-entry variant
+E_T, PAIR_T, PAIR0, PAIR1 = tup(204, 4), tup(212), "v212", "v213"
+CLOBBERS = [f"v{r}" for r in range(120, 214)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
 SD, SAVE, BAD, CHK, HV, REN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
+RET, XSAVE, FLAGGED, V1, V2 = "s[70:71]", "s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]"    # (s96..s101 are flat_scratch / xnack_mask)
+B16 = False           # True: 12 < P <= 24, the lookup is one 16-byte bucket entry (DecLut::b16) instead of the table of 2^P quantiles
 
 
 def quotient_lookup(a, nxt_sym):
@@ -73,6 +78,11 @@ def quotient_lookup(a, nxt_sym):
     a.i(f"v_fma_f64 {EST}, {FX}, {RC}, {DELTA}", "x / scale + 2^-30: never below the true quotient")
     a.i(f"v_cvt_u32_f64 {Q}, {EST}")
     a.i(f"v_min_u32 {Q}, %[qmax], {Q}", "(a quantile >= 2^P is invalid data: the clamped lookup fails the check)")
+    if B16:
+        a.i(f"v_lshrrev_b32 {LA}, %[bsh], {Q}")
+        a.i(f"v_lshl_add_u32 {LA}, {LA}, 4, %[lut]")
+        a.ds(f"ds_read_b128 {E_T}, {LA}", "cp", "next bucket entry  <- end of the serial chain")
+        return
     a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
     a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next c | p << 16  <- end of the serial chain (a random 64-bit read costs ~35 cycles more)")
     a.ds(f"ds_read_b32 {nxt_sym}, {LA} offset:16384", "sym")
@@ -86,10 +96,35 @@ def word_request(a):
 
 def gen(ends):
     a = Asm()
+    halves = (0, 16) if B16 else (0,)       # where a window of K_CHUNKS chunks is requested (it lands before the next one)
+
+    def window_requests():
+        a.i(f"v_add_u32 {WANT}, {AHEAD}, {POS}")
+        a.i(f"v_min_u32 {WANT}, {WANT}, %[endr]", "want_hi = min(pos + kDecAhead, end rounded up to a chunk)")
+        for k in range(K_CHUNKS):
+            a.i(f"v_cmp_lt_u32 vcc, {HI}, {WANT}", f"chunk slot {k}: needed?")
+            a.i(f"v_lshlrev_b32 {TADDR}, 8, {HI}")
+            a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+            a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+            a.i(f"v_lshl_add_u32 {TOFF}, {HI}, 2, %[woff]")
+            a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+            a.i(f"s_mov_b64 exec, {SAVE}")
+            a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+            a.i(f"v_add_u32 {HI}, {HI}, {TMP}")
+
+    def window_landing(comment):
+        a.wait_lds_all(comment)
+        a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than the stores since")
+        for k in range(K_CHUNKS):
+            r = PEND[k][1]
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+
     a.i(f"v_mov_b32 {X0}, %[x0]"); a.i(f"v_mov_b32 {X1}, %[x1]"); a.i(f"v_mov_b32 {RG0}, %[rg0]"); a.i(f"v_mov_b32 {RG1}, %[rg1]")
     a.i(f"v_mov_b32 {POS}, %[pos]"); a.i(f"v_mov_b32 {HI}, %[hi_issued]")
     a.i("v_mov_b32 v144, 0"); a.i("v_mov_b32 v145, 0x41f00000", "2^32")
-    a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, 0x3e100000", "+2^-30")
+    a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, %[dhi]", "+2^-30 (P <= 16) or +2^-22: above the estimate's error of 2^(P - 48.5)")
     a.i(f"v_mov_b32 {GOFF[0]}, %[goff0]")
     for k in range(1, 8):
         a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
@@ -101,36 +136,39 @@ def gen(ends):
     quotient_lookup(a, SYM[0])
     a.i("1:", None)
     if not ends:
-        a.i(f"v_add_u32 {TMP}, 13, {POS}")
+        a.i(f"v_add_u32 {TMP}, {25 if B16 else 13}, {POS}")
         a.i(f"v_cmp_gt_u32 vcc, {TMP}, %[lens]", "a lane that may run out of words inside this tile?")
         a.i("s_cbranch_vccnz 2f", "-> the rest goes to the statement that knows about the end of the data")
-    word_request(a)       # (after the previous tile's chunks have landed)
-
-    # ---- window: request the chunks the NEXT tile may need (landed at the end of this iteration) ----
-    a.i(f"v_add_u32 {WANT}, {AHEAD}, {POS}")
-    a.i(f"v_min_u32 {WANT}, {WANT}, %[endr]", "want_hi = min(pos + kDecAhead, end rounded up to a chunk)")
-    for k in range(K_CHUNKS):
-        a.i(f"v_cmp_lt_u32 vcc, {HI}, {WANT}", f"chunk slot {k}: needed?")
-        a.i(f"v_lshlrev_b32 {TADDR}, 8, {HI}")
-        a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
-        a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
-        a.i(f"v_lshl_add_u32 {TOFF}, {HI}, 2, %[woff]")
-        a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
-        a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
-        a.i(f"s_mov_b64 exec, {SAVE}")
-        a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
-        a.i(f"v_add_u32 {HI}, {HI}, {TMP}")
 
     for j in range(32):
         quad, pos = divmod(j, 4)
         nxt = j + 1
         sym_reg = SYM[(nxt // 4 % 2) * 4 + nxt % 4]        # (step 31: symbol 0 of the next tile)
-        if "cp" in a.lds:                                  # (step 0 of a later tile: the wait at the end of the previous one covered it)
-            a.wait_lds("cp", f"---- step {j}: (c, p) is back")
+        if j in halves:
+            word_request(a)       # (after the previous window's chunks have landed)
+            window_requests()
+        if "cp" in a.lds:                                  # (right after a landing: its wait covered the entry)
+            a.wait_lds("cp", f"---- step {j}: the table entry is back")
         else:
             a.i(f"; ---- step {j}")
-        a.i(f"v_and_b32 {C}, 0xffff, {CP}")
-        a.i(f"v_lshrrev_b32 {PR}, 16, {CP}")
+        if B16:
+            a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
+            a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
+            a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
+            a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
+            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+            a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
+            a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
+            a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
+            a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
+            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
+            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
+            a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare)")
+            a.i(f"2{j:02d}:", None)
+            a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
+        else:
+            a.i(f"v_and_b32 {C}, 0xffff, {CP}")
+            a.i(f"v_lshrrev_b32 {PR}, 16, {CP}")
         a.i(f"v_mad_u64_u32 {PC_T}, {SD}, {SC0}, {C}, 0", "scale * c")
         a.i(f"v_mad_u64_u32 {NR_T}, {SD}, {SC0}, {PR}, 0", "nr = scale * p")
         a.i(f"v_mad_u32_u24 {PC1}, {SC1}, {C}, {PC1}")
@@ -152,8 +190,10 @@ def gen(ends):
         quotient_lookup(a, sym_reg)
         a.i(f"s_or_b64 {BAD}, {BAD}, {CHK}", "(sticky: the caller repeats the streams with the exact step)")
         a.i(f"v_addc_co_u32_e64 {POS}, {SD}, 0, {POS}, {REN if ends else 'vcc'}", "a renormalisation took the word")
-        if j < 31:
+        if (j + 1) % 32 not in halves:
             word_request(a)
+        if B16:
+            a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
         if pos == 1:
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
@@ -162,13 +202,11 @@ def gen(ends):
         if pos == 3:
             base = 160 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
+        if (j + 1) % 32 in halves and j != 31:
+            window_landing("---- middle of the tile: the first half's chunks land")
+            a.wait_lds_all("landed chunks visible")
 
-    a.wait_lds_all("---- end of tile")
-    a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
-    for k in range(K_CHUNKS):
-        r = PEND[k][1]
-        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
-        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+    window_landing("---- end of tile")
     a.i("v_swap_b32 %[rowcur], %[rowprev]")
     a.i("v_swap_b32 %[trcur], %[trprev]")
     a.i("s_add_u32 s80, s80, s83")
@@ -185,23 +223,58 @@ def gen(ends):
     a.i(f"v_mov_b32 %[pos], {POS}"); a.i(f"v_mov_b32 %[hi_issued], {HI}")
     a.i("v_mov_b32 %[tiles], s82"); a.i("v_mov_b32 %[ginc], s83")
     a.i("s_or_b32 s88, s88, s89"); a.i("v_mov_b32 %[bad], s88")
+    if B16:
+        a.i("s_branch 3f")
+        # ---- out of line: the walk (entered with the lanes to walk in vcc; Q, E0 as in the step) ----
+        for j in range(32):
+            a.i(f"1{j:02d}:", None)
+            a.i(f"s_call_b64 {RET}, 4f")
+            a.i(f"s_branch 2{j:02d}b")
+        a.i("4:", None)
+        a.i(f"s_mov_b64 {XSAVE}, exec")
+        a.i(f"s_mov_b64 {FLAGGED}, vcc")
+        a.i("s_mov_b64 exec, vcc")
+        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+        a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+        a.i("5:", None)
+        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+        a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
+        a.i("s_and_b64 exec, exec, vcc")
+        a.i("s_cbranch_execnz 5b")
+        a.i(f"s_mov_b64 exec, {FLAGGED}")
+        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+        a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_mov_b32 {C}, {PAIR0}")
+        a.i(f"v_mov_b32 {NXT}, {PAIR1}")
+        a.i(f"s_mov_b64 exec, {XSAVE}")
+        a.i(f"s_setpc_b64 {RET}")
+        a.i("3:", None)
     return a
 
 
 def main():
-    for ends in (False, True):
-        a = gen(ends)
-        header = ["// GENERATED by scripts/gen_range_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
-                  "// Main loop of the hand-scheduled (32,64) range decoder" + (", end-of-data aware" if ends else "") + ": see cst_range_fast.hip."]
-        ops = ['    : [x0] "+v"(x0), [x1] "+v"(x1), [rg0] "+v"(rg0), [rg1] "+v"(rg1), [pos] "+v"(pos), [hi_issued] "+v"(hi_issued),',
-               '      [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev), [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev), [tiles] "+v"(tiles), [ginc] "+v"(ginc),',
-               '      [bad] "=v"(bad)',
-               '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base),',
-               '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
-               '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)',
-               "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-        OUT[ends].write_text(a.render(header, ops))
-        print(f"wrote {OUT[ends]} ({a.n_instr()} instructions incl. loop control)")
+    global B16
+    for b16 in (False, True):
+        B16 = b16
+        for ends in (False, True):
+            a = gen(ends)
+            header = ["// GENERATED by scripts/gen_range_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
+                      "// Main loop of the hand-scheduled (32,64) range decoder" + (", 12 < P <= 24 (bucket entries)" if b16 else "") +
+                      (", end-of-data aware" if ends else "") + ": see cst_range_fast.hip."]
+            ops = ['    : [x0] "+v"(x0), [x1] "+v"(x1), [rg0] "+v"(rg0), [rg1] "+v"(rg1), [pos] "+v"(pos), [hi_issued] "+v"(hi_issued),',
+                   '      [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev), [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev), [tiles] "+v"(tiles), [ginc] "+v"(ginc),',
+                   '      [bad] "=v"(bad)',
+                   '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
+                   '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
+                   '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)' +
+                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol)' if b16 else ''),
+                   "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
+            OUT[(b16, ends)].write_text(a.render(header, ops))
+            print(f"wrote {OUT[(b16, ends)]} ({a.n_instr()} instructions incl. loop control)")
 
 
 if __name__ == "__main__":

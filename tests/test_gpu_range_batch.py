@@ -179,3 +179,36 @@ def test_range_long_inverted_runs(B, O, P):
     for s in range(len(sym)):
         assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
     assert np.array_equal(dec.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("P", [13, 16, 20, 24])
+def test_range_bucket_entry_decoder_walks_the_tails(B, O, P):
+    """12 < P <= 24: the decoder's lookup is one 16-byte bucket entry + a walk over the cdf table beyond its third symbol.
+    256 symbols, 100 + 155 of them with probability 1 / 2^P crowded into the first and last bucket, data drawn uniformly
+    over the alphabet; full and partial waves, and decoding past the end of the data."""
+    n = 256
+    probs = np.ones(n, dtype=np.int64)
+    probs[100] = (1 << P) - (n - 1) - 500
+    probs[37] += 300; probs[200] += 200
+    cdf = np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+    model = B.Model.from_cdf(cdf, -7, P)
+    rng = np.random.default_rng(100 + P)
+    for n_streams, n_per in ((192, 640), (70, 96), (64, 64), (3, 100)):
+        sym = (rng.integers(0, n, (n_streams, n_per)) - 7).astype(np.int32)
+        sym[:, ::3] = 93
+        want_words, want_n, _ = O.rc_encode_batch(sym, -7, cdf, P)
+        enc = B.range_encode(dev(sym), model, (32, 64, P))
+        torch.cuda.synchronize()
+        words, n_words, status = enc.to_numpy()
+        assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+        for s in range(n_streams):
+            assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+        dec, st = B.range_decode(enc, model, n_per)
+        torch.cuda.synchronize()
+        assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+        want_more, want_st = O.rc_decode_batch(want_words, want_n, n_per + 36, -7, cdf, P)
+        more, st3 = B.range_decode(enc, model, n_per + 36)
+        torch.cuda.synchronize()
+        assert st3.cpu().numpy().tolist() == want_st.tolist()
+        ok = want_st == 0
+        assert np.array_equal(more.cpu().numpy()[ok], want_more[ok])
