@@ -1051,5 +1051,8 @@ cst_status ans_decode_small(const AnsDecodeArgs& a, hipStream_t hs);
 // the hand-scheduled decoder for 12 < P <= 24 (cst_ans_b16.hip)
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_b16(const AnsDecodeArgs& a, hipStream_t hs);
+// the hand-scheduled decoder of the (16,32) preset (cst_ans_w16.hip)
+bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
+cst_status ans_decode_w16(const AnsDecodeArgs& a, hipStream_t hs);
 
 } // namespace cst

@@ -1,0 +1,190 @@
+// cst_ans_w16.hip -- the hand-scheduled decoder of the (16,32) preset (SmallAnsCoder, src/stream/stack.rs:153),
+// 8 <= P <= 12, shared table in LDS, stream-major.  scripts/gen_decode_loop_w16.py has the instruction-level account;
+// the step is AnsCoder::decode_symbol, stack.rs:1084-1097, on a 32-bit state with 16-bit words (one per 32-bit slot).
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+__device__ __forceinline__ void ans_decode_w16_tiles_loop(uint32_t& st, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur, uint32_t& row_prev,
+                                                          uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
+                                                          uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t goff_stride,
+                                                          uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                          uint32_t words_off, uint32_t goff0) {
+#include "cst_decode_loop_w16.inc"
+}
+
+constexpr int kW16RingWords = 64;             // 16-bit words of ring per lane: [position][lane] halfwords, 8 KiB per wave
+constexpr int kW16Ahead = 40;                 // 12 words of a half tile + 24 until requested chunks have landed + a chunk
+constexpr uint32_t kW16RingMask = (kW16RingWords - 1) * kWave * 2;
+constexpr size_t kW16RingBytes = (size_t)(kBlock / kWave) * kW16RingWords * kWave * 2;
+constexpr size_t kW16TileWords = (size_t)kWave * kTileStride;
+constexpr size_t kW16LdsBytes = kW16RingBytes + kTileLutBytes + 2 * (size_t)(kBlock / kWave) * kW16TileWords * 4 + kTileDumpBytes;
+
+// Per-lane (16,32) decoder with its word ring (stack semantics: words are consumed from the END of the stream).
+struct W16Lane {
+    uint32_t state;
+    int32_t status;
+    uint32_t rd;           // words not yet consumed (next word has stream index rd - 1)
+    uint32_t shift;
+    uint32_t lo_issued;    // lowest position (multiple of 4) whose chunk is in the ring
+    const uint32_t* base16;
+    uint16_t* ring;        // this wave's ring
+    int lane;
+
+    __device__ __forceinline__ uint16_t* slot(uint32_t pos) const { return ring + ((pos & (kW16RingWords - 1)) * kWave + lane); }
+
+    __device__ __forceinline__ void init(const uint32_t* in, uint32_t len, uint16_t* wave_ring, int lane_) {
+        shift = (uint32_t)((reinterpret_cast<uintptr_t>(in) & 15) >> 2);
+        base16 = in - shift;
+        ring = wave_ring; lane = lane_; rd = len; status = CST_STREAM_OK; state = 0;
+    }
+
+    // from_compressed + read_initial_state (stack.rs:299-318, 440-462), straight from HBM
+    __device__ __forceinline__ void read_initial_state() {
+        if (rd == 0) return;
+        const uint32_t first = base16[shift + --rd];
+        if (first == 0) { status = CST_STREAM_INVALID_DATA; rd = 0; return; }
+        uint32_t st = first;
+        while (rd > 0) {
+            st = (st << 16) | base16[shift + --rd];
+            if (st >= (1u << 16)) break;
+        }
+        state = st;
+    }
+
+    // blocking top-up of the window from wherever it stands
+    __device__ __forceinline__ void fill_blocking() {
+        const uint32_t top = rd + shift;
+        const uint32_t want_lo = top > (uint32_t)kW16Ahead ? top - kW16Ahead : 0u;
+        while (lo_issued > want_lo) {
+            lo_issued -= 4;
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            uint16_t* b = slot(lo_issued);   // chunk positions are multiples of 4: the four rows follow each other
+            b[0] = (uint16_t)v.x; b[kWave] = (uint16_t)v.y; b[2 * kWave] = (uint16_t)v.z; b[3 * kWave] = (uint16_t)v.w;
+        }
+    }
+
+    __device__ __forceinline__ void prime() {
+        lo_issued = (rd + shift + 3) & ~3u;
+        fill_blocking();
+    }
+
+    // one step (stack.rs:1084-1097); returns the decoded symbol
+    __device__ __forceinline__ int32_t step(const uint32_t* cp_table, const int32_t* sym_table, int P) {
+        const uint32_t q = state & ((1u << P) - 1u);
+        const uint32_t cp = cp_table[q];
+        const int32_t sym = sym_table[q];
+        const uint32_t st = (state >> P) * (cp >> 16) + (q - (cp & 0xffffu));
+        const bool refill = st < (1u << 16) && rd > 0;
+        const uint32_t w = *slot(rd - 1u + shift);     // ignored if no refill
+        state = refill ? ((st << 16) | w) : st;
+        rd -= refill ? 1u : 0u;
+        return sym;
+    }
+};
+
+// LDS layout: [word rings, 8 KiB per wave][cp | symbols (stage_tile_tables)][symbol tiles A][symbol tiles B][dump rows]
+__global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    DecLut lut{};
+    stage_tile_tables(smem + kW16RingBytes, P, a.dec_cp, a.dec_idx, a.min_symbol, lut);
+    uint16_t* ring = reinterpret_cast<uint16_t*>(smem) + wave_in_block * (kW16RingWords * kWave);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kW16RingBytes + kTileLutBytes) + wave_in_block * kW16TileWords;
+    int32_t* tile_b = tile + (kBlock / kWave) * kW16TileWords;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kW16RingBytes + kTileLutBytes + 2 * (size_t)(kBlock / kWave) * kW16TileWords * 4) +
+                     wave_in_block * (4 * kWave) + lane;
+    if ((lds_addr(ring) & (uint32_t)(kW16RingWords * kWave * 2 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const size_t n_full = N / kTileSyms;
+
+    W16Lane L;
+    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    L.read_initial_state();
+    L.prime();
+    wave_lds_fence();
+
+    // one tile with the compiler-scheduled step into `dst` (the lane's tile row); the window is topped up every half tile
+    auto tile_cxx = [&](int32_t* dst) {
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                int4 v;
+                v.x = L.step(lut.cp, lut.sym, P); v.y = L.step(lut.cp, lut.sym, P); v.z = L.step(lut.cp, lut.sym, P); v.w = L.step(lut.cp, lut.sym, P);
+                *reinterpret_cast<int4*>(dst + 16 * h + 4 * j) = v;
+            }
+            L.fill_blocking();
+            wave_lds_fence();
+        }
+    };
+
+    int32_t* my = tile + lane * kTileStride;
+    size_t tb = 0;
+    {
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)L.rd + 8) < 0x80000000ull;
+        if (s0 + kWave <= a.n_streams && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+            tile_cxx(my);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            // current = B (tile 1), previous = A (tile 0)
+            uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+            uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
+            ans_decode_w16_tiles_loop(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
+                                      kW16RingMask, words_base, store_base, (uint32_t)(8 * N * 4),
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
+                                      lds_addr(dump), (uint32_t)w_off, goff0);
+            // the last tile is still in LDS (buffer A if it has an even index)
+            wave_lds_fence();
+            tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+            wave_lds_fence();
+            tb = n_full;
+        }
+    }
+    for (; tb < n_full; ++tb) {
+        tile_cxx(my);
+        tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        wave_lds_fence();
+    }
+    int32_t* row = a.symbols + (active ? s : 0) * N;
+    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        const int32_t sym = L.step(lut.cp, lut.sym, P);
+        if (active) row[t] = sym;
+        L.fill_blocking();
+        wave_lds_fence();
+    }
+    if (!active) return;
+    a.status[s] = L.status;
+}
+
+bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    return cfg.word_bits == 16 && cfg.state_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 12 &&
+           a.dec_cp && a.dec_idx && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
+}
+
+cst_status ans_decode_w16(const AnsDecodeArgs& a, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_w16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kW16LdsBytes));
+    hipLaunchKernelGGL(ans_decode_w16_kernel, dim3((unsigned)blocks), dim3(kBlock), kW16LdsBytes, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+} // namespace cst

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): scripts/pmc_range.sh <tag> [range|ans|range_dec|ans_dec]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
+# usage (GPU box, repo root): scripts/pmc_range.sh <tag> [range|ans|w16|range_dec|ans_dec|w16_dec]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
 set -u
 tag=${1:-rng}; which=${2:-range}
 case $which in *_dec) pat=decode;; *) pat=encode;; esac
@@ -16,7 +16,10 @@ cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
 sym = bench.synth_symbols_device(0xC0FFEE, 0, 65536, 4096, -50, cdf, P)
 which = "$which"
 f = B.range_encode if which.startswith("range") else B.ans_encode
-enc = f(sym, m, (32, 64, P))
+cfg = (16, 32, P) if which.startswith("w16") else (32, 64, P)
+_f = f
+f = lambda *a, **k: _f(a[0], a[1], cfg, **k)
+enc = f(sym, m, cfg)
 if which.endswith("_dec"):
     g = B.range_decode if which.startswith("range") else B.ans_decode
     out = torch.empty_like(sym)

@@ -87,6 +87,13 @@ def test_b16_decode_loop_is_in_sync(tmp_path, monkeypatch):
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
 
 
+def test_w16_decode_loop_is_in_sync(tmp_path, monkeypatch):
+    """the (16,32) ANS decoder's main loop"""
+    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+    text = _regenerate(_load("gen_decode_loop_w16"), tmp_path, "cst_decode_loop_w16.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_w16.inc").read_text()
+
+
 def test_wait_bookkeeping_rejects_unreachable_counts():
     """asmgen refuses a wait whose operand would exceed what the hardware counter can express."""
     asmgen = _load("asmgen")
