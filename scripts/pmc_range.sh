@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): scripts/pmc_range.sh <tag> [range|ans|w16|range_dec|ans_dec|w16_dec]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
+# usage (GPU box, repo root): [P=24] scripts/pmc_range.sh <tag> [range|ans|w16|range_dec|ans_dec|w16_dec]  -- SQ counters of the hand-scheduled encoder at the C2 / C4 shape
 set -u
 tag=${1:-rng}; which=${2:-range}
 case $which in *_dec) pat=decode;; *) pat=encode;; esac
@@ -10,7 +10,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, "$R")
 import bench
 from constriction_amd import batched as B
-P = 12
+P = int("${P:-12}")
 m = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
 cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
 sym = bench.synth_symbols_device(0xC0FFEE, 0, 65536, 4096, -50, cdf, P)

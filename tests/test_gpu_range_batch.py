@@ -66,10 +66,11 @@ def test_range_skewed_model_exercises_carry_paths(B, O):
     assert np.array_equal(dec.cpu().numpy(), sym)
 
 
-def test_range_invalid_data(B, O):
+@pytest.mark.parametrize("P", [12, 24])
+def test_range_invalid_data(B, O, P):
     """Random words decoded with a model whose last quantiles are unreachable give InvalidData
-    exactly where the oracle says (queue.rs:989-993)."""
-    P = 12
+    exactly where the oracle says (queue.rs:989-993); full waves go through the hand-scheduled loops, whose symbol
+    check must send them to the exact step."""
     cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
     rng = np.random.default_rng(8)
