@@ -87,11 +87,14 @@ def test_b16_decode_loop_is_in_sync(tmp_path, monkeypatch):
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
 
 
-def test_w16_decode_loop_is_in_sync(tmp_path, monkeypatch):
-    """the (16,32) ANS decoder's main loop"""
-    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+def test_w16_loops_are_in_sync(tmp_path, monkeypatch):
+    """the (16,32) ANS coder's main loops"""
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT"):
+        monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop_w16"), tmp_path, "cst_decode_loop_w16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_w16.inc").read_text()
+    text = _regenerate(_load("gen_encode_loop_w16"), tmp_path, "cst_encode_loop_w16.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_w16.inc").read_text()
 
 
 def test_wait_bookkeeping_rejects_unreachable_counts():
