@@ -106,6 +106,9 @@ def load_library():
         raise BackendUnavailable(
             f"{LIB_PATH} is missing: build it with `python -m constriction_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    # torch first: it brings its own HIP runtime, and a process must not end up with two of them (the library loaded
+    # before torch binds /opt/rocm's runtime and then sees no device once torch has initialised its bundled one)
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
