@@ -42,7 +42,7 @@ bench = json.loads((g / f"{tag}_stats" / "bench.json").read_text())
 fetch, write, l2 = pmc(f"{tag}_fetch"), pmc(f"{tag}_write"), pmc(f"{tag}_l2")
 traffic = {}
 lines = [f"# {tag}: rocprofv3 summary of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (headline C2 + the `configs` block, 1 MI355X)", "",
-         "Kernels by configuration: `ans_*_kernel<32, 64, 0, true, ...8, true>` = C2 headline; `ans_encode_kernel<16, 32, ...>` / `ans_decode_w16_kernel` = 16-bit words;",
+         "Kernels by configuration: `ans_*_kernel<32, 64, 0, true, ...8, true>` = C2 headline; `ans_*_w16_kernel` = 16-bit words;",
          "`ans_encode_kernel<32, 64, 0, true, 4, ...>` / `ans_decode_b16_kernel` = P = 24; `range_*_fast_kernel<...>` = C4 (`<1>`/`<false>`: P = 12, `<2>`/`<true>`: P = 24);",
          "`ans_*_pt_kernel` = C3 (per-stream tables); `ans_*_small_kernel` = C5 shard (131072 streams); `compact_kernel` = packing.", "",
          f"bench line: value = {bench['value']} Msym/s, encode {bench['encode_ms']} ms, decode {bench['decode_ms']} ms, "
