@@ -124,6 +124,121 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     a.status[s] = L.status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Encoder for 12 < P <= 24 (scripts/gen_encode_loop_wide.py): the P <= 12 pipeline on unpacked table entries
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ans_encode_wide_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                           int32_t& smax, const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
+                                                           uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
+                                                           uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                           uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_wide.inc"
+}
+
+constexpr size_t kWideRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
+constexpr size_t kWideTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;
+
+// LDS layout: [word rings, 16 KiB per wave][table][symbol tiles A][symbol tiles B]
+__global__ __launch_bounds__(kBlock) void ans_encode_wide_kernel(const AnsEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    const size_t table_bytes = (size_t)a.n_symbols * sizeof(EncEntry);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem + kWideRingBytes);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kWideRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
+    if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = a.enc[i];
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t n_full = N / kTileSyms;
+
+    EncLane<32, 64> L;
+    L.init(a.words + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    auto code = [&](int32_t v) { L.template step<true>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P); };
+
+    // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
+    const int32_t* row = a.symbols + (active ? s : 0) * N;
+    for (size_t t = N; t > n_full * kTileSyms;) {
+        --t;
+        code(active ? row[t] : 0);
+        L.flush_chunks();
+    }
+    size_t tb = n_full;
+    if (n_full > 0) {
+        const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
+        const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                        (L.out.cap & 15u) == 0 && L.out.shift == 0;
+        if (s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!ok)) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
+            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+            uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+            int32_t smin = a.min_symbol, smax = a.min_symbol;
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            ans_encode_wide_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap,
+                                       (uint32_t)slab_off, lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            L.state = ((uint64_t)hi << 32) | lo;
+            // a symbol below min_symbol wraps to a huge index
+            L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+            tb = 0;
+        }
+    }
+    // partial waves and odd slabs: tile by tile with the per-step statement
+    for (; tb > 0;) {
+        --tb;
+        int32_t r[kTileSyms];
+        tile_fetch<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, r);
+        wave_lds_fence();
+        tile_to_lds<true>(tile, lane, r);
+        wave_lds_fence();
+        const int32_t* my = tile + lane * kTileStride;
+#pragma unroll 8
+        for (int j = kTileSyms - 1; j >= 0; --j) {
+            code(my[j]);
+            if ((j & 7) == 0) L.flush_chunks();
+        }
+    }
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(true, nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+bool wide_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    return cfg.word_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision > 12 && a.precision <= 24 &&
+           !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 &&
+           kWideRingBytes + (size_t)a.n_symbols * sizeof(EncEntry) + 2 * kWideTileBytes <= 160 * 1024;
+}
+
+cst_status ans_encode_wide(const AnsEncodeArgs& a, hipStream_t hs) {
+    const size_t lds = kWideRingBytes + (size_t)a.n_symbols * sizeof(EncEntry) + 2 * kWideTileBytes;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ans_encode_wide_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     return cfg.word_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision > 12 && a.precision <= 24 &&
            bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 &&

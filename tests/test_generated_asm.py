@@ -80,11 +80,14 @@ def test_range_decode_loops_are_in_sync(tmp_path, monkeypatch):
         assert (tmp_path / name).read_text() == (ROOT / "constriction_amd" / "csrc" / name).read_text(), name
 
 
-def test_b16_decode_loop_is_in_sync(tmp_path, monkeypatch):
-    """the ANS decoder's main loop for 12 < P <= 24 (bucket entries)"""
-    monkeypatch.delenv("GEN_NO_LGKM", raising=False)
+def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
+    """the ANS coder's main loops for 12 < P <= 24 (bucket entries / unpacked table entries)"""
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT"):
+        monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop_b16"), tmp_path, "cst_decode_loop_b16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
+    text = _regenerate(_load("gen_encode_loop_wide"), tmp_path, "cst_encode_loop_wide.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide.inc").read_text()
 
 
 def test_w16_loops_are_in_sync(tmp_path, monkeypatch):
