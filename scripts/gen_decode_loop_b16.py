@@ -39,15 +39,15 @@ def gen():
     PR, T0, T1, LA, WD, RA, R1, Q = "v124", "v125", "v126", "v127", "v129", "v131", "v132", "v133"
     SYM = [f"v{134 + k}" for k in range(8)]      # two quads
     X = tup(144)
-    E0, E1, E2, E3 = (f"v{148 + k}" for k in range(4))
-    E_T = tup(148)
+    ESET = [[f"v{148 + k}" for k in range(4)], [f"v{188 + k}" for k in range(4)]]     # entry registers of even / odd steps
+    ESET_T = [tup(148), tup(188)]
     C, NXT, IDX, TMPA = "v152", "v153", "v154", "v155"
     PAIR0, PAIR1, PAIR_T = "v156", "v157", tup(156, 2)
     PEND = [(tup(160 + 4 * k), [f"v{160 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
     LAND = [f"v{172 + k}" for k in range(K_CHUNKS)]
     WANT, TMP, TADDR, TOFF = "v175", "v176", "v177", "v178"
     GOFF = [f"v{180 + k}" for k in range(8)]
-    clobbers = [f"v{r}" for r in range(120, 188)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
+    clobbers = [f"v{r}" for r in range(120, 192)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
     SD, SAVE, V1, V2 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]"
     RET, XSAVE, FLAGGED = "s[70:71]", "s[72:73]", "s[74:75]"
 
@@ -74,11 +74,11 @@ def gen():
             a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
             a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
 
-    def lookup():
-        a.i(f"v_and_b32 {Q}, %[mask], %[lo]", "quantile")
-        a.i(f"v_lshrrev_b32 {LA}, %[bsh], {Q}")
+    def lookup(step):
+        a.i(f"v_bfe_u32 {LA}, %[lo], %[bsh], 11", "bucket = bits [P - 11, P) of the state")
         a.i(f"v_lshl_add_u32 {LA}, {LA}, 4, %[lut]")
-        a.ds(f"ds_read_b128 {E_T}, {LA}", "e", "bucket entry  <- end of the serial chain")
+        a.ds(f"ds_read_b128 {ESET_T[step % 2]}, {LA}", "e", "bucket entry  <- end of the serial chain")
+        a.i(f"v_and_b32 {Q}, %[mask], %[lo]", "quantile")
 
     def word_request():
         a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
@@ -98,24 +98,22 @@ def gen():
         if j in (0, 16):
             # ---- window: request the chunks the next half tile may need, then this half tile's first lookup ----
             window_requests()
-            lookup()
+            lookup(j)
             word_request()
             a.i(f"v_min_u32 {R1}, 1, %[rd]")
             a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
             a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        E0, E1, E2, E3 = ESET[j % 2]
         a.wait_lds("e", f"---- step {j}: the bucket entry is back")
         a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
         a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
         a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
         a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
-        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
         a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
         a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
-        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
-        a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare)")
+        a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare; it also leaves index - 2 in the entry)")
         a.i(f"2{j:02d}:", None)
         a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
         a.i(f"v_sub_u32 {D}, {Q}, {C}", "q - c")
@@ -126,10 +124,13 @@ def gen():
         a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
         last_of_half = j in (15, 31)
         if not last_of_half:
-            lookup()
+            lookup(j + 1)
         a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
         if not last_of_half:
             word_request()
+        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
         a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
         if pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
@@ -158,33 +159,40 @@ def gen():
     a.i("s_cbranch_scc1 1b")
     a.i("s_branch 3f")
 
-    # ---- out of line: the walk (entered with the lanes to walk in vcc; Q, E0 as in the step) ----
+    # ---- out of line: the walk (entered with the lanes to walk in vcc; Q and the entry as in the step), one copy per
+    # ---- entry register set
     for j in range(32):
         a.i(f"1{j:02d}:", None)
-        a.i(f"s_call_b64 {RET}, 4f")
+        a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
         a.i(f"s_branch 2{j:02d}b")
-    a.i("4:", None)
-    a.i(f"s_mov_b64 {XSAVE}, exec")
-    a.i(f"s_mov_b64 {FLAGGED}, vcc")
-    a.i("s_mov_b64 exec, vcc")
-    a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
-    a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
-    a.i("5:", None)
-    a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
-    a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
-    a.i("s_waitcnt lgkmcnt(0)")
-    a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
-    a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
-    a.i("s_and_b64 exec, exec, vcc")
-    a.i("s_cbranch_execnz 5b")
-    a.i(f"s_mov_b64 exec, {FLAGGED}")
-    a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
-    a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
-    a.i("s_waitcnt lgkmcnt(0)")
-    a.i(f"v_mov_b32 {C}, {PAIR0}")
-    a.i(f"v_mov_b32 {NXT}, {PAIR1}")
-    a.i(f"s_mov_b64 exec, {XSAVE}")
-    a.i(f"s_setpc_b64 {RET}")
+    for st in range(2):
+        E0 = ESET[st][0]
+        a.i(f"{4 + st}:", None)
+        a.i(f"s_mov_b64 {XSAVE}, exec")
+        a.i(f"s_mov_b64 {FLAGGED}, vcc")
+        a.i("s_mov_b64 exec, vcc")
+        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+        a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+        a.i(f"{6 + st}:", None)
+        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+        a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
+        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
+        a.i("s_and_b64 exec, exec, vcc")
+        a.i(f"s_cbranch_execnz {6 + st}b")
+        a.i(f"s_mov_b64 exec, {FLAGGED}")
+        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+        a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_mov_b32 {C}, {PAIR0}")
+        a.i(f"v_mov_b32 {NXT}, {PAIR1}")
+        a.i(f"v_sub_u32 {IDX}, {IDX}, 2", "q >= e1 and q >= e2 hold for these lanes: the step adds 2 again")
+        a.i(f"v_lshlrev_b32 {IDX}, 24, {IDX}")
+        a.i(f"v_and_b32 {E0}, 0xffffff, {E0}")
+        a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
+        a.i(f"s_mov_b64 exec, {XSAVE}")
+        a.i(f"s_setpc_b64 {RET}")
     a.i("3:", None)
     a.wait_vm_all("nothing may land in the scratch registers after the statement")
     return a, clobbers

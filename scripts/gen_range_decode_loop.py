@@ -54,15 +54,17 @@ PEND = [(tup(176 + 4 * k, 4), [f"v{176 + 4 * k + j}" for j in range(4)]) for k i
 LAND = [f"v{188 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v191", "v192", "v193", "v194"
 GOFF = [f"v{196 + k}" for k in range(8)]
-E0, E1, E2, E3, NXT, IDX, TMPA = (f"v{r}" for r in (204, 205, 206, 207, 208, 209, 210))        # bucket-entry variant
-E_T, PAIR_T, PAIR0, PAIR1 = tup(204, 4), tup(212), "v212", "v213"
-CLOBBERS = [f"v{r}" for r in range(120, 214)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
+NXT, IDX, TMPA = "v208", "v209", "v210"                                                # bucket-entry variant:
+ESET = [[f"v{204 + k}" for k in range(4)], [f"v{216 + k}" for k in range(4)]]           # entry registers of even / odd steps
+ESET_T = [tup(204, 4), tup(216, 4)]
+PAIR_T, PAIR0, PAIR1 = tup(212), "v212", "v213"
+CLOBBERS = [f"v{r}" for r in range(120, 220)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
 SD, SAVE, BAD, CHK, HV, REN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
 RET, XSAVE, FLAGGED, V1, V2 = "s[70:71]", "s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]"    # (s96..s101 are flat_scratch / xnack_mask)
 B16 = False           # True: 12 < P <= 24, the lookup is one 16-byte bucket entry (DecLut::b16) instead of the table of 2^P quantiles
 
 
-def quotient_lookup(a, nxt_sym):
+def quotient_lookup(a, nxt_sym, step=0):
     """from (x, range) to the requests for the next step's table entry and symbol"""
     a.i(f"v_alignbit_b32 {SC0}, {RG1}, {RG0}, %[P]", "scale = range >> P")
     a.i(f"v_lshrrev_b32 {SC1}, %[P], {RG1}")
@@ -81,7 +83,7 @@ def quotient_lookup(a, nxt_sym):
     if B16:
         a.i(f"v_lshrrev_b32 {LA}, %[bsh], {Q}")
         a.i(f"v_lshl_add_u32 {LA}, {LA}, 4, %[lut]")
-        a.ds(f"ds_read_b128 {E_T}, {LA}", "cp", "next bucket entry  <- end of the serial chain")
+        a.ds(f"ds_read_b128 {ESET_T[step % 2]}, {LA}", "cp", "next bucket entry  <- end of the serial chain")
         return
     a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
     a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next c | p << 16  <- end of the serial chain (a random 64-bit read costs ~35 cycles more)")
@@ -133,7 +135,7 @@ def gen(ends):
     a.i("v_readfirstlane_b32 s82, %[tiles]", "tiles left")
     a.i("v_readfirstlane_b32 s83, %[ginc]", "0 in front of the very first tile, then 128 B")
     # the first lookup: every tile's last step issues the next tile's
-    quotient_lookup(a, SYM[0])
+    quotient_lookup(a, SYM[0], 0)
     a.i("1:", None)
     if not ends:
         a.i(f"v_add_u32 {TMP}, {25 if B16 else 13}, {POS}")
@@ -152,18 +154,16 @@ def gen(ends):
         else:
             a.i(f"; ---- step {j}")
         if B16:
+            E0, E1, E2, E3 = ESET[j % 2]
             a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
             a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
             a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
             a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
-            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
             a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
             a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
             a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
             a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
-            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
-            a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare)")
+            a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare; it also leaves index - 2 in the entry)")
             a.i(f"2{j:02d}:", None)
             a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
         else:
@@ -187,12 +187,15 @@ def gen(ends):
         a.i(f"v_cndmask_b32_e64 {RG0}, {NR0}, 0, vcc")
         a.i(f"v_cndmask_b32_e32 {X1}, {REM1}, {REM0}, vcc", "x = renorm ? rem << 32 | word : rem")
         a.i(f"v_cndmask_b32_e32 {X0}, {REM0}, {WD}, vcc")
-        quotient_lookup(a, sym_reg)
+        quotient_lookup(a, sym_reg, j + 1)
         a.i(f"s_or_b64 {BAD}, {BAD}, {CHK}", "(sticky: the caller repeats the streams with the exact step)")
         a.i(f"v_addc_co_u32_e64 {POS}, {SD}, 0, {POS}, {REN if ends else 'vcc'}", "a renormalisation took the word")
         if (j + 1) % 32 not in halves:
             word_request(a)
         if B16:
+            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
+            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
+            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
             a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
         if pos == 1:
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
@@ -225,33 +228,40 @@ def gen(ends):
     a.i("s_or_b32 s88, s88, s89"); a.i("v_mov_b32 %[bad], s88")
     if B16:
         a.i("s_branch 3f")
-        # ---- out of line: the walk (entered with the lanes to walk in vcc; Q, E0 as in the step) ----
+        # ---- out of line: the walk (entered with the lanes to walk in vcc; Q and the entry as in the step), one copy per
+        # ---- entry register set
         for j in range(32):
             a.i(f"1{j:02d}:", None)
-            a.i(f"s_call_b64 {RET}, 4f")
+            a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
             a.i(f"s_branch 2{j:02d}b")
-        a.i("4:", None)
-        a.i(f"s_mov_b64 {XSAVE}, exec")
-        a.i(f"s_mov_b64 {FLAGGED}, vcc")
-        a.i("s_mov_b64 exec, vcc")
-        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
-        a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
-        a.i("5:", None)
-        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
-        a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
-        a.i("s_waitcnt lgkmcnt(0)")
-        a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
-        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
-        a.i("s_and_b64 exec, exec, vcc")
-        a.i("s_cbranch_execnz 5b")
-        a.i(f"s_mov_b64 exec, {FLAGGED}")
-        a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
-        a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
-        a.i("s_waitcnt lgkmcnt(0)")
-        a.i(f"v_mov_b32 {C}, {PAIR0}")
-        a.i(f"v_mov_b32 {NXT}, {PAIR1}")
-        a.i(f"s_mov_b64 exec, {XSAVE}")
-        a.i(f"s_setpc_b64 {RET}")
+        for st in range(2):
+            E0 = ESET[st][0]
+            a.i(f"{4 + st}:", None)
+            a.i(f"s_mov_b64 {XSAVE}, exec")
+            a.i(f"s_mov_b64 {FLAGGED}, vcc")
+            a.i("s_mov_b64 exec, vcc")
+            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+            a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+            a.i(f"{6 + st}:", None)
+            a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+            a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"v_cmp_le_u32 vcc, {NXT}, {Q}")
+            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, vcc")
+            a.i("s_and_b64 exec, exec, vcc")
+            a.i(f"s_cbranch_execnz {6 + st}b")
+            a.i(f"s_mov_b64 exec, {FLAGGED}")
+            a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
+            a.i(f"ds_read2_b32 {PAIR_T}, {TMPA} offset1:1")
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"v_mov_b32 {C}, {PAIR0}")
+            a.i(f"v_mov_b32 {NXT}, {PAIR1}")
+            a.i(f"v_sub_u32 {IDX}, {IDX}, 2", "q >= e1 and q >= e2 hold for these lanes: the step adds 2 again")
+            a.i(f"v_lshlrev_b32 {IDX}, 24, {IDX}")
+            a.i(f"v_and_b32 {E0}, 0xffffff, {E0}")
+            a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
+            a.i(f"s_mov_b64 exec, {XSAVE}")
+            a.i(f"s_setpc_b64 {RET}")
         a.i("3:", None)
     return a
 
