@@ -12,7 +12,8 @@ __device__ __forceinline__ void ans_decode_b16_tiles_loop(uint32_t& lo, uint32_t
                                                           uint32_t cdf_addr, uint32_t mask, uint32_t P, uint32_t bucket_shift,
                                                           int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                           uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
-                                                          uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0) {
+                                                          uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0,
+                                                          uint32_t goff_limit) {
 #include "cst_decode_loop_b16.inc"
 }
 
@@ -54,8 +55,11 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     const size_t n_full = N / kTileSyms;
     const int bucket_shift = P - a.bucket_bits;
 
+    // the lanes of a partial wave beyond its last stream REPEAT that stream (same words, same symbols, stored onto its row
+    // again): the wave then runs the main-loop statement like a full one
+    const size_t se = active ? s : a.n_streams - 1;
     DecLane<32, 64, kDecRingSlots, kDecAhead> L;
-    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    L.init(a.words + (a.offsets ? a.offsets[se] : se * a.stride_words), a.n_words[se], ring, lane);
     L.read_initial_state();
     L.in.prime();
     wave_lds_fence();
@@ -84,8 +88,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
-        if (s0 + kWave <= a.n_streams && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+        if (n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
             tile_cxx(my);
+            const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
             const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
             ans_decode_b16_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
                                       (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
                                       words_base, store_base, (uint32_t)(8 * N * 4), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0);
+                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit);
             L.state = ((uint64_t)hi << 32) | lo;
             // the last tile is still in LDS (buffer A if it has an even index)
             wave_lds_fence();
@@ -161,16 +166,17 @@ __global__ __launch_bounds__(kBlock) void ans_encode_wide_kernel(const AnsEncode
     const uint32_t nsym = (uint32_t)a.n_symbols;
     const size_t n_full = N / kTileSyms;
 
+    // the lanes of a partial wave beyond its last stream REPEAT that stream (same symbols, same slab, same words)
+    const size_t se = active ? s : a.n_streams - 1;
     EncLane<32, 64> L;
-    L.init(a.words + (active ? s : 0) * a.stride_words,
-           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    L.init(a.words + se * a.stride_words, (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words), ring, lane);
     auto code = [&](int32_t v) { L.template step<true>(table[enc_index(v, a.min_symbol, nsym, L.bad)], P); };
 
     // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
-    const int32_t* row = a.symbols + (active ? s : 0) * N;
+    const int32_t* row = a.symbols + se * N;
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
-        code(active ? row[t] : 0);
+        code(row[t]);
         L.flush_chunks();
     }
     size_t tb = n_full;
@@ -178,10 +184,11 @@ __global__ __launch_bounds__(kBlock) void ans_encode_wide_kernel(const AnsEncode
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
         const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
                         (L.out.cap & 15u) == 0 && L.out.shift == 0;
-        if (s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!ok)) {
+        if (N < (1u << 24) && !__any(!ok)) {
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
             const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_wide_kernel(const AnsEncode
         wave_lds_fence();
         tile_to_lds<true>(tile, lane, r);
         wave_lds_fence();
-        const int32_t* my = tile + lane * kTileStride;
+        const int32_t* my = tile + min((size_t)lane, a.n_streams - 1 - s0) * kTileStride;   // (repeating lanes read the last stream's row)
 #pragma unroll 8
         for (int j = kTileSyms - 1; j >= 0; --j) {
             code(my[j]);

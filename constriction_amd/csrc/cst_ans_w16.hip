@@ -9,7 +9,7 @@ __device__ __forceinline__ void ans_decode_w16_tiles_loop(uint32_t& st, uint32_t
                                                           uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
                                                           uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t goff_stride,
                                                           uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
-                                                          uint32_t words_off, uint32_t goff0) {
+                                                          uint32_t words_off, uint32_t goff0, uint32_t goff_limit) {
 #include "cst_decode_loop_w16.inc"
 }
 
@@ -107,8 +107,11 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     const size_t N = a.n_per_stream;
     const size_t n_full = N / kTileSyms;
 
+    // the lanes of a partial wave beyond its last stream REPEAT that stream (same words, same symbols, stored onto its row
+    // again): the wave then runs the main-loop statement like a full one
+    const size_t se = active ? s : a.n_streams - 1;
     W16Lane L;
-    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    L.init(a.words + (a.offsets ? a.offsets[se] : se * a.stride_words), a.n_words[se], ring, lane);
     L.read_initial_state();
     L.prime();
     wave_lds_fence();
@@ -134,8 +137,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.rd + 8) < 0x80000000ull;
-        if (s0 + kWave <= a.n_streams && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+        if (n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
             tile_cxx(my);
+            const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             // current = B (tile 1), previous = A (tile 0)
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
             ans_decode_w16_tiles_loop(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
                                       kW16RingMask, words_base, store_base, (uint32_t)(8 * N * 4),
                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
-                                      lds_addr(dump), (uint32_t)w_off, goff0);
+                                      lds_addr(dump), (uint32_t)w_off, goff0, goff_limit);
             // the last tile is still in LDS (buffer A if it has an even index)
             wave_lds_fence();
             tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
@@ -216,16 +220,17 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
     const uint32_t nsym = (uint32_t)a.n_symbols;
     const size_t n_full = N / kTileSyms;
 
+    // the lanes of a partial wave beyond its last stream REPEAT that stream (same symbols, same slab, same words)
+    const size_t se = active ? s : a.n_streams - 1;
     EncLane<16, 32> L;
-    L.init(a.words + (active ? s : 0) * a.stride_words,
-           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    L.init(a.words + se * a.stride_words, (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words), ring, lane);
     auto code = [&](int32_t v) { L.template step<false>(a.enc[enc_index(v, a.min_symbol, nsym, L.bad)], P); };
 
     // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
-    const int32_t* row = a.symbols + (active ? s : 0) * N;
+    const int32_t* row = a.symbols + se * N;
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
-        code(active ? row[t] : 0);
+        code(row[t]);
         L.flush_chunks();
     }
     size_t tb = n_full;
@@ -233,10 +238,11 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
         const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
                         (L.out.cap & 15u) == 0 && L.out.shift == 0;
-        if (s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!ok)) {
+        if (N < (1u << 24) && !__any(!ok)) {
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
             const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
         wave_lds_fence();
         tile_to_lds<true>(tile, lane, r);
         wave_lds_fence();
-        const int32_t* my = tile + lane * kTileStride;
+        const int32_t* my = tile + min((size_t)lane, a.n_streams - 1 - s0) * kTileStride;   // (repeating lanes read the last stream's row)
 #pragma unroll 8
         for (int j = kTileSyms - 1; j >= 0; --j) {
             code(my[j]);

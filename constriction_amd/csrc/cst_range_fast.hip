@@ -19,12 +19,15 @@ struct RangeEncHeld {
     uint64_t lower, range;
     uint32_t lw;          // the held word: stream position out.wr, not yet final
     uint32_t bad;
+    bool owner;           // false for the lanes of a partial wave that merely repeat its last stream: they must not
+                          // read-modify-write words that have left for HBM
     RingWriter<> out;     // out.wr = final words (-1 until the first word exists)
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
         out.init(slab, capacity, wave_ring, lane_);
         out.wr = 0xffffffffu;
         lower = 0; range = ~0ull; lw = 0; bad = 0;   // RangeCoderState::default, queue.rs:96-104
+        owner = true;
     }
 
     // + 1 on the number spelled by the final words (the held word overflowed)
@@ -37,6 +40,7 @@ struct RangeEncHeld {
                 *out.slot(pos) = w;
             } else {
                 if ((uint32_t)i >= out.cap) break;                       // never stored: the stream ends as CST_STREAM_CAPACITY
+                if (!owner) break;                                       // (everything older has left too, and the owner's update serves every copy)
                 __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the lane's own store of this word has landed
                 w = __hip_atomic_load(out.base16 + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
                 __hip_atomic_store(out.base16 + pos, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -124,20 +128,25 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
     const int P = a.precision;
     const uint32_t nsym = (uint32_t)a.n_symbols;
     const size_t n_full = N / kTileSyms;
-    uint32_t* slab = a.words + (active ? s : 0) * a.stride_words;
-    const uint32_t cap = active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u;
+    // The lanes of a partial wave beyond its last stream REPEAT that stream (same symbols, same slab, same words): the wave
+    // then runs the main-loop statement like a full one, and only the per-stream results are written by the owner alone.
+    const size_t se = active ? s : a.n_streams - 1;
+    uint32_t* slab = a.words + se * a.stride_words;
+    const uint32_t cap = (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words);
 
     RangeEncHeld L;
     L.init(slab, cap, ring, lane);
+    L.owner = active;
     bool done = false;
     {
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
         const bool ok = slab_off + 4ull * cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
                         (cap & 15u) == 0 && L.out.shift == 0;
-        if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!ok)) {
+        if (n_full > 0 && N < (1u << 24) && !__any(!ok)) {
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
             const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
             wave_lds_fence();
             tile_to_lds<true>(tile, lane, r);
             wave_lds_fence();
-            const int32_t* my = tile + lane * kTileStride;
+            const int32_t* my = tile + min((size_t)lane, a.n_streams - 1 - s0) * kTileStride;   // (repeating lanes read the last stream's row)
 #pragma unroll 8
             for (int j = 0; j < kTileSyms; ++j) {
                 const CumProb e = table[enc_index(my[j], a.min_symbol, nsym, L.bad)];
@@ -177,9 +186,9 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
             }
         }
     }
-    const int32_t* row = a.symbols + (active ? s : 0) * N;
+    const int32_t* row = a.symbols + se * N;
     for (size_t t = n_full * kTileSyms; t < N; ++t) {
-        const CumProb e = table[enc_index(active ? row[t] : 0, a.min_symbol, nsym, L.bad)];
+        const CumProb e = table[enc_index(row[t], a.min_symbol, nsym, L.bad)];
         L.step(e.c, e.p, P);
         L.flush();
     }
@@ -204,8 +213,8 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
                                                         uint32_t lut_addr, uint32_t qmax, uint32_t P, uint32_t ring_mask,
                                                         const void* words_base, uint32_t delta_hi, uint64_t store_base, uint32_t goff_stride,
                                                         uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
-                                                        uint32_t words_off, uint32_t goff0, uint32_t bucket_shift, uint32_t cdf_addr,
-                                                        int32_t min_symbol) {
+                                                        uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t bucket_shift,
+                                                        uint32_t cdf_addr, int32_t min_symbol) {
     if constexpr (B16) {
         if constexpr (ENDS) {
 #include "cst_range_decode_loop_b16_ends.inc"
@@ -267,8 +276,10 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     const size_t N = a.n_per_stream;
     const size_t n_full = N / kTileSyms;
     const int bucket_shift = P - a.bucket_bits;
-    const uint32_t* my_words = a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0);
-    const uint32_t my_len = active ? a.n_words[s] : 0u;
+    // the lanes of a partial wave beyond its last stream repeat that stream (see the encoder)
+    const size_t se = active ? s : a.n_streams - 1;
+    const uint32_t* my_words = a.words + (a.offsets ? a.offsets[se] : se * a.stride_words);
+    const uint32_t my_len = a.n_words[se];
 
     RangeDecLane<32, 64, kRdSlots, kRdAhead> L;
     L.init(my_words, my_len, ring, lane);
@@ -299,9 +310,10 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)my_len + 8) < 0x80000000ull;
-        if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && !__any(!off_ok)) {
+        if (n_full > 0 && N < (1u << 24) && !__any(!off_ok)) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statements keep their own book from here
             const uint32_t shift = L.in.shift;
+            const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             uint32_t x0 = (uint32_t)L.point, x1 = (uint32_t)(L.point >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
             uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
             const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
@@ -321,15 +333,15 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
             range_decode_tiles_loop<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
                                                 qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
-                                                lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, (uint32_t)bucket_shift, cdf_addr,
-                                                a.min_symbol);
+                                                lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
+                                                cdf_addr, a.min_symbol);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
                 const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
                 range_decode_tiles_loop<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
                                                    lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
-                                                   lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, (uint32_t)bucket_shift,
+                                                   lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
                                                    cdf_addr, a.min_symbol);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {

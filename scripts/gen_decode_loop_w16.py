@@ -80,9 +80,10 @@ def gen():
     def sym_reg(j):
         return SYM[(j // 4 % 2) * 4 + j % 4]
 
-    a.i(f"v_mov_b32 {GOFF[0]}, %[goff0]")
+    a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
     for k in range(1, 8):
         a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+        a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     window_requests("B")      # (the set that lands after step 15)
@@ -149,7 +150,7 @@ def main():
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
            '      [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
-           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)',
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)',
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
     OUT.write_text(a.render(header, ops))
     print(f"wrote {OUT} ({a.n_instr()} instructions per iteration incl. loop control)")

@@ -127,9 +127,10 @@ def gen(ends):
     a.i(f"v_mov_b32 {POS}, %[pos]"); a.i(f"v_mov_b32 {HI}, %[hi_issued]")
     a.i("v_mov_b32 v144, 0"); a.i("v_mov_b32 v145, 0x41f00000", "2^32")
     a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, %[dhi]", "+2^-30 (P <= 16) or +2^-22: above the estimate's error of 2^(P - 48.5)")
-    a.i(f"v_mov_b32 {GOFF[0]}, %[goff0]")
+    a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
     for k in range(1, 8):
         a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+        a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
     a.i(f"s_mov_b64 {BAD}, 0")
     a.i("s_mov_b64 s[80:81], %[gbase]", "where the PREVIOUS tile goes (first tile of all: onto itself, rewritten one tile later)")
     a.i("v_readfirstlane_b32 s82, %[tiles]", "tiles left")
@@ -280,7 +281,7 @@ def main():
                    '      [bad] "=v"(bad)',
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
                    '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
-                   '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0)' +
+                   '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' +
                    (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol)' if b16 else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
             OUT[(b16, ends)].write_text(a.render(header, ops))
