@@ -84,3 +84,24 @@ def model_args(model, params, n_expected=None):
     if hasattr(model, "family_rows"):      # tabulated families: one cdf row per symbol position
         return ("rows", model.family_rows(params), model.min_symbol)
     raise TypeError("unsupported model family")
+
+
+class Scalars:
+    """The per-call scalars of one coder in ONE 32-byte device buffer -- coder state (u64), word count in / out (u32 each),
+    stream status (i32) -- so that a call costs one small upload and one small download instead of one per value."""
+    STATE, N, N_OUT, STATUS = 0, 8, 12, 16          # byte offsets
+
+    def __init__(self, state: int = 0, n: int = 0):
+        host = np.zeros(4, dtype=np.int64)
+        host[0] = np.uint64(state).astype(np.int64)
+        host[1] = int(n)                             # n in the low word, n_out = 0 in the high one
+        self.t = torch.from_numpy(host).cuda()
+
+    def p(self, offset):
+        return C.c_void_p(self.t.data_ptr() + offset)
+
+    def read(self):
+        """(state, n, n_out, status) after the calls on the current stream (the copy synchronises)"""
+        h = self.t.cpu().numpy()
+        w = h.view(np.uint32)
+        return int(h.view(np.uint64)[0]), int(w[2]), int(w[3]), int(h.view(np.int32)[4])

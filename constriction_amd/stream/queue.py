@@ -20,14 +20,25 @@ _MAX = (1 << _S) - 1
 _MASK = _MAX
 
 
-def _rstate_tensor(lower, rng, point=0, inv_n=0, inv_first=0, position=0):
-    rs = N.RangeState(lower, rng, point, inv_n, inv_first, position)
-    buf = np.frombuffer(bytes(rs), dtype=np.uint8).copy()
-    return torch.from_numpy(buf).cuda()
+class _Scalars:
+    """cst_range_state + word count + stream status of one call in ONE 64-byte device buffer (one upload, one download)"""
+    N_OFF, STATUS_OFF = 48, 52
 
+    def __init__(self, lower, rng, point=0, inv_n=0, inv_first=0, position=0, n=0):
+        rs = N.RangeState(lower, rng, point, inv_n, inv_first, position)
+        buf = np.zeros(64, dtype=np.uint8)
+        raw = np.frombuffer(bytes(rs), dtype=np.uint8)
+        assert len(raw) <= self.N_OFF
+        buf[: len(raw)] = raw
+        buf[self.N_OFF: self.N_OFF + 4] = np.frombuffer(np.uint32(n).tobytes(), dtype=np.uint8)
+        self.t = torch.from_numpy(buf).cuda()
+        self.state, self.n, self.status = (C.c_void_p(self.t.data_ptr() + off) for off in (0, self.N_OFF, self.STATUS_OFF))
 
-def _read_rstate(t):
-    return N.RangeState.from_buffer_copy(t.cpu().numpy().tobytes())
+    def read(self):
+        """(cst_range_state, n_words, status) after the calls on the current stream (the copy synchronises)"""
+        h = self.t.cpu().numpy()
+        return (N.RangeState.from_buffer_copy(h[: self.N_OFF].tobytes()), int(h[self.N_OFF: self.N_OFF + 4].view(np.uint32)[0]),
+                int(h[self.STATUS_OFF: self.STATUS_OFF + 4].view(np.int32)[0]))
 
 
 class RangeEncoder:
@@ -98,20 +109,19 @@ class RangeEncoder:
         L = N.lib()
         cap = L.cst_range_max_words(n, S.cfg()) + self._inv_n + 2
         d_words = torch.empty(cap, dtype=torch.int32, device="cuda")
-        d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_rs = _rstate_tensor(self._lower, self._range, 0, self._inv_n, self._inv_first, 0)
+        sc = _Scalars(self._lower, self._range, 0, self._inv_n, self._inv_first, 0)
+        d_n, d_rs, d_status = sc.n, sc.state, sc.status
         sp = S.stream_ptr()
         if kind[0] == "table":
             d_sym = S.dev(sym)
             st = L.cst_range_encode_batch(kind[1]._h, S.cfg(), S.ptr(d_sym), 1, n, N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap,
-                                          S.ptr(d_n), S.ptr(d_rs), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                          d_n, d_rs, d_status, N.FLAG_RAW_STATE, sp)
         elif kind[0] == "gaussian":
             _, lo, hi, means, stds = kind
             d_sym, d_mu, d_sd = S.dev(sym), S.dev(means), S.dev(stds)
             st = L.cst_range_encode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_sym), S.ptr(d_mu), S.ptr(d_sd), 1, n,
-                                                   N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap, S.ptr(d_n), S.ptr(d_rs),
-                                                   S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                                   N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap, d_n, d_rs,
+                                                   d_status, N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
             idx = sym.astype(np.int64) - kind[2]
@@ -122,14 +132,12 @@ class RangeEncoder:
             prob = np.where(ok, rows[ar, safe + 1].astype(np.int64) - left.astype(np.int64), 0).astype(np.uint32)
             d_left, d_prob = S.dev(left.view(np.int32)), S.dev(prob.view(np.int32))
             st = L.cst_range_encode_cp_batch(S.cfg(), S.ptr(d_left), S.ptr(d_prob), 1, n, N.LAYOUT_STREAM_MAJOR, S.ptr(d_words),
-                                             cap, S.ptr(d_n), S.ptr(d_rs), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                             cap, d_n, d_rs, d_status, N.FLAG_RAW_STATE, sp)
         N.check(st, "range encode")
-        torch.cuda.current_stream().synchronize()
-        S.raise_for_status(int(d_status.item()))
-        k = int(d_n.item())
+        rs, k, status = sc.read()
+        S.raise_for_status(status)
         if k:
             self._bulk = np.concatenate([self._bulk, d_words[:k].cpu().numpy().view(np.uint32)])
-        rs = _read_rstate(d_rs)
         self._lower, self._range, self._inv_n, self._inv_first = rs.lower, rs.range, rs.inverted_n, rs.inverted_first
 
 
@@ -197,30 +205,28 @@ class RangeDecoder:
         window = self._words[self._pos: self._pos + amt]
         nwin = len(window)
         d_words = S.dev(window.view(np.int32)) if nwin else torch.zeros(4, dtype=torch.int32, device="cuda")
-        d_n = torch.tensor([nwin], dtype=torch.int32, device="cuda")
-        d_status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_rs = _rstate_tensor(self._lower, self._range, self._point, 0, 0, 0)
+        sc = _Scalars(self._lower, self._range, self._point, 0, 0, 0, nwin)
+        d_n, d_rs, d_status = sc.n, sc.state, sc.status
         d_sym = torch.empty(amt, dtype=torch.int32, device="cuda")
         sp = S.stream_ptr()
         if kind[0] == "table":
-            st = L.cst_range_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(nwin, 1), S.ptr(d_n), S.ptr(d_sym), 1, amt,
-                                          N.LAYOUT_STREAM_MAJOR, S.ptr(d_rs), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+            st = L.cst_range_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(nwin, 1), d_n, S.ptr(d_sym), 1, amt,
+                                          N.LAYOUT_STREAM_MAJOR, d_rs, d_status, N.FLAG_RAW_STATE, sp)
         elif kind[0] == "gaussian":
             _, lo, hi, means, stds = kind
             d_mu, d_sd = S.dev(means), S.dev(stds)
-            st = L.cst_range_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(nwin, 1), S.ptr(d_n), S.ptr(d_mu),
-                                                   S.ptr(d_sd), S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, S.ptr(d_rs),
-                                                   S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+            st = L.cst_range_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(nwin, 1), d_n, S.ptr(d_mu),
+                                                   S.ptr(d_sd), S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, d_rs,
+                                                   d_status, N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
             d_rows = S.dev(rows.view(np.int32))
-            st = L.cst_range_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(nwin, 1), S.ptr(d_n), S.ptr(d_rows),
-                                               rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, S.ptr(d_rs),
-                                               S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+            st = L.cst_range_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(nwin, 1), d_n, S.ptr(d_rows),
+                                               rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, d_rs,
+                                               d_status, N.FLAG_RAW_STATE, sp)
         N.check(st, "range decode")
-        torch.cuda.current_stream().synchronize()
-        S.raise_for_status(int(d_status.item()))
-        rs = _read_rstate(d_rs)
+        rs, _, status = sc.read()
+        S.raise_for_status(status)
         self._lower, self._range, self._point = rs.lower, rs.range, rs.point
         self._pos += int(rs.position)
         out = d_sym.cpu().numpy()

@@ -120,20 +120,19 @@ class AnsCoder:
         L = N.lib()
         cap = L.cst_ans_max_words(n, S.cfg())
         d_words = torch.empty(cap, dtype=torch.int32, device="cuda")
-        d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_state = torch.tensor([np.uint64(self._state).astype(np.int64)], dtype=torch.int64, device="cuda")
+        sc = S.Scalars(self._state)
+        d_n, d_state, d_status = sc.p(sc.N), sc.p(sc.STATE), sc.p(sc.STATUS)
         sp = S.stream_ptr()
         if kind[0] == "table":
             d_sym = S.dev(sym)
             st = L.cst_ans_encode_batch(kind[1]._h, S.cfg(), S.ptr(d_sym), 1, n, N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap,
-                                        S.ptr(d_n), S.ptr(d_state), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                        d_n, d_state, d_status, N.FLAG_RAW_STATE, sp)
         elif kind[0] == "gaussian":
             _, lo, hi, means, stds = kind
             d_sym, d_mu, d_sd = S.dev(sym), S.dev(means), S.dev(stds)
             st = L.cst_ans_encode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_sym), S.ptr(d_mu), S.ptr(d_sd), 1, n,
-                                                 N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap, S.ptr(d_n), S.ptr(d_state),
-                                                 S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                                 N.LAYOUT_STREAM_MAJOR, S.ptr(d_words), cap, d_n, d_state,
+                                                 d_status, N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
             idx = sym.astype(np.int64) - kind[2]
@@ -144,14 +143,13 @@ class AnsCoder:
             prob = np.where(ok, rows[ar, safe + 1].astype(np.int64) - left.astype(np.int64), 0).astype(np.uint32)
             d_left, d_prob = S.dev(left.view(np.int32)), S.dev(prob.view(np.int32))
             st = L.cst_ans_encode_cp_batch(S.cfg(), S.ptr(d_left), S.ptr(d_prob), 1, n, N.LAYOUT_STREAM_MAJOR, S.ptr(d_words),
-                                           cap, S.ptr(d_n), S.ptr(d_state), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                           cap, d_n, d_state, d_status, N.FLAG_RAW_STATE, sp)
         N.check(st, "ans encode")
-        torch.cuda.current_stream().synchronize()
-        S.raise_for_status(int(d_status.item()))
-        k = int(d_n.item())
+        state, k, _, status = sc.read()
+        S.raise_for_status(status)
         if k:
             self._bulk = np.concatenate([self._bulk, d_words[:k].cpu().numpy().view(np.uint32)])
-        self._state = int(np.int64(d_state.item()).astype(np.uint64))
+        self._state = state
 
     def decode(self, model, *optional_amt_or_model_params):
         params = optional_amt_or_model_params
@@ -172,34 +170,32 @@ class AnsCoder:
         tail = min(len(self._bulk), amt)
         words = self._bulk[len(self._bulk) - tail:]
         d_words = S.dev(words.view(np.int32)) if tail else torch.zeros(4, dtype=torch.int32, device="cuda")
-        d_n = torch.tensor([tail], dtype=torch.int32, device="cuda")
-        d_n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_status = torch.zeros(1, dtype=torch.int32, device="cuda")
-        d_state = torch.tensor([np.uint64(self._state).astype(np.int64)], dtype=torch.int64, device="cuda")
+        sc = S.Scalars(self._state, tail)
+        d_n, d_n_out, d_state, d_status = sc.p(sc.N), sc.p(sc.N_OUT), sc.p(sc.STATE), sc.p(sc.STATUS)
         d_sym = torch.empty(amt, dtype=torch.int32, device="cuda")
         sp = S.stream_ptr()
         if kind[0] == "table":
-            st = L.cst_ans_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(tail, 1), S.ptr(d_n), S.ptr(d_sym), 1, amt,
-                                        N.LAYOUT_STREAM_MAJOR, S.ptr(d_state), S.ptr(d_n_out), S.ptr(d_status),
+            st = L.cst_ans_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_sym), 1, amt,
+                                        N.LAYOUT_STREAM_MAJOR, d_state, d_n_out, d_status,
                                         N.FLAG_RAW_STATE, sp)
         elif kind[0] == "gaussian":
             _, lo, hi, means, stds = kind
             d_mu, d_sd = S.dev(means), S.dev(stds)
-            st = L.cst_ans_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(tail, 1), S.ptr(d_n), S.ptr(d_mu),
-                                                 S.ptr(d_sd), S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, S.ptr(d_state),
-                                                 S.ptr(d_n_out), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+            st = L.cst_ans_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_mu),
+                                                 S.ptr(d_sd), S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, d_state,
+                                                 d_n_out, d_status, N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
             d_rows = S.dev(rows.view(np.int32))
-            st = L.cst_ans_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(tail, 1), S.ptr(d_n), S.ptr(d_rows),
+            st = L.cst_ans_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_rows),
                                              rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR,
-                                             S.ptr(d_state), S.ptr(d_n_out), S.ptr(d_status), N.FLAG_RAW_STATE, sp)
+                                             d_state, d_n_out, d_status, N.FLAG_RAW_STATE, sp)
         N.check(st, "ans decode")
-        torch.cuda.current_stream().synchronize()
-        S.raise_for_status(int(d_status.item()))
-        consumed = tail - int(d_n_out.item())
+        state, _, n_left, status = sc.read()
+        S.raise_for_status(status)
+        consumed = tail - n_left
         if consumed:
             self._bulk = self._bulk[: len(self._bulk) - consumed].copy()
-        self._state = int(np.int64(d_state.item()).astype(np.uint64))
+        self._state = state
         out = d_sym.cpu().numpy()
         return int(out[0]) if scalar else out
