@@ -5,6 +5,10 @@ import sys
 from pathlib import Path
 import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+import constriction_amd._native as N
+if os.environ.get("LIB"):          # a variant library built by scripts/exp_variants.sh
+    N.LIB_PATH = Path(os.environ["LIB"]).resolve()
 import bench
 from constriction_amd import batched as B
 

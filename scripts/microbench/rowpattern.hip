@@ -4,9 +4,9 @@
 #include <cstdio>
 #include <cstdint>
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kRows = 65536, kRowBytes = 16384;
+constexpr int kRows = 65536;
 
-template <int SEG, int MODE>   // MODE 0 read, 1 write, 2 copy
+template <int SEG, int MODE, int kRowBytes>   // MODE 0 read, 1 write, 2 copy
 __global__ __launch_bounds__(256) void k(const char* __restrict__ in, char* __restrict__ out, int* sink) {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -33,21 +33,24 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ in, char* __re
     }
     if (MODE == 0 && acc.x == 0x12345678) sink[0] = acc.y;
 }
-template <int SEG, int MODE> void run(const char* in, char* out, int* sink) {
+template <int SEG, int MODE, int kRowBytes = 16384> void run(const char* in, char* out, int* sink) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<SEG, MODE>), dim3(kRows / 256), dim3(256), 0, 0, in, out, sink);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<SEG, MODE, kRowBytes>), dim3(kRows / 256), dim3(256), 0, 0, in, out, sink);
     (void)hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<SEG, MODE>), dim3(kRows / 256), dim3(256), 0, 0, in, out, sink);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<SEG, MODE, kRowBytes>), dim3(kRows / 256), dim3(256), 0, 0, in, out, sink);
     (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     const double gb = (double)kRows * kRowBytes * (MODE == 2 ? 2 : 1) / 1e9;
-    printf("segment %4d B  %-5s: %.3f ms  %.2f TB/s\n", SEG, MODE == 0 ? "read" : MODE == 1 ? "write" : "copy", ms, gb / ms);
+    printf("rows of %5d B, segment %4d B  %-5s: %.3f ms  %.2f TB/s\n", kRowBytes, SEG, MODE == 0 ? "read" : MODE == 1 ? "write" : "copy", ms, gb / ms);
 }
 int main() {
-    char *a, *b; int* s; (void)hipMalloc(&a, (size_t)kRows * kRowBytes); (void)hipMalloc(&b, (size_t)kRows * kRowBytes); (void)hipMalloc(&s, 64);
-    (void)hipMemset(a, 1, (size_t)kRows * kRowBytes);
+    constexpr size_t kMax = (size_t)kRows * 65536;
+    char *a, *b; int* s; (void)hipMalloc(&a, kMax); (void)hipMalloc(&b, kMax); (void)hipMalloc(&s, 64);
+    (void)hipMemset(a, 1, kMax);
     run<128, 0>(a, b, s); run<256, 0>(a, b, s); run<512, 0>(a, b, s); run<1024, 0>(a, b, s);
     run<128, 1>(a, b, s); run<256, 1>(a, b, s); run<512, 1>(a, b, s); run<1024, 1>(a, b, s);
     run<128, 2>(a, b, s); run<256, 2>(a, b, s); run<512, 2>(a, b, s); run<1024, 2>(a, b, s);
+    // the same pattern over longer rows (2 GiB, 4 GiB)
+    run<128, 0, 32768>(a, b, s); run<128, 1, 32768>(a, b, s); run<128, 0, 65536>(a, b, s); run<128, 1, 65536>(a, b, s);
     return 0;
 }
