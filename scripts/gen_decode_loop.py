@@ -108,7 +108,7 @@ def gen():
             if NO_STORE:
                 a.vm.append(f"store{quad}")
             else:
-                a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] {os.environ.get('GEN_STORE_MOD', 'nt')}".rstrip(), f"store{quad}")
+                a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] {os.environ.get('GEN_STORE_MOD', 'nt').replace('+', ' ')}".rstrip(), f"store{quad}")
         if pos == 3:
             base = (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{134 + base}:{137 + base}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
