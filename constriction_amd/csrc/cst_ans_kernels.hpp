@@ -381,16 +381,25 @@ struct RingReader {
     // direct HBM access to word `i` of the stream (initial-state words)
     __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
 
-    // fill the ring with the kAhead words below the read position (blocking; once per stream)
+    // fill the ring with the kAhead words below the read position (once per stream).  Every chunk is requested before
+    // the first one is waited for: the loop form paid one HBM round trip per chunk at the start of every kernel.
     __device__ __forceinline__ void prime() {
         const uint32_t top = rd + shift;
-        lo_issued = (top + 3) & ~3u;
+        const uint32_t start = (top + 3) & ~3u;
         const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
-        while (lo_issued > want_lo) {
-            lo_issued -= 4;
-            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
-            uint32_t* b = slot(lo_issued);   // chunk positions are multiples of 4: slots are base + i * kWave
-            b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
+        constexpr int KMAX = AHEAD / 4 + 2;       // chunks between want_lo and the rounded-up top
+        uint4 v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (start > want_lo + 4u * (uint32_t)k) v[k] = *reinterpret_cast<const uint4*>(base16 + (start - 4u * (uint32_t)(k + 1)));
+        lo_issued = start;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (start > want_lo + 4u * (uint32_t)k) {
+                lo_issued = start - 4u * (uint32_t)(k + 1);
+                uint32_t* b = slot(lo_issued);   // chunk positions are multiples of 4: slots are base + i * kWave
+                b[0] = v[k].x; b[kWave] = v[k].y; b[2 * kWave] = v[k].z; b[3 * kWave] = v[k].w;
+            }
         }
     }
 
