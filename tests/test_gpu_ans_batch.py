@@ -682,3 +682,26 @@ def test_bucket_entry_decoder_walks_the_tails(B, O, P):
         torch.cuda.synchronize()
         assert st3.cpu().numpy().tolist() == want_st.tolist()
         assert np.array_equal(more.cpu().numpy(), want_more)
+
+
+def test_packed_container_through_the_gpu(B, O, tmp_path):
+    """encode -> compact -> container file -> load -> decode from the packed form; every stream's slice of the file is the
+    array one reference coder would have written with `tofile` (src/pybindings/stream/stack.rs:149-166)"""
+    from constriction_amd import container
+    P = 24
+    model, cdf = make_model(B, O, P)
+    sym = O.synth_symbols(0xC0FFEE, 3, 200, 333, -50, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, -50, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    torch.cuda.synchronize()
+    path = tmp_path / "batch.cst"
+    container.save(path, packed, offsets, (32, 64, P))
+    words, off, cfg = container.load(path)
+    assert cfg == (32, 64, P)
+    for s in (0, 57, 199):
+        assert words[off[s]: off[s + 1]].tolist() == want_words[s, : want_n[s]].tolist()
+    n_words = np.diff(off.astype(np.int64)).astype(np.int32)
+    dec, st = B.ans_decode((dev(words.view(np.int32)), dev(n_words)), model, 333, offsets=dev(off.astype(np.int64)), config=cfg)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)

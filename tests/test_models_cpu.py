@@ -93,3 +93,30 @@ def test_categorical_flags_like_the_reference(capsys):
     assert M.Bernoulli(0.25, perfect=False).cdf.tolist() == M.fast_quantized_cdf(np.array([0.75, 0.25])).tolist()
     with pytest.raises(ValueError):
         M.Bernoulli(1.5, perfect=True)       # (the fast quantisation does not look at signs: categorical.rs:16-54)
+
+
+def test_packed_batch_container_roundtrip(tmp_path):
+    """the wire format of a packed batch (counterpart of `compressed.tofile` in the reference's docs): little-endian on disk,
+    every stream's slice unchanged, malformed files rejected"""
+    import numpy as np
+    from constriction_amd import container
+    rng = np.random.default_rng(4)
+    lens = rng.integers(0, 9, 13)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    words = rng.integers(0, 2 ** 32, int(offsets[-1]) + 5, dtype=np.uint64).astype(np.uint32)   # (capacity may exceed the total)
+    path = tmp_path / "batch.cst"
+    container.save(path, words, offsets, (32, 64, 24))
+    got_words, got_offsets, cfg = container.load(path)
+    assert cfg == (32, 64, 24) and got_offsets.tolist() == offsets.tolist()
+    assert got_words.tolist() == words[: int(offsets[-1])].tolist()
+    raw = path.read_bytes()
+    assert raw[:8] == b"CSTPACK1" and raw[40 + 8 * 14: 40 + 8 * 14 + 4] == int(words[0]).to_bytes(4, "little")
+    import pytest
+    (tmp_path / "short.cst").write_bytes(raw[:-3])
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "short.cst")
+    (tmp_path / "magic.cst").write_bytes(b"X" + raw[1:])
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "magic.cst")
+    with pytest.raises(ValueError):
+        container.save(tmp_path / "bad.cst", words, offsets[::-1].copy(), (32, 64, 24))
