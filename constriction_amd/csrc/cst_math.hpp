@@ -128,10 +128,107 @@ __device__ inline double erf_exact(double x) {
     return sign ? -y : y;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same erf for kernels whose lanes sit in DIFFERENT branches of it (one model per lane): a wave pays for every
+// branch some lane takes, and the four rational approximations above (98 multiply-adds, 120 f64 constants that do
+// not fit the scalar registers) are the bulk.  Here every lane runs ONE Horner recurrence of degree 8 over its own
+// branch's coefficients, read per lane from a 576-byte LDS table; shorter polynomials are padded with zero
+// coefficients at the high end, which leaves every partial result unchanged (c + s * 0 == c exactly).  The two exp of
+// the erfc branches run straight-line (their arguments are bounded there).  Same operations in the same order as
+// erf_exact on every path, hence the same bits; tests/test_gpu_ans_batch.py compares both with the CPU oracle.
+
+constexpr int kErfTabEntries = 4 * 9;             // [branch][k] -> {numerator[k], denominator[k]}
+
+__device__ const double kErfTabInit[kErfTabEntries * 2] = {
+    // |x| < 0.84375: pp / qq in z = x * x
+    1.28379167095512558561e-01, 1.0, -3.25042107247001499370e-01, 3.97917223959155352819e-01,
+    -2.84817495755985104766e-02, 6.50222499887672944485e-02, -5.77027029648944159157e-03, 5.08130628187576562776e-03,
+    -2.37630166566501626084e-05, 1.32494738004321644526e-04, 0.0, -3.96022827877536812320e-06, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+    // 0.84375 <= |x| < 1.25: pa / qa in s = |x| - 1
+    -2.36211856075265944077e-03, 1.0, 4.14856118683748331666e-01, 1.06420880400844228286e-01,
+    -3.72207876035701323847e-01, 5.40397917702171048937e-01, 3.18346619901161753674e-01, 7.18286544141962662868e-02,
+    -1.10894694282396677476e-01, 1.26171219808761642112e-01, 3.54783043256182359371e-02, 1.36370839120290507362e-02,
+    -2.16637559486879084300e-03, 1.19844998467991074170e-02, 0.0, 0.0, 0.0, 0.0,
+    // 1.25 <= |x| < 1/0.35: ra / sa in s = 1 / x^2
+    -9.86494403484714822705e-03, 1.0, -6.93858572707181764372e-01, 1.96512716674392571292e+01,
+    -1.05586262253232909814e+01, 1.37657754143519042600e+02, -6.23753324503260060396e+01, 4.34565877475229228821e+02,
+    -1.62396669462573470355e+02, 6.45387271733267880336e+02, -1.84605092906711035994e+02, 4.29008140027567833386e+02,
+    -8.12874355063065934246e+01, 1.08635005541779435134e+02, -9.81432934416914548592e+00, 6.57024977031928170135e+00,
+    0.0, -6.04244152148580987438e-02,
+    // 1/0.35 <= |x| < 6: rb / sb in s = 1 / x^2
+    -9.86494292470009928597e-03, 1.0, -7.99283237680523006574e-01, 3.03380607434824582924e+01,
+    -1.77579549177547519889e+01, 3.25792512996573918826e+02, -1.60636384855821916062e+02, 1.53672958608443695994e+03,
+    -6.37566443368389627722e+02, 3.19985821950859553908e+03, -1.02509513161107724954e+03, 2.55305040643316442583e+03,
+    -4.83519191608651397019e+02, 4.74528541206955367215e+02, 0.0, -2.24409524465858183362e+01, 0.0, 0.0,
+};
+
+// every thread of the block calls this once (then __syncthreads, or a wave fence if `tab` is private to the wave)
+__device__ __forceinline__ void erf_tab_fill(double2* tab, int tid, int n_threads) {
+    for (int i = tid; i < kErfTabEntries; i += n_threads) tab[i] = make_double2(kErfTabInit[2 * i], kErfTabInit[2 * i + 1]);
+}
+
+// exp_exact for 2^-28 < |x| < 700, without branches: k == 0 multiplies by 2^0, lo == 0.0 subtracts nothing
+__device__ __forceinline__ double exp_exact_bounded(double x) {
+    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                     invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                     P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                     P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const uint32_t hx = f64_hi(x) & 0x7fffffffu;
+    const bool neg = (f64_hi(x) >> 31) != 0;
+    const bool reduce = hx > 0x3fd62e42u;
+    const int kg = (int)(invln2 * x + (neg ? -0.5 : 0.5));
+    const int k = !reduce ? 0 : hx >= 0x3ff0a2b2u ? kg : neg ? -1 : 1;
+    const double kd = (double)k;
+    const double hi = reduce ? x - kd * ln2hi : x;
+    const double lo = reduce ? kd * ln2lo : 0.0;
+    const double r = reduce ? hi - lo : x;
+    const double xx = r * r;
+    const double c = r - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    const double y = 1.0 + (r * c / (2.0 - c) - lo + hi);
+    const double scaled = y * f64_pow2(k);
+    return hx > 0x3e300000u ? scaled : 1.0 + x;
+}
+
+__device__ inline double erf_exact_tab(double x, const double2* tab) {
+    constexpr double erx = 8.45062911510467529297e-01, efx8 = 1.02703333676410069053e+00;
+    const uint32_t hx = f64_hi(x), ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    const double ax = fabs(x);
+    const uint32_t branch = (ix >= 0x3feb0000u ? 1u : 0u) + (ix >= 0x3ff40000u ? 1u : 0u) + (ix >= 0x4006db6du ? 1u : 0u);
+    const bool tail = ix >= 0x3ff40000u && ix < 0x40180000u;        // 1.25 <= |x| < 6: exp(-x^2 + R / S) / x
+    // all nine LDS reads are requested before the division below, which covers their latency
+    const double2* c = tab + branch * 9;
+    double2 t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = c[k];
+    double s = branch == 0 ? x * x : ax - 1.0;
+    if (tail) s = 1.0 / (ax * ax);
+    double num = t[8].x, den = t[8].y;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) { num = t[k].x + s * num; den = t[k].y + s * den; }
+    const double quot = num / den;
+    double y = 1.0 - ((1.0 - erx) - quot);                          // 0.84375 <= |x| < 1.25
+    if (tail) {
+        const double z = f64_clear_lo(ax);
+        y = 1.0 - exp_exact_bounded(-z * z - 0.5625) * exp_exact_bounded((z - ax) * (z + ax) + quot) / ax;
+    }
+    if (ix >= 0x40180000u) y = 1.0 - 0x1p-1022;                     // (and +-inf: (1 - 2 sign) + 1 / x)
+    y = neg ? -y : y;
+    if (ix < 0x3feb0000u) y = x + x * quot;
+    if (ix < 0x3e300000u) y = 0.125 * (8.0 * x + efx8 * x);
+    if (x != x) y = x;
+    return y;
+}
+
 // probability::distribution::Gaussian::distribution (third-party; used at quantize.rs:546,558)
-__device__ __forceinline__ double gaussian_cdf_exact(double x, double mu, double sigma) {
+// (TAB: erf_exact_tab with the LDS table `tab` instead of the branchy erf_exact -- same bits either way.  A template
+// flag, not a null test: address 0 is a valid LDS address, so the compiler would keep both.)
+template <bool TAB = false>
+__device__ __forceinline__ double gaussian_cdf_exact(double x, double mu, double sigma, const double2* tab = nullptr) {
     constexpr double sqrt2 = 1.41421356237309504880168872420969808;
-    return (1.0 + erf_exact((x - mu) / (sigma * sqrt2))) / 2.0;
+    const double arg = (x - mu) / (sigma * sqrt2);
+    if constexpr (TAB) return (1.0 + erf_exact_tab(arg, tab)) / 2.0;
+    else return (1.0 + erf_exact(arg)) / 2.0;
 }
 
 // Rust `f64 as u32`
@@ -144,8 +241,9 @@ __device__ __forceinline__ uint32_t f64_as_u32_sat(double v) {
 // LeakilyQuantizedDistribution::left_cumulative_and_probability, quantize.rs:525-568, for
 // Symbol=i32 and Probability=u{prob_bits}.  Returns false if sym is outside [lo, hi].
 // `left` and `prob` are wrapped to prob_bits bits; prob == 0 signals an invalid distribution.
-__device__ inline bool leaky_gaussian_lcp(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu,
-                                          double sigma, uint32_t& left, uint32_t& prob) {
+template <bool TAB = false>
+__device__ __forceinline__ bool leaky_gaussian_lcp(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu,
+                                                   double sigma, uint32_t& left, uint32_t& prob, const double2* tab = nullptr) {
     if (sym < lo || sym > hi) return false;
     const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
     const uint32_t max_prob = pmask >> (prob_bits - P);
@@ -153,9 +251,9 @@ __device__ inline bool leaky_gaussian_lcp(int32_t sym, int32_t lo, int32_t hi, i
     const uint32_t slack = ((uint32_t)sym - (uint32_t)lo) & pmask;               // quantize.rs:475-486
     uint32_t l, r;
     if (sym == lo) l = 0u;
-    else l = (f64_as_u32_sat(free_weight * gaussian_cdf_exact((double)sym - 0.5, mu, sigma)) + slack) & pmask;
+    else l = (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>((double)sym - 0.5, mu, sigma, tab)) + slack) & pmask;
     if (sym == hi) r = (P >= 32 ? 0u : (1u << P)) & pmask;
-    else r = (f64_as_u32_sat(free_weight * gaussian_cdf_exact((double)sym + 0.5, mu, sigma)) + slack + 1u) & pmask;
+    else r = (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>((double)sym + 0.5, mu, sigma, tab)) + slack + 1u) & pmask;
     left = l;
     prob = (r - l) & pmask;
     return true;
@@ -163,15 +261,16 @@ __device__ inline bool leaky_gaussian_lcp(int32_t sym, int32_t lo, int32_t hi, i
 
 // left cumulative of symbol index i in [0, n]  (i == n gives 2^P); used to tabulate a model and for
 // decode-side searches.  Bit-identical to the `left` of leaky_gaussian_lcp(lo + i).
-__device__ inline uint32_t leaky_gaussian_left(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
-                                               double sigma) {
+template <bool TAB = false>
+__device__ __forceinline__ uint32_t leaky_gaussian_left(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
+                                                        double sigma, const double2* tab = nullptr) {
     const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
     if (i <= 0) return 0u;
     if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
     const uint32_t max_prob = pmask >> (prob_bits - P);
     const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
     const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
-    return (f64_as_u32_sat(free_weight * gaussian_cdf_exact(x, mu, sigma)) + (uint32_t)i) & pmask;
+    return (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>(x, mu, sigma, tab)) + (uint32_t)i) & pmask;
 }
 
 } // namespace cst

@@ -15,6 +15,9 @@ namespace cst {
 __global__ void gaussian_cdf_kernel(int P, int32_t lo, int32_t n, const double* __restrict__ means,
                                     const double* __restrict__ stds, double mean0, double std0, size_t n_tables,
                                     uint32_t* __restrict__ cdf) {
+    __shared__ double2 erf_tab[kErfTabEntries];
+    erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)n + 1;
     if (gid >= n_tables * per) return;
@@ -22,7 +25,7 @@ __global__ void gaussian_cdf_kernel(int P, int32_t lo, int32_t n, const double* 
     const int32_t i = (int32_t)(gid - tbl * per);
     const double mu = means ? means[tbl] : mean0;
     const double sd = stds ? stds[tbl] : std0;
-    cdf[gid] = leaky_gaussian_left(i, lo, n, P, 32, mu, sd);
+    cdf[gid] = leaky_gaussian_left<true>(i, lo, n, P, 32, mu, sd, erf_tab);
 }
 
 // 16-bit per-stream cdf rows for the LDS-resident per-stream models (values modulo 2^16).  Also validates
@@ -186,6 +189,14 @@ __global__ void indices_to_symbols_kernel(const int32_t* __restrict__ symbol_of_
 __global__ void debug_erf_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = erf_exact(x[i]);
+}
+
+__global__ void debug_erf_tab_kernel(const double* __restrict__ x, double* __restrict__ out, size_t n) {
+    __shared__ double2 tab[kErfTabEntries];
+    erf_tab_fill(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = erf_exact_tab(x[i], tab);
 }
 
 __global__ void debug_lcp_kernel(int P, int prob_bits, int32_t lo, int32_t hi, const int32_t* __restrict__ sym,
@@ -449,6 +460,14 @@ cst_status cst_model_get_cdf(const cst_model* m, size_t index, uint32_t* h_cdf, 
     const size_t per = (size_t)m->n_symbols + 1;
     CST_HIP_TRY(hipMemcpyAsync(h_cdf, m->d_cdf + index * per, 4 * per, hipMemcpyDeviceToHost, (hipStream_t)stream));
     CST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CST_OK;
+}
+
+cst_status cst_debug_erf_tab(const double* d_x, double* d_out, size_t n, void* stream) {
+    if (!d_x || !d_out) return CST_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(debug_erf_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_out, n);
+    CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
 

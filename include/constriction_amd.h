@@ -357,6 +357,8 @@ cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_w
  * out[i] = erf(x[i]) resp. Gaussian cdf, evaluated by the same device code the table kernels use.
  * ---------------------------------------------------------------------------------------- */
 cst_status cst_debug_erf(const double *d_x, double *d_out, size_t n, void *stream);
+/* the same erf as the per-symbol kernels evaluate it (one Horner recurrence over per-lane coefficients from LDS) */
+cst_status cst_debug_erf_tab(const double *d_x, double *d_out, size_t n, void *stream);
 cst_status cst_debug_gaussian_lcp(int32_t precision, int32_t prob_bits, int32_t min_symbol, int32_t max_symbol,
                                   const int32_t *d_symbols, const double *d_means, const double *d_stds,
                                   uint32_t *d_left, uint32_t *d_prob, size_t n, void *stream);

@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(path)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r['Kernel_Name']
-    if 'ans_' in k or 'range_' in k:
+    if any(t in k for t in ('ans_', 'range_', 'gaussian', 'entries', 'decode_wave')):
         agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in agg.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}

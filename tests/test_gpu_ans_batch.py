@@ -41,15 +41,17 @@ def test_device_erf_bit_exact(B, O):
         -(10.0 ** rng.uniform(-320, 3, 50_000)),
         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 0.84375, 1.25, 2.857142857142857, 6.0, 1e-300, 5e-324, 2.0 ** -28]),
     ])
+    x = np.concatenate([x, np.nextafter(x[-12:], np.inf), np.nextafter(x[-12:], -np.inf), -x[-12:]])
     dx = dev(x)
-    dout = torch.empty_like(dx)
-    N.check(N.lib().cst_debug_erf(dx.data_ptr(), dout.data_ptr(), dx.numel(), None), "erf")
-    torch.cuda.synchronize()
-    got = dout.cpu().numpy()
     lib = O.load()
     want = np.array([lib.cst_oracle_erf(float(v)) for v in x])
-    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
-    assert same.all(), f"{(~same).sum()} of {len(x)} erf values differ, first at x={x[~same][0]!r}"
+    for fn in ("cst_debug_erf", "cst_debug_erf_tab"):       # the branchy erf and the table-driven one of the per-symbol kernels
+        dout = torch.empty_like(dx)
+        N.check(getattr(N.lib(), fn)(dx.data_ptr(), dout.data_ptr(), dx.numel(), None), fn)
+        torch.cuda.synchronize()
+        got = dout.cpu().numpy()
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), f"{fn}: {(~same).sum()} of {len(x)} erf values differ, first at x={x[~same][0]!r}"
 
 
 @pytest.mark.parametrize("lo,hi,P,prob_bits", [(-100, 100, 24, 32), (-50, 50, 12, 16), (-127, 127, 12, 16), (0, 1, 1, 16),

@@ -98,3 +98,29 @@ def test_gaussian_per_symbol_batch_errors(B, O):
     c = O.AnsCoder()
     c.encode_gaussian_reverse(sym2[1], lo2, hi2, mu2[1], sd2[1], 24, 32)
     assert enc2.stream(1).tolist() == c.get_compressed().tolist()
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+def test_gaussian_per_symbol_decode_of_random_words_extreme_models(B, O, cfg):
+    """Decoding RANDOM words draws every quantile, the far tails included, and the models here are the hard ones for a
+    search that starts from an inverse-CDF guess: needle-thin and very wide Gaussians, means far outside the support
+    (all the mass in the leak), supports of two symbols.  The lane-per-stream decoder must find the reference's symbol."""
+    W, S, P = cfg
+    rng = np.random.default_rng(P)
+    n_streams, n_per = 130, 70
+    for lo, hi in ((-100, 100), (0, 1), (-5, 2000 if P == 24 else 900)):
+        mu = rng.uniform(lo - 50.0, hi + 50.0, (n_streams, n_per))
+        sd = np.exp(rng.uniform(np.log(1e-7), np.log(1e6), (n_streams, n_per)))
+        mu[:, 0] = lo - 1e9; mu[:, 1] = hi + 1e9; sd[:, 2] = 1e-300; sd[:, 3] = 1e300
+        stride = 160
+        words = rng.integers(1, 1 << W, (n_streams, stride), dtype=np.uint64).astype(np.uint32)
+        enc = B.EncodedBatch(dev(words.view(np.int32)), dev(np.full(n_streams, stride, np.int32)), dev(np.zeros(n_streams, np.int32)), cfg)
+        dec, st = B.ans_decode_gaussian(enc, lo, hi, dev(mu), dev(sd))
+        torch.cuda.synchronize()
+        dec = dec.cpu().numpy()
+        assert (st.cpu().numpy() == 0).all()
+        for s in range(0, n_streams, 3):
+            comp = words[s] if W == 32 else words[s].astype(np.uint16)
+            c = O.AnsCoder(comp, W=W, S=S)
+            want = c.decode_gaussian(n_per, lo, hi, mu[s], sd[s], P, 32 if W == 32 else 16)
+            assert dec[s].tolist() == list(want), f"stream {s} support [{lo}, {hi}]"
