@@ -69,6 +69,8 @@ struct EntriesEncodeArgs {
     uint32_t flags;
 };
 
+constexpr int kEntryGroup = 8;     // entries requested together (8 x 16 bytes = one 128-byte line of a stream-major row)
+
 // one lane per stream over precomputed entries; ANS walks backwards, the range coder forwards
 template <int W, int S, int KIND>
 __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEncodeArgs a) {
@@ -93,13 +95,39 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
         EncLane<W, S> L;
         L.init(slab, cap, ring, lane);
         if (raw && active) L.state = (typename StateT<S>::type)a.state[s];
-        for (size_t t = N; t-- > 0;) {
+        // entries come kEntryGroup at a time, one group ahead of their use: a lone wave per SIMD has no other wave to
+        // hide a load behind, and the address of every entry is known from the start
+        const size_t tail = N % kEntryGroup;
+        for (size_t t = N; t-- > N - tail;) {
             if (active) {
                 const EncEntry e = my[t * stride_t];
                 if (e.p == 0) bad = 1;
                 else if (!bad) L.template step<false>(e, P);
             }
             if (--countdown == 0) { countdown = G4; L.flush_chunks(); }
+        }
+        EncEntry cur[kEntryGroup], nxt[kEntryGroup];
+        size_t g = N - tail;                       // entries [g - kEntryGroup, g) are the next group
+        if (g > 0 && active) {
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) nxt[j] = my[(g - 1 - j) * stride_t];
+        }
+        while (g > 0) {
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) cur[j] = nxt[j];
+            g -= kEntryGroup;
+            if (g > 0 && active) {
+#pragma unroll
+                for (int j = 0; j < kEntryGroup; ++j) nxt[j] = my[(g - 1 - j) * stride_t];
+            }
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) {
+                if (active) {
+                    if (cur[j].p == 0) bad = 1;
+                    else if (!bad) L.template step<false>(cur[j], P);
+                }
+                if (--countdown == 0) { countdown = G4; L.flush_chunks(); }
+            }
         }
         status = L.finish(!raw, 1u, n_words);
         if (active && raw) a.state[s] = (uint64_t)L.state;
@@ -111,7 +139,31 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
             L.lower = (typename StateT<S>::type)r.lower; L.range = (typename StateT<S>::type)r.range;
             L.inv_n = r.inverted_n; L.inv_first = r.inverted_first;
         }
-        for (size_t t = 0; t < N; ++t) {
+        EncEntry cur[kEntryGroup], nxt[kEntryGroup];
+        const size_t n_grouped = N - N % kEntryGroup;
+        size_t g = 0;                              // entries [g, g + kEntryGroup) are the next group
+        if (n_grouped > 0 && active) {
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) nxt[j] = my[j * stride_t];
+        }
+        while (g < n_grouped) {
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) cur[j] = nxt[j];
+            g += kEntryGroup;
+            if (g < n_grouped && active) {
+#pragma unroll
+                for (int j = 0; j < kEntryGroup; ++j) nxt[j] = my[(g + j) * stride_t];
+            }
+#pragma unroll
+            for (int j = 0; j < kEntryGroup; ++j) {
+                if (active) {
+                    if (cur[j].p == 0) bad = 1;
+                    else if (!bad) L.step(cur[j].c, cur[j].p, P);
+                }
+                if (--countdown == 0) { countdown = G4; L.out.flush_chunks(); }
+            }
+        }
+        for (size_t t = n_grouped; t < N; ++t) {
             if (active) {
                 const EncEntry e = my[t * stride_t];
                 if (e.p == 0) bad = 1;
@@ -161,6 +213,8 @@ struct PerSymbolDecodeArgs {
     uint32_t flags;
 };
 
+struct DecodeResume { uint64_t s0, s1, s2; uint32_t pos; int32_t status; };
+
 // Uniform (per-wave or per-lane) coder front end reading words straight from HBM.
 template <int W, int S, int KIND> struct DirectDecoder;
 
@@ -193,6 +247,14 @@ struct DirectDecoder<W, S, kAns> {
     }
     __device__ __forceinline__ void finish(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
         if (raw) { a.state[s] = (uint64_t)state; if (a.n_words_out) a.n_words_out[s] = rd; }
+    }
+    // a decoder parked between two launches over consecutive pieces of the same stream
+    __device__ __forceinline__ void park(DecodeResume& r) const { r.s0 = (uint64_t)state; r.pos = rd; }
+    __device__ __forceinline__ void resume(const PerSymbolDecodeArgs& a, size_t s, const DecodeResume& r) {
+        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        idle = a.n_words + s; status = CST_STREAM_OK; ahead = 0;
+        state = (st_t)r.s0; rd = r.pos;
+        look_ahead();
     }
 };
 
@@ -230,6 +292,15 @@ struct DirectDecoder<W, S, kRange> {
             r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.point = (uint64_t)L.point; r.position = pos;
             a.rstate[s] = r;
         }
+    }
+    __device__ __forceinline__ void park(DecodeResume& r) const {
+        r.s0 = (uint64_t)L.lower; r.s1 = (uint64_t)L.range; r.s2 = (uint64_t)L.point; r.pos = pos;
+    }
+    __device__ __forceinline__ void resume(const PerSymbolDecodeArgs& a, size_t s, const DecodeResume& r) {
+        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        idle = a.n_words + s; len = a.n_words[s]; status = CST_STREAM_OK; L.status = CST_STREAM_OK; ahead = 0;
+        L.lower = (st_t)r.s0; L.range = (st_t)r.s1; L.point = (st_t)r.s2; pos = r.pos;
+        look_ahead();
     }
 };
 
@@ -439,6 +510,167 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     D.finish(a, s, raw);
 }
 
+// FEWER streams than a wave has lanes -- down to the reference's own usage, ONE coder and a long message.  Decoding a
+// stream is sequential, and with the model search inside the chain every symbol costs an erf latency (1.7 us).  But
+// only the QUANTILE depends on the coder state, the models do not: a first kernel tabulates every symbol's whole cdf row
+// at full occupancy (256 erf per symbol: 2.4 ms per million symbols), and the sequential kernel is left with a lookup.
+// A row is 256 left cumulatives (supports up to 255 symbols, padded with 2^P); lane l of the stream's wave holds
+// entries 4l..4l+3 of the current row in registers, straight from one coalesced 1-KiB load issued eight symbols
+// earlier.  One ballot finds the lane, three compares the entry: ~45 instructions per symbol instead of ~600.
+constexpr int kRowEntries = 256;
+constexpr int kRowsAhead = 16;
+
+__global__ __launch_bounds__(kRowEntries) void gaussian_rows_kernel(int P, int32_t lo, int32_t n, const double* __restrict__ means,
+                                                                   const double* __restrict__ stds, int32_t layout, size_t n_streams,
+                                                                   size_t N, size_t t0, size_t count, uint32_t* __restrict__ rows) {
+    __shared__ double2 erf_tab[kErfTabEntries];
+    erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const size_t row = blockIdx.x;                     // = stream * count + (t - t0)
+    const size_t s = row / count, t = t0 + row % count;
+    const size_t e = layout == CST_LAYOUT_SYMBOL_MAJOR ? t * n_streams + s : s * N + t;
+    const double mu = means[e], sd = stds[e];
+    const int32_t i = (int32_t)threadIdx.x;
+    const uint32_t total = 1u << P;
+    uint32_t v;
+    if (sd > 0.0 && sd <= 1.7976931348623157e308 && fabs(mu) <= 1.7976931348623157e308)
+        v = i <= n ? leaky_gaussian_left<true>(i, lo, n, P, 32, mu, sd, erf_tab) : total;
+    else v = i == 0 ? 0xffffffffu : total;             // invalid model (a valid row starts with 0)
+    rows[row * kRowEntries + i] = v;
+}
+
+struct RowsDecodeArgs {
+    PerSymbolDecodeArgs a;
+    const uint4* rows;          // [stream][count][64 lanes] x 4 entries
+    size_t t0, count;
+    DecodeResume* resume;       // [stream]
+    int32_t first, last;
+};
+
+// The row queue and the word blocks below are plain loads: the compiler's own counter bookkeeping waits, at the use of a
+// row, for exactly the loads older than the fifteen youngest -- as long as NO other load sits in the loop (a per-symbol
+// look-ahead of the next compressed word, waited for every symbol, drags the whole in-order queue with it and collapses
+// the 16-deep queue to depth one; measured 340 ns per symbol).  Hand-issued loads in inline asm are not an option in a
+// C++ loop: the compiler copies loop-carried registers at the bottom of the loop, in flight or not.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// The stream's compressed words, 64 at a time in one register across the wave (lane l: the l-th word from the block's
+// origin in reading direction).  A symbol consumes at most one word, so a block fetched at the start of a 64-symbol
+// group lasts for the whole group.
+template <int KIND>
+struct WordBlock {
+    uint32_t cur;
+    uint32_t origin;                    // read position the block starts at (ANS: counts down, range: up)
+    __device__ __forceinline__ void fetch(const uint32_t* in, uint32_t len, uint32_t position, int lane) {
+        origin = position;
+        const uint32_t i = KIND == kAns ? position - 1u - (uint32_t)lane : position + (uint32_t)lane;      // (ANS: wraps below 0)
+        cur = in[i < len ? i : 0u];
+    }
+    // the word at read position `position` (ANS: the next word to pop is in[position - 1])
+    __device__ __forceinline__ uint32_t at(uint32_t position) const {
+        const uint32_t off = KIND == kAns ? origin - position : position - origin;
+        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(off & 63u));
+    }
+};
+
+// one symbol of decode_rows_wave_kernel: `r` = this lane's four entries of the symbol's row
+template <int W, int S, int KIND>
+__device__ __forceinline__ void rows_step(DirectDecoder<W, S, KIND>& D, const WordBlock<KIND>& words, const v4u r, uint32_t slot, int lane,
+                                          uint32_t n, int32_t min_symbol, int P, int32_t& status, int32_t& mine) {
+    const uint32_t q = D.quantile(P);
+    const bool le = r.x <= q;
+    const unsigned long long m = __ballot(le);
+    const uint32_t cnt = (le ? 1u : 0u) + (r.y <= q ? 1u : 0u) + (r.z <= q ? 1u : 0u) + (r.w <= q ? 1u : 0u);
+    const uint32_t my_c = cnt >= 4 ? r.w : cnt == 3 ? r.z : cnt == 2 ? r.y : r.x;
+    const uint32_t my_n = cnt == 3 ? r.w : cnt == 2 ? r.z : r.y;
+    const uint32_t k = ((uint32_t)__popcll(m) - 1u) & 63u;   // the last lane whose first entry is <= q
+    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)k);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_c, (int)k);
+    const uint32_t n_in = (uint32_t)__builtin_amdgcn_readlane((int)my_n, (int)k);
+    const uint32_t n_out = (uint32_t)__builtin_amdgcn_readlane((int)r.x, (int)min(k + 1u, 63u));
+    const uint32_t nxt = ck >= 4 ? n_out : n_in;
+    const uint32_t idx = 4u * k + ck - 1u, p = nxt - c;
+    // an invalid model marks entry 0 (then no lane's first entry is <= q, or lane 0's is not); a degenerate distribution
+    // (quantize.rs:562-565) has p == 0; a quantile beyond the support cannot happen for a valid row
+    const bool bad = (m & 1) == 0 || idx >= n || p == 0;
+    const int32_t fail = D.status != CST_STREAM_OK ? D.status : bad ? CST_STREAM_IMPOSSIBLE_SYMBOL : CST_STREAM_OK;
+    if (status == CST_STREAM_OK) {
+        status = fail;
+        if (fail == CST_STREAM_OK) {
+            if ((uint32_t)lane == slot) mine = min_symbol + (int32_t)idx;
+            if constexpr (KIND == kAns) D.ahead = words.at(D.rd);
+            else D.ahead = words.at(D.pos);
+            D.advance(q, c, p, P);
+        }
+    }
+}
+
+template <int W, int S, int KIND>
+__global__ __launch_bounds__(kWave) void decode_rows_wave_kernel(const RowsDecodeArgs ra) {
+    const PerSymbolDecodeArgs& a = ra.a;
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const uint32_t n = (uint32_t)a.n_symbols;
+    const size_t stride_t = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    int32_t* out = a.symbols + (a.layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N) + ra.t0 * stride_t;
+    const v4u* rows = reinterpret_cast<const v4u*>(ra.rows) + s * ra.count * kWave + lane;
+    const size_t count = ra.count;
+
+    DirectDecoder<W, S, KIND> D;
+    int32_t status;
+    if (ra.first) { D.init(a, s, raw); status = D.status; }
+    else { const DecodeResume r = ra.resume[s]; D.resume(a, s, r); status = r.status; }
+    WordBlock<KIND> words;
+    const uint32_t n_words = max(a.n_words[s], 1u);
+    auto fetch_words = [&]() {
+        if constexpr (KIND == kAns) words.fetch(D.in, n_words, D.rd, lane);
+        else words.fetch(D.in, n_words, D.pos, lane);
+        // waited for HERE, once per 64 symbols: left pending, the compiler waits at every use with a count that drains
+        // the row queue to two
+        asm volatile("" : "+v"(words.cur));
+    };
+
+    v4u ahead[kRowsAhead];
+#pragma unroll
+    for (int j = 0; j < kRowsAhead; ++j) ahead[j] = __builtin_nontemporal_load(rows + min((size_t)j, count - 1) * kWave);
+    int32_t mine = 0;                                  // lane l keeps the symbol of position 64 g + l until the group is stored
+    size_t tl = 0;
+    // whole blocks whose rows ahead all exist: no bounds checks
+    for (; tl + 2 * kRowsAhead <= count && status == CST_STREAM_OK; tl += kRowsAhead) {
+        if ((tl & 63) == 0) fetch_words();
+        const uint32_t slot0 = (uint32_t)(tl & 63);
+        const v4u* next = rows + (tl + kRowsAhead) * kWave;
+#pragma unroll
+        for (int j = 0; j < kRowsAhead; ++j) {
+            const v4u r = ahead[j];
+            ahead[j] = __builtin_nontemporal_load(next + j * kWave);
+            rows_step<W, S, KIND>(D, words, r, slot0 + j, lane, n, a.min_symbol, P, status, mine);
+        }
+        if (slot0 == 64 - kRowsAhead) out[(tl + kRowsAhead - 64 + lane) * stride_t] = mine;     // (also the group an error stopped in)
+    }
+    // the last one or two blocks
+    for (; tl < count && status == CST_STREAM_OK; tl += kRowsAhead) {
+        if ((tl & 63) == 0) fetch_words();
+#pragma unroll
+        for (int j = 0; j < kRowsAhead; ++j) {
+            const size_t t = tl + j;
+            const v4u r = ahead[j];
+            if (t + kRowsAhead < count) ahead[j] = __builtin_nontemporal_load(rows + (t + kRowsAhead) * kWave);
+            if (t < count) rows_step<W, S, KIND>(D, words, r, (uint32_t)(t & 63), lane, n, a.min_symbol, P, status, mine);
+            if (t < count && (t & 63) == 63) out[(t - 63 + lane) * stride_t] = mine;
+        }
+    }
+    // the last, partial group (or the group an error stopped in: its remaining symbols are unspecified)
+    const size_t reached = min(tl, count);
+    if ((reached & 63) != 0 && (reached & ~(size_t)63) + lane < count) out[((reached & ~(size_t)63) + lane) * stride_t] = mine;
+    if (lane != 0) return;
+    if (ra.last) { a.status[s] = status; D.finish(a, s, raw); }
+    else { DecodeResume r; D.park(r); r.status = status; ra.resume[s] = r; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -501,6 +733,34 @@ static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t
     return st;
 }
 
+// few streams: cdf rows at full occupancy, then a lookup per symbol; in pieces of at most 64 MiB of rows
+template <int KIND>
+static cst_status decode_gaussian_by_rows(cst_coder_config cfg, const PerSymbolDecodeArgs& a, hipStream_t hs) {
+    const size_t N = a.n_per_stream;
+    // 65 536 rows = 64 MiB of rows per piece (the piece size makes no measurable difference from 4096 rows up: the
+    // sequential kernel is bound by its dependent instruction chain, not by the rows' memory latency)
+    size_t piece = ((size_t)65536 / a.n_streams) & ~(size_t)63;        // (n_streams < 64: at least 1024 symbols)
+    if (piece > N) piece = N;
+    keep_pool_memory();
+    uint32_t* rows = nullptr;
+    DecodeResume* resume = nullptr;
+    CST_HIP_TRY(hipMallocAsync((void**)&rows, a.n_streams * piece * kRowEntries * sizeof(uint32_t), hs));
+    hipError_t err = hipMallocAsync((void**)&resume, a.n_streams * sizeof(DecodeResume), hs);
+    for (size_t t0 = 0; t0 < N && err == hipSuccess; t0 += piece) {
+        const size_t count = N - t0 < piece ? N - t0 : piece;
+        hipLaunchKernelGGL(gaussian_rows_kernel, dim3((unsigned)(a.n_streams * count)), dim3(kRowEntries), 0, hs, a.precision, a.min_symbol,
+                           a.n_symbols, a.means, a.stds, a.layout, a.n_streams, N, t0, count, rows);
+        RowsDecodeArgs ra{a, reinterpret_cast<const uint4*>(rows), t0, count, resume, t0 == 0, t0 + count == N};
+        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_rows_wave_kernel<32, 64, KIND>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, ra);
+        else hipLaunchKernelGGL((decode_rows_wave_kernel<16, 32, KIND>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, ra);
+        err = hipGetLastError();
+    }
+    if (resume) (void)hipFreeAsync(resume, hs);
+    (void)hipFreeAsync(rows, hs);
+    CST_HIP_TRY(err);
+    return CST_OK;
+}
+
 template <int KIND>
 static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
     if (a.n_streams == 0) return CST_OK;
@@ -510,6 +770,8 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
         const size_t lane_blocks = (a.n_streams + kBlock - 1) / kBlock;
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
         else hipLaunchKernelGGL((decode_gaussian_lane_kernel<16, 32, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
+    } else if (gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
+        return decode_gaussian_by_rows<KIND>(cfg, a, hs);
     } else if (gaussian) {
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_wave_kernel<32, 64, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
         else hipLaunchKernelGGL((decode_wave_kernel<16, 32, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);

@@ -236,9 +236,13 @@ struct RangeDecLane {
     __device__ __forceinline__ uint32_t peek_quantile(int P) {
         const st_t scale = (st_t)(range >> P);
         const st_t x = (st_t)(point - lower);
-        // the quotient is < 2^(P+1) <= 2^25: estimate it as x * rcp(scale) in f64 (v_rcp_f64 is good to ~1 ulp, so the
-        // estimate is within one of the true quotient; an IEEE division would cost ~15 instructions), then make it exact
-        uint32_t q = (uint32_t)((double)x * __builtin_amdgcn_rcp((double)scale));
+        // the quotient is < 2^(P+1) <= 2^25: estimate it as x * (1 / scale) in f64, then make it exact.  v_rcp_f64 alone
+        // is good to 2^-24.4 only (scripts/microbench/rcp_f64_error.hip), which at P = 24 could leave the estimate two
+        // off; one Newton step (two fma) puts it within one for every P.  (An IEEE division costs ~15 instructions.)
+        const double sd = (double)scale;
+        double r = __builtin_amdgcn_rcp(sd);
+        r = __builtin_fma(__builtin_fma(-sd, r, 1.0), r, r);
+        uint32_t q = (uint32_t)((double)x * r);
         const st_t prod = (st_t)((st_t)q * scale);
         if (prod > x) --q;
         else if ((st_t)(x - prod) >= scale) ++q;

@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(path)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r['Kernel_Name']
-    if any(t in k for t in ('ans_', 'range_', 'gaussian', 'entries', 'decode_wave')):
+    if any(t in k for t in ('ans_', 'range_', 'gaussian', 'entries', 'decode_wave', 'decode_rows')):
         agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in agg.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}

@@ -100,15 +100,16 @@ def test_gaussian_per_symbol_batch_errors(B, O):
     assert enc2.stream(1).tolist() == c.get_compressed().tolist()
 
 
+@pytest.mark.parametrize("n_streams", [130, 3])          # a lane per stream / cdf rows + a wave per stream
 @pytest.mark.parametrize("cfg", [(32, 64, 24), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
-def test_gaussian_per_symbol_decode_of_random_words_extreme_models(B, O, cfg):
+def test_gaussian_per_symbol_decode_of_random_words_extreme_models(B, O, cfg, n_streams):
     """Decoding RANDOM words draws every quantile, the far tails included, and the models here are the hard ones for a
     search that starts from an inverse-CDF guess: needle-thin and very wide Gaussians, means far outside the support
     (all the mass in the leak), supports of two symbols.  The lane-per-stream decoder must find the reference's symbol."""
     W, S, P = cfg
     rng = np.random.default_rng(P)
-    n_streams, n_per = 130, 70
-    for lo, hi in ((-100, 100), (0, 1), (-5, 2000 if P == 24 else 900)):
+    n_per = 70
+    for lo, hi in ((-100, 100), (0, 1), (-5, 2000 if P == 24 else 900), (-127, 127)):
         mu = rng.uniform(lo - 50.0, hi + 50.0, (n_streams, n_per))
         sd = np.exp(rng.uniform(np.log(1e-7), np.log(1e6), (n_streams, n_per)))
         mu[:, 0] = lo - 1e9; mu[:, 1] = hi + 1e9; sd[:, 2] = 1e-300; sd[:, 3] = 1e300
@@ -119,8 +120,45 @@ def test_gaussian_per_symbol_decode_of_random_words_extreme_models(B, O, cfg):
         torch.cuda.synchronize()
         dec = dec.cpu().numpy()
         assert (st.cpu().numpy() == 0).all()
-        for s in range(0, n_streams, 3):
+        for s in range(0, n_streams, 3 if n_streams > 3 else 1):
             comp = words[s] if W == 32 else words[s].astype(np.uint16)
             c = O.AnsCoder(comp, W=W, S=S)
             want = c.decode_gaussian(n_per, lo, hi, mu[s], sd[s], P, 32 if W == 32 else 16)
             assert dec[s].tolist() == list(want), f"stream {s} support [{lo}, {hi}]"
+
+
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_gaussian_per_symbol_few_long_streams_in_pieces(B, O, coder, layout):
+    """Fewer streams than lanes: the decoder tabulates cdf rows piece by piece (64 MiB of rows at a time) and parks the
+    coders between pieces.  40 streams x 14 000 symbols = nine pieces of 1600 symbols; one stream has an invalid model
+    in a later piece (all other streams must be unaffected, and so must that stream's symbols before it)."""
+    lo, hi, cfg = -100, 100, (32, 64, 24)
+    n_streams, n_per = 40, 14000
+    sym, mu, sd = workload(n_streams, n_per, lo, hi, 99)
+    t = (lambda a: a.T) if layout == "symbol_major" else (lambda a: a)
+    enc_fn = B.ans_encode_gaussian if coder == "ans" else B.range_encode_gaussian
+    dec_fn = B.ans_decode_gaussian if coder == "ans" else B.range_decode_gaussian
+    enc = enc_fn(dev(t(sym)), lo, hi, dev(t(mu)), dev(t(sd)), cfg, layout)
+    torch.cuda.synchronize()
+    for s in (0, 17, 39):
+        if coder == "ans":
+            c = O.AnsCoder()
+            c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], 24, 32)
+        else:
+            c = O.RangeEncoder()
+            c.encode(sym[s], [O.GaussianModel(lo, hi, m, d, 24, 32) for m, d in zip(mu[s], sd[s])], 24)
+        assert enc.stream(s).tolist() == c.get_compressed().tolist()
+    dec, st = dec_fn(enc, lo, hi, dev(t(mu)), dev(t(sd)), layout)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    assert np.array_equal(t(dec.cpu().numpy()), sym)
+    sd_bad = sd.copy()
+    sd_bad[5, 9000] = -1.0
+    dec, st = dec_fn(enc, lo, hi, dev(t(mu)), dev(t(sd_bad)), layout)
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    assert st[5] == 1 and (np.delete(st, 5) == 0).all()
+    got = t(dec.cpu().numpy())
+    assert np.array_equal(np.delete(got, 5, axis=0), np.delete(sym, 5, axis=0))
+    assert np.array_equal(got[5, :8960], sym[5, :8960])            # (whole 64-symbol groups before the failure are delivered)
