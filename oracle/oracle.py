@@ -206,7 +206,7 @@ class AnsCoder:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and load is not None:            # (module globals are torn down before objects at interpreter exit)
             load().cst_oracle_ans_free(h)
 
     # model-generic per-symbol paths
@@ -305,7 +305,7 @@ class RangeEncoder:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and load is not None:            # (module globals are torn down before objects at interpreter exit)
             load().cst_oracle_rc_encoder_free(h)
 
     def encode(self, symbols, models, P=24):
@@ -342,7 +342,7 @@ class RangeDecoder:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and load is not None:            # (module globals are torn down before objects at interpreter exit)
             load().cst_oracle_rc_decoder_free(h)
 
     def decode(self, models, n=None, P=24):
