@@ -90,6 +90,7 @@ SIGNATURES = {
     "cst_range_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_range_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
     "cst_range_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_release_scratch": (_i32, []),
     "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_erf_tab": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_gaussian_lcp": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _z, _vp]),

@@ -365,6 +365,11 @@ def _decode_gaussian(fn_name, ans, encoded, min_symbol, max_symbol, means, stds,
     return out, status
 
 
+def release_scratch():
+    """Hands the scratch memory the per-symbol calls keep in the device's memory pool back to the system."""
+    N.check(N.lib().cst_release_scratch(), "cst_release_scratch")
+
+
 def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
     """One AnsCoder per stream: AnsCoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
     return _decode_gaussian("cst_ans_decode_gaussian_batch", True, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)

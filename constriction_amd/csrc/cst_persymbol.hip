@@ -803,6 +803,16 @@ using namespace cst;
 
 extern "C" {
 
+cst_status cst_release_scratch(void) {
+    int dev = 0;
+    CST_HIP_TRY(hipGetDevice(&dev));
+    hipMemPool_t pool;
+    CST_HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+    CST_HIP_TRY(hipDeviceSynchronize());
+    CST_HIP_TRY(hipMemPoolTrimTo(pool, 0));
+    return CST_OK;
+}
+
 cst_status cst_ans_encode_cp_batch(cst_coder_config cfg, const uint32_t* d_left, const uint32_t* d_prob, size_t n_streams,
                                    size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
                                    uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags, void* stream) {

@@ -352,6 +352,12 @@ cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_w
                                        size_t n_per_stream, cst_layout layout, cst_range_state *d_rstate,
                                        int32_t *d_status, uint32_t flags, void *stream);
 
+/* The per-symbol entry points above take their scratch (16 B per symbol for encoding; 1 KiB per symbol of cdf rows, at
+ * most 64 MiB at a time, for decoding fewer than 64 streams) from the device's stream-ordered memory pool and tell the
+ * pool to KEEP freed memory (re-allocating 4 GiB per call cost more than coding them).  This hands it back: synchronises
+ * the device and trims its default pool. */
+cst_status cst_release_scratch(void);
+
 /* ------------------------------------------------------------------------------------------
  * bit-exact f64 special functions on device (test hooks for the model kernels)
  * out[i] = erf(x[i]) resp. Gaussian cdf, evaluated by the same device code the table kernels use.

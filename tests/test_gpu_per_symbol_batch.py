@@ -162,3 +162,13 @@ def test_gaussian_per_symbol_few_long_streams_in_pieces(B, O, coder, layout):
     got = t(dec.cpu().numpy())
     assert np.array_equal(np.delete(got, 5, axis=0), np.delete(sym, 5, axis=0))
     assert np.array_equal(got[5, :8960], sym[5, :8960])            # (whole 64-symbol groups before the failure are delivered)
+
+
+def test_release_scratch(B):
+    lo, hi = -20, 20
+    sym, mu, sd = workload(100, 64, lo, hi, 3)
+    enc = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu), dev(sd))
+    B.release_scratch()
+    dec, st = B.ans_decode_gaussian(enc, lo, hi, dev(mu), dev(sd))       # (and everything still works afterwards)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
