@@ -43,3 +43,18 @@ def cold(fn, reps=10):
     return tot / reps
 print(f"65536 streams, cache flushed before each call: decode {cold(lambda: B.ans_decode(halves[0], m, k, out=outs[0])):.3f} ms, "
       f"encode {cold(lambda: B.ans_encode(esym[0], m, (32, 64, 12), out=halves[0])):.3f} ms")
+
+# does a STREAMING read of the words (sequential, DRAM-friendly) before the decode bring them into the Infinity Cache?
+def cold_then(pre, fn, reps=10):
+    tot_pre = tot = 0.0
+    for _ in range(reps):
+        flush.fill_(1); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); pre(); e[1].record(); fn(); e[2].record(); torch.cuda.synchronize()
+        tot_pre += e[0].elapsed_time(e[1]); tot += e[1].elapsed_time(e[2])
+    return tot_pre / reps, tot / reps
+w0 = halves[0].words
+used = int(enc.n_words.max().item())
+w0 = w0[:, : (used + 31) // 32 * 32]
+pre, d = cold_then(lambda: w0.max(), lambda: B.ans_decode(halves[0], m, k, out=outs[0]))
+print(f"flush, then a streaming read of the used part of the 65536 slabs ({w0.numel() * 4 / 1e6:.0f} MB): {pre:.3f} ms, then decode: {d:.3f} ms")
