@@ -430,8 +430,8 @@ def main():
     packed, offsets = B.compact(enc)
     compact_ms = event_ms(lambda: B.compact(enc, out=(packed, offsets)), 5)
 
-    # The timed steps decode what the encoder has just written: those words (181 MB at C2) sit in the 256-MiB Infinity
-    # Cache.  For the record, the same two kernels with the cache flushed before every launch (words and symbols from HBM):
+    # The timed steps decode what the encoder has just written.  For the record, the same two kernels after a 1-GiB fill
+    # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):
     flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 
     def after_flush_ms(fn, reps=3):
