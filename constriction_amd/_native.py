@@ -21,6 +21,7 @@ STREAM_OK = 0
 STREAM_IMPOSSIBLE_SYMBOL = 1
 STREAM_CAPACITY = 2
 STREAM_INVALID_DATA = 3
+STREAM_OUT_OF_DATA = 4
 
 LAYOUT_STREAM_MAJOR = 0
 LAYOUT_SYMBOL_MAJOR = 1
@@ -90,6 +91,13 @@ SIGNATURES = {
     "cst_range_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_range_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
     "cst_range_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_chain_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _vp, _z, _vp, _vp, _z, _vp, _vp, _vp, _vp]),
+    "cst_chain_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _z, _vp, _vp, _z, _vp,
+                                               _vp, _vp, _vp]),
+    "cst_chain_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp,
+                                               _vp, _vp, _vp]),
+    "cst_chain_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _i32, _i32, _vp, _z, _z, _i32, _vp, _z, _vp, _vp,
+                                           _vp, _vp]),
     "cst_release_scratch": (_i32, []),
     "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_erf_tab": (_i32, [_vp, _vp, _z, _vp]),

@@ -16,7 +16,7 @@
 
 namespace cst {
 
-enum CoderKind : int { kAns = 0, kRange = 1 };
+enum CoderKind : int { kAns = 0, kRange = 1, kChain = 2 };
 
 __device__ __forceinline__ EncEntry make_entry(uint32_t c, uint32_t p) {
     uint64_t m = 0;
@@ -67,6 +67,9 @@ struct EntriesEncodeArgs {
     cst_range_state* rstate;    // range raw state
     int32_t* status;
     uint32_t flags;
+    // chain coder: the remainders stack that is popped, and the heads
+    const uint32_t* pop_words; const uint64_t* pop_offsets; size_t pop_stride; uint32_t* n_pop;
+    cst_chain_heads* heads;
 };
 
 constexpr int kEntryGroup = 8;     // entries requested together (8 x 16 bytes = one 128-byte line of a stream-major row)
@@ -91,7 +94,46 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
     int32_t status;
     int countdown = G4;
 
-    if constexpr (KIND == kAns) {
+    if constexpr (KIND == kChain) {
+        // ChainCoder::encode_symbol (src/stream/chain.rs:1140-1209), symbols last to first.  Not a hot path of the
+        // library: plain per-lane loads and stores.
+        using st_t = typename StateT<S>::type;
+        constexpr uint32_t wmask = W == 32 ? 0xffffffffu : ((1u << (W % 32)) - 1u);
+        status = CST_STREAM_OK;
+        if (active) {
+            cst_chain_heads h = a.heads[s];
+            st_t rh = (st_t)h.remainders_head;
+            uint32_t ch = h.compressed_head;
+            const uint32_t* pop = a.pop_words + (a.pop_offsets ? a.pop_offsets[s] : s * a.pop_stride);
+            uint32_t rd = a.n_pop[s];
+            for (size_t t = N; t-- > 0 && status == CST_STREAM_OK && !bad;) {
+                const EncEntry e = my[t * stride_t];
+                if (e.p == 0) { bad = 1; break; }
+                if (rh < ((st_t)e.p << (S - W - P))) {                      // refill_remainders_head, chain.rs:799-815
+                    if (rd == 0) { status = CST_STREAM_OUT_OF_DATA; break; }
+                    rh = (st_t)((rh << (W % S)) | (st_t)(pop[--rd] & wmask));
+                }
+                st_t q;
+                if constexpr (S == 64) q = mulhi64(rh, e.m_lo, e.m_hi);     // floor(rh / p) or one less
+                else q = __umulhi(rh, e.m_hi);
+                uint32_t r = (uint32_t)rh - (uint32_t)q * e.p;
+                if (r >= e.p) { r -= e.p; q += 1; }
+                const uint32_t quantile = e.c + r;
+                rh = q;
+                if (P != W && ch < (1u << (W - P))) ch = (ch << P) | quantile;
+                else {
+                    const uint32_t word = P == W ? quantile : (((ch << P) | quantile) & wmask);
+                    if (P != W) ch >>= (W - P);
+                    if (n_words < cap) slab[n_words] = word;
+                    ++n_words;
+                }
+            }
+            if (n_words > cap) status = CST_STREAM_CAPACITY;
+            h.remainders_head = (uint64_t)rh; h.compressed_head = ch;
+            a.heads[s] = h;
+            a.n_pop[s] = rd;
+        }
+    } else if constexpr (KIND == kAns) {
         EncLane<W, S> L;
         L.init(slab, cap, ring, lane);
         if (raw && active) L.state = (typename StateT<S>::type)a.state[s];
@@ -187,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
     if (!active) return;
     if (bad) status = CST_STREAM_IMPOSSIBLE_SYMBOL;
     a.status[s] = status;
-    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+    a.n_words[s] = (status == CST_STREAM_OK || KIND == kChain) ? n_words : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,6 +251,10 @@ struct PerSymbolDecodeArgs {
     uint64_t* state;            // ANS raw
     uint32_t* n_words_out;
     cst_range_state* rstate;    // range raw
+    size_t row_stride;          // explicit rows: entries from one symbol's row to the next (0: one row for all)
+    // chain coder: the remainders pushed, and the heads (n_words_out = what is left of the popped stack)
+    uint32_t* push_words; size_t push_stride; uint32_t* n_push;
+    cst_chain_heads* heads;
     int32_t* status;
     uint32_t flags;
 };
@@ -304,6 +350,51 @@ struct DirectDecoder<W, S, kRange> {
     }
 };
 
+// ChainCoder::decode_symbol (src/stream/chain.rs:1044-1122): P bits per symbol come off `compressed` whatever the model;
+// what the symbol did not use goes onto `remainders` (flush_remainders_head, :784-796).
+template <int W, int S>
+struct DirectDecoder<W, S, kChain> {
+    using st_t = typename StateT<S>::type;
+    static constexpr uint32_t wmask = W == 32 ? 0xffffffffu : ((1u << (W % 32)) - 1u);
+    st_t rh; uint32_t ch, rd, wr, cap; const uint32_t* in; uint32_t* out; int32_t status;
+    uint32_t ahead; const uint32_t* idle;
+    __device__ __forceinline__ void look_ahead() { ahead = *(rd > 0 ? in + (rd - 1) : idle); }
+    __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool) {
+        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        rd = a.n_words[s]; idle = a.n_words + s; status = CST_STREAM_OK;
+        const cst_chain_heads h = a.heads[s];
+        rh = (st_t)h.remainders_head; ch = h.compressed_head;
+        out = a.push_words + s * a.push_stride;
+        cap = (uint32_t)(a.push_stride > 0xffffffffull ? 0xffffffffull : a.push_stride); wr = 0;
+        look_ahead();
+    }
+    __device__ __forceinline__ uint32_t quantile(int P) {
+        uint32_t word;
+        if (P == W || ch < (1u << P)) {
+            if (rd == 0) { status = CST_STREAM_OUT_OF_DATA; return 0u; }
+            word = ahead & wmask; --rd;                       // (the caller looks ahead again after advance())
+            if (P != W) ch = ((ch << (W - P)) | (word >> P)) & wmask;
+        } else {
+            word = ch; ch >>= P;
+        }
+        return P == W ? word : (word & ((1u << P) - 1u));
+    }
+    __device__ __forceinline__ void advance(uint32_t q, uint32_t c, uint32_t p, int P) {
+        rh = (st_t)(rh * (st_t)p + (st_t)(q - c));
+        if (rh >= ((st_t)1 << (S - P))) {
+            if (wr < cap) out[wr] = (uint32_t)rh & wmask;
+            ++wr;
+            rh = (st_t)(rh >> (W % S));
+        }
+    }
+    __device__ __forceinline__ void finish(const PerSymbolDecodeArgs& a, size_t s, bool) {
+        cst_chain_heads h; h.remainders_head = (uint64_t)rh; h.compressed_head = ch; h.reserved = 0;
+        a.heads[s] = h;
+        a.n_words_out[s] = rd; a.n_push[s] = wr;
+        if (wr > cap && a.status[s] == CST_STREAM_OK) a.status[s] = CST_STREAM_CAPACITY;
+    }
+};
+
 // One WAVE per stream.  Every lane carries the same coder state; the search for quantile_function (semantics of
 // quantize.rs:580-779 / lookup_contiguous.rs:564-605: the unique symbol with left(sym) <= q < left(sym+1)) evaluates up
 // to 64 candidate left cumulatives per round: two rounds for a 201-symbol support.  MODEL supplies left(element, i).
@@ -326,7 +417,7 @@ struct RowLeft {                       // explicit cdf rows [n + 1] per coded sy
     const PerSymbolDecodeArgs& a;
     const double2* unused;
     const uint32_t* row;
-    __device__ __forceinline__ bool load(size_t e) { row = a.cdf_rows + e * ((size_t)a.n_symbols + 1); return true; }
+    __device__ __forceinline__ bool load(size_t e) { row = a.cdf_rows + e * a.row_stride; return true; }
     __device__ __forceinline__ uint32_t left(uint32_t i) const { return row[i]; }
 };
 
@@ -770,8 +861,8 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
         const size_t lane_blocks = (a.n_streams + kBlock - 1) / kBlock;
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
         else hipLaunchKernelGGL((decode_gaussian_lane_kernel<16, 32, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
-    } else if (gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
-        return decode_gaussian_by_rows<KIND>(cfg, a, hs);
+    } else if (KIND != kChain && gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
+        if constexpr (KIND != kChain) return decode_gaussian_by_rows<KIND>(cfg, a, hs);
     } else if (gaussian) {
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_wave_kernel<32, 64, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
         else hipLaunchKernelGGL((decode_wave_kernel<16, 32, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
@@ -794,7 +885,46 @@ static cst_status fill_decode_args(PerSymbolDecodeArgs& a, cst_coder_config cfg,
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
     a.min_symbol = min_symbol; a.n_symbols = (int32_t)n_symbols; a.status = d_status; a.flags = flags;
+    a.row_stride = (size_t)n_symbols + 1;
     return CST_OK;
+}
+
+// ---- chain coder: shared parts of the entry points ----
+static cst_status chain_decode_common(PerSymbolDecodeArgs& a, cst_coder_config cfg, const uint32_t* d_pop_words, const uint64_t* d_pop_offsets,
+                                      size_t pop_stride, uint32_t* d_n_pop, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                                      cst_layout layout, int32_t min_symbol, int64_t n_symbols, uint32_t* d_push_words, size_t push_stride,
+                                      uint32_t* d_n_push, cst_chain_heads* d_heads, int32_t* d_status) {
+    if (cst_status st = fill_decode_args(a, cfg, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
+                                         min_symbol, n_symbols, d_status, 0)) return st;
+    if (!d_heads || !d_n_push || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
+    a.push_words = d_push_words; a.push_stride = push_stride; a.n_push = d_n_push; a.heads = d_heads; a.n_words_out = d_n_pop;
+    return CST_OK;
+}
+
+template <typename Fill>
+static cst_status chain_encode_common(cst_coder_config cfg, size_t n_streams, size_t n_per_stream, cst_layout layout, const uint32_t* d_pop_words,
+                                      const uint64_t* d_pop_offsets, size_t pop_stride, uint32_t* d_n_pop, uint32_t* d_push_words,
+                                      size_t push_stride, uint32_t* d_n_push, cst_chain_heads* d_heads, int32_t* d_status, hipStream_t hs,
+                                      Fill fill) {
+    if (cst_status st = check_common(cfg, layout)) return st;
+    if (!d_heads || !d_n_pop || !d_n_push || !d_status || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    const size_t n = n_streams * n_per_stream;
+    EncEntry* entries = nullptr;
+    if (n > 0) {
+        keep_pool_memory();
+        CST_HIP_TRY(hipMallocAsync((void**)&entries, n * sizeof(EncEntry), hs));
+        fill(entries, n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_hip_error(e, "entry kernel"); (void)hipFreeAsync(entries, hs); return CST_ERR_HIP; }
+    }
+    EntriesEncodeArgs a{};
+    a.entries = entries; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
+    a.words = d_push_words; a.stride_words = push_stride; a.n_words = d_n_push; a.status = d_status;
+    a.pop_words = d_pop_words; a.pop_offsets = d_pop_offsets; a.pop_stride = pop_stride; a.n_pop = d_n_pop; a.heads = d_heads;
+    const cst_status st = launch_encode_entries<kChain>(cfg, a, hs);
+    if (entries) CST_HIP_TRY(hipFreeAsync(entries, hs));
+    return st;
 }
 
 } // namespace cst
@@ -917,6 +1047,63 @@ cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_w
     if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
     a.cdf_rows = d_cdf_rows; a.rstate = d_rstate;
     return decode_per_symbol<kRange>(cfg, a, false, (hipStream_t)stream);
+}
+
+// ---- chain coder ----
+cst_status cst_chain_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_pop_words,
+                                           const uint64_t* d_pop_offsets, size_t pop_stride, uint32_t* d_n_pop, const double* d_means,
+                                           const double* d_stds, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, uint32_t* d_push_words, size_t push_stride, uint32_t* d_n_push,
+                                           cst_chain_heads* d_heads, int32_t* d_status, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (max_symbol <= min_symbol) return CST_ERR_MODEL;
+    if (cst_status st = chain_decode_common(a, cfg, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
+                                            min_symbol, (int64_t)max_symbol - min_symbol + 1, d_push_words, push_stride, d_n_push, d_heads,
+                                            d_status)) return st;
+    if (n_per_stream > 0 && (!d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    a.means = d_means; a.stds = d_stds;
+    return decode_per_symbol<kChain>(cfg, a, true, (hipStream_t)stream);
+}
+
+cst_status cst_chain_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_pop_words, const uint64_t* d_pop_offsets, size_t pop_stride,
+                                       uint32_t* d_n_pop, const uint32_t* d_cdf_rows, size_t row_stride, int32_t n_symbols,
+                                       int32_t min_symbol, int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                       uint32_t* d_push_words, size_t push_stride, uint32_t* d_n_push, cst_chain_heads* d_heads,
+                                       int32_t* d_status, void* stream) {
+    PerSymbolDecodeArgs a{};
+    if (cst_status st = chain_decode_common(a, cfg, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
+                                            min_symbol, n_symbols, d_push_words, push_stride, d_n_push, d_heads, d_status)) return st;
+    if (n_per_stream > 0 && !d_cdf_rows) return CST_ERR_INVALID_ARGUMENT;
+    if (row_stride != 0 && row_stride != (size_t)n_symbols + 1) return CST_ERR_INVALID_ARGUMENT;
+    a.cdf_rows = d_cdf_rows; a.row_stride = row_stride;
+    return decode_per_symbol<kChain>(cfg, a, false, (hipStream_t)stream);
+}
+
+cst_status cst_chain_encode_cp_batch(cst_coder_config cfg, const uint32_t* d_left, const uint32_t* d_prob, size_t n_streams,
+                                     size_t n_per_stream, cst_layout layout, const uint32_t* d_pop_words, const uint64_t* d_pop_offsets,
+                                     size_t pop_stride, uint32_t* d_n_pop, uint32_t* d_push_words, size_t push_stride, uint32_t* d_n_push,
+                                     cst_chain_heads* d_heads, int32_t* d_status, void* stream) {
+    if (n_per_stream > 0 && (!d_left || !d_prob)) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    return chain_encode_common(cfg, n_streams, n_per_stream, layout, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_push_words, push_stride,
+                               d_n_push, d_heads, d_status, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(cp_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, d_left, d_prob, n, cfg.precision, out);
+    });
+}
+
+cst_status cst_chain_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                           const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, const uint32_t* d_pop_words, const uint64_t* d_pop_offsets, size_t pop_stride,
+                                           uint32_t* d_n_pop, uint32_t* d_push_words, size_t push_stride, uint32_t* d_n_push,
+                                           cst_chain_heads* d_heads, int32_t* d_status, void* stream) {
+    if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
+    hipStream_t hs = (hipStream_t)stream;
+    return chain_encode_common(cfg, n_streams, n_per_stream, layout, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_push_words, push_stride,
+                               d_n_push, d_heads, d_status, hs, [&](EncEntry* out, size_t n) {
+        hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
+                           max_symbol, d_symbols, d_means, d_stds, n, out);
+    });
 }
 
 } // extern "C"

@@ -49,8 +49,10 @@ typedef enum cst_stream_status {
     CST_STREAM_IMPOSSIBLE_SYMBOL = 1, /* DefaultEncoderFrontendError::ImpossibleSymbol, src/lib.rs:376-385
                                          (Python: KeyError, src/pybindings/stream/mod.rs:82-89) */
     CST_STREAM_CAPACITY = 2,          /* output slab too small (reference: backend WriteError) */
-    CST_STREAM_INVALID_DATA = 3       /* trailing zero word (src/stream/stack.rs:299-318) or
+    CST_STREAM_INVALID_DATA = 3,      /* trailing zero word (src/stream/stack.rs:299-318) or
                                          range-decoder InvalidData (src/stream/queue.rs:989-993) */
+    CST_STREAM_OUT_OF_DATA = 4        /* chain coder: DecoderFrontendError::OutOfCompressedData /
+                                         EncoderFrontendError::OutOfRemainders (src/stream/chain.rs:854-890) */
 } cst_stream_status;
 
 /* memory layout of the int32 symbol matrix */
@@ -351,6 +353,55 @@ cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_w
                                        int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
                                        size_t n_per_stream, cst_layout layout, cst_range_state *d_rstate,
                                        int32_t *d_status, uint32_t flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ChainCoder (src/stream/chain.rs:231-246; DefaultChainCoder = <u32, u64, 24>, SmallChainCoder = <u16, u32, 12>)
+ *
+ * A chain coder holds two word stacks, `compressed` and `remainders`, and two heads (chain.rs:248-258):
+ *   compressed_head   the bits of the last compressed word that are not consumed yet, below a leading 1 bit
+ *   remainders_head   2^(S-W-P) <= head < 2^(S-P) between calls
+ * Decoding (decode_symbol, chain.rs:1044-1122) POPS P bits per symbol from `compressed` -- whatever the model -- and
+ * PUSHES what the symbol did not use onto `remainders`; encoding (encode_symbol, chain.rs:1140-1209; symbols last to
+ * first) pops from `remainders` and pushes P bits per symbol onto `compressed`.  The constructors and terminators
+ * (from_binary / from_compressed / from_remainders, into_remainders / into_compressed / into_binary: a handful of
+ * words each) are host code in the binding (constriction_amd/stream/chain.py); these entry points are the symbol loops.
+ *
+ *   d_pop_words / d_pop_offsets / pop_stride / d_n_pop   the stack that is popped, laid out like d_words of the ANS
+ *             decoder (stream s: d_pop_words[off(s) .. off(s) + d_n_pop[s]), consumed from the END); d_n_pop is updated
+ *   d_push_words / push_stride / d_n_push                the words pushed, in push order, stream s at s * push_stride;
+ *             at most one word per symbol; d_n_push[s] = their number
+ *   d_heads   in / out, one per stream
+ * d_status: CST_STREAM_OUT_OF_DATA if the popped stack ran empty (the reference returns an error; the stream stops
+ * there), IMPOSSIBLE_SYMBOL / CAPACITY as for the other coders.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cst_chain_heads {
+    uint64_t remainders_head;
+    uint32_t compressed_head;
+    uint32_t reserved;
+} cst_chain_heads;
+
+cst_status cst_chain_encode_cp_batch(cst_coder_config cfg, const uint32_t *d_left, const uint32_t *d_prob, size_t n_streams,
+                                     size_t n_per_stream, cst_layout layout, const uint32_t *d_pop_words,
+                                     const uint64_t *d_pop_offsets, size_t pop_stride, uint32_t *d_n_pop, uint32_t *d_push_words,
+                                     size_t push_stride, uint32_t *d_n_push, cst_chain_heads *d_heads, int32_t *d_status,
+                                     void *stream);
+cst_status cst_chain_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t *d_symbols,
+                                           const double *d_means, const double *d_stds, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, const uint32_t *d_pop_words, const uint64_t *d_pop_offsets,
+                                           size_t pop_stride, uint32_t *d_n_pop, uint32_t *d_push_words, size_t push_stride,
+                                           uint32_t *d_n_push, cst_chain_heads *d_heads, int32_t *d_status, void *stream);
+cst_status cst_chain_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t *d_pop_words,
+                                           const uint64_t *d_pop_offsets, size_t pop_stride, uint32_t *d_n_pop, const double *d_means,
+                                           const double *d_stds, int32_t *d_symbols, size_t n_streams, size_t n_per_stream,
+                                           cst_layout layout, uint32_t *d_push_words, size_t push_stride, uint32_t *d_n_push,
+                                           cst_chain_heads *d_heads, int32_t *d_status, void *stream);
+/* explicit cdf rows [n_symbols + 1] per coded symbol; row_stride = n_symbols + 1, or 0 for ONE row shared by every
+ * symbol (a concrete model: decode_iid_symbols) */
+cst_status cst_chain_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_pop_words, const uint64_t *d_pop_offsets,
+                                       size_t pop_stride, uint32_t *d_n_pop, const uint32_t *d_cdf_rows, size_t row_stride,
+                                       int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
+                                       size_t n_per_stream, cst_layout layout, uint32_t *d_push_words, size_t push_stride,
+                                       uint32_t *d_n_push, cst_chain_heads *d_heads, int32_t *d_status, void *stream);
 
 /* The per-symbol entry points above take their scratch (16 B per symbol for encoding; 1 KiB per symbol of cdf rows, at
  * most 64 MiB at a time, for decoding fewer than 64 streams) from the device's stream-ordered memory pool and tell the

@@ -368,6 +368,119 @@ class RangeDecoder:
 # batched drivers (CPU baseline) and the synthetic workload
 # ---------------------------------------------------------------------------------------------
 
+class ChainCoder:
+    """stream::chain::ChainCoder<Word, State, Vec<Word>, Vec<Word>, P> (src/stream/chain.rs:231-246) restated in Python
+    integers -- small cases only.  `models`: one model (iid) or one per symbol; a model answers lcp(sym) and quantile(q).
+    Constructors: from_binary (:326-346, seal), from_compressed (:358-377), from_remainders (:430-456)."""
+
+    class OutOfCompressedData(Exception):
+        pass
+
+    class OutOfRemainders(Exception):
+        pass
+
+    def __init__(self, data, is_remainders=False, seal=False, W=32, S=64, P=24):
+        self.W, self.S, self.P = W, S, P
+        data = [int(x) for x in np.asarray(data).tolist()]
+        if is_remainders:
+            if seal:
+                raise AssertionError("Cannot seal remainders data.")
+            if not data or data[-1] == 0:                       # chain.rs:438-441
+                raise ValueError("Too little data provided, or provided data ends in zero word and `is_remainders==True`.")
+            head = data.pop()
+            self.remainders, self.compressed = data, []
+            self.rem_head = self._new_heads(self.remainders, False)
+            self.comp_head = head
+        else:
+            self.compressed, self.remainders = data, []
+            self.rem_head = self._new_heads(self.compressed, seal)
+            self.comp_head = 1
+
+    def _new_heads(self, source, push_one):                     # ChainCoderHeads::new, chain.rs:270-303
+        threshold = 1 << (self.S - self.W - self.P)
+        if push_one:
+            head = 1
+        else:
+            if not source or source[-1] == 0:
+                raise ValueError("Too little data provided, or provided data ends in zero word.")
+            head = source.pop()
+        while head < threshold:
+            if not source:
+                raise ValueError("Too little data provided.")
+            head = (head << self.W) | source.pop()
+        return head
+
+    def _models(self, models, n):
+        return models if isinstance(models, (list, tuple)) else [models] * n
+
+    def decode(self, models, n=None):                           # decode_symbol, chain.rs:1044-1122
+        W, S, P = self.W, self.S, self.P
+        if n is None:
+            n = len(models)
+        out = []
+        for m in self._models(models, n):
+            if P == W or self.comp_head < (1 << P):
+                if not self.compressed:
+                    raise ChainCoder.OutOfCompressedData()
+                word = self.compressed.pop()
+                if P != W:
+                    self.comp_head = ((self.comp_head << (W - P)) | (word >> P)) & ((1 << W) - 1)
+            else:
+                word = self.comp_head
+                self.comp_head >>= P
+            quantile = word & ((1 << P) - 1) if P != W else word
+            sym, left, prob = m.quantile(quantile)
+            self.rem_head = self.rem_head * prob + (quantile - left)
+            if self.rem_head >= (1 << (S - P)):
+                self.remainders.append(self.rem_head & ((1 << W) - 1))     # flush_remainders_head, :784-796
+                self.rem_head >>= W
+            out.append(sym)
+        return np.array(out, dtype=np.int32)
+
+    def encode_reverse(self, symbols, models):                  # encode_symbol, chain.rs:1140-1209, last symbol first
+        W, S, P = self.W, self.S, self.P
+        symbols = [int(x) for x in np.atleast_1d(np.asarray(symbols)).tolist()]
+        ms = self._models(models, len(symbols))
+        for sym, m in zip(reversed(symbols), reversed(ms)):
+            left, prob = m.lcp(sym)
+            if self.rem_head < (prob << (S - W - P)):
+                if not self.remainders:
+                    raise ChainCoder.OutOfRemainders()
+                self.rem_head = ((self.rem_head << W) | self.remainders.pop()) & ((1 << S) - 1)   # refill, :799-815
+            remainder = self.rem_head % prob
+            quantile = left + remainder
+            self.rem_head //= prob
+            if P != W and self.comp_head < (1 << (W - P)):
+                self.comp_head = (self.comp_head << P) | quantile
+            else:
+                if P == W:
+                    word = quantile
+                else:
+                    word = ((self.comp_head << P) | quantile) & ((1 << W) - 1)
+                    self.comp_head >>= (W - P)
+                self.compressed.append(word)
+
+    def is_whole(self):
+        return self.comp_head == 1
+
+    def get_remainders(self):                                   # into_remainders, chain.rs:406-423 -> (compressed, remainders)
+        rem, head = list(self.remainders), self.rem_head
+        while head != 0:
+            rem.append(head & ((1 << self.W) - 1))
+            head >>= self.W
+        rem.append(self.comp_head)
+        return np.array(self.compressed, dtype=np.uint32), np.array(rem, dtype=np.uint32)
+
+    def get_data(self, unseal=False):                           # into_compressed :475-496 / into_binary :516-541 -> (remainders, compressed)
+        if not self.is_whole() or (unseal and (self.rem_head.bit_length() - 1) % self.W != 0):
+            raise AssertionError("Fractional number of words in compressed or remainders data.")
+        comp, head = list(self.compressed), self.rem_head
+        while head > (1 if unseal else 0):
+            comp.append(head & ((1 << self.W) - 1))
+            head >>= self.W
+        return np.array(self.remainders, dtype=np.uint32), np.array(comp, dtype=np.uint32)
+
+
 def synth_symbols(seed, stream_begin, n_streams, n_per_stream, lo, cdf, P, per_stream_tables=False):
     """q = splitmix64(seed ^ stream).next() >> (64-P); sym = quantile(q)   (SURVEY.md 8d)."""
     cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
