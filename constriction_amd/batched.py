@@ -365,6 +365,58 @@ def _decode_gaussian(fn_name, ans, encoded, min_symbol, max_symbol, means, stds,
     return out, status
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# chain coders (src/stream/chain.rs), many at once.  A chain has two word stacks and two heads; a call pops one stack and
+# pushes the other (decode: pops `compressed`, pushes `remainders`; encode: the reverse).
+# ---------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class ChainBatch:
+    """words / n_words: the stack that the next call pops, stream s = words[s, :n_words[s]], consumed from the end;
+    heads: int64 [n_streams, 2] = cst_chain_heads (remainders head; compressed head in the low word).  Calls update
+    n_words and heads in place and return what they pushed."""
+    words: torch.Tensor
+    n_words: torch.Tensor
+    heads: torch.Tensor
+    config: tuple = (32, 64, 24)
+
+
+def _chain_call(fn_name, chains: ChainBatch, n_streams, n_per, call):
+    dev = chains.words.device
+    pushed = torch.empty((n_streams, max(n_per, 1)), dtype=torch.int32, device=dev)
+    n_pushed = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    status = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    N.check(call(pushed, n_pushed, status), fn_name)
+    return pushed, n_pushed, status
+
+
+def chain_decode_gaussian(chains: ChainBatch, min_symbol, max_symbol, means, stds, layout="stream_major"):
+    """ChainCoder.decode(QuantizedGaussian(min, max), means[s], stds[s]) for every chain.
+    Returns (symbols, pushed remainders words [n_streams, n_per], their counts, status)."""
+    n_streams, n_per, lay = _layout_shape(means, layout)
+    means, stds = _gaussian_args(means.shape, means, stds)
+    out = torch.empty(tuple(means.shape), dtype=torch.int32, device=means.device)
+    fn = "cst_chain_decode_gaussian_batch"
+    pushed, n_pushed, status = _chain_call(fn, chains, n_streams, n_per, lambda pw, pn, st: getattr(N.lib(), fn)(
+        _cfg(*chains.config), int(min_symbol), int(max_symbol), _ptr(chains.words), None, chains.words.shape[1], _ptr(chains.n_words),
+        _ptr(means), _ptr(stds), _ptr(out), n_streams, n_per, lay, _ptr(pw), pw.shape[1], _ptr(pn), _ptr(chains.heads), _ptr(st),
+        _stream_ptr()))
+    return out, pushed, n_pushed, status
+
+
+def chain_encode_gaussian(chains: ChainBatch, symbols, min_symbol, max_symbol, means, stds, layout="stream_major"):
+    """ChainCoder.encode_reverse(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) for every chain; `chains` holds
+    the REMAINDERS stacks.  Returns (pushed compressed words [n_streams, n_per], their counts, status)."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    means, stds = _gaussian_args(symbols.shape, means, stds)
+    fn = "cst_chain_encode_gaussian_batch"
+    return _chain_call(fn, chains, n_streams, n_per, lambda pw, pn, st: getattr(N.lib(), fn)(
+        _cfg(*chains.config), int(min_symbol), int(max_symbol), _ptr(symbols), _ptr(means), _ptr(stds), n_streams, n_per, lay,
+        _ptr(chains.words), None, chains.words.shape[1], _ptr(chains.n_words), _ptr(pw), pw.shape[1], _ptr(pn), _ptr(chains.heads),
+        _ptr(st), _stream_ptr()))
+
+
 def release_scratch():
     """Hands the scratch memory the per-symbol calls keep in the device's memory pool back to the system."""
     N.check(N.lib().cst_release_scratch(), "cst_release_scratch")

@@ -190,12 +190,16 @@ class ChainCoder:
                 return L.cst_chain_encode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_s), S.ptr(d_mu), S.ptr(d_sd), 1, n, N.LAYOUT_STREAM_MAJOR,
                                                          d_pop, None, 0, d_n_pop, d_push, cap, d_n_push, d_heads, d_status, sp)
             if kind[0] == "table":
-                cdf = kind[1].cdf().astype(np.int64)
-                idx = sym.astype(np.int64) - kind[1].min_symbol
-                ok = (idx >= 0) & (idx < len(cdf) - 1)
-                safe = np.where(ok, idx, 0)
-                left = cdf[safe].astype(np.uint32)
-                prob = np.where(ok, cdf[safe + 1] - cdf[safe], 0).astype(np.uint32)
+                # (c, p) of every symbol: a gather from the model's cdf, on the device
+                d_cdf = S.dev(kind[1].cdf().astype(np.int64))
+                idx = S.dev(sym).to(torch.int64) - int(kind[1].min_symbol)
+                ok = (idx >= 0) & (idx < d_cdf.numel() - 1)
+                safe = torch.where(ok, idx, torch.zeros_like(idx))
+                d_left = d_cdf[safe].to(torch.int32)
+                d_prob = torch.where(ok, d_cdf[safe + 1] - d_cdf[safe], torch.zeros_like(idx)).to(torch.int32)
+                keep.extend((d_left, d_prob))
+                return L.cst_chain_encode_cp_batch(S.cfg(), S.ptr(d_left), S.ptr(d_prob), 1, n, N.LAYOUT_STREAM_MAJOR, d_pop, None, 0,
+                                                   d_n_pop, d_push, cap, d_n_push, d_heads, d_status, sp)
             else:
                 rows = kind[1]
                 idx = sym.astype(np.int64) - kind[2]

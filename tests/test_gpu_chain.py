@@ -169,9 +169,7 @@ def test_chain_errors(constriction):
 def test_chain_batch_entry_points(constriction, O, cfg, n_streams, layout):
     """Many chains at once through the C ABI (one wave per chain below 64 chains, one lane per chain from 64 on): decode
     per-symbol Gaussians, then re-encode them; every chain against the oracle."""
-    from constriction_amd import _native as N
     W, S, P = cfg
-    L = N.lib()
     rng = np.random.default_rng(n_streams * 7 + P)
     n_per, stride = 90, 100
     lo, hi = (-100, 100) if P > 8 else (-20, 20)
@@ -186,15 +184,12 @@ def test_chain_batch_entry_points(constriction, O, cfg, n_streams, layout):
         oracles.append(c)
         heads[s, 0] = c.rem_head; heads[s, 1] = c.comp_head
         n_pop[s] = len(c.compressed)
-    d_words, d_heads, d_n_pop = dev(words.view(np.int32)), dev(heads.view(np.int64)), dev(n_pop.view(np.int32))
+    from constriction_amd import batched as B
+    chains = B.ChainBatch(dev(words.view(np.int32)), dev(n_pop.view(np.int32)), dev(heads.view(np.int64)), cfg)
     d_mu, d_sd = dev(t(mu)), dev(t(sd))
-    d_sym = torch.empty(t(mu).shape, dtype=torch.int32, device="cuda")
-    d_push = torch.empty((n_streams, n_per), dtype=torch.int32, device="cuda")
-    d_n_push = torch.empty(n_streams, dtype=torch.int32, device="cuda"); d_status = torch.empty_like(d_n_push)
-    p = lambda x: C.c_void_p(x.data_ptr())
-    c_cfg = N.CoderConfig(W, S, P)
-    N.check(L.cst_chain_decode_gaussian_batch(c_cfg, lo, hi, p(d_words), None, stride, p(d_n_pop), p(d_mu), p(d_sd), p(d_sym), n_streams,
-                                              n_per, layout, p(d_push), n_per, p(d_n_push), p(d_heads), p(d_status), None), "chain decode")
+    lay = "symbol_major" if layout == 1 else "stream_major"
+    d_sym, d_push, d_n_push, d_status = B.chain_decode_gaussian(chains, lo, hi, d_mu, d_sd, lay)
+    d_heads, d_n_pop = chains.heads, chains.n_words
     torch.cuda.synchronize()
     sym = t(d_sym.cpu().numpy())
     assert (d_status.cpu().numpy() == 0).all()
@@ -207,11 +202,8 @@ def test_chain_batch_entry_points(constriction, O, cfg, n_streams, layout):
         assert int(got_heads[s, 0]) == c.rem_head and int(got_heads[s, 1] & 0xffffffff) == c.comp_head
         assert left[s] == len(c.compressed) and pushed[s, : n_pushed[s]].tolist() == c.remainders
     # back again: pop the remainders just pushed, push onto (what is left of) compressed
-    d_back = torch.empty((n_streams, n_per), dtype=torch.int32, device="cuda")
-    d_n_back = torch.empty(n_streams, dtype=torch.int32, device="cuda")
-    d_n_rem = d_n_push.clone()
-    N.check(L.cst_chain_encode_gaussian_batch(c_cfg, lo, hi, p(d_sym), p(d_mu), p(d_sd), n_streams, n_per, layout, p(d_push), None, n_per,
-                                              p(d_n_rem), p(d_back), n_per, p(d_n_back), p(d_heads), p(d_status), None), "chain encode")
+    rem = B.ChainBatch(d_push, d_n_push.clone(), chains.heads, cfg)
+    d_back, d_n_back, d_status = B.chain_encode_gaussian(rem, d_sym, lo, hi, d_mu, d_sd, lay)
     torch.cuda.synchronize()
     assert (d_status.cpu().numpy() == 0).all()
     back, n_back = d_back.cpu().numpy().view(np.uint32), d_n_back.cpu().numpy()
