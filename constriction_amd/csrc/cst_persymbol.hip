@@ -106,15 +106,19 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
             uint32_t ch = h.compressed_head;
             const uint32_t* pop = a.pop_words + (a.pop_offsets ? a.pop_offsets[s] : s * a.pop_stride);
             uint32_t rd = a.n_pop[s];
-            for (size_t t = N; t-- > 0 && status == CST_STREAM_OK && !bad;) {
-                const EncEntry e = my[t * stride_t];
-                if (e.p == 0) { bad = 1; break; }
-                if (rh < ((st_t)e.p << (S - W - P))) {                      // refill_remainders_head, chain.rs:799-815
-                    if (rd == 0) { status = CST_STREAM_OUT_OF_DATA; break; }
-                    rh = (st_t)((rh << (W % S)) | (st_t)(pop[--rd] & wmask));
-                }
+            // entries kEntryGroup at a time, one group ahead of their use, and the next word of the popped stack one symbol
+            // ahead (see the ANS branch)
+            const uint32_t* idle = a.n_pop + s;
+            uint32_t ahead = *(rd > 0 ? pop + (rd - 1) : idle);
+            auto one = [&](const EncEntry e) {
+                if (status != CST_STREAM_OK || bad) return;
+                if (e.p == 0) { bad = 1; return; }
+                bool refill = rh < ((st_t)e.p << (S - W - P));                  // refill_remainders_head, chain.rs:799-815
+                if (refill && rd == 0) { status = CST_STREAM_OUT_OF_DATA; return; }
+                rh = refill ? (st_t)((rh << (W % S)) | (st_t)(ahead & wmask)) : rh;
+                rd -= refill ? 1u : 0u;
                 st_t q;
-                if constexpr (S == 64) q = mulhi64(rh, e.m_lo, e.m_hi);     // floor(rh / p) or one less
+                if constexpr (S == 64) q = mulhi64(rh, e.m_lo, e.m_hi);         // floor(rh / p) or one less
                 else q = __umulhi(rh, e.m_hi);
                 uint32_t r = (uint32_t)rh - (uint32_t)q * e.p;
                 if (r >= e.p) { r -= e.p; q += 1; }
@@ -127,6 +131,25 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
                     if (n_words < cap) slab[n_words] = word;
                     ++n_words;
                 }
+            };
+            const size_t tail = N % kEntryGroup;
+            for (size_t t = N; t-- > N - tail;) { one(my[t * stride_t]); ahead = *(rd > 0 ? pop + (rd - 1) : idle); }
+            EncEntry cur[kEntryGroup], nxt[kEntryGroup];
+            size_t g = N - tail;
+            if (g > 0) {
+#pragma unroll
+                for (int k = 0; k < kEntryGroup; ++k) nxt[k] = my[(g - 1 - k) * stride_t];
+            }
+            while (g > 0 && status == CST_STREAM_OK && !bad) {
+#pragma unroll
+                for (int k = 0; k < kEntryGroup; ++k) cur[k] = nxt[k];
+                g -= kEntryGroup;
+                if (g > 0) {
+#pragma unroll
+                    for (int k = 0; k < kEntryGroup; ++k) nxt[k] = my[(g - 1 - k) * stride_t];
+                }
+#pragma unroll
+                for (int k = 0; k < kEntryGroup; ++k) { one(cur[k]); ahead = *(rd > 0 ? pop + (rd - 1) : idle); }
             }
             if (n_words > cap) status = CST_STREAM_CAPACITY;
             h.remainders_head = (uint64_t)rh; h.compressed_head = ch;
@@ -763,6 +786,150 @@ __global__ __launch_bounds__(kWave) void decode_rows_wave_kernel(const RowsDecod
 }
 
 // ------------------------------------------------------------------------------------------------
+// A FEW CHAINS (down to the reference's own usage: one).  A chain coder's quantiles do not depend on the models: symbol
+// t's P bits sit at a position of `compressed` that only the head's fill level decides.  So decoding is three kernels:
+//   1. per chain, sequential but trivial: cut the quantiles out of the words (no model in the loop);
+//   2. per SYMBOL, in parallel over the whole chip: the model search (exact erf brackets / binary search of a cdf row);
+//   3. per chain, sequential but trivial: fold (quantile - left, probability) into the remainders head, flush words.
+// One wave per chain for 1 and 3, with the coder state uniform (the compiler keeps it in scalar registers) and the
+// inputs fetched 64 at a time.  Against one wave per chain searching inside the loop: ~1.7 us -> ~0.1 us per symbol.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(kWave) void chain_quantiles_kernel(const PerSymbolDecodeArgs a, uint32_t* __restrict__ quantiles,
+                                                                uint32_t* __restrict__ n_cut) {
+    constexpr uint32_t wmask = W == 32 ? 0xffffffffu : ((1u << (W % 32)) - 1u);
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x, N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t* in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+    const uint32_t n_words = max(a.n_words[s], 1u);
+    uint32_t rd = a.n_words[s];
+    uint32_t ch = a.heads[s].compressed_head;
+    WordBlock<kAns> words;
+    uint32_t mine = 0;
+    size_t t = 0;
+    for (; t < N; ++t) {
+        if ((t & 63) == 0) { words.fetch(in, n_words, rd, lane); asm volatile("" : "+v"(words.cur)); }
+        uint32_t word;
+        if (P == W || ch < (1u << P)) {                         // decode_symbol, chain.rs:1060-1098
+            if (rd == 0) break;                                 // DecoderFrontendError::OutOfCompressedData
+            word = words.at(rd) & wmask; --rd;
+            if (P != W) ch = ((ch << (W - P)) | (word >> P)) & wmask;
+        } else {
+            word = ch; ch >>= P;
+        }
+        const uint32_t q = P == W ? word : (word & ((1u << P) - 1u));
+        if ((uint32_t)lane == (uint32_t)(t & 63)) mine = q;
+        if ((t & 63) == 63) quantiles[s * N + t - 63 + lane] = mine;
+    }
+    if ((t & 63) != 0 && (uint32_t)lane < (uint32_t)(t & 63)) quantiles[s * N + (t & ~(size_t)63) + lane] = mine;
+    if (lane == 0) {
+        n_cut[s] = (uint32_t)t;
+        a.heads[s].compressed_head = ch;
+        a.n_words_out[s] = rd;
+    }
+}
+
+// (symbol, quantile - left, probability) of every cut quantile; probability 0 marks an invalid model
+template <bool GAUSSIAN>
+__global__ __launch_bounds__(kBlock) void chain_lookup_kernel(const PerSymbolDecodeArgs a, const uint32_t* __restrict__ quantiles,
+                                                              const uint32_t* __restrict__ n_cut, uint2* __restrict__ pairs) {
+    __shared__ double2 erf_tab[kErfTabEntries];
+    erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const size_t N = a.n_per_stream;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_streams * N) return;
+    const size_t s = i / N, t = i - s * N;
+    if (t >= n_cut[s]) return;
+    const size_t e = a.layout == CST_LAYOUT_SYMBOL_MAJOR ? t * a.n_streams + s : i;
+    const uint32_t q = quantiles[i];
+    const int P = a.precision;
+    const uint32_t n = (uint32_t)a.n_symbols;
+    uint32_t lo_i = 0, hi_i = n, lo_v = 0, hi_v = P >= 32 ? 0u : (1u << P);     // left(lo_i) = lo_v <= q < hi_v = left(hi_i)
+    bool ok = true;
+    if constexpr (GAUSSIAN) {
+        const double mu = a.means[e], sd = a.stds[e];
+        ok = sd > 0.0 && sd <= 1.7976931348623157e308 && fabs(mu) <= 1.7976931348623157e308;
+        if (ok) {
+            // the guess and the bracketing of decode_gaussian_lane_kernel
+            const double free_weight = (double)((P >= 32 ? 0xffffffffu : ((1u << P) - 1u)) - (n - 1u));
+            const float total_f = (float)(1ull << P), free_f = (float)free_weight;
+            const double guess_shift = 0.5 - (double)a.min_symbol;
+            const float below = (float)q + 0.5f, above = total_f - below;
+            float z = ndtri_lower_f32(fminf(below, above) / total_f);
+            double x = mu + sd * (double)(below < above ? z : -z) + guess_shift;
+            if ((double)n * 64.0 > free_weight) {
+                const float b1 = below - (float)fmin(fmax(x, 0.0), (double)(n - 1u)), a1 = free_f - b1;
+                z = ndtri_lower_f32(fmaxf(fminf(b1, a1), 0.25f) / free_f);
+                x = mu + sd * (double)(b1 < a1 ? z : -z) + guess_shift;
+            }
+            uint32_t probe = (uint32_t)fmin(fmax(x, 1.0), (double)(n - 1u)), step = 1;
+            bool up = false, down = false;
+            while (hi_i - lo_i > 1) {
+                const uint32_t v = leaky_gaussian_left<true>((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
+                if (v <= q) { lo_i = probe; lo_v = v; up = true; } else { hi_i = probe; hi_v = v; down = true; }
+                if (up && down) probe = lo_i + (hi_i - lo_i) / 2;
+                else if (up) probe = min(lo_i + step, hi_i - 1u);
+                else probe = max(hi_i - min(step, hi_i - 1u), lo_i + 1u);
+                step *= 2;
+            }
+        }
+    } else {
+        const uint32_t* row = a.cdf_rows + e * a.row_stride;
+        while (hi_i - lo_i > 1) {                               // lookup_contiguous.rs:564-605: any search finds the same entry
+            const uint32_t mid = lo_i + (hi_i - lo_i) / 2, v = row[mid];
+            if (v <= q) { lo_i = mid; lo_v = v; } else { hi_i = mid; hi_v = v; }
+        }
+        lo_v = row[lo_i]; hi_v = row[lo_i + 1];
+        ok = lo_v <= q && hi_v > lo_v && ((uint64_t)hi_v <= ((uint64_t)1 << P)) && q < hi_v;
+    }
+    const uint32_t p = hi_v - lo_v;
+    ok = ok && p != 0 && lo_v <= q && (uint64_t)lo_v + p <= ((uint64_t)1 << P);
+    a.symbols[e] = a.min_symbol + (int32_t)lo_i;
+    pairs[i] = ok ? make_uint2(q - lo_v, p) : make_uint2(0u, 0u);
+}
+
+template <int W, int S>
+__global__ __launch_bounds__(kWave) void chain_fold_kernel(const PerSymbolDecodeArgs a, const uint2* __restrict__ pairs,
+                                                           const uint32_t* __restrict__ n_cut, int32_t bad_model_status) {
+    using st_t = typename StateT<S>::type;
+    constexpr uint32_t wmask = W == 32 ? 0xffffffffu : ((1u << (W % 32)) - 1u);
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x, N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t n = n_cut[s];
+    st_t rh = (st_t)a.heads[s].remainders_head;
+    uint32_t* out = a.push_words + s * a.push_stride;
+    const uint32_t cap = (uint32_t)(a.push_stride > 0xffffffffull ? 0xffffffffull : a.push_stride);
+    uint32_t wr = 0, mine = 0;
+    int32_t status = CST_STREAM_OK;
+    for (uint32_t t0 = 0; t0 < n && status == CST_STREAM_OK; t0 += kWave) {
+        const uint2 pr = t0 + lane < n ? pairs[s * N + t0 + lane] : make_uint2(0u, 1u);
+        const uint32_t m = min((uint32_t)kWave, n - t0);
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)pr.x, (int)j);
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pr.y, (int)j);
+            if (p == 0) { status = bad_model_status; break; }
+            rh = (st_t)(rh * (st_t)p + (st_t)rem);              // decode_symbol, chain.rs:1104-1116
+            if (rh >= ((st_t)1 << (S - P))) {
+                if ((uint32_t)lane == (wr & 63u)) mine = (uint32_t)rh & wmask;
+                if ((wr & 63u) == 63u && wr < cap) out[wr - 63u + lane] = mine;     // (cap is a multiple of 64 or the tail below stores)
+                ++wr;
+                rh = (st_t)(rh >> (W % S));
+            }
+        }
+    }
+    if ((wr & 63u) != 0 && (uint32_t)lane < (wr & 63u) && (wr & ~63u) + lane < cap) out[(wr & ~63u) + lane] = mine;
+    if (lane != 0) return;
+    if (status == CST_STREAM_OK && n < N) status = CST_STREAM_OUT_OF_DATA;
+    if (wr > cap) status = CST_STREAM_CAPACITY;
+    a.heads[s].remainders_head = (uint64_t)rh;
+    a.n_push[s] = wr;
+    a.status[s] = status;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 
@@ -852,11 +1019,36 @@ static cst_status decode_gaussian_by_rows(cst_coder_config cfg, const PerSymbolD
     return CST_OK;
 }
 
+// a few chains: cut the quantiles, search all symbols in parallel, fold the remainders
+static cst_status decode_chains_in_three(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
+    const size_t n = a.n_streams * a.n_per_stream;
+    keep_pool_memory();
+    uint32_t* scratch = nullptr;                 // [quantiles n][pairs 2n][n_cut n_streams]
+    CST_HIP_TRY(hipMallocAsync((void**)&scratch, (3 * n + a.n_streams + 2) * sizeof(uint32_t), hs));
+    uint32_t* quantiles = scratch;
+    uint2* pairs = reinterpret_cast<uint2*>(scratch + ((n + 1) & ~(size_t)1));
+    uint32_t* n_cut = scratch + ((n + 1) & ~(size_t)1) + 2 * n;
+    if (cfg.word_bits == 32) hipLaunchKernelGGL((chain_quantiles_kernel<32>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, a, quantiles, n_cut);
+    else hipLaunchKernelGGL((chain_quantiles_kernel<16>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, a, quantiles, n_cut);
+    const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+    if (gaussian) hipLaunchKernelGGL((chain_lookup_kernel<true>), dim3(blocks), dim3(kBlock), 0, hs, a, quantiles, n_cut, pairs);
+    else hipLaunchKernelGGL((chain_lookup_kernel<false>), dim3(blocks), dim3(kBlock), 0, hs, a, quantiles, n_cut, pairs);
+    const int32_t bad = gaussian ? GaussianLeft::kBadModel : RowLeft::kBadModel;
+    if (cfg.word_bits == 32) hipLaunchKernelGGL((chain_fold_kernel<32, 64>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, a, pairs, n_cut, bad);
+    else hipLaunchKernelGGL((chain_fold_kernel<16, 32>), dim3((unsigned)a.n_streams), dim3(kWave), 0, hs, a, pairs, n_cut, bad);
+    const hipError_t err = hipGetLastError();
+    (void)hipFreeAsync(scratch, hs);
+    CST_HIP_TRY(err);
+    return CST_OK;
+}
+
 template <int KIND>
 static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
     if (a.n_streams == 0) return CST_OK;
     const size_t blocks = (a.n_streams * kWave + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    if (KIND == kChain && a.n_streams < (size_t)kWave && a.n_per_stream >= 64 && a.n_streams * a.n_per_stream < ((size_t)1 << 31))
+        return decode_chains_in_three(cfg, a, gaussian, hs);
     if (gaussian && a.n_streams >= (size_t)kWave) {      // enough streams to give every lane its own
         const size_t lane_blocks = (a.n_streams + kBlock - 1) / kBlock;
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);

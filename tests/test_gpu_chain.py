@@ -161,6 +161,20 @@ def test_chain_errors(constriction):
     assert np.concatenate(coder.get_data(unseal=True)).tolist() == [5, 6, 7, 8]
     with pytest.raises(AssertionError):
         coder.encode_reverse(np.zeros(40, np.int32), model)                             # out of remainders
+    # the same on the three-kernel path (64 symbols and more): the coder is left as it was
+    data = np.arange(1, 21, dtype=np.uint32)
+    coder = constriction.stream.chain.ChainCoder(data, seal=True)
+    fam = M.QuantizedGaussian(-10, 10)
+    with pytest.raises(AssertionError):
+        coder.decode(fam, np.zeros(200), np.full(200, 3.0))
+    with pytest.raises(KeyError):
+        coder.decode(fam, np.zeros(20), np.concatenate([np.full(19, 3.0), [-1.0]]))       # (short path: invalid model)
+    big = constriction.stream.chain.ChainCoder(np.arange(1, 101, dtype=np.uint32), seal=True)
+    with pytest.raises(KeyError):
+        big.decode(fam, np.zeros(75), np.concatenate([np.full(74, 3.0), [-1.0]]))         # (three-kernel path: invalid model)
+    sym = coder.decode(fam, np.zeros(20), np.full(20, 3.0))
+    coder.encode_reverse(sym, fam, np.zeros(20), np.full(20, 3.0))
+    assert np.concatenate(coder.get_data(unseal=True)).tolist() == data.tolist()
 
 
 @pytest.mark.parametrize("cfg", [(32, 64, 24), (16, 32, 12), (16, 32, 16)], ids=lambda c: "W%dS%dP%d" % c)
