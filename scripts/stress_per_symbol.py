@@ -57,6 +57,36 @@ while time.time() < t_end:
                 continue
             assert st[s] == 0 and dec[s].tolist() == want, (tag, s)
 
+    # ---- chain coders over the same models: decode random words, put the symbols back (oracle: src/stream/chain.rs) ----
+    if rng.random() < 0.5 and n_per * P <= 40 * W * 32:
+        stride = n_per + 8
+        words = rng.integers(1, 1 << W, (n_streams, stride), dtype=np.uint64).astype(np.uint32)
+        oracles, heads, n_pop = [], np.zeros((n_streams, 2), dtype=np.uint64), np.zeros(n_streams, np.uint32)
+        for s in range(n_streams):
+            c = O.ChainCoder(words[s], W=W, S=S, P=P)
+            oracles.append(c); heads[s] = (c.rem_head, c.comp_head); n_pop[s] = len(c.compressed)
+        chains = B.ChainBatch(dev(words.view(np.int32)), dev(n_pop.view(np.int32)), dev(heads.view(np.int64)), cfg)
+        csym, pushed, n_pushed, cst = B.chain_decode_gaussian(chains, lo, hi, dev(t(mu)), dev(t(sd)), layout)
+        back, n_back, est2 = B.chain_encode_gaussian(B.ChainBatch(pushed, n_pushed.clone(), chains.heads, cfg), csym, lo, hi,
+                                                     dev(t(mu)), dev(t(sd)), layout)
+        torch.cuda.synchronize()
+        csym_h, cst, est2 = t(csym.cpu().numpy()), cst.cpu().numpy(), est2.cpu().numpy()
+        pushed_h, n_pushed_h, back_h, n_back_h = pushed.cpu().numpy().view(np.uint32), n_pushed.cpu().numpy(), back.cpu().numpy().view(np.uint32), n_back.cpu().numpy()
+        for s in check:
+            c = oracles[s]
+            models = [O.GaussianModel(lo, hi, m, d, P, prob_bits) for m, d in zip(mu[s], sd[s])]
+            try:
+                want = c.decode(models).tolist()
+            except O.ChainCoder.OutOfCompressedData:
+                assert cst[s] == 4, (tag, s, "chain: oracle ran out of data, GPU did not say so")
+                continue
+            assert cst[s] == 0 and csym_h[s].tolist() == want, (tag, s, "chain decode")
+            assert pushed_h[s, : n_pushed_h[s]].tolist() == c.remainders, (tag, s, "chain remainders")
+            before = len(c.compressed)
+            c.encode_reverse(csym_h[s], models)
+            assert est2[s] == 0 and back_h[s, : n_back_h[s]].tolist() == c.compressed[before:], (tag, s, "chain encode")
+            assert np.array_equal(np.concatenate(c.get_data()), words[s]), (tag, s, "chain restore")
+
     # ---- encode symbols drawn from the models, compare words, decode back ----
     sym = np.clip(np.rint(mu + sd * rng.standard_normal(mu.shape)), lo, hi).astype(np.int32)
     enc_fn = B.ans_encode_gaussian if coder == "ans" else B.range_encode_gaussian
