@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity stress of every batched kernel against the CPU oracle (not part of the test suite: minutes of GPU
 time).  Random presets, precisions, alphabets, stream counts / lengths (partial waves, ragged tiles), slab and packed
-layouts; words, counts, status and round trips must all agree.  usage: python scripts/stress_parity.py [seconds] [seed] [big]"""
+layouts; words, counts, status and round trips must all agree.  usage: python tests/stress/stress_parity.py [seconds] [seed] [big]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from constriction_amd import batched as B
 from oracle import oracle as O
 

@@ -3,11 +3,11 @@
 suite: minutes of GPU time).  Every dispatch: one wave per stream, cdf rows + row lookup (fewer than 64 streams, supports
 up to 255), one lane per stream; both coders, both layouts, presets (32,64,P) and (16,32,P); tame and extreme models;
 encode + decode round trips and decoding of RANDOM words (every quantile, the tails included).
-usage: python scripts/stress_per_symbol.py [seconds] [seed]"""
+usage: python tests/stress/stress_per_symbol.py [seconds] [seed]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from constriction_amd import batched as B
 from oracle import oracle as O
 
