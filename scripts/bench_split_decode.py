@@ -58,3 +58,13 @@ used = int(enc.n_words.max().item())
 w0 = w0[:, : (used + 31) // 32 * 32]
 pre, d = cold_then(lambda: w0.max(), lambda: B.ans_decode(halves[0], m, k, out=outs[0]))
 print(f"flush, then a streaming read of the used part of the 65536 slabs ({w0.numel() * 4 / 1e6:.0f} MB): {pre:.3f} ms, then decode: {d:.3f} ms")
+
+# the same input decoded into two output buffers alternately (the words stay resident, the output does not)
+out_b = torch.empty_like(outs[0])
+def alt():
+    B.ans_decode(halves[0], m, k, out=outs[0]); B.ans_decode(halves[0], m, k, out=out_b)
+print(f"same words, two output buffers alternately: {bench.event_ms(alt, 10) / 2:.3f} ms per decode (one output buffer: {first:.3f})")
+# and two inputs into ONE output buffer
+def alt_in():
+    B.ans_decode(halves[0], m, k, out=out_b); B.ans_decode(halves[1], m, k, out=out_b)
+print(f"two inputs alternately, one output buffer: {bench.event_ms(alt_in, 10) / 2:.3f} ms per decode")
