@@ -1,9 +1,9 @@
 // cst_ans_asm.hpp -- the hand-scheduled gfx950 statements of the default preset (W,S) = (32,64):
 //   ans_encode_step_asm      one encoder step                       (8 <= P <= 24, used by the generic tile loop)
 //   ans_encode_tile32        32 encoder steps, software pipelined   (P <= 12)
-//   ans_encode_tiles_loop    the encoder's whole main loop          (generated: cst_encode_loop.inc)
+//   ans_encode_tiles_loop    the encoder's whole main loop          (generated: cst_encode_loop.inc; symbol-major: cst_encode_loop_sm.inc)
 //   ans_decode_tile32        32 decoder steps                       (P <= 12)
-//   ans_decode_tiles_loop    the decoder's whole main loop          (generated: cst_decode_loop.inc)
+//   ans_decode_tiles_loop    the decoder's whole main loop          (generated: cst_decode_loop.inc; symbol-major: cst_decode_loop_sm.inc)
 // Why inline asm at all, the machine model behind the schedules and the measured results: DESIGN.md 3.6-3.8.
 // The loop statements are emitted by scripts/gen_{encode,decode}_loop.py, which also keep the s_waitcnt book.
 #pragma once
@@ -201,6 +201,19 @@ __device__ __forceinline__ void ans_encode_tiles_loop(uint32_t& lo, uint32_t& hi
 #include "cst_encode_loop.inc"
 }
 
+// The same main loop for symbols[t][stream] (CST_LAYOUT_SYMBOL_MAJOR; generated: cst_encode_loop_sm.inc).  Only the staging
+// differs: symbols_base = address of (first symbol of the last full tile, stream s0);  goff[k] : byte offset of symbol row
+// (lane >> 2) + 16 (k & 1), streams 16 (k >> 1) + 4 (lane & 3) .. + 3;  tile_tr_addr[b] : tile[4 (lane & 3)][lane >> 2] in
+// buffer b;  tile_step_bytes = 32 * n_streams * 4.
+__device__ __forceinline__ void ans_encode_tiles_loop_sm(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                         int32_t& smax, const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
+                                                         uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
+                                                         uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                         uint64_t symbols_base, uint32_t n_tiles, uint32_t tile_step_bytes,
+                                                         const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_sm.inc"
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hand-scheduled decode of one 32-symbol tile for (W,S) = (32,64), 8 <= P <= 12, tables in LDS  
 //
@@ -310,6 +323,19 @@ __device__ __forceinline__ void ans_decode_tiles_loop(uint32_t& lo, uint32_t& hi
                                                       uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                       uint32_t words_off, const uint32_t (&goff)[8]) {
 #include "cst_decode_loop.inc"
+}
+
+// The same main loop for symbols[t][stream] (generated: cst_decode_loop_sm.inc): quad k of the previous tile leaves as the
+// 16 bytes of streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row (lane >> 2) + 16 (k & 1); goff[k] is that position
+// relative to store_base (tile 0, stream s0), tr_cur / tr_prev = tile[4 (lane & 3)][lane >> 2] of the two buffers,
+// tile_step_bytes = 32 * n_streams * 4.
+__device__ __forceinline__ void ans_decode_tiles_loop_sm(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued,
+                                                         uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev,
+                                                         uint32_t lut_addr, uint32_t mask, uint32_t P, uint32_t ring_mask,
+                                                         const void* words_base, uint64_t store_base, uint32_t n_tiles,
+                                                         uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                         uint32_t words_off, uint32_t tile_step_bytes, const uint32_t (&goff)[8]) {
+#include "cst_decode_loop_sm.inc"
 }
 
 } // namespace cst

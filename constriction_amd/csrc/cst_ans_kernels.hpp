@@ -354,6 +354,20 @@ struct RingWriter {
     }
 };
 
+// LDS tile -> symbols[t][stream] (full wave, n_streams % 4 == 0, 16-byte aligned base): the mapping of the symbol-major
+// main-loop statements (scripts/gen_{encode,decode}_loop.py): piece k = streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row
+// (lane >> 2) + 16 (k & 1); the four LDS reads of a piece are conflict-free.
+__device__ __forceinline__ void tile_store_sm(int32_t* __restrict__ sym, size_t n_streams, size_t s0, size_t t0, int lane, const int32_t* tile) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = 16 * (k >> 1) + 4 * (lane & 3), t = (lane >> 2) + 16 * (k & 1);
+        v4i v;
+        v.x = tile[(r + 0) * kTileStride + t]; v.y = tile[(r + 1) * kTileStride + t];
+        v.z = tile[(r + 2) * kTileStride + t]; v.w = tile[(r + 3) * kTileStride + t];
+        __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(sym + (t0 + (size_t)t) * n_streams + s0 + (size_t)r));
+    }
+}
+
 // Input side (stack semantics: words are consumed from the END of the stream's buffer).
 // SLOTS words of ring per lane; AHEAD = words kept requested below the read position.
 template <int SLOTS = kRingSlots, int AHEAD = kAhead>
@@ -541,7 +555,7 @@ template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST, bool GLOBAL_TABL
 __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // packed LDS entries <=> this instantiation has the hand-scheduled tile statements
-    constexpr bool PACKED = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE && LAYOUT == CST_LAYOUT_STREAM_MAJOR;
+    constexpr bool PACKED = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE;
     // LDS layout: [word rings: one 16-KiB ring per wave, 16-KiB aligned][encoder table][symbol tiles]
     constexpr size_t kRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
     const EncEntry* table;
@@ -583,6 +597,43 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
         const int32_t* col = a.symbols + (active ? s : 0);
         size_t t = N;
         int countdown = G;
+        // ---- the hand-scheduled main loop over the full tiles (full wave, 64-byte aligned slabs, 16-byte aligned rows) ----
+        if constexpr (FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE) {
+            const size_t n_full = N / kTileSyms;
+            const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
+            const bool lane_ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                                 (L.out.cap & 15u) == 0 && L.out.shift == 0;
+            if ((a.flags & CST_KFLAG_TWO_TILES) && n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && a.n_streams % 4 == 0 &&
+                a.n_streams < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && !__any(!lane_ok)) {
+                // the ragged top [32 * n_full, N) first (the coder walks the symbols last to first)
+                while (t > n_full * kTileSyms) {
+                    --t;
+                    L.template step<FAST>(entry(enc_index(col[t * a.n_streams], a.min_symbol, nsym, L.bad)), P);
+                    L.flush_chunks();
+                }
+                int32_t smin = a.min_symbol, smax = a.min_symbol;
+                uint32_t goff[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
+                const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + (n_full - 1) * kTileSyms * a.n_streams + s0);
+                const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
+                const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+                int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+                const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+                const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+                ans_encode_tiles_loop_sm(lo, hi, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap,
+                                         (uint32_t)slab_off, lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+                L.state = ((uint64_t)hi << 32) | lo;
+                L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+                t = 0;
+            }
+        }
         while (t >= 4) {
             t -= 4;
             int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -958,7 +1009,50 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
         int32_t* col = a.symbols + (active ? s : 0);
         int countdown = 4 * G;
-        for (size_t t = 0; t < N; ++t) {
+        size_t t_done = 0;
+        if constexpr (TILE_ASM) {
+            // ---- the hand-scheduled main loop over the full tiles (see the stream-major branch below for the flow) ----
+            const size_t n_full = N / kTileSyms;
+            const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+            const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+            const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
+            if ((s0 + kWave <= a.n_streams) && n_full >= 2 && N < (1u << 24) && a.n_streams % 4 == 0 && a.n_streams < (1u << 24) &&
+                (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && !__any(!off_ok)) {
+                if ((lds_addr(ring) & (uint32_t)(kWaveRingWords * 4 - 1)) != 0) __builtin_trap();
+                int32_t* my = tile + lane * kTileStride;
+                uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+                const uint32_t qmask = (1u << P) - 1u;
+                const uint32_t lut_addr = lds_addr(lut.cp), lane_addr = lds_addr(ring + lane);
+                int32_t* tile_b = tile + (kBlock / kWave) * kTileWords;
+                uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRingBytes + lds_off + 2 * (size_t)(kBlock / kWave) * kTileWords * 4) +
+                                 wave_in_block * (4 * kWave) + lane;
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, lds_addr(my), L.in.shift - 1u, lane_addr, kDecRingMask);
+                L.in.refill_blocking();
+                wave_lds_fence();
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                uint32_t goff[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
+                const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+                uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+                uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+                const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
+                const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                ans_decode_tiles_loop_sm(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                         kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
+                                         L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off,
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+                wave_lds_fence();
+                tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                wave_lds_fence();
+                L.state = ((uint64_t)hi << 32) | lo;
+                t_done = n_full * kTileSyms;
+            }
+        }
+        for (size_t t = t_done; t < N; ++t) {
             const uint32_t idx = next_index();
             if (active) col[t * a.n_streams] = a.min_symbol + (int32_t)idx;
             if (--countdown == 0) { countdown = 4 * G; L.in.advance_window(); }

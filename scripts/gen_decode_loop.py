@@ -12,6 +12,12 @@ Run:  python scripts/gen_decode_loop.py   (rewrites the .inc; the .inc is checke
 from pathlib import Path
 
 OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop.inc"
+OUT_SM = OUT.with_name("cst_decode_loop_sm.inc")
+# SYMBOL_MAJOR (cst_decode_loop_sm.inc): symbols[t][stream].  Only the way the previous tile leaves differs: quad k reads
+# tile[16 (k >> 1) + 4 (lane & 3) + c][(lane >> 2) + 16 (k & 1)], c = 0..3 (four conflict-free ds_read_b32) and stores the
+# 16 bytes at symbol row (lane >> 2) + 16 (k & 1), streams 16 (k >> 1) + 4 (lane & 3) .. + 3; the store base moves by
+# 32 * n_streams * 4 bytes per tile (an operand) instead of 128.
+SYMBOL_MAJOR = False
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kDecAhead - 1  (want_lo = max(rd + shift - kDecAhead, 0) = sat_sub(rd + (shift-1), kDecAhead-1))
@@ -97,7 +103,11 @@ def gen():
         a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
         a.ds(f"ds_read_b32 {WD}, {RA}", "w")
         a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
-        if pos == 1:
+        if pos == 1 and SYMBOL_MAJOR:
+            for c in range(4):
+                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x",
+                     f"previous tile, stream 16*{quad >> 1}+4*(lane&3)+{c}, symbol (lane>>2)+{16 * (quad & 1)}")
+        elif pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
         a.i(f"v_min_u32 {R1}, 1, %[rd]")
@@ -121,7 +131,7 @@ def gen():
         a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
     a.i("v_swap_b32 %[rowcur], %[rowprev]")
     a.i("v_swap_b32 %[trcur], %[trprev]")
-    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_add_u32 s80, s80, %[tilestep]" if SYMBOL_MAJOR else "s_add_u32 s80, s80, 0x80")
     a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
@@ -131,17 +141,26 @@ def gen():
 
 
 def main():
+    global SYMBOL_MAJOR
+    for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
+        emit(out)
+
+
+def emit(out):
     a, clobbers = gen()
     header = ["// GENERATED by scripts/gen_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (32,64) ANS decoder: see ans_decode_tiles_loop in cst_ans_kernels.hpp."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
-           '      [ntiles] "s"(n_tiles), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),',
+           '      [ntiles] "s"(n_tiles), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),'
+           + (' [tilestep] "s"(tile_step_bytes),' if SYMBOL_MAJOR else ''),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
-    OUT.write_text(a.render(header, ops))
-    print(f"wrote {OUT} ({a.n_instr()} instructions per iteration incl. loop control)")
+    if SYMBOL_MAJOR:
+        header[1] = "// Main loop of the hand-scheduled (32,64) ANS decoder, symbols[t][stream]: see ans_decode_tiles_loop_sm in cst_ans_asm.hpp."
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions per iteration incl. loop control)")
 
 
 if __name__ == "__main__":

@@ -28,11 +28,18 @@ from asmgen import Asm  # noqa: E402
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
 OUT = CSRC / "cst_encode_loop.inc"
 OUT_SINGLE = CSRC / "cst_encode_loop_1buf.inc"
+OUT_SM = CSRC / "cst_encode_loop_sm.inc"
 # SINGLE: ONE tile buffer per wave and a 32-slot word ring (cst_encode_loop_1buf.inc): 17 KiB of LDS per wave instead of
 # 34, so that two workgroups share a CU when a batch has more than one wave per SIMD.  The next tile is staged between
 # the last read of the current tile (quad 0's symbols, requested in quad 2) and the first read of the next one (its
 # quad 7, requested in quad 1) -- one wave's LDS operations execute in order.
 SINGLE = False
+# SYMBOL_MAJOR (cst_encode_loop_sm.inc): symbols[t][stream].  Only the staging differs: a load instruction reads 16 rows
+# (t) of 64 bytes (16 streams), lane l = row l >> 2, streams 4 (l & 3) .. + 3 -- coalesced 64-byte pieces whose other
+# halves the next instruction reads -- and the four symbols of a register go to four ROWS of the LDS tile
+# (tile[stream][t], stride 36 words): with this lane mapping the 64 lanes of a ds_write_b32 hit 64 different banks.
+# The base moves by 32 * n_streams * 4 bytes per tile (an operand) instead of 128.
+SYMBOL_MAJOR = False
 
 
 def regs(base, n=4):
@@ -118,7 +125,7 @@ def fold_minmax(a, g):
 def advance_base(a):
     """s[80:81] -> symbols of the next tile to request; stays on tile 0 once every tile has been requested"""
     a.i("s_cmp_lg_u32 s83, 0")
-    a.i("s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s88, %[tilestep], 0" if SYMBOL_MAJOR else "s_cselect_b32 s88, 0x80, 0")
     a.i("s_cselect_b32 s89, 1, 0")
     a.i("s_sub_u32 s80, s80, s88")
     a.i("s_subb_u32 s81, s81, 0")
@@ -138,6 +145,14 @@ def stage_set(a, name, buf):
     a.wait_vm(f"ld{name}", f"symbols in set {name} have arrived")
     if os.environ.get("GEN_NO_VMWAIT") and len(a.lines) > 100:      # timing experiment only: results are wrong
         a.lines.pop()
+    if SYMBOL_MAJOR:
+        base = {"A": 100, "B": 132}[name]
+        for k in range(8):
+            for c in range(4):
+                a.ds(f"ds_write_b32 {TR[buf]}, v{base + 4 * k + c} offset:{(16 * (k >> 1) + c) * 144 + 64 * (k & 1)}", f"tl{k}")
+            if k >= 2:
+                a.wait_lds(f"tl{k - 2}", cap=True)      # (lgkmcnt only counts to 15: at most 8 of these writes stay in flight)
+        return
     for k in range(8):
         a.ds(f"ds_write_b128 {TR[0 if SINGLE else buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
@@ -232,9 +247,9 @@ def gen():
     return a, notes
 
 
-def emit(out, single):
-    global SINGLE
-    SINGLE = single
+def emit(out, single, symbol_major=False):
+    global SINGLE, SYMBOL_MAJOR
+    SINGLE, SYMBOL_MAJOR = single, symbol_major
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (32,64) ANS encoder: see ans_encode_tiles_loop in cst_ans_kernels.hpp."]
@@ -247,7 +262,7 @@ def emit(out, single):
                '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),']
     ops += ['      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
             '      [tbl] "s"(table_addr_biased), [twoP] "v"(1u << P), [c3f00] "s"(' + ("ring_mask" if single else "0x3f00u") + '), [wbase] "s"(words_base),',
-            '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+            '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
             '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
             "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
     out.write_text(a.render(header, ops))
@@ -259,6 +274,7 @@ def emit(out, single):
 def main():
     emit(OUT, False)
     emit(OUT_SINGLE, True)
+    emit(OUT_SM, False, True)
 
 
 if __name__ == "__main__":

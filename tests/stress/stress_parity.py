@@ -62,6 +62,17 @@ while time.time() < t_end:
         dec, dst = B.range_decode(enc, model, n_per + extra)
         packed, offsets = B.compact(enc)
         dec2, dst2 = B.range_decode((packed, enc.n_words), model, n_per + extra, offsets=offsets, config=cfg)
+    if coder == "ans":
+        # the same batch as symbols[t][stream]: same words, same symbols back
+        encT = B.ans_encode(dev(sym.T), model, cfg, "symbol_major")
+        decT, dstT = B.ans_decode(encT, model, n_per + extra, "symbol_major")
+        torch.cuda.synchronize()
+        wT, nT, sT = encT.to_numpy()
+        assert sT.tolist() == want_st.tolist() and nT.tolist() == want_n.tolist(), (tag, "symbol-major")
+        for s in range(n_streams):
+            assert wT[s, : nT[s]].tolist() == want_words[s, : want_n[s]].tolist(), (tag, s, "symbol-major")
+        okT = want_dst == 0
+        assert dstT.cpu().numpy().tolist() == want_dst.tolist() and np.array_equal(decT.cpu().numpy().T[okT], want_dec[okT]), (tag, "symbol-major decode")
     torch.cuda.synchronize()
     for d, st in ((dec, dst), (dec2, dst2)):
         st = st.cpu().numpy()

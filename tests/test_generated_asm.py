@@ -19,6 +19,8 @@ def _regenerate(mod, tmp_path, name):
     mod.OUT = tmp_path / name
     if hasattr(mod, "OUT_SINGLE"):          # (never rewrite a checked-in file: its mtime triggers a rebuild of the library)
         mod.OUT_SINGLE = tmp_path / ("single_" + name)
+    if hasattr(mod, "OUT_SM"):
+        mod.OUT_SM = tmp_path / ("sm_" + name)
     mod.main()
     return (tmp_path / name).read_text()
 
@@ -35,6 +37,8 @@ def test_decode_loop_is_in_sync(tmp_path, monkeypatch):
         monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop"), tmp_path, "cst_decode_loop.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop.inc").read_text()
+    # ... and its symbol-major variant
+    assert (tmp_path / "sm_cst_decode_loop.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_sm.inc").read_text()
 
 
 def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
@@ -42,9 +46,11 @@ def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
     for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_NO_STORE", "GEN_NO_LOAD"):
         monkeypatch.delenv(var, raising=False)
     mod = _load("gen_encode_loop")
-    mod.OUT, mod.OUT_SINGLE = tmp_path / "a.inc", tmp_path / "b.inc"
+    mod.OUT, mod.OUT_SINGLE, mod.OUT_SM = tmp_path / "a.inc", tmp_path / "b.inc", tmp_path / "c.inc"
     mod.main()
     assert (tmp_path / "b.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_1buf.inc").read_text()
+    # ... and the symbol-major staging of the same loop
+    assert (tmp_path / "c.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_sm.inc").read_text()
     text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small.inc").read_text()
 

@@ -707,3 +707,31 @@ def test_packed_container_through_the_gpu(B, O, tmp_path):
     dec, st = B.ans_decode((dev(words.view(np.int32)), dev(n_words)), model, 333, offsets=dev(off.astype(np.int64)), config=cfg)
     torch.cuda.synchronize()
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+def test_symbol_major_main_loops(B, O):
+    """symbols[t][stream] through the hand-scheduled main loops (scripts/gen_{encode,decode}_loop.py, SYMBOL_MAJOR): full
+    waves beside a partial one, ragged top, an impossible symbol inside a tile (that stream only), decoding past the end."""
+    P, cfg = 12, (32, 64, 12)
+    model, cdf = make_model(B, O, P)
+    n_streams, n_per = 196, 203                      # three full waves + four streams; six tiles + eleven symbols
+    sym = O.synth_symbols(4711, 0, n_streams, n_per, -50, cdf, P)
+    want_words, want_n, want_st = O.ans_encode_batch(sym, -50, cdf, P)
+    enc = B.ans_encode(dev(sym.T), model, cfg, "symbol_major")
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_st.tolist() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    extra = 40
+    want_dec, want_dst = O.ans_decode_batch(want_words, want_n, n_per + extra, -50, cdf, P)
+    dec, dst = B.ans_decode(enc, model, n_per + extra, "symbol_major")
+    torch.cuda.synchronize()
+    assert dst.cpu().numpy().tolist() == want_dst.tolist()
+    assert np.array_equal(dec.cpu().numpy().T, want_dec)
+    bad = sym.copy()
+    bad[70, 100] = 51                                # outside the support, in the middle of a tile of a full wave
+    enc = B.ans_encode(dev(bad.T), model, cfg, "symbol_major")
+    torch.cuda.synchronize()
+    st = enc.status.cpu().numpy()
+    assert st[70] == 1 and (np.delete(st, 70) == 0).all()
