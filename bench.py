@@ -154,16 +154,18 @@ def event_ms(fn, reps):
     return float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
 
 
-def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO):
+def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major"):
     """One entry of the `configs` block: kernel times of encode and decode (HIP events), achieved fraction of the HBM
-    roofline (algorithmic bytes 4 B / symbol + 4 B / word per direction), bit-exactness of every stream."""
-    n_streams, n_per = symbols.shape
+    roofline (algorithmic bytes 4 B / symbol + 4 B / word per direction), bit-exactness of every stream.
+    layout "symbol_major": `symbols` is [n_per, n_streams]."""
+    n_streams, n_per = symbols.shape if layout == "stream_major" else symbols.shape[::-1]
     enc_fn = B.ans_encode if coder == "ans" else B.range_encode
     dec_fn = B.ans_decode if coder == "ans" else B.range_decode
-    enc = enc_fn(symbols, model, cfg)
+    kw = {} if layout == "stream_major" else {"layout": layout}
+    enc = enc_fn(symbols, model, cfg, **kw)
     decoded = torch.empty_like(symbols)
-    enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc), reps)
-    dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded), reps)
+    enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc, **kw), reps)
+    dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded, **kw), reps)
     total_words = enc.total_words()
     n_sym = n_streams * n_per
     byts = 4 * n_sym + 4 * total_words
@@ -178,7 +180,8 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
         ok = bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
         if ok and cdf_host is not None:
             words, n_words, _ = enc.to_numpy()
-            ok = cpu_words_match(coder, symbols.cpu().numpy(), words, n_words, lo, cdf_host, cfg[2], cfg[0], cfg[1])
+            host_sym = symbols.cpu().numpy() if layout == "stream_major" else np.ascontiguousarray(symbols.cpu().numpy().T)
+            ok = cpu_words_match(coder, host_sym, words, n_words, lo, cdf_host, cfg[2], cfg[0], cfg[1])
             entry["bit_exact_scope"] = f"all {n_streams} streams: words and counts vs CPU oracle, decoded symbols vs input"
         entry["bit_exact"] = ok
     return entry, enc
@@ -201,6 +204,11 @@ def other_configs(B, rank, world, dist, args, reps=5):
     cdf12_dev = torch.from_numpy(cdf12.astype(np.int64)).cuda()
     sym12 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, cdf12_dev, 12)
     if world == 1:
+        symT = sym12.t().contiguous()
+        e, _ = run_config(B, "C2 as symbols[t][stream] (symbol-major layout)", "ans", (32, 64, 12), m12, symT, reps, check, cdf12,
+                          layout="symbol_major")
+        out.append(e)
+        del symT
         e, _ = run_config(B, "C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
         out.append(e)
         m24, cdf24 = gaussian(24)
