@@ -316,26 +316,37 @@ constexpr int kDecRingSlots = 32;            // ring words per lane for this dec
 constexpr int kDecAhead = 24;                // two tiles of at most 12 words each
 constexpr uint32_t kDecRingMask = (kDecRingSlots - 1) * kWave * 4;
 
+// PLAIN_STORES: the tile stores without the non-temporal hint -- for rows that are not cache-line aligned (scripts/gen_decode_loop.py)
+template <bool PLAIN_STORES = false>
 __device__ __forceinline__ void ans_decode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued,
                                                       uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev,
                                                       uint32_t lut_addr, uint32_t mask, uint32_t P, uint32_t ring_mask,
                                                       const void* words_base, uint64_t store_base, uint32_t n_tiles,
                                                       uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                       uint32_t words_off, const uint32_t (&goff)[8]) {
+    if constexpr (PLAIN_STORES) {
+#include "cst_decode_loop_plain.inc"
+    } else {
 #include "cst_decode_loop.inc"
+    }
 }
 
 // The same main loop for symbols[t][stream] (generated: cst_decode_loop_sm.inc): quad k of the previous tile leaves as the
 // 16 bytes of streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row (lane >> 2) + 16 (k & 1); goff[k] is that position
 // relative to store_base (tile 0, stream s0), tr_cur / tr_prev = tile[4 (lane & 3)][lane >> 2] of the two buffers,
 // tile_step_bytes = 32 * n_streams * 4.
+template <bool PLAIN_STORES = false>
 __device__ __forceinline__ void ans_decode_tiles_loop_sm(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued,
                                                          uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev,
                                                          uint32_t lut_addr, uint32_t mask, uint32_t P, uint32_t ring_mask,
                                                          const void* words_base, uint64_t store_base, uint32_t n_tiles,
                                                          uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                          uint32_t words_off, uint32_t tile_step_bytes, const uint32_t (&goff)[8]) {
+    if constexpr (PLAIN_STORES) {
+#include "cst_decode_loop_sm_plain.inc"
+    } else {
 #include "cst_decode_loop_sm.inc"
+    }
 }
 
 } // namespace cst

@@ -1041,10 +1041,18 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
                 const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-                ans_decode_tiles_loop_sm(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
-                                         kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                         L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off,
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+                // (64-byte pieces of rows of n_streams symbols: line-aligned iff the rows are)
+                const uint32_t nt_loop = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((a.n_streams * 4) % 128 == 0 && (sb & 127) == 0) ? 1 : 0));
+                const uint32_t n_loop = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1));
+                const uint32_t tile_step = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4));
+                if (nt_loop)
+                    ans_decode_tiles_loop_sm<false>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                                    kDecRingMask, words_base, store_base, n_loop, L.in.shift - 1u, lane_addr, lds_addr(dump),
+                                                    (uint32_t)w_off, tile_step, goff);
+                else
+                    ans_decode_tiles_loop_sm<true>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                                   kDecRingMask, words_base, store_base, n_loop, L.in.shift - 1u, lane_addr, lds_addr(dump),
+                                                   (uint32_t)w_off, tile_step, goff);
                 wave_lds_fence();
                 tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
                 wave_lds_fence();
@@ -1099,9 +1107,17 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 // (readfirstlane returns int: go through uint32_t or the low half sign-extends into the high one)
                 const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-                ans_decode_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
-                                      kDecRingMask, words_base, store_base,
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
+                // rows that start on cache-line boundaries stream out non-temporally; others need L2 to merge the two halves
+                // of the lines a 128-byte segment straddles (0.86 -> 0.52 ms at 65 536 x 4100)
+                const uint32_t nt_loop = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((N * 4) % 128 == 0 && (sb & 127) == 0) ? 1 : 0));
+                if (nt_loop)
+                    ans_decode_tiles_loop<false>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                                 kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
+                                                 L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
+                else
+                    ans_decode_tiles_loop<true>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                                kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
+                                                L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
                 // the last tile is still in LDS (buffer A if it has an even index)
                 wave_lds_fence();
                 tile_store<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);

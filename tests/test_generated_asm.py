@@ -19,8 +19,9 @@ def _regenerate(mod, tmp_path, name):
     mod.OUT = tmp_path / name
     if hasattr(mod, "OUT_SINGLE"):          # (never rewrite a checked-in file: its mtime triggers a rebuild of the library)
         mod.OUT_SINGLE = tmp_path / ("single_" + name)
-    if hasattr(mod, "OUT_SM"):
-        mod.OUT_SM = tmp_path / ("sm_" + name)
+    for attr, prefix in (("OUT_SM", "sm_"), ("OUT_PLAIN", "plain_"), ("OUT_SM_PLAIN", "sm_plain_")):
+        if hasattr(mod, attr):
+            setattr(mod, attr, tmp_path / (prefix + name))
     mod.main()
     return (tmp_path / name).read_text()
 
@@ -37,8 +38,9 @@ def test_decode_loop_is_in_sync(tmp_path, monkeypatch):
         monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop"), tmp_path, "cst_decode_loop.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop.inc").read_text()
-    # ... and its symbol-major variant
-    assert (tmp_path / "sm_cst_decode_loop.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_sm.inc").read_text()
+    # ... and its symbol-major / plain-store variants
+    for prefix, name in (("sm_", "cst_decode_loop_sm.inc"), ("plain_", "cst_decode_loop_plain.inc"), ("sm_plain_", "cst_decode_loop_sm_plain.inc")):
+        assert (tmp_path / (prefix + "cst_decode_loop.inc")).read_text() == (ROOT / "constriction_amd" / "csrc" / name).read_text()
 
 
 def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
