@@ -316,7 +316,8 @@ constexpr int kDecRingSlots = 32;            // ring words per lane for this dec
 constexpr int kDecAhead = 24;                // two tiles of at most 12 words each
 constexpr uint32_t kDecRingMask = (kDecRingSlots - 1) * kWave * 4;
 
-// PLAIN_STORES: the tile stores without the non-temporal hint -- for rows that are not cache-line aligned (scripts/gen_decode_loop.py)
+// PLAIN_STORES: the tile stores without the non-temporal hint (CST_STORE_MOD) -- for rows that are not cache-line aligned
+// (scripts/gen_decode_loop.py)
 template <bool PLAIN_STORES = false>
 __device__ __forceinline__ void ans_decode_tiles_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued,
                                                       uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev,
@@ -325,9 +326,13 @@ __device__ __forceinline__ void ans_decode_tiles_loop(uint32_t& lo, uint32_t& hi
                                                       uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                       uint32_t words_off, const uint32_t (&goff)[8]) {
     if constexpr (PLAIN_STORES) {
-#include "cst_decode_loop_plain.inc"
-    } else {
+#define CST_STORE_MOD ""
 #include "cst_decode_loop.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop.inc"
+#undef CST_STORE_MOD
     }
 }
 
@@ -343,9 +348,13 @@ __device__ __forceinline__ void ans_decode_tiles_loop_sm(uint32_t& lo, uint32_t&
                                                          uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                          uint32_t words_off, uint32_t tile_step_bytes, const uint32_t (&goff)[8]) {
     if constexpr (PLAIN_STORES) {
-#include "cst_decode_loop_sm_plain.inc"
-    } else {
+#define CST_STORE_MOD ""
 #include "cst_decode_loop_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_sm.inc"
+#undef CST_STORE_MOD
     }
 }
 

@@ -13,8 +13,16 @@ __device__ __forceinline__ void ans_decode_b16_tiles_loop(uint32_t& lo, uint32_t
                                                           int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                           uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
                                                           uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0,
-                                                          uint32_t goff_limit) {
+                                                          uint32_t goff_limit, bool plain_stores) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_decode_loop_b16.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_b16.inc"
+#undef CST_STORE_MOD
+    }
 }
 
 constexpr size_t kB16RingBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4;
@@ -100,11 +108,13 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
             ans_decode_b16_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
                                       (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
                                       words_base, store_base, (uint32_t)(8 * N * 4), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit);
+                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, plain_stores);
             L.state = ((uint64_t)hi << 32) | lo;
             // the last tile is still in LDS (buffer A if it has an even index)
             wave_lds_fence();

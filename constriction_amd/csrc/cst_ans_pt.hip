@@ -60,8 +60,16 @@ __device__ __forceinline__ void pt_decode_tiles_loop(uint32_t& lo, uint32_t& hi,
                                                      uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
                                                      uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                      uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
-                                                     const uint32_t (&goff)[8]) {
+                                                     const uint32_t (&goff)[8], bool plain_stores) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_pt_decode_loop.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_pt_decode_loop.inc"
+#undef CST_STORE_MOD
+    }
 }
 
 // Main loop of the encoder: all full tiles of a FULL wave in one asm statement (generated, with its wait counts, by
@@ -315,11 +323,13 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
             // wave-uniform store base in SGPRs (readfirstlane returns int: go through uint32_t)
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             pt_decode_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kPtRingSlots - 1) * kWave * 4), (uint32_t)P,
                                  a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
                                  lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
-                                 lds_addr(my), lds_addr(tile) + tr_off, goff);
+                                 lds_addr(my), lds_addr(tile) + tr_off, goff, plain_stores);
             tb = n_full;
         }
     }

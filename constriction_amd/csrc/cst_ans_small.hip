@@ -39,8 +39,16 @@ __device__ __forceinline__ void decode_tiles_loop_small(uint32_t& lo, uint32_t& 
                                                         uint32_t mask, uint32_t ring_mask, uint32_t P, const void* words_base,
                                                         uint64_t store_base, uint32_t n_tiles, int32_t min_symbol, uint32_t shift_minus_1,
                                                         uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
-                                                        uint32_t tile_row_addr, uint32_t tile_tr_addr, const uint32_t (&goff)[8]) {
+                                                        uint32_t tile_row_addr, uint32_t tile_tr_addr, const uint32_t (&goff)[8], bool plain_stores) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_decode_loop_small.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_small.inc"
+#undef CST_STORE_MOD
+    }
 }
 
 // LDS layout: [word rings, 8 KiB per wave][encoder table][symbol tiles, 9 KiB per wave]
@@ -202,10 +210,12 @@ __global__ __launch_bounds__(kSmDecThreads) void ans_decode_small_kernel(const A
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             decode_tiles_loop_small(lo, hi, L.in.rd, L.in.lo_issued, lds_addr(lut), qmask, kSmRingMask, (uint32_t)P, words_base, store_base,
                                     (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), a.min_symbol, L.in.shift - 1u,
-                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, lds_addr(my), lds_addr(tile) + tr_off, goff);
+                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, lds_addr(my), lds_addr(tile) + tr_off, goff, plain_stores);
             tb = n_full;
         }
     }

@@ -214,19 +214,47 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
                                                         const void* words_base, uint32_t delta_hi, uint64_t store_base, uint32_t goff_stride,
                                                         uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                         uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t bucket_shift,
-                                                        uint32_t cdf_addr, int32_t min_symbol) {
-    if constexpr (B16) {
-        if constexpr (ENDS) {
+                                                        uint32_t cdf_addr, int32_t min_symbol, bool plain_stores) {
+    if constexpr (B16 && ENDS) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_range_decode_loop_b16_ends.inc"
-        } else {
-#include "cst_range_decode_loop_b16.inc"
-        }
+#undef CST_STORE_MOD
     } else {
-        if constexpr (ENDS) {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16_ends.inc"
+#undef CST_STORE_MOD
+    }
+    } else if constexpr (B16) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_b16.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16.inc"
+#undef CST_STORE_MOD
+    }
+    } else if constexpr (ENDS) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_range_decode_loop_ends.inc"
-        } else {
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_ends.inc"
+#undef CST_STORE_MOD
+    }
+    } else {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
 #include "cst_range_decode_loop.inc"
-        }
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop.inc"
+#undef CST_STORE_MOD
+    }
     }
 }
 
@@ -324,6 +352,8 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
             const uint32_t goff_stride = (uint32_t)(8 * N * 4);
             const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             range_decode_tiles_loop<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
                                                 qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
                                                 lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                cdf_addr, a.min_symbol);
+                                                cdf_addr, a.min_symbol, plain_stores);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
@@ -342,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
                 range_decode_tiles_loop<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
                                                    lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
                                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                   cdf_addr, a.min_symbol);
+                                                   cdf_addr, a.min_symbol, plain_stores);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
                 // the last tile is still in LDS (buffer A if it has an even index)

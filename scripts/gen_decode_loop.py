@@ -13,18 +13,16 @@ from pathlib import Path
 
 OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop.inc"
 OUT_SM = OUT.with_name("cst_decode_loop_sm.inc")
-OUT_PLAIN = OUT.with_name("cst_decode_loop_plain.inc")
-OUT_SM_PLAIN = OUT.with_name("cst_decode_loop_sm_plain.inc")
 # SYMBOL_MAJOR (cst_decode_loop_sm.inc): symbols[t][stream].  Only the way the previous tile leaves differs: quad k reads
 # tile[16 (k >> 1) + 4 (lane & 3) + c][(lane >> 2) + 16 (k & 1)], c = 0..3 (four conflict-free ds_read_b32) and stores the
 # 16 bytes at symbol row (lane >> 2) + 16 (k & 1), streams 16 (k >> 1) + 4 (lane & 3) .. + 3; the store base moves by
 # 32 * n_streams * 4 bytes per tile (an operand) instead of 128.
 SYMBOL_MAJOR = False
-# PLAIN_STORES (cst_decode_loop_plain.inc, cst_decode_loop_sm_plain.inc): the tile stores without the non-temporal hint.  With
-# `nt` a 128-byte row segment that straddles two cache lines (rows whose length is not a multiple of 32 symbols) goes to HBM
-# as two partial lines per tile: 0.86 ms instead of 0.29 at 65 536 x 4100; plain stores let L2 merge the halves (0.52 ms), but
-# cost the aligned case its streaming behaviour (0.37 instead of 0.29 ms).  The kernel picks the loop by the rows' alignment.
-PLAIN_STORES = False
+# The tile stores carry the modifier CST_STORE_MOD, a string macro the including function defines: "nt" for rows that start
+# on cache-line boundaries, "" otherwise.  With `nt` a 128-byte row segment that straddles two cache lines (rows whose length
+# is not a multiple of 32 symbols) goes to HBM as two partial lines per tile: 0.86 ms instead of 0.29 at 65 536 x 4100; plain
+# stores let L2 merge the halves (0.54 ms) but cost the aligned case its streaming behaviour (0.37 instead of 0.29 ms).
+STORE_MOD = '" CST_STORE_MOD "'
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kDecAhead - 1  (want_lo = max(rd + shift - kDecAhead, 0) = sat_sub(rd + (shift-1), kDecAhead-1))
@@ -125,7 +123,7 @@ def gen():
             if NO_STORE:
                 a.vm.append(f"store{quad}")
             else:
-                a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] {'' if PLAIN_STORES else os.environ.get('GEN_STORE_MOD', 'nt').replace('+', ' ')}".rstrip(), f"store{quad}")
+                a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] {os.environ['GEN_STORE_MOD'].replace('+', ' ') if 'GEN_STORE_MOD' in os.environ else STORE_MOD}".rstrip(), f"store{quad}")
         if pos == 3:
             base = (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{134 + base}:{137 + base}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
@@ -148,8 +146,8 @@ def gen():
 
 
 def main():
-    global SYMBOL_MAJOR, PLAIN_STORES
-    for SYMBOL_MAJOR, PLAIN_STORES, out in ((False, False, OUT), (True, False, OUT_SM), (False, True, OUT_PLAIN), (True, True, OUT_SM_PLAIN)):
+    global SYMBOL_MAJOR
+    for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
         emit(out)
 
 

@@ -141,7 +141,7 @@ def gen():
             a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
             a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
         if pos == 2:
-            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {X}, s[80:81] nt", f"store{quad}")
+            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {X}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
         if pos == 3:
             base = 134 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")

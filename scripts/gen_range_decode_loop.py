@@ -202,7 +202,7 @@ def gen(ends):
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
             # XT was read in step pos 1 and is covered by this step's lgkmcnt(0)
-            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] nt", f"store{quad}")
+            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
         if pos == 3:
             base = 160 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
