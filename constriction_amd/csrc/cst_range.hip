@@ -52,7 +52,28 @@ __global__ __launch_bounds__(kBlock) void range_encode_kernel(const RangeEncodeA
     if constexpr (LAYOUT == CST_LAYOUT_SYMBOL_MAJOR) {
         const int32_t* col = a.symbols + (active ? s : 0);
         int countdown = 4 * G;
-        for (size_t t = 0; t < N; ++t) {
+        // four symbols per request, one group ahead of their use (a lone wave has nobody to hide a load behind)
+        size_t t = 0;
+        int32_t nxt[4] = {0, 0, 0, 0};
+        if (N >= 4 && active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = col[(size_t)j * a.n_streams];
+        }
+        for (; t + 4 <= N; t += 4) {
+            int32_t cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+            if (t + 8 <= N && active) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = col[(t + 4 + j) * a.n_streams];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                code(cur[j]);
+                if (--countdown == 0) { countdown = 4 * G; L.out.flush_chunks(); }
+            }
+        }
+        for (; t < N; ++t) {
             code(active ? col[t * a.n_streams] : 0);
             if (--countdown == 0) { countdown = 4 * G; L.out.flush_chunks(); }
         }
