@@ -95,6 +95,7 @@ def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
     text = _regenerate(_load("gen_encode_loop_wide"), tmp_path, "cst_encode_loop_wide.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide.inc").read_text()
+    assert (tmp_path / "sm_cst_encode_loop_wide.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide_sm.inc").read_text()
 
 
 def test_w16_loops_are_in_sync(tmp_path, monkeypatch):
