@@ -25,6 +25,25 @@ __device__ __forceinline__ void ans_decode_b16_tiles_loop(uint32_t& lo, uint32_t
     }
 }
 
+// the same for symbols[t][stream] (scripts/gen_decode_loop_b16.py, SYMBOL_MAJOR): full waves only
+__device__ __forceinline__ void ans_decode_b16_tiles_loop_sm(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur,
+                                                             uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr,
+                                                             uint32_t cdf_addr, uint32_t mask, uint32_t P, uint32_t bucket_shift,
+                                                             int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
+                                                             uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
+                                                             uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0,
+                                                             uint32_t goff_limit, uint32_t tile_step_bytes, bool plain_stores) {
+    if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_decode_loop_b16_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_b16_sm.inc"
+#undef CST_STORE_MOD
+    }
+}
+
 constexpr size_t kB16RingBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4;
 constexpr size_t kB16TileWords = (size_t)kWave * kTileStride;
 
@@ -36,7 +55,9 @@ static size_t b16_lds_bytes(int n_symbols, int bucket_bits) {
 }
 
 // LDS layout: [word rings, 8 KiB per wave][cdf][bucket entries][symbol tiles A][symbol tiles B][dump rows]
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeArgs a) {
+    constexpr bool SM = LAYOUT == CST_LAYOUT_SYMBOL_MAJOR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -96,7 +117,35 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
-        if (n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+        if (SM && n_full >= 2 && N < (1u << 24) && !__any(!off_ok) && s0 + kWave <= a.n_streams && a.n_streams % 4 == 0 &&
+            a.n_streams < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
+            tile_cxx(my);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+            uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+            uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const bool plain = __builtin_amdgcn_readfirstlane((int)(((a.n_streams * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
+            // (this branch depends on s0, which the compiler takes for divergent: pin the uniform operands to SGPRs)
+            const uint64_t wb = (uint64_t)reinterpret_cast<uintptr_t>(words_base);
+            const void* words_base_u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32)) << 32) |
+                                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4);
+            ans_decode_b16_tiles_loop_sm(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
+                                         (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
+                                         words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lds_addr(ring + lane),
+                                         lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), plain);
+            L.state = ((uint64_t)hi << 32) | lo;
+            wave_lds_fence();
+            tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+            wave_lds_fence();
+            tb = n_full;
+        } else if (!SM && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
             tile_cxx(my);
             const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
@@ -125,13 +174,20 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     }
     for (; tb < n_full; ++tb) {
         tile_cxx(my);
-        tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        if constexpr (SM) {
+            // (partial waves and odd buffers: every lane writes its own column, 64 consecutive streams per symbol row)
+            if (active)
+                for (int t = 0; t < kTileSyms; ++t) a.symbols[(tb * kTileSyms + t) * a.n_streams + s] = my[t];
+        } else {
+            tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        }
         wave_lds_fence();
     }
-    int32_t* row = a.symbols + (active ? s : 0) * N;
+    int32_t* row = SM ? a.symbols + (active ? s : 0) : a.symbols + (active ? s : 0) * N;
+    const size_t step_t = SM ? a.n_streams : 1;
     for (size_t t = n_full * kTileSyms; t < N; ++t) {
         const int32_t sym = next_symbol();
-        if (active) row[t] = sym;
+        if (active) row[t * step_t] = sym;
         L.in.refill_blocking();
         wave_lds_fence();
     }
@@ -304,17 +360,20 @@ cst_status ans_encode_wide(const AnsEncodeArgs& a, cst_layout layout, hipStream_
 }
 
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    return cfg.word_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision > 12 && a.precision <= 24 &&
-           bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 &&
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR && (a.n_streams % 4 != 0 || a.n_streams < (size_t)kWave)) return false;
+    return cfg.word_bits == 32 && a.precision > 12 && a.precision <= 24 &&
+           bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && !(a.flags & CST_FLAG_RAW_STATE) &&
+           (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && b16_lds_bytes(a.n_symbols, a.bucket_bits) <= 160 * 1024;
 }
 
-cst_status ans_decode_b16(const AnsDecodeArgs& a, hipStream_t hs) {
+cst_status ans_decode_b16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t lds = b16_lds_bytes(a.n_symbols, a.bucket_bits);
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_b16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ans_decode_b16_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    auto kernel = layout == CST_LAYOUT_SYMBOL_MAJOR ? ans_decode_b16_kernel<CST_LAYOUT_SYMBOL_MAJOR> : ans_decode_b16_kernel<CST_LAYOUT_STREAM_MAJOR>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

@@ -93,6 +93,7 @@ def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
         monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop_b16"), tmp_path, "cst_decode_loop_b16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
+    assert (tmp_path / "sm_cst_decode_loop_b16.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16_sm.inc").read_text()
     text = _regenerate(_load("gen_encode_loop_wide"), tmp_path, "cst_encode_loop_wide.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide.inc").read_text()
     assert (tmp_path / "sm_cst_encode_loop_wide.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide_sm.inc").read_text()
