@@ -43,3 +43,8 @@ if __name__ == "__main__":
   run("ANS (16,32,12) symbol-major", "ans", (16, 32, 12), 4096, "symbol_major")
   run("range (32,64,12) symbol-major", "range", (32, 64, 12), 4096, "symbol_major")
   run("range (32,64,12) decode from the packed buffer", "range", (32, 64, 12), 4096, packed=True)
+  run("range (32,64,12) 4100 symbols", "range", (32, 64, 12), 4100)
+  run("ANS (32,64,24) 4100 symbols", "ans", (32, 64, 24), 4100)
+  run("ANS (16,32,12) 4100 symbols", "ans", (16, 32, 12), 4100)
+  run("ANS (32,64,12) symbol-major", "ans", (32, 64, 12), 4096, "symbol_major")
+  run("ANS (32,64,12) symbol-major, 4100 symbols", "ans", (32, 64, 12), 4100, "symbol_major")
