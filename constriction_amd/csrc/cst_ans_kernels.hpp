@@ -1174,7 +1174,7 @@ bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout 
 cst_status ans_decode_b16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs);
 // the hand-scheduled decoder of the (16,32) preset (cst_ans_w16.hip)
 bool w16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);
-cst_status ans_encode_w16(const AnsEncodeArgs& a, hipStream_t hs);
+cst_status ans_encode_w16(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs);
 bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_w16(const AnsDecodeArgs& a, hipStream_t hs);
 

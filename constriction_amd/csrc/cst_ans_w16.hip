@@ -199,11 +199,22 @@ __device__ __forceinline__ void ans_encode_w16_tiles_loop(uint32_t& st, uint32_t
 #include "cst_encode_loop_w16.inc"
 }
 
+// the same for symbols[t][stream] (staging as in ans_encode_tiles_loop_sm, cst_ans_asm.hpp)
+__device__ __forceinline__ void ans_encode_w16_tiles_loop_sm(uint32_t& st, uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax,
+                                                             const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
+                                                             uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off, uint32_t table_addr_biased,
+                                                             uint32_t P, const void* words_base, uint64_t symbols_base, uint32_t n_tiles,
+                                                             uint32_t tile_step_bytes, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_w16_sm.inc"
+}
+
 constexpr size_t kW16EncRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
 constexpr size_t kW16EncTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;
 
 // LDS layout: [word rings, 16 KiB per wave][table][symbol tiles A][symbol tiles B]
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeArgs a) {
+    constexpr bool SM = LAYOUT == CST_LAYOUT_SYMBOL_MAJOR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -237,10 +248,11 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
     auto code = [&](int32_t v) { L.template step<false>(a.enc[enc_index(v, a.min_symbol, nsym, L.bad)], P); };
 
     // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
-    const int32_t* row = a.symbols + se * N;
+    const int32_t* row = SM ? a.symbols + se : a.symbols + se * N;
+    const size_t step_t = SM ? a.n_streams : 1;
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
-        code(row[t]);
+        code(row[t * step_t]);
         L.flush_chunks();
     }
     size_t tb = n_full;
@@ -248,7 +260,30 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
         const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
                         (L.out.cap & 15u) == 0 && L.out.shift == 0;
-        if (N < (1u << 24) && !__any(!ok)) {
+        if (SM && N < (1u << 24) && !__any(!ok) && s0 + kWave <= a.n_streams && a.n_streams % 4 == 0 && a.n_streams < (1u << 24) &&
+            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + (n_full - 1) * kTileSyms * a.n_streams + s0);
+            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+            uint32_t st = (uint32_t)L.state;
+            int32_t smin = a.min_symbol, smax = a.min_symbol;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            ans_encode_w16_tiles_loop_sm(st, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
+                                         lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+            L.state = st;
+            L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+            tb = 0;
+        } else if (!SM && N < (1u << 24) && !__any(!ok)) {
             const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
@@ -273,6 +308,14 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
         }
     }
     // partial waves and odd slabs: tile by tile with the compiler-scheduled step
+    if constexpr (SM) {
+        for (size_t t = tb * kTileSyms; t > 0;) {
+            --t;
+            code(row[t * step_t]);
+            if ((t & 7) == 0) L.flush_chunks();
+        }
+        tb = 0;
+    }
     for (; tb > 0;) {
         --tb;
         int32_t r[kTileSyms];
@@ -295,17 +338,20 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
 }
 
 bool w16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    return cfg.word_bits == 16 && cfg.state_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 12 &&
-           !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 &&
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR && (a.n_streams % 4 != 0 || a.n_streams < (size_t)kWave)) return false;
+    return cfg.word_bits == 16 && cfg.state_bits == 32 && a.precision >= 8 && a.precision <= 12 &&
+           !(a.flags & CST_FLAG_RAW_STATE) && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
+           (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 &&
            kW16EncRingBytes + (size_t)a.n_symbols * sizeof(W16Entry) + 2 * kW16EncTileBytes <= 160 * 1024;
 }
 
-cst_status ans_encode_w16(const AnsEncodeArgs& a, hipStream_t hs) {
+cst_status ans_encode_w16(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t lds = kW16EncRingBytes + (size_t)a.n_symbols * sizeof(W16Entry) + 2 * kW16EncTileBytes;
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_w16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ans_encode_w16_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    auto kernel = layout == CST_LAYOUT_SYMBOL_MAJOR ? ans_encode_w16_kernel<CST_LAYOUT_SYMBOL_MAJOR> : ans_encode_w16_kernel<CST_LAYOUT_STREAM_MAJOR>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

@@ -136,19 +136,29 @@ def gen():
     return a, notes
 
 
+OUT_SM = OUT.with_name("cst_encode_loop_w16_sm.inc")
+
+
 def main():
+    emit(OUT, False)
+    emit(OUT_SM, True)              # symbols[t][stream]: gen_encode_loop.py's SYMBOL_MAJOR staging
+
+
+def emit(out, symbol_major):
+    G.SYMBOL_MAJOR = symbol_major
     a, notes = gen()
+    G.SYMBOL_MAJOR = False
     header = ["// GENERATED by scripts/gen_encode_loop_w16.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (16,32) ANS encoder: see cst_ans_w16.hip."]
     ops = ['    : [st] "+v"(st), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [tbl] "s"(table_addr_biased), [P] "s"(P), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in G.CLOBBERS) + ");"]
-    OUT.write_text(a.render(header, ops))
-    print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
 
