@@ -1176,6 +1176,6 @@ cst_status ans_decode_b16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t
 bool w16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_encode_w16(const AnsEncodeArgs& a, cst_layout layout, hipStream_t hs);
 bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
-cst_status ans_decode_w16(const AnsDecodeArgs& a, hipStream_t hs);
+cst_status ans_decode_w16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs);
 
 } // namespace cst

@@ -21,6 +21,24 @@ __device__ __forceinline__ void ans_decode_w16_tiles_loop(uint32_t& st, uint32_t
     }
 }
 
+// the same for symbols[t][stream] (scripts/gen_decode_loop_w16.py, SYMBOL_MAJOR): full waves only
+__device__ __forceinline__ void ans_decode_w16_tiles_loop_sm(uint32_t& st, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur, uint32_t& row_prev,
+                                                             uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
+                                                             uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t goff_stride,
+                                                             uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                             uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t tile_step_bytes,
+                                                             bool plain_stores) {
+    if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_decode_loop_w16_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_w16_sm.inc"
+#undef CST_STORE_MOD
+    }
+}
+
 constexpr int kW16RingWords = 64;             // 16-bit words of ring per lane: [position][lane] halfwords, 8 KiB per wave
 constexpr int kW16Ahead = 40;                 // 12 words of a half tile + 24 until requested chunks have landed + a chunk
 constexpr uint32_t kW16RingMask = (kW16RingWords - 1) * kWave * 2;
@@ -92,7 +110,9 @@ struct W16Lane {
 };
 
 // LDS layout: [word rings, 8 KiB per wave][cp | symbols (stage_tile_tables)][symbol tiles A][symbol tiles B][dump rows]
+template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeArgs a) {
+    constexpr bool SM = LAYOUT == CST_LAYOUT_SYMBOL_MAJOR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -145,7 +165,32 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.rd + 8) < 0x80000000ull;
-        if (n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+        if (SM && n_full >= 2 && N < (1u << 24) && !__any(!off_ok) && s0 + kWave <= a.n_streams && a.n_streams % 4 == 0 &&
+            a.n_streams < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
+            tile_cxx(my);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+            uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
+            uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const bool plain = __builtin_amdgcn_readfirstlane((int)(((a.n_streams * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
+            // (this branch depends on s0, which the compiler takes for divergent: pin the uniform operands to SGPRs)
+            const uint64_t wb = (uint64_t)reinterpret_cast<uintptr_t>(words_base);
+            const void* words_base_u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32)) << 32) |
+                                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4);
+            ans_decode_w16_tiles_loop_sm(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
+                                         kW16RingMask, words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
+                                         lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), plain);
+            wave_lds_fence();
+            tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+            wave_lds_fence();
+            tb = n_full;
+        } else if (!SM && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
             tile_cxx(my);
             const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
@@ -172,13 +217,18 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     }
     for (; tb < n_full; ++tb) {
         tile_cxx(my);
+        if constexpr (SM) {
+            if (active)
+                for (int t = 0; t < kTileSyms; ++t) a.symbols[(tb * kTileSyms + t) * a.n_streams + s] = my[t];
+        } else
         tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
         wave_lds_fence();
     }
-    int32_t* row = a.symbols + (active ? s : 0) * N;
+    int32_t* row = SM ? a.symbols + (active ? s : 0) : a.symbols + (active ? s : 0) * N;
+    const size_t step_t = SM ? a.n_streams : 1;
     for (size_t t = n_full * kTileSyms; t < N; ++t) {
         const int32_t sym = L.step(lut.cp, lut.sym, P);
-        if (active) row[t] = sym;
+        if (active) row[t * step_t] = sym;
         L.fill_blocking();
         wave_lds_fence();
     }
@@ -357,16 +407,18 @@ cst_status ans_encode_w16(const AnsEncodeArgs& a, cst_layout layout, hipStream_t
 }
 
 bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    return cfg.word_bits == 16 && cfg.state_bits == 32 && layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 12 &&
-           a.dec_cp && a.dec_idx && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR && (a.n_streams % 4 != 0 || a.n_streams < (size_t)kWave)) return false;
+    return cfg.word_bits == 16 && cfg.state_bits == 32 && a.precision >= 8 && a.precision <= 12 &&
+           a.dec_cp && a.dec_idx && !(a.flags & CST_FLAG_RAW_STATE) && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
+           (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
 }
 
-cst_status ans_decode_w16(const AnsDecodeArgs& a, hipStream_t hs) {
+cst_status ans_decode_w16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_w16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kW16LdsBytes));
-    hipLaunchKernelGGL(ans_decode_w16_kernel, dim3((unsigned)blocks), dim3(kBlock), kW16LdsBytes, hs, a);
+    auto kernel = layout == CST_LAYOUT_SYMBOL_MAJOR ? ans_decode_w16_kernel<CST_LAYOUT_SYMBOL_MAJOR> : ans_decode_w16_kernel<CST_LAYOUT_STREAM_MAJOR>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kW16LdsBytes));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), kW16LdsBytes, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

@@ -305,7 +305,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     hipStream_t hs = (hipStream_t)stream;
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
     if (b16_decode_usable(a, cfg, layout)) return ans_decode_b16(a, layout, hs);                        // 12 < P <= 24
-    if (w16_decode_usable(a, cfg, layout)) return ans_decode_w16(a, hs);                        // SmallAnsCoder preset
+    if (w16_decode_usable(a, cfg, layout)) return ans_decode_w16(a, layout, hs);                        // SmallAnsCoder preset
     if (cfg.word_bits == 32) return decode_dispatch<32, 64>(a, layout, hs);
     return decode_dispatch<16, 32>(a, layout, hs);
 }

@@ -31,6 +31,11 @@ def tup(base, n=4):
     return f"v[{base}:{base + n - 1}]"
 
 
+# SYMBOL_MAJOR (cst_decode_loop_w16_sm.inc): symbols[t][stream], staged like gen_decode_loop_b16.py's SYMBOL_MAJOR (full waves only)
+SYMBOL_MAJOR = False
+OUT_SM = OUT.with_name("cst_decode_loop_w16_sm.inc")
+
+
 def gen():
     a = Asm()
     N, D, PR, T, LA, CP, WD, RA, R1, Q, NS = (f"v{120 + k}" for k in range(11))
@@ -80,10 +85,16 @@ def gen():
     def sym_reg(j):
         return SYM[(j // 4 % 2) * 4 + j % 4]
 
-    a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
-    for k in range(1, 8):
-        a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
-        a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
+    if SYMBOL_MAJOR:
+        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
+        a.i(f"v_add_u32 {GOFF[1]}, %[gstride], {GOFF[0]}", "symbol rows + 16")
+        for k in range(2, 8):
+            a.i(f"v_add_u32 {GOFF[k]}, 64, {GOFF[k - 2]}", "streams + 16")
+    else:
+        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
+        for k in range(1, 8):
+            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+            a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     window_requests("B")      # (the set that lands after step 15)
@@ -113,7 +124,10 @@ def gen():
         a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
         if not last_of_half:
             word_request()
-        if pos == 1:
+        if pos == 1 and SYMBOL_MAJOR:
+            for c in range(4):
+                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x")
+        elif pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if not last_of_half:
             a.i(f"v_min_u32 {R1}, 1, %[rd]")
@@ -130,7 +144,7 @@ def gen():
     window_landing("A", "---- end of tile")
     a.i("v_swap_b32 %[rowcur], %[rowprev]")
     a.i("v_swap_b32 %[trcur], %[trprev]")
-    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_add_u32 s80, s80, %[tilestep]" if SYMBOL_MAJOR else "s_add_u32 s80, s80, 0x80")
     a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
@@ -143,6 +157,13 @@ def gen():
 
 
 def main():
+    global SYMBOL_MAJOR
+    for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
+        emit(out)
+    SYMBOL_MAJOR = False
+
+
+def emit(out):
     a, clobbers = gen()
     header = ["// GENERATED by scripts/gen_decode_loop_w16.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (16,32) ANS decoder: see cst_ans_w16.hip."]
@@ -150,10 +171,10 @@ def main():
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
            '      [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
-           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)',
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
-    OUT.write_text(a.render(header, ops))
-    print(f"wrote {OUT} ({a.n_instr()} instructions per iteration incl. loop control)")
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions per iteration incl. loop control)")
 
 
 if __name__ == "__main__":

@@ -105,6 +105,7 @@ def test_w16_loops_are_in_sync(tmp_path, monkeypatch):
         monkeypatch.delenv(var, raising=False)
     text = _regenerate(_load("gen_decode_loop_w16"), tmp_path, "cst_decode_loop_w16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_w16.inc").read_text()
+    assert (tmp_path / "sm_cst_decode_loop_w16.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_w16_sm.inc").read_text()
     text = _regenerate(_load("gen_encode_loop_w16"), tmp_path, "cst_encode_loop_w16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_w16.inc").read_text()
     assert (tmp_path / "sm_cst_encode_loop_w16.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_w16_sm.inc").read_text()
