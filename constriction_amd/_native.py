@@ -26,6 +26,8 @@ STREAM_OUT_OF_DATA = 4
 LAYOUT_STREAM_MAJOR = 0
 LAYOUT_SYMBOL_MAJOR = 1
 
+FAMILY_LAPLACE, FAMILY_CAUCHY, FAMILY_BINOMIAL = 1, 2, 3
+
 FLAG_NONE = 0
 FLAG_RAW_STATE = 1
 
@@ -70,10 +72,10 @@ SIGNATURES = {
     "cst_model_n_tables": (_z, [_vp]),
     "cst_model_get_cdf": (_i32, [_vp, _z, _vp, _vp]),
     "cst_ans_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
-    "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
-    "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
+    "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_compact_scratch_bytes": (_z, [_z]),
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
     "cst_rccl_get_unique_id": (_i32, [_vp]),
@@ -81,16 +83,17 @@ SIGNATURES = {
     "cst_rccl_comm_destroy": (_i32, [_vp]),
     "cst_gather_sizes_rccl": (_i32, [_vp, _i32, _i32, _vp, _z, _vp, _vp]),
     "cst_gather_rccl": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cst_scatter_rccl": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cst_ans_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
-    "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
-    "cst_ans_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "cst_ans_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_range_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
-    "cst_range_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
     "cst_range_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_range_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
-    "cst_range_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
-    "cst_range_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _vp, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
+    "cst_range_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _i32, _i32, _vp, _z, _z, _i32, _vp, _vp, _u32, _vp]),
     "cst_chain_encode_cp_batch": (_i32, [CoderConfig, _vp, _vp, _z, _z, _i32, _vp, _vp, _z, _vp, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_chain_encode_gaussian_batch": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _vp, _z, _vp, _vp, _z, _vp,
                                                _vp, _vp, _vp]),
@@ -98,6 +101,10 @@ SIGNATURES = {
                                                _vp, _vp, _vp]),
     "cst_chain_decode_rows_batch": (_i32, [CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _i32, _i32, _vp, _z, _z, _i32, _vp, _z, _vp, _vp,
                                            _vp, _vp]),
+    "cst_family_cdf_rows": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _z, _vp, _vp, _vp]),
+    "cst_categorical_perfect_cdf": (_i32, [_vp, _z, _i32, _vp]),
+    "cst_debug_family_fn": (_i32, [_i32, _vp, _vp, _z, _vp]),
+    "cst_debug_host_log1p": (_f64, [_f64]),
     "cst_release_scratch": (_i32, []),
     "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_erf_tab": (_i32, [_vp, _vp, _z, _vp]),
@@ -124,7 +131,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.cst_abi_version() != 2:
+    if lib.cst_abi_version() != 3:
         raise BackendUnavailable("ABI version mismatch between _native.py and libconstriction_amd.so")
     _lib = lib
     return lib

@@ -133,6 +133,35 @@ class Model:
         return out
 
 
+def family_cdf_rows(family: int, min_symbol: int, max_symbol: int, a, b=None, n_per_row=None, precision: int = 24,
+                    to_numpy: bool = True):
+    """LeakyQuantizer(min..=max) x Laplace / Cauchy / Binomial tabulated on the GPU, one cdf row per parameter pair
+    (cst_family_cdf_rows; family = 1 Laplace(mean, scale), 2 Cauchy(loc, scale), 3 Binomial(p) over 0..=max or, with
+    `n_per_row`, over 0..=n_per_row[r]).  Returns uint32 rows [n_rows, max - min + 2] (numpy, or a torch.int32 view of
+    them in HBM with to_numpy=False); raises ValueError where the reference panics (a probability of zero)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def dev_f64(x):
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            return _require_cuda(x, torch.float64, "model parameter")
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+
+    da, db = dev_f64(a), dev_f64(b)
+    dn = None if n_per_row is None else torch.from_numpy(np.ascontiguousarray(n_per_row, dtype=np.int32)).to(dev)
+    n_rows = da.numel()
+    width = int(max_symbol) - int(min_symbol) + 2
+    rows = torch.empty((n_rows, width), dtype=torch.int32, device=dev)
+    bad = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    N.check(N.lib().cst_family_cdf_rows(int(family), int(precision), int(min_symbol), int(max_symbol), _ptr(da), _ptr(db), _ptr(dn),
+                                        n_rows, _ptr(rows), _ptr(bad), _stream_ptr()), "cst_family_cdf_rows")
+    if n_rows and bool(bad.any().item()):
+        raise ValueError("Invalid model: a symbol of the support gets probability zero under the leaky quantizer "
+                         "(quantize.rs:560-566).")
+    return rows.cpu().numpy().view(np.uint32) if to_numpy else rows
+
+
 @dataclass
 class EncodedBatch:
     """Per-stream compressed words in fixed-stride slabs (stream s: words[s, :n_words[s]])."""
@@ -209,7 +238,7 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
         out = torch.empty(shape, dtype=torch.int32, device=dev)
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
-    N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
+    N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                          _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status), N.FLAG_NONE,
                                          _stream_ptr()), "cst_ans_decode_batch")
     if model.noncontiguous:
@@ -287,7 +316,7 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
         out = torch.empty(shape, dtype=torch.int32, device=dev)
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
-    N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, _ptr(n_words),
+    N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                            _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
                                            _stream_ptr()), "cst_range_decode_batch")
     return out, status
@@ -357,7 +386,7 @@ def _decode_gaussian(fn_name, ans, encoded, min_symbol, max_symbol, means, stds,
     if out is None:
         out = torch.empty(tuple(means.shape), dtype=torch.int32, device=dev)
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
-    args = [_cfg(*config), int(min_symbol), int(max_symbol), _ptr(words), _ptr(offsets), stride, _ptr(n_words), _ptr(means), _ptr(stds),
+    args = [_cfg(*config), int(min_symbol), int(max_symbol), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words), _ptr(means), _ptr(stds),
             _ptr(out), n_streams, n_per, lay, None]
     if ans:
         args.append(None)          # d_n_words_out
@@ -476,6 +505,6 @@ def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, mod
     L = N.lib()
     scratch = torch.empty(L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval), dtype=torch.uint8, device=dev)
     N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
-                                        checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
+                                        encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
                                         n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()), "cst_ans_decode_batch_ckpt")
     return out, status

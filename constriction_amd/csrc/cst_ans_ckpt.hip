@@ -131,7 +131,7 @@ size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt
 }
 
 cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                                     size_t stride_words, size_t ckpt_interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
+                                     size_t stride_words, size_t words_capacity, size_t ckpt_interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
                                      int32_t* d_symbols, size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status,
                                      void* stream) {
     if (!model || !d_ckpt_pos || !d_ckpt_state || !d_scratch || !d_status || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
@@ -144,7 +144,9 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
     hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);
     CST_HIP_TRY(hipGetLastError());
     CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));   // (the raw decode updates its state array)
-    return cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR,
+    // every virtual stream's slice [off(s), off(s) + pos) is checked against the buffer (slab form: against all slabs)
+    const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    return cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR,
                                 v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
 }
 

@@ -146,6 +146,7 @@ struct AnsDecodeArgs {
     uint32_t* n_words_out;
     int32_t* status;
     uint32_t flags;
+    uint64_t words_capacity;  // uint32 slots behind `words` (0 = unknown): see word_slice
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -995,7 +996,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const int bucket_shift = P - a.bucket_bits;
 
     DecLane<W, S, SLOTS, AHEAD> L;
-    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    const WordSlice ws = active ? word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words + ws.off, ws.n, ring, lane);
     if (raw) L.state = active ? (typename StateT<S>::type)a.state[s] : 0;
     else L.read_initial_state();
     L.in.prime();
@@ -1155,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     }
 
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         a.state[s] = (uint64_t)L.state;
         if (a.n_words_out) a.n_words_out[s] = L.in.rd;

@@ -33,6 +33,7 @@ struct PsArgs {
     uint64_t* state;
     int32_t* status;
     uint32_t flags;
+    uint64_t words_capacity;   // decode: uint32 slots behind `words_in` (0 = unknown): see word_slice
 };
 
 // this lane's column of its wave's transposed table: entry i at base[i * kWave]
@@ -168,7 +169,8 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
     LaneRow R{rows + (size_t)(threadIdx.x >> 6) * a.L * kWave + lane};
 
     DecLane<W, S> L;
-    L.init(a.words_in + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words_in[s] : 0u, ring, lane);
+    const WordSlice ws = active ? word_slice(a.offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words_in + ws.off, ws.n, ring, lane);
     if (raw) L.state = active ? (st_t)a.state[s] : 0;
     else L.read_initial_state();
     L.in.prime();
@@ -253,7 +255,7 @@ __global__ void ans_decode_ps_kernel(const PsArgs a) {
         if (--countdown <= 0) { countdown = G4; L.in.advance_window(); }
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         a.state[s] = (uint64_t)L.state;
         if (a.n_words_left) a.n_words_left[s] = L.in.rd;
@@ -298,11 +300,12 @@ cst_status ans_encode_per_stream(const cst_model* model, cst_coder_config cfg, c
 }
 
 cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                                 size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                                 size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
                                  size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
                                  int32_t* d_status, uint32_t flags, hipStream_t hs) {
     if (model->n_tables != n_streams || !model->d_cdf16) return CST_ERR_INVALID_ARGUMENT;
     PsArgs a{};
+    a.words_capacity = words_capacity;
     a.symbols_out = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout;
     a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
     a.cdf16 = model->d_cdf16; a.L = model->cdf16_stride; a.words_in = d_words; a.offsets = d_offsets;

@@ -51,6 +51,7 @@ struct PtArgs {
     uint64_t* state;
     int32_t* status;
     uint32_t flags;
+    uint64_t words_capacity;   // decode: uint32 slots behind `words_in` (0 = unknown): see word_slice
 };
 
 // Main loop of the decoder for P = 12: all full tiles of a FULL wave in one asm statement (generated, with its wait
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     const uint8_t* l1p = l1_l + (((threadIdx.x >> bshift) * kPtBuckets) << bshift) + (threadIdx.x & ((1u << bshift) - 1u));
 
     DecLane<32, 64, kPtRingSlots, kPtAhead> L;
-    L.init(a.words_in + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words_in[s] : 0u, ring, lane);
+    const WordSlice ws = active ? word_slice(a.offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words_in + ws.off, ws.n, ring, lane);
     if (raw) L.state = active ? a.state[s] : 0;
     else L.read_initial_state();
     L.in.prime();
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
         L.in.advance_window();
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         a.state[s] = ((uint64_t)hi << 32) | lo;
         if (a.n_words_left) a.n_words_left[s] = L.in.rd;
@@ -396,11 +398,12 @@ cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int
 }
 
 cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                         size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
-                         uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, hipStream_t hs) {
+                         size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                         size_t n_per_stream, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, hipStream_t hs) {
     (void)cfg;
     if (model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
     PtArgs a{};
+    a.words_capacity = words_capacity;
     a.symbols_out = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
     a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
     a.meta = model->d_pt_meta; a.rows_dec = model->d_pt_dec; a.l1 = model->d_pt_l1;

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kSmDecThreads) void ans_decode_small_kernel(const A
     const uint32_t qmask = (1u << P) - 1u;
 
     DecLane<32, 64, kSmRingSlots, kSmAhead> L;
-    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    const WordSlice ws = active ? word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words + ws.off, ws.n, ring, lane);
     if (raw) L.state = active ? a.state[s] : 0;
     else L.read_initial_state();
     L.in.prime();
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kSmDecThreads) void ans_decode_small_kernel(const A
         L.in.advance_window();
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         a.state[s] = ((uint64_t)hi << 32) | lo;
         if (a.n_words_out) a.n_words_out[s] = L.in.rd;

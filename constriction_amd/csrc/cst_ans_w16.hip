@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     // again): the wave then runs the main-loop statement like a full one
     const size_t se = active ? s : a.n_streams - 1;
     W16Lane L;
-    L.init(a.words + (a.offsets ? a.offsets[se] : se * a.stride_words), a.n_words[se], ring, lane);
+    const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, se, a.words_capacity);
+    L.init(a.words + ws.off, ws.n, ring, lane);
     L.read_initial_state();
     L.prime();
     wave_lds_fence();
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
         wave_lds_fence();
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
 }
 
 // ------------------------------------------------------------------------------------------------

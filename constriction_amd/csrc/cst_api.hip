@@ -280,7 +280,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
 }
 
 cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
-                                const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, const uint32_t* d_n_words,
                                 int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                 uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
@@ -291,17 +291,17 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))
-        return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, d_state,
-                             d_n_words_out, d_status, flags, (hipStream_t)stream);
+        return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream,
+                             d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
     if (model->per_stream)
-        return ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream,
-                                     layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
+        return ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams,
+                                     n_per_stream, layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
     AnsDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
-    a.status = d_status; a.flags = flags;
+    a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
     if (b16_decode_usable(a, cfg, layout)) return ans_decode_b16(a, layout, hs);                        // 12 < P <= 24

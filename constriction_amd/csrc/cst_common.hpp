@@ -131,7 +131,7 @@ cst_status ans_encode_per_stream(const cst_model* model, cst_coder_config cfg, c
                                  size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words,
                                  uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags, hipStream_t hs);
 cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                                 size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                                 size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
                                  size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
                                  int32_t* d_status, uint32_t flags, hipStream_t hs);
 
@@ -141,9 +141,25 @@ cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int
                          size_t n_per_stream, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
                          int32_t* d_status, uint32_t flags, hipStream_t hs);
 cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                         size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                         size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
                          size_t n_per_stream, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags,
                          hipStream_t hs);
+
+// Where stream s's compressed words lie in the caller's buffer -- CHECKED.  The reference's decoder cannot read out of
+// bounds (its backend is a Vec: src/backends.rs:495-507); here the counts and offsets are caller data, so a slice
+// [off, off + n) that leaves the buffer of `capacity` words (0 = capacity unknown, the caller vouches) or, in slab form,
+// its own slab of `stride` words (stride 0: every stream at offset 0, unchecked) is replaced by the empty slice at offset 0 and the stream reports
+// CST_STREAM_INVALID_DATA (decoding an empty stream is well defined: stack.rs:1070-1100 with state 0).
+struct WordSlice { uint64_t off; uint32_t n; bool bad; };
+__device__ __forceinline__ WordSlice word_slice(const uint64_t* offsets, size_t stride, const uint32_t* n_words, size_t s,
+                                                uint64_t capacity) {
+    WordSlice w;
+    w.off = offsets ? offsets[s] : (uint64_t)s * stride;
+    w.n = n_words[s];
+    w.bad = (!offsets && stride != 0 && w.n > stride) || (capacity != 0 && (w.off > capacity || w.n > capacity - w.off));
+    if (w.bad) { w.off = 0; w.n = 0; }
+    return w;
+}
 
 inline bool config_supported(cst_coder_config c) {
     if (c.word_bits == 32 && c.state_bits == 64) return c.precision >= 1 && c.precision <= 24;

@@ -280,6 +280,8 @@ struct PerSymbolDecodeArgs {
     cst_chain_heads* heads;
     int32_t* status;
     uint32_t flags;
+    uint64_t words_capacity;    // uint32 slots behind `words` (0 = unknown): see word_slice
+    __device__ __forceinline__ WordSlice slice(size_t s) const { return word_slice(offsets, stride_words, n_words, s, words_capacity); }
 };
 
 struct DecodeResume { uint64_t s0, s1, s2; uint32_t pos; int32_t status; };
@@ -293,8 +295,9 @@ struct DirectDecoder<W, S, kAns> {
     st_t state; uint32_t rd; const uint32_t* in; int32_t status;
     uint32_t ahead;                                           // in[rd - 1], requested when the word before it was taken
     __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
-        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
-        rd = a.n_words[s]; status = CST_STREAM_OK; state = 0; ahead = 0; idle = a.n_words + s;
+        const WordSlice ws = a.slice(s);
+        in = a.words + ws.off;
+        rd = ws.n; status = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (int32_t)CST_STREAM_OK; state = 0; ahead = 0; idle = a.n_words + s;
         if (raw) { state = (st_t)a.state[s]; look_ahead(); return; }
         if (rd == 0) return;                                  // read_initial_state, stack.rs:440-462
         const uint32_t first = in[--rd];
@@ -320,7 +323,7 @@ struct DirectDecoder<W, S, kAns> {
     // a decoder parked between two launches over consecutive pieces of the same stream
     __device__ __forceinline__ void park(DecodeResume& r) const { r.s0 = (uint64_t)state; r.pos = rd; }
     __device__ __forceinline__ void resume(const PerSymbolDecodeArgs& a, size_t s, const DecodeResume& r) {
-        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
+        in = a.words + a.slice(s).off;
         idle = a.n_words + s; status = CST_STREAM_OK; ahead = 0;
         state = (st_t)r.s0; rd = r.pos;
         look_ahead();
@@ -335,8 +338,9 @@ struct DirectDecoder<W, S, kRange> {
     const uint32_t* idle;                                     // (see the ANS decoder)
     __device__ __forceinline__ void look_ahead() { ahead = *(pos < len ? in + pos : idle); }
     __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
-        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
-        len = a.n_words[s]; pos = 0; L.status = CST_STREAM_OK; idle = a.n_words + s;
+        const WordSlice ws = a.slice(s);
+        in = a.words + ws.off;
+        len = ws.n; pos = 0; L.status = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (int32_t)CST_STREAM_OK; idle = a.n_words + s;
         L.lower = 0; L.range = (st_t)~(st_t)0;
         if (raw) {
             const cst_range_state r = a.rstate[s];
@@ -347,7 +351,7 @@ struct DirectDecoder<W, S, kRange> {
             if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
             L.point = pt;
         }
-        status = CST_STREAM_OK; ahead = 0;
+        status = L.status; ahead = 0;
         look_ahead();
     }
     __device__ __forceinline__ uint32_t quantile(int P) { const uint32_t q = L.peek_quantile(P); status = L.status; return q; }
@@ -366,8 +370,9 @@ struct DirectDecoder<W, S, kRange> {
         r.s0 = (uint64_t)L.lower; r.s1 = (uint64_t)L.range; r.s2 = (uint64_t)L.point; r.pos = pos;
     }
     __device__ __forceinline__ void resume(const PerSymbolDecodeArgs& a, size_t s, const DecodeResume& r) {
-        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
-        idle = a.n_words + s; len = a.n_words[s]; status = CST_STREAM_OK; L.status = CST_STREAM_OK; ahead = 0;
+        const WordSlice ws = a.slice(s);
+        in = a.words + ws.off;
+        idle = a.n_words + s; len = ws.n; status = CST_STREAM_OK; L.status = CST_STREAM_OK; ahead = 0;
         L.lower = (st_t)r.s0; L.range = (st_t)r.s1; L.point = (st_t)r.s2; pos = r.pos;
         look_ahead();
     }
@@ -383,8 +388,9 @@ struct DirectDecoder<W, S, kChain> {
     uint32_t ahead; const uint32_t* idle;
     __device__ __forceinline__ void look_ahead() { ahead = *(rd > 0 ? in + (rd - 1) : idle); }
     __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool) {
-        in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
-        rd = a.n_words[s]; idle = a.n_words + s; status = CST_STREAM_OK;
+        const WordSlice ws = a.slice(s);
+        in = a.words + ws.off;
+        rd = ws.n; idle = a.n_words + s; status = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (int32_t)CST_STREAM_OK;
         const cst_chain_heads h = a.heads[s];
         rh = (st_t)h.remainders_head; ch = h.compressed_head;
         out = a.push_words + s * a.push_stride;
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(kWave) void decode_rows_wave_kernel(const RowsDecod
     if (ra.first) { D.init(a, s, raw); status = D.status; }
     else { const DecodeResume r = ra.resume[s]; D.resume(a, s, r); status = r.status; }
     WordBlock<KIND> words;
-    const uint32_t n_words = max(a.n_words[s], 1u);
+    const uint32_t n_words = max(a.slice(s).n, 1u);
     auto fetch_words = [&]() {
         if constexpr (KIND == kAns) words.fetch(D.in, n_words, D.rd, lane);
         else words.fetch(D.in, n_words, D.pos, lane);
@@ -801,9 +807,10 @@ __global__ __launch_bounds__(kWave) void chain_quantiles_kernel(const PerSymbolD
     const int lane = threadIdx.x;
     const size_t s = blockIdx.x, N = a.n_per_stream;
     const int P = a.precision;
-    const uint32_t* in = a.words + (a.offsets ? a.offsets[s] : s * a.stride_words);
-    const uint32_t n_words = max(a.n_words[s], 1u);
-    uint32_t rd = a.n_words[s];
+    const WordSlice ws = a.slice(s);
+    const uint32_t* in = a.words + ws.off;
+    const uint32_t n_words = max(ws.n, 1u);
+    uint32_t rd = ws.n;
     uint32_t ch = a.heads[s].compressed_head;
     WordBlock<kAns> words;
     uint32_t mine = 0;
@@ -949,19 +956,42 @@ static cst_status launch_encode_entries(cst_coder_config cfg, const EntriesEncod
     return CST_OK;
 }
 
-// The entry buffer (16 bytes per symbol) comes from the device's stream-ordered pool; by default the pool returns freed
-// memory to the system at the next synchronisation, and allocating 4 GiB afresh costs more than coding them (measured:
-// 70 of 88 ms per call at 65 536 x 4096).  Tell the pool to keep it.
-static void keep_pool_memory() {
-    static thread_local int done_for_device = -1;
+// Scratch (encoder entries, cdf rows of few-stream decodes, chain quantiles) comes from a stream-ordered memory pool
+// that belongs to THIS LIBRARY -- one per device, created at first use -- whose release threshold is raised so that it
+// keeps freed memory: a pool at its defaults hands everything back at the next synchronisation, and allocating 4 GiB
+// afresh costs more than coding them (measured: 70 of 88 ms per call at 65 536 x 4096).  The device's DEFAULT pool is
+// never touched: a host application's own hipMallocAsync traffic (PyTorch's async allocator, say) keeps its behaviour.
+static std::mutex g_pool_mutex;
+static hipMemPool_t g_pools[64] = {};
+
+static hipError_t scratch_pool(hipMemPool_t* out) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev == done_for_device) return;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (!g_pools[dev]) {
+        hipMemPoolProps props{};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        e = hipMemPoolCreate(&pool, &props);
+        if (e != hipSuccess) return e;
         uint64_t keep = ~0ull;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        g_pools[dev] = pool;
     }
-    done_for_device = dev;
+    *out = g_pools[dev];
+    return hipSuccess;
+}
+
+static hipError_t scratch_alloc(void** ptr, size_t bytes, hipStream_t hs) {
+    hipMemPool_t pool;
+    hipError_t e = scratch_pool(&pool);
+    if (e != hipSuccess) return e;
+    return hipMallocFromPoolAsync(ptr, bytes, pool, hs);
 }
 
 // pass 1 (entries) + pass 2 (sequential coder); `fill` launches the entry kernel into the temporary buffer
@@ -976,8 +1006,7 @@ static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t
     const size_t n = n_streams * n_per_stream;
     EncEntry* entries = nullptr;
     if (n > 0) {
-        keep_pool_memory();
-        CST_HIP_TRY(hipMallocAsync((void**)&entries, n * sizeof(EncEntry), hs));
+        CST_HIP_TRY(scratch_alloc((void**)&entries, n * sizeof(EncEntry), hs));
         fill(entries, n);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_hip_error(e, "entry kernel"); (void)hipFreeAsync(entries, hs); return CST_ERR_HIP; }
@@ -999,11 +1028,10 @@ static cst_status decode_gaussian_by_rows(cst_coder_config cfg, const PerSymbolD
     // sequential kernel is bound by its dependent instruction chain, not by the rows' memory latency)
     size_t piece = ((size_t)65536 / a.n_streams) & ~(size_t)63;        // (n_streams < 64: at least 1024 symbols)
     if (piece > N) piece = N;
-    keep_pool_memory();
     uint32_t* rows = nullptr;
     DecodeResume* resume = nullptr;
-    CST_HIP_TRY(hipMallocAsync((void**)&rows, a.n_streams * piece * kRowEntries * sizeof(uint32_t), hs));
-    hipError_t err = hipMallocAsync((void**)&resume, a.n_streams * sizeof(DecodeResume), hs);
+    CST_HIP_TRY(scratch_alloc((void**)&rows, a.n_streams * piece * kRowEntries * sizeof(uint32_t), hs));
+    hipError_t err = scratch_alloc((void**)&resume, a.n_streams * sizeof(DecodeResume), hs);
     for (size_t t0 = 0; t0 < N && err == hipSuccess; t0 += piece) {
         const size_t count = N - t0 < piece ? N - t0 : piece;
         hipLaunchKernelGGL(gaussian_rows_kernel, dim3((unsigned)(a.n_streams * count)), dim3(kRowEntries), 0, hs, a.precision, a.min_symbol,
@@ -1022,9 +1050,8 @@ static cst_status decode_gaussian_by_rows(cst_coder_config cfg, const PerSymbolD
 // a few chains: cut the quantiles, search all symbols in parallel, fold the remainders
 static cst_status decode_chains_in_three(cst_coder_config cfg, const PerSymbolDecodeArgs& a, bool gaussian, hipStream_t hs) {
     const size_t n = a.n_streams * a.n_per_stream;
-    keep_pool_memory();
     uint32_t* scratch = nullptr;                 // [quantiles n][pairs 2n][n_cut n_streams]
-    CST_HIP_TRY(hipMallocAsync((void**)&scratch, (3 * n + a.n_streams + 2) * sizeof(uint32_t), hs));
+    CST_HIP_TRY(scratch_alloc((void**)&scratch, (3 * n + a.n_streams + 2) * sizeof(uint32_t), hs));
     uint32_t* quantiles = scratch;
     uint2* pairs = reinterpret_cast<uint2*>(scratch + ((n + 1) & ~(size_t)1));
     uint32_t* n_cut = scratch + ((n + 1) & ~(size_t)1) + 2 * n;
@@ -1067,7 +1094,7 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
 }
 
 static cst_status fill_decode_args(PerSymbolDecodeArgs& a, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
-                                   size_t stride_words, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
+                                   size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams,
                                    size_t n_per_stream, cst_layout layout, int32_t min_symbol, int64_t n_symbols, int32_t* d_status,
                                    uint32_t flags) {
     if (cst_status st = check_common(cfg, layout)) return st;
@@ -1077,7 +1104,7 @@ static cst_status fill_decode_args(PerSymbolDecodeArgs& a, cst_coder_config cfg,
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.precision = cfg.precision;
     a.min_symbol = min_symbol; a.n_symbols = (int32_t)n_symbols; a.status = d_status; a.flags = flags;
-    a.row_stride = (size_t)n_symbols + 1;
+    a.row_stride = (size_t)n_symbols + 1; a.words_capacity = words_capacity;
     return CST_OK;
 }
 
@@ -1086,7 +1113,7 @@ static cst_status chain_decode_common(PerSymbolDecodeArgs& a, cst_coder_config c
                                       size_t pop_stride, uint32_t* d_n_pop, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
                                       cst_layout layout, int32_t min_symbol, int64_t n_symbols, uint32_t* d_push_words, size_t push_stride,
                                       uint32_t* d_n_push, cst_chain_heads* d_heads, int32_t* d_status) {
-    if (cst_status st = fill_decode_args(a, cfg, d_pop_words, d_pop_offsets, pop_stride, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
+    if (cst_status st = fill_decode_args(a, cfg, d_pop_words, d_pop_offsets, pop_stride, 0, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, n_symbols, d_status, 0)) return st;
     if (!d_heads || !d_n_push || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
     a.push_words = d_push_words; a.push_stride = push_stride; a.n_push = d_n_push; a.heads = d_heads; a.n_words_out = d_n_pop;
@@ -1104,8 +1131,7 @@ static cst_status chain_encode_common(cst_coder_config cfg, size_t n_streams, si
     const size_t n = n_streams * n_per_stream;
     EncEntry* entries = nullptr;
     if (n > 0) {
-        keep_pool_memory();
-        CST_HIP_TRY(hipMallocAsync((void**)&entries, n * sizeof(EncEntry), hs));
+        CST_HIP_TRY(scratch_alloc((void**)&entries, n * sizeof(EncEntry), hs));
         fill(entries, n);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_hip_error(e, "entry kernel"); (void)hipFreeAsync(entries, hs); return CST_ERR_HIP; }
@@ -1126,10 +1152,8 @@ using namespace cst;
 extern "C" {
 
 cst_status cst_release_scratch(void) {
-    int dev = 0;
-    CST_HIP_TRY(hipGetDevice(&dev));
     hipMemPool_t pool;
-    CST_HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+    CST_HIP_TRY(scratch_pool(&pool));
     CST_HIP_TRY(hipDeviceSynchronize());
     CST_HIP_TRY(hipMemPoolTrimTo(pool, 0));
     return CST_OK;
@@ -1186,13 +1210,13 @@ cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_sym
 }
 
 cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
-                                         const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                         const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, const uint32_t* d_n_words,
                                          const double* d_means, const double* d_stds, int32_t* d_symbols, size_t n_streams,
                                          size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
                                          int32_t* d_status, uint32_t flags, void* stream) {
     PerSymbolDecodeArgs a{};
     if (max_symbol <= min_symbol) return CST_ERR_MODEL;
-    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, (int64_t)max_symbol - min_symbol + 1, d_status, flags)) return st;
     if (n_per_stream > 0 && (!d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
@@ -1201,13 +1225,13 @@ cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
 }
 
 cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
-                                           const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                           const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, const uint32_t* d_n_words,
                                            const double* d_means, const double* d_stds, int32_t* d_symbols, size_t n_streams,
                                            size_t n_per_stream, cst_layout layout, cst_range_state* d_rstate, int32_t* d_status,
                                            uint32_t flags, void* stream) {
     PerSymbolDecodeArgs a{};
     if (max_symbol <= min_symbol) return CST_ERR_MODEL;
-    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, (int64_t)max_symbol - min_symbol + 1, d_status, flags)) return st;
     if (n_per_stream > 0 && (!d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;
@@ -1215,12 +1239,12 @@ cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_sym
     return decode_per_symbol<kRange>(cfg, a, true, (hipStream_t)stream);
 }
 
-cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words, size_t words_capacity,
                                      const uint32_t* d_n_words, const uint32_t* d_cdf_rows, int32_t n_symbols, int32_t min_symbol,
                                      int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout, uint64_t* d_state,
                                      uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream) {
     PerSymbolDecodeArgs a{};
-    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, n_symbols, d_status, flags)) return st;
     if (n_per_stream > 0 && !d_cdf_rows) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
@@ -1228,12 +1252,12 @@ cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_wor
     return decode_per_symbol<kAns>(cfg, a, false, (hipStream_t)stream);
 }
 
-cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words, size_t words_capacity,
                                        const uint32_t* d_n_words, const uint32_t* d_cdf_rows, int32_t n_symbols, int32_t min_symbol,
                                        int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                        cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
     PerSymbolDecodeArgs a{};
-    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+    if (cst_status st = fill_decode_args(a, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, n_symbols, d_status, flags)) return st;
     if (n_per_stream > 0 && !d_cdf_rows) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_rstate) return CST_ERR_INVALID_ARGUMENT;

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeA
     const int bucket_shift = P - a.bucket_bits;
 
     RangeDecLane<W, S> L;
-    L.init(a.words + (active ? (a.offsets ? a.offsets[s] : s * a.stride_words) : 0), active ? a.n_words[s] : 0u, ring, lane);
+    const WordSlice ws = active ? word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words + ws.off, ws.n, ring, lane);
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     if (raw && active) {
         const cst_range_state r = a.rstate[s];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_kernel(const RangeDecodeA
         }
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         cst_range_state r = a.rstate[s];
         r.lower = (uint64_t)L.lower; r.range = (uint64_t)L.range; r.point = (uint64_t)L.point; r.position = L.in.pos;
@@ -323,7 +324,7 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
 }
 
 cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
-                                  const uint64_t* d_offsets, size_t stride_words, const uint32_t* d_n_words,
+                                  const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, const uint32_t* d_n_words,
                                   int32_t* d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                   cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
@@ -338,7 +339,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
-    a.rstate = d_rstate; a.flags = flags;
+    a.rstate = d_rstate; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
     if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, hs);
     if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);

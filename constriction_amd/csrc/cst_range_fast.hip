@@ -306,8 +306,9 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     const int bucket_shift = P - a.bucket_bits;
     // the lanes of a partial wave beyond its last stream repeat that stream (see the encoder)
     const size_t se = active ? s : a.n_streams - 1;
-    const uint32_t* my_words = a.words + (a.offsets ? a.offsets[se] : se * a.stride_words);
-    const uint32_t my_len = a.n_words[se];
+    const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, se, a.words_capacity);
+    const uint32_t* my_words = a.words + ws.off;
+    const uint32_t my_len = ws.n;
 
     RangeDecLane<32, 64, kRdSlots, kRdAhead> L;
     L.init(my_words, my_len, ring, lane);
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
         L.in.advance_window();
     }
     if (!active) return;
-    a.status[s] = L.status;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
 }
 
 static size_t range_decode_fast_lds(const RangeDecodeArgs& a) {

@@ -39,6 +39,7 @@ struct RangeDecodeArgs {
     int32_t* status;
     cst_range_state* rstate;
     uint32_t flags;
+    uint64_t words_capacity;  // uint32 slots behind `words` (0 = unknown): see word_slice
 };
 
 // cst_range_fast.hip: the hand-scheduled (32,64) kernels; `*_usable` says whether a call qualifies

@@ -5,7 +5,8 @@
 //   (1) cst_gather_sizes_rccl : one ncclAllGather of (n_streams, total_words) per rank (16 bytes each),
 //   (2) cst_gather_rccl       : grouped ncclSend / ncclRecv of the packed words and of the local offsets straight into
 //                               their final positions on the root (every peer uses its own xGMI link to the root), then
-//                               one small kernel on the root turns local offsets into global ones.
+//                               one small kernel on the root turns local offsets into global ones;
+//   (3) cst_scatter_rccl      : the inverse, for decoding on the ranks what one rank holds.
 // librccl is opened at first use (dlopen "librccl.so.1"): the coder library itself has no link-time dependency on it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -57,10 +58,12 @@ __global__ void own_sizes_kernel(const uint64_t* __restrict__ offsets, size_t n_
 }
 
 // global offsets of rank r's streams: local offset + words of the ranks before it
-__global__ void rebase_offsets_kernel(uint64_t* __restrict__ all_offsets, size_t first, size_t n, uint64_t words_before) {
+__global__ void rebase_offsets_kernel(uint64_t* __restrict__ all_offsets, size_t first, size_t n, int64_t delta) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) all_offsets[first + i] += words_before;
+    if (i < n) all_offsets[first + i] += (uint64_t)delta;
 }
+
+__global__ void set_u64_kernel(uint64_t* __restrict__ slot, uint64_t value) { *slot = value; }
 
 } // namespace cst
 
@@ -105,6 +108,27 @@ cst_status cst_gather_sizes_rccl(void* comm, int32_t n_ranks, int32_t rank, cons
     return CST_OK;
 }
 
+// One group of point-to-point operations: the first failure is REMEMBERED, the group is always closed (a thread that
+// returned between ncclGroupStart and ncclGroupEnd would leave the group open: later collectives on the communicator hang,
+// and the peers block in their own GroupEnd), and only then is the failure reported.
+struct Group {
+    cst_status st = CST_OK;
+    bool open = false;
+    Group() {
+        if (rccl().GroupStart() == ncclSuccess) open = true;
+        else fail("rccl: ncclGroupStart");
+    }
+    void fail(const char* what) { if (st == CST_OK) { set_hip_error(hipErrorUnknown, what); st = CST_ERR_HIP; } }
+    void nccl(ncclResult_t r, const char* what) { if (r != ncclSuccess) fail(what); }
+    void hip(hipError_t e, const char* what) { if (e != hipSuccess && st == CST_OK) { set_hip_error(e, what); st = CST_ERR_HIP; } }
+    bool good() const { return open && st == CST_OK; }       // (after a failure nothing more is posted)
+    cst_status end() {
+        if (open) { open = false; nccl(rccl().GroupEnd(), "rccl: ncclGroupEnd"); }
+        return st;
+    }
+    ~Group() { if (open) (void)rccl().GroupEnd(); }
+};
+
 cst_status cst_gather_rccl(void* comm, int32_t n_ranks, int32_t rank, int32_t root, const uint32_t* d_packed, const uint64_t* d_offsets,
                            const uint64_t* h_sizes, uint32_t* d_all_packed, uint64_t* d_all_offsets, void* stream) {
     if (!comm || !h_sizes || n_ranks < 1 || rank < 0 || rank >= n_ranks || root < 0 || root >= n_ranks) return CST_ERR_INVALID_ARGUMENT;
@@ -114,39 +138,81 @@ cst_status cst_gather_rccl(void* comm, int32_t n_ranks, int32_t rank, int32_t ro
     const size_t my_streams = (size_t)h_sizes[2 * rank], my_words = (size_t)h_sizes[2 * rank + 1];
     if ((my_words > 0 && !d_packed) || (my_streams > 0 && !d_offsets)) return CST_ERR_INVALID_ARGUMENT;
     if (rank != root) {
-        CST_NCCL_TRY(rccl().GroupStart());
-        if (my_words) CST_NCCL_TRY(rccl().Send(d_packed, my_words, ncclUint32, root, c, hs));
-        if (my_streams) CST_NCCL_TRY(rccl().Send(d_offsets, my_streams, ncclUint64, root, c, hs));
-        CST_NCCL_TRY(rccl().GroupEnd());
-        return CST_OK;
+        Group g;
+        if (g.good() && my_words) g.nccl(rccl().Send(d_packed, my_words, ncclUint32, root, c, hs), "rccl: ncclSend(words)");
+        if (g.good() && my_streams) g.nccl(rccl().Send(d_offsets, my_streams, ncclUint64, root, c, hs), "rccl: ncclSend(offsets)");
+        return g.end();
     }
     if (!d_all_packed || !d_all_offsets) return CST_ERR_INVALID_ARGUMENT;
     size_t words_before = 0, streams_before = 0;
-    CST_NCCL_TRY(rccl().GroupStart());
-    for (int r = 0; r < n_ranks; ++r) {
-        const size_t ns = (size_t)h_sizes[2 * r], nw = (size_t)h_sizes[2 * r + 1];
-        if (r == rank) {
-            if (nw) CST_HIP_TRY(hipMemcpyAsync(d_all_packed + words_before, d_packed, 4 * nw, hipMemcpyDeviceToDevice, hs));
-            if (ns) CST_HIP_TRY(hipMemcpyAsync(d_all_offsets + streams_before, d_offsets, 8 * ns, hipMemcpyDeviceToDevice, hs));
-        } else {
-            if (nw) CST_NCCL_TRY(rccl().Recv(d_all_packed + words_before, nw, ncclUint32, r, c, hs));
-            if (ns) CST_NCCL_TRY(rccl().Recv(d_all_offsets + streams_before, ns, ncclUint64, r, c, hs));
+    {
+        Group g;
+        for (int r = 0; r < n_ranks; ++r) {
+            const size_t ns = (size_t)h_sizes[2 * r], nw = (size_t)h_sizes[2 * r + 1];
+            if (r == rank) {
+                if (g.good() && nw) g.hip(hipMemcpyAsync(d_all_packed + words_before, d_packed, 4 * nw, hipMemcpyDeviceToDevice, hs), "gather: own words");
+                if (g.good() && ns) g.hip(hipMemcpyAsync(d_all_offsets + streams_before, d_offsets, 8 * ns, hipMemcpyDeviceToDevice, hs), "gather: own offsets");
+            } else {
+                if (g.good() && nw) g.nccl(rccl().Recv(d_all_packed + words_before, nw, ncclUint32, r, c, hs), "rccl: ncclRecv(words)");
+                if (g.good() && ns) g.nccl(rccl().Recv(d_all_offsets + streams_before, ns, ncclUint64, r, c, hs), "rccl: ncclRecv(offsets)");
+            }
+            words_before += nw; streams_before += ns;
         }
-        words_before += nw; streams_before += ns;
+        if (cst_status st = g.end()) return st;
     }
-    CST_NCCL_TRY(rccl().GroupEnd());
-    // local offsets -> global offsets (after the receives, same stream)
+    // local offsets -> global offsets (after the receives, same stream); offsets[n_total] = all words.  No host
+    // synchronisation: the call is asynchronous on `stream` like every other one.
     words_before = 0; streams_before = 0;
     for (int r = 0; r < n_ranks; ++r) {
         const size_t ns = (size_t)h_sizes[2 * r], nw = (size_t)h_sizes[2 * r + 1];
         if (ns && words_before)
-            hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, hs, d_all_offsets, streams_before, ns, words_before);
+            hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, hs, d_all_offsets, streams_before, ns, (int64_t)words_before);
         words_before += nw; streams_before += ns;
     }
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, hs, d_all_offsets + streams_before, (uint64_t)words_before);
     CST_HIP_TRY(hipGetLastError());
-    const uint64_t total = words_before;
-    CST_HIP_TRY(hipMemcpyAsync(d_all_offsets + streams_before, &total, 8, hipMemcpyHostToDevice, hs));   // offsets[n_total] = all words
-    CST_HIP_TRY(hipStreamSynchronize(hs));   // (`total` lives on this stack frame)
+    return CST_OK;
+}
+
+// The inverse ("decode needs the inverse scatter"): the root holds the packed words of all ranks' streams and
+// the global offsets[n_total + 1]; rank r receives its own words and its offsets[n_r + 1] rebased to start at 0 -- the
+// form cst_ans_decode_batch / cst_range_decode_batch take.  h_sizes as in cst_gather_rccl (known on every rank).
+cst_status cst_scatter_rccl(void* comm, int32_t n_ranks, int32_t rank, int32_t root, const uint32_t* d_all_packed,
+                            const uint64_t* d_all_offsets, const uint64_t* h_sizes, uint32_t* d_packed, uint64_t* d_offsets, void* stream) {
+    if (!comm || !h_sizes || n_ranks < 1 || rank < 0 || rank >= n_ranks || root < 0 || root >= n_ranks) return CST_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return CST_ERR_NO_DEVICE;
+    hipStream_t hs = (hipStream_t)stream;
+    ncclComm_t c = reinterpret_cast<ncclComm_t>(comm);
+    const size_t my_streams = (size_t)h_sizes[2 * rank], my_words = (size_t)h_sizes[2 * rank + 1];
+    if ((my_words > 0 && !d_packed) || !d_offsets) return CST_ERR_INVALID_ARGUMENT;
+    size_t my_words_before = 0;
+    for (int r = 0; r < rank; ++r) my_words_before += (size_t)h_sizes[2 * r + 1];
+    if (rank != root) {
+        Group g;
+        if (g.good() && my_words) g.nccl(rccl().Recv(d_packed, my_words, ncclUint32, root, c, hs), "rccl: ncclRecv(words)");
+        if (g.good()) g.nccl(rccl().Recv(d_offsets, my_streams + 1, ncclUint64, root, c, hs), "rccl: ncclRecv(offsets)");
+        if (cst_status st = g.end()) return st;
+    } else {
+        if (!d_all_packed || !d_all_offsets) return CST_ERR_INVALID_ARGUMENT;
+        size_t words_before = 0, streams_before = 0;
+        Group g;
+        for (int r = 0; r < n_ranks; ++r) {
+            const size_t ns = (size_t)h_sizes[2 * r], nw = (size_t)h_sizes[2 * r + 1];
+            if (r == rank) {
+                if (g.good() && nw) g.hip(hipMemcpyAsync(d_packed, d_all_packed + words_before, 4 * nw, hipMemcpyDeviceToDevice, hs), "scatter: own words");
+                if (g.good()) g.hip(hipMemcpyAsync(d_offsets, d_all_offsets + streams_before, 8 * (ns + 1), hipMemcpyDeviceToDevice, hs), "scatter: own offsets");
+            } else {
+                if (g.good() && nw) g.nccl(rccl().Send(d_all_packed + words_before, nw, ncclUint32, r, c, hs), "rccl: ncclSend(words)");
+                if (g.good()) g.nccl(rccl().Send(d_all_offsets + streams_before, ns + 1, ncclUint64, r, c, hs), "rccl: ncclSend(offsets)");
+            }
+            words_before += nw; streams_before += ns;
+        }
+        if (cst_status st = g.end()) return st;
+    }
+    if (my_words_before)      // global -> local offsets
+        hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((my_streams + 256) / 256)), dim3(256), 0, hs, d_offsets, (size_t)0, my_streams + 1,
+                           -(int64_t)my_words_before);
+    CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
 

@@ -168,6 +168,26 @@ class RcclComm:
         N.check(lib.cst_gather_rccl(self._h, self.world, self.rank, dst, C.c_void_p(packed.data_ptr()), C.c_void_p(offsets.data_ptr()),
                                     h_sizes.ctypes.data, C.c_void_p(all_packed.data_ptr()) if all_packed is not None else None,
                                     C.c_void_p(all_off.data_ptr()) if all_off is not None else None, sp), "cst_gather_rccl")
+        self.last_sizes = h_sizes                                              # (n_streams, n_words) per rank, for scatter_packed
         if self.rank == dst:
             return all_packed[: int(h_sizes[1::2].sum())], all_off
         return None
+
+    def scatter_packed(self, all_packed, all_offsets, h_sizes=None, src: int = 0, device=None):
+        """Inverse of gather_packed (cst_scatter_rccl): `src` hands every rank the words of its own streams and their offsets
+        rebased to 0.  h_sizes: (n_streams, n_words) per rank as a flat uint64 array (default: those of the last gather).
+        Returns (packed_local, offsets_local) on every rank."""
+        import ctypes as C
+        import numpy as np
+        from . import _native as N
+        lib = N.lib()
+        h_sizes = np.ascontiguousarray(self.last_sizes if h_sizes is None else h_sizes, dtype=np.uint64)
+        dev = device or (all_offsets.device if all_offsets is not None else torch.device("cuda", torch.cuda.current_device()))
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n_local, w_local = int(h_sizes[2 * self.rank]), int(h_sizes[2 * self.rank + 1])
+        packed = torch.empty(max(w_local, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(n_local + 1, dtype=torch.int64, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        N.check(lib.cst_scatter_rccl(self._h, self.world, self.rank, src, p(all_packed), p(all_offsets), h_sizes.ctypes.data,
+                                     p(packed), p(offsets), sp), "cst_scatter_rccl")
+        return packed[:w_local], offsets

@@ -3,18 +3,20 @@
 Mirrors src/pybindings/stream/model.rs: every model fixes PRECISION = 24 bits, Symbol = i32, Probability = u32
 (src/pybindings/stream/model/internals.rs:26-39).  A model is either *concrete* (all parameters given to the
 constructor; usable for i.i.d. symbols) or a *family* (parameters passed per symbol to encode/decode).
-The cumulative tables of concrete models are built on the GPU (Gaussian, bit-exact f64) or on the host
-(categorical quantisations, leaky quantisation of other continuous families: a handful of floats) and live in HBM as a
-`cst_model`.
+The cumulative tables are built by the HIP library: on the GPU in bit-exact f64 (Gaussian: cst_model_create_gaussian;
+Laplace / Cauchy / Binomial: cst_family_cdf_rows, one thread per table entry), in host C++ where the algorithm is a
+sequential search (Categorical(perfect=True): cst_categorical_perfect_cdf), and here in numpy only for the "fast"
+categorical quantisation (two vector operations in the caller's dtype) and for user-supplied Python CDFs
+(CustomModel / ScipyModel: the CDF is a Python callable in the reference too).  They live in HBM as a `cst_model`.
 
-What pins which family (tests/golden/reference_vectors.json holds the reference's own vectors):
+What pins which family (tests/golden/*.json hold the reference's own vectors):
   QuantizedGaussian, Categorical(perfect=False / lazy=True), CustomModel, ScipyModel   -- golden vectors
   Uniform                                                                             -- integer arithmetic only (uniform.rs)
-  Categorical(perfect=True), Bernoulli                                                -- restated from categorical.rs:56-177;
-        the reference holds no vector for them, and the result depends on libm's log1p to the last bit
-  QuantizedLaplace, QuantizedCauchy, Binomial                                         -- leaky quantisation is exact, but the
-        continuous CDF lives in the un-vendored `probability` crate and no vector pins it: tables can differ from the
-        reference's by one unit in rare entries (documented in DESIGN.md as UNPINNED)
+  Categorical(perfect=True), Bernoulli                                                -- categorical.rs:56-177 over libm::log1p;
+        no reference vector exists; compared with the oracle's separate restatement (tests/test_model_families_cpu.py)
+  QuantizedLaplace, QuantizedCauchy, Binomial                                         -- the CDFs live in the un-vendored
+        `probability` crate and no reference vector pins them; device tables are compared bit for bit with the oracle's
+        separate restatement (tests/test_gpu_model_families.py), which DEFINES the last ulp
 """
 from __future__ import annotations
 
@@ -82,72 +84,22 @@ def perfect_quantized_cdf(probabilities: np.ndarray, precision: int = PRECISION)
     """`perfectly_quantized_probabilities` + cumulation (src/stream/model/categorical.rs:56-177, contiguous.rs:301-313):
     start from weight 1 + trunc(p * (2^P - n) / sum p) per symbol, hand the remaining weight to the symbols with the
     largest win, then move single units from the cheapest seller to the best buyer while that lowers the cross entropy.
-    f64 throughout (f32 inputs are widened: `F: Into<f64>`); ties resolve like Rust's stable sort / max_by (last
-    maximum) / min_by (first minimum)."""
-    import math
+    f64 throughout (f32 inputs are widened: `F: Into<f64>`).  Runs in the library's host code
+    (cst_categorical_perfect_cdf, csrc/cst_families.hip) over its own `libm::log1p`."""
+    from .. import _native as N
     p = np.asarray(probabilities)
     if p.dtype not in (np.float32, np.float64):
         p = p.astype(np.float64)
     if p.ndim != 1:
         raise ValueError("probabilities must be rank 1")
-    err = ValueError("Probability distribution not normalizable (the array of probabilities\n"
-                     "might be empty, contain negative values or NaNs, or sum to infinity).")
-    n = p.shape[0]
-    if n < 2 or n > 0xFFFFFFFF:
-        raise err
-    probs = [float(x) for x in p]
-    norm = 0.0
-    for x in probs:                      # Iterator::sum over f64
-        norm += x
-    if not math.isfinite(norm) or not norm >= 2.2250738585072014e-308:
-        raise err
-    remaining = (1 << precision) - n
-    if remaining < 0:
-        raise err
-    scale = float(remaining) / norm
-    inf = math.inf
-    weight, win, loss = [0] * n, [0.0] * n, [0.0] * n
-    for i, x in enumerate(probs):
-        if x < 0.0:
-            raise err
-        v = x * scale
-        free = 0 if not v > 0.0 else (0xFFFFFFFF if v >= 4294967295.0 else int(v))
-        remaining -= free
-        if remaining < 0:
-            raise err
-        weight[i] = free + 1
-        win[i] = x * math.log1p(1.0 / weight[i])
-        loss[i] = inf if weight[i] == 1 else -x * math.log1p(-1.0 / weight[i])
-    order = list(range(n))               # `slots` in their current order
-    while remaining != 0:
-        order.sort(key=lambda k: -win[k])                 # stable, descending by win
-        batch = min(remaining, n)
-        for k in order[:batch]:
-            weight[k] += 1
-            win[k] = probs[k] * math.log1p(1.0 / weight[k])
-            loss[k] = -probs[k] * math.log1p(-1.0 / weight[k])
-        remaining -= batch
-    while True:
-        buyer = order[0]
-        for k in order:                                   # max_by: the last of several maxima
-            if win[k] >= win[buyer]:
-                buyer = k
-        seller = order[0]
-        for k in order:                                   # min_by: the first of several minima
-            if loss[k] < loss[seller]:
-                seller = k
-        if buyer == seller or win[buyer] <= loss[seller]:
-            break
-        weight[seller] -= 1
-        win[seller] = -inf
-        loss[seller] = inf if weight[seller] == 1 else -probs[seller] * math.log1p(-1.0 / weight[seller])
-        weight[buyer] += 1
-        loss[buyer] = inf
-        win[buyer] = probs[buyer] * math.log1p(1.0 / weight[buyer])
-    cdf = np.zeros(n + 1, dtype=np.uint32)
-    cdf[1:] = np.cumsum(np.array(weight, dtype=np.uint64)).astype(np.uint32)
-    if int(cdf[n]) != (1 << precision):
-        raise err
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    cdf = np.empty(p.shape[0] + 1, dtype=np.uint32)
+    rc = N.CST_ERR_MODEL if p.shape[0] < 2 else \
+        N.load_library().cst_categorical_perfect_cdf(p.ctypes.data, p.shape[0], int(precision), cdf.ctypes.data)
+    if rc == N.CST_ERR_MODEL:
+        raise ValueError("Probability distribution not normalizable (the array of probabilities\n"
+                         "might be empty, contain negative values or NaNs, or sum to infinity).")
+    N.check(rc, "cst_categorical_perfect_cdf")
     return cdf
 
 
@@ -432,9 +384,10 @@ class ScipyModel(CustomModel):
 
 class _LeakyFamily(Model):
     """A continuous two-parameter family under the LeakyQuantizer<f64,i32,u32,24> (quantize.rs:284-308, 525-568), tabulated
-    on the host.  Subclasses give `_cdf(x, a, b)`."""
+    on the device (cst_family_cdf_rows).  Subclasses name the family."""
     _n_params = 2
     _names = ("a", "b")
+    _family = None
 
     def __init__(self, min_symbol_inclusive, max_symbol_inclusive, a=None, b=None):
         lo, hi = int(min_symbol_inclusive), int(max_symbol_inclusive)
@@ -448,23 +401,27 @@ class _LeakyFamily(Model):
         self.a = None if a is None else float(a)
         self.b = None if b is None else float(b)
         if self.b is not None:
-            self._check(self.a, self.b)
+            self._check(np.array([self.a]), np.array([self.b]))
         self._dev = None
 
     def _check(self, a, b):
-        if not b > 0.0:
+        if not np.all(b > 0.0):
             raise ValueError(f"Invalid model parameter: `{self._names[1]}` must be positive.")
 
     def is_concrete(self):
         return self.a is not None
+
+    def cdf_table(self) -> np.ndarray:
+        """the concrete model's cdf[n + 1] (computed on the device)"""
+        from .. import batched
+        return batched.family_cdf_rows(self._family, self.min_symbol, self.max_symbol, [self.a], [self.b])[0]
 
     def _device_model(self):
         if not self.is_concrete():
             return super()._device_model()
         if self._dev is None:
             from .. import batched
-            self._dev = batched.Model.from_cdf(leaky_cdf_table(self._cdf, self.min_symbol, self.max_symbol, (self.a, self.b)),
-                                               self.min_symbol, PRECISION)
+            self._dev = batched.Model.from_cdf(self.cdf_table(), self.min_symbol, PRECISION)
         return self._dev
 
     def family_rows(self, params):
@@ -474,49 +431,41 @@ class _LeakyFamily(Model):
         if len(a) != len(b):
             raise ValueError("Model parameters have unequal lengths.")
         n = self.max_symbol - self.min_symbol + 1
-        rows = []
-        for x, y in zip(a, b):
-            self._check(float(x), float(y))
-            rows.append(leaky_cdf_table(self._cdf, self.min_symbol, self.max_symbol, (float(x), float(y))))
-        return np.stack(rows) if rows else np.zeros((0, n + 1), np.uint32)
+        if len(a) == 0:
+            return np.zeros((0, n + 1), np.uint32)
+        self._check(a, b)
+        from .. import batched
+        return batched.family_cdf_rows(self._family, self.min_symbol, self.max_symbol, a, b)
 
 
 class QuantizedLaplace(_LeakyFamily):
     """constriction.stream.model.QuantizedLaplace(min_symbol_inclusive, max_symbol_inclusive, mean=None, scale=None)
-    (src/pybindings/stream/model.rs:736-800).  CDF of the `probability` crate's Laplace (UNPINNED: no reference vector):
-    x <= mean: exp((x - mean) / scale) / 2, else 1 - exp(-(x - mean) / scale) / 2."""
+    (src/pybindings/stream/model.rs:736-800).  CDF of the `probability` crate's Laplace (no reference vector; pinned to
+    the oracle's restatement): x <= mean: exp((x - mean) / scale) / 2, else 1 - exp(-(x - mean) / scale) / 2."""
     _names = ("mean", "scale")
+    _family = 1     # CST_FAMILY_LAPLACE
 
     def __init__(self, min_symbol_inclusive, max_symbol_inclusive, mean=None, scale=None):
         super().__init__(min_symbol_inclusive, max_symbol_inclusive, mean, scale)
 
-    @staticmethod
-    def _cdf(x, mean, scale):
-        import math
-        if x <= mean:
-            return 0.5 * math.exp((x - mean) / scale)
-        return 1.0 - 0.5 * math.exp(-(x - mean) / scale)
-
 
 class QuantizedCauchy(_LeakyFamily):
     """constriction.stream.model.QuantizedCauchy(min_symbol_inclusive, max_symbol_inclusive, loc=None, scale=None)
-    (src/pybindings/stream/model.rs:836-900).  CDF atan((x - loc) / scale) / pi + 1/2 (UNPINNED: no reference vector)."""
+    (src/pybindings/stream/model.rs:836-900).  CDF atan((x - loc) / scale) / pi + 1/2 (no reference vector; pinned to the
+    oracle's restatement)."""
     _names = ("loc", "scale")
+    _family = 2     # CST_FAMILY_CAUCHY
 
     def __init__(self, min_symbol_inclusive, max_symbol_inclusive, loc=None, scale=None):
         super().__init__(min_symbol_inclusive, max_symbol_inclusive, loc, scale)
 
-    @staticmethod
-    def _cdf(x, loc, scale):
-        import math
-        return math.atan((x - loc) / scale) / math.pi + 0.5
-
 
 class Binomial(Model):
     """constriction.stream.model.Binomial(n=None, p=None) (src/pybindings/stream/model.rs:903-966): LeakyQuantizer over
-    {0, ..., n} applied to the Binomial(n, p) CDF (UNPINNED: the reference evaluates it through the `probability` crate's
-    regularised incomplete beta function; here through scipy.stats.binom).  Forms: Binomial(n, p), Binomial(n) with `p` per
-    symbol, Binomial() with `n` and `p` per symbol."""
+    {0, ..., n} applied to the Binomial(n, p) CDF, which the `probability` crate evaluates as a regularised incomplete beta
+    function (Algorithm AS 63 in the `special` crate); tabulated on the device the same way (cst_family_cdf_rows; no
+    reference vector, pinned to the oracle's restatement).  Forms: Binomial(n, p), Binomial(n) with `p` per symbol,
+    Binomial() with `n` and `p` per symbol."""
     _n_params = 2
     min_symbol = 0
 
@@ -530,16 +479,15 @@ class Binomial(Model):
         self._dev = None
 
     @staticmethod
-    def _row(n, p, width=None):
-        from scipy.stats import binom
-        if n < 1:
+    def _rows(ns, ps):
+        """one row per (n, p) pair, padded to the largest n with 2^24"""
+        ns, ps = np.asarray(ns, dtype=np.int32), np.asarray(ps, dtype=np.float64)
+        if np.any(ns < 1):
             raise ValueError("`n` must be at least 1.")
-        if not 0.0 <= p <= 1.0:
+        if not np.all((ps >= 0.0) & (ps <= 1.0)):
             raise ValueError("`p` must be >= 0.0 and <= 1.0.")
-        row = leaky_cdf_table(lambda x: float(binom.cdf(x, n, p)), 0, n)
-        if width is not None and width > n:
-            row = np.concatenate([row, np.full(width - n, 1 << PRECISION, dtype=np.uint32)])
-        return row
+        from .. import batched
+        return batched.family_cdf_rows(3, 0, int(ns.max()), ps, None, n_per_row=ns)     # CST_FAMILY_BINOMIAL
 
     def is_concrete(self):
         return self.n is not None and self.p is not None
@@ -549,7 +497,7 @@ class Binomial(Model):
             return super()._device_model()
         if self._dev is None:
             from .. import batched
-            self._dev = batched.Model.from_cdf(self._row(self.n, self.p), 0, PRECISION)
+            self._dev = batched.Model.from_cdf(self._rows([self.n], [self.p])[0], 0, PRECISION)
         return self._dev
 
     def family_rows(self, params):
@@ -571,5 +519,4 @@ class Binomial(Model):
             return np.zeros((0, 3), np.uint32)
         if int(ns.max()) > 4096:
             raise ValueError("per-symbol Binomial models are tabulated: `n` may be at most 4096 in this form.")
-        width = int(ns.max())
-        return np.stack([self._row(int(a), float(b), width) for a, b in zip(ns, ps)])
+        return self._rows(ns, ps)

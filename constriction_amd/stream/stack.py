@@ -175,19 +175,19 @@ class AnsCoder:
         d_sym = torch.empty(amt, dtype=torch.int32, device="cuda")
         sp = S.stream_ptr()
         if kind[0] == "table":
-            st = L.cst_ans_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_sym), 1, amt,
+            st = L.cst_ans_decode_batch(kind[1]._h, S.cfg(), S.ptr(d_words), None, max(tail, 1), d_words.numel(), d_n, S.ptr(d_sym), 1, amt,
                                         N.LAYOUT_STREAM_MAJOR, d_state, d_n_out, d_status,
                                         N.FLAG_RAW_STATE, sp)
         elif kind[0] == "gaussian":
             _, lo, hi, means, stds = kind
             d_mu, d_sd = S.dev(means), S.dev(stds)
-            st = L.cst_ans_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_mu),
+            st = L.cst_ans_decode_gaussian_batch(S.cfg(), lo, hi, S.ptr(d_words), None, max(tail, 1), d_words.numel(), d_n, S.ptr(d_mu),
                                                  S.ptr(d_sd), S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR, d_state,
                                                  d_n_out, d_status, N.FLAG_RAW_STATE, sp)
         else:
             rows = kind[1]
             d_rows = S.dev(rows.view(np.int32))
-            st = L.cst_ans_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(tail, 1), d_n, S.ptr(d_rows),
+            st = L.cst_ans_decode_rows_batch(S.cfg(), S.ptr(d_words), None, max(tail, 1), d_words.numel(), d_n, S.ptr(d_rows),
                                              rows.shape[1] - 1, kind[2], S.ptr(d_sym), 1, amt, N.LAYOUT_STREAM_MAJOR,
                                              d_state, d_n_out, d_status, N.FLAG_RAW_STATE, sp)
         N.check(st, "ans decode")

@@ -42,7 +42,7 @@ int main(void) {
 
     CHECK_CST(cst_ans_encode_batch(model, cfg, d_sym, n_streams, n_per, CST_LAYOUT_STREAM_MAJOR, d_words, stride, d_n_words, NULL,
                                    d_status, 0, NULL));
-    CHECK_CST(cst_ans_decode_batch(model, cfg, d_words, NULL, stride, d_n_words, d_dec, n_streams, n_per, CST_LAYOUT_STREAM_MAJOR,
+    CHECK_CST(cst_ans_decode_batch(model, cfg, d_words, NULL, stride, n_streams * stride, d_n_words, d_dec, n_streams, n_per, CST_LAYOUT_STREAM_MAJOR,
                                    NULL, NULL, d_status, 0, NULL));
     CHECK_HIP(hipDeviceSynchronize());
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CST_ABI_VERSION 2
+#define CST_ABI_VERSION 3
 
 typedef enum cst_status {
     CST_OK = 0,
@@ -156,6 +156,39 @@ size_t cst_model_n_tables(const cst_model *model); /* 1 = shared, else n_streams
 cst_status cst_model_get_cdf(const cst_model *model, size_t index, uint32_t *h_cdf, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * model families other than the quantized Gaussian
+ * ---------------------------------------------------------------------------------------- */
+
+typedef enum cst_family {
+    CST_FAMILY_LAPLACE = 1, /* constriction.stream.model.QuantizedLaplace(min, max, mean, scale), src/pybindings/stream/model.rs:736-800 */
+    CST_FAMILY_CAUCHY = 2,  /* QuantizedCauchy(min, max, loc, scale), model.rs:836-900 */
+    CST_FAMILY_BINOMIAL = 3 /* Binomial(n, p) over 0..=n, model.rs:903-966 */
+} cst_family;
+
+/* LeakyQuantizer<f64,i32,u32,P>(min..=max) x family(a[row], b[row]) tabulated on the device, one row of
+ * (max - min + 2) left cumulatives per parameter pair (src/stream/model/quantize.rs:284-308, 525-568 over the
+ * `probability` crate's Laplace / Cauchy / Binomial CDFs, evaluated with the libm-crate algorithms in bit-exact f64).
+ * Laplace: a = mean, b = scale.  Cauchy: a = loc, b = scale.  Binomial: a = p, d_b unused (may be NULL), min_symbol
+ * must be 0 and max_symbol = n; with d_n_per_row != NULL row r is the model over 0..=d_n_per_row[r] (<= max_symbol)
+ * and entries past its own 2^P repeat 2^P (the family form `Binomial()` with per-symbol n).  d_bad (optional, one
+ * int32 per row) is set to 1 where a row is not strictly increasing, i.e. where the reference panics
+ * (quantize.rs:560-566).  The rows feed cst_model_create_table / the *_rows_batch / *_cp_batch entry points. */
+cst_status cst_family_cdf_rows(int32_t family, int32_t precision, int32_t min_symbol, int32_t max_symbol,
+                               const double *d_a, const double *d_b, const int32_t *d_n_per_row, size_t n_rows,
+                               uint32_t *d_rows, int32_t *d_bad, void *stream);
+
+/* Categorical(probabilities, perfect=True): `perfectly_quantized_probabilities` + cumulation
+ * (src/stream/model/categorical.rs:56-177, contiguous.rs:301-313) for Probability = u32.  HOST function (a sequential
+ * greedy search); h_probs are f64 (f32 inputs widened by the caller, as `F: Into<f64>` does); writes h_cdf[n + 1].
+ * CST_ERR_MODEL where the reference returns Err (n < 2, negative / non-normalisable probabilities). */
+cst_status cst_categorical_perfect_cdf(const double *h_probs, size_t n, int32_t precision, uint32_t *h_cdf);
+
+/* test hooks: the elementary functions behind the two calls above as the device evaluates them
+ * (which: 0 log, 1 log1p, 2 atan, 3 lgamma for x > 0, 4 exp), and the host's log1p */
+cst_status cst_debug_family_fn(int32_t which, const double *d_x, double *d_out, size_t n, void *stream);
+double cst_debug_host_log1p(double x);
+
+/* ------------------------------------------------------------------------------------------
  * batched ANS coder: one independent AnsCoder<W,S> per stream
  * ---------------------------------------------------------------------------------------- */
 
@@ -188,15 +221,19 @@ cst_status cst_ans_encode_batch(const cst_model *model, cst_coder_config cfg, co
  * so both the slab layout written by cst_ans_encode_batch and the packed layout written by
  * cst_compact_words decode without a copy.  Decoding past the end of a stream is legal and
  * deterministic, exactly as in the reference (stack.rs:1062-1065).
- * The caller vouches for the metadata: [off(s), off(s) + d_n_words[s]) must lie inside the buffer behind d_words (the
- * kernels read whole aligned 16-byte chunks: up to 12 bytes before the first and after the last word of a stream are
- * touched, never interpreted; buffers from cst_ans_encode_batch / cst_compact_words via hipMalloc satisfy this).
+ * Memory safety on corrupt metadata (the reference's decoder pops from a Vec and cannot leave it, src/backends.rs:495-507):
+ * `words_capacity` = the number of uint32 slots behind d_words.  A stream whose slice [off(s), off(s) + d_n_words[s])
+ * leaves the buffer -- or, in slab form, whose d_n_words[s] exceeds stride_words (checked always) -- is decoded as an
+ * EMPTY stream and reports CST_STREAM_INVALID_DATA; nothing outside the buffer is read.  words_capacity = 0 means
+ * "unknown": the caller vouches for the packed offsets as in ABI 2.  (The kernels read whole aligned 16-byte chunks:
+ * up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; a capacity that is
+ * the true size of a hipMalloc'ed buffer satisfies this.)  Every decode entry point below takes the same argument.
  * The model must have been created on the current device (CST_ERR_INVALID_ARGUMENT otherwise).
  * With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
  * count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).
  */
 cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
-                                const uint64_t *d_offsets, size_t stride_words, const uint32_t *d_n_words,
+                                const uint64_t *d_offsets, size_t stride_words, size_t words_capacity, const uint32_t *d_n_words,
                                 int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                 uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
                                 uint32_t flags, void *stream);
@@ -216,7 +253,7 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model *model, cst_coder_config cf
                                      uint32_t *d_ckpt_pos, uint64_t *d_ckpt_state, int32_t *d_status, void *stream);
 size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval);
 cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
-                                     const uint64_t *d_offsets, size_t stride_words, size_t ckpt_interval,
+                                     const uint64_t *d_offsets, size_t stride_words, size_t words_capacity, size_t ckpt_interval,
                                      const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_state, int32_t *d_symbols,
                                      size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
                                      void *stream);
@@ -254,11 +291,19 @@ cst_status cst_gather_sizes_rccl(void *comm, int32_t n_ranks, int32_t rank, cons
 
 /* Step 2 (every rank): h_sizes = host copy of d_sizes.  Root: d_all_packed (capacity >= sum of words) receives the packed
  * words of all ranks in rank order, d_all_offsets[sum of streams + 1] their global offsets; other ranks pass NULL for
- * both.  Grouped point-to-point transfers straight into their final positions; the root's call returns after its
- * stream has been synchronised, the other ranks' calls are asynchronous on `stream`. */
+ * both.  Grouped point-to-point transfers straight into their final positions, asynchronous on `stream` on every
+ * rank.  A failing transfer never leaves an RCCL group open: the group is closed first, then the error is returned. */
 cst_status cst_gather_rccl(void *comm, int32_t n_ranks, int32_t rank, int32_t root, const uint32_t *d_packed,
                            const uint64_t *d_offsets, const uint64_t *h_sizes, uint32_t *d_all_packed,
                            uint64_t *d_all_offsets, void *stream);
+
+/* The inverse (decoding on the ranks what one rank holds): the root passes the packed words of all ranks'
+ * streams in rank order and their global offsets[sum of streams + 1] (NULL on the other ranks); every rank receives its
+ * own words in d_packed (capacity >= h_sizes[2 * rank + 1]) and d_offsets[n_streams_local + 1] rebased to start at 0 --
+ * what the `d_offsets` form of cst_ans_decode_batch / cst_range_decode_batch takes.  h_sizes as above, on every rank. */
+cst_status cst_scatter_rccl(void *comm, int32_t n_ranks, int32_t rank, int32_t root, const uint32_t *d_all_packed,
+                            const uint64_t *d_all_offsets, const uint64_t *h_sizes, uint32_t *d_packed,
+                            uint64_t *d_offsets, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * per-symbol quantized Gaussians: the reference's flagship Python call
@@ -276,7 +321,7 @@ cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
                                          uint64_t *d_state, int32_t *d_status, uint32_t flags, void *stream);
 
 cst_status cst_ans_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
-                                         const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                         const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
                                          const uint32_t *d_n_words, const double *d_means, const double *d_stds,
                                          int32_t *d_symbols, size_t n_streams, size_t n_per_stream,
                                          cst_layout layout, uint64_t *d_state, uint32_t *d_n_words_out,
@@ -294,7 +339,7 @@ cst_status cst_ans_encode_cp_batch(cst_coder_config cfg, const uint32_t *d_left,
                                    uint32_t flags, void *stream);
 
 cst_status cst_ans_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_words, const uint64_t *d_offsets,
-                                     size_t stride_words, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
+                                     size_t stride_words, size_t words_capacity, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
                                      int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
                                      size_t n_per_stream, cst_layout layout, uint64_t *d_state,
                                      uint32_t *d_n_words_out, int32_t *d_status, uint32_t flags, void *stream);
@@ -325,7 +370,7 @@ cst_status cst_range_encode_batch(const cst_model *model, cst_coder_config cfg, 
                                   cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
 
 cst_status cst_range_decode_batch(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
-                                  const uint64_t *d_offsets, size_t stride_words, const uint32_t *d_n_words,
+                                  const uint64_t *d_offsets, size_t stride_words, size_t words_capacity, const uint32_t *d_n_words,
                                   int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                   cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
 
@@ -342,14 +387,14 @@ cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_sym
                                            cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
 
 cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
-                                           const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                           const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
                                            const uint32_t *d_n_words, const double *d_means, const double *d_stds,
                                            int32_t *d_symbols, size_t n_streams, size_t n_per_stream,
                                            cst_layout layout, cst_range_state *d_rstate, int32_t *d_status,
                                            uint32_t flags, void *stream);
 
 cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_words, const uint64_t *d_offsets,
-                                       size_t stride_words, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
+                                       size_t stride_words, size_t words_capacity, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
                                        int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,
                                        size_t n_per_stream, cst_layout layout, cst_range_state *d_rstate,
                                        int32_t *d_status, uint32_t flags, void *stream);
@@ -404,9 +449,10 @@ cst_status cst_chain_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_p
                                        uint32_t *d_n_push, cst_chain_heads *d_heads, int32_t *d_status, void *stream);
 
 /* The per-symbol entry points above take their scratch (16 B per symbol for encoding; 1 KiB per symbol of cdf rows, at
- * most 64 MiB at a time, for decoding fewer than 64 streams) from the device's stream-ordered memory pool and tell the
- * pool to KEEP freed memory (re-allocating 4 GiB per call cost more than coding them).  This hands it back: synchronises
- * the device and trims its default pool. */
+ * most 64 MiB at a time, for decoding fewer than 64 streams) from a stream-ordered memory pool that the LIBRARY owns (one
+ * per device, created at first use; the device's default pool is never touched) and that keeps freed memory
+ * (re-allocating 4 GiB per call cost more than coding them).  This hands it back: synchronises the device and trims the
+ * library's pool. */
 cst_status cst_release_scratch(void);
 
 /* ------------------------------------------------------------------------------------------

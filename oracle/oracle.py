@@ -27,11 +27,11 @@ f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 
 
 def build(native: bool = False) -> Path:
-    """Compile oracle.c if the .so is missing or older than the source."""
+    """Compile oracle.c + oracle_families.c if the .so is missing or older than the sources."""
     name = "liboracle_native.so" if native else "liboracle.so"
     so = _HERE / "_build" / name
-    src = _HERE / "oracle.c"
-    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    newest = max((_HERE / f).stat().st_mtime for f in ("oracle.c", "oracle_families.c", "Makefile"))
+    if not so.exists() or so.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(_HERE), "native" if native else "all"], check=True,
                        stdout=subprocess.DEVNULL)
     return so
@@ -93,6 +93,19 @@ def load(native: bool = False):
         "cst_oracle_synth_symbols": (None, [u64, z, z, z, i32, i, u32p, i, i, i32p]),
         "cst_oracle_rc_encode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
         "cst_oracle_rc_decode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
+        # oracle_families.c
+        "cst_oracle_log": (d, [d]),
+        "cst_oracle_log1p": (d, [d]),
+        "cst_oracle_atan": (d, [d]),
+        "cst_oracle_lgamma": (d, [d]),
+        "cst_oracle_laplace_cdf": (d, [d, d, d]),
+        "cst_oracle_cauchy_cdf": (d, [d, d, d]),
+        "cst_oracle_binomial_cdf": (d, [d, i32, d]),
+        "cst_oracle_inc_beta": (d, [d, d, d, d]),
+        "cst_oracle_leaky_family_cdf_table": (i, [i, i32, i32, i, d, d, u32p]),
+        "cst_oracle_categorical_perfect_cdf": (i, [f64p, i64, i, u32p]),
+        "cst_oracle_lazy_categorical_lcp": (i, [vp, i64, i, i, i64, C.POINTER(u), C.POINTER(u)]),
+        "cst_oracle_lazy_categorical_quantile": (i, [vp, i64, i, i, u, C.POINTER(i64), C.POINTER(u), C.POINTER(u)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -174,6 +187,57 @@ def categorical_fast_cdf(probs, P=24):
     if rc:
         raise ValueError("Probability distribution not normalizable")
     return cdf
+
+
+FAMILY_LAPLACE, FAMILY_CAUCHY, FAMILY_BINOMIAL = 1, 2, 3
+
+
+def leaky_family_cdf(family, lo, hi, a, b=0.0, P=24):
+    """LeakyQuantizer<f64,i32,u32,P>(lo..=hi) over Laplace(a, b) / Cauchy(a, b) / Binomial(n = hi, p = a), tabulated
+    (oracle_families.c; quantize.rs:525-568 over the `probability` crate's CDFs)."""
+    cdf = np.zeros(int(hi) - int(lo) + 2, dtype=np.uint32)
+    rc = load().cst_oracle_leaky_family_cdf_table(int(family), int(lo), int(hi), P, float(a), float(b), cdf)
+    if rc:
+        raise ArithmeticError("zero probability")
+    return cdf
+
+
+def categorical_perfect_cdf(probs, P=24):
+    """perfectly_quantized_probabilities + cumulation (categorical.rs:56-177, contiguous.rs:301-313); f32 inputs are
+    widened to f64 first (`F: Into<f64>`)."""
+    probs = np.ascontiguousarray(np.asarray(probs), dtype=np.float64)
+    cdf = np.zeros(len(probs) + 1, dtype=np.uint32)
+    if load().cst_oracle_categorical_perfect_cdf(probs, len(probs), P, cdf):
+        raise ValueError("Probability distribution not normalizable")
+    return cdf
+
+
+class LazyCategoricalModel:
+    """LazyContiguousCategoricalEntropyModel<u32, F, _, P> (lazy_contiguous.rs:132-331): nothing is tabulated, every
+    call sums the probabilities it needs in F = the dtype of `probs` (f32 stays f32)."""
+
+    def __init__(self, probs, P=24, lo=0):
+        probs = np.asarray(probs)
+        self.is_f32 = probs.dtype == np.float32
+        self.probs = np.ascontiguousarray(probs, dtype=np.float32 if self.is_f32 else np.float64)
+        self.P, self.lo, self.n = P, int(lo), len(self.probs)
+
+    def lcp(self, sym):
+        l, p = C.c_uint32(), C.c_uint32()
+        rc = load().cst_oracle_lazy_categorical_lcp(self.probs.ctypes.data, self.n, int(self.is_f32), self.P,
+                                                    int(sym) - self.lo, C.byref(l), C.byref(p))
+        if rc == 1:
+            raise KeyError("impossible symbol")
+        if rc:
+            raise ValueError("Probability distribution not normalizable")
+        return l.value, p.value
+
+    def quantile(self, q):
+        s, l, p = C.c_int64(), C.c_uint32(), C.c_uint32()
+        if load().cst_oracle_lazy_categorical_quantile(self.probs.ctypes.data, self.n, int(self.is_f32), self.P, int(q),
+                                                       C.byref(s), C.byref(l), C.byref(p)):
+            raise ValueError("Probability distribution not normalizable")
+        return self.lo + s.value, l.value, p.value
 
 
 def lookup_from_cdf(cdf, P):

@@ -27,6 +27,15 @@ def models_for(step, P, backend, prob_bits=32):
     if kind == "categorical_fast_rows":
         rows = np.asarray(m["probs"], dtype=np.float32 if m["dtype"] == "f32" else np.float64)
         return [backend.TableModel(backend.categorical_fast_cdf(r, P), 0, P) for r in rows], len(rows)
+    if kind == "categorical_lazy":          # Categorical(probs, lazy=True): nothing tabulated (lazy_contiguous.rs:228-331)
+        probs = np.asarray(m["probs"], dtype=np.float32 if m["dtype"] == "f32" else np.float64)
+        return (backend.LazyCategoricalModel(probs, P) if hasattr(backend, "LazyCategoricalModel")
+                else backend.TableModel(backend.categorical_fast_cdf(probs, P), 0, P)), n
+    if kind == "categorical_lazy_rows":
+        rows = np.asarray(m["probs"], dtype=np.float32 if m["dtype"] == "f32" else np.float64)
+        mk = (lambda r: backend.LazyCategoricalModel(r, P)) if hasattr(backend, "LazyCategoricalModel") else \
+             (lambda r: backend.TableModel(backend.categorical_fast_cdf(r, P), 0, P))
+        return [mk(r) for r in rows], len(rows)
     if kind == "table":
         return backend.TableModel(np.asarray(m["cdf"], dtype=np.uint32), m["lo"], P), n
     if kind in ("scipy_norm", "scipy_norm_family"):

@@ -570,6 +570,16 @@ def test_rccl_gather_through_the_c_abi_single_rank(B, O):
         torch.cuda.synchronize()
         total = int(offsets[-1])
         assert torch.equal(all_off, offsets) and torch.equal(all_packed, packed[:total])
+        # the inverse (cst_scatter_rccl): the rank gets its words and offsets back and decodes them
+        back_packed, back_off = comm.scatter_packed(all_packed, all_off, src=0)
+        torch.cuda.synchronize()
+        assert torch.equal(back_off, offsets) and torch.equal(back_packed, packed[:total])
+        dec, st = B.ans_decode((back_packed, enc.n_words), model, 50, offsets=back_off, config=(32, 64, P))
+        torch.cuda.synchronize()
+        assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+        # sizes as a two-rank job would see them on rank 1 are rejected cleanly (bad rank), not hung
+        from constriction_amd import _native as N
+        assert N.lib().cst_scatter_rccl(comm._h, 1, 1, 0, None, None, comm.last_sizes.ctypes.data, None, None, None) == N.CST_ERR_INVALID_ARGUMENT
         comm.close()
     finally:
         if created:

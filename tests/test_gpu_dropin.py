@@ -35,6 +35,10 @@ def _call_args(constriction, step):
         return mod.Categorical(np.array(m["probs"], dtype=_dtype(m["dtype"])), perfect=False), ()
     if m["kind"] == "categorical_fast_rows":
         return mod.Categorical(perfect=False), (np.array(m["probs"], dtype=_dtype(m["dtype"])),)
+    if m["kind"] == "categorical_lazy":      # tests/python/test_lazy_f64.py:130-131
+        return mod.Categorical(np.array(m["probs"], dtype=_dtype(m["dtype"])), lazy=True), ()
+    if m["kind"] == "categorical_lazy_rows":  # tests/python/test_lazy_f64.py:157-161
+        return mod.Categorical(lazy=True), (np.array(m["probs"], dtype=_dtype(m["dtype"])),)
     if m["kind"] == "scipy_norm":            # tests/python/test_constriction.py:233-235
         import scipy.stats
         model_py = scipy.stats.norm(m["loc"], m["scale"])
