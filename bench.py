@@ -16,9 +16,11 @@ the launch stream around the dominant kernel; `cpu_baseline` times the CPU oracl
 repo's C restatement of the reference arithmetic, the Rust crate cannot be built here) on the
 host cores of the same box.  The `configs` block carries, on the same clock, every other single-GPU
 configuration of BASELINE.json (the 16-bit-word and 24-bit presets of C2, C3 = one table per stream, C4 = range
-coder at P = 12 / 24, the C5 shard of 131 072 streams per GPU with compaction and -- N > 1 -- the RCCL gather of
-the packed words to rank 0): encode_ms / decode_ms / achieved fraction of the HBM roofline / bit_exact, where
-bit_exact compares EVERY stream's words with the CPU oracle's and the decoded symbols with the input.
+coder at P = 12 / 24, f1 = every symbol its own f64 (mean, std) -- the reference's flagship Python call, batched --, the C5
+shard of 131 072 streams per GPU with compaction and -- N > 1 -- the RCCL gather of the packed words to rank 0):
+encode_ms / decode_ms / achieved fraction of the HBM roofline / bit_exact, where bit_exact compares EVERY stream's words
+with the CPU oracle's and the decoded symbols with the input.  With N > 1 the line also carries `per_rank` (every rank's
+own encode_ms / decode_ms) and `rccl_ranks_seen`, so that a scaling run diagnoses itself.
 """
 import argparse
 import json
@@ -63,6 +65,45 @@ def synth_symbols_device(seed, stream_begin, n_streams, n_per, lo, cdf_dev, prec
         q = (z >> (64 - precision)) & ((1 << precision) - 1)
         idx = torch.searchsorted(inner, q, right=True)  # largest i with cdf[i] <= q
         out[a:b] = (idx + lo).to(torch.int32)
+    return out
+
+
+def splitmix_draws(seed, stream_begin, n_streams, first, count, dev):
+    """draws first .. first + count - 1 (1-based, as oracle.synth_symbols counts them) of the per-stream generators
+    splitmix64(seed ^ stream_id): int64 tensor [n_streams, count] holding the 64-bit outputs"""
+    G, C1, C2 = -7046029254386353131, -4658895280553007687, -7723592293110705685
+    t = torch.arange(first, first + count, dtype=torch.int64, device=dev)[None, :] * G
+    sid = torch.arange(stream_begin, stream_begin + n_streams, dtype=torch.int64, device=dev)
+    z = (sid ^ seed)[:, None] + t
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * C1
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * C2
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def unit_draws(z):
+    """u = (x >> 11) * 2^-53 in [0, 1): the 53-bit mantissa draw of SURVEY.md 8(d)"""
+    return ((z >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+
+
+def c3_parameters(seed, stream_begin, n_streams, n_per, dev):
+    """mu_s = -10 + 20 u1, sigma_s = exp(ln 0.5 + u2 ln 32) with u1, u2 the two draws of stream s's
+    generator that follow its n_per symbol draws"""
+    u = unit_draws(splitmix_draws(seed, stream_begin, n_streams, n_per + 1, 2, dev))
+    return -10.0 + 20.0 * u[:, 0], torch.exp(float(np.log(0.5)) + u[:, 1] * float(np.log(32.0)))
+
+
+def synth_symbols_per_stream(seed, stream_begin, n_per, lo, cdf_rows, precision, chunk=2048):
+    """the 8(d) recipe under one table per stream: sym = quantile_function_s(draw_t >> (64 - P)); cdf_rows int32/int64
+    [n_streams, n + 1] on the device"""
+    n_streams = cdf_rows.shape[0]
+    dev = cdf_rows.device
+    out = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
+    inner = cdf_rows[:, 1:-1].to(torch.int64).contiguous()
+    for a in range(0, n_streams, chunk):
+        b = min(a + chunk, n_streams)
+        z = splitmix_draws(seed, stream_begin + a, b - a, 1, n_per, dev)
+        q = (z >> (64 - precision)) & ((1 << precision) - 1)
+        out[a:b] = (torch.searchsorted(inner[a:b], q, right=True) + lo).to(torch.int32)
     return out
 
 
@@ -187,6 +228,62 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     return entry, enc
 
 
+def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100, hi=100):
+    """f1: every symbol its own f64 (mean, std) -- coder.encode_reverse(symbols, QuantizedGaussian(lo, hi),
+    means, stds) / coder.decode(family, means, stds), src/pybindings/stream/stack.rs:567-588, 733-751 -- for all streams at
+    once, preset (32, 64, 24).  Algorithmic bytes per symbol and direction: 4 (symbol) + 16 (two f64 parameters) + 4 per
+    compressed word.  Parameters from the streams' splitmix64 generators (draws n_per + 3 ...), symbols = the model's
+    rounded normal deviate; every stream's words are compared with the CPU oracle's."""
+    from oracle import oracle as O
+    dev = "cuda"
+    mu = torch.empty((n_streams, n_per), dtype=torch.float64, device=dev)
+    sd = torch.empty_like(mu)
+    sym = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
+    for a in range(0, n_streams, 4096):
+        b = min(a + 4096, n_streams)
+        u = unit_draws(splitmix_draws(SEED, a, b - a, n_per + 3, 3 * n_per, dev)).view(b - a, n_per, 3)
+        mu[a:b] = -30.0 + 60.0 * u[:, :, 0]
+        sd[a:b] = torch.exp(float(np.log(0.5)) + u[:, :, 1] * float(np.log(32.0)))
+        z = torch.special.ndtri(u[:, :, 2].clamp(1e-12, 1 - 1e-12))
+        sym[a:b] = torch.clamp(torch.round(mu[a:b] + sd[a:b] * z), lo, hi).to(torch.int32)
+        del u, z
+    cfg = (32, 64, 24)
+    enc = B.ans_encode_gaussian(sym, lo, hi, mu, sd, cfg)
+    decoded = torch.empty_like(sym)
+    enc_ms = event_ms(lambda: B.ans_encode_gaussian(sym, lo, hi, mu, sd, cfg, out=enc), reps)
+    dec_ms = event_ms(lambda: B.ans_decode_gaussian(enc, lo, hi, mu, sd, out=decoded), reps)
+    total_words = enc.total_words()
+    n_sym = n_streams * n_per
+    byts = 20 * n_sym + 4 * total_words
+    entry = {"workload": f"f1: every symbol its own f64 (mean, std), support {lo}..{hi} (the reference's flagship Python call, batched)",
+             "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
+             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_sym / (enc_ms + dec_ms) / 1e3, 1),
+             "words_per_stream": round(total_words / n_streams, 2), "algorithmic_bytes_per_symbol": round(byts / n_sym, 3),
+             "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    if check:
+        ok = bool(torch.equal(decoded, sym)) and int(enc.status.abs().sum().item()) == 0
+        if ok:
+            words, n_words, _ = enc.to_numpy()
+            h_sym, h_mu, h_sd = sym.cpu().numpy(), mu.cpu().numpy(), sd.cpu().numpy()
+
+            def work(ab):
+                for s in range(*ab):
+                    c = O.AnsCoder()
+                    c.encode_gaussian_reverse(h_sym[s], lo, hi, h_mu[s], h_sd[s], 24, 32)
+                    w = c.get_compressed()
+                    if len(w) != n_words[s] or not np.array_equal(w, words[s, : n_words[s]]):
+                        return False
+                return True
+            cores = os.cpu_count() or 1
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                ok = all(pool.map(work, _blocks(n_streams, 8 * cores)))
+            entry["bit_exact_scope"] = f"all {n_streams} streams: words and counts vs CPU oracle, decoded symbols vs input"
+        entry["bit_exact"] = ok
+    B.release_scratch()
+    return entry
+
+
 def other_configs(B, rank, world, dist, args, reps=5):
     """Every other single-GPU configuration of BASELINE.json, same clock, same checks (see the module docstring)."""
     out = []
@@ -221,19 +318,16 @@ def other_configs(B, rank, world, dist, args, reps=5):
         out.append(e)
         del sym24, m24
         # C3: one (mean, std) per stream, support -127..127
-        rng = np.random.default_rng(SEED)
-        mu = -10 + 20 * rng.random(N_STREAMS)
-        sigma = np.exp(np.log(0.5) + rng.random(N_STREAMS) * np.log(32))
-        mu_d, sigma_d = torch.from_numpy(mu).cuda(), torch.from_numpy(sigma).cuda()
+        # (parameters and symbols from the per-stream splitmix64 generators, like C2's)
+        mu_d, sigma_d = c3_parameters(SEED, rank * N_STREAMS, N_STREAMS, N_PER, "cuda")
+        mu, sigma = mu_d.cpu().numpy(), sigma_d.cpu().numpy()
         m3 = B.Model.quantized_gaussian_per_stream(-127, 127, mu_d, sigma_d, 12)
-        g = torch.Generator(device="cuda").manual_seed(1234)
-        z = torch.randn((N_STREAMS, N_PER), generator=g, device="cuda", dtype=torch.float32)
-        sym3 = torch.clamp(torch.round(z * sigma_d.float()[:, None] + mu_d.float()[:, None]), -127, 127).to(torch.int32)
-        del z
+        sym3 = synth_symbols_per_stream(SEED, rank * N_STREAMS, N_PER, -127, m3.cdfs_device(), 12)
         cdfs = cpu_tables(-127, 127, mu, sigma, 12) if check else None
         e, _ = run_config(B, "C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
         out.append(e)
         del sym3, m3, cdfs
+        out.append(per_symbol_config(B, reps, check))
     del sym12
     torch.cuda.empty_cache()
     # C5 shard: 131 072 streams per GPU, compaction, gather of the packed words to rank 0
@@ -456,18 +550,32 @@ def main():
             "what": "same kernels, a 1-GiB fill before every launch (nothing of the batch left in L2 or the Infinity Cache)"}
     del flush
 
+    # N > 1: every rank's own kernel times and how many ranks RCCL really connected (a scaling run diagnoses itself)
+    per_rank, ranks_seen = None, None
+    if dist is not None:
+        mine = torch.tensor([float(rank), enc_ms, dec_ms, float(total_words)], dtype=torch.float64, device="cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = torch.stack(gathered).cpu().numpy()
+        per_rank = [{"rank": int(r[0]), "encode_ms": round(float(r[1]), 4), "decode_ms": round(float(r[2]), 4), "words": int(r[3])} for r in rows]
+        ranks_seen = len({int(r[0]) for r in rows})
+
     configs = None
     if not args.no_configs:
         configs = other_configs(B, rank, world, dist, args)
 
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the committed summary
+        # of the same command, named as the source
+        traffic, traffic_source = None, None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
                 traffic = json.loads(tf.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this command, scripts/pmc_all.sh)"
             except Exception:
                 traffic = None
+        dom_cold_ms = cold["encode_ms"] if dominant == "ans_encode_kernel" else cold["decode_ms"]
         line = {
             "metric": "Msymbols/s encode+decode, 64k x 4k-symbol streams, bit-exact vs CPU",
             "value": round(world * n_sym * args.steps / elapsed / 1e6, 1),
@@ -484,11 +592,16 @@ def main():
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4), "after_cache_flush": cold,
             "words_per_stream": round(total_words / n_streams, 2),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_cold": round(bytes_per_launch / (dom_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(dom_ms, 4),
                          "encode_GBps": round(bytes_per_launch / (enc_ms * 1e-3) / 1e9, 1),
                          "decode_GBps": round(bytes_per_launch / (dec_ms * 1e-3) / 1e9, 1)},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["rccl_ranks_seen"] = ranks_seen
         if configs is not None:
             line["configs"] = configs
             ok = ok and all(c.get("bit_exact", True) for c in configs)

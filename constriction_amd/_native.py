@@ -71,6 +71,7 @@ SIGNATURES = {
     "cst_model_n_symbols": (_i32, [_vp]),
     "cst_model_n_tables": (_z, [_vp]),
     "cst_model_get_cdf": (_i32, [_vp, _z, _vp, _vp]),
+    "cst_model_copy_cdfs": (_i32, [_vp, _z, _z, _vp, _vp]),
     "cst_ans_encode_batch": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),

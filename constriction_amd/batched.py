@@ -127,6 +127,14 @@ class Model:
     def n_tables(self):
         return N.load_library().cst_model_n_tables(self._h)
 
+    def cdfs_device(self, first: int = 0, count: Optional[int] = None) -> torch.Tensor:
+        """The cdfs of tables [first, first + count) as an int32-typed tensor [count, n_symbols + 1] in HBM (values < 2^31
+        for every precision <= 24 ... 30), copied on the current stream."""
+        count = self.n_tables - first if count is None else count
+        out = torch.empty((count, self.n_symbols + 1), dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        N.check(N.lib().cst_model_copy_cdfs(self._h, int(first), int(count), _ptr(out), _stream_ptr()), "cst_model_copy_cdfs")
+        return out
+
     def cdf(self, index: int = 0) -> np.ndarray:
         out = np.zeros(self.n_symbols + 1, dtype=np.uint32)
         N.check(N.lib().cst_model_get_cdf(self._h, index, out.ctypes.data, _stream_ptr()), "cst_model_get_cdf")
@@ -160,6 +168,19 @@ def family_cdf_rows(family: int, min_symbol: int, max_symbol: int, a, b=None, n_
         raise ValueError("Invalid model: a symbol of the support gets probability zero under the leaky quantizer "
                          "(quantize.rs:560-566).")
     return rows.cpu().numpy().view(np.uint32) if to_numpy else rows
+
+
+def _to_indices(model: "Model", symbols: torch.Tensor) -> torch.Tensor:
+    """Every table-model entry point codes INDICES into the model's alphabet; for a non-contiguous alphabet
+    (Model.from_cdf_noncontiguous) the symbols are translated first (a symbol outside the alphabet becomes index n, which the
+    coders report as CST_STREAM_IMPOSSIBLE_SYMBOL), for a contiguous one the kernels subtract min_symbol themselves."""
+    return model.symbols_to_indices(symbols) if model.noncontiguous else symbols
+
+
+def _to_symbols(model: "Model", decoded: torch.Tensor) -> torch.Tensor:
+    if model.noncontiguous:
+        model.indices_to_symbols(decoded, out=decoded)
+    return decoded
 
 
 @dataclass
@@ -203,9 +224,7 @@ def _layout_shape(symbols: torch.Tensor, layout: str):
 def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
                stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
     """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895)."""
-    symbols = _require_cuda(symbols, torch.int32, "symbols")
-    if model.noncontiguous:
-        symbols = model.symbols_to_indices(symbols)
+    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         stride = stride or max_words(n_per, config)
@@ -241,20 +260,20 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                          _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status), N.FLAG_NONE,
                                          _stream_ptr()), "cst_ans_decode_batch")
-    if model.noncontiguous:
-        model.indices_to_symbols(out, out=out)
-    return out, status
+    return _to_symbols(model, out), status
 
 
 _scratch = {}
 
 
 def _compact_scratch(device, n_streams):
+    # (one scratch per device AND stream: two compactions on different streams must not share ticket / status words)
     need = N.load_library().cst_compact_scratch_bytes(n_streams)
-    t = _scratch.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _scratch.get(key)
     if t is None or t.numel() < need:
         t = torch.empty(max(need, 4096), dtype=torch.uint8, device=device)
-        _scratch[device] = t
+        _scratch[key] = t
     return t
 
 
@@ -262,8 +281,11 @@ def compact(encoded: EncodedBatch, capacity: Optional[int] = None, out=None):
     """Packs the slabs: returns (packed uint32 words as int32 tensor, offsets int64[n_streams+1]); offsets[-1] = total words.
 
     One asynchronous kernel (single-pass scan fused with the gather), no host synchronisation: `packed` has `capacity`
-    words (default: the upper bound n_streams * stride, so that nothing can overflow) of which the first offsets[-1]
-    are valid.  `out=(packed, offsets)` reuses buffers of an earlier call."""
+    words (default: the upper bound n_streams * stride, so that nothing can overflow) of which ONLY the first offsets[-1]
+    are valid -- slice with `packed[:int(offsets[-1])]` (that reads the total back from the device; callers that stay on
+    the device hand `packed` and `offsets` on as they are).  `out=(packed, offsets)` reuses buffers of an earlier call.
+    With a caller-chosen `capacity` or `out` the words may not fit: streams that would overflow are left out by the kernel,
+    and this function then reads offsets[-1] back (one synchronisation, only in this case) and raises."""
     n_streams = encoded.n_words.numel()
     dev = encoded.words.device
     if out is not None:
@@ -275,6 +297,8 @@ def compact(encoded: EncodedBatch, capacity: Optional[int] = None, out=None):
     N.check(N.lib().cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
                                       _ptr(offsets), _ptr(packed), packed.numel(), _ptr(_compact_scratch(dev, n_streams)),
                                       _stream_ptr()), "cst_compact_words")
+    if (out is not None or capacity is not None) and int(offsets[-1].item()) > packed.numel():
+        raise ValueError(f"compact: {int(offsets[-1].item())} words do not fit the packed buffer of {packed.numel()} words")
     return packed, offsets
 
 
@@ -285,7 +309,7 @@ def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
 def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
                  stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
     """One RangeEncoder per stream: encode_iid_symbols + get_compressed (queue.rs:612-705, 458-523)."""
-    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         stride = stride or range_max_words(n_per, config)
@@ -319,7 +343,7 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
     N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                            _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
                                            _stream_ptr()), "cst_range_decode_batch")
-    return out, status
+    return _to_symbols(model, out), status
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -477,7 +501,7 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
                             stride: Optional[int] = None):
     """ans_encode + a checkpoint in front of every `interval` symbols.  Returns (EncodedBatch, Checkpoints); the words are
     those of ans_encode."""
-    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     stride = stride or max_words(n_per, config)
     dev = symbols.device
@@ -507,4 +531,4 @@ def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, mod
     N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
                                         encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
                                         n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()), "cst_ans_decode_batch_ckpt")
-    return out, status
+    return _to_symbols(model, out), status

@@ -52,9 +52,19 @@ def load(path):
         magic, n_streams, total, w, s, p, _ = _HEADER.unpack(head)
         if magic != MAGIC:
             raise ValueError("not a packed-batch container (bad magic)")
+        # the header is untrusted: sizes are checked against the file BEFORE anything is read or allocated
+        f.seek(0, 2)
+        if _HEADER.size + 8 * (n_streams + 1) + 4 * total != f.tell():
+            raise ValueError("truncated or inconsistent packed-batch container (sizes in the header do not match the file)")
+        if (w, s) not in ((32, 64), (16, 32)) or not 1 <= p <= (24 if w == 32 else 16):
+            raise ValueError(f"packed-batch container for an unsupported coder preset ({w}, {s}, {p})")
+        f.seek(_HEADER.size)
         offsets = np.frombuffer(f.read(8 * (n_streams + 1)), dtype="<u8")
         words = np.frombuffer(f.read(4 * total), dtype="<u4")
-    if len(offsets) != n_streams + 1 or len(words) != total or (n_streams + 1 and int(offsets[-1]) != total):
+    # ... and the offsets go straight into the `offsets=` form of the GPU decoders: they must start at 0, never decrease
+    # and end at the number of words (what `save` enforces)
+    if (len(offsets) != n_streams + 1 or len(words) != total or int(offsets[0]) != 0 or int(offsets[-1]) != total
+            or np.any(offsets[1:] < offsets[:-1])):
         raise ValueError("truncated or inconsistent packed-batch container")
     return words.astype(np.uint32), offsets.astype(np.uint64), (int(w), int(s), int(p))
 

@@ -220,6 +220,76 @@ __device__ inline double erf_exact_tab(double x, const double2* tab) {
     return y;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FAST erf with an exact fallback.  What the coders need from the Gaussian CDF is ONE integer, trunc(free_weight * cdf):
+// the reference's value of it changes only when free_weight * cdf crosses an integer.  So the per-symbol kernels evaluate
+// erf the cheap way first -- the same msun rational approximations, but with fused multiply-adds, divisions by a
+// Newton-refined v_rcp_f64 and ONE exp of -x^2 + R/S - 0.5625 instead of msun's split pair -- which is within
+// kErfFastBound of erf_exact (a few 1e-16 in practice: tests/test_gpu_ans_batch.py::test_fast_erf_error_bound measures
+// it), and fall back to erf_exact only where free_weight * cdf lands within kLeftGuard of an integer, i.e. where the
+// deviation could change the truncation (about two evaluations in a million).  The result is the reference's integer in
+// every case; the cost drops from ~290 to ~100 instructions per evaluation.
+
+constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_tab - erf_exact_tab|
+constexpr double kLeftGuard = 0x1p-20;       // >= 2^24 * kErfFastBound / 2 + rounding of the two products, with room to spare
+
+// a / b to ~1 ulp without the IEEE division sequence (v_rcp_f64 is good to 2^-24 on gfx950: two Newton steps)
+__device__ __forceinline__ double fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
+// exp(x) for -745 < x < 1, a few ulp: msun's reduction and polynomial, fused
+__device__ __forceinline__ double fast_exp_neg(double x) {
+    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                     invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                     P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                     P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const double kd = __builtin_rint(x * invln2);
+    const double hi = __builtin_fma(-kd, ln2hi, x), lo = kd * ln2lo;
+    const double r = hi - lo;
+    const double xx = r * r;
+    const double c = __builtin_fma(-xx, __builtin_fma(xx, __builtin_fma(xx, __builtin_fma(xx, __builtin_fma(xx, P5, P4), P3), P2), P1), r);
+    const double y = 1.0 + (fast_div(r * c, 2.0 - c) - lo + hi);
+    return __builtin_amdgcn_ldexp(y, (int)kd);       // (k >= -1075: gradual underflow like scalbn)
+}
+
+__device__ inline double erf_fast_tab(double x, const double2* tab) {
+    constexpr double erx = 8.45062911510467529297e-01, efx8 = 1.02703333676410069053e+00;
+    const uint32_t hx = f64_hi(x), ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    const double ax = fabs(x);
+    const uint32_t branch = (ix >= 0x3feb0000u ? 1u : 0u) + (ix >= 0x3ff40000u ? 1u : 0u) + (ix >= 0x4006db6du ? 1u : 0u);
+    const bool tail = ix >= 0x3ff40000u && ix < 0x40180000u;        // 1.25 <= |x| < 6
+    const double2* c = tab + branch * 9;
+    double2 t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = c[k];
+    const double x2 = ax * ax;
+    double s = branch == 0 ? x2 : ax - 1.0;
+    if (tail) s = fast_div(1.0, x2);
+    double num = t[8].x, den = t[8].y;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) { num = __builtin_fma(s, num, t[k].x); den = __builtin_fma(s, den, t[k].y); }
+    const double quot = fast_div(num, den);
+    double y = 1.0 - ((1.0 - erx) - quot);                          // 0.84375 <= |x| < 1.25
+    if (tail) {
+        // erfc(x) = exp(-x^2 - 0.5625 + R/S) / x with x^2 = x2 + x2_lo exactly
+        const double x2_lo = __builtin_fma(ax, ax, -x2);
+        const double e = fast_exp_neg((quot - 0.5625) - x2 - x2_lo);
+        y = 1.0 - fast_div(e, ax);
+    }
+    if (ix >= 0x40180000u) y = 1.0 - 0x1p-1022;
+    y = neg ? -y : y;
+    if (ix < 0x3feb0000u) y = __builtin_fma(x, quot, x);
+    if (ix < 0x3e300000u) y = 0.125 * (8.0 * x + efx8 * x);
+    if (x != x) y = x;
+    return y;
+}
+
 // probability::distribution::Gaussian::distribution (third-party; used at quantize.rs:546,558)
 // (TAB: erf_exact_tab with the LDS table `tab` instead of the branchy erf_exact -- same bits either way.  A template
 // flag, not a null test: address 0 is a valid LDS address, so the compiler would keep both.)
@@ -271,6 +341,44 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left(int32_t i, int32_t lo, i
     const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
     const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
     return (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>(x, mu, sigma, tab)) + (uint32_t)i) & pmask;
+}
+
+// leaky_gaussian_left via the fast erf, with the exact evaluation wherever the truncation could depend on the difference
+// (see erf_fast_tab).  Bit-identical to leaky_gaussian_left<true> for every input.  `n_exact` (optional) counts fallbacks.
+__device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
+                                                              double sigma, const double2* tab, uint32_t* n_exact = nullptr) {
+    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
+    if (i <= 0) return 0u;
+    if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    const uint32_t max_prob = pmask >> (prob_bits - P);
+    const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
+    const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
+    const double arg = (x - mu) / (sigma * sqrt2);                   // exactly the reference's three operations
+    double y = free_weight * ((1.0 + erf_fast_tab(arg, tab)) / 2.0);
+    const double fr = y - __builtin_floor(y);
+    const bool unsure = !(fr > kLeftGuard && fr < 1.0 - kLeftGuard);  // (NaN: unsure)
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
+        if (unsure) {
+            y = free_weight * ((1.0 + erf_exact_tab(arg, tab)) / 2.0);
+            if (n_exact) ++*n_exact;
+        }
+    }
+    return (f64_as_u32_sat(y) + (uint32_t)i) & pmask;
+}
+
+// left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp)
+__device__ __forceinline__ bool leaky_gaussian_lcp_quick(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu, double sigma,
+                                                         uint32_t& left, uint32_t& prob, const double2* tab) {
+    if (sym < lo || sym > hi) return false;
+    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
+    const int32_t n = (int32_t)((uint32_t)hi - (uint32_t)lo + 1u);
+    const int32_t i = (int32_t)((uint32_t)sym - (uint32_t)lo);
+    const uint32_t l = leaky_gaussian_left_quick(i, lo, n, P, prob_bits, mu, sigma, tab);
+    const uint32_t r = leaky_gaussian_left_quick(i + 1, lo, n, P, prob_bits, mu, sigma, tab);
+    left = l;
+    prob = (r - l) & pmask;
+    return true;
 }
 
 } // namespace cst

@@ -463,6 +463,15 @@ cst_status cst_model_get_cdf(const cst_model* m, size_t index, uint32_t* h_cdf, 
     return CST_OK;
 }
 
+cst_status cst_model_copy_cdfs(const cst_model* m, size_t first, size_t count, uint32_t* d_cdfs, void* stream) {
+    if (!m || first > m->n_tables || count > m->n_tables - first) return CST_ERR_INVALID_ARGUMENT;
+    if (count == 0) return CST_OK;
+    if (!d_cdfs) return CST_ERR_INVALID_ARGUMENT;
+    const size_t per = (size_t)m->n_symbols + 1;
+    CST_HIP_TRY(hipMemcpyAsync(d_cdfs, m->d_cdf + first * per, 4 * per * count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CST_OK;
+}
+
 cst_status cst_debug_erf_tab(const double* d_x, double* d_out, size_t n, void* stream) {
     if (!d_x || !d_out) return CST_ERR_INVALID_ARGUMENT;
     if (n == 0) return CST_OK;

@@ -11,6 +11,8 @@
 // LANE per stream runs the sequential recurrence over those entries.  Decoding uses one WAVE per stream:
 // 64 lanes evaluate 64 candidate left cumulatives at once (two erf rounds / two coalesced row reads for a 201-symbol
 // support).
+#include <mutex>
+
 #include "cst_range_kernels.hpp"
 #include "cst_math.hpp"
 
@@ -1115,7 +1117,9 @@ static cst_status chain_decode_common(PerSymbolDecodeArgs& a, cst_coder_config c
                                       uint32_t* d_n_push, cst_chain_heads* d_heads, int32_t* d_status) {
     if (cst_status st = fill_decode_args(a, cfg, d_pop_words, d_pop_offsets, pop_stride, 0, d_n_pop, d_symbols, n_streams, n_per_stream, layout,
                                          min_symbol, n_symbols, d_status, 0)) return st;
-    if (!d_heads || !d_n_push || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
+    // (d_pop_words must be a valid device pointer even when every d_n_pop[s] is 0: the kernels request a stream's next word
+    // ahead of knowing whether they will need it)
+    if (!d_heads || !d_n_push || !d_pop_words || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
     a.push_words = d_push_words; a.push_stride = push_stride; a.n_push = d_n_push; a.heads = d_heads; a.n_words_out = d_n_pop;
     return CST_OK;
 }
@@ -1126,7 +1130,7 @@ static cst_status chain_encode_common(cst_coder_config cfg, size_t n_streams, si
                                       size_t push_stride, uint32_t* d_n_push, cst_chain_heads* d_heads, int32_t* d_status, hipStream_t hs,
                                       Fill fill) {
     if (cst_status st = check_common(cfg, layout)) return st;
-    if (!d_heads || !d_n_pop || !d_n_push || !d_status || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_heads || !d_n_pop || !d_n_push || !d_status || !d_pop_words || (n_per_stream > 0 && !d_push_words)) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     const size_t n = n_streams * n_per_stream;
     EncEntry* entries = nullptr;

@@ -154,6 +154,9 @@ int32_t cst_model_n_symbols(const cst_model *model);
 size_t cst_model_n_tables(const cst_model *model); /* 1 = shared, else n_streams */
 /* Copies table `index`'s cdf[n_symbols+1] to host (synchronises `stream`). */
 cst_status cst_model_get_cdf(const cst_model *model, size_t index, uint32_t *h_cdf, void *stream);
+/* Copies the cdfs of tables [first, first + count) -- (n_symbols + 1) entries each, back to back -- into DEVICE memory,
+ * asynchronously on `stream` (e.g. to draw test symbols from per-stream models without a host round trip). */
+cst_status cst_model_copy_cdfs(const cst_model *model, size_t first, size_t count, uint32_t *d_cdfs, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * model families other than the quantized Gaussian
@@ -412,7 +415,8 @@ cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_w
  * words each) are host code in the binding (constriction_amd/stream/chain.py); these entry points are the symbol loops.
  *
  *   d_pop_words / d_pop_offsets / pop_stride / d_n_pop   the stack that is popped, laid out like d_words of the ANS
- *             decoder (stream s: d_pop_words[off(s) .. off(s) + d_n_pop[s]), consumed from the END); d_n_pop is updated
+ *             decoder (stream s: d_pop_words[off(s) .. off(s) + d_n_pop[s]), consumed from the END); d_n_pop is updated;
+ *             d_pop_words must be a valid device pointer (at least one word) even if every d_n_pop[s] is 0
  *   d_push_words / push_stride / d_n_push                the words pushed, in push order, stream s at s * push_stride;
  *             at most one word per symbol; d_n_push[s] = their number
  *   d_heads   in / out, one per stream

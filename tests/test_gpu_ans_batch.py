@@ -488,11 +488,15 @@ def test_compact_offsets_and_words(B, O, n_streams, n_per):
     flat = np.concatenate([words[s, : n_words[s]] for s in range(n_streams)] + [np.zeros(0, np.uint32)])
     assert np.array_equal(pk[: off[-1]], flat)
     if n_streams > 10:
-        # a packed buffer that is too small: streams that do not fit are skipped, the total still tells
+        # a packed buffer that is too small, at the C ABI: streams that do not fit are skipped, the total still tells
+        # (batched.compact turns that into a ValueError: test_compact_reports_a_packed_buffer_that_is_too_small)
+        from constriction_amd import _native as N
         cap = int(off[n_streams // 2]) + 1
-        small, off2 = B.compact(enc, capacity=cap)
-        small.fill_(-1)
-        small, off2 = B.compact(enc, out=(small, off2))
+        small = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+        off2 = torch.empty(n_streams + 1, dtype=torch.int64, device="cuda")
+        scratch = torch.empty(N.lib().cst_compact_scratch_bytes(n_streams), dtype=torch.uint8, device="cuda")
+        N.check(N.lib().cst_compact_words(enc.words.data_ptr(), enc.words.shape[1], enc.n_words.data_ptr(), n_streams, off2.data_ptr(),
+                                          small.data_ptr(), cap, scratch.data_ptr(), None), "cst_compact_words")
         torch.cuda.synchronize()
         assert off2.cpu().numpy().tolist() == want.tolist() and int(off2[-1]) > cap
         sm = small.cpu().numpy().view(np.uint32)
@@ -624,6 +628,22 @@ def test_golden_vectors_through_the_batched_abi(B, O, golden):
     assert done >= 3
 
 
+def test_compact_reports_a_packed_buffer_that_is_too_small(B, O):
+    P = 12
+    cdf = O.GaussianModel(-20, 20, 1.5, 4.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, -20, P)
+    sym = O.synth_symbols(5, 0, 300, 200, -20, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    total = enc.total_words()
+    packed, offsets = B.compact(enc, capacity=total)               # exactly enough
+    assert int(offsets[-1]) == total
+    with pytest.raises(ValueError):
+        B.compact(enc, capacity=total - 1)
+    small = (torch.empty(total // 2, dtype=torch.int32, device="cuda"), torch.empty(301, dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        B.compact(enc, out=small)
+
+
 def test_noncontiguous_alphabet(B, O):
     """NonContiguousCategoricalEncoderModel / NonContiguousLookupDecoderModel (the reference's test:
     src/stream/model/categorical/lookup_noncontiguous.rs:703-760): symbols 'a','x','c','y' with probabilities 3, 18, 1, 42 of
@@ -653,6 +673,23 @@ def test_noncontiguous_alphabet(B, O):
         bad[5, 3] = 424242                                               # not in the alphabet
         st = B.ans_encode(dev(bad), model, (32, 64, P)).status.cpu().numpy()
         assert st[5] == 1 and (np.delete(st, 5) == 0).all()
+        # the same alphabet through the other table-model entry points: range coder, checkpointed streams
+        want_rw, want_rn, _ = O.rc_encode_batch(idx, 0, cdf, P)
+        renc = B.range_encode(dev(sym), model, (32, 64, P))
+        rdec, rst = B.range_decode(renc, model, sym.shape[1])
+        torch.cuda.synchronize()
+        rwords, rn, rstatus = renc.to_numpy()
+        assert (rstatus == 0).all() and rn.tolist() == want_rn.tolist()
+        for s in (0, 1, 64, len(sym) - 1):
+            assert rwords[s, : rn[s]].tolist() == want_rw[s, : want_rn[s]].tolist()
+        assert (rst.cpu().numpy() == 0).all() and np.array_equal(rdec.cpu().numpy(), sym)
+        assert B.range_encode(dev(bad), model, (32, 64, P)).status.cpu().numpy()[5] == 1
+        cenc, ck = B.ans_encode_checkpointed(dev(sym[:, :70]), model, 10, (32, 64, P))
+        cdec, cst = B.ans_decode_checkpointed(cenc, ck, model, 70)
+        torch.cuda.synchronize()
+        assert (cst.cpu().numpy() == 0).all() and np.array_equal(cdec.cpu().numpy(), sym[:, :70])
+        plain = B.ans_encode(dev(sym[:, :70]), model, (32, 64, P))
+        assert torch.equal(cenc.n_words, plain.n_words) and cenc.stream(3).tolist() == plain.stream(3).tolist()
     with pytest.raises(ValueError):
         B.Model.from_cdf_noncontiguous([1, 2, 1], np.array([0, 10, 20, 64], dtype=np.uint32), 6)   # duplicate symbol
 

@@ -118,3 +118,24 @@ def test_packed_batch_container_roundtrip(tmp_path):
         container.load(tmp_path / "magic.cst")
     with pytest.raises(ValueError):
         container.save(tmp_path / "bad.cst", words, offsets[::-1].copy(), (32, 64, 24))
+    # a hostile header: huge sizes must be rejected from the file size alone (nothing of that size is read or allocated)
+    import struct
+    (tmp_path / "huge.cst").write_bytes(struct.pack("<8sQQIIII", b"CSTPACK1", 1 << 60, 1 << 61, 32, 64, 24, 0) + raw[40:])
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "huge.cst")
+    # offsets that decrease / do not start at 0 / a preset the coders do not have: what `save` refuses, `load` refuses too
+    body = bytearray(raw)
+    body[40 + 8 * 3: 40 + 8 * 4] = struct.pack("<Q", int(offsets[-1]))        # offsets[3] > offsets[4]
+    (tmp_path / "order.cst").write_bytes(bytes(body))
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "order.cst")
+    body = bytearray(raw)
+    body[40: 48] = struct.pack("<Q", 1)
+    (tmp_path / "start.cst").write_bytes(bytes(body))
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "start.cst")
+    body = bytearray(raw)
+    body[24: 28] = struct.pack("<I", 64)
+    (tmp_path / "preset.cst").write_bytes(bytes(body))
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "preset.cst")
