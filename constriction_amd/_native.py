@@ -109,6 +109,8 @@ SIGNATURES = {
     "cst_release_scratch": (_i32, []),
     "cst_debug_erf": (_i32, [_vp, _vp, _z, _vp]),
     "cst_debug_erf_tab": (_i32, [_vp, _vp, _z, _vp]),
+    "cst_debug_erf_fast": (_i32, [_i32, _vp, _vp, _z, _vp]),
+    "cst_debug_gaussian_left_quick": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _z, _vp, _vp]),
     "cst_debug_gaussian_lcp": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _z, _vp]),
 }
 

@@ -233,28 +233,41 @@ __device__ inline double erf_exact_tab(double x, const double2* tab) {
 constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_tab - erf_exact_tab|
 constexpr double kLeftGuard = 0x1p-20;       // >= 2^24 * kErfFastBound / 2 + rounding of the two products, with room to spare
 
-// a / b to ~1 ulp without the IEEE division sequence (v_rcp_f64 is good to 2^-24 on gfx950: two Newton steps)
-__device__ __forceinline__ double fast_div(double a, double b) {
+// 1 / b to ~1 ulp without the IEEE division sequence (v_rcp_f64 is good to 2^-24 on gfx950: two Newton steps)
+__device__ __forceinline__ double fast_rcp(double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+
+// a / b with a residual correction (the host-style use in make_entry_f64 wants the last ulp or so)
+__device__ __forceinline__ double fast_div(double a, double b) {
+    const double r = fast_rcp(b);
     const double q = a * r;
     return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
-// exp(x) for -745 < x < 1, a few ulp: msun's reduction and polynomial, fused
+// exp(x) for -745 < x <= 0 to ~2 ulp: x = k ln2 + r, |r| <= ln2 / 2, exp(r) by its Taylor polynomial of degree 13
+// (remainder < 2e-17 relative), scaled by ldexp -- no division, no branches
 __device__ __forceinline__ double fast_exp_neg(double x) {
-    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
-                     invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
-                     P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-                     P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
     const double kd = __builtin_rint(x * invln2);
-    const double hi = __builtin_fma(-kd, ln2hi, x), lo = kd * ln2lo;
-    const double r = hi - lo;
-    const double xx = r * r;
-    const double c = __builtin_fma(-xx, __builtin_fma(xx, __builtin_fma(xx, __builtin_fma(xx, __builtin_fma(xx, P5, P4), P3), P2), P1), r);
-    const double y = 1.0 + (fast_div(r * c, 2.0 - c) - lo + hi);
-    return __builtin_amdgcn_ldexp(y, (int)kd);       // (k >= -1075: gradual underflow like scalbn)
+    const double r = __builtin_fma(-kd, ln2lo, __builtin_fma(-kd, ln2hi, x));
+    double p = 1.0 / 6227020800.0;                       // 1 / 13!
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)kd);           // (k >= -1075: gradual underflow like scalbn)
 }
 
 __device__ inline double erf_fast_tab(double x, const double2* tab) {
@@ -269,18 +282,19 @@ __device__ inline double erf_fast_tab(double x, const double2* tab) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) t[k] = c[k];
     const double x2 = ax * ax;
+    const double inv_x2 = fast_rcp(tail ? x2 : 1.0);               // (only the tail uses it: s = 1 / x^2, 1 / x = x s)
     double s = branch == 0 ? x2 : ax - 1.0;
-    if (tail) s = fast_div(1.0, x2);
+    if (tail) s = inv_x2;
     double num = t[8].x, den = t[8].y;
 #pragma unroll
     for (int k = 7; k >= 0; --k) { num = __builtin_fma(s, num, t[k].x); den = __builtin_fma(s, den, t[k].y); }
-    const double quot = fast_div(num, den);
+    const double quot = num * fast_rcp(den);
     double y = 1.0 - ((1.0 - erx) - quot);                          // 0.84375 <= |x| < 1.25
     if (tail) {
         // erfc(x) = exp(-x^2 - 0.5625 + R/S) / x with x^2 = x2 + x2_lo exactly
         const double x2_lo = __builtin_fma(ax, ax, -x2);
         const double e = fast_exp_neg((quot - 0.5625) - x2 - x2_lo);
-        y = 1.0 - fast_div(e, ax);
+        y = __builtin_fma(-e, ax * inv_x2, 1.0);
     }
     if (ix >= 0x40180000u) y = 1.0 - 0x1p-1022;
     y = neg ? -y : y;
@@ -343,39 +357,57 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left(int32_t i, int32_t lo, i
     return (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>(x, mu, sigma, tab)) + (uint32_t)i) & pmask;
 }
 
-// leaky_gaussian_left via the fast erf, with the exact evaluation wherever the truncation could depend on the difference
-// (see erf_fast_tab).  Bit-identical to leaky_gaussian_left<true> for every input.  `n_exact` (optional) counts fallbacks.
-__device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
-                                                              double sigma, const double2* tab, uint32_t* n_exact = nullptr) {
-    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
-    if (i <= 0) return 0u;
-    if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+// The integer trunc(free_weight * cdf(x)) + slack through the fast erf, with the exact evaluation wherever the truncation
+// could depend on the difference (see erf_fast_tab).  `inv_d` ~ 1 / (sigma sqrt 2): the fast path's argument
+// (x - mu) inv_d is within a few ulp of the reference's (x - mu) / (sigma sqrt 2) -- part of the same error budget; the
+// fallback forms the reference's argument with the reference's three operations.  `n_exact` (optional) counts fallbacks.
+__device__ __forceinline__ uint32_t leaky_left_value_quick(double x, double mu, double sigma, double inv_d, double free_weight,
+                                                           const double2* tab, uint32_t* n_exact) {
     constexpr double sqrt2 = 1.41421356237309504880168872420969808;
-    const uint32_t max_prob = pmask >> (prob_bits - P);
-    const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
-    const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
-    const double arg = (x - mu) / (sigma * sqrt2);                   // exactly the reference's three operations
+    const double arg = (x - mu) * inv_d;
     double y = free_weight * ((1.0 + erf_fast_tab(arg, tab)) / 2.0);
     const double fr = y - __builtin_floor(y);
-    const bool unsure = !(fr > kLeftGuard && fr < 1.0 - kLeftGuard);  // (NaN: unsure)
+    // |arg| >= 6: erf is +-1 in both evaluations (the exact one rounds to +-1 from 5.87 on), no doubt there although
+    // free_weight * cdf is then an exact integer.  A NaN argument (sigma sqrt 2 overflowed or is subnormal: the reciprocal
+    // broke down) is always in doubt.
+    const bool same = (f64_hi(arg) & 0x7fffffffu) >= 0x40180000u && arg == arg;
+    const bool unsure = !same && !(fr > kLeftGuard && fr < 1.0 - kLeftGuard);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
         if (unsure) {
-            y = free_weight * ((1.0 + erf_exact_tab(arg, tab)) / 2.0);
+            y = free_weight * ((1.0 + erf_exact_tab((x - mu) / (sigma * sqrt2), tab)) / 2.0);
             if (n_exact) ++*n_exact;
         }
     }
-    return (f64_as_u32_sat(y) + (uint32_t)i) & pmask;
+    return f64_as_u32_sat(y);
 }
 
-// left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp)
+// leaky_gaussian_left, quick.  Bit-identical to leaky_gaussian_left<true> for every input.
+__device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
+                                                              double sigma, const double2* tab, uint32_t* n_exact = nullptr) {
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
+    if (i <= 0) return 0u;
+    if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+    const uint32_t max_prob = pmask >> (prob_bits - P);
+    const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
+    const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
+    return (leaky_left_value_quick(x, mu, sigma, fast_rcp(sigma * sqrt2), free_weight, tab, n_exact) + (uint32_t)i) & pmask;
+}
+
+// left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp); one reciprocal
+// serves both ends of the bin
 __device__ __forceinline__ bool leaky_gaussian_lcp_quick(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu, double sigma,
                                                          uint32_t& left, uint32_t& prob, const double2* tab) {
     if (sym < lo || sym > hi) return false;
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
     const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
-    const int32_t n = (int32_t)((uint32_t)hi - (uint32_t)lo + 1u);
-    const int32_t i = (int32_t)((uint32_t)sym - (uint32_t)lo);
-    const uint32_t l = leaky_gaussian_left_quick(i, lo, n, P, prob_bits, mu, sigma, tab);
-    const uint32_t r = leaky_gaussian_left_quick(i + 1, lo, n, P, prob_bits, mu, sigma, tab);
+    const uint32_t max_prob = pmask >> (prob_bits - P);
+    const double free_weight = (double)(max_prob - ((uint32_t)hi - (uint32_t)lo));
+    const uint32_t slack = ((uint32_t)sym - (uint32_t)lo) & pmask;
+    const double inv_d = fast_rcp(sigma * sqrt2);
+    uint32_t l = 0u, r = (P >= 32 ? 0u : (1u << P)) & pmask;
+    if (sym != lo) l = (leaky_left_value_quick((double)sym - 0.5, mu, sigma, inv_d, free_weight, tab, nullptr) + slack) & pmask;
+    if (sym != hi) r = (leaky_left_value_quick((double)sym + 0.5, mu, sigma, inv_d, free_weight, tab, nullptr) + slack + 1u) & pmask;
     left = l;
     prob = (r - l) & pmask;
     return true;

@@ -25,7 +25,7 @@ __global__ void gaussian_cdf_kernel(int P, int32_t lo, int32_t n, const double* 
     const int32_t i = (int32_t)(gid - tbl * per);
     const double mu = means ? means[tbl] : mean0;
     const double sd = stds ? stds[tbl] : std0;
-    cdf[gid] = leaky_gaussian_left<true>(i, lo, n, P, 32, mu, sd, erf_tab);
+    cdf[gid] = leaky_gaussian_left_quick(i, lo, n, P, 32, mu, sd, erf_tab);
 }
 
 // 16-bit per-stream cdf rows for the LDS-resident per-stream models (values modulo 2^16).  Also validates
@@ -197,6 +197,33 @@ __global__ void debug_erf_tab_kernel(const double* __restrict__ x, double* __res
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = erf_exact_tab(x[i], tab);
+}
+
+// which: 0 erf_fast_tab(x) -> out; 1 |erf_fast_tab - erf_exact_tab| -> out
+__global__ void debug_erf_fast_kernel(int which, const double* __restrict__ x, double* __restrict__ out, size_t n) {
+    __shared__ double2 tab[kErfTabEntries];
+    erf_tab_fill(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double f = erf_fast_tab(x[i], tab);
+    out[i] = which == 0 ? f : fabs(f - erf_exact_tab(x[i], tab));
+}
+
+// the quick (fast erf + exact fallback) and the plain exact left cumulatives side by side: counts[0] += mismatches,
+// counts[1] += exact fallbacks taken
+__global__ void debug_left_quick_kernel(int P, int32_t lo, int32_t n_sym, const int32_t* __restrict__ idx, const double* __restrict__ means,
+                                        const double* __restrict__ stds, size_t n, unsigned long long* __restrict__ counts) {
+    __shared__ double2 tab[kErfTabEntries];
+    erf_tab_fill(tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t fallbacks = 0;
+    const uint32_t quick = leaky_gaussian_left_quick(idx[i], lo, n_sym, P, 32, means[i], stds[i], tab, &fallbacks);
+    const uint32_t exact = leaky_gaussian_left<true>(idx[i], lo, n_sym, P, 32, means[i], stds[i], tab);
+    if (quick != exact) atomicAdd(&counts[0], 1ull);
+    if (fallbacks) atomicAdd(&counts[1], (unsigned long long)fallbacks);
 }
 
 __global__ void debug_lcp_kernel(int P, int prob_bits, int32_t lo, int32_t hi, const int32_t* __restrict__ sym,
@@ -485,6 +512,24 @@ cst_status cst_debug_erf(const double* d_x, double* d_out, size_t n, void* strea
     if (n == 0) return CST_OK;
     hipLaunchKernelGGL(debug_erf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_out,
                        n);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+cst_status cst_debug_erf_fast(int32_t which, const double* d_x, double* d_out, size_t n, void* stream) {
+    if (!d_x || !d_out || which < 0 || which > 1) return CST_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(debug_erf_fast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, d_x, d_out, n);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+cst_status cst_debug_gaussian_left_quick(int32_t precision, int32_t min_symbol, int32_t max_symbol, const int32_t* d_index,
+                                         const double* d_means, const double* d_stds, size_t n, uint64_t* d_counts, void* stream) {
+    if (!d_index || !d_means || !d_stds || !d_counts || precision < 1 || precision > 32 || max_symbol <= min_symbol) return CST_ERR_INVALID_ARGUMENT;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(debug_left_quick_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, precision, min_symbol,
+                       (int32_t)((int64_t)max_symbol - min_symbol + 1), d_index, d_means, d_stds, n, reinterpret_cast<unsigned long long*>(d_counts));
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

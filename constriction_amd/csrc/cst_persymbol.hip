@@ -11,6 +11,7 @@
 // LANE per stream runs the sequential recurrence over those entries.  Decoding uses one WAVE per stream:
 // 64 lanes evaluate 64 candidate left cumulatives at once (two erf rounds / two coalesced row reads for a 201-symbol
 // support).
+#include <cstdlib>
 #include <mutex>
 
 #include "cst_range_kernels.hpp"
@@ -53,7 +54,7 @@ __global__ void gaussian_entries_kernel(int P, int32_t lo, int32_t hi, const int
     // `assert!(std > 0.0)` and finite parameters (pybindings/stream/model.rs:654-657); out-of-support symbols
     // (quantize.rs:537-539) and degenerate distributions (quantize.rs:562-565) all end up with p = 0 = impossible
     if (s > 0.0 && s <= 1.7976931348623157e308 && m == m && m <= 1.7976931348623157e308 && m >= -1.7976931348623157e308) {
-        if (!leaky_gaussian_lcp<true>(sym[i], lo, hi, P, 32, m, s, c, p, erf_tab)) p = 0;
+        if (!leaky_gaussian_lcp_quick(sym[i], lo, hi, P, 32, m, s, c, p, erf_tab)) p = 0;
     }
     out[i] = make_entry(c, p);
 }
@@ -258,6 +259,191 @@ __global__ __launch_bounds__(kBlock) void encode_entries_kernel(const EntriesEnc
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-symbol Gaussians, ONE kernel (batches of many streams): a wave owns kFuStreams streams and alternates, tile by tile
+// of kFuTile symbols, between
+//   (A) all 64 lanes turning the tile's kFuStreams x kFuTile (symbol, mean, std) triples into coder entries
+//       (two Gaussian cumulatives + floor(2^64 / p) each) in a wave-private LDS tile, and
+//   (B) one lane per stream running the sequential coder recurrence over its row of that tile.
+// Nothing but the inputs and the compressed words touches HBM: the two-pass form above writes a 16-byte entry per symbol
+// and reads it back (4 GiB of scratch and 2.5x the algorithmic traffic at 65 536 x 4096).  The entry pass is the bulk of
+// the work and runs with full lanes; the coder steps run on kFuStreams of the 64 lanes, which is why a wave takes 32
+// streams, not 64: two waves per SIMD then cover each other's stalls.  Inputs are requested four items (~ 5000 cycles of
+// arithmetic) before they are used.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFuTile = 16;                               // symbols per tile
+constexpr int kFuStreams = 32;                            // streams per wave
+constexpr int kFuIters = kFuTile * kFuStreams / kWave;    // entries per lane and tile
+constexpr int kFuRingSlots = 32;
+constexpr int kFuAhead = 4;                               // items requested ahead of their use (kFuIters % kFuAhead == 0)
+constexpr int kFuRowStride = kFuStreams + 1;              // entries: row t of the tile starts at t * kFuRowStride (conflict-free both ways)
+constexpr int kFuBlock = 256;
+constexpr size_t kFuTabBytes = 1024;                      // the erf coefficient table (576 bytes), padded
+constexpr size_t kFuWaveBytes = (size_t)kFuRingSlots * kWave * 4 + (size_t)kFuTile * kFuRowStride * sizeof(EncEntry);
+
+struct GaussianFusedArgs {
+    const int32_t* symbols;
+    const double* means;
+    const double* stds;
+    size_t n_streams, n_per_stream;
+    int32_t layout, precision, lo, hi;
+    uint32_t* words;
+    size_t stride_words;
+    uint32_t* n_words;
+    uint64_t* state;
+    cst_range_state* rstate;
+    int32_t* status;
+    uint32_t flags;
+};
+
+// floor(2^64 / p) for 2 <= p <= 2^24 through two f64 quotients, each corrected by its exact remainder:
+// 2^64 / p = 2^32 q1 + 2^32 r1 / p with q1 = floor(2^32 / p), r1 = 2^32 - q1 p
+__device__ __forceinline__ EncEntry make_entry_f64(uint32_t c, uint32_t p) {
+    if (p <= 1u) return EncEntry{c, p, p ? 0xffffffffu : 0u, p ? 0xffffffffu : 0u};
+    const double inv = fast_rcp((double)p);
+    uint32_t q1 = (uint32_t)(4294967296.0 * inv);                       // within one of floor(2^32 / p)
+    int64_t r1 = (int64_t)(1ull << 32) - (int64_t)((uint64_t)q1 * p);
+    if (r1 < 0) { q1 -= 1u; r1 += p; }
+    else if (r1 >= (int64_t)p) { q1 += 1u; r1 -= p; }
+    const uint64_t x2 = (uint64_t)r1 << 32;                             // < 2^56: exact as a double
+    uint32_t q2 = (uint32_t)((double)x2 * inv);
+    int64_t r2 = (int64_t)x2 - (int64_t)((uint64_t)q2 * p);
+    if (r2 < 0) q2 -= 1u;
+    else if (r2 >= (int64_t)p) q2 += 1u;
+    return EncEntry{c, p, q2, q1};
+}
+
+template <int W, int S, int KIND>
+__global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const GaussianFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2* erf_tab = reinterpret_cast<double2*>(smem);
+    erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave_in_block = threadIdx.x >> 6;
+    unsigned char* mine = smem + kFuTabBytes + (size_t)wave_in_block * kFuWaveBytes;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(mine);
+    EncEntry* tile = reinterpret_cast<EncEntry*>(mine + (size_t)kFuRingSlots * kWave * 4);
+    const size_t s0 = ((size_t)blockIdx.x * (kFuBlock / kWave) + wave_in_block) * kFuStreams;
+    if (s0 >= a.n_streams) return;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const bool symbol_major = a.layout == CST_LAYOUT_SYMBOL_MAJOR;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const size_t s = s0 + lane;
+    const bool active = lane < kFuStreams && s < a.n_streams;            // this lane codes a stream in phase B
+
+    // phase A's work items: item w = it * 64 + lane of a tile is (stream j, symbol tl); consecutive lanes take consecutive
+    // addresses of the input matrices in either layout.  Items are requested ONE item ahead of their use (the loop stays
+    // rolled: eight unrolled copies of two erf would not fit the instruction cache).
+    const size_t n_tiles = (N + kFuTile - 1) / kFuTile;
+    auto tile_of = [&](size_t step) { return KIND == kAns ? n_tiles - 1 - step : step; };   // ANS codes last to first
+    auto item_j = [&](int it) { const int w = it * kWave + lane; return symbol_major ? w % kFuStreams : w / kFuTile; };
+    auto item_t = [&](int it) { const int w = it * kWave + lane; return symbol_major ? w / kFuStreams : w % kFuTile; };
+    // a queue of kFuAhead requested items (HBM latency is two to three items' worth of arithmetic); the item loop below is
+    // unrolled by kFuAhead so that every queue slot is a fixed set of registers
+    int32_t sy_q[kFuAhead];
+    double mu_q[kFuAhead], sd_q[kFuAhead];
+    bool ok_q[kFuAhead];
+    auto request = [&](int slot, size_t k, int it) {
+        const size_t sj = s0 + (size_t)item_j(it), t = k * kFuTile + (size_t)item_t(it);
+        ok_q[slot] = sj < a.n_streams && t < N;
+        // (unconditional loads from an address that is always valid: a conditional load is waited for at once)
+        const size_t e = ok_q[slot] ? (symbol_major ? t * a.n_streams + sj : sj * N + t) : 0;
+        sy_q[slot] = __builtin_nontemporal_load(a.symbols + e);
+        mu_q[slot] = __builtin_nontemporal_load(a.means + e);
+        sd_q[slot] = __builtin_nontemporal_load(a.stds + e);
+    };
+
+    uint32_t* slab = a.words + (active ? s : 0) * a.stride_words;
+    const uint32_t cap = active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u;
+    EncLane<W, S, kFuRingSlots> LA;
+    RangeEncLane<W, S, kFuRingSlots> LR;
+    if constexpr (KIND == kAns) {
+        LA.init(slab, cap, ring, lane);
+        if (raw && active) LA.state = (typename StateT<S>::type)a.state[s];
+    } else {
+        LR.init(slab, cap, ring, lane);
+        if (raw && active) {
+            const cst_range_state r = a.rstate[s];
+            LR.lower = (typename StateT<S>::type)r.lower; LR.range = (typename StateT<S>::type)r.range;
+            LR.inv_n = r.inverted_n; LR.inv_first = r.inverted_first;
+        }
+    }
+    uint32_t bad = 0;
+
+    if (n_tiles > 0) {
+#pragma unroll
+        for (int q = 0; q < kFuAhead; ++q) request(q, tile_of(0), q);
+    }
+    for (size_t step = 0; step < n_tiles; ++step) {
+        const size_t k = tile_of(step);
+        wave_lds_fence();                                  // (the previous tile has been read)
+        // ---- phase A: entries of tile k ----
+#pragma unroll 1
+        for (int it0 = 0; it0 < kFuIters; it0 += kFuAhead) {
+#pragma unroll
+            for (int q = 0; q < kFuAhead; ++q) {
+                const int it = it0 + q;
+                const int32_t sy = ok_q[q] ? sy_q[q] : a.lo;            // (items past the matrix: never coded)
+                const double m = ok_q[q] ? mu_q[q] : 0.0, sg = ok_q[q] ? sd_q[q] : 1.0;
+                if (it + kFuAhead < kFuIters) request(q, k, it + kFuAhead);
+                else if (step + 1 < n_tiles) request(q, tile_of(step + 1), it + kFuAhead - kFuIters);
+                uint32_t c = 0, p = 0;
+                // `assert!(std > 0.0)` and finite parameters (pybindings/stream/model.rs:654-657); out-of-support symbols
+                // (quantize.rs:537-539) and degenerate distributions (quantize.rs:562-565) all end up with p = 0 = impossible
+                if (sg > 0.0 && sg <= 1.7976931348623157e308 && fabs(m) <= 1.7976931348623157e308) {
+                    if (!leaky_gaussian_lcp_quick(sy, a.lo, a.hi, P, 32, m, sg, c, p, erf_tab)) p = 0;
+                }
+                if ((uint64_t)c + p > ((uint64_t)1 << P)) p = 0;
+                tile[item_t(it) * kFuRowStride + item_j(it)] = make_entry_f64(c, p);
+            }
+        }
+        wave_lds_fence();
+        // ---- phase B: every stream's lane over its row ----
+        const size_t t0 = k * kFuTile;
+        const int n_here = (int)(N - t0 < (size_t)kFuTile ? N - t0 : (size_t)kFuTile);
+        if (active) {
+            if constexpr (KIND == kAns) {
+                for (int tl = n_here - 1; tl >= 0; --tl) {
+                    const EncEntry e = tile[tl * kFuRowStride + lane];
+                    if (e.p == 0) bad = 1;
+                    else if (!bad) LA.template step<false>(e, P);
+                }
+            } else {
+                for (int tl = 0; tl < n_here; ++tl) {
+                    const EncEntry e = tile[tl * kFuRowStride + lane];
+                    if (e.p == 0) bad = 1;
+                    else if (!bad) LR.step(e.c, e.p, P);
+                }
+            }
+        }
+        // at most kFuTile new words per stream and tile: whole chunks leave here (<= 19 pending before, < 4 after)
+        if constexpr (KIND == kAns) LA.flush_chunks(); else LR.out.flush_chunks();
+    }
+
+    uint32_t n_words = 0;
+    int32_t status;
+    if constexpr (KIND == kAns) {
+        status = LA.finish(!raw, 1u, n_words);
+        if (active && raw) a.state[s] = (uint64_t)LA.state;
+    } else if (raw) {
+        LR.out.drain();
+        n_words = LR.out.wr;
+        status = LR.out.wr > LR.out.cap ? CST_STREAM_CAPACITY : CST_STREAM_OK;
+        if (active) {
+            cst_range_state r = a.rstate[s];
+            r.lower = (uint64_t)LR.lower; r.range = (uint64_t)LR.range; r.inverted_n = LR.inv_n; r.inverted_first = LR.inv_first;
+            a.rstate[s] = r;
+        }
+    } else {
+        status = LR.finish(1u, n_words);
+    }
+    if (!active) return;
+    if (bad) status = CST_STREAM_IMPOSSIBLE_SYMBOL;
+    a.status[s] = status;
+    a.n_words[s] = status == CST_STREAM_OK ? n_words : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
 // decoding with per-symbol models
 // ------------------------------------------------------------------------------------------------
 
@@ -312,6 +498,11 @@ struct DirectDecoder<W, S, kAns> {
     // (an unconditional load from a pointer that is always valid: a conditional one makes the compiler wait for it at once)
     const uint32_t* idle;
     __device__ __forceinline__ void look_ahead() { ahead = *(rd > 0 ? in + (rd - 1) : idle); }
+    // the lane-per-stream decoder keeps a window of the stream's words in LDS: where the window starts / which word is next
+    static constexpr bool kDownward = true;
+    __device__ __forceinline__ uint32_t position() const { return rd; }
+    __device__ __forceinline__ int64_t next_index() const { return (int64_t)rd - 1; }
+    __device__ __forceinline__ uint32_t length() const { return 0xffffffffu; }          // (every index below rd exists)
     __device__ __forceinline__ uint32_t quantile(int P) { return (uint32_t)state & ((1u << P) - 1u); }
     __device__ __forceinline__ void advance(uint32_t q, uint32_t c, uint32_t p, int P) {      // stack.rs:1086-1097
         st_t st = (st_t)((st_t)(state >> P) * (st_t)p + (st_t)(q - c));
@@ -339,6 +530,10 @@ struct DirectDecoder<W, S, kRange> {
     uint32_t ahead;                                           // in[pos], requested when the word before it was taken
     const uint32_t* idle;                                     // (see the ANS decoder)
     __device__ __forceinline__ void look_ahead() { ahead = *(pos < len ? in + pos : idle); }
+    static constexpr bool kDownward = false;
+    __device__ __forceinline__ uint32_t position() const { return pos; }
+    __device__ __forceinline__ int64_t next_index() const { return (int64_t)pos; }
+    __device__ __forceinline__ uint32_t length() const { return len; }
     __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool raw) {
         const WordSlice ws = a.slice(s);
         in = a.words + ws.off;
@@ -389,6 +584,10 @@ struct DirectDecoder<W, S, kChain> {
     st_t rh; uint32_t ch, rd, wr, cap; const uint32_t* in; uint32_t* out; int32_t status;
     uint32_t ahead; const uint32_t* idle;
     __device__ __forceinline__ void look_ahead() { ahead = *(rd > 0 ? in + (rd - 1) : idle); }
+    static constexpr bool kDownward = true;
+    __device__ __forceinline__ uint32_t position() const { return rd; }
+    __device__ __forceinline__ int64_t next_index() const { return (int64_t)rd - 1; }
+    __device__ __forceinline__ uint32_t length() const { return 0xffffffffu; }
     __device__ __forceinline__ void init(const PerSymbolDecodeArgs& a, size_t s, bool) {
         const WordSlice ws = a.slice(s);
         in = a.words + ws.off;
@@ -440,7 +639,7 @@ struct GaussianLeft {
         return sd > 0.0 && sd <= 1.7976931348623157e308 && mu == mu && mu <= 1.7976931348623157e308 && mu >= -1.7976931348623157e308;
     }
     __device__ __forceinline__ uint32_t left(uint32_t i) const {
-        return leaky_gaussian_left<true>((int32_t)i, a.min_symbol, a.n_symbols, a.precision, 32, mu, sd, erf_tab);
+        return leaky_gaussian_left_quick((int32_t)i, a.min_symbol, a.n_symbols, a.precision, 32, mu, sd, erf_tab);
     }
 };
 struct RowLeft {                       // explicit cdf rows [n + 1] per coded symbol: 64 coalesced entries per round
@@ -533,14 +732,29 @@ __device__ __noinline__ void store_symbol_tile(int32_t* sym, size_t n_streams, s
     else tile_store<false>(sym, n_streams, N, s0, t0, lane, tile);
 }
 
+// LDS of the lane-per-stream decoder, per wave: the symbol tile (stream-major output), one tile of parameters
+// [kParTile][64 streams (+1)] for each of mean and std, and a window of kWordWindow words per stream.  Everything that comes
+// from HBM is requested ONE TILE (16 symbols ~ 40 000 cycles of model search) before it is used, with coalesced loads
+// where the layout allows: per-lane loads issued a symbol ahead exposed ~2300 cycles of latency per symbol (half the
+// kernel's time: rocprofv3 SQ_WAIT_ANY), because a wave-wide load of 64 different cache lines takes longer than a symbol.
+constexpr int kParTile = 16;
+constexpr int kParStride = kWave + 1;                 // doubles per tile row: conflict-free writes (stream-major) and reads
+constexpr int kWordWindow = 32;                       // slots per stream, position p lives in slot p % 32
+constexpr size_t kLaneDecWaveBytes = (size_t)kWave * kTileStride * 4 + 2 * (size_t)kParTile * kParStride * 8 + (size_t)kWordWindow * kWave * 4;
+constexpr size_t kLaneDecLdsBytes = 1024 + (size_t)(kBlock / kWave) * kLaneDecWaveBytes;
+
 template <int W, int S, int KIND>
 __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerSymbolDecodeArgs a) {
-    __shared__ int32_t tiles[kBlock / kWave][kWave * kTileStride];
-    __shared__ double2 erf_tab[kErfTabEntries];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2* erf_tab = reinterpret_cast<double2*>(smem);
     erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    int32_t* tile = tiles[threadIdx.x >> 6];
+    unsigned char* mine = smem + 1024 + (size_t)(threadIdx.x >> 6) * kLaneDecWaveBytes;
+    int32_t* tile = reinterpret_cast<int32_t*>(mine);
+    double* par_mu = reinterpret_cast<double*>(mine + (size_t)kWave * kTileStride * 4);
+    double* par_sd = par_mu + kParTile * kParStride;
+    uint32_t* win = reinterpret_cast<uint32_t*>(par_sd + kParTile * kParStride);
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t s0 = s - lane;
     if (s0 >= a.n_streams) return;
@@ -557,69 +771,124 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     const float total_f = (float)(1ull << P), free_f = (float)free_weight, inv_total_f = 1.0f / total_f, inv_free_f = 1.0f / free_f;
     const double guess_shift = 0.5 - (double)a.min_symbol;            // symbol index of the real number x: x - min_symbol + 0.5
     const bool vec = !symbol_major && (N % 4 == 0) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
-
-    // a lone wave per SIMD cannot hide a load behind another wave: the parameters of the NEXT symbol are requested a
-    // whole symbol (thousands of cycles of erf) before they are needed
     const bool two_step_guess = (double)n * 64.0 > free_weight;      // the leak moves the guess by more than 1/64 quantile
+
     DirectDecoder<W, S, KIND> D;
     D.init(a, se, raw);
     int32_t status = D.status;
-    const double* mu_p = a.means + e0;
-    const double* sd_p = a.stds + e0;
     int32_t* sym_p = a.symbols + e0;
-    double mu_next = N ? *mu_p : 0.0, sd_next = N ? *sd_p : 1.0;
-    for (size_t t = 0; t < N; ++t) {
-        int32_t sym = 0;
-        const double mu = mu_next, sd = sd_next;
-        mu_p += stride_t; sd_p += stride_t;
-        if (t + 1 < N) { mu_next = *mu_p; sd_next = *sd_p; }
-        if (status == CST_STREAM_OK) {
-            // the reference panics on an invalid model (pybindings/stream/model.rs:654-657)
-            const bool model_ok = sd > 0.0 && sd <= 1.7976931348623157e308 && fabs(mu) <= 1.7976931348623157e308;
-            const uint32_t q = model_ok ? D.quantile(P) : 0u;
-            if (!model_ok) status = CST_STREAM_IMPOSSIBLE_SYMBOL;
-            else if (D.status != CST_STREAM_OK) status = D.status;
-            else {
-                // guess: ignore the leak (one quantile per symbol) first, then account for the guessed symbol's share of it
-                const float below = (float)q + 0.5f, above = total_f - below;
-                float z = ndtri_lower_f32(fminf(below, above) * inv_total_f);
-                double x = mu + sd * (double)(below < above ? z : -z) + guess_shift;
-                if (two_step_guess) {
-                    const float b1 = below - (float)fmin(fmax(x, 0.0), (double)(n - 1u)), a1 = free_f - b1;
-                    z = ndtri_lower_f32(fmaxf(fminf(b1, a1), 0.25f) * inv_free_f);
-                    x = mu + sd * (double)(b1 < a1 ? z : -z) + guess_shift;
-                }
-                const uint32_t g = (uint32_t)fmin(fmax(x, 1.0), (double)(n - 1u));
-                // bracket [lo_i, hi_i): left(lo_i) = lo_v <= q < hi_v = left(hi_i)
-                uint32_t lo_i = 0, hi_i = n, lo_v = 0, hi_v = P >= 32 ? 0u : (1u << P);
-                uint32_t probe = g, step = 1;
-                bool up = false, down = false;
-                while (hi_i - lo_i > 1) {
-                    const uint32_t v = leaky_gaussian_left<true>((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
-                    if (v <= q) { lo_i = probe; lo_v = v; up = true; } else { hi_i = probe; hi_v = v; down = true; }
-                    if (up && down) probe = lo_i + (hi_i - lo_i) / 2;
-                    else if (up) probe = min(lo_i + step, hi_i - 1u);
-                    else probe = max(hi_i - min(step, hi_i - 1u), lo_i + 1u);
-                    step *= 2;
-                }
-                const uint32_t c = lo_v, p = hi_v - lo_v;
-                if (p == 0 || c > q || (uint64_t)c + p > ((uint64_t)1 << P)) status = CST_STREAM_IMPOSSIBLE_SYMBOL;   // degenerate distribution (quantize.rs:562-565)
+
+    // ---- parameter tiles: item w = it * 64 + lane of a tile is (stream j, symbol tl), consecutive lanes on consecutive
+    // addresses in either layout ----
+    double mu_r[kParTile], sd_r[kParTile];
+    auto par_request = [&](size_t t0) {
+#pragma unroll
+        for (int it = 0; it < kParTile; ++it) {
+            const int w = it * kWave + lane;
+            const size_t j = symbol_major ? w % kWave : w / kParTile, tl = symbol_major ? w / kWave : w % kParTile;
+            // (idle lanes of a partial wave repeat its last stream -- with that stream's parameters: the chain coder's lanes
+            // write their remainders as they go)
+            const size_t sj = s0 + j < a.n_streams ? s0 + j : a.n_streams - 1;
+            const size_t e = t0 + tl < N ? (symbol_major ? (t0 + tl) * a.n_streams + sj : sj * N + t0 + tl) : 0;
+            mu_r[it] = __builtin_nontemporal_load(a.means + e);
+            sd_r[it] = __builtin_nontemporal_load(a.stds + e);
+        }
+    };
+    auto par_land = [&]() {
+#pragma unroll
+        for (int it = 0; it < kParTile; ++it) {
+            const int w = it * kWave + lane;
+            const int j = symbol_major ? w % kWave : w / kParTile, tl = symbol_major ? w / kWave : w % kParTile;
+            par_mu[tl * kParStride + j] = mu_r[it];
+            par_sd[tl * kParStride + j] = sd_r[it];
+        }
+    };
+    // ---- word window: a tile of 16 symbols takes at most 16 words, so with the 16 words behind the read position in
+    // LDS at the start of a tile the NEXT 16 can be on their way during it ----
+    uint32_t w_r[kParTile];
+    int64_t w_first = 0;                                      // index of w_r[0]
+    auto win_request = [&](int64_t first) {
+        w_first = first;
+        const int64_t len = (int64_t)D.length();
+#pragma unroll
+        for (int i = 0; i < kParTile; ++i) {
+            const int64_t p = first + i;
+            w_r[i] = *(p >= 0 && p < len ? D.in + p : D.idle);
+        }
+    };
+    auto win_land = [&]() {
+#pragma unroll
+        for (int i = 0; i < kParTile; ++i) win[(((uint32_t)(w_first + i)) & (kWordWindow - 1)) * kWave + lane] = w_r[i];
+    };
+    const auto window_of = [&](int ahead_tiles) -> int64_t {  // first index of the 16 words `ahead_tiles` tiles ahead
+        return D.kDownward ? (int64_t)D.position() - (int64_t)kParTile * (ahead_tiles + 1) : (int64_t)D.position() + (int64_t)kParTile * ahead_tiles;
+    };
+
+    if (N > 0) {
+        par_request(0);
+        win_request(window_of(0));
+    }
+    for (size_t t0 = 0; t0 < N; t0 += kParTile) {
+        wave_lds_fence();                                     // (the previous tile's parameters have been read)
+        par_land();
+        win_land();
+        if (t0 + kParTile < N) par_request(t0 + kParTile);
+        win_request(window_of(1));                            // (the words one tile further: used from the next tile on)
+        wave_lds_fence();
+        const int n_here = (int)(N - t0 < (size_t)kParTile ? N - t0 : (size_t)kParTile);
+#pragma unroll 1
+        for (int tl = 0; tl < n_here; ++tl) {
+            const size_t t = t0 + (size_t)tl;
+            int32_t sym = 0;
+            const double mu = par_mu[tl * kParStride + lane], sd = par_sd[tl * kParStride + lane];
+            D.ahead = win[(((uint32_t)D.next_index()) & (kWordWindow - 1)) * kWave + lane];
+            if (status == CST_STREAM_OK) {
+                // the reference panics on an invalid model (pybindings/stream/model.rs:654-657)
+                const bool model_ok = sd > 0.0 && sd <= 1.7976931348623157e308 && fabs(mu) <= 1.7976931348623157e308;
+                const uint32_t q = model_ok ? D.quantile(P) : 0u;
+                if (!model_ok) status = CST_STREAM_IMPOSSIBLE_SYMBOL;
+                else if (D.status != CST_STREAM_OK) status = D.status;
                 else {
-                    sym = a.min_symbol + (int32_t)lo_i;
-                    D.advance(q, c, p, P);
+                    // guess: ignore the leak (one quantile per symbol) first, then account for the guessed symbol's share of it
+                    const float below = (float)q + 0.5f, above = total_f - below;
+                    float z = ndtri_lower_f32(fminf(below, above) * inv_total_f);
+                    double x = mu + sd * (double)(below < above ? z : -z) + guess_shift;
+                    if (two_step_guess) {
+                        const float b1 = below - (float)fmin(fmax(x, 0.0), (double)(n - 1u)), a1 = free_f - b1;
+                        z = ndtri_lower_f32(fmaxf(fminf(b1, a1), 0.25f) * inv_free_f);
+                        x = mu + sd * (double)(b1 < a1 ? z : -z) + guess_shift;
+                    }
+                    const uint32_t g = (uint32_t)fmin(fmax(x, 1.0), (double)(n - 1u));
+                    // bracket [lo_i, hi_i): left(lo_i) = lo_v <= q < hi_v = left(hi_i)
+                    uint32_t lo_i = 0, hi_i = n, lo_v = 0, hi_v = P >= 32 ? 0u : (1u << P);
+                    uint32_t probe = g, step = 1;
+                    bool up = false, down = false;
+                    while (hi_i - lo_i > 1) {
+                        const uint32_t v = leaky_gaussian_left_quick((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
+                        if (v <= q) { lo_i = probe; lo_v = v; up = true; } else { hi_i = probe; hi_v = v; down = true; }
+                        if (up && down) probe = lo_i + (hi_i - lo_i) / 2;
+                        else if (up) probe = min(lo_i + step, hi_i - 1u);
+                        else probe = max(hi_i - min(step, hi_i - 1u), lo_i + 1u);
+                        step *= 2;
+                    }
+                    const uint32_t c = lo_v, p = hi_v - lo_v;
+                    if (p == 0 || c > q || (uint64_t)c + p > ((uint64_t)1 << P)) status = CST_STREAM_IMPOSSIBLE_SYMBOL;   // degenerate distribution (quantize.rs:562-565)
+                    else {
+                        sym = a.min_symbol + (int32_t)lo_i;
+                        D.advance(q, c, p, P);
+                    }
                 }
             }
-        }
-        D.look_ahead();
-        if (symbol_major) {
-            if (active) *sym_p = sym;
-            sym_p += stride_t;
-        } else {
-            tile[lane * kTileStride + (t % kTileSyms)] = sym;
-            if (t % kTileSyms == kTileSyms - 1) {
-                wave_lds_fence();
-                store_symbol_tile(a.symbols, a.n_streams, N, s0, t - (kTileSyms - 1), lane, tile, vec);
-                wave_lds_fence();
+            if (symbol_major) {
+                if (active) *sym_p = sym;
+                sym_p += stride_t;
+            } else {
+                tile[lane * kTileStride + (t % kTileSyms)] = sym;
+                if (t % kTileSyms == kTileSyms - 1) {
+                    wave_lds_fence();
+                    store_symbol_tile(a.symbols, a.n_streams, N, s0, t - (kTileSyms - 1), lane, tile, vec);
+                    wave_lds_fence();
+                }
             }
         }
     }
@@ -656,7 +925,7 @@ __global__ __launch_bounds__(kRowEntries) void gaussian_rows_kernel(int P, int32
     const uint32_t total = 1u << P;
     uint32_t v;
     if (sd > 0.0 && sd <= 1.7976931348623157e308 && fabs(mu) <= 1.7976931348623157e308)
-        v = i <= n ? leaky_gaussian_left<true>(i, lo, n, P, 32, mu, sd, erf_tab) : total;
+        v = i <= n ? leaky_gaussian_left_quick(i, lo, n, P, 32, mu, sd, erf_tab) : total;
     else v = i == 0 ? 0xffffffffu : total;             // invalid model (a valid row starts with 0)
     rows[row * kRowEntries + i] = v;
 }
@@ -876,7 +1145,7 @@ __global__ __launch_bounds__(kBlock) void chain_lookup_kernel(const PerSymbolDec
             uint32_t probe = (uint32_t)fmin(fmax(x, 1.0), (double)(n - 1u)), step = 1;
             bool up = false, down = false;
             while (hi_i - lo_i > 1) {
-                const uint32_t v = leaky_gaussian_left<true>((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
+                const uint32_t v = leaky_gaussian_left_quick((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
                 if (v <= q) { lo_i = probe; lo_v = v; up = true; } else { hi_i = probe; hi_v = v; down = true; }
                 if (up && down) probe = lo_i + (hi_i - lo_i) / 2;
                 else if (up) probe = min(lo_i + step, hi_i - 1u);
@@ -1022,6 +1291,43 @@ static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t
     return st;
 }
 
+// The fused kernel pays one coder step per kFuStreams-stream wave and symbol whatever the batch; the two-pass form runs its
+// entry pass on the whole chip however few streams there are.  From 16 384 streams on (512 waves of 32 streams: two
+// for every SIMD pair) the fused kernel is the faster one; below, and for the one long stream of the drop-in API, two passes.
+// (CST_FUSED_MIN_STREAMS in the environment moves the threshold: the parity tests run the fused kernel on small batches.)
+static bool fused_encode_usable(size_t n_streams, size_t n_per_stream) {
+    size_t min_streams = 16384;
+    if (const char* env = getenv("CST_FUSED_MIN_STREAMS")) min_streams = (size_t)strtoull(env, nullptr, 10);
+    return n_streams >= min_streams && n_per_stream >= 1;
+}
+
+template <int KIND>
+static cst_status encode_gaussian_fused(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                        const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                                        uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
+                                        cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, hipStream_t hs) {
+    if (cst_status st = check_common(cfg, layout)) return st;
+    if (!d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_RAW_STATE) && (KIND == kAns ? (void*)d_state : (void*)d_rstate) == nullptr) return CST_ERR_INVALID_ARGUMENT;
+    GaussianFusedArgs a{};
+    a.symbols = d_symbols; a.means = d_means; a.stds = d_stds; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.layout = layout; a.precision = cfg.precision; a.lo = min_symbol; a.hi = max_symbol;
+    a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.rstate = d_rstate;
+    a.status = d_status; a.flags = flags;
+    const size_t per_block = (size_t)(kFuBlock / kWave) * kFuStreams;
+    const size_t blocks = (n_streams + per_block - 1) / per_block;
+    const size_t lds = kFuTabBytes + (size_t)(kFuBlock / kWave) * kFuWaveBytes;
+    if (cfg.word_bits == 32) {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_gaussian_fused_kernel<32, 64, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((encode_gaussian_fused_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kFuBlock), lds, hs, a);
+    } else {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_gaussian_fused_kernel<16, 32, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((encode_gaussian_fused_kernel<16, 32, KIND>), dim3((unsigned)blocks), dim3(kFuBlock), lds, hs, a);
+    }
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 // few streams: cdf rows at full occupancy, then a lookup per symbol; in pieces of at most 64 MiB of rows
 template <int KIND>
 static cst_status decode_gaussian_by_rows(cst_coder_config cfg, const PerSymbolDecodeArgs& a, hipStream_t hs) {
@@ -1080,8 +1386,13 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
         return decode_chains_in_three(cfg, a, gaussian, hs);
     if (gaussian && a.n_streams >= (size_t)kWave) {      // enough streams to give every lane its own
         const size_t lane_blocks = (a.n_streams + kBlock - 1) / kBlock;
-        if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
-        else hipLaunchKernelGGL((decode_gaussian_lane_kernel<16, 32, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), 0, hs, a);
+        if (cfg.word_bits == 32) {
+            CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gaussian_lane_kernel<32, 64, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLaneDecLdsBytes));
+            hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), kLaneDecLdsBytes, hs, a);
+        } else {
+            CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gaussian_lane_kernel<16, 32, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLaneDecLdsBytes));
+            hipLaunchKernelGGL((decode_gaussian_lane_kernel<16, 32, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), kLaneDecLdsBytes, hs, a);
+        }
     } else if (KIND != kChain && gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
         if constexpr (KIND != kChain) return decode_gaussian_by_rows<KIND>(cfg, a, hs);
     } else if (gaussian) {
@@ -1192,6 +1503,9 @@ cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
     if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
     if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
     hipStream_t hs = (hipStream_t)stream;
+    if (fused_encode_usable(n_streams, n_per_stream))
+        return encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words,
+                                           stride_words, d_n_words, d_state, nullptr, d_status, flags, hs);
     return encode_two_pass<kAns>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, nullptr,
                                  d_status, flags, hs, [&](EncEntry* out, size_t n) {
         hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
@@ -1206,6 +1520,9 @@ cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_sym
     if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
     if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
     hipStream_t hs = (hipStream_t)stream;
+    if (fused_encode_usable(n_streams, n_per_stream))
+        return encode_gaussian_fused<kRange>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words,
+                                             stride_words, d_n_words, nullptr, d_rstate, d_status, flags, hs);
     return encode_two_pass<kRange>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, nullptr, d_rstate,
                                    d_status, flags, hs, [&](EncEntry* out, size_t n) {
         hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,

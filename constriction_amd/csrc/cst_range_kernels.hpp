@@ -115,13 +115,13 @@ struct RingReaderFwd {
     __device__ __forceinline__ uint32_t word_direct(uint32_t i) const { return base16[shift + i]; }
 };
 
-template <int W, int S>
+template <int W, int S, int SLOTS = kRingSlots>
 struct RangeEncLane {
     using st_t = typename StateT<S>::type;
     st_t lower, range;
     uint32_t inv_n, inv_first;   // EncoderSituation: inv_n == 0 <=> Normal
     uint32_t bad;
-    RingWriter<> out;
+    RingWriter<SLOTS> out;
 
     __device__ __forceinline__ void init(uint32_t* slab, uint32_t capacity, uint32_t* wave_ring, int lane_) {
         out.init(slab, capacity, wave_ring, lane_);

@@ -466,6 +466,15 @@ cst_status cst_release_scratch(void);
 cst_status cst_debug_erf(const double *d_x, double *d_out, size_t n, void *stream);
 /* the same erf as the per-symbol kernels evaluate it (one Horner recurrence over per-lane coefficients from LDS) */
 cst_status cst_debug_erf_tab(const double *d_x, double *d_out, size_t n, void *stream);
+/* The per-symbol kernels evaluate the Gaussian left cumulative through a FAST erf and fall back to the bit-exact one
+ * wherever free_weight * cdf lies so close to an integer that the difference could change the truncation (cst_math.hpp);
+ * the integer is the reference's in every case.  Hooks: which = 0: out[i] = fast erf(x[i]); 1: |fast - exact|. */
+cst_status cst_debug_erf_fast(int32_t which, const double *d_x, double *d_out, size_t n, void *stream);
+/* left cumulative of symbol index d_index[i] (0 .. n_symbols) under Gaussian(d_means[i], d_stds[i]) both ways:
+ * d_counts[0] += results that differ (must stay 0), d_counts[1] += exact fallbacks taken (caller zeroes d_counts). */
+cst_status cst_debug_gaussian_left_quick(int32_t precision, int32_t min_symbol, int32_t max_symbol, const int32_t *d_index,
+                                         const double *d_means, const double *d_stds, size_t n, uint64_t *d_counts,
+                                         void *stream);
 cst_status cst_debug_gaussian_lcp(int32_t precision, int32_t prob_bits, int32_t min_symbol, int32_t max_symbol,
                                   const int32_t *d_symbols, const double *d_means, const double *d_stds,
                                   uint32_t *d_left, uint32_t *d_prob, size_t n, void *stream);

@@ -54,6 +54,92 @@ def test_device_erf_bit_exact(B, O):
         assert same.all(), f"{fn}: {(~same).sum()} of {len(x)} erf values differ, first at x={x[~same][0]!r}"
 
 
+def test_fast_erf_error_bound(B, O):
+    """The per-symbol kernels evaluate erf the cheap way first (cst_math.hpp: erf_fast_tab) and rely on
+    |fast - exact| <= 2^-46 to decide where the exact evaluation is needed.  Measured here on 6 M arguments over every branch,
+    the branch boundaries and the special values: the real deviation is a few 1e-16."""
+    from constriction_amd import _native as N
+    rng = np.random.default_rng(2)
+    edges = np.array([0.0, 2.0 ** -28, 0.84375, 1.25, 2.857142857142857, 6.0, 5.999999, 27.0, 1e-300, 5e-324, 1e300])
+    x = np.concatenate([rng.uniform(-6.5, 6.5, 3_000_000), rng.normal(0, 1.5, 2_000_000), rng.uniform(0.8, 1.3, 500_000) * rng.choice([-1, 1], 500_000),
+                        10.0 ** rng.uniform(-320, 2, 250_000), -(10.0 ** rng.uniform(-320, 2, 250_000)),
+                        edges, -edges, np.nextafter(edges, np.inf), np.nextafter(edges, -np.inf), [np.inf, -np.inf]])
+    dx = dev(x)
+    out = torch.empty_like(dx)
+    N.check(N.lib().cst_debug_erf_fast(1, dx.data_ptr(), out.data_ptr(), dx.numel(), None), "cst_debug_erf_fast")
+    torch.cuda.synchronize()
+    err = out.cpu().numpy()
+    assert np.isfinite(err).all()
+    worst = float(err.max())
+    assert worst <= 2.0 ** -46, f"fast erf deviates by {worst:.3e} at x = {x[int(err.argmax())]!r}"
+    assert worst < 1e-14                                     # (in practice ~5e-16: an order of magnitude of room and more)
+    nan = dev(np.array([np.nan]))
+    o1 = torch.empty_like(nan)
+    N.check(N.lib().cst_debug_erf_fast(0, nan.data_ptr(), o1.data_ptr(), 1, None), "cst_debug_erf_fast")
+    torch.cuda.synchronize()
+    assert np.isnan(o1.cpu().numpy()[0])
+
+
+def test_quick_left_cumulatives_equal_the_exact_ones(B, O):
+    """leaky_gaussian_left_quick (fast erf + exact fallback next to integers) against leaky_gaussian_left on the device:
+    40 M random evaluations over four supports and scales from needle-thin to huge -- no difference; the fallback is taken
+    about twice in a million -- and 20 000 CRAFTED cases whose free_weight * cdf lies within 1e-9 ... 1e-6 of an integer
+    (found by bisection on the oracle's cdf), where the fast value alone would truncate wrongly about every other time."""
+    from constriction_amd import _native as N
+    lib = N.lib()
+    rng = np.random.default_rng(3)
+    total = fallbacks = 0
+    for lo, hi, P in ((-100, 100, 24), (-127, 127, 12), (-3000, 3000, 24), (0, 1, 24), (-50, 50, 16)):
+        n = 8_000_000
+        mu = rng.uniform(lo - 20, hi + 20, n)
+        sd = np.exp(rng.uniform(-3, 6, n))
+        # half of the indices anywhere in the support (mostly where the cdf saturates), half next to the mean (what a coder asks for)
+        near = np.clip(np.rint(mu + sd * rng.standard_normal(n)) - lo + rng.integers(0, 2, n), 0, hi - lo + 1)
+        idx = np.where(rng.random(n) < 0.5, rng.integers(0, hi - lo + 2, n), near).astype(np.int32)
+        counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+        d_idx, d_mu, d_sd = dev(idx), dev(mu), dev(sd)
+        N.check(lib.cst_debug_gaussian_left_quick(P, lo, hi, d_idx.data_ptr(), d_mu.data_ptr(), d_sd.data_ptr(), n, counts.data_ptr(), None), "quick")
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy()
+        assert c[0] == 0, (lo, hi, P, int(c[0]))
+        total += n
+        fallbacks += int(c[1])
+    assert 0 < fallbacks < total * 2e-5, (fallbacks, total)
+    # crafted: mu such that free_weight * cdf(x; mu, sd) sits next to an integer k
+    ol = O.load()
+    lo, hi, P = -100, 100, 24
+    fw = float(((1 << P) - 1) - (hi - lo))
+    m = 20000
+    idx = rng.integers(1, hi - lo + 1, m).astype(np.int32)
+    sd = np.exp(rng.uniform(-1, 4, m))
+    mus = np.empty(m)
+    for j in range(m):
+        x = float(lo + int(idx[j])) - 0.5
+        target = (float(rng.integers(1000, (1 << P) - 1000)) + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-9, -6)) / fw
+        a, b = x - 12 * sd[j], x + 12 * sd[j]            # cdf(x; mu) decreases in mu
+        for _ in range(70):
+            mid = 0.5 * (a + b)
+            if ol.cst_oracle_gaussian_cdf(x, mid, float(sd[j])) > target:
+                a = mid
+            else:
+                b = mid
+        mus[j] = a
+    counts = torch.zeros(2, dtype=torch.int64, device="cuda")
+    d_idx, d_mu, d_sd = dev(idx), dev(mus), dev(sd)
+    N.check(lib.cst_debug_gaussian_left_quick(P, lo, hi, d_idx.data_ptr(), d_mu.data_ptr(), d_sd.data_ptr(), m, counts.data_ptr(), None), "quick")
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy()
+    assert c[0] == 0 and c[1] > m // 2, c.tolist()      # (most crafted cases must have taken the exact path)
+    want = np.array([O.GaussianModel(lo, hi, float(mus[j]), float(sd[j]), P, 32).lcp(lo + int(idx[j]))[0] for j in range(0, m, 50)])
+    l = torch.empty(len(want), dtype=torch.int32, device="cuda")
+    p = torch.empty_like(l)
+    sym = dev((lo + idx[::50]).astype(np.int32))
+    N.check(lib.cst_debug_gaussian_lcp(P, 32, lo, hi, sym.data_ptr(), dev(mus[::50]).data_ptr(), dev(sd[::50]).data_ptr(), l.data_ptr(), p.data_ptr(),
+                                       len(want), None), "lcp")
+    torch.cuda.synchronize()
+    assert np.array_equal(l.cpu().numpy().view(np.uint32), want.astype(np.uint32))
+
+
 @pytest.mark.parametrize("lo,hi,P,prob_bits", [(-100, 100, 24, 32), (-50, 50, 12, 16), (-127, 127, 12, 16), (0, 1, 1, 16),
                                                (-2000, 2000, 16, 16), (-30000, 30000, 24, 32)])
 def test_device_gaussian_lcp_bit_exact(B, O, lo, hi, P, prob_bits):

@@ -40,7 +40,11 @@ def workload(n_streams, n_per, lo, hi, seed):
 @pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
 @pytest.mark.parametrize("n_streams,n_per", [(1, 300), (65, 40), (1000, 21)])
 @pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
-def test_gaussian_per_symbol_batch_parity(B, O, coder, cfg, n_streams, n_per, layout):
+@pytest.mark.parametrize("encoder", ["two_pass", "fused"])
+def test_gaussian_per_symbol_batch_parity(B, O, coder, cfg, n_streams, n_per, layout, encoder, monkeypatch):
+    # batches of >= 16 384 streams take the fused encoder kernel (entries computed and coded in one kernel, nothing but inputs
+    # and words in HBM); CST_FUSED_MIN_STREAMS moves that threshold so that the small parity shapes run it too
+    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1" if encoder == "fused" else "1000000000")
     W, S, P = cfg
     lo, hi = (-100, 100) if P == 24 else (-60, 60)
     sym, mu, sd = workload(n_streams, n_per, lo, hi, n_streams * 13 + n_per + P)
