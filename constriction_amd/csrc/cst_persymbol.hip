@@ -858,7 +858,11 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
                         z = ndtri_lower_f32(fmaxf(fminf(b1, a1), 0.25f) * inv_free_f);
                         x = mu + sd * (double)(b1 < a1 ? z : -z) + guess_shift;
                     }
-                    const uint32_t g = (uint32_t)fmin(fmax(x, 1.0), (double)(n - 1u));
+                    // first probe: the bin BOUNDARY nearest to the guess (boundary i lies at x = i) -- whichever side of it the
+                    // quantile falls, the second probe closes the bracket as long as the guess is within half a symbol; probing
+                    // floor(x) first cost a third evaluation whenever the guess was a hair low, and a wave runs as many
+                    // evaluations as its worst lane
+                    const uint32_t g = (uint32_t)fmin(fmax(x + 0.5, 1.0), (double)(n - 1u));
                     // bracket [lo_i, hi_i): left(lo_i) = lo_v <= q < hi_v = left(hi_i)
                     uint32_t lo_i = 0, hi_i = n, lo_v = 0, hi_v = P >= 32 ? 0u : (1u << P);
                     uint32_t probe = g, step = 1;
