@@ -318,7 +318,7 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
-    if (cfg.word_bits == 32 && range_encode_fast_usable(a, layout)) return range_encode_fast(a, hs);
+    if (cfg.word_bits == 32 && range_encode_fast_usable(a, layout)) return range_encode_fast(a, layout, hs);
     if (cfg.word_bits == 32) return range_encode_ws<32, 64>(a, layout, hs);
     return range_encode_ws<16, 32>(a, layout, hs);
 }
@@ -341,7 +341,7 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
-    if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, hs);
+    if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, layout, hs);
     if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
     return range_decode_ws<16, 32>(a, layout, hs);
 }

@@ -1,4 +1,4 @@
-// cst_range_fast.hip -- the hand-scheduled (32,64) range coder kernels (BASELINE config C4), 8 <= P <= 24, stream-major.
+// cst_range_fast.hip -- the hand-scheduled (32,64) range coder kernels (BASELINE config C4), 8 <= P <= 24, both symbol layouts.
 //
 // Encoder: the lazy carry of RangeEncoder::encode_symbol (src/stream/queue.rs:612-705, EncoderSituation :126-142) in its
 // "held word" form.  The reference holds back the words of an Inverted situation until it knows whether a carry
@@ -89,24 +89,30 @@ struct RangeEncHeld {
     }
 };
 
-template <int FLUSHES>
+template <int FLUSHES, bool SM>
 __device__ __forceinline__ void range_encode_tiles_loop(uint32_t& lo0, uint32_t& lo1, uint32_t& rg0, uint32_t& rg1, uint32_t& lw,
                                                         uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax, uint32_t& slow,
                                                         const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
                                                         uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off,
                                                         uint32_t table_addr_biased, uint32_t P, const void* words_base,
-                                                        uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
-    if constexpr (FLUSHES == 1) {
+                                                        uint64_t symbols_base, uint32_t n_tiles, [[maybe_unused]] uint32_t tile_step_bytes,
+                                                        const uint32_t (&goff)[8]) {
+    if constexpr (FLUSHES == 1 && !SM) {
 #include "cst_range_encode_loop.inc"
-    } else {
+    } else if constexpr (FLUSHES == 1) {
+#include "cst_range_encode_loop_sm.inc"
+    } else if constexpr (!SM) {
 #include "cst_range_encode_loop_2f.inc"
+    } else {
+#include "cst_range_encode_loop_2f_sm.inc"
     }
 }
 
 constexpr size_t kFastRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
 constexpr size_t kFastTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;
 
-template <int FLUSHES>
+// SM: symbols[t][stream] (CST_LAYOUT_SYMBOL_MAJOR); the launch makes sure that every wave is full and that rows are 16-byte aligned
+template <int FLUSHES, bool SM>
 __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -146,20 +152,25 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
             const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            for (int k = 0; k < 8; ++k)
+                goff[k] = SM ? (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4)
+                             : (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(SM ? a.symbols + s0 : a.symbols + s0 * N);
             const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            // where a lane's loaded registers go in the tile (tile[stream][t], stride kTileStride): see the generators
+            const uint32_t tr_off = SM ? (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4)
+                                       : (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
             const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
             const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
             uint32_t lo0 = 0, lo1 = 0, rg0 = 0xffffffffu, rg1 = 0xffffffffu, lw = 0, wr = 0xffffffffu, flushed = 0, slow = 0;
             int32_t smin = a.min_symbol, smax = a.min_symbol;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-            range_encode_tiles_loop<FLUSHES>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, row_addr, tr_addr, L.out.lane_addr, cap,
-                                             (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
-                                             symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            range_encode_tiles_loop<FLUSHES, SM>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, row_addr, tr_addr, L.out.lane_addr, cap,
+                                                 (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
+                                                 symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
             if (__builtin_amdgcn_readfirstlane(slow) == 0) {
                 L.lower = ((uint64_t)lo1 << 32) | lo0; L.range = ((uint64_t)rg1 << 32) | rg0; L.lw = lw;
                 L.out.wr = wr; L.out.flushed = flushed;
@@ -171,24 +182,35 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
     }
     if (!done) {
         // partial waves, odd slabs, and streams whose carry had to travel: tile by tile with the C++ step
-        int32_t r[kTileSyms];
-        for (size_t tb = 0; tb < n_full; ++tb) {
-            tile_fetch<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, r);
-            wave_lds_fence();
-            tile_to_lds<true>(tile, lane, r);
-            wave_lds_fence();
-            const int32_t* my = tile + min((size_t)lane, a.n_streams - 1 - s0) * kTileStride;   // (repeating lanes read the last stream's row)
-#pragma unroll 8
-            for (int j = 0; j < kTileSyms; ++j) {
-                const CumProb e = table[enc_index(my[j], a.min_symbol, nsym, L.bad)];
+        if constexpr (SM) {
+            // (rare: a carry had to travel) lane-coalesced reads, one symbol row at a time
+            const int32_t* col = a.symbols + se;
+            for (size_t t = 0; t < n_full * kTileSyms; ++t) {
+                const CumProb e = table[enc_index(col[t * a.n_streams], a.min_symbol, nsym, L.bad)];
                 L.step(e.c, e.p, P);
-                if ((j & 7) == 7) L.flush();
+                if ((t & 7) == 7) L.flush();
+            }
+        } else {
+            int32_t r[kTileSyms];
+            for (size_t tb = 0; tb < n_full; ++tb) {
+                tile_fetch<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, r);
+                wave_lds_fence();
+                tile_to_lds<true>(tile, lane, r);
+                wave_lds_fence();
+                const int32_t* my = tile + min((size_t)lane, a.n_streams - 1 - s0) * kTileStride;   // (repeating lanes read the last stream's row)
+#pragma unroll 8
+                for (int j = 0; j < kTileSyms; ++j) {
+                    const CumProb e = table[enc_index(my[j], a.min_symbol, nsym, L.bad)];
+                    L.step(e.c, e.p, P);
+                    if ((j & 7) == 7) L.flush();
+                }
             }
         }
     }
-    const int32_t* row = a.symbols + se * N;
+    const int32_t* row = SM ? a.symbols + se : a.symbols + se * N;
+    const size_t row_step = SM ? a.n_streams : 1;
     for (size_t t = n_full * kTileSyms; t < N; ++t) {
-        const CumProb e = table[enc_index(row[t], a.min_symbol, nsym, L.bad)];
+        const CumProb e = table[enc_index(row[t * row_step], a.min_symbol, nsym, L.bad)];
         L.step(e.c, e.p, P);
         L.flush();
     }
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
 constexpr int kRdSlots = kDecRingSlots, kRdAhead = kDecAhead;
 constexpr size_t kRdRingBytes = (size_t)(kBlock / kWave) * kRdSlots * kWave * 4;
 
-template <bool ENDS, bool B16>
+template <bool ENDS, bool B16, bool SM>
 __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& x1, uint32_t& rg0, uint32_t& rg1, uint32_t& pos,
                                                         uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
                                                         uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
@@ -214,8 +236,19 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
                                                         const void* words_base, uint32_t delta_hi, uint64_t store_base, uint32_t goff_stride,
                                                         uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                         uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t bucket_shift,
-                                                        uint32_t cdf_addr, int32_t min_symbol, bool plain_stores) {
-    if constexpr (B16 && ENDS) {
+                                                        uint32_t cdf_addr, int32_t min_symbol, [[maybe_unused]] uint32_t tile_step_bytes,
+                                                        bool plain_stores) {
+    if constexpr (B16 && ENDS && SM) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_b16_ends_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16_ends_sm.inc"
+#undef CST_STORE_MOD
+    }
+    } else if constexpr (B16 && ENDS) {
     if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
 #define CST_STORE_MOD ""
 #include "cst_range_decode_loop_b16_ends.inc"
@@ -223,6 +256,16 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
     } else {
 #define CST_STORE_MOD "nt"
 #include "cst_range_decode_loop_b16_ends.inc"
+#undef CST_STORE_MOD
+    }
+    } else if constexpr (B16 && SM) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_b16_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16_sm.inc"
 #undef CST_STORE_MOD
     }
     } else if constexpr (B16) {
@@ -235,6 +278,16 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
 #include "cst_range_decode_loop_b16.inc"
 #undef CST_STORE_MOD
     }
+    } else if constexpr (ENDS && SM) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_ends_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_ends_sm.inc"
+#undef CST_STORE_MOD
+    }
     } else if constexpr (ENDS) {
     if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
 #define CST_STORE_MOD ""
@@ -243,6 +296,16 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
     } else {
 #define CST_STORE_MOD "nt"
 #include "cst_range_decode_loop_ends.inc"
+#undef CST_STORE_MOD
+    }
+    } else if constexpr (SM) {
+    if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_sm.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_sm.inc"
 #undef CST_STORE_MOD
     }
     } else {
@@ -263,7 +326,8 @@ static size_t b16_tables_bytes(int n_symbols, int bucket_bits) {
 }
 
 // B16: 12 < P <= 24, at most 256 symbols: the lookup is one 16-byte bucket entry (DecLut::b16) instead of the quantile table
-template <bool B16>
+// SM: symbols[t][stream] (CST_LAYOUT_SYMBOL_MAJOR); the launch makes sure that every wave is full and that rows are 16-byte aligned
+template <bool B16, bool SM>
 __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -342,43 +406,48 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
         if (n_full > 0 && N < (1u << 24) && !__any(!off_ok)) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statements keep their own book from here
             const uint32_t shift = L.in.shift;
-            const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint32_t goff_limit = SM ? 0xffffffffu : (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
             uint32_t x0 = (uint32_t)L.point, x1 = (uint32_t)(L.point >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
             uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
             const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
-            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            const uint32_t tr_off = SM ? (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4)
+                                       : (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             uint32_t row_cur = lds_addr(tile + lane * kTileStride), row_prev = lds_addr(tile_b + lane * kTileStride);
             uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
             uint32_t tiles = (uint32_t)n_full, ginc = 0, bad = 0, bad2 = 0;
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(SM ? a.symbols + s0 : a.symbols + s0 * N);
+            const uint32_t tile_step = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SM ? kTileSyms * a.n_streams * 4 : kTileSyms * 4));
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
             // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
-            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
-            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint32_t goff_stride = (uint32_t)(8 * N * 4);
+            // (symbol-major: 64-byte pieces of rows of n_streams symbols, line-aligned iff the rows are)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((((SM ? a.n_streams : N) * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
+            const uint32_t goff0 = SM ? (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4)
+                                      : (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint32_t goff_stride = SM ? (uint32_t)(16 * a.n_streams * 4) : (uint32_t)(8 * N * 4);
             const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
             // the estimate's error is 2^(P - 48.5): the bias on top of it (high word of the f64)
             const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22
             const uint32_t lut_addr = B16 ? lds_addr(blut.b16) : lds_addr(lut);
             const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
-            range_decode_tiles_loop<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
-                                                qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
-                                                lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                cdf_addr, a.min_symbol, plain_stores);
+            range_decode_tiles_loop<false, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
+                                                    qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
+                                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
+                                                    cdf_addr, a.min_symbol, tile_step, plain_stores);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
-                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
-                range_decode_tiles_loop<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
-                                                   lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
-                                                   lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                   cdf_addr, a.min_symbol, plain_stores);
+                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * tile_step : 0);
+                range_decode_tiles_loop<true, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
+                                                       lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
+                                                       lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
+                                                       cdf_addr, a.min_symbol, tile_step, plain_stores);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
                 // the last tile is still in LDS (buffer A if it has an even index)
                 wave_lds_fence();
-                tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                if constexpr (SM) tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                else tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
                 wave_lds_fence();
                 L.lower = 0; L.point = ((uint64_t)x1 << 32) | x0; L.range = ((uint64_t)rg1 << 32) | rg0;
                 L.in.pos = pos - shift; L.in.hi_issued = hi_issued;
@@ -401,13 +470,15 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             L.in.advance_window();
         }
         wave_lds_fence();
-        tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
+        if constexpr (SM) tile_store_sm(a.symbols, a.n_streams, s0, tb * kTileSyms, lane, tile);
+        else tile_store<true>(a.symbols, a.n_streams, N, s0, tb * kTileSyms, lane, tile);
         wave_lds_fence();
     }
-    int32_t* row = a.symbols + (active ? s : 0) * N;
+    int32_t* row = SM ? a.symbols + (active ? s : 0) : a.symbols + (active ? s : 0) * N;
+    const size_t row_step = SM ? a.n_streams : 1;
     for (size_t t = n_full * kTileSyms; t < N; ++t) {
         const int32_t sym = step();
-        if (active) row[t] = sym;
+        if (active) row[t * row_step] = sym;
         L.in.advance_window();
     }
     if (!active) return;
@@ -419,14 +490,19 @@ static size_t range_decode_fast_lds(const RangeDecodeArgs& a) {
     return kRdRingBytes + tables + 2 * kFastTileBytes + (size_t)(kBlock / kWave) * 4 * kWave * 4;
 }
 
+// symbol-major batches take the same statements with another staging (scripts/gen_range_*_loop.py, SYMBOL_MAJOR): full waves,
+// whole quads of streams per 16-byte piece, 32-bit offsets inside a tile of 32 symbol rows
+static bool symbol_major_ok(size_t n_streams) { return n_streams % kWave == 0 && n_streams < (1u << 24); }
+
 bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout) {
     const bool table = a.precision >= 8 && a.precision <= 12 && a.dec_cp && a.dec_idx;
     const bool entries = a.precision > 12 && a.precision <= 24 && bucket16_usable(a.n_symbols, a.precision) && a.cdf && a.bucket;
-    return layout == CST_LAYOUT_STREAM_MAJOR && (table || entries) && !(a.flags & CST_FLAG_RAW_STATE) && a.n_per_stream % 4 == 0 &&
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR && !symbol_major_ok(a.n_streams)) return false;
+    return (table || entries) && !(a.flags & CST_FLAG_RAW_STATE) && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && range_decode_fast_lds(a) <= 160 * 1024;
 }
 
-cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs) {
+cst_status range_decode_fast(const RangeDecodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t lds = range_decode_fast_lds(a);
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
@@ -436,19 +512,21 @@ cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs) {
         CST_HIP_TRY(hipGetLastError());
         return CST_OK;
     };
-    return a.precision <= 12 ? go(range_decode_fast_kernel<false>) : go(range_decode_fast_kernel<true>);
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return a.precision <= 12 ? go(range_decode_fast_kernel<false, true>) : go(range_decode_fast_kernel<true, true>);
+    return a.precision <= 12 ? go(range_decode_fast_kernel<false, false>) : go(range_decode_fast_kernel<true, false>);
 }
 
 bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
-    return layout == CST_LAYOUT_STREAM_MAJOR && a.precision >= 8 && a.precision <= 24 && !(a.flags & CST_FLAG_RAW_STATE) &&
-           a.n_per_stream >= (size_t)kTileSyms && a.n_per_stream % 4 == 0 && a.n_per_stream < (1u << 24) &&
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR && !symbol_major_ok(a.n_streams)) return false;
+    return a.precision >= 8 && a.precision <= 24 && !(a.flags & CST_FLAG_RAW_STATE) &&
+           a.n_per_stream >= (size_t)kTileSyms && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) && a.n_per_stream < (1u << 24) &&
            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.words) & 63) == 0 &&
            a.stride_words % 16 == 0 && a.n_streams * a.stride_words * 4 < 0x100000000ull &&
            kFastRingBytes + table_bytes + 2 * kFastTileBytes <= 160 * 1024;
 }
 
-cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs) {
+cst_status range_encode_fast(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs) {
     const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
     const size_t lds = kFastRingBytes + table_bytes + 2 * kFastTileBytes;
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
@@ -459,7 +537,8 @@ cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs) {
         CST_HIP_TRY(hipGetLastError());
         return CST_OK;
     };
-    return a.precision <= 16 ? go(range_encode_fast_kernel<1>) : go(range_encode_fast_kernel<2>);
+    if (layout == CST_LAYOUT_SYMBOL_MAJOR) return a.precision <= 16 ? go(range_encode_fast_kernel<1, true>) : go(range_encode_fast_kernel<2, true>);
+    return a.precision <= 16 ? go(range_encode_fast_kernel<1, false>) : go(range_encode_fast_kernel<2, false>);
 }
 
 } // namespace cst

@@ -44,9 +44,9 @@ struct RangeDecodeArgs {
 
 // cst_range_fast.hip: the hand-scheduled (32,64) kernels; `*_usable` says whether a call qualifies
 bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
-cst_status range_encode_fast(const RangeEncodeArgs& a, hipStream_t hs);
+cst_status range_encode_fast(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs);
 bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout);
-cst_status range_decode_fast(const RangeDecodeArgs& a, hipStream_t hs);
+cst_status range_decode_fast(const RangeDecodeArgs& a, cst_layout layout, hipStream_t hs);
 
 // Forward-reading counterpart of RingReader (queue semantics).
 template <int SLOTS = kRingSlots, int AHEAD = kAhead>

@@ -34,6 +34,10 @@ from asmgen import Asm  # noqa: E402
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
 OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
+# SYMBOL_MAJOR (the same four files with _sm): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR: quad k of the
+# previous tile leaves as streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row (lane >> 2) + 16 (k & 1); full waves only
+# (goff0 = that position for k = 0, gstride = 16 rows, the store base moves by %[tilestep] per tile).
+SYMBOL_MAJOR = False
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD = 24            # kDecAhead
@@ -127,10 +131,16 @@ def gen(ends):
     a.i(f"v_mov_b32 {POS}, %[pos]"); a.i(f"v_mov_b32 {HI}, %[hi_issued]")
     a.i("v_mov_b32 v144, 0"); a.i("v_mov_b32 v145, 0x41f00000", "2^32")
     a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, %[dhi]", "+2^-30 (P <= 16) or +2^-22: above the estimate's error of 2^(P - 48.5)")
-    a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
-    for k in range(1, 8):
-        a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
-        a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
+    if SYMBOL_MAJOR:
+        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
+        a.i(f"v_add_u32 {GOFF[1]}, %[gstride], {GOFF[0]}", "symbol rows + 16")
+        for k in range(2, 8):
+            a.i(f"v_add_u32 {GOFF[k]}, 64, {GOFF[k - 2]}", "streams + 16")
+    else:
+        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
+        for k in range(1, 8):
+            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
+            a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
     a.i(f"s_mov_b64 {BAD}, 0")
     a.i("s_mov_b64 s[80:81], %[gbase]", "where the PREVIOUS tile goes (first tile of all: onto itself, rewritten one tile later)")
     a.i("v_readfirstlane_b32 s82, %[tiles]", "tiles left")
@@ -198,7 +208,10 @@ def gen(ends):
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
             a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
-        if pos == 1:
+        if pos == 1 and SYMBOL_MAJOR:
+            for c in range(4):
+                a.ds(f"ds_read_b32 v{172 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x")
+        elif pos == 1:
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
             # XT was read in step pos 1 and is covered by this step's lgkmcnt(0)
@@ -215,7 +228,7 @@ def gen(ends):
     a.i("v_swap_b32 %[trcur], %[trprev]")
     a.i("s_add_u32 s80, s80, s83")
     a.i("s_addc_u32 s81, s81, 0")
-    a.i("s_movk_i32 s83, 0x80")
+    a.i("s_mov_b32 s83, %[tilestep]" if SYMBOL_MAJOR else "s_movk_i32 s83, 0x80")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.wait_lds_all("landed chunks visible to the next tile")
@@ -268,9 +281,9 @@ def gen(ends):
 
 
 def main():
-    global B16
-    for b16 in (False, True):
-        B16 = b16
+    global B16, SYMBOL_MAJOR
+    for sm, b16 in ((False, False), (False, True), (True, False), (True, True)):
+        B16, SYMBOL_MAJOR = b16, sm
         for ends in (False, True):
             a = gen(ends)
             header = ["// GENERATED by scripts/gen_range_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
@@ -282,10 +295,15 @@ def main():
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
                    '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
                    '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' +
-                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol)' if b16 else ''),
+                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol)' if b16 else '') +
+                   (', [tilestep] "s"(tile_step_bytes)' if sm else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-            OUT[(b16, ends)].write_text(a.render(header, ops))
-            print(f"wrote {OUT[(b16, ends)]} ({a.n_instr()} instructions incl. loop control)")
+            out = OUT[(b16, ends)]
+            if sm:
+                out = out.with_name(out.name.replace(".inc", "_sm.inc"))
+                header[1] = header[1].replace(": see", ", symbols[t][stream]: see")
+            out.write_text(a.render(header, ops))
+            print(f"wrote {out} ({a.n_instr()} instructions incl. loop control)")
 
 
 if __name__ == "__main__":

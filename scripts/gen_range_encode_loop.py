@@ -29,8 +29,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
-OUT = {1: CSRC / "cst_range_encode_loop.inc", 2: CSRC / "cst_range_encode_loop_2f.inc"}
+OUT = {(1, False): CSRC / "cst_range_encode_loop.inc", (2, False): CSRC / "cst_range_encode_loop_2f.inc",
+       (1, True): CSRC / "cst_range_encode_loop_sm.inc", (2, True): CSRC / "cst_range_encode_loop_2f_sm.inc"}
 FLUSHES = 1
+# SYMBOL_MAJOR (cst_range_encode_loop*_sm.inc): symbols[t][stream].  Only the staging differs (gen_encode_loop.py): a load
+# instruction reads 16 symbol rows of 64 bytes (lane l: row l >> 2, streams 4 (l & 3) .. + 3), the four symbols of a
+# register go to four ROWS of the LDS tile (tile[stream][t], stride 36 words: 64 different banks per ds_write_b32), and the
+# base moves by 32 * n_streams * 4 bytes per tile (an operand) instead of 128.  Full waves only.
+SYMBOL_MAJOR = False
 
 
 def regs(base, n=4):
@@ -103,7 +109,7 @@ def fold_minmax(a, g):
 def advance_base(a):
     """s[80:81] -> symbols of the next tile to request; stays on the last tile once every tile has been requested"""
     a.i("s_cmp_lg_u32 s83, 0")
-    a.i("s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s88, %[tilestep], 0" if SYMBOL_MAJOR else "s_cselect_b32 s88, 0x80, 0")
     a.i("s_cselect_b32 s89, 1, 0")
     a.i("s_add_u32 s80, s80, s88")
     a.i("s_addc_u32 s81, s81, 0")
@@ -115,6 +121,11 @@ def stage_wait(a, name):
 
 
 def stage_one(a, name, buf, k):
+    if SYMBOL_MAJOR:
+        base = {"A": 100, "B": 132}[name]
+        for c in range(4):
+            a.ds(f"ds_write_b32 {TR[buf]}, v{base + 4 * k + c} offset:{(16 * (k >> 1) + c) * 144 + 64 * (k & 1)}", "tl")
+        return
     a.ds(f"ds_write_b128 {TR[buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
 
@@ -246,9 +257,9 @@ def gen():
     return a, notes
 
 
-def emit(flushes):
-    global FLUSHES
-    FLUSHES = flushes
+def emit(flushes, symbol_major=False):
+    global FLUSHES, SYMBOL_MAJOR
+    FLUSHES, SYMBOL_MAJOR = flushes, symbol_major
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_range_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               f"// Main loop of the hand-scheduled (32,64) range encoder, {flushes} word group(s) per tile: see cst_range_fast.hip."]
@@ -257,18 +268,21 @@ def emit(flushes):
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [tbl] "s"(table_addr_biased), [P] "s"(P), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-    OUT[flushes].write_text(a.render(header, ops))
-    print(f"wrote {OUT[flushes]} ({a.n_instr()} instructions incl. prologue)")
+    if symbol_major:
+        header[1] = header[1].replace(": see", ", symbols[t][stream]: see")
+    OUT[(flushes, symbol_major)].write_text(a.render(header, ops))
+    print(f"wrote {OUT[(flushes, symbol_major)]} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
 
 
 def main():
-    emit(1)
-    emit(2)
+    for sm in (False, True):
+        emit(1, sm)
+        emit(2, sm)
 
 
 if __name__ == "__main__":

@@ -636,6 +636,53 @@ def test_more_than_one_wave_per_simd(B, O, P, n_sym, n_per, stride_extra):
     assert np.array_equal(dec.cpu().numpy()[good], sym[good]) and np.array_equal(dec2.cpu().numpy()[good], sym[good])
 
 
+def test_c5_shard_full_size(B, O):
+    """Config C5's per-GPU shard at FULL size -- 131 072 streams x 4096 symbols (two waves per SIMD) -- encode, compaction,
+    the gather of the packed words through the library's RCCL communicator (one rank: the only world size this box has),
+    decode from the gathered buffer; words of sampled streams against the oracle, every decoded symbol against the input."""
+    import os
+    import torch.distributed as dist
+    from constriction_amd import dist as D
+    P, n_streams, n_per = 12, 131072, 4096
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+    base = O.synth_symbols(0xC0FFEE, 0, 512, n_per, -50, cdf, P)
+    dsym = dev(base).repeat(n_streams // 512, 1)
+    shift = torch.arange(n_streams, device="cuda") // 512
+    idx = (torch.arange(n_per, device="cuda")[None, :] + 5 * shift[:, None]) % n_per
+    dsym = torch.gather(dsym, 1, idx).contiguous()
+    enc = B.ans_encode(dsym, model, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum().item()) == 0
+    total = int(offsets[-1].item())
+    assert total == enc.total_words() and 680 * n_streams < total < 700 * n_streams
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        comm = D.RcclComm()
+        all_packed, all_off = comm.gather_packed(packed, offsets, dst=0)
+        torch.cuda.synchronize()
+        assert torch.equal(all_off, offsets) and torch.equal(all_packed, packed[:total])
+        comm.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    dec, status = B.ans_decode((all_packed, enc.n_words), model, n_per, offsets=all_off, config=(32, 64, P))
+    torch.cuda.synchronize()
+    assert int(status.abs().sum().item()) == 0 and torch.equal(dec, dsym)
+    sample = [0, 511, 512, 65535, 65536, 100000, n_streams - 1]
+    want_words, want_n, _ = O.ans_encode_batch(dsym[sample].cpu().numpy(), -50, cdf, P)
+    off = all_off.cpu().numpy()
+    pk = all_packed.cpu().numpy().view(np.uint32)
+    for k, s in enumerate(sample):
+        assert pk[off[s]: off[s + 1]].tolist() == want_words[k, : want_n[k]].tolist()
+
+
 def test_rccl_gather_through_the_c_abi_single_rank(B, O):
     """cst_rccl_* / cst_gather_sizes_rccl / cst_gather_rccl with a communicator of ONE rank (the only world size a
     single-GPU box offers): ids, sizes all-gather, the root's own copy and the offset re-basing."""

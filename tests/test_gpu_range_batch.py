@@ -25,7 +25,8 @@ def dev(a):
 
 
 @pytest.mark.parametrize("cfg", [(32, 64, 12), (32, 64, 24), (16, 32, 12), (16, 32, 16)], ids=lambda c: "W%dS%dP%d" % c)
-@pytest.mark.parametrize("n_streams,n_per", [(1, 1), (1, 777), (64, 32), (65, 100), (300, 257), (129, 4096), (7, 0)])
+@pytest.mark.parametrize("n_streams,n_per", [(1, 1), (1, 777), (64, 32), (65, 100), (300, 257), (129, 4096), (7, 0), (128, 4096), (192, 75),
+                                             (256, 2050)])
 @pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
 def test_range_roundtrip_parity(B, O, cfg, n_streams, n_per, layout):
     W, S, P = cfg
@@ -45,6 +46,48 @@ def test_range_roundtrip_parity(B, O, cfg, n_streams, n_per, layout):
     got = dec.cpu().numpy()
     assert (dstatus.cpu().numpy() == 0).all()
     assert np.array_equal(got.T if layout == "symbol_major" else got, sym)
+
+
+@pytest.mark.parametrize("P", [8, 12, 16, 24])
+def test_range_symbol_major_main_loops(B, O, P):
+    """symbols[t][stream] through the hand-scheduled range coder statements (cst_range_{encode,decode}_loop*_sm.inc: whole
+    waves, any row count): rows of 4096 + 7 symbols (ragged tail after the last full tile), a skewed model (carries,
+    inverted runs -> the slow-path repeat), decoding n + 40 symbols past the end, words against the oracle."""
+    n_streams, n_per = 320, 4096 + 7
+    rng = np.random.default_rng(P)
+    n_sym = 40
+    probs = rng.dirichlet(np.ones(n_sym) * 0.3) if P > 8 else rng.dirichlet(np.ones(n_sym) * 2.0)
+    cdf = O.categorical_fast_cdf(probs, P)
+    model = B.Model.from_cdf(cdf, -7, P)
+    sym = O.synth_symbols(21, 0, n_streams, n_per, -7, cdf, P)
+    want_words, want_n, want_status = O.rc_encode_batch(sym, -7, cdf, P)
+    d_sym = dev(sym.T)
+    enc = B.range_encode(d_sym, model, (32, 64, P), "symbol_major")
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    width = min(words.shape[1], want_words.shape[1])
+    assert int(n_words.max()) <= width
+    mask = np.arange(width, dtype=np.uint32)[None, :] < n_words[:, None]
+    assert np.array_equal(np.where(mask, words[:, :width], 0), np.where(mask, want_words[:, :width], 0))
+    dec, dstatus = B.range_decode(enc, model, n_per, "symbol_major")
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy().T, sym)
+    # past the end: the reference's decoder keeps going on zeros (queue.rs:1020-1024)
+    # (until a quantile of 2^P or more turns up: then the reference returns InvalidData, queue.rs:989-993, and the stream's
+    # remaining symbols are undefined)
+    more, more_st = B.range_decode(enc, model, n_per + 40, "symbol_major")
+    want_more, want_more_st = O.rc_decode_batch(want_words, want_n, n_per + 40, -7, cdf, P)
+    torch.cuda.synchronize()
+    assert more_st.cpu().numpy().tolist() == want_more_st.tolist()
+    fine = want_more_st == 0
+    assert fine.sum() > 0 and np.array_equal(more.cpu().numpy().T[fine], want_more[fine])
+    assert np.array_equal(more.cpu().numpy().T[:, :n_per], sym)
+    # an impossible symbol in one stream flags that stream only
+    bad = sym.copy()
+    bad[77, 1000] = -8
+    st = B.range_encode(dev(bad.T), model, (32, 64, P), "symbol_major").status.cpu().numpy()
+    assert st[77] == 1 and (np.delete(st, 77) == 0).all()
 
 
 def test_range_skewed_model_exercises_carry_paths(B, O):
@@ -85,9 +128,10 @@ def test_range_invalid_data(B, O, P):
     assert np.array_equal(got.cpu().numpy()[ok], want[ok])
 
 
-def test_range_full_size_c4(B, O):
-    """Config C4 at full size: 65 536 x 4096 round trip + sampled bit-exactness."""
-    P, n_streams, n_per = 12, 65536, 4096
+@pytest.mark.parametrize("P", [12, 24])
+def test_range_full_size_c4(B, O, P):
+    """Config C4 at full size, both precisions of the bench: 65 536 x 4096 round trip + sampled bit-exactness."""
+    n_streams, n_per = 65536, 4096
     cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
     base = O.synth_symbols(0xC0FFEE, 0, 256, n_per, -50, cdf, P)
