@@ -317,6 +317,20 @@ def other_configs(B, rank, world, dist, args, reps=5):
         e, _ = run_config(B, "C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         out.append(e)
         del sym24, m24
+        symT = sym12.t().contiguous()
+        e, _ = run_config(B, "C4 range coder, P = 12, symbols[t][stream] (symbol-major layout)", "range", (32, 64, 12), m12, symT, reps, check, cdf12,
+                          layout="symbol_major")
+        out.append(e)
+        del symT
+        # an alphabet of 700 symbols at P = 16 and rows of 4100 symbols: no 2^P-entry lookup table, more symbols than a bucket entry
+        # addresses, rows that are not cache-line aligned (the shapes next to the hand-scheduled ones: scripts/bench_variants.py)
+        big = B.Model.quantized_gaussian(-350, 349, 3.2, 96.0, 16)
+        cdf_big = big.cdf()
+        sym_big = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, 4100, -350, torch.from_numpy(cdf_big.astype(np.int64)).cuda(), 16)
+        e, _ = run_config(B, "ANS, 700 symbols at P = 16, rows of 4100 symbols (off the hand-scheduled paths)", "ans", (32, 64, 16), big, sym_big,
+                          reps, check, cdf_big, lo=-350)
+        out.append(e)
+        del sym_big, big
         # C3: one (mean, std) per stream, support -127..127
         # (parameters and symbols from the per-stream splitmix64 generators, like C2's)
         mu_d, sigma_d = c3_parameters(SEED, rank * N_STREAMS, N_STREAMS, N_PER, "cuda")
