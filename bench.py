@@ -472,9 +472,9 @@ def main():
     decoded = torch.empty_like(symbols)
     torch.cuda.synchronize()
 
-    def eager_step():
-        B.ans_encode(symbols, model, (W, S, P), out=enc)
-        B.ans_decode(enc, model, N_PER, out=decoded)
+    # one step = cst_ans_encode_batch + cst_ans_decode_batch through the C ABI, arguments converted once (the Python
+    # wrappers cost ~40 us per call: nothing next to a kernel, but a busy host core then shows up as gaps between them)
+    eager_step = B.ans_roundtrip_launcher(symbols, model, enc, decoded)
 
     # One step = two kernel launches of ~0.3 ms.  Eager launches pipeline (the host is two launches ahead of the GPU);
     # replaying the step as a HIP graph was measured SLOWER (0.65 vs 0.59 ms per step: ~60 us of fixed cost per replay

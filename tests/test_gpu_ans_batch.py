@@ -771,6 +771,24 @@ def test_golden_vectors_through_the_batched_abi(B, O, golden):
     assert done >= 3
 
 
+def test_roundtrip_launcher_equals_the_wrappers(B, O):
+    """batched.ans_roundtrip_launcher (what bench.py's timed loop calls: both C-ABI entry points with pre-converted
+    arguments) produces what ans_encode / ans_decode produce"""
+    P = 12
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, -50, P)
+    sym = dev(O.synth_symbols(9, 0, 300, 500, -50, cdf, P))
+    want = B.ans_encode(sym, model, (32, 64, P))
+    enc = B.ans_encode(torch.zeros_like(sym) - 50, model, (32, 64, P))          # buffers to be overwritten
+    dec = torch.empty_like(sym)
+    step = B.ans_roundtrip_launcher(sym, model, enc, dec)
+    step(); step()
+    torch.cuda.synchronize()
+    assert torch.equal(enc.n_words, want.n_words) and torch.equal(dec, sym) and int(step.decode_status.abs().sum()) == 0
+    for s in (0, 64, 299):
+        assert enc.stream(s).tolist() == want.stream(s).tolist()
+
+
 def test_compact_reports_a_packed_buffer_that_is_too_small(B, O):
     P = 12
     cdf = O.GaussianModel(-20, 20, 1.5, 4.0, P, 32).cdf_table()
