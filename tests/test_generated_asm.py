@@ -66,17 +66,19 @@ def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
 
 
 def test_range_loops_are_in_sync(tmp_path, monkeypatch):
-    """the range encoder's main loops (one / two word groups per tile)"""
+    """the range encoder's main loops (one / two word groups per tile, both symbol layouts)"""
     monkeypatch.delenv("GEN_NO_LGKM", raising=False)
     mod = _load("gen_range_encode_loop")
-    mod.OUT = {1: tmp_path / "r1.inc", 2: tmp_path / "r2.inc"}
+    names = {key: path.name for key, path in mod.OUT.items()}
+    mod.OUT = {key: tmp_path / name for key, name in names.items()}
     mod.main()
-    assert (tmp_path / "r1.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_encode_loop.inc").read_text()
-    assert (tmp_path / "r2.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_range_encode_loop_2f.inc").read_text()
+    assert len(names) == 4
+    for name in names.values():
+        assert (tmp_path / name).read_text() == (ROOT / "constriction_amd" / "csrc" / name).read_text(), name
 
 
 def test_range_decode_loops_are_in_sync(tmp_path, monkeypatch):
-    """the range decoder's main loops (plain / end-of-data aware)"""
+    """the range decoder's main loops (plain / end-of-data aware, P <= 12 / bucket entries, both symbol layouts)"""
     monkeypatch.delenv("GEN_NO_LGKM", raising=False)
     mod = _load("gen_range_decode_loop")
     names = {key: path.name for key, path in mod.OUT.items()}
@@ -85,6 +87,8 @@ def test_range_decode_loops_are_in_sync(tmp_path, monkeypatch):
     assert len(names) == 4
     for name in names.values():
         assert (tmp_path / name).read_text() == (ROOT / "constriction_amd" / "csrc" / name).read_text(), name
+        sm = name.replace(".inc", "_sm.inc")
+        assert (tmp_path / sm).read_text() == (ROOT / "constriction_amd" / "csrc" / sm).read_text(), sm
 
 
 def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
