@@ -381,13 +381,17 @@ __device__ __forceinline__ uint32_t leaky_left_value_quick(double x, double mu, 
     return f64_as_u32_sat(y);
 }
 
-// leaky_gaussian_left, quick.  Bit-identical to leaky_gaussian_left<true> for every input.
+// leaky_gaussian_left, quick.  Bit-identical to leaky_gaussian_left<true> for every input.  INNER: the caller guarantees
+// 0 < i < n (a decoder's probes), which spares two divergent early exits per evaluation.
+template <bool INNER = false>
 __device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t lo, int32_t n, int P, int prob_bits, double mu,
                                                               double sigma, const double2* tab, uint32_t* n_exact = nullptr) {
     constexpr double sqrt2 = 1.41421356237309504880168872420969808;
     const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
-    if (i <= 0) return 0u;
-    if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+    if constexpr (!INNER) {
+        if (i <= 0) return 0u;
+        if (i >= n) return (P >= 32 ? 0u : (1u << P)) & pmask;
+    }
     const uint32_t max_prob = pmask >> (prob_bits - P);
     const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
     const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;

@@ -725,6 +725,16 @@ __device__ __forceinline__ float ndtri_lower_f32(float tail) {
     return tail < 0.02425f ? zt : zc;
 }
 
+// The same quantile from Abramowitz & Stegun 26.2.23 (|error| < 4.5e-4 over the whole lower half): a third of the instructions.
+// Good for a first probe as long as 4.5e-4 sigma stays well below half a symbol; the lane decoder uses it when no lane of the
+// wave has sigma >= 200.
+__device__ __forceinline__ float ndtri_lower_coarse_f32(float tail) {
+    const float t = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(tail));          // sqrt(-2 ln(tail))
+    const float num = (0.010328f * t + 0.802853f) * t + 2.515517f;
+    const float den = ((0.001308f * t + 0.189269f) * t + 1.432788f) * t + 1.0f;
+    return num * __builtin_amdgcn_rcpf(den) - t;
+}
+
 // Out of line ON PURPOSE: inlined, the compiler hoists the 32 + 8 row addresses of both variants out of the symbol loop
 // into 130 VGPRs and then spills the erf's registers around every call of it.
 __device__ __noinline__ void store_symbol_tile(int32_t* sym, size_t n_streams, size_t N, size_t s0, size_t t0, int lane, const int32_t* tile, bool vec) {
@@ -781,7 +791,24 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     // ---- parameter tiles: item w = it * 64 + lane of a tile is (stream j, symbol tl), consecutive lanes on consecutive
     // addresses in either layout ----
     double mu_r[kParTile], sd_r[kParTile];
+    // item `it` of a tile that lies wholly inside the matrix: element base_e + t0 * t_stride + it * item_stride (stream-major:
+    // stream s0 + lane / 16 + 4 it, symbol t0 + lane % 16; symbol-major: symbol t0 + it, stream s0 + lane), LDS slot
+    // base_l + it * l_stride -- pointer increments; tiles that stick out (last streams, last symbols) take the general form
+    const size_t base_e = symbol_major ? s0 + (size_t)lane : (s0 + (size_t)(lane / kParTile)) * N + (size_t)(lane % kParTile);
+    const size_t t_stride = symbol_major ? a.n_streams : 1, item_stride = symbol_major ? a.n_streams : (size_t)(kWave / kParTile) * N;
+    const int base_l = symbol_major ? lane : (lane % kParTile) * kParStride + lane / kParTile;
+    const int l_stride = symbol_major ? kParStride : kWave / kParTile;
     auto par_request = [&](size_t t0) {
+        if (s0 + kWave <= a.n_streams && t0 + kParTile <= N) {
+            const double* pm = a.means + base_e + t0 * t_stride;
+            const double* ps = a.stds + base_e + t0 * t_stride;
+#pragma unroll
+            for (int it = 0; it < kParTile; ++it) {
+                mu_r[it] = __builtin_nontemporal_load(pm + (size_t)it * item_stride);
+                sd_r[it] = __builtin_nontemporal_load(ps + (size_t)it * item_stride);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < kParTile; ++it) {
             const int w = it * kWave + lane;
@@ -797,10 +824,8 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     auto par_land = [&]() {
 #pragma unroll
         for (int it = 0; it < kParTile; ++it) {
-            const int w = it * kWave + lane;
-            const int j = symbol_major ? w % kWave : w / kParTile, tl = symbol_major ? w / kWave : w % kParTile;
-            par_mu[tl * kParStride + j] = mu_r[it];
-            par_sd[tl * kParStride + j] = sd_r[it];
+            par_mu[base_l + it * l_stride] = mu_r[it];
+            par_sd[base_l + it * l_stride] = sd_r[it];
         }
     };
     // ---- word window: a tile of 16 symbols takes at most 16 words, so with the 16 words behind the read position in
@@ -810,6 +835,12 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     auto win_request = [&](int64_t first) {
         w_first = first;
         const int64_t len = (int64_t)D.length();
+        if (!__any(first < 0 || first + kParTile > len)) {    // every lane's 16 words exist: one pointer, sixteen offsets
+            const uint32_t* pw = D.in + first;
+#pragma unroll
+            for (int i = 0; i < kParTile; ++i) w_r[i] = pw[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kParTile; ++i) {
             const int64_t p = first + i;
@@ -851,7 +882,8 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
                 else {
                     // guess: ignore the leak (one quantile per symbol) first, then account for the guessed symbol's share of it
                     const float below = (float)q + 0.5f, above = total_f - below;
-                    float z = ndtri_lower_f32(fminf(below, above) * inv_total_f);
+                    const bool coarse = !__any(sd >= 200.0);          // (wave-uniform: the cheap quantile is good enough)
+                    float z = coarse ? ndtri_lower_coarse_f32(fminf(below, above) * inv_total_f) : ndtri_lower_f32(fminf(below, above) * inv_total_f);
                     double x = mu + sd * (double)(below < above ? z : -z) + guess_shift;
                     if (two_step_guess) {
                         const float b1 = below - (float)fmin(fmax(x, 0.0), (double)(n - 1u)), a1 = free_f - b1;
@@ -868,7 +900,8 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
                     uint32_t probe = g, step = 1;
                     bool up = false, down = false;
                     while (hi_i - lo_i > 1) {
-                        const uint32_t v = leaky_gaussian_left_quick((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
+                        // (every probe lies strictly inside (lo_i, hi_i), a subset of (0, n))
+                        const uint32_t v = leaky_gaussian_left_quick<true>((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
                         if (v <= q) { lo_i = probe; lo_v = v; up = true; } else { hi_i = probe; hi_v = v; down = true; }
                         if (up && down) probe = lo_i + (hi_i - lo_i) / 2;
                         else if (up) probe = min(lo_i + step, hi_i - 1u);
