@@ -1,5 +1,5 @@
 // cst_ans_b16.hip -- the hand-scheduled (32,64) ANS decoder for 12 < P <= 24 (DefaultAnsCoder's PRECISION = 24),
-// shared table of at most 256 symbols, stream-major.  At this precision there is no table of 2^P quantiles: the lookup
+// shared table of at most 256 symbols (1024 for P <= 22), both symbol layouts.  At this precision there is no table of 2^P quantiles: the lookup
 // (lookup_contiguous.rs:564-605, contiguous.rs:628-665) is ONE 16-byte LDS read of a bucket entry (DecLut::b16,
 // cst_common.hpp); scripts/gen_decode_loop_b16.py has the instruction-level account.  The step itself is
 // AnsCoder::decode_symbol, stack.rs:1084-1097.
@@ -13,7 +13,7 @@ __device__ __forceinline__ void ans_decode_b16_tiles_loop(uint32_t& lo, uint32_t
                                                           int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                           uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
                                                           uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0,
-                                                          uint32_t goff_limit, bool plain_stores) {
+                                                          uint32_t goff_limit, uint32_t c_field_mask, uint32_t index_shift, bool plain_stores) {
     if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
 #define CST_STORE_MOD ""
 #include "cst_decode_loop_b16.inc"
@@ -32,7 +32,8 @@ __device__ __forceinline__ void ans_decode_b16_tiles_loop_sm(uint32_t& lo, uint3
                                                              int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                              uint32_t goff_stride, uint32_t n_tiles, uint32_t shift_minus_1,
                                                              uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off, uint32_t goff0,
-                                                             uint32_t goff_limit, uint32_t tile_step_bytes, bool plain_stores) {
+                                                             uint32_t goff_limit, uint32_t tile_step_bytes, uint32_t c_field_mask, uint32_t index_shift,
+                                                             bool plain_stores) {
     if (plain_stores) {
 #define CST_STORE_MOD ""
 #include "cst_decode_loop_b16_sm.inc"
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
                                          words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lds_addr(ring + lane),
                                          lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), plain);
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), (1u << lut.idx_shift) - 1u, (uint32_t)lut.idx_shift, plain);
             L.state = ((uint64_t)hi << 32) | lo;
             wave_lds_fence();
             tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
             ans_decode_b16_tiles_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
                                       (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
                                       words_base, store_base, (uint32_t)(8 * N * 4), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, plain_stores);
+                                      L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (1u << lut.idx_shift) - 1u, (uint32_t)lut.idx_shift, plain_stores);
             L.state = ((uint64_t)hi << 32) | lo;
             // the last tile is still in LDS (buffer A if it has an even index)
             wave_lds_fence();

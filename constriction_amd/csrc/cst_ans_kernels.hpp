@@ -808,7 +808,7 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
     } else {
         if (lut.b16) {
             const uint4 e = lut.b16[q >> bucket_shift];
-            const uint32_t c0 = e.x & 0xffffffu, i0 = e.x >> 24;
+            const uint32_t c0 = e.x & ((1u << lut.idx_shift) - 1u), i0 = e.x >> lut.idx_shift;
             const uint32_t k = (q >= e.y ? 1u : 0u) + (q >= e.z ? 1u : 0u);
             c = k == 0 ? c0 : (k == 1 ? e.y : e.z);
             uint32_t nxt = k == 0 ? e.y : (k == 1 ? e.z : e.w);
@@ -918,10 +918,10 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
                 const uint32_t n = (uint32_t)n_symbols;
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
                     const uint32_t i0 = g_bucket[i];
-                    b[i] = make_uint4(g_cdf[i0] | (i0 << 24), g_cdf[min(i0 + 1u, n)], g_cdf[min(i0 + 2u, n)], g_cdf[min(i0 + 3u, n)]);
+                    b[i] = make_uint4(g_cdf[i0] | (i0 << bucket16_index_shift(n_symbols)), g_cdf[min(i0 + 1u, n)], g_cdf[min(i0 + 2u, n)], g_cdf[min(i0 + 3u, n)]);
                 }
                 lds_off += (size_t)nb * 16;
-                lut.b16 = b; cdf = c;
+                lut.b16 = b; lut.idx_shift = bucket16_index_shift(n_symbols); cdf = c;
             } else {
                 uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];

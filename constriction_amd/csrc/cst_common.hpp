@@ -43,13 +43,18 @@ struct DecLut {      // pointers into LDS or global memory
     const uint16_t* idx;    // symbol index per quantile ...
     const int32_t* sym;     // ... or, if non-null, the decoded symbol itself (idx + min_symbol)
     int32_t min_symbol;
-    // bucket mode, alphabets of <= 256 symbols, tables in LDS: ONE 16-byte entry per bucket of quantiles,
-    //   { cdf[i0] | i0 << 24, cdf[i0 + 1], cdf[i0 + 2], cdf[i0 + 3] }   (i0 = the symbol that holds the bucket's first quantile,
-    // cumulatives beyond the table read as 2^P): a single LDS round trip resolves up to three symbols per bucket
+    // bucket mode, tables in LDS: ONE 16-byte entry per bucket of quantiles,
+    //   { cdf[i0] | i0 << idx_shift, cdf[i0 + 1], cdf[i0 + 2], cdf[i0 + 3] }   (i0 = the symbol that holds the bucket's first
+    // quantile, cumulatives beyond the table read as 2^P): a single LDS round trip resolves up to three symbols per bucket.
+    // The index shares the first word with its cumulative: 8 bits above 24 (alphabets of <= 256 symbols, P <= 24) or 10 bits
+    // above 22 (<= 1024 symbols, P <= 22).
     const uint4* b16;
+    int32_t idx_shift;
 };
-constexpr int kBucket16MaxSymbols = 256;
-__host__ __device__ inline bool bucket16_usable(int n_symbols, int P) { return n_symbols <= kBucket16MaxSymbols && P <= 24; }
+__host__ __device__ inline int bucket16_index_shift(int n_symbols) { return n_symbols <= 256 ? 24 : 22; }
+__host__ __device__ inline bool bucket16_usable(int n_symbols, int P) {
+    return (n_symbols <= 256 && P <= 24) || (n_symbols <= 1024 && P <= 22);
+}
 
 // Per-stream tables in their compact form (cst_ans_pt.hip).  A quantized distribution over a support much wider than
 // its scale (the learned-compression case: support -127..127, std 0.5..16) consists mostly of runs of unit

@@ -237,6 +237,7 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
                                                         uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                         uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t bucket_shift,
                                                         uint32_t cdf_addr, int32_t min_symbol, [[maybe_unused]] uint32_t tile_step_bytes,
+                                                        [[maybe_unused]] uint32_t c_field_mask, [[maybe_unused]] uint32_t index_shift,
                                                         bool plain_stores) {
     if constexpr (B16 && ENDS && SM) {
     if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
@@ -430,10 +431,11 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22
             const uint32_t lut_addr = B16 ? lds_addr(blut.b16) : lds_addr(lut);
             const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
+            const uint32_t idx_shift = B16 ? (uint32_t)blut.idx_shift : 24u, idx_mask = (1u << idx_shift) - 1u;
             range_decode_tiles_loop<false, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
                                                     qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
                                                     lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                    cdf_addr, a.min_symbol, tile_step, plain_stores);
+                                                    cdf_addr, a.min_symbol, tile_step, idx_mask, idx_shift, plain_stores);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
                 range_decode_tiles_loop<true, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
                                                        lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
                                                        lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
-                                                       cdf_addr, a.min_symbol, tile_step, plain_stores);
+                                                       cdf_addr, a.min_symbol, tile_step, idx_mask, idx_shift, plain_stores);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
                 // the last tile is still in LDS (buffer A if it has an even index)

@@ -122,7 +122,7 @@ def gen():
         a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
         a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
         a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
-        a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
+        a.i(f"v_and_b32 {C}, %[cfield], {E0}", "(the cumulative shares its word with the index: 24 + 8 or 22 + 10 bits)")
         a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
         a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
@@ -142,7 +142,7 @@ def gen():
         a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
         if not last_of_half:
             word_request()
-        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
+        a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
         a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
         a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
         a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
@@ -188,7 +188,7 @@ def gen():
         a.i(f"s_mov_b64 {XSAVE}, exec")
         a.i(f"s_mov_b64 {FLAGGED}, vcc")
         a.i("s_mov_b64 exec, vcc")
-        a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+        a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
         a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
         a.i(f"{6 + st}:", None)
         a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
@@ -205,8 +205,8 @@ def gen():
         a.i(f"v_mov_b32 {C}, {PAIR0}")
         a.i(f"v_mov_b32 {NXT}, {PAIR1}")
         a.i(f"v_sub_u32 {IDX}, {IDX}, 2", "q >= e1 and q >= e2 hold for these lanes: the step adds 2 again")
-        a.i(f"v_lshlrev_b32 {IDX}, 24, {IDX}")
-        a.i(f"v_and_b32 {E0}, 0xffffff, {E0}")
+        a.i(f"v_lshlrev_b32 {IDX}, %[ishift], {IDX}")
+        a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
         a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
         a.i(f"s_mov_b64 exec, {XSAVE}")
         a.i(f"s_setpc_b64 {RET}")
@@ -228,7 +228,7 @@ def emit(out):
               "// Main loop of the hand-scheduled (32,64) ANS decoder for 12 < P <= 24 (bucket entries): see cst_ans_b16.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
-           '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "s"(min_symbol),',
+           '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift),',
            '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
            '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]

@@ -169,7 +169,7 @@ def gen(ends):
             a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
             a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
             a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
-            a.i(f"v_and_b32 {C}, 0xffffff, {E0}")
+            a.i(f"v_and_b32 {C}, %[cfield], {E0}", "(the cumulative shares its word with the index: 24 + 8 or 22 + 10 bits)")
             a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
             a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
             a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
@@ -204,7 +204,7 @@ def gen(ends):
         if (j + 1) % 32 not in halves:
             word_request(a)
         if B16:
-            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
+            a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
             a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
@@ -254,7 +254,7 @@ def gen(ends):
             a.i(f"s_mov_b64 {XSAVE}, exec")
             a.i(f"s_mov_b64 {FLAGGED}, vcc")
             a.i("s_mov_b64 exec, vcc")
-            a.i(f"v_lshrrev_b32 {IDX}, 24, {E0}")
+            a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
             a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
             a.i(f"{6 + st}:", None)
             a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
@@ -271,8 +271,8 @@ def gen(ends):
             a.i(f"v_mov_b32 {C}, {PAIR0}")
             a.i(f"v_mov_b32 {NXT}, {PAIR1}")
             a.i(f"v_sub_u32 {IDX}, {IDX}, 2", "q >= e1 and q >= e2 hold for these lanes: the step adds 2 again")
-            a.i(f"v_lshlrev_b32 {IDX}, 24, {IDX}")
-            a.i(f"v_and_b32 {E0}, 0xffffff, {E0}")
+            a.i(f"v_lshlrev_b32 {IDX}, %[ishift], {IDX}")
+            a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
             a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
             a.i(f"s_mov_b64 exec, {XSAVE}")
             a.i(f"s_setpc_b64 {RET}")
@@ -295,7 +295,7 @@ def main():
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
                    '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
                    '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' +
-                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol)' if b16 else '') +
+                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else '') +
                    (', [tilestep] "s"(tile_step_bytes)' if sm else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
             out = OUT[(b16, ends)]

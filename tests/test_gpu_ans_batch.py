@@ -894,6 +894,44 @@ def test_bucket_entry_decoder_walks_the_tails(B, O, P):
         assert np.array_equal(more.cpu().numpy(), want_more)
 
 
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("P,n", [(13, 300), (16, 700), (22, 1024), (20, 257)])
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_large_alphabets_through_the_bucket_entries(B, O, coder, P, n, layout):
+    """Alphabets of 257 ... 1024 symbols at 12 < P <= 22: the bucket entry keeps a 10-bit symbol index above a 22-bit cumulative
+    and the hand-scheduled decoders take these shapes too (both coders, both layouts).  A skewed model whose tails are crowded
+    with unit probabilities (the walk beyond a bucket's third symbol), data drawn over the whole alphabet; words and decoded
+    symbols against the oracle."""
+    rng = np.random.default_rng(P * 7 + n)
+    probs = np.ones(n, dtype=np.int64)
+    heavy = rng.choice(n, 12, replace=False)
+    rest = (1 << P) - n
+    share = rng.dirichlet(np.ones(12)) * rest
+    probs[heavy] += share.astype(np.int64)
+    probs[heavy[0]] += (1 << P) - int(probs.sum())
+    cdf = np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+    assert int(cdf[-1]) == 1 << P and (np.diff(cdf.astype(np.int64)) > 0).all()
+    lo = -n // 2
+    model = B.Model.from_cdf(cdf, lo, P)
+    n_streams, n_per = 192, 200
+    sym = (rng.integers(0, n, (n_streams, n_per)) + lo).astype(np.int32)
+    sym[:, ::2] = np.asarray(heavy)[rng.integers(0, 12, (n_streams, (n_per + 1) // 2))] + lo
+    sym[0, :4] = [lo, lo + n - 1, lo + 256, lo + 255]
+    enc_f, dec_f = (B.ans_encode, B.ans_decode) if coder == "ans" else (B.range_encode, B.range_decode)
+    want_words, want_n, _ = (O.ans_encode_batch if coder == "ans" else O.rc_encode_batch)(sym, lo, cdf, P)
+    d_sym = dev(sym if layout == "stream_major" else sym.T)
+    enc = enc_f(d_sym, model, (32, 64, P), layout)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    dec, st = dec_f(enc, model, n_per, layout)
+    torch.cuda.synchronize()
+    got = dec.cpu().numpy()
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(got if layout == "stream_major" else got.T, sym)
+
+
 def test_packed_container_through_the_gpu(B, O, tmp_path):
     """encode -> compact -> container file -> load -> decode from the packed form; every stream's slice of the file is the
     array one reference coder would have written with `tofile` (src/pybindings/stream/stack.rs:149-166)"""
