@@ -355,6 +355,25 @@ struct RingWriter {
     }
 };
 
+// Rows that do not start on cache-line boundaries (row length not a multiple of 32 symbols): a lane's tiles begin `pre`
+// symbols into its row, at the row's next 128-byte boundary, so that every 128-byte segment a tile store writes is ONE whole
+// cache line again (a segment that straddles two lines reaches memory as two partial lines: 1.8x the decode time at
+// 65 536 x 4100).  `pre` depends only on where the row starts:
+__device__ __forceinline__ uint32_t row_skew(const int32_t* sym, size_t row, size_t N) {
+    return (uint32_t)(((128u - (uint32_t)((reinterpret_cast<uintptr_t>(sym) + row * N * 4) & 127u)) & 127u) >> 2);
+}
+// LDS tile -> HBM for such rows (full wave): row R's 32 symbols go to sym[R][skew(R) + t0 ...]
+__device__ __forceinline__ void tile_store_skewed(int32_t* __restrict__ sym, size_t N, size_t s0, size_t t0, int lane, const int32_t* tile) {
+    const int chunk = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t R = s0 + (size_t)((lane >> 3) + 8 * k);
+        const int4 v = *reinterpret_cast<const int4*>(tile + ((lane >> 3) + 8 * k) * kTileStride + 4 * chunk);
+        v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(sym + R * N + row_skew(sym, R, N) + t0 + 4 * chunk));
+    }
+}
+
 // LDS tile -> symbols[t][stream] (full wave, n_streams % 4 == 0, 16-byte aligned base): the mapping of the symbol-major
 // main-loop statements (scripts/gen_{encode,decode}_loop.py): piece k = streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row
 // (lane >> 2) + 16 (k & 1); the four LDS reads of a piece are conflict-free.
@@ -427,6 +446,19 @@ struct RingReader {
             const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
             uint32_t* b = slot(lo_issued);
             b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
+        }
+    }
+
+    // land what the last advance_window() requested, request nothing (before handing the ring to a statement that keeps its
+    // own book of requests)
+    __device__ __forceinline__ void land_pending() {
+#pragma unroll
+        for (int k = 0; k < kMaxChunksPerPoint; ++k) {
+            if (pend_pos[k] >= 0) {
+                uint32_t* b = slot((uint32_t)pend_pos[k]);
+                b[0] = pend[k].x; b[kWave] = pend[k].y; b[2 * kWave] = pend[k].z; b[3 * kWave] = pend[k].w;
+                pend_pos[k] = -1;
+            }
         }
     }
 
@@ -1071,6 +1103,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
         int32_t* row = a.symbols + (active ? s : 0) * N;
         const size_t n_full = N / kTileSyms;
         int32_t* my = tile + lane * kTileStride;
+        bool all_done = false;              // the main-loop statement path also decodes the rows' ragged ends
         if constexpr (TILE_ASM) {
             // the ring address is formed with v_and_or: this wave's ring must be aligned to its size
             if ((lds_addr(ring) & (uint32_t)(kWaveRingWords * 4 - 1)) != 0) __builtin_trap();
@@ -1090,16 +1123,40 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
             const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
             const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
             const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
-            const bool use_loop = (s0 + kWave <= a.n_streams) && n_full >= 2 && N < (1u << 24) && !__any(!off_ok);
+            const bool use_loop = (s0 + kWave <= a.n_streams) && N >= 4 * kTileSyms && N < (1u << 24) && !__any(!off_ok);
             size_t tb = 0;
             if (use_loop) {
+                // ---- rows of any length and alignment: every lane first decodes the `pre` symbols in front of its row's next
+                // cache-line boundary (0 for rows that start on one), so that its tiles -- and the 128-byte segments the
+                // tile stores write -- are whole cache lines (row_skew above) ----
+                const uint32_t pre = row_skew(a.symbols, s, N);
+                uint32_t max_pre = pre;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+                max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+                if (max_pre) {
+                    L.state = ((uint64_t)hi << 32) | lo;
+                    for (uint32_t j = 0; j < max_pre; ++j) {
+                        if (j < pre) row[j] = a.min_symbol + (int32_t)next_index();
+                        L.in.advance_window();
+                    }
+                    L.in.land_pending();
+                    L.in.refill_blocking();
+                    wave_lds_fence();
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    lo = (uint32_t)L.state; hi = (uint32_t)(L.state >> 32);
+                }
+                const size_t n_t = (N - max_pre) / kTileSyms;          // whole tiles every lane has (>= 3)
                 ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, lds_addr(my), L.in.shift - 1u, lane_addr, kDecRingMask);
                 L.in.refill_blocking();
                 wave_lds_fence();
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 uint32_t goff[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+                for (int k = 0; k < 8; ++k) {
+                    const size_t R = (size_t)(lane >> 3) + 8 * k;
+                    goff[k] = (uint32_t)((R * N + row_skew(a.symbols, s0 + R, N) + 4 * (size_t)(lane & 7)) * 4);
+                }
                 const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
                 // current = B (tile 1), previous = A (tile 0)
                 uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
@@ -1109,22 +1166,29 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 // (readfirstlane returns int: go through uint32_t or the low half sign-extends into the high one)
                 const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-                // rows that start on cache-line boundaries stream out non-temporally; others need L2 to merge the two halves
-                // of the lines a 128-byte segment straddles (0.86 -> 0.52 ms at 65 536 x 4100)
-                const uint32_t nt_loop = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((N * 4) % 128 == 0 && (sb & 127) == 0) ? 1 : 0));
-                if (nt_loop)
-                    ans_decode_tiles_loop<false>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
-                                                 kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                                 L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
-                else
-                    ans_decode_tiles_loop<true>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
-                                                kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)),
-                                                L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
+                // (every stored segment is a whole cache line now: the streaming form of the stores in every case)
+                ans_decode_tiles_loop<false>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P,
+                                             kDecRingMask, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_t - 1)),
+                                             L.in.shift - 1u, lane_addr, lds_addr(dump), (uint32_t)w_off, goff);
                 // the last tile is still in LDS (buffer A if it has an even index)
                 wave_lds_fence();
-                tile_store<VEC>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                tile_store_skewed(a.symbols, N, s0, (n_t - 1) * kTileSyms, lane, ((n_t - 1) & 1) ? tile_b : tile);
                 wave_lds_fence();
+                // ---- and what is left of each row behind its last whole tile (fewer than 64 symbols) ----
+                L.state = ((uint64_t)hi << 32) | lo;
+                const uint32_t done = pre + (uint32_t)(n_t * kTileSyms), rest = (uint32_t)N - done;
+                const uint32_t max_rest = (uint32_t)N - (uint32_t)(n_t * kTileSyms);          // (a lane with pre == 0 exists or not: an upper bound)
+                if (max_rest) {
+                    L.in.refill_blocking();
+                    wave_lds_fence();
+                    for (uint32_t j = 0; j < max_rest; ++j) {
+                        if (j < rest) row[done + j] = a.min_symbol + (int32_t)next_index();
+                        L.in.advance_window();
+                    }
+                }
+                lo = (uint32_t)L.state; hi = (uint32_t)(L.state >> 32);
                 tb = n_full;
+                all_done = true;
             }
             for (; tb < n_full; ++tb) {
                 ans_decode_tile32(lo, hi, L.in.rd, lut_addr, qmask, (uint32_t)P, lds_addr(my), L.in.shift - 1u, lane_addr, kDecRingMask);
@@ -1149,7 +1213,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 wave_lds_fence();
             }
         }
-        for (size_t t = n_full * kTileSyms; t < N; ++t) {
+        for (size_t t = all_done ? N : n_full * kTileSyms; t < N; ++t) {
             const uint32_t idx = next_index();
             if (active) row[t] = a.min_symbol + (int32_t)idx;
             L.in.advance_window();

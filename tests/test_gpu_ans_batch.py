@@ -932,6 +932,33 @@ def test_large_alphabets_through_the_bucket_entries(B, O, coder, P, n, layout):
     assert (st.cpu().numpy() == 0).all() and np.array_equal(got if layout == "stream_major" else got.T, sym)
 
 
+@pytest.mark.parametrize("n_per", [128, 129, 131, 4095, 4100, 4099])
+@pytest.mark.parametrize("base_shift", [0, 1, 3])
+def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift):
+    """The headline decoder's main-loop statement on rows that do not start on cache-line boundaries: every lane decodes the
+    symbols in front of ITS row's next 128-byte boundary first, so that its tiles are whole cache lines (row_skew,
+    cst_ans_kernels.hpp).  Row lengths with every residue that matters, symbol buffers that start 4 and 12 bytes off a
+    16-byte boundary, full waves plus a partial one; words against the oracle, decoding 70 symbols past the end too."""
+    P, n_streams = 12, 200
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, -50, P)
+    sym = O.synth_symbols(n_per, 0, n_streams, n_per, -50, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, -50, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    assert enc.n_words.cpu().numpy().tolist() == want_n.tolist()
+    for extra in (0, 70):
+        n_dec = n_per + extra
+        buf = torch.full((n_streams * n_dec + 8,), -99, dtype=torch.int32, device="cuda")
+        out = buf[base_shift: base_shift + n_streams * n_dec].view(n_streams, n_dec)
+        dec, st = B.ans_decode(enc, model, n_dec, out=out)
+        torch.cuda.synchronize()
+        want, want_st = O.ans_decode_batch(want_words, want_n, n_dec, -50, cdf, P)
+        assert st.cpu().numpy().tolist() == want_st.tolist()
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert (buf[:base_shift].cpu().numpy() == -99).all() and (buf[base_shift + n_streams * n_dec:].cpu().numpy() == -99).all()
+
+
 def test_packed_container_through_the_gpu(B, O, tmp_path):
     """encode -> compact -> container file -> load -> decode from the packed form; every stream's slice of the file is the
     array one reference coder would have written with `tofile` (src/pybindings/stream/stack.rs:149-166)"""
