@@ -688,49 +688,92 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
     } else {
         const int32_t* row = a.symbols + (active ? s : 0) * N;
         const size_t n_full = N / kTileSyms; // full tiles [32k, 32k+32)
+        constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE;
+        [[maybe_unused]] int32_t smin = a.min_symbol, smax = a.min_symbol;
+        // wave-uniform: every slab of this wave 16-byte aligned and a whole number of chunks long
+        const bool aligned_slabs = !__any(L.out.shift != 0 || (L.out.cap & 3u) != 0);
+        // ---- main loop as one asm statement (full wave, aligned slabs, 32-bit offsets), rows of any length and alignment:
+        // lane l's tiles start row_skew() symbols into its row, so that every 128-byte segment a tile load reads is one
+        // whole cache line (a straddling segment costs two: 1.4x the encode time at 65 536 x 4100); what is left of the
+        // row above the highest and below the lowest whole tile goes through LDS in two bulk reads ----
+        bool done = false;
+        if constexpr (TILE_ASM) {
+            const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) -
+                                                 reinterpret_cast<const unsigned char*>(a.words));
+            const bool off_ok = slab_off + 4ull * L.out.cap < 0x100000000ull;
+            // the statement writes whole 64-byte groups: slabs 64-byte aligned and a whole number of groups long
+            const bool groups_ok = (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 && (L.out.cap & 15u) == 0 && L.out.shift == 0;
+            if ((a.flags & CST_KFLAG_TWO_TILES) && aligned_slabs && s0 + kWave <= a.n_streams && N >= 4 * kTileSyms && N < (1u << 24) &&
+                !__any(!off_ok || !groups_ok)) {
+                int32_t* my = tile + lane * kTileStride;
+                // row[p0 .. p0 + cnt) downwards, cnt <= 32 per lane: all reads in flight at once, then the steps from LDS
+                auto ragged = [&](size_t p0, uint32_t cnt) {
+                    uint32_t mx = cnt;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+                    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+                    if (!mx) return;
+                    wave_lds_fence();
+                    {
+                        int32_t r[kTileSyms];
+#pragma unroll
+                        for (int k = 0; k < kTileSyms; ++k) r[k] = ((uint32_t)k < cnt) ? __builtin_nontemporal_load(row + p0 + k) : a.min_symbol;
+#pragma unroll
+                        for (int k = 0; k < kTileSyms; ++k) my[k] = r[k];
+                    }
+                    wave_lds_fence();
+                    int32_t v = my[mx - 1];
+                    for (uint32_t k = mx; k-- > 0;) {
+                        const EncEntry e = entry(enc_index(v, a.min_symbol, nsym, L.bad));
+                        if (k > 0) v = my[k - 1];
+                        if (k < cnt) L.template step<FAST>(e, P);
+                        L.flush_chunks();
+                    }
+                };
+                const uint32_t pre = row_skew(a.symbols, s, N);
+                uint32_t max_pre = pre;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+                max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+                const size_t n_t = (N - max_pre) / kTileSyms;           // whole tiles every lane has (>= 3)
+                const size_t top = pre + n_t * kTileSyms;               // this lane's symbols [top, N) come first: fewer than 64
+                const uint32_t n_top = (uint32_t)(N - top);
+                ragged(top + kTileSyms, n_top > (uint32_t)kTileSyms ? n_top - (uint32_t)kTileSyms : 0u);
+                ragged(top, min(n_top, (uint32_t)kTileSyms));
+                wave_lds_fence();
+                uint32_t goff[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const size_t R = (size_t)(lane >> 3) + 8 * k;
+                    goff[k] = (uint32_t)((R * N + row_skew(a.symbols, s0 + R, N) + 4 * (size_t)(lane & 7)) * 4);
+                }
+                const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_t - 1) * kTileSyms);
+                // wave-uniform base in SGPRs (readfirstlane returns int: go through uint32_t)
+                const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
+                const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+                int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);   // second buffer behind all first ones
+                const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+                const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+                ans_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr,
+                                      L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
+                                      lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_t), goff);
+                L.state = ((uint64_t)hi << 32) | lo;
+                ragged(0, pre);
+                done = true;
+            }
+        }
         // ragged top part [32*n_full, N): direct (uncoalesced) reads, at most 31 symbols per stream
-        for (size_t t = N; t > n_full * kTileSyms;) {
+        for (size_t t = done ? 0 : N; t > n_full * kTileSyms;) {
             --t;
             const int32_t v = active ? row[t] : 0;
             L.template step<FAST>(entry(enc_index(v, a.min_symbol, nsym, L.bad)), P);
             L.flush_chunks();
         }
         if (n_full > 0) {
-            constexpr bool TILE_ASM = FAST && W == 32 && S == 64 && G == 8 && !GLOBAL_TABLE;
-            [[maybe_unused]] int32_t smin = a.min_symbol, smax = a.min_symbol;
-            // wave-uniform: every slab of this wave 16-byte aligned and a whole number of chunks long
-            const bool aligned_slabs = !__any(L.out.shift != 0 || (L.out.cap & 3u) != 0);
-            // ---- main loop as one asm statement (full wave, aligned slabs, 32-bit offsets) ----
-            bool done = false;
-            if constexpr (TILE_ASM) {
-                const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) -
-                                                     reinterpret_cast<const unsigned char*>(a.words));
-                const bool off_ok = slab_off + 4ull * L.out.cap < 0x100000000ull;
-                // the statement writes whole 64-byte groups: slabs 64-byte aligned and a whole number of groups long
-                const bool groups_ok = (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 && (L.out.cap & 15u) == 0 && L.out.shift == 0;
-                if ((a.flags & CST_KFLAG_TWO_TILES) && aligned_slabs && s0 + kWave <= a.n_streams && N < (1u << 24) &&
-                    !__any(!off_ok || !groups_ok)) {
-                    uint32_t goff[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
-                    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
-                    // wave-uniform base in SGPRs (readfirstlane returns int: go through uint32_t)
-                    const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
-                                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-                    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)((uint64_t)L.state >> 32);
-                    const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
-                    int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);   // second buffer behind all first ones
-                    const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
-                    const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-                    ans_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr,
-                                          L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
-                                          lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
-                    L.state = ((uint64_t)hi << 32) | lo;
-                    done = true;
-                }
-            }
             // Symbol tiles are prefetched TWO tiles ahead into two register sets: under full load an HBM round trip is
             // longer than the ~2.4 us one tile takes, and a single tile of lead left ~35 cycles per symbol of vmcnt wait.
             int32_t rA[kTileSyms], rB[kTileSyms];

@@ -935,8 +935,8 @@ def test_large_alphabets_through_the_bucket_entries(B, O, coder, P, n, layout):
 @pytest.mark.parametrize("n_per", [128, 129, 131, 4095, 4100, 4099])
 @pytest.mark.parametrize("base_shift", [0, 1, 3])
 def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift):
-    """The headline decoder's main-loop statement on rows that do not start on cache-line boundaries: every lane decodes the
-    symbols in front of ITS row's next 128-byte boundary first, so that its tiles are whole cache lines (row_skew,
+    """The headline coder's main-loop statements on rows that do not start on cache-line boundaries: every lane codes the
+    symbols in front of ITS row's next 128-byte boundary outside the loop, so that its tiles are whole cache lines (row_skew,
     cst_ans_kernels.hpp).  Row lengths with every residue that matters, symbol buffers that start 4 and 12 bytes off a
     16-byte boundary, full waves plus a partial one; words against the oracle, decoding 70 symbols past the end too."""
     P, n_streams = 12, 200
@@ -944,9 +944,14 @@ def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift):
     model = B.Model.from_cdf(cdf, -50, P)
     sym = O.synth_symbols(n_per, 0, n_streams, n_per, -50, cdf, P)
     want_words, want_n, _ = O.ans_encode_batch(sym, -50, cdf, P)
-    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    src = torch.zeros(n_streams * n_per + 8, dtype=torch.int32, device="cuda")
+    src[base_shift: base_shift + sym.size] = dev(sym).reshape(-1)
+    enc = B.ans_encode(src[base_shift: base_shift + sym.size].view(n_streams, n_per), model, (32, 64, P))
     torch.cuda.synchronize()
     assert enc.n_words.cpu().numpy().tolist() == want_n.tolist()
+    got_words = enc.to_numpy()[0]
+    for i in range(n_streams):
+        assert got_words[i, : want_n[i]].tolist() == want_words[i, : want_n[i]].tolist(), i
     for extra in (0, 70):
         n_dec = n_per + extra
         buf = torch.full((n_streams * n_dec + 8,), -99, dtype=torch.int32, device="cuda")
