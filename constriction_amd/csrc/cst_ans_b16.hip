@@ -49,13 +49,13 @@ constexpr size_t kB16RingBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWav
 constexpr size_t kB16TileWords = (size_t)kWave * kTileStride;
 
 static size_t b16_table_bytes(int n_symbols, int bucket_bits) {
-    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits);
+    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits) + kSubAreaBytes;
 }
 static size_t b16_lds_bytes(int n_symbols, int bucket_bits) {
     return kB16RingBytes + b16_table_bytes(n_symbols, bucket_bits) + 2 * (size_t)(kBlock / kWave) * kB16TileWords * 4 + kTileDumpBytes;
 }
 
-// LDS layout: [word rings, 8 KiB per wave][cdf][bucket entries][symbol tiles A][symbol tiles B][dump rows]
+// LDS layout: [word rings, 8 KiB per wave][cdf][bucket entries][second-level tables][symbol tiles A][symbol tiles B][dump rows]
 template <int LAYOUT>
 __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeArgs a) {
     constexpr bool SM = LAYOUT == CST_LAYOUT_SYMBOL_MAJOR;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     DecLut lut{};
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    const size_t lds_off = stage_decoder_tables<kDecBucket, true>(smem + kB16RingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+    const size_t lds_off = stage_decoder_tables<kDecBucket, true, true>(smem + kB16RingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                                   a.n_symbols, lut, cdf, bucket);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kDecRingSlots * kWave);
     int32_t* tile = reinterpret_cast<int32_t*>(smem + kB16RingBytes + lds_off) + wave_in_block * kB16TileWords;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
                                                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
             const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4);
             ans_decode_b16_tiles_loop_sm(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
-                                         (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)bucket_shift, a.min_symbol, kDecRingMask,
+                                         (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), a.min_symbol, kDecRingMask,
                                          words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lds_addr(ring + lane),
                                          lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,

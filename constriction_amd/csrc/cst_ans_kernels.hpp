@@ -882,7 +882,13 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
         idx = lut.sym ? (uint32_t)(lut.sym[q] - lut.min_symbol) : (uint32_t)lut.idx[q];
     } else {
         if (lut.b16) {
-            const uint4 e = lut.b16[q >> bucket_shift];
+            uint4 e = lut.b16[q >> bucket_shift];
+            if (lut.sub_bits) {             // (uniform) this image has second-level tables: DecLut, cst_common.hpp
+                if (__any(e.y == 0u)) {
+                    const uint32_t part = (q >> (bucket_shift - lut.sub_bits)) & ((1u << lut.sub_bits) - 1u);
+                    if (e.y == 0u) e = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(lut.b16) + e.x + 16u * part);
+                }
+            }
             const uint32_t c0 = e.x & ((1u << lut.idx_shift) - 1u), i0 = e.x >> lut.idx_shift;
             const uint32_t k = (q >= e.y ? 1u : 0u) + (q >= e.z ? 1u : 0u);
             c = k == 0 ? c0 : (k == 1 ? e.y : e.z);
@@ -966,7 +972,8 @@ __device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, c
 }
 
 // Copies the decoder tables selected by MODE into LDS (if LUT_IN_LDS) and returns the bytes used.
-template <int MODE, bool LUT_IN_LDS>
+// SUB: with second-level tables behind the bucket entries (kSubAreaBytes more; every thread of the workgroup must call)
+template <int MODE, bool LUT_IN_LDS, bool SUB = false>
 __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int P, const uint32_t* dec_cp, const uint16_t* dec_idx,
                                                        const uint32_t* g_cdf, const uint16_t* g_bucket, int bucket_bits,
                                                        int n_symbols, DecLut& lut, const uint32_t*& cdf,
@@ -991,12 +998,46 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
             if (bucket16_usable(n_symbols, P)) {
                 uint4* b = reinterpret_cast<uint4*>(smem + lds_off);
                 const uint32_t n = (uint32_t)n_symbols;
+                const int ishift = bucket16_index_shift(n_symbols);
+                auto entry_at = [&](uint32_t i0) {
+                    return make_uint4(g_cdf[i0] | (i0 << ishift), g_cdf[min(i0 + 1u, n)], g_cdf[min(i0 + 2u, n)], g_cdf[min(i0 + 3u, n)]);
+                };
+                const int shift = P - bucket_bits;
+                const int sb = SUB ? min(kSubBitsMax, shift) : 0;
+                uint32_t* ctl = reinterpret_cast<uint32_t*>(smem + lds_off + (size_t)nb * 16 + (size_t)kSubTables * kSubTableBytes);
+                if constexpr (SUB) {
+                    if (threadIdx.x == 0) ctl[0] = 0;
+                    __syncthreads();
+                }
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-                    const uint32_t i0 = g_bucket[i];
-                    b[i] = make_uint4(g_cdf[i0] | (i0 << bucket16_index_shift(n_symbols)), g_cdf[min(i0 + 1u, n)], g_cdf[min(i0 + 2u, n)], g_cdf[min(i0 + 3u, n)]);
+                    uint4 e = entry_at(g_bucket[i]);
+                    if constexpr (SUB) {
+                        // more than three symbols begin in this bucket <=> a quantile of it lies at or above the fourth cumulative
+                        if (sb > 0 && e.w < ((uint32_t)(i + 1) << shift)) {
+                            const uint32_t slot = atomicAdd(&ctl[0], 1u);
+                            if (slot < (uint32_t)kSubTables) {
+                                ctl[4 + slot] = (uint32_t)i;
+                                e = make_uint4((uint32_t)nb * 16u + slot * (uint32_t)kSubTableBytes, 0u, 0u, 0u);
+                            }
+                        }
+                    }
+                    b[i] = e;
                 }
                 lds_off += (size_t)nb * 16;
-                lut.b16 = b; lut.idx_shift = bucket16_index_shift(n_symbols); cdf = c;
+                if constexpr (SUB) {
+                    __syncthreads();            // (the cdf copy `c` is complete, too)
+                    const uint32_t count = min(ctl[0], (uint32_t)kSubTables);
+                    uint4* sub = b + nb;
+                    for (uint32_t t = threadIdx.x; t < (count << sb); t += blockDim.x) {
+                        const uint32_t slot = t >> sb, part = t & ((1u << sb) - 1u);
+                        const uint32_t q0 = (ctl[4 + slot] << shift) + (part << (shift - sb));
+                        uint32_t lo = 0, hi = n;                                   // c[0] = 0 <= q0 < 2^P = c[n]
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (c[mid] <= q0) lo = mid; else hi = mid; }
+                        sub[slot * (kSubTableBytes / 16) + part] = entry_at(lo);
+                    }
+                    lds_off += kSubAreaBytes;
+                }
+                lut.b16 = b; lut.idx_shift = ishift; lut.sub_bits = sb; cdf = c;
             } else {
                 uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];

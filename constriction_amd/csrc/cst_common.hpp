@@ -50,7 +50,18 @@ struct DecLut {      // pointers into LDS or global memory
     // above 22 (<= 1024 symbols, P <= 22).
     const uint4* b16;
     int32_t idx_shift;
+    // Second-level tables (0 = none): a bucket in which MORE than three symbols begin -- the far tails of a distribution: for
+    // the BASELINE Gaussian at P = 24, 22 symbols share bucket 0 -- would send its lanes on a walk over the cdf table, one LDS
+    // round trip per symbol (28 % of the P = 24 decoder's time, all of it in two buckets).  Up to kSubTables such buckets hold
+    //   { byte offset of their table from b16[0], 0, 0, 0 }      (a real entry's second word, cdf[i0 + 1], is never 0)
+    // instead, and the table, 2^sub_bits entries of the same form for the bucket's 2^sub_bits equal parts, is read with the
+    // next sub_bits bits of the quantile: one more round trip, then the selects again.  What still overflows there walks.
+    int32_t sub_bits;
 };
+constexpr int kSubTables = 32;                  // second-level tables per workgroup image
+constexpr int kSubBitsMax = 4;                  // entries per table = 2^min(kSubBitsMax, P - bucket_bits)
+constexpr int kSubTableBytes = 16 << kSubBitsMax;
+constexpr int kSubAreaBytes = kSubTables * kSubTableBytes + 16 + 4 * kSubTables;     // tables, their count, their buckets
 __host__ __device__ inline int bucket16_index_shift(int n_symbols) { return n_symbols <= 256 ? 24 : 22; }
 __host__ __device__ inline bool bucket16_usable(int n_symbols, int P) {
     return (n_symbols <= 256 && P <= 24) || (n_symbols <= 1024 && P <= 22);

@@ -323,7 +323,7 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
 }
 
 static size_t b16_tables_bytes(int n_symbols, int bucket_bits) {
-    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits);
+    return ((((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15) + ((size_t)16 << bucket_bits) + kSubAreaBytes;
 }
 
 // B16: 12 < P <= 24, at most 256 symbols: the lookup is one 16-byte bucket entry (DecLut::b16) instead of the quantile table
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     const uint16_t* bucket = a.bucket;
     size_t table_bytes = kTileLutBytes;
     if constexpr (B16) {
-        table_bytes = stage_decoder_tables<kDecBucket, true>(smem + kRdRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+        table_bytes = stage_decoder_tables<kDecBucket, true, true>(smem + kRdRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                              a.n_symbols, blut, cdf, bucket);
     } else {
         for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {

@@ -59,6 +59,8 @@ class Asm:
         assert n <= 63, (tag, n)
         self.vm = self.vm[len(self.vm) - n:] if n else []
         self.events.append(("wait_vm", tag, n))
+        if os.environ.get("GEN_NO_VMWAIT_ALL"):    # timing experiment only: results are wrong
+            return
         self.i(f"s_waitcnt vmcnt({n})", comment)
 
     def wait_vm_all(self, comment=None):

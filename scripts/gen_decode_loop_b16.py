@@ -17,6 +17,7 @@ workgroup's LDS image at 142 KiB.
 
 Run:  python scripts/gen_decode_loop_b16.py   (rewrites the .inc; the .inc is checked in)
 """
+import os
 import sys
 from pathlib import Path
 
@@ -57,6 +58,7 @@ def gen():
     clobbers = [f"v{r}" for r in range(120, 192)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
     SD, SAVE, V1, V2 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]"
     RET, XSAVE, FLAGGED = "s[70:71]", "s[72:73]", "s[74:75]"
+    SBITS, SSH = "s76", "s77"
 
     def window_requests():
         a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
@@ -93,6 +95,9 @@ def gen():
         a.ds(f"ds_read_b32 {WD}, {RA}", "w")
 
     a.i("v_mov_b32 v123, 0")
+    a.i(f"s_min_u32 {SBITS}, %[bsh], 4", "second-level tables: 2^min(4, P - 11) parts per bucket (kSubBitsMax)")
+    a.i(f"s_sub_u32 {SSH}, %[bsh], {SBITS}")
+    a.i(f"s_bfm_b32 {SBITS}, {SBITS}, 0", "(as a mask)")
     if SYMBOL_MAJOR:
         a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
         a.i(f"v_add_u32 {GOFF[1]}, %[gstride], {GOFF[0]}", "symbol rows + 16")
@@ -119,6 +124,7 @@ def gen():
             a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
         E0, E1, E2, E3 = ESET[j % 2]
         a.wait_lds("e", f"---- step {j}: the bucket entry is back")
+        a.i(f"3{j:02d}:", None)
         a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
         a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
         a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
@@ -127,7 +133,8 @@ def gen():
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
         a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
-        a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare; it also leaves index - 2 in the entry)")
+        if not os.environ.get("GEN_NO_WALK"):       # timing experiment only: results are wrong
+            a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare; it also leaves index - 2 in the entry)")
         a.i(f"2{j:02d}:", None)
         a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
         a.i(f"v_sub_u32 {D}, {Q}, {C}", "q - c")
@@ -181,13 +188,28 @@ def gen():
     for j in range(32):
         a.i(f"1{j:02d}:", None)
         a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
+        a.i(f"s_cbranch_scc1 3{j:02d}b", "second-level entries have landed: the selects again")
         a.i(f"s_branch 2{j:02d}b")
     for st in range(2):
-        E0 = ESET[st][0]
+        E0, E1 = ESET[st][0], ESET[st][1]
         a.i(f"{4 + st}:", None)
         a.i(f"s_mov_b64 {XSAVE}, exec")
         a.i(f"s_mov_b64 {FLAGGED}, vcc")
         a.i("s_mov_b64 exec, vcc")
+        # lanes whose bucket has a second-level table (DecLut, cst_common.hpp: { table offset, 0, 0, 0 }): fetch its entry
+        a.i(f"v_cmp_eq_u32 vcc, 0, {E1}", "(a real entry's cdf[i0 + 1] is never 0)")
+        a.i(f"s_cbranch_vccz {8 + st}f")
+        a.i("s_mov_b64 exec, vcc")
+        a.i(f"v_lshrrev_b32 {TMPA}, {SSH}, {Q}", "which part of the bucket")
+        a.i(f"v_and_b32 {TMPA}, {SBITS}, {TMPA}")
+        a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, {E0}")
+        a.i(f"v_add_u32 {TMPA}, %[lut], {TMPA}")
+        a.i(f"ds_read_b128 {ESET_T[st]}, {TMPA}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"s_mov_b64 exec, {XSAVE}")
+        a.i("s_cmp_eq_u32 s82, s82", "scc = 1: run the selects again")
+        a.i(f"s_setpc_b64 {RET}")
+        a.i(f"{8 + st}:", None)
         a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
         a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
         a.i(f"{6 + st}:", None)
@@ -209,6 +231,7 @@ def gen():
         a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
         a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
         a.i(f"s_mov_b64 exec, {XSAVE}")
+        a.i("s_cmp_lg_u32 s82, s82", "scc = 0")
         a.i(f"s_setpc_b64 {RET}")
     a.i("3:", None)
     a.wait_vm_all("nothing may land in the scratch registers after the statement")

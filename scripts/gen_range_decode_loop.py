@@ -166,6 +166,7 @@ def gen(ends):
             a.i(f"; ---- step {j}")
         if B16:
             E0, E1, E2, E3 = ESET[j % 2]
+            a.i(f"3{j:02d}:", None)
             a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
             a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
             a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}", "beyond the third symbol of the bucket?")
@@ -247,13 +248,31 @@ def gen(ends):
         for j in range(32):
             a.i(f"1{j:02d}:", None)
             a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
+            a.i(f"s_cbranch_scc1 3{j:02d}b", "second-level entries have landed: the selects again")
             a.i(f"s_branch 2{j:02d}b")
         for st in range(2):
-            E0 = ESET[st][0]
+            E0, E1 = ESET[st][0], ESET[st][1]
             a.i(f"{4 + st}:", None)
             a.i(f"s_mov_b64 {XSAVE}, exec")
             a.i(f"s_mov_b64 {FLAGGED}, vcc")
             a.i("s_mov_b64 exec, vcc")
+            # lanes whose bucket has a second-level table (DecLut, cst_common.hpp: { table offset, 0, 0, 0 }): fetch its entry
+            a.i(f"v_cmp_eq_u32 vcc, 0, {E1}", "(a real entry's cdf[i0 + 1] is never 0)")
+            a.i(f"s_cbranch_vccz {8 + st}f")
+            a.i("s_mov_b64 exec, vcc")
+            a.i("s_min_u32 s86, %[bsh], 4", "2^min(4, P - 11) parts per bucket (kSubBitsMax)")
+            a.i("s_sub_u32 s87, %[bsh], s86")
+            a.i("s_bfm_b32 s86, s86, 0", "(as a mask)")
+            a.i(f"v_lshrrev_b32 {TMPA}, s87, {Q}", "which part of the bucket")
+            a.i(f"v_and_b32 {TMPA}, s86, {TMPA}")
+            a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, {E0}")
+            a.i(f"v_add_u32 {TMPA}, %[lut], {TMPA}")
+            a.i(f"ds_read_b128 {ESET_T[st]}, {TMPA}")
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"s_mov_b64 exec, {XSAVE}")
+            a.i("s_cmp_eq_u32 s82, s82", "scc = 1: run the selects again")
+            a.i(f"s_setpc_b64 {RET}")
+            a.i(f"{8 + st}:", None)
             a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
             a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
             a.i(f"{6 + st}:", None)
@@ -275,6 +294,7 @@ def gen(ends):
             a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
             a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
             a.i(f"s_mov_b64 exec, {XSAVE}")
+            a.i("s_cmp_lg_u32 s82, s82", "scc = 0")
             a.i(f"s_setpc_b64 {RET}")
         a.i("3:", None)
     return a

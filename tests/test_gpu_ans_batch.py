@@ -1013,3 +1013,46 @@ def test_symbol_major_main_loops(B, O):
     torch.cuda.synchronize()
     st = enc.status.cpu().numpy()
     assert st[70] == 1 and (np.delete(st, 70) == 0).all()
+
+
+def _clustered_cdf(n_sym, P, cluster, period, rng):
+    """runs of `cluster` symbols of probability 1 / 2^P between symbols that share the rest: every run lies inside one bucket
+    of 2^(P - 11) quantiles, far more than the three symbols a bucket entry resolves"""
+    probs = np.ones(n_sym, dtype=np.int64)
+    big = np.arange(0, n_sym, period)
+    rest = (1 << P) - n_sym
+    share = rng.multinomial(rest, rng.dirichlet(np.ones(len(big)) * 2.0))
+    probs[big] += share
+    assert probs.sum() == 1 << P and cluster < period
+    return np.concatenate([[0], np.cumsum(probs)]).astype(np.uint32)
+
+
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("P,n_sym,period", [(24, 256, 32), (24, 250, 5), (22, 1024, 8), (16, 700, 7), (14, 200, 4), (13, 256, 16)])
+def test_second_level_tables(B, O, coder, P, n_sym, period):
+    """Buckets in which more than three symbols begin (DecLut::sub_bits, cst_common.hpp): runs of minimal-probability symbols
+    in the MIDDLE of the distribution, a few of them (every such bucket gets a second-level table) or hundreds (the first 32
+    get one, the others walk the cdf table); symbols drawn so that the runs are hit far more often than their mass says.
+    Main-loop statements (200 full-wave streams of 32 k + 7 symbols) against the oracle's words and symbols."""
+    rng = np.random.default_rng(P * 1000 + n_sym)
+    cdf = _clustered_cdf(n_sym, P, period - 1, period, rng)
+    lo = -(n_sym // 2)
+    model = B.Model.from_cdf(cdf, lo, P)
+    n_streams, n_per = 200, 32 * 8 + 4
+    sym = O.synth_symbols(P, 0, n_streams, n_per, lo, cdf, P)
+    tiny = rng.integers(0, n_sym, size=sym.shape).astype(np.int32) + lo               # uniform over symbols: mostly the tiny ones
+    sym = np.where(rng.random(sym.shape) < 0.3, tiny, sym).astype(np.int32)
+    if coder == "ans":
+        want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+        enc = B.ans_encode(dev(sym), model, (32, 64, P))
+        dec, st = B.ans_decode(enc, model, n_per)
+    else:
+        want_words, want_n, _ = O.rc_encode_batch(sym, lo, cdf, P)
+        enc = B.range_encode(dev(sym), model, (32, 64, P))
+        dec, st = B.range_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), s
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
