@@ -137,9 +137,18 @@ __device__ inline double erf_exact(double x) {
 // the erfc branches run straight-line (their arguments are bounded there).  Same operations in the same order as
 // erf_exact on every path, hence the same bits; tests/test_gpu_ans_batch.py compares both with the CPU oracle.
 
-constexpr int kErfTabEntries = 4 * 9;             // [branch][k] -> {numerator[k], denominator[k]}
+constexpr int kErfExactEntries = 4 * 9;           // [branch][k] -> {numerator[k], denominator[k]}
+// ... followed by the polynomials of the FAST evaluation (erf_fast_poly below): kErfPolyRows rows of 8 coefficients, one row
+// every 80 bytes (the four 16-byte reads of a lane then start in one of 16 bank groups instead of 4)
+constexpr int kErfPolyRows = 96, kErfPolyRowD2 = 5;
+constexpr int kErfTabEntries = kErfExactEntries + kErfPolyRows * kErfPolyRowD2;      // double2 entries of the LDS image (8256 bytes)
+constexpr size_t kErfTabBytes = 9 * 1024;         // what a kernel with dynamic LDS sets aside for it
 
-__device__ const double kErfTabInit[kErfTabEntries * 2] = {
+__device__ const double kErfPolyInit[kErfPolyRows * 8] = {
+#include "cst_erf_poly.inc"
+};
+
+__device__ const double kErfTabInit[kErfExactEntries * 2] = {
     // |x| < 0.84375: pp / qq in z = x * x
     1.28379167095512558561e-01, 1.0, -3.25042107247001499370e-01, 3.97917223959155352819e-01,
     -2.84817495755985104766e-02, 6.50222499887672944485e-02, -5.77027029648944159157e-03, 5.08130628187576562776e-03,
@@ -164,7 +173,9 @@ __device__ const double kErfTabInit[kErfTabEntries * 2] = {
 
 // every thread of the block calls this once (then __syncthreads, or a wave fence if `tab` is private to the wave)
 __device__ __forceinline__ void erf_tab_fill(double2* tab, int tid, int n_threads) {
-    for (int i = tid; i < kErfTabEntries; i += n_threads) tab[i] = make_double2(kErfTabInit[2 * i], kErfTabInit[2 * i + 1]);
+    for (int i = tid; i < kErfExactEntries; i += n_threads) tab[i] = make_double2(kErfTabInit[2 * i], kErfTabInit[2 * i + 1]);
+    double* rows = reinterpret_cast<double*>(tab + kErfExactEntries);
+    for (int i = tid; i < kErfPolyRows * 8; i += n_threads) rows[(i >> 3) * (2 * kErfPolyRowD2) + (i & 7)] = kErfPolyInit[i];
 }
 
 // exp_exact for 2^-28 < |x| < 700, without branches: k == 0 multiplies by 2^0, lo == 0.0 subtracts nothing
@@ -223,14 +234,15 @@ __device__ inline double erf_exact_tab(double x, const double2* tab) {
 // ------------------------------------------------------------------------------------------------
 // FAST erf with an exact fallback.  What the coders need from the Gaussian CDF is ONE integer, trunc(free_weight * cdf):
 // the reference's value of it changes only when free_weight * cdf crosses an integer.  So the per-symbol kernels evaluate
-// erf the cheap way first -- the same msun rational approximations, but with fused multiply-adds, divisions by a
-// Newton-refined v_rcp_f64 and ONE exp of -x^2 + R/S - 0.5625 instead of msun's split pair -- which is within
-// kErfFastBound of erf_exact (a few 1e-16 in practice: tests/test_gpu_ans_batch.py::test_fast_erf_error_bound measures
-// it), and fall back to erf_exact only where free_weight * cdf lands within kLeftGuard of an integer, i.e. where the
-// deviation could change the truncation (about two evaluations in a million).  The result is the reference's integer in
-// every case; the cost drops from ~290 to ~100 instructions per evaluation.
+// erf the cheap way first -- a polynomial of degree 7 per interval of width 1/16 (scripts/gen_erf_poly.py; 15 VALU
+// instructions and four 16-byte LDS reads; within 2^-52 of erf, tests/test_models_cpu.py replays it on the CPU and
+// tests/test_gpu_ans_batch.py::test_fast_erf_error_bound measures the device) -- and fall back to erf_exact only where
+// free_weight * cdf lands within kLeftGuard of an integer, i.e. where the deviation could change the truncation (about two
+// evaluations in a million).  The result is the reference's integer in every case; the cost drops from ~290 (exact) to ~30
+// instructions per evaluation.  (Round 3's first fast path kept msun's rational approximations with fused operations,
+// Newton reciprocals and one exp: ~100 instructions, and the per-symbol encoder was bound by them.)
 
-constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_tab - erf_exact_tab|
+constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_poly - erf_exact_tab|
 constexpr double kLeftGuard = 0x1p-20;       // >= 2^24 * kErfFastBound / 2 + rounding of the two products, with room to spare
 
 // 1 / b to ~1 ulp without the IEEE division sequence (v_rcp_f64 is good to 2^-24 on gfx950: two Newton steps)
@@ -247,61 +259,22 @@ __device__ __forceinline__ double fast_div(double a, double b) {
     return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
-// exp(x) for -745 < x <= 0 to ~2 ulp: x = k ln2 + r, |r| <= ln2 / 2, exp(r) by its Taylor polynomial of degree 13
-// (remainder < 2e-17 relative), scaled by ldexp -- no division, no branches
-__device__ __forceinline__ double fast_exp_neg(double x) {
-    constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
-    const double kd = __builtin_rint(x * invln2);
-    const double r = __builtin_fma(-kd, ln2lo, __builtin_fma(-kd, ln2hi, x));
-    double p = 1.0 / 6227020800.0;                       // 1 / 13!
-    p = __builtin_fma(p, r, 1.0 / 479001600.0);
-    p = __builtin_fma(p, r, 1.0 / 39916800.0);
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)kd);           // (k >= -1075: gradual underflow like scalbn)
-}
-
-__device__ inline double erf_fast_tab(double x, const double2* tab) {
-    constexpr double erx = 8.45062911510467529297e-01, efx8 = 1.02703333676410069053e+00;
-    const uint32_t hx = f64_hi(x), ix = hx & 0x7fffffffu;
-    const bool neg = (hx >> 31) != 0;
-    const double ax = fabs(x);
-    const uint32_t branch = (ix >= 0x3feb0000u ? 1u : 0u) + (ix >= 0x3ff40000u ? 1u : 0u) + (ix >= 0x4006db6du ? 1u : 0u);
-    const bool tail = ix >= 0x3ff40000u && ix < 0x40180000u;        // 1.25 <= |x| < 6
-    const double2* c = tab + branch * 9;
-    double2 t[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = c[k];
-    const double x2 = ax * ax;
-    const double inv_x2 = fast_rcp(tail ? x2 : 1.0);               // (only the tail uses it: s = 1 / x^2, 1 / x = x s)
-    double s = branch == 0 ? x2 : ax - 1.0;
-    if (tail) s = inv_x2;
-    double num = t[8].x, den = t[8].y;
-#pragma unroll
-    for (int k = 7; k >= 0; --k) { num = __builtin_fma(s, num, t[k].x); den = __builtin_fma(s, den, t[k].y); }
-    const double quot = num * fast_rcp(den);
-    double y = 1.0 - ((1.0 - erx) - quot);                          // 0.84375 <= |x| < 1.25
-    if (tail) {
-        // erfc(x) = exp(-x^2 - 0.5625 + R/S) / x with x^2 = x2 + x2_lo exactly
-        const double x2_lo = __builtin_fma(ax, ax, -x2);
-        const double e = fast_exp_neg((quot - 0.5625) - x2 - x2_lo);
-        y = __builtin_fma(-e, ax * inv_x2, 1.0);
-    }
-    if (ix >= 0x40180000u) y = 1.0 - 0x1p-1022;
-    y = neg ? -y : y;
-    if (ix < 0x3feb0000u) y = __builtin_fma(x, quot, x);
-    if (ix < 0x3e300000u) y = 0.125 * (8.0 * x + efx8 * x);
-    if (x != x) y = x;
-    return y;
+// erf(x) to 2^-52 (absolute) for every finite x; |x| >= 6 evaluates the last polynomial at its upper end (1 - 2e-17).
+// A NaN comes back as +-1: callers that care test the argument (leaky_left_value_quick does).
+__device__ __forceinline__ double erf_fast_poly(double x, const double2* tab) {
+    const double s = __builtin_fmin(__builtin_fabs(x) * 16.0, 0x1.7ffffffffffffp+6);     // interval number + position in it, < 96
+    const int idx = (int)s;
+    const double u = __builtin_fma(__builtin_amdgcn_fract(s), 2.0, -1.0);
+    const double2* row = tab + kErfExactEntries + idx * kErfPolyRowD2;
+    const double2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
+    double y = __builtin_fma(c67.y, u, c67.x);
+    y = __builtin_fma(y, u, c45.y);
+    y = __builtin_fma(y, u, c45.x);
+    y = __builtin_fma(y, u, c23.y);
+    y = __builtin_fma(y, u, c23.x);
+    y = __builtin_fma(y, u, c01.y);
+    y = __builtin_fma(y, u, c01.x);
+    return __builtin_copysign(y, x);
 }
 
 // probability::distribution::Gaussian::distribution (third-party; used at quantize.rs:546,558)
@@ -358,20 +331,22 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left(int32_t i, int32_t lo, i
 }
 
 // The integer trunc(free_weight * cdf(x)) + slack through the fast erf, with the exact evaluation wherever the truncation
-// could depend on the difference (see erf_fast_tab).  `inv_d` ~ 1 / (sigma sqrt 2): the fast path's argument
+// could depend on the difference (see erf_fast_poly).  `inv_d` ~ 1 / (sigma sqrt 2): the fast path's argument
 // (x - mu) inv_d is within a few ulp of the reference's (x - mu) / (sigma sqrt 2) -- part of the same error budget; the
 // fallback forms the reference's argument with the reference's three operations.  `n_exact` (optional) counts fallbacks.
 __device__ __forceinline__ uint32_t leaky_left_value_quick(double x, double mu, double sigma, double inv_d, double free_weight,
                                                            const double2* tab, uint32_t* n_exact) {
     constexpr double sqrt2 = 1.41421356237309504880168872420969808;
     const double arg = (x - mu) * inv_d;
-    double y = free_weight * ((1.0 + erf_fast_tab(arg, tab)) / 2.0);
-    const double fr = y - __builtin_floor(y);
+    const double half = 0.5 * free_weight;
+    double y = __builtin_fma(erf_fast_poly(arg, tab), half, half);             // free_weight (1 + erf) / 2, one rounding
+    const double fr = __builtin_amdgcn_fract(y);                               // (y >= 0)
     // |arg| >= 6: erf is +-1 in both evaluations (the exact one rounds to +-1 from 5.87 on), no doubt there although
     // free_weight * cdf is then an exact integer.  A NaN argument (sigma sqrt 2 overflowed or is subnormal: the reciprocal
-    // broke down) is always in doubt.
-    const bool same = (f64_hi(arg) & 0x7fffffffu) >= 0x40180000u && arg == arg;
-    const bool unsure = !same && !(fr > kLeftGuard && fr < 1.0 - kLeftGuard);
+    // broke down) is always in doubt: it fails both tests.
+    const bool same = __builtin_fabs(arg) >= 6.0;
+    const bool sure = __builtin_fabs(fr - 0.5) < 0.5 - kLeftGuard;
+    const bool unsure = !(same || sure);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
         if (unsure) {
             y = free_weight * ((1.0 + erf_exact_tab((x - mu) / (sigma * sqrt2), tab)) / 2.0);

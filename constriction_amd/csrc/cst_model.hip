@@ -199,14 +199,14 @@ __global__ void debug_erf_tab_kernel(const double* __restrict__ x, double* __res
     if (i < n) out[i] = erf_exact_tab(x[i], tab);
 }
 
-// which: 0 erf_fast_tab(x) -> out; 1 |erf_fast_tab - erf_exact_tab| -> out
+// which: 0 erf_fast_poly(x) -> out; 1 |erf_fast_poly - erf_exact_tab| -> out
 __global__ void debug_erf_fast_kernel(int which, const double* __restrict__ x, double* __restrict__ out, size_t n) {
     __shared__ double2 tab[kErfTabEntries];
     erf_tab_fill(tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double f = erf_fast_tab(x[i], tab);
+    const double f = erf_fast_poly(x[i], tab);
     out[i] = which == 0 ? f : fabs(f - erf_exact_tab(x[i], tab));
 }
 

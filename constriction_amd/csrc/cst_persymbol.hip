@@ -277,7 +277,7 @@ constexpr int kFuRingSlots = 32;
 constexpr int kFuAhead = 4;                               // items requested ahead of their use (kFuIters % kFuAhead == 0)
 constexpr int kFuRowStride = kFuStreams + 1;              // entries: row t of the tile starts at t * kFuRowStride (conflict-free both ways)
 constexpr int kFuBlock = 256;
-constexpr size_t kFuTabBytes = 1024;                      // the erf coefficient table (576 bytes), padded
+constexpr size_t kFuTabBytes = kErfTabBytes;              // the erf tables (cst_math.hpp)
 constexpr size_t kFuWaveBytes = (size_t)kFuRingSlots * kWave * 4 + (size_t)kFuTile * kFuRowStride * sizeof(EncEntry);
 
 struct GaussianFusedArgs {
@@ -751,7 +751,7 @@ constexpr int kParTile = 16;
 constexpr int kParStride = kWave + 1;                 // doubles per tile row: conflict-free writes (stream-major) and reads
 constexpr int kWordWindow = 32;                       // slots per stream, position p lives in slot p % 32
 constexpr size_t kLaneDecWaveBytes = (size_t)kWave * kTileStride * 4 + 2 * (size_t)kParTile * kParStride * 8 + (size_t)kWordWindow * kWave * 4;
-constexpr size_t kLaneDecLdsBytes = 1024 + (size_t)(kBlock / kWave) * kLaneDecWaveBytes;
+constexpr size_t kLaneDecLdsBytes = kErfTabBytes + (size_t)(kBlock / kWave) * kLaneDecWaveBytes;
 
 template <int W, int S, int KIND>
 __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerSymbolDecodeArgs a) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    unsigned char* mine = smem + 1024 + (size_t)(threadIdx.x >> 6) * kLaneDecWaveBytes;
+    unsigned char* mine = smem + kErfTabBytes + (size_t)(threadIdx.x >> 6) * kLaneDecWaveBytes;
     int32_t* tile = reinterpret_cast<int32_t*>(mine);
     double* par_mu = reinterpret_cast<double*>(mine + (size_t)kWave * kTileStride * 4);
     double* par_sd = par_mu + kParTile * kParStride;

@@ -139,3 +139,4 @@ def test_packed_batch_container_roundtrip(tmp_path):
     (tmp_path / "preset.cst").write_bytes(bytes(body))
     with pytest.raises(ValueError):
         container.load(tmp_path / "preset.cst")
+
