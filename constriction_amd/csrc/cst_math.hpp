@@ -252,6 +252,20 @@ __device__ __forceinline__ double fast_rcp(double b) {
     return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
 }
 
+// 1 / b to 2^-48 (one Newton step): enough wherever the consumer has slack of its own -- the argument of the fast erf (an
+// argument off by 2^-48 moves erf by < 2^-49), quotients that are corrected by their exact remainder
+__device__ __forceinline__ double fast_rcp1(double b) {
+    const double r = __builtin_amdgcn_rcp(b);
+    return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+
+// Rust's `f64 as u32` in one instruction: v_cvt_u32_f64 truncates, saturates at both ends and turns a NaN into 0
+__device__ __forceinline__ uint32_t f64_as_u32_hw(double v) {
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // a / b with a residual correction (the host-style use in make_entry_f64 wants the last ulp or so)
 __device__ __forceinline__ double fast_div(double a, double b) {
     const double r = fast_rcp(b);
@@ -353,7 +367,7 @@ __device__ __forceinline__ uint32_t leaky_left_value_quick(double x, double mu, 
             if (n_exact) ++*n_exact;
         }
     }
-    return f64_as_u32_sat(y);
+    return f64_as_u32_hw(y);
 }
 
 // leaky_gaussian_left, quick.  Bit-identical to leaky_gaussian_left<true> for every input.  INNER: the caller guarantees
@@ -370,26 +384,46 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t
     const uint32_t max_prob = pmask >> (prob_bits - P);
     const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
     const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
-    return (leaky_left_value_quick(x, mu, sigma, fast_rcp(sigma * sqrt2), free_weight, tab, n_exact) + (uint32_t)i) & pmask;
+    return (leaky_left_value_quick(x, mu, sigma, fast_rcp1(sigma * sqrt2), free_weight, tab, n_exact) + (uint32_t)i) & pmask;
 }
 
-// left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp); one reciprocal
-// serves both ends of the bin
+// left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp), BOTH ends of the bin in
+// one straight line: one reciprocal, the eight LDS reads of the two polynomials in flight together, one test for the rare
+// exact evaluation.  A symbol outside [lo, hi] is evaluated as `lo` and reported by the return value (no divergent early exit:
+// one model per lane).
 __device__ __forceinline__ bool leaky_gaussian_lcp_quick(int32_t sym, int32_t lo, int32_t hi, int P, int prob_bits, double mu, double sigma,
                                                          uint32_t& left, uint32_t& prob, const double2* tab) {
-    if (sym < lo || sym > hi) return false;
     constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    const bool inside = sym >= lo && sym <= hi;
+    const int32_t sc = inside ? sym : lo;
     const uint32_t pmask = prob_bits >= 32 ? 0xffffffffu : ((1u << prob_bits) - 1u);
     const uint32_t max_prob = pmask >> (prob_bits - P);
     const double free_weight = (double)(max_prob - ((uint32_t)hi - (uint32_t)lo));
-    const uint32_t slack = ((uint32_t)sym - (uint32_t)lo) & pmask;
-    const double inv_d = fast_rcp(sigma * sqrt2);
-    uint32_t l = 0u, r = (P >= 32 ? 0u : (1u << P)) & pmask;
-    if (sym != lo) l = (leaky_left_value_quick((double)sym - 0.5, mu, sigma, inv_d, free_weight, tab, nullptr) + slack) & pmask;
-    if (sym != hi) r = (leaky_left_value_quick((double)sym + 0.5, mu, sigma, inv_d, free_weight, tab, nullptr) + slack + 1u) & pmask;
+    const double half = 0.5 * free_weight;
+    const uint32_t slack = ((uint32_t)sc - (uint32_t)lo) & pmask;
+    const double inv_d = fast_rcp1(sigma * sqrt2);
+    const double xl = (double)sc - 0.5, xr = (double)sc + 0.5;
+    const double al = (xl - mu) * inv_d, ar = (xr - mu) * inv_d;
+    double yl = __builtin_fma(erf_fast_poly(al, tab), half, half), yr = __builtin_fma(erf_fast_poly(ar, tab), half, half);
+    // in doubt (see leaky_left_value_quick): not saturated and within kLeftGuard of an integer -- or a NaN argument
+    const bool unsure_l = !(__builtin_fabs(al) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(yl) - 0.5) < 0.5 - kLeftGuard) && sc != lo;
+    const bool unsure_r = !(__builtin_fabs(ar) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(yr) - 0.5) < 0.5 - kLeftGuard) && sc != hi;
+    if (__builtin_amdgcn_ballot_w64(unsure_l || unsure_r) != 0ull) {
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const bool u = side ? unsure_r : unsure_l;
+            if (__builtin_amdgcn_ballot_w64(u) == 0ull) continue;
+            if (u) {
+                const double y = free_weight * ((1.0 + erf_exact_tab(((side ? xr : xl) - mu) / (sigma * sqrt2), tab)) / 2.0);
+                if (side) yr = y; else yl = y;
+            }
+        }
+    }
+    const uint32_t l = sc == lo ? 0u : (f64_as_u32_hw(yl) + slack) & pmask;
+    const uint32_t r = sc == hi ? ((P >= 32 ? 0u : (1u << P)) & pmask) : (f64_as_u32_hw(yr) + slack + 1u) & pmask;
     left = l;
     prob = (r - l) & pmask;
-    return true;
+    return inside;
 }
 
 } // namespace cst

@@ -298,30 +298,35 @@ struct GaussianFusedArgs {
 // floor(2^64 / p) for 2 <= p <= 2^24 through two f64 quotients, each corrected by its exact remainder:
 // 2^64 / p = 2^32 q1 + 2^32 r1 / p with q1 = floor(2^32 / p), r1 = 2^32 - q1 p
 __device__ __forceinline__ EncEntry make_entry_f64(uint32_t c, uint32_t p) {
-    if (p <= 1u) return EncEntry{c, p, p ? 0xffffffffu : 0u, p ? 0xffffffffu : 0u};
-    const double inv = fast_rcp((double)p);
-    uint32_t q1 = (uint32_t)(4294967296.0 * inv);                       // within one of floor(2^32 / p)
-    int64_t r1 = (int64_t)(1ull << 32) - (int64_t)((uint64_t)q1 * p);
-    if (r1 < 0) { q1 -= 1u; r1 += p; }
-    else if (r1 >= (int64_t)p) { q1 += 1u; r1 -= p; }
-    const uint64_t x2 = (uint64_t)r1 << 32;                             // < 2^56: exact as a double
-    uint32_t q2 = (uint32_t)((double)x2 * inv);
-    int64_t r2 = (int64_t)x2 - (int64_t)((uint64_t)q2 * p);
-    if (r2 < 0) q2 -= 1u;
-    else if (r2 >= (int64_t)p) q2 += 1u;
-    return EncEntry{c, p, q2, q1};
+    // straight line (one model per lane: a branch would be taken by some lane every time); p <= 1 is patched in at the end
+    const uint32_t pp = p > 1u ? p : 2u;
+    const double inv = fast_rcp1((double)pp);                           // 2^-48: both quotients below are within one
+    uint32_t q1 = f64_as_u32_hw(4294967296.0 * inv);
+    int64_t r1 = (int64_t)(1ull << 32) - (int64_t)((uint64_t)q1 * pp);
+    const uint32_t dn1 = r1 < 0 ? 1u : 0u, up1 = r1 >= (int64_t)pp ? 1u : 0u;
+    q1 = q1 - dn1 + up1;
+    const uint32_t r1u = (uint32_t)r1 + (dn1 ? pp : 0u) - (up1 ? pp : 0u);          // 0 <= r1 < p now
+    const double x2 = __builtin_amdgcn_ldexp((double)r1u, 32);         // < 2^56: exact as a double
+    uint32_t q2 = f64_as_u32_hw(x2 * inv);
+    const int64_t r2 = (int64_t)((uint64_t)r1u << 32) - (int64_t)((uint64_t)q2 * pp);
+    q2 = q2 - (r2 < 0 ? 1u : 0u) + (r2 >= (int64_t)pp ? 1u : 0u);
+    const uint32_t ones = p ? 0xffffffffu : 0u;
+    return EncEntry{c, p, p > 1u ? q2 : ones, p > 1u ? q1 : ones};
 }
 
 template <int W, int S, int KIND>
 __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const GaussianFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double2* erf_tab = reinterpret_cast<double2*>(smem);
+    const int lane = threadIdx.x & (kWave - 1), wave_in_block = threadIdx.x >> 6;
+    // LDS: [word rings, one per wave, aligned to their size: the hand-scheduled step forms slot addresses with and/or]
+    //      [erf tables][entry tiles, one per wave]
+    constexpr size_t kRingBytes = (size_t)kFuRingSlots * kWave * 4;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + (size_t)wave_in_block * kRingBytes);
+    double2* erf_tab = reinterpret_cast<double2*>(smem + (kFuBlock / kWave) * kRingBytes);
+    EncEntry* tile = reinterpret_cast<EncEntry*>(smem + (kFuBlock / kWave) * kRingBytes + kFuTabBytes + (size_t)wave_in_block * (kFuWaveBytes - kRingBytes));
+    if ((lds_addr(ring) & (uint32_t)(kRingBytes - 1)) != 0) __builtin_trap();
     erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave_in_block = threadIdx.x >> 6;
-    unsigned char* mine = smem + kFuTabBytes + (size_t)wave_in_block * kFuWaveBytes;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(mine);
-    EncEntry* tile = reinterpret_cast<EncEntry*>(mine + (size_t)kFuRingSlots * kWave * 4);
     const size_t s0 = ((size_t)blockIdx.x * (kFuBlock / kWave) + wave_in_block) * kFuStreams;
     if (s0 >= a.n_streams) return;
     const size_t N = a.n_per_stream;
@@ -389,11 +394,11 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
                 else if (step + 1 < n_tiles) request(q, tile_of(step + 1), it + kFuAhead - kFuIters);
                 uint32_t c = 0, p = 0;
                 // `assert!(std > 0.0)` and finite parameters (pybindings/stream/model.rs:654-657); out-of-support symbols
-                // (quantize.rs:537-539) and degenerate distributions (quantize.rs:562-565) all end up with p = 0 = impossible
-                if (sg > 0.0 && sg <= 1.7976931348623157e308 && fabs(m) <= 1.7976931348623157e308) {
-                    if (!leaky_gaussian_lcp_quick(sy, a.lo, a.hi, P, 32, m, sg, c, p, erf_tab)) p = 0;
-                }
-                if ((uint64_t)c + p > ((uint64_t)1 << P)) p = 0;
+                // (quantize.rs:537-539) and degenerate distributions (quantize.rs:562-565) all end up with p = 0 = impossible.
+                // No branches: invalid parameters are evaluated as (0, 1) and thrown away.
+                const bool valid = sg > 0.0 && sg <= 1.7976931348623157e308 && fabs(m) <= 1.7976931348623157e308;
+                const bool inside = leaky_gaussian_lcp_quick(sy, a.lo, a.hi, P, 32, valid ? m : 0.0, valid ? sg : 1.0, c, p, erf_tab);
+                if (!valid || !inside || (uint64_t)c + p > ((uint64_t)1 << P)) p = 0;
                 tile[item_t(it) * kFuRowStride + item_j(it)] = make_entry_f64(c, p);
             }
         }
@@ -403,10 +408,26 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
         const int n_here = (int)(N - t0 < (size_t)kFuTile ? N - t0 : (size_t)kFuTile);
         if (active) {
             if constexpr (KIND == kAns) {
-                for (int tl = n_here - 1; tl >= 0; --tl) {
-                    const EncEntry e = tile[tl * kFuRowStride + lane];
-                    if (e.p == 0) bad = 1;
-                    else if (!bad) LA.template step<false>(e, P);
+                constexpr bool FAST = W == 32 && S == 64;            // the 32-bit-halves step (8 <= P)
+                if (FAST && P >= 8 && n_here == kFuTile) {
+                    // a whole tile: all sixteen entries first (one LDS wait), then sixteen hand-scheduled steps.  An
+                    // impossible symbol is coded as (0, 1) -- its stream is flagged and its words are never used.
+                    EncEntry e[kFuTile];
+#pragma unroll
+                    for (int tl = 0; tl < kFuTile; ++tl) e[tl] = tile[tl * kFuRowStride + lane];
+#pragma unroll
+                    for (int tl = kFuTile - 1; tl >= 0; --tl) {
+                        const bool none = e[tl].p == 0;
+                        bad |= none ? 1u : 0u;
+                        const EncEntry f{none ? 0u : e[tl].c, none ? 1u : e[tl].p, none ? 0xffffffffu : e[tl].m_lo, none ? 0xffffffffu : e[tl].m_hi};
+                        LA.template step<FAST>(f, P);
+                    }
+                } else {
+                    for (int tl = n_here - 1; tl >= 0; --tl) {
+                        const EncEntry e = tile[tl * kFuRowStride + lane];
+                        if (e.p == 0) bad = 1;
+                        else if (!bad) LA.template step<false>(e, P);
+                    }
                 }
             } else {
                 for (int tl = 0; tl < n_here; ++tl) {
