@@ -344,6 +344,13 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left(int32_t i, int32_t lo, i
     return (f64_as_u32_sat(free_weight * gaussian_cdf_exact<TAB>(x, mu, sigma, tab)) + (uint32_t)i) & pmask;
 }
 
+// The exact evaluation of one left cumulative's f64 value, out of line: the quick paths call it for about two evaluations in
+// a million, and inlined into each of them it was most of their code
+static __device__ __attribute__((noinline)) double leaky_left_f64_exact(double x, double mu, double sigma, double free_weight, const double2* tab) {
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    return free_weight * ((1.0 + erf_exact_tab((x - mu) / (sigma * sqrt2), tab)) / 2.0);
+}
+
 // The integer trunc(free_weight * cdf(x)) + slack through the fast erf, with the exact evaluation wherever the truncation
 // could depend on the difference (see erf_fast_poly).  `inv_d` ~ 1 / (sigma sqrt 2): the fast path's argument
 // (x - mu) inv_d is within a few ulp of the reference's (x - mu) / (sigma sqrt 2) -- part of the same error budget; the
@@ -363,7 +370,7 @@ __device__ __forceinline__ uint32_t leaky_left_value_quick(double x, double mu, 
     const bool unsure = !(same || sure);
     if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
         if (unsure) {
-            y = free_weight * ((1.0 + erf_exact_tab((x - mu) / (sigma * sqrt2), tab)) / 2.0);
+            y = leaky_left_f64_exact(x, mu, sigma, free_weight, tab);
             if (n_exact) ++*n_exact;
         }
     }
@@ -385,6 +392,38 @@ __device__ __forceinline__ uint32_t leaky_gaussian_left_quick(int32_t i, int32_t
     const double free_weight = (double)(max_prob - (uint32_t)(n - 1));
     const double x = (double)(int32_t)((uint32_t)lo + (uint32_t)i) - 0.5;
     return (leaky_left_value_quick(x, mu, sigma, fast_rcp1(sigma * sqrt2), free_weight, tab, n_exact) + (uint32_t)i) & pmask;
+}
+
+// Three consecutive left cumulatives at once, indices g - 1, g, g + 1 with 1 <= g <= n - 1 (a decoder's first look around
+// its guess): one reciprocal, twelve LDS reads in flight together, one test for the exact evaluation.  Bit-identical to
+// leaky_gaussian_left<true> at the three indices.
+__device__ __forceinline__ void leaky_gaussian_left3_quick(uint32_t g, int32_t lo, uint32_t n, int P, double mu, double sigma,
+                                                           const double2* tab, uint32_t (&v)[3]) {
+    constexpr double sqrt2 = 1.41421356237309504880168872420969808;
+    const uint32_t total = P >= 32 ? 0u : (1u << P);
+    const double free_weight = (double)((total - 1u) - (n - 1u));
+    const double half = 0.5 * free_weight;
+    const double inv_d = fast_rcp1(sigma * sqrt2);
+    const double x1 = (double)(int32_t)((uint32_t)lo + g) - 0.5;
+    const double x[3] = {x1 - 1.0, x1, x1 + 1.0};
+    double y[3];
+    bool unsure[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double arg = (x[k] - mu) * inv_d;
+        y[k] = __builtin_fma(erf_fast_poly(arg, tab), half, half);
+        unsure[k] = !(__builtin_fabs(arg) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(y[k]) - 0.5) < 0.5 - kLeftGuard);
+    }
+    unsure[0] = unsure[0] && g > 1u;                 // (index 0 and index n are not evaluated: 0 and 2^P)
+    unsure[2] = unsure[2] && g + 1u < n;
+    if (__builtin_amdgcn_ballot_w64(unsure[0] || unsure[1] || unsure[2]) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (unsure[k]) y[k] = leaky_left_f64_exact(x[k], mu, sigma, free_weight, tab);
+    }
+    v[0] = g > 1u ? f64_as_u32_hw(y[0]) + (g - 1u) : 0u;
+    v[1] = f64_as_u32_hw(y[1]) + g;
+    v[2] = g + 1u < n ? f64_as_u32_hw(y[2]) + (g + 1u) : total;
 }
 
 // left_cumulative_and_probability through the quick evaluation (same contract as leaky_gaussian_lcp), BOTH ends of the bin in
@@ -414,7 +453,7 @@ __device__ __forceinline__ bool leaky_gaussian_lcp_quick(int32_t sym, int32_t lo
             const bool u = side ? unsure_r : unsure_l;
             if (__builtin_amdgcn_ballot_w64(u) == 0ull) continue;
             if (u) {
-                const double y = free_weight * ((1.0 + erf_exact_tab(((side ? xr : xl) - mu) / (sigma * sqrt2), tab)) / 2.0);
+                const double y = leaky_left_f64_exact(side ? xr : xl, mu, sigma, free_weight, tab);
                 if (side) yr = y; else yl = y;
             }
         }

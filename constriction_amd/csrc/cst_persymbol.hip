@@ -920,6 +920,21 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
                     uint32_t lo_i = 0, hi_i = n, lo_v = 0, hi_v = P >= 32 ? 0u : (1u << P);
                     uint32_t probe = g, step = 1;
                     bool up = false, down = false;
+                    {
+                        // ... and its two neighbours in the same breath: the three evaluations share their LDS latency, and a
+                        // guess within half a symbol -- almost every one -- is bracketed without a second look
+                        uint32_t v3[3];
+                        leaky_gaussian_left3_quick(g, a.min_symbol, n, P, mu, sd, erf_tab, v3);
+                        if (v3[1] <= q) {
+                            up = true;
+                            if (q < v3[2]) { lo_i = g; lo_v = v3[1]; hi_i = g + 1u; hi_v = v3[2]; }
+                            else { lo_i = g + 1u; lo_v = v3[2]; probe = min(g + 2u, n - 1u); step = 2; }
+                        } else {
+                            down = true;
+                            if (v3[0] <= q) { lo_i = g - 1u; lo_v = v3[0]; hi_i = g; hi_v = v3[1]; }
+                            else { hi_i = g - 1u; hi_v = v3[0]; probe = max(g - 1u, 2u) - 1u; step = 2; }
+                        }
+                    }
                     while (hi_i - lo_i > 1) {
                         // (every probe lies strictly inside (lo_i, hi_i), a subset of (0, n))
                         const uint32_t v = leaky_gaussian_left_quick<true>((int32_t)probe, a.min_symbol, (int32_t)n, P, 32, mu, sd, erf_tab);
