@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
             tile_cxx(my);
             __builtin_amdgcn_s_waitcnt(0x0F70);
             uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
-            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+            const uint32_t tr_off = (uint32_t)(((4 * (lane & 7)) * kTileStride + (lane >> 3)) * 4);
             uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
             uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
             const uint64_t wb = (uint64_t)reinterpret_cast<uintptr_t>(words_base);
             const void* words_base_u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32)) << 32) |
                                                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
-            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4);
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * a.n_streams + 4 * (size_t)(lane & 7)) * 4);
             ans_decode_b16_tiles_loop_sm(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
                                          (P >= 32) ? 0xffffffffu : ((1u << P) - 1u), (uint32_t)P, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), a.min_symbol, kDecRingMask,
-                                         words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
+                                         words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(8 * a.n_streams * 4)),
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.in.shift - 1u, lds_addr(ring + lane),
                                          lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), (1u << lut.idx_shift) - 1u, (uint32_t)lut.idx_shift, plain);

@@ -375,12 +375,12 @@ __device__ __forceinline__ void tile_store_skewed(int32_t* __restrict__ sym, siz
 }
 
 // LDS tile -> symbols[t][stream] (full wave, n_streams % 4 == 0, 16-byte aligned base): the mapping of the symbol-major
-// main-loop statements (scripts/gen_{encode,decode}_loop.py): piece k = streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row
-// (lane >> 2) + 16 (k & 1); the four LDS reads of a piece are conflict-free.
+// decoder statements (scripts/gen_decode_loop*.py, SYMBOL_MAJOR): piece k = streams 32 (k & 1) + 4 (lane & 7) .. + 3 of symbol
+// row (lane >> 3) + 8 (k >> 1), i.e. eight whole 128-byte lines per store instruction.
 __device__ __forceinline__ void tile_store_sm(int32_t* __restrict__ sym, size_t n_streams, size_t s0, size_t t0, int lane, const int32_t* tile) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int r = 16 * (k >> 1) + 4 * (lane & 3), t = (lane >> 2) + 16 * (k & 1);
+        const int r = 32 * (k & 1) + 4 * (lane & 7), t = (lane >> 3) + 8 * (k >> 1);
         v4i v;
         v.x = tile[(r + 0) * kTileStride + t]; v.y = tile[(r + 1) * kTileStride + t];
         v.z = tile[(r + 2) * kTileStride + t]; v.w = tile[(r + 3) * kTileStride + t];
@@ -1152,8 +1152,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
                 uint32_t goff[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
-                const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+                    goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * (k >> 1)) * a.n_streams + 32 * (size_t)(k & 1) + 4 * (size_t)(lane & 7)) * 4);
+                const uint32_t tr_off = (uint32_t)(((4 * (lane & 7)) * kTileStride + (lane >> 3)) * 4);
                 uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
                 uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
                 const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);

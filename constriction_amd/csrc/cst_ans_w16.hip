@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
             a.n_streams < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
             tile_cxx(my);
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+            const uint32_t tr_off = (uint32_t)(((4 * (lane & 7)) * kTileStride + (lane >> 3)) * 4);
             uint32_t row_cur = lds_addr(tile_b + lane * kTileStride), row_prev = lds_addr(my);
             uint32_t tr_cur = lds_addr(tile_b) + tr_off, tr_prev = lds_addr(tile) + tr_off;
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0);
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
             const uint64_t wb = (uint64_t)reinterpret_cast<uintptr_t>(words_base);
             const void* words_base_u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32)) << 32) |
                                                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
-            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4);
+            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * a.n_streams + 4 * (size_t)(lane & 7)) * 4);
             ans_decode_w16_tiles_loop_sm(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
-                                         kW16RingMask, words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(16 * a.n_streams * 4)),
+                                         kW16RingMask, words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(8 * a.n_streams * 4)),
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
                                          lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), plain);

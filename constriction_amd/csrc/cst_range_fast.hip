@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             uint32_t x0 = (uint32_t)L.point, x1 = (uint32_t)(L.point >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
             uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
             const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
-            const uint32_t tr_off = SM ? (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4)
+            const uint32_t tr_off = SM ? (uint32_t)(((4 * (lane & 7)) * kTileStride + (lane >> 3)) * 4)
                                        : (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             uint32_t row_cur = lds_addr(tile + lane * kTileStride), row_prev = lds_addr(tile_b + lane * kTileStride);
             uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
             // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
             // (symbol-major: 64-byte pieces of rows of n_streams symbols, line-aligned iff the rows are)
             const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((((SM ? a.n_streams : N) * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
-            const uint32_t goff0 = SM ? (uint32_t)((((size_t)(lane >> 2)) * a.n_streams + 4 * (size_t)(lane & 3)) * 4)
+            const uint32_t goff0 = SM ? (uint32_t)((((size_t)(lane >> 3)) * a.n_streams + 4 * (size_t)(lane & 7)) * 4)
                                       : (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint32_t goff_stride = SM ? (uint32_t)(16 * a.n_streams * 4) : (uint32_t)(8 * N * 4);
+            const uint32_t goff_stride = SM ? (uint32_t)(8 * a.n_streams * 4) : (uint32_t)(8 * N * 4);
             const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
             // the estimate's error is 2^(P - 48.5): the bias on top of it (high word of the f64)
             const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22

@@ -14,9 +14,10 @@ from pathlib import Path
 OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop.inc"
 OUT_SM = OUT.with_name("cst_decode_loop_sm.inc")
 # SYMBOL_MAJOR (cst_decode_loop_sm.inc): symbols[t][stream].  Only the way the previous tile leaves differs: quad k reads
-# tile[16 (k >> 1) + 4 (lane & 3) + c][(lane >> 2) + 16 (k & 1)], c = 0..3 (four conflict-free ds_read_b32) and stores the
-# 16 bytes at symbol row (lane >> 2) + 16 (k & 1), streams 16 (k >> 1) + 4 (lane & 3) .. + 3; the store base moves by
-# 32 * n_streams * 4 bytes per tile (an operand) instead of 128.
+# tile[32 (k & 1) + 4 (lane & 7) + c][(lane >> 3) + 8 (k >> 1)], c = 0..3 (four ds_read_b32, two lanes per bank) and stores the
+# 16 bytes at symbol row (lane >> 3) + 8 (k >> 1), streams 32 (k & 1) + 4 (lane & 7) .. + 3: every store instruction writes eight
+# WHOLE 128-byte lines (round 2's mapping wrote sixteen half lines: the halves of a line left in different instructions, which
+# cost the P = 24 decoder a third of its time); the store base moves by 32 * n_streams * 4 bytes per tile (an operand).
 SYMBOL_MAJOR = False
 # The tile stores carry the modifier CST_STORE_MOD, a string macro the including function defines: "nt" for rows that start
 # on cache-line boundaries, "" otherwise.  With `nt` a 128-byte row segment that straddles two cache lines (rows whose length
@@ -110,8 +111,8 @@ def gen():
         a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
-                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x",
-                     f"previous tile, stream 16*{quad >> 1}+4*(lane&3)+{c}, symbol (lane>>2)+{16 * (quad & 1)}")
+                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x",
+                     f"previous tile, stream 32*{quad & 1}+4*(lane&7)+{c}, symbol (lane>>3)+{8 * (quad >> 1)}")
         elif pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")

@@ -87,9 +87,9 @@ def gen():
 
     if SYMBOL_MAJOR:
         a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
-        a.i(f"v_add_u32 {GOFF[1]}, %[gstride], {GOFF[0]}", "symbol rows + 16")
+        a.i(f"v_add_u32 {GOFF[1]}, 0x80, {GOFF[0]}", "streams + 32")
         for k in range(2, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, 64, {GOFF[k - 2]}", "streams + 16")
+            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 2]}", "symbol rows + 8")
     else:
         a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
         for k in range(1, 8):
@@ -126,7 +126,7 @@ def gen():
             word_request()
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
-                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x")
+                a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
         elif pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if not last_of_half:

@@ -17,6 +17,7 @@ hide this costs 36 KiB of LDS the rows need).
 
 Run:  python scripts/gen_pt_decode_loop.py   (rewrites the .inc; the .inc is checked in)
 """
+import os
 import sys
 from pathlib import Path
 
@@ -87,7 +88,7 @@ def step(a, j):
     a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[3]}, {M3}")
     a.i(f"s_cmp_lg_u64 {MORE}, 0")
     a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[4]}, {M4}")
-    a.i("s_cbranch_scc0 4f")
+    a.i("s_branch 4f" if os.environ.get("GEN_NO_MORE") else "s_cbranch_scc0 4f")      # (GEN_NO_MORE: timing experiment only)
     # wave-uniform continuation for the lanes in MORE (the others re-read their six entries and keep E)
     a.i("3:")
     a.i(f"v_cndmask_b32_e64 {TS}, 0, 16, {MORE}")

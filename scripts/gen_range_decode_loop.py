@@ -34,9 +34,9 @@ from asmgen import Asm  # noqa: E402
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
 OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
-# SYMBOL_MAJOR (the same four files with _sm): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR: quad k of the
-# previous tile leaves as streams 16 (k >> 1) + 4 (lane & 3) .. + 3 of symbol row (lane >> 2) + 16 (k & 1); full waves only
-# (goff0 = that position for k = 0, gstride = 16 rows, the store base moves by %[tilestep] per tile).
+# SYMBOL_MAJOR (the same four files with _sm): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR (whole lines): quad k of the
+# previous tile leaves as streams 32 (k & 1) + 4 (lane & 7) .. + 3 of symbol row (lane >> 3) + 8 (k >> 1); full waves only
+# (goff0 = that position for k = 0, gstride = 8 rows, the store base moves by %[tilestep] per tile).
 SYMBOL_MAJOR = False
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
@@ -133,9 +133,9 @@ def gen(ends):
     a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, %[dhi]", "+2^-30 (P <= 16) or +2^-22: above the estimate's error of 2^(P - 48.5)")
     if SYMBOL_MAJOR:
         a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
-        a.i(f"v_add_u32 {GOFF[1]}, %[gstride], {GOFF[0]}", "symbol rows + 16")
+        a.i(f"v_add_u32 {GOFF[1]}, 0x80, {GOFF[0]}", "streams + 32")
         for k in range(2, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, 64, {GOFF[k - 2]}", "streams + 16")
+            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 2]}", "symbol rows + 8")
     else:
         a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
         for k in range(1, 8):
@@ -211,7 +211,7 @@ def gen(ends):
             a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
-                a.ds(f"ds_read_b32 v{172 + c}, %[trprev] offset:{(16 * (quad >> 1) + c) * 144 + 64 * (quad & 1)}", "x")
+                a.ds(f"ds_read_b32 v{172 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
         elif pos == 1:
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
