@@ -15,6 +15,8 @@
 namespace cst {
 
 __device__ __forceinline__ uint32_t f64_hi(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t f64_lo(double x) { return (uint32_t)__double2loint(x); }
+__device__ __forceinline__ double f64_from(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ __forceinline__ double f64_clear_lo(double x) { return __hiloint2double(__double2hiint(x), 0); }
 __device__ __forceinline__ double f64_pow2(int n) { return __hiloint2double((0x3ff + n) << 20, 0); }
 

@@ -314,6 +314,34 @@ __device__ __forceinline__ EncEntry make_entry_f64(uint32_t c, uint32_t p) {
     return EncEntry{c, p, p > 1u ? q2 : ones, p > 1u ? q1 : ones};
 }
 
+// From P = 18 on (kInvMinPrecision: the Python API's P = 24) the fused encoder's entries carry 1 / p as an f64 (2^-48:
+// v_rcp_f64 + one Newton step) where the table kernels carry floor(2^64 / p): with one model per symbol the entry is built as
+// often as it is used, and floor(2^64 / p) costs ~35 instructions against 4.  The (32,64) step that goes with it
+// (encode_step_inv below) has the length of the table kernels' hand-scheduled one.
+constexpr int kInvMinPrecision = 18;
+__device__ __forceinline__ EncEntry make_entry_inv(uint32_t c, uint32_t p) {
+    const double inv = fast_rcp1((double)p);                       // (p = 0: an impossible symbol, replaced before it is used)
+    return EncEntry{c, p, f64_lo(inv), f64_hi(inv)};
+}
+
+// One ANS encoder step (stack.rs:1014-1048) on the 32-bit halves of a 64-bit state, 18 <= P <= 24, 1 <= p < 2^P, with
+// inv = 1 / p to 2^-48:  A = emit ? state >> 32 : state  is below p 2^(64 - P) <= 2^46 p, so  A inv  is within 2^-1.9 of the
+// quotient (2^-7.9 at P = 24) and its nearest integer q' is the quotient or one more; A - q' p then fits 32 signed bits and
+// its sign says which.
+template <int SLOTS>
+__device__ __forceinline__ void encode_step_inv(EncLane<32, 64, SLOTS>& L, uint32_t c, uint32_t p, double inv, int P) {
+    const uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+    const bool emit = hi >= (p << (32 - P));                       // (state >> (64 - P)) >= p
+    L.out.push(lo, emit ? 1u : 0u);
+    const uint32_t a0 = emit ? hi : lo, a1 = emit ? 0u : hi;
+    const double af = __builtin_fma((double)a1, 4294967296.0, (double)a0);
+    const double qm = af * inv + 0x1p52;                           // the integer nearest to A / p in the low mantissa bits
+    const uint32_t ql = f64_lo(qm), qh = f64_hi(qm) & 0xfffffu;
+    const int32_t r = (int32_t)(a0 - ql * p);                      // A - q' p, exact: -p <= r < p
+    const int32_t y = r + (r < 0 ? (int32_t)(c + p) - (int32_t)(1u << P) : (int32_t)c);   // q' one too large: q = q' - 1, r + p
+    L.state = ((((uint64_t)qh << 32) | ql) << P) + (uint64_t)(int64_t)y;
+}
+
 template <int W, int S, int KIND>
 __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const GaussianFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -333,6 +361,7 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
     const int P = a.precision;
     const bool symbol_major = a.layout == CST_LAYOUT_SYMBOL_MAJOR;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const bool use_inv = KIND == kAns && W == 32 && S == 64 && P >= kInvMinPrecision;      // entries with 1 / p (make_entry_inv)
     const size_t s = s0 + lane;
     const bool active = lane < kFuStreams && s < a.n_streams;            // this lane codes a stream in phase B
 
@@ -399,7 +428,9 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
                 const bool valid = sg > 0.0 && sg <= 1.7976931348623157e308 && fabs(m) <= 1.7976931348623157e308;
                 const bool inside = leaky_gaussian_lcp_quick(sy, a.lo, a.hi, P, 32, valid ? m : 0.0, valid ? sg : 1.0, c, p, erf_tab);
                 if (!valid || !inside || (uint64_t)c + p > ((uint64_t)1 << P)) p = 0;
-                tile[item_t(it) * kFuRowStride + item_j(it)] = make_entry_f64(c, p);
+                EncEntry entry{c, p, 0u, 0u};                                   // (the range coder divides by nothing)
+                if constexpr (KIND == kAns) entry = use_inv ? make_entry_inv(c, p) : make_entry_f64(c, p);
+                tile[item_t(it) * kFuRowStride + item_j(it)] = entry;
             }
         }
         wave_lds_fence();
@@ -419,14 +450,17 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
                     for (int tl = kFuTile - 1; tl >= 0; --tl) {
                         const bool none = e[tl].p == 0;
                         bad |= none ? 1u : 0u;
-                        const EncEntry f{none ? 0u : e[tl].c, none ? 1u : e[tl].p, none ? 0xffffffffu : e[tl].m_lo, none ? 0xffffffffu : e[tl].m_hi};
-                        LA.template step<FAST>(f, P);
+                        if constexpr (FAST) {
+                            if (use_inv) encode_step_inv(LA, none ? 0u : e[tl].c, none ? 1u : e[tl].p, none ? 1.0 : f64_from(e[tl].m_lo, e[tl].m_hi), P);
+                            else LA.template step<FAST>(EncEntry{none ? 0u : e[tl].c, none ? 1u : e[tl].p, none ? 0xffffffffu : e[tl].m_lo, none ? 0xffffffffu : e[tl].m_hi}, P);
+                        }
                     }
                 } else {
+                    // (other presets, P < 8, the ragged tile)
                     for (int tl = n_here - 1; tl >= 0; --tl) {
                         const EncEntry e = tile[tl * kFuRowStride + lane];
                         if (e.p == 0) bad = 1;
-                        else if (!bad) LA.template step<false>(e, P);
+                        else if (!bad) LA.template step<false>(use_inv ? make_entry(e.c, e.p) : e, P);
                     }
                 }
             } else {

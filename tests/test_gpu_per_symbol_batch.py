@@ -176,3 +176,28 @@ def test_release_scratch(B):
     dec, st = B.ans_decode_gaussian(enc, lo, hi, dev(mu), dev(sd))       # (and everything still works afterwards)
     torch.cuda.synchronize()
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("P", [8, 13, 17, 18, 19, 21, 23, 24])
+def test_fused_encoder_step_variants(B, O, P, monkeypatch):
+    """The fused Gaussian encoder codes with entries that carry 1 / p as an f64 from P = 18 on (encode_step_inv: the quotient
+    from one f64 product, within 0.27 of the true one at P = 18) and with floor(2^64 / p) below: both sides of that switch,
+    the precisions next to it, symbols of probability 1 / 2^P (far off the means) next to near-certain ones; words of every
+    stream against the oracle."""
+    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")
+    lo, hi = -100, 100
+    n_streams, n_per = 70, 16 * 12 + 5
+    rng = np.random.default_rng(P)
+    mu = rng.uniform(-60, 60, (n_streams, n_per))
+    sd = np.exp(rng.uniform(np.log(0.05), np.log(40.0), (n_streams, n_per)))
+    sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), lo, hi).astype(np.int32)
+    far = rng.random((n_streams, n_per)) < 0.1
+    sym[far] = rng.integers(lo, hi + 1, size=int(far.sum()))                # symbols the model gives the minimal probability
+    enc = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu), dev(sd), (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    for s in range(n_streams):
+        c = O.AnsCoder(W=32, S=64)
+        c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], P, 32)
+        assert words[s, : n_words[s]].tolist() == c.get_compressed().tolist(), f"stream {s}"
