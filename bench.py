@@ -183,7 +183,9 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
 
 
 def event_ms(fn, reps):
-    """average duration of fn() in ms, HIP events on torch's current stream (the launch stream of the library calls)"""
+    """typical duration of fn() in ms (the MEDIAN of `reps` launches timed one by one: on a shared box one launch in a hundred
+    is preempted for milliseconds, and a mean of five would report that), HIP events on torch's current stream (the launch
+    stream of the library calls).  The bench line itself is the mean over its timed region, as the contract says."""
     fn()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
@@ -192,7 +194,7 @@ def event_ms(fn, reps):
         fn()
         ev[k + 1].record()
     torch.cuda.synchronize()
-    return float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
+    return float(np.median([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
 
 
 def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major"):
