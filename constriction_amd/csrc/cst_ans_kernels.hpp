@@ -582,6 +582,34 @@ __device__ __forceinline__ EncEntry pack_entry(const EncEntry e, int P) {
 }
 __device__ __forceinline__ EncEntry unpack_entry(const EncEntry e) { return EncEntry{e.c & 0xffffu, e.p & 0xffffu, e.m_lo, e.m_hi}; }
 
+// row[p0 .. p0 + cnt) coded downwards, cnt <= kTileSyms per lane (the ragged ends of rows that are skewed onto cache-line
+// boundaries, row_skew above): all reads in flight at once, then the steps out of the lane's LDS row `my`.
+// code(v): one coder step for symbol v; flush(): the scheduled point behind it.
+template <class CODE, class FLUSH>
+__device__ __forceinline__ void code_ragged(const int32_t* row, size_t p0, uint32_t cnt, int32_t* my, int32_t fill, CODE&& code, FLUSH&& flush) {
+    uint32_t mx = cnt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+    if (!mx) return;
+    wave_lds_fence();
+    {
+        int32_t r[kTileSyms];
+#pragma unroll
+        for (int k = 0; k < kTileSyms; ++k) r[k] = ((uint32_t)k < cnt) ? __builtin_nontemporal_load(row + p0 + k) : fill;
+#pragma unroll
+        for (int k = 0; k < kTileSyms; ++k) my[k] = r[k];
+    }
+    wave_lds_fence();
+    int32_t v = my[mx - 1];
+    for (uint32_t k = mx; k-- > 0;) {
+        const int32_t cur = v;
+        if (k > 0) v = my[k - 1];
+        if (k < cnt) code(cur);
+        flush();
+    }
+}
+
 // LAYOUT 0: symbols[stream][t] staged through LDS tiles; LAYOUT 1: symbols[t][stream] read directly.
 // GLOBAL_TABLE: the encoder entries stay in HBM / L2 (alphabets too large for LDS: more than ~3800 symbols)
 template <int W, int S, int LAYOUT, bool VEC, int G, bool FAST, bool GLOBAL_TABLE = false>
@@ -706,29 +734,10 @@ __global__ __launch_bounds__(kBlock) void ans_encode_kernel(const AnsEncodeArgs 
             if ((a.flags & CST_KFLAG_TWO_TILES) && aligned_slabs && s0 + kWave <= a.n_streams && N >= 4 * kTileSyms && N < (1u << 24) &&
                 !__any(!off_ok || !groups_ok)) {
                 int32_t* my = tile + lane * kTileStride;
-                // row[p0 .. p0 + cnt) downwards, cnt <= 32 per lane: all reads in flight at once, then the steps from LDS
                 auto ragged = [&](size_t p0, uint32_t cnt) {
-                    uint32_t mx = cnt;
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
-                    mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
-                    if (!mx) return;
-                    wave_lds_fence();
-                    {
-                        int32_t r[kTileSyms];
-#pragma unroll
-                        for (int k = 0; k < kTileSyms; ++k) r[k] = ((uint32_t)k < cnt) ? __builtin_nontemporal_load(row + p0 + k) : a.min_symbol;
-#pragma unroll
-                        for (int k = 0; k < kTileSyms; ++k) my[k] = r[k];
-                    }
-                    wave_lds_fence();
-                    int32_t v = my[mx - 1];
-                    for (uint32_t k = mx; k-- > 0;) {
-                        const EncEntry e = entry(enc_index(v, a.min_symbol, nsym, L.bad));
-                        if (k > 0) v = my[k - 1];
-                        if (k < cnt) L.template step<FAST>(e, P);
-                        L.flush_chunks();
-                    }
+                    code_ragged(row, p0, cnt, my, a.min_symbol,
+                                [&](int32_t v) { L.template step<FAST>(entry(enc_index(v, a.min_symbol, nsym, L.bad)), P); },
+                                [&]() { L.flush_chunks(); });
                 };
                 const uint32_t pre = row_skew(a.symbols, s, N);
                 uint32_t max_pre = pre;

@@ -36,7 +36,7 @@ def tup(base, n=4):
 
 # SYMBOL_MAJOR (cst_decode_loop_b16_sm.inc): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR: quad k of the
 # previous tile leaves as streams 32 (k & 1) + 4 (lane & 7) .. + 3 of symbol row (lane >> 3) + 8 (k >> 1); full waves only
-# (goff0 = that position for k = 0, gstride = 8 rows, the base moves by %[tilestep] per tile).
+# (the base moves by %[tilestep] per tile).
 SYMBOL_MAJOR = False
 OUT_SM = OUT.with_name("cst_decode_loop_b16_sm.inc")
 
@@ -98,16 +98,13 @@ def gen():
     a.i(f"s_min_u32 {SBITS}, %[bsh], 4", "second-level tables: 2^min(4, P - 11) parts per bucket (kSubBitsMax)")
     a.i(f"s_sub_u32 {SSH}, %[bsh], {SBITS}")
     a.i(f"s_bfm_b32 {SBITS}, {SBITS}, 0", "(as a mask)")
-    if SYMBOL_MAJOR:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
-        a.i(f"v_add_u32 {GOFF[1]}, 0x80, {GOFF[0]}", "streams + 32")
-        for k in range(2, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 2]}", "symbol rows + 8")
-    else:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
-        for k in range(1, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
-            a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
+    # the eight store offsets of a tile's pieces wait in the lane's row of the CURRENT tile buffer (written by the kernel, read
+    # here before the first step writes symbols over them): rows of any length take per-row offsets (row_skew,
+    # cst_ans_kernels.hpp), partial waves repeat their last row, symbol-major batches have their own mapping -- all the
+    # kernel's business, and an asm statement has room for 30 operands
+    a.ds(f"ds_read_b128 {tup(180)}, %[rowcur]", "goff")
+    a.ds(f"ds_read_b128 {tup(184)}, %[rowcur] offset:16", "goff")
+    a.wait_lds_all("the store offsets")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     a.i("1:", None)
@@ -252,8 +249,8 @@ def emit(out):
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift),',
-           '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
-           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
+           '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [ntiles] "s"(n_tiles),',
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions per iteration incl. loop control)")

@@ -938,12 +938,14 @@ def test_large_alphabets_through_the_bucket_entries(B, O, coder, P, n, layout):
 
 @pytest.mark.parametrize("n_per", [128, 129, 131, 4095, 4100, 4099])
 @pytest.mark.parametrize("base_shift", [0, 1, 3])
-def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift):
-    """The headline coder's main-loop statements on rows that do not start on cache-line boundaries: every lane codes the
+@pytest.mark.parametrize("P", [12, 24])
+def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift, P):
+    """The (32,64) coders' main-loop statements (P <= 12 and the bucket-entry / unpacked-entry ones of P = 24) on rows that do not
+    start on cache-line boundaries: every lane codes the
     symbols in front of ITS row's next 128-byte boundary outside the loop, so that its tiles are whole cache lines (row_skew,
     cst_ans_kernels.hpp).  Row lengths with every residue that matters, symbol buffers that start 4 and 12 bytes off a
     16-byte boundary, full waves plus a partial one; words against the oracle, decoding 70 symbols past the end too."""
-    P, n_streams = 12, 200
+    n_streams = 200
     cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, -50, P)
     sym = O.synth_symbols(n_per, 0, n_streams, n_per, -50, cdf, P)
