@@ -7,9 +7,9 @@ namespace cst {
 
 __device__ __forceinline__ void ans_decode_w16_tiles_loop(uint32_t& st, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur, uint32_t& row_prev,
                                                           uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
-                                                          uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t goff_stride,
+                                                          uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                           uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
-                                                          uint32_t words_off, uint32_t goff0, uint32_t goff_limit, bool plain_stores) {
+                                                          uint32_t words_off, bool plain_stores) {
     if (plain_stores) {          // rows that are not cache-line aligned: see scripts/gen_decode_loop.py (CST_STORE_MOD)
 #define CST_STORE_MOD ""
 #include "cst_decode_loop_w16.inc"
@@ -24,9 +24,9 @@ __device__ __forceinline__ void ans_decode_w16_tiles_loop(uint32_t& st, uint32_t
 // the same for symbols[t][stream] (scripts/gen_decode_loop_w16.py, SYMBOL_MAJOR): full waves only
 __device__ __forceinline__ void ans_decode_w16_tiles_loop_sm(uint32_t& st, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur, uint32_t& row_prev,
                                                              uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
-                                                             uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t goff_stride,
+                                                             uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                              uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
-                                                             uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t tile_step_bytes,
+                                                             uint32_t words_off, uint32_t tile_step_bytes,
                                                              bool plain_stores) {
     if (plain_stores) {
 #define CST_STORE_MOD ""
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
 
     int32_t* my = tile + lane * kTileStride;
     size_t tb = 0;
+    bool all_done = false;
     {
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.base16) - words_base);
@@ -181,19 +182,50 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
             const uint64_t wb = (uint64_t)reinterpret_cast<uintptr_t>(words_base);
             const void* words_base_u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32)) << 32) |
                                                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wb));
-            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * a.n_streams + 4 * (size_t)(lane & 7)) * 4);
+            // the statement reads its eight store offsets from the lane's row of the current tile buffer
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                tile_b[lane * kTileStride + k] = (int32_t)(uint32_t)((((size_t)(lane >> 3) + 8 * (k >> 1)) * a.n_streams + 32 * (size_t)(k & 1) + 4 * (size_t)(lane & 7)) * 4);
+            wave_lds_fence();
             ans_decode_w16_tiles_loop_sm(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
-                                         kW16RingMask, words_base_u, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(8 * a.n_streams * 4)),
+                                         kW16RingMask, words_base_u, store_base,
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
-                                         lds_addr(dump), (uint32_t)w_off, goff0, 0xffffffffu,
+                                         lds_addr(dump), (uint32_t)w_off,
                                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), plain);
             wave_lds_fence();
             tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
             wave_lds_fence();
             tb = n_full;
-        } else if (!SM && n_full >= 2 && N < (1u << 24) && !__any(!off_ok)) {
+        } else if (!SM && N >= 4 * kTileSyms && N < (1u << 24) && !__any(!off_ok)) {
+            // Rows of any length and alignment (row_skew, cst_ans_kernels.hpp; as in cst_ans_b16.hip): every lane first decodes
+            // the `pre` symbols in front of its row's next cache-line boundary; the lanes of a partial wave beyond its last
+            // stream repeat that stream's row.
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+            const size_t se = active ? s : a.n_streams - 1;
+            int32_t* out_row = a.symbols + se * N;
+            const uint32_t pre = row_skew(a.symbols, se, N);
+            uint32_t max_pre = pre;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+            max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+            // `count` more symbols of every lane that has them, straight to HBM (the window is topped up every eight)
+            auto direct = [&](uint32_t first, uint32_t have, uint32_t count) {
+                for (uint32_t j = 0; j < count; ++j) {
+                    if (j < have) { const int32_t sym = L.step(lut.cp, lut.sym, P); if (active) out_row[first + j] = sym; }
+                    if ((j & 7) == 7) { L.fill_blocking(); wave_lds_fence(); }
+                }
+                L.fill_blocking();
+                wave_lds_fence();
+            };
+            if (max_pre) direct(0, pre, max_pre);
+            const size_t n_t = (N - max_pre) / kTileSyms;           // whole tiles every lane has (>= 3)
             tile_cxx(my);
-            const uint32_t goff_limit = (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                tile_b[lane * kTileStride + k] = (int32_t)(uint32_t)((R * N + row_skew(a.symbols, s0 + R, N) + 4 * (size_t)(lane & 7)) * 4);
+            }
+            wave_lds_fence();
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             // current = B (tile 1), previous = A (tile 0)
@@ -202,17 +234,30 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
-            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
-            const uint32_t goff0 = (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
+            // (every stored segment is a whole cache line now: the streaming form of the stores in every case)
             ans_decode_w16_tiles_loop(L.state, L.rd, L.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.cp), (1u << P) - 1u, (uint32_t)P,
-                                      kW16RingMask, words_base, store_base, (uint32_t)(8 * N * 4),
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_full - 1)), L.shift - 1u, lds_addr(ring + lane),
-                                      lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, plain_stores);
+                                      kW16RingMask, words_base, store_base,
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_t - 1)), L.shift - 1u, lds_addr(ring + lane),
+                                      lds_addr(dump), (uint32_t)w_off, false);
             // the last tile is still in LDS (buffer A if it has an even index)
             wave_lds_fence();
-            tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+            {
+                const int32_t* last = ((n_t - 1) & 1) ? tile_b : tile;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                    const int4 v = *reinterpret_cast<const int4*>(last + ((lane >> 3) + 8 * k) * kTileStride + 4 * (lane & 7));
+                    v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(a.symbols + (s0 + R) * N + row_skew(a.symbols, s0 + R, N) + (n_t - 1) * kTileSyms + 4 * (lane & 7)));
+                }
+            }
             wave_lds_fence();
+            // ... and what is left of each row behind its last whole tile (fewer than 64 symbols)
+            L.fill_blocking();
+            wave_lds_fence();
+            const uint32_t done = pre + (uint32_t)(n_t * kTileSyms);
+            direct(done, (uint32_t)N - done, (uint32_t)N - (uint32_t)(n_t * kTileSyms));
+            all_done = true;
             tb = n_full;
         }
     }
@@ -227,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     }
     int32_t* row = SM ? a.symbols + (active ? s : 0) : a.symbols + (active ? s : 0) * N;
     const size_t step_t = SM ? a.n_streams : 1;
-    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+    for (size_t t = all_done ? N : n_full * kTileSyms; t < N; ++t) {
         const int32_t sym = L.step(lut.cp, lut.sym, P);
         if (active) row[t * step_t] = sym;
         L.fill_blocking();
@@ -298,64 +343,86 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16_kernel(const AnsEncodeA
     L.init(a.words + se * a.stride_words, (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words), ring, lane);
     auto code = [&](int32_t v) { L.template step<false>(a.enc[enc_index(v, a.min_symbol, nsym, L.bad)], P); };
 
-    // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
     const int32_t* row = SM ? a.symbols + se : a.symbols + se * N;
     const size_t step_t = SM ? a.n_streams : 1;
-    for (size_t t = N; t > n_full * kTileSyms;) {
-        --t;
-        code(row[t * step_t]);
-        L.flush_chunks();
-    }
+    const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
+    const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                    (L.out.cap & 15u) == 0 && L.out.shift == 0;
     size_t tb = n_full;
-    if (n_full > 0) {
-        const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
-        const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
-                        (L.out.cap & 15u) == 0 && L.out.shift == 0;
-        if (SM && N < (1u << 24) && !__any(!ok) && s0 + kWave <= a.n_streams && a.n_streams % 4 == 0 && a.n_streams < (1u << 24) &&
-            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
-            uint32_t goff[8];
+    if (!SM && N >= 4 * kTileSyms && N < (1u << 24) && !__any(!ok)) {
+        // Rows of any length and alignment (row_skew, cst_ans_kernels.hpp; as in the encoder of cst_ans_b16.hip): lane l's tiles
+        // start row_skew() symbols into its row; the ragged ends of the row go through LDS in bulk reads.  The lanes of a
+        // partial wave beyond its last stream repeat that stream.
+        const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+        int32_t* my = tile + lane * kTileStride;
+        auto ragged = [&](size_t p0, uint32_t cnt) { code_ragged(row, p0, cnt, my, a.min_symbol, code, [&]() { L.flush_chunks(); }); };
+        const uint32_t pre = row_skew(a.symbols, se, N);
+        uint32_t max_pre = pre;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + (n_full - 1) * kTileSyms * a.n_streams + s0);
-            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
-                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-            const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
-            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
-            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
-            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
-            uint32_t st = (uint32_t)L.state;
-            int32_t smin = a.min_symbol, smax = a.min_symbol;
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            ans_encode_w16_tiles_loop_sm(st, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
-                                         lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
-            L.state = st;
-            L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
-            tb = 0;
-        } else if (!SM && N < (1u << 24) && !__any(!ok)) {
-            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
-            uint32_t goff[8];
+        for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+        max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+        const size_t n_t = (N - max_pre) / kTileSyms;           // whole tiles every lane has (>= 3)
+        const size_t top = pre + n_t * kTileSyms;               // this lane's symbols [top, N) come first: fewer than 64
+        const uint32_t n_top = (uint32_t)(N - top);
+        ragged(top + kTileSyms, n_top > (uint32_t)kTileSyms ? n_top - (uint32_t)kTileSyms : 0u);
+        ragged(top, min(n_top, (uint32_t)kTileSyms));
+        wave_lds_fence();
+        uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_full - 1) * kTileSyms);
-            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
-                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
-            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
-            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
-            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
-            uint32_t st = (uint32_t)L.state;
-            int32_t smin = a.min_symbol, smax = a.min_symbol;
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-            ans_encode_w16_tiles_loop(st, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
-                                      lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
-            L.state = st;
-            // a symbol below min_symbol wraps to a huge index
-            L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
-            tb = 0;
+        for (int k = 0; k < 8; ++k) {
+            const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+            goff[k] = (uint32_t)((R * N + row_skew(a.symbols, s0 + R, N) + 4 * (size_t)(lane & 7)) * 4);
+        }
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (n_t - 1) * kTileSyms);
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+        int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+        const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+        const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+        uint32_t st = (uint32_t)L.state;
+        int32_t smin = a.min_symbol, smax = a.min_symbol;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+        ans_encode_w16_tiles_loop(st, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
+                                  lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_t), goff);
+        L.state = st;
+        // a symbol below min_symbol wraps to a huge index
+        L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+        ragged(0, pre);
+        tb = 0;
+    } else {
+        // ragged top part [32 * n_full, N): direct reads, at most 31 symbols per stream (the coder runs backwards)
+        for (size_t t = N; t > n_full * kTileSyms;) {
+            --t;
+            code(row[t * step_t]);
+            L.flush_chunks();
+        }
+        if (n_full > 0) {
+            if (SM && N < (1u << 24) && !__any(!ok) && s0 + kWave <= a.n_streams && a.n_streams % 4 == 0 && a.n_streams < (1u << 24) &&
+                (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0) {
+                uint32_t goff[8];
+    #pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    goff[k] = (uint32_t)((((size_t)(lane >> 2) + 16 * (k & 1)) * a.n_streams + 16 * (size_t)(k >> 1) + 4 * (size_t)(lane & 3)) * 4);
+                const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + (n_full - 1) * kTileSyms * a.n_streams + s0);
+                const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+                const uint32_t tr_off = (uint32_t)(((4 * (lane & 3)) * kTileStride + (lane >> 2)) * 4);
+                int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+                const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+                const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+                uint32_t st = (uint32_t)L.state;
+                int32_t smin = a.min_symbol, smax = a.min_symbol;
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                ans_encode_w16_tiles_loop_sm(st, L.out.wr, L.out.flushed, smin, smax, row_addr, tr_addr, L.out.lane_addr, L.out.cap, (uint32_t)slab_off,
+                                             lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+                L.state = st;
+                L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+                tb = 0;
+            }
         }
     }
     // partial waves and odd slabs: tile by tile with the compiler-scheduled step

@@ -85,16 +85,11 @@ def gen():
     def sym_reg(j):
         return SYM[(j // 4 % 2) * 4 + j % 4]
 
-    if SYMBOL_MAJOR:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
-        a.i(f"v_add_u32 {GOFF[1]}, 0x80, {GOFF[0]}", "streams + 32")
-        for k in range(2, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 2]}", "symbol rows + 8")
-    else:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
-        for k in range(1, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
-            a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
+    # the eight store offsets wait in the lane's row of the CURRENT tile buffer (gen_decode_loop_b16.py: rows of any length,
+    # partial waves and the symbol-major mapping are the kernel's business)
+    a.ds(f"ds_read_b128 {tup(168)}, %[rowcur]", "goff")
+    a.ds(f"ds_read_b128 {tup(172)}, %[rowcur] offset:16", "goff")
+    a.wait_lds_all("the store offsets")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     window_requests("B")      # (the set that lands after step 15)
@@ -170,8 +165,8 @@ def emit(out):
     ops = ['    : [st] "+v"(st), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
-           '      [gstride] "s"(goff_stride), [ntiles] "s"(n_tiles),',
-           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
+           '      [ntiles] "s"(n_tiles),',
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions per iteration incl. loop control)")

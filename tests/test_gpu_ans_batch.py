@@ -938,33 +938,34 @@ def test_large_alphabets_through_the_bucket_entries(B, O, coder, P, n, layout):
 
 @pytest.mark.parametrize("n_per", [128, 129, 131, 4095, 4100, 4099])
 @pytest.mark.parametrize("base_shift", [0, 1, 3])
-@pytest.mark.parametrize("P", [12, 24])
-def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift, P):
-    """The (32,64) coders' main-loop statements (P <= 12 and the bucket-entry / unpacked-entry ones of P = 24) on rows that do not
-    start on cache-line boundaries: every lane codes the
+@pytest.mark.parametrize("cfg", [(32, 64, 12), (32, 64, 24), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+def test_rows_of_any_length_through_the_main_loop(B, O, n_per, base_shift, cfg):
+    """The ANS coders' main-loop statements (P <= 12, the bucket-entry / unpacked-entry ones of P = 24, the 16-bit preset) on rows
+    that do not start on cache-line boundaries: every lane codes the
     symbols in front of ITS row's next 128-byte boundary outside the loop, so that its tiles are whole cache lines (row_skew,
     cst_ans_kernels.hpp).  Row lengths with every residue that matters, symbol buffers that start 4 and 12 bytes off a
     16-byte boundary, full waves plus a partial one; words against the oracle, decoding 70 symbols past the end too."""
     n_streams = 200
+    W, S, P = cfg
     cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, -50, P)
     sym = O.synth_symbols(n_per, 0, n_streams, n_per, -50, cdf, P)
-    want_words, want_n, _ = O.ans_encode_batch(sym, -50, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, -50, cdf, P, W, S)
     src = torch.zeros(n_streams * n_per + 8, dtype=torch.int32, device="cuda")
     src[base_shift: base_shift + sym.size] = dev(sym).reshape(-1)
-    enc = B.ans_encode(src[base_shift: base_shift + sym.size].view(n_streams, n_per), model, (32, 64, P))
+    enc = B.ans_encode(src[base_shift: base_shift + sym.size].view(n_streams, n_per), model, cfg)
     torch.cuda.synchronize()
     assert enc.n_words.cpu().numpy().tolist() == want_n.tolist()
     got_words = enc.to_numpy()[0]
     for i in range(n_streams):
-        assert got_words[i, : want_n[i]].tolist() == want_words[i, : want_n[i]].tolist(), i
+        assert (got_words[i, : want_n[i]] & ((1 << W) - 1)).tolist() == want_words[i, : want_n[i]].tolist(), i
     for extra in (0, 70):
         n_dec = n_per + extra
         buf = torch.full((n_streams * n_dec + 8,), -99, dtype=torch.int32, device="cuda")
         out = buf[base_shift: base_shift + n_streams * n_dec].view(n_streams, n_dec)
         dec, st = B.ans_decode(enc, model, n_dec, out=out)
         torch.cuda.synchronize()
-        want, want_st = O.ans_decode_batch(want_words, want_n, n_dec, -50, cdf, P)
+        want, want_st = O.ans_decode_batch(want_words, want_n, n_dec, -50, cdf, P, W, S)
         assert st.cpu().numpy().tolist() == want_st.tolist()
         assert np.array_equal(out.cpu().numpy(), want)
         assert (buf[:base_shift].cpu().numpy() == -99).all() and (buf[base_shift + n_streams * n_dec:].cpu().numpy() == -99).all()
