@@ -582,10 +582,10 @@ __device__ __forceinline__ EncEntry pack_entry(const EncEntry e, int P) {
 }
 __device__ __forceinline__ EncEntry unpack_entry(const EncEntry e) { return EncEntry{e.c & 0xffffu, e.p & 0xffffu, e.m_lo, e.m_hi}; }
 
-// row[p0 .. p0 + cnt) coded downwards, cnt <= kTileSyms per lane (the ragged ends of rows that are skewed onto cache-line
-// boundaries, row_skew above): all reads in flight at once, then the steps out of the lane's LDS row `my`.
-// code(v): one coder step for symbol v; flush(): the scheduled point behind it.
-template <class CODE, class FLUSH>
+// row[p0 .. p0 + cnt) coded downwards (UP: upwards, the range coder's direction), cnt <= kTileSyms per lane (the ragged ends
+// of rows that are skewed onto cache-line boundaries, row_skew above): all reads in flight at once, then the steps out of the
+// lane's LDS row `my`.  code(v): one coder step for symbol v; flush(): the scheduled point behind it.
+template <bool UP = false, class CODE, class FLUSH>
 __device__ __forceinline__ void code_ragged(const int32_t* row, size_t p0, uint32_t cnt, int32_t* my, int32_t fill, CODE&& code, FLUSH&& flush) {
     uint32_t mx = cnt;
 #pragma unroll
@@ -601,12 +601,22 @@ __device__ __forceinline__ void code_ragged(const int32_t* row, size_t p0, uint3
         for (int k = 0; k < kTileSyms; ++k) my[k] = r[k];
     }
     wave_lds_fence();
-    int32_t v = my[mx - 1];
-    for (uint32_t k = mx; k-- > 0;) {
-        const int32_t cur = v;
-        if (k > 0) v = my[k - 1];
-        if (k < cnt) code(cur);
-        flush();
+    if constexpr (UP) {
+        int32_t v = my[0];
+        for (uint32_t k = 0; k < mx; ++k) {
+            const int32_t cur = v;
+            if (k + 1 < mx) v = my[k + 1];
+            if (k < cnt) code(cur);
+            flush();
+        }
+    } else {
+        int32_t v = my[mx - 1];
+        for (uint32_t k = mx; k-- > 0;) {
+            const int32_t cur = v;
+            if (k > 0) v = my[k - 1];
+            if (k < cnt) code(cur);
+            flush();
+        }
     }
 }
 

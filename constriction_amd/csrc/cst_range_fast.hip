@@ -143,12 +143,69 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
     RangeEncHeld L;
     L.init(slab, cap, ring, lane);
     L.owner = active;
-    bool done = false;
+    bool done = false, all_done = false;
     {
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
         const bool ok = slab_off + 4ull * cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
                         (cap & 15u) == 0 && L.out.shift == 0;
-        if (n_full > 0 && N < (1u << 24) && !__any(!ok)) {
+        if (!SM && N >= 4 * kTileSyms && N < (1u << 24) && !__any(!ok)) {
+            // Rows of any length and alignment (row_skew, cst_ans_kernels.hpp; as in the ANS encoders): lane l's tiles start
+            // row_skew() symbols into its row, so that every 128-byte segment a tile load reads is one whole cache line; the
+            // symbols in front of the first and behind the last whole tile go through LDS in bulk reads.
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+            const int32_t* in_row = a.symbols + se * N;
+            int32_t* my = tile + lane * kTileStride;
+            auto ragged = [&](size_t p0, uint32_t cnt) {
+                code_ragged<true>(in_row, p0, cnt, my, a.min_symbol,
+                                  [&](int32_t v) { const CumProb e = table[enc_index(v, a.min_symbol, nsym, L.bad)]; L.step(e.c, e.p, P); },
+                                  [&]() { L.flush(); });
+            };
+            const uint32_t pre = row_skew(a.symbols, se, N);
+            uint32_t max_pre = pre;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+            max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+            const size_t n_t = (N - max_pre) / kTileSyms;           // whole tiles every lane has (>= 3)
+            ragged(0, pre);
+            wave_lds_fence();
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                goff[k] = (uint32_t)((R * N + row_skew(a.symbols, s0 + R, N) + 4 * (size_t)(lane & 7)) * 4);
+            }
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+            const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+            int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+            const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+            const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+            // the statement continues from the state the skew symbols left
+            uint32_t lo0 = (uint32_t)L.lower, lo1 = (uint32_t)(L.lower >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
+            uint32_t lw = L.lw, wr = L.out.wr, flushed = L.out.flushed, slow = 0;
+            int32_t smin = a.min_symbol, smax = a.min_symbol;
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            range_encode_tiles_loop<FLUSHES, SM>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, row_addr, tr_addr, L.out.lane_addr, cap,
+                                                 (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
+                                                 symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_t),
+                                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kTileSyms * a.n_streams * 4)), goff);
+            if (__builtin_amdgcn_readfirstlane(slow) == 0) {
+                L.lower = ((uint64_t)lo1 << 32) | lo0; L.range = ((uint64_t)rg1 << 32) | rg0; L.lw = lw;
+                L.out.wr = wr; L.out.flushed = flushed;
+                L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
+                const size_t top = pre + n_t * kTileSyms;           // fewer than 64 symbols are left behind the last whole tile
+                const uint32_t n_top = (uint32_t)(N - top);
+                ragged(top, min(n_top, (uint32_t)kTileSyms));
+                ragged(top + kTileSyms, n_top > (uint32_t)kTileSyms ? n_top - (uint32_t)kTileSyms : 0u);
+                done = all_done = true;
+            } else {
+                // (rare: a carry had to travel) the wave's streams again from their first symbol, with the C++ step
+                L.init(slab, cap, ring, lane);
+                L.owner = active;
+                wave_lds_fence();
+            }
+        } else if (n_full > 0 && N < (1u << 24) && !__any(!ok)) {
             const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
@@ -209,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void range_encode_fast_kernel(const RangeEn
     }
     const int32_t* row = SM ? a.symbols + se : a.symbols + se * N;
     const size_t row_step = SM ? a.n_streams : 1;
-    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+    for (size_t t = all_done ? N : n_full * kTileSyms; t < N; ++t) {
         const CumProb e = table[enc_index(row[t * row_step], a.min_symbol, nsym, L.bad)];
         L.step(e.c, e.p, P);
         L.flush();

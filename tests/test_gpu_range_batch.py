@@ -257,3 +257,33 @@ def test_range_bucket_entry_decoder_walks_the_tails(B, O, P):
         assert st3.cpu().numpy().tolist() == want_st.tolist()
         ok = want_st == 0
         assert np.array_equal(more.cpu().numpy()[ok], want_more[ok])
+
+
+@pytest.mark.parametrize("n_per", [128, 131, 4095, 4100])
+@pytest.mark.parametrize("base_shift", [0, 1, 3])
+@pytest.mark.parametrize("P", [12, 24])
+def test_range_rows_of_any_length(B, O, n_per, base_shift, P):
+    """The range ENCODER's main-loop statement on rows that do not start on cache-line boundaries (row_skew, cst_ans_kernels.hpp:
+    the symbols in front of a row's next 128-byte boundary and behind its last whole tile are coded outside the statement, which
+    continues from the state they left); symbol buffers 4 and 12 bytes off a 16-byte boundary, full waves plus a partial one,
+    a skewed model whose carries travel (the slow-path repeat from the first symbol); words against the oracle, and the decoder
+    on the same rows."""
+    n_streams = 200
+    rng = np.random.default_rng(P + n_per)
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(40) * 0.3), P)
+    model = B.Model.from_cdf(cdf, -7, P)
+    sym = O.synth_symbols(n_per, 0, n_streams, n_per, -7, cdf, P)
+    want_words, want_n, want_status = O.rc_encode_batch(sym, -7, cdf, P)
+    src = torch.zeros(n_streams * n_per + 8, dtype=torch.int32, device="cuda")
+    src[base_shift: base_shift + sym.size] = dev(sym).reshape(-1)
+    enc = B.range_encode(src[base_shift: base_shift + sym.size].view(n_streams, n_per), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_status.tolist() and n_words.tolist() == want_n.tolist()
+    for i in range(n_streams):
+        assert words[i, : n_words[i]].tolist() == want_words[i, : want_n[i]].tolist(), i
+    buf = torch.full((n_streams * n_per + 8,), -99, dtype=torch.int32, device="cuda")
+    out = buf[base_shift: base_shift + n_streams * n_per].view(n_streams, n_per)
+    dec, st = B.range_decode(enc, model, n_per, out=out)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(out.cpu().numpy(), sym)
