@@ -290,9 +290,9 @@ __device__ __forceinline__ void range_decode_tiles_loop(uint32_t& x0, uint32_t& 
                                                         uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
                                                         uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
                                                         uint32_t lut_addr, uint32_t qmax, uint32_t P, uint32_t ring_mask,
-                                                        const void* words_base, uint32_t delta_hi, uint64_t store_base, uint32_t goff_stride,
+                                                        const void* words_base, uint32_t delta_hi, uint64_t store_base,
                                                         uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
-                                                        uint32_t words_off, uint32_t goff0, uint32_t goff_limit, uint32_t bucket_shift,
+                                                        uint32_t words_off, uint32_t bucket_shift,
                                                         uint32_t cdf_addr, int32_t min_symbol, [[maybe_unused]] uint32_t tile_step_bytes,
                                                         [[maybe_unused]] uint32_t c_field_mask, [[maybe_unused]] uint32_t index_shift,
                                                         bool plain_stores) {
@@ -457,60 +457,122 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     };
 
     size_t tb = 0;
+    bool all_done = false;
     {
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)my_len + 8) < 0x80000000ull;
         if (n_full > 0 && N < (1u << 24) && !__any(!off_ok)) {
+            // Rows of any length and alignment (row_skew, cst_ans_kernels.hpp; as in the ANS decoders): every lane first decodes
+            // the `pre` symbols in front of its row's next cache-line boundary, so that its tiles -- and the 128-byte segments the
+            // tile stores write -- are whole cache lines.
+            const bool skew = !SM && N >= 4 * kTileSyms;
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+            int32_t* out_row = a.symbols + se * (SM ? 0 : N);
+            // `count` more symbols of every lane that has them, straight to HBM (the window is topped up every four)
+            auto direct = [&](uint32_t first, uint32_t have, uint32_t count) {
+                for (uint32_t j = 0; j < count; ++j) {
+                    if (j < have) { const int32_t sym = step(); if (active) out_row[first + j] = sym; }
+                    if ((j & 3) == 3) { L.in.fill_blocking(); wave_lds_fence(); }
+                }
+                L.in.fill_blocking();
+                wave_lds_fence();
+            };
+            uint32_t pre = 0;
+            size_t n_loop = n_full;
+            if (skew) {
+                pre = row_skew(a.symbols, se, N);
+                uint32_t max_pre = pre;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) max_pre = max(max_pre, (uint32_t)__shfl_xor((int)max_pre, d));
+                max_pre = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_pre);
+                if (max_pre) direct(0, pre, max_pre);
+                n_loop = (N - max_pre) / kTileSyms;             // whole tiles every lane has (>= 3)
+            }
+            // the eight store offsets of a tile's pieces: the statements read them from the lane's row of their CURRENT buffer
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (SM) {
+                    goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * (k >> 1)) * a.n_streams + 32 * (size_t)(k & 1) + 4 * (size_t)(lane & 7)) * 4);
+                } else {
+                    const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                    goff[k] = (uint32_t)((R * N + (skew ? row_skew(a.symbols, s0 + R, N) : 0u) + 4 * (size_t)(lane & 7)) * 4);
+                }
+            }
+            auto leave_offsets = [&](uint32_t row_cur_addr) {
+                int32_t* cur = row_cur_addr == lds_addr(tile + lane * kTileStride) ? tile : tile_b;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cur[lane * kTileStride + k] = (int32_t)goff[k];
+                wave_lds_fence();
+            };
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statements keep their own book from here
             const uint32_t shift = L.in.shift;
-            const uint32_t goff_limit = SM ? 0xffffffffu : (uint32_t)(((min((size_t)kWave, a.n_streams - s0) - 1) * N + 4 * (size_t)(lane & 7)) * 4);
-            uint32_t x0 = (uint32_t)L.point, x1 = (uint32_t)(L.point >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
+            // (the statements carry x = point - lower: after the skew symbols `lower` is no longer 0)
+            const uint64_t x_in = (uint64_t)L.point - (uint64_t)L.lower;
+            uint32_t x0 = (uint32_t)x_in, x1 = (uint32_t)(x_in >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
             uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
             const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
             const uint32_t tr_off = SM ? (uint32_t)(((4 * (lane & 7)) * kTileStride + (lane >> 3)) * 4)
                                        : (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             uint32_t row_cur = lds_addr(tile + lane * kTileStride), row_prev = lds_addr(tile_b + lane * kTileStride);
             uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
-            uint32_t tiles = (uint32_t)n_full, ginc = 0, bad = 0, bad2 = 0;
+            uint32_t tiles = (uint32_t)n_loop, ginc = 0, bad = 0, bad2 = 0;
             const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(SM ? a.symbols + s0 : a.symbols + s0 * N);
             const uint32_t tile_step = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(SM ? kTileSyms * a.n_streams * 4 : kTileSyms * 4));
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-            // rows that do not start on cache-line boundaries: plain tile stores (scripts/gen_decode_loop.py, CST_STORE_MOD)
-            // (symbol-major: 64-byte pieces of rows of n_streams symbols, line-aligned iff the rows are)
-            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((((SM ? a.n_streams : N) * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
-            const uint32_t goff0 = SM ? (uint32_t)((((size_t)(lane >> 3)) * a.n_streams + 4 * (size_t)(lane & 7)) * 4)
-                                      : (uint32_t)((((size_t)(lane >> 3)) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint32_t goff_stride = SM ? (uint32_t)(8 * a.n_streams * 4) : (uint32_t)(8 * N * 4);
+            // rows that do not start on cache-line boundaries and are too short for the skew: plain tile stores
+            // (scripts/gen_decode_loop.py, CST_STORE_MOD; symbol-major: rows of n_streams symbols, line-aligned iff the rows are)
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((!skew && (((SM ? a.n_streams : N) * 4) % 128 != 0 || (sb & 127) != 0)) ? 1 : 0)) != 0;
             const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
             // the estimate's error is 2^(P - 48.5): the bias on top of it (high word of the f64)
             const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22
             const uint32_t lut_addr = B16 ? lds_addr(blut.b16) : lds_addr(lut);
             const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
             const uint32_t idx_shift = B16 ? (uint32_t)blut.idx_shift : 24u, idx_mask = (1u << idx_shift) - 1u;
+            leave_offsets(row_cur);
             range_decode_tiles_loop<false, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
-                                                    qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, goff_stride, lens, endr,
-                                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
+                                                    qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, lens, endr,
+                                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift),
                                                     cdf_addr, a.min_symbol, tile_step, idx_mask, idx_shift, plain_stores);
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
-                const uint32_t done = (uint32_t)n_full - tiles;
+                const uint32_t done = (uint32_t)n_loop - tiles;
                 const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * tile_step : 0);
+                leave_offsets(row_cur);
                 range_decode_tiles_loop<true, B16, SM>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
-                                                       lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, goff_stride, lens, endr,
-                                                       lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, goff0, goff_limit, (uint32_t)bucket_shift,
+                                                       lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, lens, endr,
+                                                       lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift),
                                                        cdf_addr, a.min_symbol, tile_step, idx_mask, idx_shift, plain_stores);
             }
             if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
                 // the last tile is still in LDS (buffer A if it has an even index)
                 wave_lds_fence();
-                if constexpr (SM) tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
-                else tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, ((n_full - 1) & 1) ? tile_b : tile);
+                const int32_t* last = ((n_loop - 1) & 1) ? tile_b : tile;
+                if constexpr (SM) tile_store_sm(a.symbols, a.n_streams, s0, (n_full - 1) * kTileSyms, lane, last);
+                else if (!skew) tile_store<true>(a.symbols, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, last);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                        const int4 v = *reinterpret_cast<const int4*>(last + ((lane >> 3) + 8 * k) * kTileStride + 4 * (lane & 7));
+                        v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                        __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(a.symbols + (s0 + R) * N + row_skew(a.symbols, s0 + R, N) + (n_loop - 1) * kTileSyms + 4 * (lane & 7)));
+                    }
+                }
                 wave_lds_fence();
                 L.lower = 0; L.point = ((uint64_t)x1 << 32) | x0; L.range = ((uint64_t)rg1 << 32) | rg0;
                 L.in.pos = pos - shift; L.in.hi_issued = hi_issued;
                 tb = n_full;
+                if (skew) {
+                    // ... and what is left of each row behind its last whole tile (fewer than 64 symbols)
+                    L.in.fill_blocking();
+                    wave_lds_fence();
+                    const uint32_t done = pre + (uint32_t)(n_loop * kTileSyms);
+                    direct(done, (uint32_t)N - done, (uint32_t)N - (uint32_t)(n_loop * kTileSyms));
+                    all_done = true;
+                }
             } else {
                 // a quantile estimate failed its check, or the data are invalid: the wave's streams again, exactly
                 L.init(my_words, my_len, ring, lane);
@@ -535,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void range_decode_fast_kernel(const RangeDe
     }
     int32_t* row = SM ? a.symbols + (active ? s : 0) : a.symbols + (active ? s : 0) * N;
     const size_t row_step = SM ? a.n_streams : 1;
-    for (size_t t = n_full * kTileSyms; t < N; ++t) {
+    for (size_t t = all_done ? N : n_full * kTileSyms; t < N; ++t) {
         const int32_t sym = step();
         if (active) row[t * row_step] = sym;
         L.in.advance_window();

@@ -36,7 +36,7 @@ OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC /
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
 # SYMBOL_MAJOR (the same four files with _sm): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR (whole lines): quad k of the
 # previous tile leaves as streams 32 (k & 1) + 4 (lane & 7) .. + 3 of symbol row (lane >> 3) + 8 (k >> 1); full waves only
-# (goff0 = that position for k = 0, gstride = 8 rows, the store base moves by %[tilestep] per tile).
+# (the store base moves by %[tilestep] per tile).
 SYMBOL_MAJOR = False
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
@@ -131,16 +131,12 @@ def gen(ends):
     a.i(f"v_mov_b32 {POS}, %[pos]"); a.i(f"v_mov_b32 {HI}, %[hi_issued]")
     a.i("v_mov_b32 v144, 0"); a.i("v_mov_b32 v145, 0x41f00000", "2^32")
     a.i("v_mov_b32 v146, 0"); a.i("v_mov_b32 v147, %[dhi]", "+2^-30 (P <= 16) or +2^-22: above the estimate's error of 2^(P - 48.5)")
-    if SYMBOL_MAJOR:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(glim = 0xffffffff: full waves only)")
-        a.i(f"v_add_u32 {GOFF[1]}, 0x80, {GOFF[0]}", "streams + 32")
-        for k in range(2, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 2]}", "symbol rows + 8")
-    else:
-        a.i(f"v_min_u32 {GOFF[0]}, %[goff0], %[glim]", "(rows beyond the last stream of a partial wave fall on its last row: they hold the same symbols)")
-        for k in range(1, 8):
-            a.i(f"v_add_u32 {GOFF[k]}, %[gstride], {GOFF[k - 1]}", "rows (lane >> 3) + 8k")
-            a.i(f"v_min_u32 {GOFF[k]}, {GOFF[k]}, %[glim]")
+    # the eight store offsets wait in the lane's row of the CURRENT tile buffer (gen_decode_loop_b16.py: rows of any length,
+    # partial waves and the symbol-major mapping are the kernel's business; it writes them in front of EACH of the two
+    # statements, whose current buffer differs)
+    a.ds(f"ds_read_b128 {tup(196, 4)}, %[rowcur]", "goff")
+    a.ds(f"ds_read_b128 {tup(200, 4)}, %[rowcur] offset:16", "goff")
+    a.wait_lds_all("the store offsets")
     a.i(f"s_mov_b64 {BAD}, 0")
     a.i("s_mov_b64 s[80:81], %[gbase]", "where the PREVIOUS tile goes (first tile of all: onto itself, rewritten one tile later)")
     a.i("v_readfirstlane_b32 s82, %[tiles]", "tiles left")
@@ -313,8 +309,8 @@ def main():
                    '      [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev), [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev), [tiles] "+v"(tiles), [ginc] "+v"(ginc),',
                    '      [bad] "=v"(bad)',
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
-                   '      [gbase] "s"(store_base), [gstride] "s"(goff_stride), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
-                   '      [dump] "v"(dump_addr), [woff] "v"(words_off), [goff0] "v"(goff0), [glim] "v"(goff_limit)' +
+                   '      [gbase] "s"(store_base), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
+                   '      [dump] "v"(dump_addr), [woff] "v"(words_off)' +
                    (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else '') +
                    (', [tilestep] "s"(tile_step_bytes)' if sm else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]

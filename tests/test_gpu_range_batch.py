@@ -263,11 +263,11 @@ def test_range_bucket_entry_decoder_walks_the_tails(B, O, P):
 @pytest.mark.parametrize("base_shift", [0, 1, 3])
 @pytest.mark.parametrize("P", [12, 24])
 def test_range_rows_of_any_length(B, O, n_per, base_shift, P):
-    """The range ENCODER's main-loop statement on rows that do not start on cache-line boundaries (row_skew, cst_ans_kernels.hpp:
-    the symbols in front of a row's next 128-byte boundary and behind its last whole tile are coded outside the statement, which
-    continues from the state they left); symbol buffers 4 and 12 bytes off a 16-byte boundary, full waves plus a partial one,
-    a skewed model whose carries travel (the slow-path repeat from the first symbol); words against the oracle, and the decoder
-    on the same rows."""
+    """The range coder's main-loop statements on rows that do not start on cache-line boundaries (row_skew, cst_ans_kernels.hpp:
+    the symbols in front of a row's next 128-byte boundary and behind its last whole tile are coded outside the statements, which
+    continue from the state they left); symbol buffers 4 and 12 bytes off a 16-byte boundary, full waves plus a partial one,
+    a skewed model whose carries travel (the encoder's slow-path repeat from the first symbol); words against the oracle,
+    decoded symbols against the input, nothing written outside the rows."""
     n_streams = 200
     rng = np.random.default_rng(P + n_per)
     cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(40) * 0.3), P)
@@ -287,3 +287,4 @@ def test_range_rows_of_any_length(B, O, n_per, base_shift, P):
     dec, st = B.range_decode(enc, model, n_per, out=out)
     torch.cuda.synchronize()
     assert (st.cpu().numpy() == 0).all() and np.array_equal(out.cpu().numpy(), sym)
+    assert (buf[:base_shift].cpu().numpy() == -99).all() and (buf[base_shift + n_streams * n_per:].cpu().numpy() == -99).all()
