@@ -247,14 +247,7 @@ __device__ inline double erf_exact_tab(double x, const double2* tab) {
 constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_poly - erf_exact_tab|
 constexpr double kLeftGuard = 0x1p-20;       // >= 2^24 * kErfFastBound / 2 + rounding of the two products, with room to spare
 
-// 1 / b to ~1 ulp without the IEEE division sequence (v_rcp_f64 is good to 2^-24 on gfx950: two Newton steps)
-__device__ __forceinline__ double fast_rcp(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-}
-
-// 1 / b to 2^-48 (one Newton step): enough wherever the consumer has slack of its own -- the argument of the fast erf (an
+// 1 / b to 2^-48 (v_rcp_f64 is good to 2^-24.4 on gfx950, scripts/microbench/rcp_f64_error.hip; one Newton step): enough wherever the consumer has slack of its own -- the argument of the fast erf (an
 // argument off by 2^-48 moves erf by < 2^-49), quotients that are corrected by their exact remainder
 __device__ __forceinline__ double fast_rcp1(double b) {
     const double r = __builtin_amdgcn_rcp(b);
@@ -266,13 +259,6 @@ __device__ __forceinline__ uint32_t f64_as_u32_hw(double v) {
     uint32_t r;
     asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
     return r;
-}
-
-// a / b with a residual correction (the host-style use in make_entry_f64 wants the last ulp or so)
-__device__ __forceinline__ double fast_div(double a, double b) {
-    const double r = fast_rcp(b);
-    const double q = a * r;
-    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
 // erf(x) to 2^-52 (absolute) for every finite x; |x| >= 6 evaluates the last polynomial at its upper end (1 - 2e-17).
