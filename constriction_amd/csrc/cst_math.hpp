@@ -263,21 +263,27 @@ __device__ __forceinline__ uint32_t f64_as_u32_hw(double v) {
 
 // erf(x) to 2^-52 (absolute) for every finite x; |x| >= 6 evaluates the last polynomial at its upper end (1 - 2e-17).
 // A NaN comes back as +-1: callers that care test the argument (leaky_left_value_quick does).
-__device__ __forceinline__ double erf_fast_poly(double x, const double2* tab) {
+// In two halves, so that a caller with several arguments can have ALL their coefficient reads in flight before the first
+// multiply-add (erf_poly_fetch for each, a scheduling barrier, erf_poly_eval for each): left to itself the compiler reads,
+// waits and evaluates one argument after the other, and a lone wave then pays an LDS round trip per argument.
+struct ErfPoly { double u; double2 c01, c23, c45, c67; };
+__device__ __forceinline__ ErfPoly erf_poly_fetch(double x, const double2* tab) {
     const double s = __builtin_fmin(__builtin_fabs(x) * 16.0, 0x1.7ffffffffffffp+6);     // interval number + position in it, < 96
     const int idx = (int)s;
-    const double u = __builtin_fma(__builtin_amdgcn_fract(s), 2.0, -1.0);
     const double2* row = tab + kErfExactEntries + idx * kErfPolyRowD2;
-    const double2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3];
-    double y = __builtin_fma(c67.y, u, c67.x);
-    y = __builtin_fma(y, u, c45.y);
-    y = __builtin_fma(y, u, c45.x);
-    y = __builtin_fma(y, u, c23.y);
-    y = __builtin_fma(y, u, c23.x);
-    y = __builtin_fma(y, u, c01.y);
-    y = __builtin_fma(y, u, c01.x);
+    return ErfPoly{__builtin_fma(__builtin_amdgcn_fract(s), 2.0, -1.0), row[0], row[1], row[2], row[3]};
+}
+__device__ __forceinline__ double erf_poly_eval(const ErfPoly& e, double x) {
+    double y = __builtin_fma(e.c67.y, e.u, e.c67.x);
+    y = __builtin_fma(y, e.u, e.c45.y);
+    y = __builtin_fma(y, e.u, e.c45.x);
+    y = __builtin_fma(y, e.u, e.c23.y);
+    y = __builtin_fma(y, e.u, e.c23.x);
+    y = __builtin_fma(y, e.u, e.c01.y);
+    y = __builtin_fma(y, e.u, e.c01.x);
     return __builtin_copysign(y, x);
 }
+__device__ __forceinline__ double erf_fast_poly(double x, const double2* tab) { return erf_poly_eval(erf_poly_fetch(x, tab), x); }
 
 // probability::distribution::Gaussian::distribution (third-party; used at quantize.rs:546,558)
 // (TAB: erf_exact_tab with the LDS table `tab` instead of the branchy erf_exact -- same bits either way.  A template
@@ -394,13 +400,19 @@ __device__ __forceinline__ void leaky_gaussian_left3_quick(uint32_t g, int32_t l
     const double inv_d = fast_rcp1(sigma * sqrt2);
     const double x1 = (double)(int32_t)((uint32_t)lo + g) - 0.5;
     const double x[3] = {x1 - 1.0, x1, x1 + 1.0};
-    double y[3];
+    double y[3], arg[3];
     bool unsure[3];
+    ErfPoly e[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double arg = (x[k] - mu) * inv_d;
-        y[k] = __builtin_fma(erf_fast_poly(arg, tab), half, half);
-        unsure[k] = !(__builtin_fabs(arg) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(y[k]) - 0.5) < 0.5 - kLeftGuard);
+        arg[k] = (x[k] - mu) * inv_d;
+        e[k] = erf_poly_fetch(arg[k], tab);
+    }
+    __builtin_amdgcn_sched_barrier(0);               // (all twelve reads are under way before the first of them is needed)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        y[k] = __builtin_fma(erf_poly_eval(e[k], arg[k]), half, half);
+        unsure[k] = !(__builtin_fabs(arg[k]) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(y[k]) - 0.5) < 0.5 - kLeftGuard);
     }
     unsure[0] = unsure[0] && g > 1u;                 // (index 0 and index n are not evaluated: 0 and 2^P)
     unsure[2] = unsure[2] && g + 1u < n;
@@ -431,7 +443,9 @@ __device__ __forceinline__ bool leaky_gaussian_lcp_quick(int32_t sym, int32_t lo
     const double inv_d = fast_rcp1(sigma * sqrt2);
     const double xl = (double)sc - 0.5, xr = (double)sc + 0.5;
     const double al = (xl - mu) * inv_d, ar = (xr - mu) * inv_d;
-    double yl = __builtin_fma(erf_fast_poly(al, tab), half, half), yr = __builtin_fma(erf_fast_poly(ar, tab), half, half);
+    const ErfPoly el = erf_poly_fetch(al, tab), er = erf_poly_fetch(ar, tab);
+    __builtin_amdgcn_sched_barrier(0);               // (all eight reads are under way before the first of them is needed)
+    double yl = __builtin_fma(erf_poly_eval(el, al), half, half), yr = __builtin_fma(erf_poly_eval(er, ar), half, half);
     // in doubt (see leaky_left_value_quick): not saturated and within kLeftGuard of an integer -- or a NaN argument
     const bool unsure_l = !(__builtin_fabs(al) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(yl) - 0.5) < 0.5 - kLeftGuard) && sc != lo;
     const bool unsure_r = !(__builtin_fabs(ar) >= 6.0 || __builtin_fabs(__builtin_amdgcn_fract(yr) - 0.5) < 0.5 - kLeftGuard) && sc != hi;
