@@ -377,7 +377,26 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
     int32_t sy_q[kFuAhead];
     double mu_q[kFuAhead], sd_q[kFuAhead];
     bool ok_q[kFuAhead];
+    // Full waves over rows of whole tiles walk the matrices by ADDING: item `it` of tile k lies at
+    //   base(lane) + it * item_stride + k * tile_stride      (both strides wave-uniform, in either layout)
+    // and the items are requested in exactly that order, so one running index per lane replaces the per-item index arithmetic
+    // (two 64-bit multiply-adds, bounds tests and their exec masks: ~25 VALU and ~15 SALU per item).
+    const bool walk = s0 + kFuStreams <= a.n_streams && N % kFuTile == 0;
+    const int64_t item_stride = symbol_major ? (int64_t)(kWave / kFuStreams) * (int64_t)a.n_streams : (int64_t)(kWave / kFuTile) * (int64_t)N;
+    const int64_t tile_stride = symbol_major ? (int64_t)kFuTile * (int64_t)a.n_streams : (int64_t)kFuTile;
+    const int64_t wrap_delta = (KIND == kAns ? -tile_stride : tile_stride) - (int64_t)(kFuIters - 1) * item_stride;
+    int64_t e_req = symbol_major ? (int64_t)item_t(0) * (int64_t)a.n_streams + (int64_t)(s0 + (size_t)item_j(0))
+                                 : (int64_t)(s0 + (size_t)item_j(0)) * (int64_t)N + (int64_t)item_t(0);
+    if (n_tiles > 0) e_req += (int64_t)tile_of(0) * tile_stride;
     auto request = [&](int slot, size_t k, int it) {
+        if (walk) {
+            ok_q[slot] = true;
+            sy_q[slot] = __builtin_nontemporal_load(a.symbols + e_req);
+            mu_q[slot] = __builtin_nontemporal_load(a.means + e_req);
+            sd_q[slot] = __builtin_nontemporal_load(a.stds + e_req);
+            e_req += it == kFuIters - 1 ? wrap_delta : item_stride;
+            return;
+        }
         const size_t sj = s0 + (size_t)item_j(it), t = k * kFuTile + (size_t)item_t(it);
         ok_q[slot] = sj < a.n_streams && t < N;
         // (unconditional loads from an address that is always valid: a conditional load is waited for at once)

@@ -201,3 +201,29 @@ def test_fused_encoder_step_variants(B, O, P, monkeypatch):
         c = O.AnsCoder(W=32, S=64)
         c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], P, 32)
         assert words[s, : n_words[s]].tolist() == c.get_compressed().tolist(), f"stream {s}"
+
+
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, monkeypatch):
+    """Full waves (a multiple of 32 streams) over rows of whole 16-symbol tiles: the fused Gaussian encoder then walks its three
+    input matrices by adding strides to one running index per lane instead of computing every item's index (the shape of the
+    bench's f1 entry); 96 streams x 80 symbols in both layouts and both coders, words against the oracle."""
+    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")
+    lo, hi, P = -100, 100, 24
+    n_streams, n_per = 96, 80
+    sym, mu, sd = workload(n_streams, n_per, lo, hi, 4242)
+    t = (lambda a: a.T) if layout == "symbol_major" else (lambda a: a)
+    enc_fn = B.ans_encode_gaussian if coder == "ans" else B.range_encode_gaussian
+    enc = enc_fn(dev(t(sym)), lo, hi, dev(t(mu)), dev(t(sd)), (32, 64, P), layout)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    for s in range(n_streams):
+        if coder == "ans":
+            c = O.AnsCoder(W=32, S=64)
+            c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], P, 32)
+        else:
+            c = O.RangeEncoder(W=32, S=64)
+            c.encode(sym[s], [O.GaussianModel(lo, hi, m, d, P, 32) for m, d in zip(mu[s], sd[s])], P)
+        assert words[s, : n_words[s]].tolist() == c.get_compressed().tolist(), f"stream {s}"
