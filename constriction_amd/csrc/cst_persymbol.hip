@@ -792,10 +792,13 @@ __device__ __forceinline__ float ndtri_lower_f32(float tail) {
         c6 = 2.938163982698783e+00f, d1 = 7.784695709041462e-03f, d2 = 3.224671290700398e-01f, d3 = 2.445134137142996e+00f,
         d4 = 3.754408661907416e+00f;
     // both branches, then a select: cheaper than diverging over 25 instructions
+    // (explicit fused multiply-adds: the library is built with -ffp-contract=off for its bit-exact f64 paths, and a guess
+    // has no bits to keep)
+    auto f = [](float a, float b, float c) { return __builtin_fmaf(a, b, c); };
     const float q = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(tail));          // sqrt(-2 ln(tail))
-    const float zt = (((((c1 * q + c2) * q + c3) * q + c4) * q + c5) * q + c6) * __builtin_amdgcn_rcpf((((d1 * q + d2) * q + d3) * q + d4) * q + 1.0f);
+    const float zt = f(f(f(f(f(c1, q, c2), q, c3), q, c4), q, c5), q, c6) * __builtin_amdgcn_rcpf(f(f(f(f(d1, q, d2), q, d3), q, d4), q, 1.0f));
     const float u = tail - 0.5f, r = u * u;
-    const float zc = (((((a1 * r + a2) * r + a3) * r + a4) * r + a5) * r + a6) * u * __builtin_amdgcn_rcpf(((((b1 * r + b2) * r + b3) * r + b4) * r + b5) * r + 1.0f);
+    const float zc = f(f(f(f(f(a1, r, a2), r, a3), r, a4), r, a5), r, a6) * u * __builtin_amdgcn_rcpf(f(f(f(f(f(b1, r, b2), r, b3), r, b4), r, b5), r, 1.0f));
     return tail < 0.02425f ? zt : zc;
 }
 
@@ -804,9 +807,9 @@ __device__ __forceinline__ float ndtri_lower_f32(float tail) {
 // wave has sigma >= 200.
 __device__ __forceinline__ float ndtri_lower_coarse_f32(float tail) {
     const float t = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(tail));          // sqrt(-2 ln(tail))
-    const float num = (0.010328f * t + 0.802853f) * t + 2.515517f;
-    const float den = ((0.001308f * t + 0.189269f) * t + 1.432788f) * t + 1.0f;
-    return num * __builtin_amdgcn_rcpf(den) - t;
+    const float num = __builtin_fmaf(__builtin_fmaf(0.010328f, t, 0.802853f), t, 2.515517f);
+    const float den = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.001308f, t, 0.189269f), t, 1.432788f), t, 1.0f);
+    return __builtin_fmaf(num, __builtin_amdgcn_rcpf(den), -t);
 }
 
 // Out of line ON PURPOSE: inlined, the compiler hoists the 32 + 8 row addresses of both variants out of the symbol loop
