@@ -482,6 +482,18 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
                         else if (!bad) LA.template step<false>(use_inv ? make_entry(e.c, e.p) : e, P);
                     }
                 }
+            } else if (n_here == kFuTile) {
+                // a whole tile: all sixteen (c, p) first (one LDS wait), then sixteen steps; an impossible symbol is coded as
+                // (0, 1) -- its stream is flagged and its words are never used
+                uint2 e[kFuTile];
+#pragma unroll
+                for (int tl = 0; tl < kFuTile; ++tl) e[tl] = *reinterpret_cast<const uint2*>(&tile[tl * kFuRowStride + lane]);
+#pragma unroll
+                for (int tl = 0; tl < kFuTile; ++tl) {
+                    const bool none = e[tl].y == 0;
+                    bad |= none ? 1u : 0u;
+                    LR.step(none ? 0u : e[tl].x, none ? 1u : e[tl].y, P);
+                }
             } else {
                 for (int tl = 0; tl < n_here; ++tl) {
                     const EncEntry e = tile[tl * kFuRowStride + lane];
