@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Best-of kernel times of one coder / preset at the headline shape (for A/B experiments on a noisy shared box):
+usage: bench_min.py ans|range W S P [n_per] [layout] -- min and median over 8 rounds of 10 launches each"""
+import sys
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import bench
+from constriction_amd import batched as B
+
+coder, W, S, P = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
+layout = sys.argv[6] if len(sys.argv) > 6 else "stream_major"
+n = 65536
+m = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
+sym = bench.synth_symbols_device(0xC0FFEE, 0, n, k, -50, cdf, P)
+if layout == "symbol_major":
+    sym = sym.t().contiguous()
+enc_f, dec_f = (B.ans_encode, B.ans_decode) if coder == "ans" else (B.range_encode, B.range_decode)
+enc = enc_f(sym, m, (W, S, P), layout)
+dec = torch.empty_like(sym)
+es, ds = [], []
+for rep in range(8):
+    es.append(bench.event_ms(lambda: enc_f(sym, m, (W, S, P), layout, out=enc), 10))
+    ds.append(bench.event_ms(lambda: dec_f(enc, m, k, layout, out=dec), 10))
+print(f"{coder} ({W},{S},{P}) {k} {layout}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}")
