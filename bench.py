@@ -576,9 +576,14 @@ def main():
         per_rank = [{"rank": int(r[0]), "encode_ms": round(float(r[1]), 4), "decode_ms": round(float(r[2]), 4), "words": int(r[3])} for r in rows]
         ranks_seen = len({int(r[0]) for r in rows})
 
-    configs = None
+    # the `configs` block is a report beside the bench line: whatever goes wrong in it (a collective of the gather leg on a
+    # box this script has never seen, say) must not take the line itself -- measured above -- with it
+    configs, configs_error = None, None
     if not args.no_configs:
-        configs = other_configs(B, rank, world, dist, args)
+        try:
+            configs = other_configs(B, rank, world, dist, args)
+        except Exception as exc:      # noqa: BLE001
+            configs_error = f"{type(exc).__name__}: {exc}"[:300]
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the committed summary
