@@ -107,6 +107,11 @@ def synth_symbols_per_stream(seed, stream_begin, n_per, lo, cdf_rows, precision,
     return out
 
 
+def host_cores():
+    """host threads this rank may use for the oracle checks: the box's cores shared among the ranks of the job"""
+    return max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
+
+
 def _blocks(n, parts):
     step = max(1, (n + parts - 1) // parts)
     return [(a, min(a + step, n)) for a in range(0, n, step)]
@@ -116,7 +121,7 @@ def cpu_words_match(kind, sym_host, gpu_words, gpu_n_words, lo, cdf, precision, 
     """Encodes EVERY stream with the CPU oracle (one block of streams per host thread; the C code runs without the
     GIL) and compares word counts and words with the GPU's slabs.  cdf: [n+1] shared or [n_streams][n+1]."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     per_stream = cdf.ndim == 2
 
     def work(ab):
@@ -141,7 +146,7 @@ def cpu_words_match(kind, sym_host, gpu_words, gpu_n_words, lo, cdf, precision, 
 def cpu_tables(lo, hi, mu, sigma, precision):
     """one quantized-Gaussian cdf per stream from the oracle (host threads)"""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
 
     def work(ab):
         return np.stack([O.GaussianModel(lo, hi, float(m), float(s), precision, 32).cdf_table() for m, s in zip(mu[ab[0]:ab[1]], sigma[ab[0]:ab[1]])])
@@ -154,7 +159,7 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
     """Times the CPU oracle (kind "port": the repo's C restatement of the reference arithmetic, -O3 -march=native,
     one disjoint block of streams per thread) on this box's host cores, on the SAME symbols the GPU coded."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     lut = O.lookup_from_cdf(cdf, P)
 
     def run(sym, threads):
@@ -277,7 +282,7 @@ def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100,
                     if len(w) != n_words[s] or not np.array_equal(w, words[s, : n_words[s]]):
                         return False
                 return True
-            cores = os.cpu_count() or 1
+            cores = host_cores()
             with ThreadPoolExecutor(max_workers=cores) as pool:
                 ok = all(pool.map(work, _blocks(n_streams, 8 * cores)))
             entry["bit_exact_scope"] = f"all {n_streams} streams: words and counts vs CPU oracle, decoded symbols vs input"
