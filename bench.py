@@ -304,39 +304,41 @@ def other_configs(B, rank, world, dist, args, reps=5):
             assert cdf.tolist() == O.GaussianModel(lo, hi, MEAN, STD, precision, 32).cdf_table().tolist(), "device table != oracle"
         return m, cdf
 
+    def add(name, *a, **k):
+        """one entry; whatever goes wrong inside it is reported in its place (and fails the run's check) instead of taking the
+        other entries with it"""
+        try:
+            entry = run_config(B, name, *a, **k)[0]
+        except Exception as exc:      # noqa: BLE001
+            entry = {"name": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
+        out.append(entry)
+
     m12, cdf12 = gaussian(12)
     cdf12_dev = torch.from_numpy(cdf12.astype(np.int64)).cuda()
     sym12 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, cdf12_dev, 12)
     if world == 1:
         symT = sym12.t().contiguous()
-        e, _ = run_config(B, "C2 as symbols[t][stream] (symbol-major layout)", "ans", (32, 64, 12), m12, symT, reps, check, cdf12,
+        add("C2 as symbols[t][stream] (symbol-major layout)", "ans", (32, 64, 12), m12, symT, reps, check, cdf12,
                           layout="symbol_major")
-        out.append(e)
         del symT
-        e, _ = run_config(B, "C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
-        out.append(e)
+        add("C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
         m24, cdf24 = gaussian(24)
         sym24 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, torch.from_numpy(cdf24.astype(np.int64)).cuda(), 24)
-        e, _ = run_config(B, "C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
-        out.append(e)
-        e, _ = run_config(B, "C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
-        out.append(e)
-        e, _ = run_config(B, "C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
-        out.append(e)
+        add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        add("C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        add("C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         del sym24, m24
         symT = sym12.t().contiguous()
-        e, _ = run_config(B, "C4 range coder, P = 12, symbols[t][stream] (symbol-major layout)", "range", (32, 64, 12), m12, symT, reps, check, cdf12,
+        add("C4 range coder, P = 12, symbols[t][stream] (symbol-major layout)", "range", (32, 64, 12), m12, symT, reps, check, cdf12,
                           layout="symbol_major")
-        out.append(e)
         del symT
-        # an alphabet of 700 symbols at P = 16 and rows of 4100 symbols: no 2^P-entry lookup table, more symbols than a bucket entry
-        # addresses, rows that are not cache-line aligned (the shapes next to the hand-scheduled ones: scripts/bench_variants.py)
+        # an alphabet of 700 symbols at P = 16 and rows of 4100 symbols: no 2^P-entry lookup table, more symbols than an 8-bit bucket
+        # index addresses, rows that are not cache-line aligned (the shapes next to the headline one: scripts/bench_variants.py)
         big = B.Model.quantized_gaussian(-350, 349, 3.2, 96.0, 16)
         cdf_big = big.cdf()
         sym_big = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, 4100, -350, torch.from_numpy(cdf_big.astype(np.int64)).cuda(), 16)
-        e, _ = run_config(B, "ANS, 700 symbols at P = 16, rows of 4100 symbols (off the hand-scheduled paths)", "ans", (32, 64, 16), big, sym_big,
+        add("ANS, 700 symbols at P = 16, rows of 4100 symbols (10-bit bucket index, second-level tables, row skew)", "ans", (32, 64, 16), big, sym_big,
                           reps, check, cdf_big, lo=-350)
-        out.append(e)
         del sym_big, big
         # C3: one (mean, std) per stream, support -127..127
         # (SURVEY.md 8(d): parameters and symbols from the per-stream splitmix64 generators, like C2's)
@@ -345,8 +347,7 @@ def other_configs(B, rank, world, dist, args, reps=5):
         m3 = B.Model.quantized_gaussian_per_stream(-127, 127, mu_d, sigma_d, 12)
         sym3 = synth_symbols_per_stream(SEED, rank * N_STREAMS, N_PER, -127, m3.cdfs_device(), 12)
         cdfs = cpu_tables(-127, 127, mu, sigma, 12) if check else None
-        e, _ = run_config(B, "C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
-        out.append(e)
+        add("C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
         del sym3, m3, cdfs
         out.append(per_symbol_config(B, reps, check))
     del sym12
