@@ -310,7 +310,7 @@ def other_configs(B, rank, world, dist, args, reps=5):
         try:
             entry = run_config(B, name, *a, **k)[0]
         except Exception as exc:      # noqa: BLE001
-            entry = {"name": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
+            entry = {"workload": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
         out.append(entry)
 
     m12, cdf12 = gaussian(12)
