@@ -439,6 +439,9 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` block")
     ap.add_argument("--graph", action="store_true", help="replay the timed step as a HIP graph instead of launching eagerly")
+    ap.add_argument("--slab-stride", default="tuned",
+                    help="words between the headline batch's slabs: 'tuned' (batched.tuned_stride measures it before the warmup), "
+                         "'default' (max_words), or a number")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of the C5 shard's packed words")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--plumbing", action="store_true",
@@ -476,7 +479,9 @@ def main():
     cdf = model.cdf()
     cdf_dev = torch.from_numpy(cdf.astype(np.int64)).cuda()
     symbols = synth_symbols_device(SEED, rank * n_streams, n_streams, N_PER, LO, cdf_dev, P)
-    enc = B.ans_encode(symbols, model, (W, S, P))          # allocates slabs / counts once
+    # allocates slabs / counts once; how far apart the slabs lie is the caller's choice at the C ABI (stride_words)
+    slab_stride = {"tuned": "tuned", "default": None}.get(args.slab_stride) if not args.slab_stride.isdigit() else int(args.slab_stride)
+    enc = B.ans_encode(symbols, model, (W, S, P), stride=slab_stride)
     decoded = torch.empty_like(symbols)
     torch.cuda.synchronize()
 
@@ -618,6 +623,7 @@ def main():
             "bit_exact": ok, "bit_exact_scope": scope, "launch": launch_mode,
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4), "after_cache_flush": cold,
             "words_per_stream": round(total_words / n_streams, 2),
+            "slab_stride_words": int(enc.words.shape[1]), "slab_stride_source": args.slab_stride,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_cold": round(bytes_per_launch / (dom_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -211,6 +211,55 @@ def max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
     return N.load_library().cst_ans_max_words(n_per_stream, _cfg(*config))
 
 
+_TUNED_STRIDES = {}
+
+
+def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), layout="stream_major", span=640, step=32) -> int:
+    """The slab stride (words per stream, >= max_words) at which THIS batch shape codes fastest on this device, by measurement.
+
+    How far apart the slabs lie is the caller's choice (`stride_words` of the C ABI), and the P <= 12 ANS decoder is sensitive to
+    it: at 65 536 x 4096 it takes 0.25 ms at some strides and 0.35 ms at others, reproducibly, with nothing in the stride's
+    residues to go by ("Slab stride": the vector-memory unit takes longer over a load whose 64 lanes
+    address 64 lines `stride` apart).  So: encode and decode the given batch at every multiple of `step` words in
+    [max_words, max_words + span] (one encode, three decodes each, HIP events), keep the stride with the smallest
+    encode + decode time, remember it per (device, shape, preset, layout).  Costs about 30 ms and a few hundred MB of scratch
+    the first time; small batches (< 2^26 symbols) get max_words at once."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, _ = _layout_shape(symbols, layout)
+    base = max_words(n_per, config)
+    key = (symbols.device.index, n_streams, n_per, tuple(config), layout)
+    if key in _TUNED_STRIDES:
+        return _TUNED_STRIDES[key]
+    best = base
+    if n_streams * n_per >= (1 << 26):
+        first = (base + step - 1) // step * step
+        cands = [base] + [c for c in range(first, base + span + 1, step) if c != base]
+        flat = torch.empty(n_streams * max(cands), dtype=torch.int32, device=symbols.device)
+        n_words = torch.empty(n_streams, dtype=torch.int32, device=symbols.device)
+        status = torch.empty(n_streams, dtype=torch.int32, device=symbols.device)
+        decoded = torch.empty_like(symbols)
+
+        def ms(fn, reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            ev[0].record()
+            for k in range(reps):
+                fn()
+                ev[k + 1].record()
+            torch.cuda.synchronize()
+            return min(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
+
+        best_ms = None
+        for c in cands:
+            enc = EncodedBatch(flat[: n_streams * c].view(n_streams, c), n_words, status, tuple(config))
+            ans_encode(symbols, model, config, layout, out=enc)
+            t = ms(lambda: ans_encode(symbols, model, config, layout, out=enc), 2) + ms(lambda: ans_decode(enc, model, n_per, layout, out=decoded), 3)
+            if best_ms is None or t < best_ms:
+                best, best_ms = c, t
+        del flat, decoded
+    _TUNED_STRIDES[key] = best
+    return best
+
+
 def _layout_shape(symbols: torch.Tensor, layout: str):
     if symbols.dim() != 2:
         raise ValueError("symbols must be 2-d")
@@ -222,8 +271,13 @@ def _layout_shape(symbols: torch.Tensor, layout: str):
 
 
 def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-               stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
-    """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895)."""
+               stride=None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895).
+    stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride)."""
+    if isinstance(stride, str):
+        if stride != "tuned":
+            raise ValueError("stride must be a number of words or 'tuned'")
+        stride = tuned_stride(symbols, model, config, layout) if out is None else None
     symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:

@@ -1063,3 +1063,35 @@ def test_second_level_tables(B, O, coder, P, n_sym, period):
     for s in range(n_streams):
         assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), s
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+def test_tuned_stride(B, O):
+    """batched.tuned_stride: max_words for small batches without measuring; for a batch of 2^26 symbols a stride from the
+    candidate list, remembered per shape; and stride="tuned" changes where the slabs lie, never what is in them."""
+    P = 12
+    model, cdf = make_model(B, O, P)
+    small = dev(O.synth_symbols(3, 0, 256, 512, -50, cdf, P))
+    assert B.tuned_stride(small, model, (32, 64, P)) == B.max_words(512, (32, 64, P))
+    with pytest.raises(ValueError):
+        B.ans_encode(small, model, (32, 64, P), stride="fastest")
+    n_streams, n_per = 16384, 4096
+    head = O.synth_symbols(9, 0, 64, n_per, -50, cdf, P)
+    sym = dev(head).repeat(n_streams // 64, 1).contiguous()
+    base = B.max_words(n_per, (32, 64, P))
+    stride = B.tuned_stride(sym, model, (32, 64, P))
+    assert base <= stride <= base + 640 and (stride == base or stride % 32 == 0)
+    assert B.tuned_stride(sym, model, (32, 64, P)) == stride
+    enc = B.ans_encode(sym, model, (32, 64, P), stride="tuned")
+    assert enc.words.shape == (n_streams, stride)
+    want_words, want_n, _ = O.ans_encode_batch(head, -50, cdf, P)
+    torch.cuda.synchronize()
+    n_words = enc.n_words.cpu().numpy()
+    assert (enc.status.cpu().numpy() == 0).all()
+    for block in (0, n_streams // 64 - 1):
+        words = enc.words[block * 64: block * 64 + 64].cpu().numpy().view(np.uint32)
+        for s in range(64):
+            assert n_words[block * 64 + s] == want_n[s]
+            assert words[s, : want_n[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    dec, dstatus = B.ans_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, sym)
