@@ -202,7 +202,7 @@ def event_ms(fn, reps):
     return float(np.median([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
 
 
-def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major"):
+def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major", stride=None):
     """One entry of the `configs` block: kernel times of encode and decode (HIP events), achieved fraction of the HBM
     roofline (algorithmic bytes 4 B / symbol + 4 B / word per direction), bit-exactness of every stream.
     layout "symbol_major": `symbols` is [n_per, n_streams]."""
@@ -210,7 +210,7 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     enc_fn = B.ans_encode if coder == "ans" else B.range_encode
     dec_fn = B.ans_decode if coder == "ans" else B.range_decode
     kw = {} if layout == "stream_major" else {"layout": layout}
-    enc = enc_fn(symbols, model, cfg, **kw)
+    enc = enc_fn(symbols, model, cfg, stride=stride, **kw)      # stride "tuned": batched.tuned_stride, like the headline batch
     decoded = torch.empty_like(symbols)
     enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc, **kw), reps)
     dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded, **kw), reps)
@@ -221,6 +221,7 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
         "workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
         "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
         "Msymbols_per_s": round(n_sym / (enc_ms + dec_ms) / 1e3, 1), "words_per_stream": round(total_words / n_streams, 2),
+        "slab_stride_words": int(enc.words.shape[1]),
         "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
     }
@@ -308,7 +309,7 @@ def other_configs(B, rank, world, dist, args, reps=5):
         """one entry; whatever goes wrong inside it is reported in its place (and fails the run's check) instead of taking the
         other entries with it"""
         try:
-            entry = run_config(B, name, *a, **k)[0]
+            entry = run_config(B, name, *a, stride="tuned" if args.slab_stride == "tuned" else None, **k)[0]
         except Exception as exc:      # noqa: BLE001
             entry = {"workload": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
         out.append(entry)
@@ -355,7 +356,8 @@ def other_configs(B, rank, world, dist, args, reps=5):
     # C5 shard: 131 072 streams per GPU, compaction, gather of the packed words to rank 0
     n5 = args.c5_streams
     sym5 = synth_symbols_device(SEED, rank * n5, n5, N_PER, LO, cdf12_dev, 12)
-    e, enc5 = run_config(B, f"C5 shard: {n5} streams/GPU x {world} GPU(s)", "ans", (32, 64, 12), m12, sym5, reps, check and world == 1, cdf12)
+    e, enc5 = run_config(B, f"C5 shard: {n5} streams/GPU x {world} GPU(s)", "ans", (32, 64, 12), m12, sym5, reps, check and world == 1, cdf12,
+                         stride="tuned" if args.slab_stride == "tuned" else None)
     packed, offsets = B.compact(enc5)
     e["compact_ms"] = round(event_ms(lambda: B.compact(enc5, out=(packed, offsets)), reps), 4)
     if dist is not None and not args.no_gather:

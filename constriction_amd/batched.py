@@ -214,7 +214,8 @@ def max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
 _TUNED_STRIDES = {}
 
 
-def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), layout="stream_major", span=640, step=32) -> int:
+def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), layout="stream_major", span=640, step=32,
+                 coder="ans", report=None) -> int:
     """The slab stride (words per stream, >= max_words) at which THIS batch shape codes fastest on this device, by measurement.
 
     How far apart the slabs lie is the caller's choice (`stride_words` of the C ABI), and the P <= 12 ANS decoder is sensitive to
@@ -223,12 +224,16 @@ def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), lay
     address 64 lines `stride` apart).  So: encode and decode the given batch at every multiple of `step` words in
     [max_words, max_words + span] (one encode, three decodes each, HIP events), keep the stride with the smallest
     encode + decode time, remember it per (device, shape, preset, layout).  Costs about 30 ms and a few hundred MB of scratch
-    the first time; small batches (< 2^26 symbols) get max_words at once."""
+    the first time; small batches (< 2^26 symbols) get max_words at once.  coder="range": the same for range_encode /
+    range_decode.  report: a list that receives (stride, encode_ms, decode_ms) per candidate."""
     symbols = _require_cuda(symbols, torch.int32, "symbols")
     n_streams, n_per, _ = _layout_shape(symbols, layout)
-    base = max_words(n_per, config)
-    key = (symbols.device.index, n_streams, n_per, tuple(config), layout)
-    if key in _TUNED_STRIDES:
+    if coder not in ("ans", "range"):
+        raise ValueError("coder must be 'ans' or 'range'")
+    enc_fn, dec_fn, base = (ans_encode, ans_decode, max_words(n_per, config)) if coder == "ans" else \
+                           (range_encode, range_decode, range_max_words(n_per, config))
+    key = (symbols.device.index, n_streams, n_per, tuple(config), layout, coder)
+    if key in _TUNED_STRIDES and report is None:
         return _TUNED_STRIDES[key]
     best = base
     if n_streams * n_per >= (1 << 26):
@@ -251,10 +256,12 @@ def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), lay
         best_ms = None
         for c in cands:
             enc = EncodedBatch(flat[: n_streams * c].view(n_streams, c), n_words, status, tuple(config))
-            ans_encode(symbols, model, config, layout, out=enc)
-            t = ms(lambda: ans_encode(symbols, model, config, layout, out=enc), 2) + ms(lambda: ans_decode(enc, model, n_per, layout, out=decoded), 3)
-            if best_ms is None or t < best_ms:
-                best, best_ms = c, t
+            enc_fn(symbols, model, config, layout, out=enc)
+            te, td = ms(lambda: enc_fn(symbols, model, config, layout, out=enc), 2), ms(lambda: dec_fn(enc, model, n_per, layout, out=decoded), 3)
+            if report is not None:
+                report.append((c, te, td))
+            if best_ms is None or te + td < best_ms:
+                best, best_ms = c, te + td
         del flat, decoded
     _TUNED_STRIDES[key] = best
     return best
@@ -390,8 +397,13 @@ def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
 
 
 def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-                 stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
-    """One RangeEncoder per stream: encode_iid_symbols + get_compressed (queue.rs:612-705, 458-523)."""
+                 stride=None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+    """One RangeEncoder per stream: encode_iid_symbols + get_compressed (queue.rs:612-705, 458-523).
+    stride: words per slab (default range_max_words), or "tuned" (tuned_stride(..., coder="range"))."""
+    if isinstance(stride, str):
+        if stride != "tuned":
+            raise ValueError("stride must be a number of words or 'tuned'")
+        stride = tuned_stride(symbols, model, config, layout, coder="range") if out is None else None
     symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
