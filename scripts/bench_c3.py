@@ -22,3 +22,7 @@ for rep in range(6):
     es.append(bench.event_ms(lambda: B.ans_encode(sym, m3, (32, 64, 12), out=enc), 10))
     ds.append(bench.event_ms(lambda: B.ans_decode(enc, m3, k, out=dec), 10))
 print(f"C3 {os.environ.get('AB_LIB', 'lib')}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}")
+if os.environ.get("C3_STRIDES"):
+    rows = []
+    best = B.tuned_stride(sym, m3, (32, 64, 12), report=rows)
+    print("tuned", best, "  ".join(f"{c}:{te:.3f}+{td:.3f}" for c, te, td in rows))
