@@ -148,8 +148,7 @@ def gen():
             word_request()
         a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
         a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-        a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
-        a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
+        a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
                 a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
@@ -248,7 +247,7 @@ def emit(out):
               "// Main loop of the hand-scheduled (32,64) ANS decoder for 12 < P <= 24 (bucket entries): see cst_ans_b16.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
-           '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift),',
+           '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "v"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift),',
            '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [ntiles] "s"(n_tiles),',
            '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]

@@ -203,8 +203,7 @@ def gen(ends):
         if B16:
             a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-            a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V2}")
-            a.i(f"v_add_u32 {SYM[(quad % 2) * 4 + pos]}, %[minsym], {IDX}", "the decoded symbol")
+            a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
                 a.ds(f"ds_read_b32 v{172 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
@@ -311,7 +310,7 @@ def main():
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
                    '      [gbase] "s"(store_base), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
                    '      [dump] "v"(dump_addr), [woff] "v"(words_off)' +
-                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "s"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else '') +
+                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "v"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else '') +
                    (', [tilestep] "s"(tile_step_bytes)' if sm else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
             out = OUT[(b16, ends)]
