@@ -22,10 +22,10 @@ sym = bench.synth_symbols_device(0xC0FFEE, 0, n, k, -50, cdf, P)
 if layout == "symbol_major":
     sym = sym.t().contiguous()
 enc_f, dec_f = (B.ans_encode, B.ans_decode) if coder == "ans" else (B.range_encode, B.range_decode)
-enc = enc_f(sym, m, (W, S, P), layout)
+enc = enc_f(sym, m, (W, S, P), layout, stride=int(os.environ.get('STRIDE', 0)) or None)      # STRIDE=<words>: slab stride
 dec = torch.empty_like(sym)
 es, ds = [], []
 for rep in range(8):
     es.append(bench.event_ms(lambda: enc_f(sym, m, (W, S, P), layout, out=enc), 10))
     ds.append(bench.event_ms(lambda: dec_f(enc, m, k, layout, out=dec), 10))
-print(f"{coder} ({W},{S},{P}) {k} {layout}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}")
+print(f"{os.environ.get('AB_LIB', '').split('/')[-1]} stride {enc.words.shape[1]} {coder} ({W},{S},{P}) {k} {layout}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}")

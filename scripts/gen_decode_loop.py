@@ -73,7 +73,7 @@ def gen():
         if NO_LOAD:
             a.vm.append(f"chunk{k}")
         else:
-            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase] {os.environ.get('GEN_LOAD_MOD', '').replace('+', ' ')}".rstrip(), f"chunk{k}")
         a.i("s_mov_b64 exec, s[86:87]")
 
     # ---- first lookup of the tile ----
