@@ -8,6 +8,8 @@ streams only; all computation happens in the HIP library behind include/constric
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -225,16 +227,32 @@ def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), lay
     [max_words, max_words + span] (one encode, three decodes each, HIP events), keep the stride with the smallest
     encode + decode time, remember it per (device, shape, preset, layout).  Costs about 30 ms and a few hundred MB of scratch
     the first time; small batches (< 2^26 symbols) get max_words at once.  coder="range": the same for range_encode /
-    range_decode.  report: a list that receives (stride, encode_ms, decode_ms) per candidate."""
+    range_decode.  report: a list that receives (stride, encode_ms, decode_ms) per candidate.  With the environment variable
+    CST_STRIDE_CACHE=<file.json> the choice is kept across processes (one file per kind of device)."""
     symbols = _require_cuda(symbols, torch.int32, "symbols")
     n_streams, n_per, _ = _layout_shape(symbols, layout)
     if coder not in ("ans", "range"):
         raise ValueError("coder must be 'ans' or 'range'")
     enc_fn, dec_fn, base = (ans_encode, ans_decode, max_words(n_per, config)) if coder == "ans" else \
                            (range_encode, range_decode, range_max_words(n_per, config))
-    key = (symbols.device.index, n_streams, n_per, tuple(config), layout, coder)
+    # (what picks the kernel: the batch shape, the preset, the layout, the coder, one table or one per stream, the alphabet size)
+    kind = ("shared" if model.n_tables == 1 else "per_stream", model.n_symbols)
+    key = (symbols.device.index, n_streams, n_per, tuple(config), layout, coder, *kind)
     if key in _TUNED_STRIDES and report is None:
         return _TUNED_STRIDES[key]
+    # CST_STRIDE_CACHE=<file.json>: strides measured by earlier processes on this kind of device (a service does not measure at
+    # every start; a profiler run of a command that has run before sees the command's own launches only)
+    cache_path = os.environ.get("CST_STRIDE_CACHE")
+    cache_key = "|".join(map(str, (n_streams, n_per, *config, layout, coder, *kind)))      # (one file per kind of device)
+    if cache_path and report is None and os.path.exists(cache_path):
+        try:
+            with open(cache_path) as f:
+                cached = int(json.load(f).get(cache_key, 0))
+        except (OSError, ValueError, TypeError, AttributeError):
+            cached = 0
+        if cached >= base:
+            _TUNED_STRIDES[key] = cached
+            return cached
     best = base
     if n_streams * n_per >= (1 << 26):
         first = (base + step - 1) // step * step
@@ -264,6 +282,17 @@ def tuned_stride(symbols: torch.Tensor, model: "Model", config=(32, 64, 12), lay
                 best, best_ms = c, te + td
         del flat, decoded
     _TUNED_STRIDES[key] = best
+    if cache_path and report is None:
+        try:
+            known = {}
+            if os.path.exists(cache_path):
+                with open(cache_path) as f:
+                    known = json.load(f)
+            known[cache_key] = best
+            with open(cache_path, "w") as f:
+                json.dump(known, f, indent=1, sort_keys=True)
+        except (OSError, ValueError, TypeError):
+            pass                                    # (a cache that cannot be written is only a cache)
     return best
 
 

@@ -8,6 +8,12 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 R=$PWD
 B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+# the slab strides bench.py measures at first use (batched.tuned_stride) are measured HERE, by an unprofiled run of the same
+# command, and remembered: the profiled runs below then hold the command's own launches only, not 63 measuring launches per
+# kernel at 21 other strides
+export CST_STRIDE_CACHE=$R/gpurun_out/${tag}_strides.json
+rm -f $CST_STRIDE_CACHE
+$B > gpurun_out/${tag}_unprofiled_bench.json 2>/dev/null
 mkdir -p gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_l2
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o bench -- $B > gpurun_out/${tag}_stats/bench.json 2> gpurun_out/${tag}_stats/err.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_fetch -o pmc -- $B > /dev/null 2> gpurun_out/${tag}_fetch/err.log

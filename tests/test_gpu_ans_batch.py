@@ -1065,7 +1065,7 @@ def test_second_level_tables(B, O, coder, P, n_sym, period):
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
 
 
-def test_tuned_stride(B, O):
+def test_tuned_stride(B, O, tmp_path, monkeypatch):
     """batched.tuned_stride: max_words for small batches without measuring; for a batch of 2^26 symbols a stride from the
     candidate list, remembered per shape; and stride="tuned" changes where the slabs lie, never what is in them."""
     P = 12
@@ -1081,6 +1081,20 @@ def test_tuned_stride(B, O):
     stride = B.tuned_stride(sym, model, (32, 64, P))
     assert base <= stride <= base + 640 and (stride == base or stride % 32 == 0)
     assert B.tuned_stride(sym, model, (32, 64, P)) == stride
+    # CST_STRIDE_CACHE: a later process (here: this one with its memory wiped) takes the file's word for it
+    cache = tmp_path / "strides.json"
+    monkeypatch.setenv("CST_STRIDE_CACHE", str(cache))
+    B._TUNED_STRIDES.clear()
+    measured = B.tuned_stride(sym, model, (32, 64, P))
+    import json
+    (key, value), = json.loads(cache.read_text()).items()
+    assert value == measured and key == "16384|4096|32|64|12|stream_major|ans|shared|101"
+    cache.write_text(json.dumps({key: base + 96}))
+    B._TUNED_STRIDES.clear()
+    assert B.tuned_stride(sym, model, (32, 64, P)) == base + 96
+    monkeypatch.delenv("CST_STRIDE_CACHE")
+    B._TUNED_STRIDES.clear()
+    stride = B.tuned_stride(sym, model, (32, 64, P))
     enc = B.ans_encode(sym, model, (32, 64, P), stride="tuned")
     assert enc.words.shape == (n_streams, stride)
     want_words, want_n, _ = O.ans_encode_batch(head, -50, cdf, P)
