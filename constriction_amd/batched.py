@@ -385,6 +385,76 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
 _scratch = {}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# streams of different lengths: thousands of small coders with one model in one launch (the reference's "compressed index"
+# pattern, tests/issue52.rs: one AnsCoder per document)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class RaggedBatch:
+    """Compressed words of streams of different lengths: stream s owns words[word_offsets[s] : word_offsets[s] + n_words[s]]."""
+    words: torch.Tensor          # int32, flat
+    word_offsets: torch.Tensor   # int64 [n_streams + 1]: the slabs (a slab is at least as long as its stream can get)
+    n_words: torch.Tensor        # int32 [n_streams]
+    status: torch.Tensor         # int32 [n_streams]
+    config: tuple
+
+    def stream(self, s: int) -> np.ndarray:
+        """get_compressed() of stream s (uint32, host)."""
+        lo, n = int(self.word_offsets[s].item()), int(self.n_words[s].item())
+        return self.words[lo: lo + n].cpu().numpy().view(np.uint32)
+
+
+def ragged(sequences, device="cuda"):
+    """list of 1-d integer arrays -> (flat int32 device tensor, int64 offsets [n + 1]) as the ragged entry points take them."""
+    lengths = np.fromiter((len(x) for x in sequences), dtype=np.int64, count=len(sequences))
+    offsets = np.zeros(len(sequences) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    flat = np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1) for x in sequences]) if len(sequences) else np.zeros(0, np.int32)
+    return torch.from_numpy(flat).to(device), torch.from_numpy(offsets).to(device)
+
+
+def ans_encode_ragged(symbols: torch.Tensor, sym_offsets: torch.Tensor, model: Model, config=(32, 64, 24)) -> RaggedBatch:
+    """One AnsCoder per stream, streams of different lengths (`symbols` flat, stream s = symbols[sym_offsets[s]:sym_offsets[s+1]]):
+    encode_iid_symbols_reverse + into_compressed per stream (stack.rs:835-849, 891-895) in ONE launch."""
+    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    sym_offsets = _require_cuda(sym_offsets, torch.int64, "sym_offsets")
+    n_streams = sym_offsets.numel() - 1
+    if symbols.dim() != 1 or n_streams < 0:
+        raise ValueError("symbols must be flat and sym_offsets hold n_streams + 1 entries")
+    W, S, P = config
+    lengths = sym_offsets[1:] - sym_offsets[:-1]
+    # a stream of n symbols fills at most min(n, ceil(n P / W)) + S / W words (cst_ans_max_words without its rounding to 64 bytes:
+    # thousands of short streams; 16-byte slabs keep the chunk stores aligned)
+    bound = torch.minimum(lengths, (lengths * P + (W - 1)) // W) + S // W
+    slabs = (bound + 3) // 4 * 4
+    word_offsets = torch.zeros(n_streams + 1, dtype=torch.int64, device=symbols.device)
+    torch.cumsum(slabs, 0, out=word_offsets[1:])
+    total = int(word_offsets[-1].item()) if n_streams else 0
+    dev = symbols.device
+    out = RaggedBatch(torch.empty(max(total, 4), dtype=torch.int32, device=dev), word_offsets,
+                      torch.empty(n_streams, dtype=torch.int32, device=dev), torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    N.check(N.lib().cst_ans_encode_ragged(model._h, _cfg(*config), _ptr(symbols), _ptr(sym_offsets), n_streams, _ptr(out.words),
+                                          _ptr(word_offsets), 0, _ptr(out.n_words), _ptr(out.status), _stream_ptr()), "cst_ans_encode_ragged")
+    return out
+
+
+def ans_decode_ragged(encoded: RaggedBatch, model: Model, sym_offsets: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """from_compressed + decode_iid_symbols per stream (stack.rs:299-318, 1070-1100): stream s yields
+    sym_offsets[s + 1] - sym_offsets[s] symbols at out[sym_offsets[s]:].  Returns (symbols flat, status per stream)."""
+    sym_offsets = _require_cuda(sym_offsets, torch.int64, "sym_offsets")
+    n_streams = sym_offsets.numel() - 1
+    dev = encoded.words.device
+    total = int(sym_offsets[-1].item()) if n_streams > 0 else 0
+    if out is None:
+        out = torch.empty(total, dtype=torch.int32, device=dev)
+    status = torch.empty(max(n_streams, 0), dtype=torch.int32, device=dev)
+    N.check(N.lib().cst_ans_decode_ragged(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(encoded.word_offsets), 0,
+                                          encoded.words.numel(), _ptr(encoded.n_words), _ptr(out), _ptr(sym_offsets), n_streams,
+                                          _ptr(status), _stream_ptr()), "cst_ans_decode_ragged")
+    return _to_symbols(model, out), status
+
+
 def _compact_scratch(device, n_streams):
     # (one scratch per device AND stream: two compactions on different streams must not share ticket / status words)
     need = N.load_library().cst_compact_scratch_bytes(n_streams)

@@ -151,6 +151,14 @@ cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, c
                                  size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out,
                                  int32_t* d_status, uint32_t flags, hipStream_t hs);
 
+// cst_ans_ragged.hip: streams of different lengths (arguments checked by the C entry points in cst_api.hip)
+cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                             size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
+                             uint32_t* d_n_words, int32_t* d_status, hipStream_t hs);
+cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                             size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, hipStream_t hs);
+
 // trimmed-packed-row coder launches (cst_ans_pt.hip); return CST_ERR_INVALID_ARGUMENT if the shape is not theirs
 bool pt_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, size_t n_per_stream);
 cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,

@@ -241,6 +241,27 @@ cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, co
                                 uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
                                 uint32_t flags, void *stream);
 
+/* Streams of DIFFERENT lengths -- thousands of small coders with a shared model in one launch: the reference's "compressed
+ * index" pattern (tests/issue52.rs:27-60, 63-80: one DefaultAnsCoder per document, `encode_symbol` per character last to
+ * first, `into_compressed`; `from_compressed` + `decode_symbol` per document), which costs one device round trip per document
+ * through the single-coder binding.
+ *     symbols of stream s = d_symbols[d_sym_offsets[s] .. d_sym_offsets[s + 1])      (d_sym_offsets: uint64 [n_streams + 1])
+ *     slab of stream s    = d_words[d_word_offsets[s] .. d_word_offsets[s + 1])      (uint64 [n_streams + 1]; a slab of
+ *                           cst_ans_max_words(length of s, cfg) words always suffices), or, with d_word_offsets = NULL,
+ *                           d_words[s * stride_words .. + stride_words)
+ * Every stream's words, count and status are those of cst_ans_encode_batch / the reference coder for that stream alone; the
+ * decoder takes the same offsets (only d_word_offsets[s] and d_n_words[s] are read) or a packed layout, with the bounds
+ * check of cst_ans_decode_batch.  Shared-table models, stream-major symbols, any preset.  A wave of 64 consecutive streams
+ * runs as long as its longest one. */
+cst_status cst_ans_encode_ragged(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                 const uint64_t *d_sym_offsets, size_t n_streams, uint32_t *d_words,
+                                 const uint64_t *d_word_offsets, size_t stride_words, uint32_t *d_n_words,
+                                 int32_t *d_status, void *stream);
+cst_status cst_ans_decode_ragged(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                 const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
+                                 const uint32_t *d_n_words, int32_t *d_symbols, const uint64_t *d_sym_offsets,
+                                 size_t n_streams, int32_t *d_status, void *stream);
+
 /* Checkpointed streams -- the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139; test :1456-1548) for the
  * batched coder.  The encoder notes, in front of every chunk of `ckpt_interval` symbols, what `AnsCoder::pos()` returns
  * there: d_ckpt_pos[s][j] = words in the bulk, d_ckpt_state[s][j] = coder state once symbols [j * interval, n) are

@@ -1,0 +1,104 @@
+"""GPU parity tests of the ragged entry points (streams of different lengths, one launch): every stream's words against the
+CPU oracle coding that stream alone, through the C ABI (`cst_ans_{encode,decode}_ragged`)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def oracle_words(O, doc, lo, cdf, cfg):
+    W, S, P = cfg
+    words, n, st = O.ans_encode_batch(np.asarray(doc, dtype=np.int32)[None, :], lo, cdf, P, W, S)
+    return words[0, : n[0]], int(st[0])
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12), (32, 64, 16)], ids=lambda c: "W%dS%dP%d" % c)
+def test_ragged_streams_vs_oracle(B, O, cfg):
+    """Documents of 0 .. 3000 symbols, 1000 of them (partial last wave): words, counts, status of every stream equal the
+    oracle's for that stream alone; decoding returns the documents."""
+    W, S, P = cfg
+    rng = np.random.default_rng(P * 7 + W)
+    n_sym, lo = 90, -17
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(n_sym) * 0.4), P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    lengths = np.concatenate([rng.integers(0, 200, 900), rng.integers(200, 3000, 95), [0, 1, 2, 3, 4]])
+    rng.shuffle(lengths)
+    docs = [O.synth_symbols(int(k), 0, 1, int(n), lo, cdf, P)[0] if n else np.zeros(0, np.int32) for k, n in enumerate(lengths)]
+    flat, offsets = B.ragged(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model, cfg)
+    torch.cuda.synchronize()
+    assert (enc.status.cpu().numpy() == 0).all()
+    n_words = enc.n_words.cpu().numpy()
+    for s in list(range(0, len(docs), 7)) + [len(docs) - 1]:
+        want, st = oracle_words(O, docs[s], lo, cdf, cfg)
+        assert st == 0 and n_words[s] == len(want) and enc.stream(s).tolist() == want.tolist(), f"stream {s} of {len(docs[s])} symbols"
+    dec, status = B.ans_decode_ragged(enc, model, offsets)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all() and torch.equal(dec, flat)
+
+
+def test_ragged_like_the_reference_index(B, O):
+    """tests/issue52.rs: documents over a small alphabet, one coder each, an EOF symbol first (decoded last); the words of
+    a document are those of the drop-in AnsCoder for it (constriction_amd.stream.stack), i.e. the reference's."""
+    from constriction_amd.stream import model as M, stack
+    text = ["the quick brown fox", "", "jumps", "over the lazy dog " * 40, "a"] * 30
+    alphabet = sorted(set("".join(text)))
+    eof = len(alphabet)
+    probs = np.ones(eof + 1) / (eof + 1)
+    docs = [np.array([alphabet.index(c) for c in doc] + [eof], dtype=np.int32) for doc in text]     # reversed coding: EOF is encoded first
+    cdf = O.categorical_fast_cdf(probs, 24)
+    model = B.Model.from_cdf(cdf, 0, 24)
+    flat, offsets = B.ragged(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model)
+    torch.cuda.synchronize()
+    single = M.Categorical(probs, perfect=False)
+    for s in (0, 1, 2, 3, 4, len(docs) - 1):
+        coder = stack.AnsCoder()
+        coder.encode_reverse(docs[s], single)
+        assert enc.stream(s).tolist() == coder.get_compressed().tolist()
+    dec, status = B.ans_decode_ragged(enc, model, offsets)
+    out, off = dec.cpu().numpy(), offsets.cpu().numpy()
+    assert ["".join(alphabet[i] for i in out[off[s]: off[s + 1] - 1]) for s in range(len(docs))] == text
+    assert all(out[off[s + 1] - 1] == eof for s in range(len(docs)))
+
+
+def test_ragged_status_and_bounds(B, O):
+    """an impossible symbol flags its stream only; corrupt counts / offsets are decoded as empty streams (INVALID_DATA) and
+    nothing outside the buffer is read; no streams at all is a no-op"""
+    P, lo = 12, 0
+    cdf = O.categorical_fast_cdf(np.ones(20) / 20, P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    docs = [np.arange(n) % 20 for n in (5, 64, 0, 300, 17)]
+    docs[3] = docs[3].copy(); docs[3][100] = 20
+    flat, offsets = B.ragged(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model, (32, 64, P))
+    torch.cuda.synchronize()
+    assert enc.status.cpu().tolist() == [0, 0, 0, 1, 0] and enc.n_words.cpu().tolist()[3] == 0
+    good = B.ragged([d for k, d in enumerate(docs) if k != 3])
+    enc = B.ans_encode_ragged(*good, model, (32, 64, P))
+    ref, _ = B.ans_decode_ragged(enc, model, good[1])
+    enc.n_words[1] = 1 << 30                      # leaves the buffer
+    enc.word_offsets[2] = 1 << 40
+    dec, status = B.ans_decode_ragged(enc, model, good[1])
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0, 3, 3, 0]
+    off = good[1].cpu().numpy()
+    assert torch.equal(dec[off[3]: off[4]], ref[off[3]: off[4]]) and torch.equal(dec[: off[1]], ref[: off[1]])
+    empty = B.ans_encode_ragged(torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), model, (32, 64, P))
+    assert empty.n_words.numel() == 0
