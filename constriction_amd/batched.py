@@ -455,6 +455,25 @@ def ans_decode_ragged(encoded: RaggedBatch, model: Model, sym_offsets: torch.Ten
     return _to_symbols(model, out), status
 
 
+def ans_decode_until(encoded: RaggedBatch, model: Model, eof_symbol: int, max_symbols: int = 1 << 20):
+    """Streams whose length is not stored: every stream is decoded until `eof_symbol` (tests/issue52.rs:63-80).  Two launches
+    -- count, prefix sum, decode.  Returns (symbols flat, sym_offsets [n + 1], status); the terminator is the last symbol of
+    every stream; status CAPACITY (2): no terminator among the first max_symbols symbols."""
+    if model.noncontiguous:
+        raise ValueError("ans_decode_until: contiguous alphabets only")
+    n_streams = encoded.n_words.numel()
+    dev = encoded.words.device
+    lengths = torch.zeros(n_streams, dtype=torch.int64, device=dev)
+    status = torch.zeros(n_streams, dtype=torch.int32, device=dev)
+    N.check(N.lib().cst_ans_count_until(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(encoded.word_offsets), 0,
+                                        encoded.words.numel(), _ptr(encoded.n_words), n_streams, int(eof_symbol), int(max_symbols),
+                                        _ptr(lengths), _ptr(status), _stream_ptr()), "cst_ans_count_until")
+    sym_offsets = torch.zeros(n_streams + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lengths, 0, out=sym_offsets[1:])
+    symbols, status2 = ans_decode_ragged(encoded, model, sym_offsets)
+    return symbols, sym_offsets, torch.where(status != 0, status, status2)
+
+
 def _compact_scratch(device, n_streams):
     # (one scratch per device AND stream: two compactions on different streams must not share ticket / status words)
     need = N.load_library().cst_compact_scratch_bytes(n_streams)

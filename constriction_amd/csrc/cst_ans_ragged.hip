@@ -102,6 +102,44 @@ __global__ __launch_bounds__(kBlock) void ans_decode_ragged_kernel(const RaggedA
     a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (too_long ? (int32_t)CST_STREAM_CAPACITY : L.status);
 }
 
+// The reference's index stores no lengths: a document ends where its terminator symbol is decoded (tests/issue52.rs:63-80).
+// First pass of that: every stream is decoded until `eof_index` appears (or `max_symbols` were decoded: CST_STREAM_CAPACITY,
+// the output a caller would size from it could not hold more), nothing is stored but the count -- terminator included.  A
+// prefix sum of the counts is the d_sym_offsets of cst_ans_decode_ragged.
+template <int W, int S>
+__global__ __launch_bounds__(kBlock) void ans_count_until_kernel(const RaggedArgs a, uint32_t eof_index, uint64_t max_symbols, uint64_t* lengths) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s - lane >= a.n_streams) return;
+    const bool active = s < a.n_streams;
+    const int P = a.precision;
+    const int bucket_shift = P - a.bucket_bits;
+    DecLane<W, S> L;
+    const WordSlice ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words_in + ws.off, ws.n, ring, lane);
+    L.read_initial_state();
+    L.in.prime();
+    wave_lds_fence();
+    const DecLut lut{};
+    uint64_t n = 0;
+    bool done = !active || ws.bad || L.status != CST_STREAM_OK || max_symbols == 0;
+    bool found = false;
+    while (__any(!done)) {
+        if (!done) {
+            const uint32_t idx = ans_decode_step<W, S, kDecBucket, false>(L, lut, a.cdf, a.bucket, bucket_shift, a.n_symbols, P);
+            ++n;
+            found = idx == eof_index;
+            done = found || n >= max_symbols;
+        }
+        L.in.advance_window();
+    }
+    if (!active) return;
+    lengths[s] = n;
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (L.status != CST_STREAM_OK ? L.status : (found ? (int32_t)CST_STREAM_OK : (int32_t)CST_STREAM_CAPACITY));
+}
+
 template <typename K>
 static cst_status ragged_launch(K kernel, const RaggedArgs& a, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
@@ -133,6 +171,26 @@ cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const
     a.words_capacity = words_capacity;
     if (cfg.word_bits == 32) return ragged_launch(ans_decode_ragged_kernel<32, 64>, a, hs);
     return ragged_launch(ans_decode_ragged_kernel<16, 32>, a, hs);
+}
+
+cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                           size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
+                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, hipStream_t hs) {
+    RaggedArgs a{};
+    a.n_streams = n_streams; a.cdf = model->d_cdf; a.bucket = model->d_bucket;
+    a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words_in = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_in = d_n_words; a.status = d_status;
+    a.words_capacity = words_capacity;
+    const size_t blocks = (n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    const size_t lds = (size_t)(kBlock / kWave) * kRingWords * 4;
+    const uint32_t eof_index = (uint32_t)eof_symbol - (uint32_t)model->min_symbol;
+    if (cfg.word_bits == 32)
+        hipLaunchKernelGGL((ans_count_until_kernel<32, 64>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, eof_index, (uint64_t)max_symbols, d_lengths);
+    else
+        hipLaunchKernelGGL((ans_count_until_kernel<16, 32>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, eof_index, (uint64_t)max_symbols, d_lengths);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 } // namespace cst

@@ -334,6 +334,18 @@ cst_status cst_ans_decode_ragged(const cst_model* model, cst_coder_config cfg, c
                              n_streams, d_status, (hipStream_t)stream);
 }
 
+cst_status cst_ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                               size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams,
+                               int32_t eof_symbol, size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, void* stream) {
+    if (!model || !config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (!d_n_words || !d_lengths || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    return ans_count_until(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, eof_symbol, max_symbols,
+                           d_lengths, d_status, (hipStream_t)stream);
+}
+
 size_t cst_compact_scratch_bytes(size_t n_streams) {
     const size_t n_blocks = (n_streams + kCompactStreams - 1) / kCompactStreams;
     return 16 + 8 * (n_blocks > 0 ? n_blocks : 1);

@@ -261,6 +261,16 @@ cst_status cst_ans_decode_ragged(const cst_model *model, cst_coder_config cfg, c
                                  const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
                                  const uint32_t *d_n_words, int32_t *d_symbols, const uint64_t *d_sym_offsets,
                                  size_t n_streams, int32_t *d_status, void *stream);
+/* The reference's index stores no lengths: a document ends where its terminator symbol is decoded
+ * (tests/issue52.rs:63-80, `core::iter::from_fn(|| { let id = coder.decode_symbol(..); alphabet.get(id) })`).  This is
+ * the first pass of that: every stream is decoded until `eof_symbol` appears, nothing is stored but the number of
+ * symbols decoded, terminator included (d_lengths, uint64 [n_streams]); a stream without a terminator among its first
+ * `max_symbols` symbols reports CST_STREAM_CAPACITY and max_symbols.  An exclusive prefix sum of d_lengths is the
+ * d_sym_offsets of cst_ans_decode_ragged. */
+cst_status cst_ans_count_until(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                               const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
+                               const uint32_t *d_n_words, size_t n_streams, int32_t eof_symbol, size_t max_symbols,
+                               uint64_t *d_lengths, int32_t *d_status, void *stream);
 
 /* Checkpointed streams -- the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139; test :1456-1548) for the
  * batched coder.  The encoder notes, in front of every chunk of `ckpt_interval` symbols, what `AnsCoder::pos()` returns

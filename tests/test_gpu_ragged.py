@@ -76,6 +76,17 @@ def test_ragged_like_the_reference_index(B, O):
     out, off = dec.cpu().numpy(), offsets.cpu().numpy()
     assert ["".join(alphabet[i] for i in out[off[s]: off[s + 1] - 1]) for s in range(len(docs))] == text
     assert all(out[off[s + 1] - 1] == eof for s in range(len(docs)))
+    # ... and as the reference's decompress does it: no lengths stored, every document ends at its EOF symbol
+    dec2, off2, status2 = B.ans_decode_until(enc, model, eof)
+    torch.cuda.synchronize()
+    assert (status2.cpu().numpy() == 0).all() and torch.equal(off2, offsets) and torch.equal(dec2, dec)
+    # a limit below the longest document: those streams report CAPACITY and the limit, the others are unaffected
+    dec3, off3, status3 = B.ans_decode_until(enc, model, eof, max_symbols=100)
+    lens, lens3 = np.diff(off), np.diff(off3.cpu().numpy())
+    assert lens3.tolist() == np.minimum(lens, 100).tolist()
+    assert status3.cpu().tolist() == [2 if n > 100 else 0 for n in lens]
+    o3 = dec3.cpu().numpy()
+    assert all(o3[off3[s]: off3[s + 1]].tolist() == out[off[s]: off[s] + lens3[s]].tolist() for s in range(len(docs)))
 
 
 def test_ragged_status_and_bounds(B, O):
