@@ -903,9 +903,16 @@ __device__ __forceinline__ void lookup_quantile(uint32_t q, const DecLut lut, co
         if (lut.b16) {
             uint4 e = lut.b16[q >> bucket_shift];
             if (lut.sub_bits) {             // (uniform) this image has second-level tables: DecLut, cst_common.hpp
-                if (__any(e.y == 0u)) {
-                    const uint32_t part = (q >> (bucket_shift - lut.sub_bits)) & ((1u << lut.sub_bits) - 1u);
-                    if (e.y == 0u) e = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(lut.b16) + e.x + 16u * part);
+                if (__any(q >= e.w)) {
+                    // slot (bucket mod kSubTables), part = the next sub_bits bits of the quantile; the entry there is this lane's if
+                    // it is a real entry whose first cumulative does not lie above q (one of a lower bucket passes, too, and
+                    // leads to a longer walk below)
+                    const uint32_t at = (q >> (bucket_shift - lut.sub_bits)) & (((uint32_t)kSubTables << lut.sub_bits) - 1u);
+                    if (q >= e.w) {
+                        const uint4 e2 = lut.sub[at];
+                        const uint32_t c2 = e2.x & ((1u << lut.idx_shift) - 1u);
+                        if (c2 <= q && e2.y > c2) e = e2;
+                    }
                 }
             }
             const uint32_t c0 = e.x & ((1u << lut.idx_shift) - 1u), i0 = e.x >> lut.idx_shift;
@@ -1025,38 +1032,37 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
                 const int sb = SUB ? min(kSubBitsMax, shift) : 0;
                 uint32_t* ctl = reinterpret_cast<uint32_t*>(smem + lds_off + (size_t)nb * 16 + (size_t)kSubTables * kSubTableBytes);
                 if constexpr (SUB) {
-                    if (threadIdx.x == 0) ctl[0] = 0;
+                    if (threadIdx.x < kSubTables) ctl[4 + threadIdx.x] = 0xffffffffu;       // slot owners: none yet
                     __syncthreads();
                 }
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-                    uint4 e = entry_at(g_bucket[i]);
+                    const uint4 e = entry_at(g_bucket[i]);
                     if constexpr (SUB) {
-                        // more than three symbols begin in this bucket <=> a quantile of it lies at or above the fourth cumulative
-                        if (sb > 0 && e.w < ((uint32_t)(i + 1) << shift)) {
-                            const uint32_t slot = atomicAdd(&ctl[0], 1u);
-                            if (slot < (uint32_t)kSubTables) {
-                                ctl[4 + slot] = (uint32_t)i;
-                                e = make_uint4((uint32_t)nb * 16u + slot * (uint32_t)kSubTableBytes, 0u, 0u, 0u);
-                            }
-                        }
+                        // more than three symbols begin in this bucket <=> a quantile of it lies at or above the fourth cumulative:
+                        // the bucket claims slot (i mod kSubTables) for a second-level table (the lowest claimant keeps it; the
+                        // others walk: DecLut, cst_common.hpp)
+                        if (sb > 0 && e.w < ((uint32_t)(i + 1) << shift)) atomicMin(&ctl[4 + (i & (kSubTables - 1))], (uint32_t)i);
                     }
                     b[i] = e;
                 }
                 lds_off += (size_t)nb * 16;
                 if constexpr (SUB) {
                     __syncthreads();            // (the cdf copy `c` is complete, too)
-                    const uint32_t count = min(ctl[0], (uint32_t)kSubTables);
                     uint4* sub = b + nb;
-                    for (uint32_t t = threadIdx.x; t < (count << sb); t += blockDim.x) {
-                        const uint32_t slot = t >> sb, part = t & ((1u << sb) - 1u);
-                        const uint32_t q0 = (ctl[4 + slot] << shift) + (part << (shift - sb));
-                        uint32_t lo = 0, hi = n;                                   // c[0] = 0 <= q0 < 2^P = c[n]
-                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (c[mid] <= q0) lo = mid; else hi = mid; }
-                        sub[slot * (kSubTableBytes / 16) + part] = entry_at(lo);
+                    for (uint32_t t = threadIdx.x; t < ((uint32_t)kSubTables << sb); t += blockDim.x) {
+                        const uint32_t slot = t >> sb, part = t & ((1u << sb) - 1u), owner = ctl[4 + slot];
+                        uint4 e = make_uint4(0u, 0u, 0u, 0u);                      // free slot: not an entry (e.y > c fails)
+                        if (owner != 0xffffffffu) {
+                            const uint32_t q0 = (owner << shift) + (part << (shift - sb));
+                            uint32_t lo = 0, hi = n;                               // c[0] = 0 <= q0 < 2^P = c[n]
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (c[mid] <= q0) lo = mid; else hi = mid; }
+                            e = entry_at(lo);
+                        }
+                        sub[t] = e;                                                // entry (slot << sb | part)
                     }
                     lds_off += kSubAreaBytes;
                 }
-                lut.b16 = b; lut.idx_shift = ishift; lut.sub_bits = sb; cdf = c;
+                lut.b16 = b; lut.idx_shift = ishift; lut.sub_bits = sb; lut.sub = SUB ? b + nb : nullptr; cdf = c;
             } else {
                 uint16_t* b = reinterpret_cast<uint16_t*>(smem + lds_off);
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = g_bucket[i];

@@ -52,10 +52,16 @@ struct DecLut {      // pointers into LDS or global memory
     int32_t idx_shift;
     // Second-level tables (0 = none): a bucket in which MORE than three symbols begin -- the far tails of a distribution: for
     // the BASELINE Gaussian at P = 24, 22 symbols share bucket 0 -- would send its lanes on a walk over the cdf table, one LDS
-    // round trip per symbol (28 % of the P = 24 decoder's time, all of it in two buckets).  Up to kSubTables such buckets hold
-    //   { byte offset of their table from b16[0], 0, 0, 0 }      (a real entry's second word, cdf[i0 + 1], is never 0)
-    // instead, and the table, 2^sub_bits entries of the same form for the bucket's 2^sub_bits equal parts, is read with the
-    // next sub_bits bits of the quantile: one more round trip, then the selects again.  What still overflows there walks.
+    // round trip per symbol (28 % of the P = 24 decoder's time, all of it in two buckets).  Such a bucket owns SLOT
+    // (bucket mod kSubTables) of the area behind the bucket entries (`sub`): 2^sub_bits entries of the same form for the
+    // bucket's 2^sub_bits equal parts, read with the low five bits of the bucket number and the next sub_bits bits of the
+    // quantile by the lanes whose quantile lies at or above their entry's fourth cumulative -- one more round trip, then the
+    // selects again; what still overflows there walks.  The bucket's own entry stays a real one (lanes below its fourth
+    // cumulative never leave the main path).  Two crowded buckets with the same slot: the lower one has it.  An entry read from
+    // a slot is taken if it is a real entry (second word above the first cumulative; free slots hold zeros) whose first
+    // cumulative does not lie above the quantile: the slot's owner passes, a LOWER owner passes too (its symbols lie below q,
+    // the walk from there is longer but ends at the same symbol), a higher owner does not (the lane walks from its own entry).
+    const uint4* sub;
     int32_t sub_bits;
 };
 constexpr int kSubTables = 32;                  // second-level tables per workgroup image

@@ -55,7 +55,9 @@ def gen():
     LAND = [f"v{172 + k}" for k in range(K_CHUNKS)]
     WANT, TMP, TADDR, TOFF = "v175", "v176", "v177", "v178"
     GOFF = [f"v{180 + k}" for k in range(8)]
-    clobbers = [f"v{r}" for r in range(120, 192)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
+    NEW = [f"v{192 + k}" for k in range(4)]                                            # a second-level entry on its way in
+    NEW_T = tup(192)
+    clobbers = [f"v{r}" for r in range(120, 196)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
     SD, SAVE, V1, V2 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]"
     RET, XSAVE, FLAGGED = "s[70:71]", "s[72:73]", "s[74:75]"
     SBITS, SSH = "s76", "s77"
@@ -95,9 +97,10 @@ def gen():
         a.ds(f"ds_read_b32 {WD}, {RA}", "w")
 
     a.i("v_mov_b32 v123, 0")
-    a.i(f"s_min_u32 {SBITS}, %[bsh], 4", "second-level tables: 2^min(4, P - 11) parts per bucket (kSubBitsMax)")
+    a.i(f"s_min_u32 {SBITS}, %[bsh], 4", "second-level tables: 2^min(4, P - 11) parts per bucket (kSubBitsMax) ...")
     a.i(f"s_sub_u32 {SSH}, %[bsh], {SBITS}")
-    a.i(f"s_bfm_b32 {SBITS}, {SBITS}, 0", "(as a mask)")
+    a.i(f"s_add_u32 {SBITS}, {SBITS}, 5", "... in the slot (bucket mod 32: kSubTables) the bucket may own")
+    a.i(f"s_bfm_b32 {SBITS}, {SBITS}, 0", "(slot | part as a mask)")
     # the eight store offsets of a tile's pieces wait in the lane's row of the CURRENT tile buffer (written by the kernel, read
     # here before the first step writes symbols over them): rows of any length take per-row offsets (row_skew,
     # cst_ans_kernels.hpp), partial waves repeat their last row, symbol-major batches have their own mapping -- all the
@@ -179,35 +182,52 @@ def gen():
     a.i("s_cbranch_scc1 1b")
     a.i("s_branch 3f")
 
-    # ---- out of line: the walk (entered with the lanes to walk in vcc; Q and the entry as in the step), one copy per
-    # ---- entry register set
+    # ---- out of line, per step: second-level entry for the lanes beyond their bucket's third symbol (vcc), the selects again,
+    # ---- and the walk over the cdf table for whoever is still beyond (one copy of the two routines per entry register set)
     for j in range(32):
+        E0, E1, E2, E3 = ESET[j % 2]
         a.i(f"1{j:02d}:", None)
-        a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
-        a.i(f"s_cbranch_scc1 3{j:02d}b", "second-level entries have landed: the selects again")
+        a.i(f"s_call_b64 {RET}, {4 + j % 2}f", "second-level entries (DecLut, cst_common.hpp) for the lanes in vcc")
+        a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
+        a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
+        a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}")
+        a.i(f"v_and_b32 {C}, %[cfield], {E0}")
+        a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
+        a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
+        a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
+        a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
+        a.i(f"s_cbranch_vccz 2{j:02d}b")
+        a.i(f"s_call_b64 {RET}, {8 + j % 2}f", "still beyond the third symbol: walk")
         a.i(f"s_branch 2{j:02d}b")
     for st in range(2):
-        E0, E1 = ESET[st][0], ESET[st][1]
+        E0, E1, E2, E3 = ESET[st]
+        # the bucket's slot is (bucket mod 32); the entry found there is the lane's if its first cumulative does not lie
+        # above the quantile and it is a real entry (a free slot holds zeros; a slot owned by a LOWER bucket passes and leads to a
+        # longer walk, which is correct; one owned by a higher bucket does not pass)
         a.i(f"{4 + st}:", None)
+        a.i(f"s_mov_b64 {XSAVE}, exec")
+        a.i("s_mov_b64 exec, vcc")
+        a.i(f"v_lshrrev_b32 {TMPA}, {SSH}, {Q}", "slot | part of the bucket")
+        a.i(f"v_and_b32 {TMPA}, {SBITS}, {TMPA}")
+        a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, %[lut]")
+        a.i(f"ds_read_b128 {NEW_T}, {TMPA} offset:32768", "(behind the 2048 bucket entries)")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_and_b32 {TMPA}, %[cfield], {NEW[0]}")
+        a.i(f"v_cmp_le_u32 vcc, {TMPA}, {Q}")
+        a.i(f"v_cmp_gt_u32 {FLAGGED}, {NEW[1]}, {TMPA}")
+        a.i(f"s_and_b64 vcc, vcc, {FLAGGED}")
+        a.i("s_and_b64 exec, exec, vcc")
+        for k in range(4):
+            a.i(f"v_mov_b32 {ESET[st][k]}, {NEW[k]}")
+        a.i(f"s_mov_b64 exec, {XSAVE}")
+        a.i(f"s_setpc_b64 {RET}")
+        # the walk: lanes in vcc; Q and the entry as in the step; leaves (C, NXT) and index - 2 in the entry
+        a.i(f"{8 + st}:", None)
         a.i(f"s_mov_b64 {XSAVE}, exec")
         a.i(f"s_mov_b64 {FLAGGED}, vcc")
         a.i("s_mov_b64 exec, vcc")
-        # lanes whose bucket has a second-level table (DecLut, cst_common.hpp: { table offset, 0, 0, 0 }): fetch its entry
-        a.i(f"v_cmp_eq_u32 vcc, 0, {E1}", "(a real entry's cdf[i0 + 1] is never 0)")
-        a.i(f"s_cbranch_vccz {8 + st}f")
-        a.i("s_mov_b64 exec, vcc")
-        a.i(f"v_lshrrev_b32 {TMPA}, {SSH}, {Q}", "which part of the bucket")
-        a.i(f"v_and_b32 {TMPA}, {SBITS}, {TMPA}")
-        a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, {E0}")
-        a.i(f"v_add_u32 {TMPA}, %[lut], {TMPA}")
-        a.i(f"ds_read_b128 {ESET_T[st]}, {TMPA}")
-        a.i("s_waitcnt lgkmcnt(0)")
-        a.i(f"s_mov_b64 exec, {XSAVE}")
-        a.i("s_cmp_eq_u32 s82, s82", "scc = 1: run the selects again")
-        a.i(f"s_setpc_b64 {RET}")
-        a.i(f"{8 + st}:", None)
         a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
-        a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+        a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the entry's first three symbols lie below q")
         a.i(f"{6 + st}:", None)
         a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
         a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
@@ -227,7 +247,6 @@ def gen():
         a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
         a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
         a.i(f"s_mov_b64 exec, {XSAVE}")
-        a.i("s_cmp_lg_u32 s82, s82", "scc = 0")
         a.i(f"s_setpc_b64 {RET}")
     a.i("3:", None)
     a.wait_vm_all("nothing may land in the scratch registers after the statement")

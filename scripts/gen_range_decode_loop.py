@@ -62,7 +62,8 @@ NXT, IDX, TMPA = "v208", "v209", "v210"                                         
 ESET = [[f"v{204 + k}" for k in range(4)], [f"v{216 + k}" for k in range(4)]]           # entry registers of even / odd steps
 ESET_T = [tup(204, 4), tup(216, 4)]
 PAIR_T, PAIR0, PAIR1 = tup(212), "v212", "v213"
-CLOBBERS = [f"v{r}" for r in range(120, 220)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
+NEW, NEW_T = [f"v{220 + k}" for k in range(4)], tup(220, 4)                             # a second-level entry on its way in
+CLOBBERS = [f"v{r}" for r in range(120, 224)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
 SD, SAVE, BAD, CHK, HV, REN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
 RET, XSAVE, FLAGGED, V1, V2 = "s[70:71]", "s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]"    # (s96..s101 are flat_scratch / xnack_mask)
 B16 = False           # True: 12 < P <= 24, the lookup is one 16-byte bucket entry (DecLut::b16) instead of the table of 2^P quantiles
@@ -238,38 +239,53 @@ def gen(ends):
     a.i("s_or_b32 s88, s88, s89"); a.i("v_mov_b32 %[bad], s88")
     if B16:
         a.i("s_branch 3f")
-        # ---- out of line: the walk (entered with the lanes to walk in vcc; Q and the entry as in the step), one copy per
-        # ---- entry register set
+        # ---- out of line, per step: second-level entry for the lanes beyond their bucket's third symbol (vcc), the selects again,
+        # ---- and the walk over the cdf table for whoever is still beyond (gen_decode_loop_b16.py; one copy of the two routines per
+        # ---- entry register set)
         for j in range(32):
+            E0, E1, E2, E3 = ESET[j % 2]
             a.i(f"1{j:02d}:", None)
-            a.i(f"s_call_b64 {RET}, {4 + j % 2}f")
-            a.i(f"s_cbranch_scc1 3{j:02d}b", "second-level entries have landed: the selects again")
+            a.i(f"s_call_b64 {RET}, {4 + j % 2}f", "second-level entries (DecLut, cst_common.hpp) for the lanes in vcc")
+            a.i(f"v_cmp_ge_u32 {V1}, {Q}, {E1}")
+            a.i(f"v_cmp_ge_u32 {V2}, {Q}, {E2}")
+            a.i(f"v_cmp_ge_u32 vcc, {Q}, {E3}")
+            a.i(f"v_and_b32 {C}, %[cfield], {E0}")
+            a.i(f"v_cndmask_b32_e64 {NXT}, {E1}, {E2}, {V1}")
+            a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
+            a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
+            a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
+            a.i(f"s_cbranch_vccz 2{j:02d}b")
+            a.i(f"s_call_b64 {RET}, {8 + j % 2}f", "still beyond the third symbol: walk")
             a.i(f"s_branch 2{j:02d}b")
         for st in range(2):
             E0, E1 = ESET[st][0], ESET[st][1]
             a.i(f"{4 + st}:", None)
             a.i(f"s_mov_b64 {XSAVE}, exec")
-            a.i(f"s_mov_b64 {FLAGGED}, vcc")
             a.i("s_mov_b64 exec, vcc")
-            # lanes whose bucket has a second-level table (DecLut, cst_common.hpp: { table offset, 0, 0, 0 }): fetch its entry
-            a.i(f"v_cmp_eq_u32 vcc, 0, {E1}", "(a real entry's cdf[i0 + 1] is never 0)")
-            a.i(f"s_cbranch_vccz {8 + st}f")
-            a.i("s_mov_b64 exec, vcc")
-            a.i("s_min_u32 s86, %[bsh], 4", "2^min(4, P - 11) parts per bucket (kSubBitsMax)")
+            a.i("s_min_u32 s86, %[bsh], 4", "2^min(4, P - 11) parts per bucket (kSubBitsMax) ...")
             a.i("s_sub_u32 s87, %[bsh], s86")
-            a.i("s_bfm_b32 s86, s86, 0", "(as a mask)")
-            a.i(f"v_lshrrev_b32 {TMPA}, s87, {Q}", "which part of the bucket")
+            a.i("s_add_u32 s86, s86, 5", "... in the slot (bucket mod 32: kSubTables) the bucket may own")
+            a.i("s_bfm_b32 s86, s86, 0", "(slot | part as a mask)")
+            a.i(f"v_lshrrev_b32 {TMPA}, s87, {Q}")
             a.i(f"v_and_b32 {TMPA}, s86, {TMPA}")
-            a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, {E0}")
-            a.i(f"v_add_u32 {TMPA}, %[lut], {TMPA}")
-            a.i(f"ds_read_b128 {ESET_T[st]}, {TMPA}")
+            a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, %[lut]")
+            a.i(f"ds_read_b128 {NEW_T}, {TMPA} offset:32768", "(behind the 2048 bucket entries)")
             a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"v_and_b32 {TMPA}, %[cfield], {NEW[0]}")
+            a.i(f"v_cmp_le_u32 vcc, {TMPA}, {Q}", "its first cumulative does not lie above q ...")
+            a.i(f"v_cmp_gt_u32 {FLAGGED}, {NEW[1]}, {TMPA}", "... and it is an entry (free slots hold zeros)")
+            a.i(f"s_and_b64 vcc, vcc, {FLAGGED}")
+            a.i("s_and_b64 exec, exec, vcc")
+            for k in range(4):
+                a.i(f"v_mov_b32 {ESET[st][k]}, {NEW[k]}")
             a.i(f"s_mov_b64 exec, {XSAVE}")
-            a.i("s_cmp_eq_u32 s82, s82", "scc = 1: run the selects again")
             a.i(f"s_setpc_b64 {RET}")
             a.i(f"{8 + st}:", None)
+            a.i(f"s_mov_b64 {XSAVE}, exec")
+            a.i(f"s_mov_b64 {FLAGGED}, vcc")
+            a.i("s_mov_b64 exec, vcc")
             a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}")
-            a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the bucket's first three symbols lie below q")
+            a.i(f"v_add_u32 {IDX}, 3, {IDX}", "the entry's first three symbols lie below q")
             a.i(f"{6 + st}:", None)
             a.i(f"v_lshl_add_u32 {TMPA}, {IDX}, 2, %[cdf]")
             a.i(f"ds_read_b32 {NXT}, {TMPA} offset:4", "cdf[idx + 1]   (cdf[n] = 2^P lies above every quantile)")
@@ -289,7 +305,6 @@ def gen(ends):
             a.i(f"v_and_b32 {E0}, %[cfield], {E0}")
             a.i(f"v_or_b32 {E0}, {E0}, {IDX}")
             a.i(f"s_mov_b64 exec, {XSAVE}")
-            a.i("s_cmp_lg_u32 s82, s82", "scc = 0")
             a.i(f"s_setpc_b64 {RET}")
         a.i("3:", None)
     return a

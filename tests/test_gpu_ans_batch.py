@@ -1065,6 +1065,49 @@ def test_second_level_tables(B, O, coder, P, n_sym, period):
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
 
 
+@pytest.mark.parametrize("coder", ["ans", "range"])
+def test_second_level_slots_shared_by_buckets(B, O, coder):
+    """Three crowded buckets that map to the SAME second-level slot (buckets b, b + 32, b + 96 of 2048 at P = 24; the lowest
+    owns it), one more on a slot of its own: lanes of the owner take its table, lanes of the higher buckets read an entry
+    that passes the check (a lower bucket's: longer walk) and must still decode their own symbols; every cluster is hit hard."""
+    P, lo = 24, -40
+    shift = P - 11
+    clusters = [(5, 12), (37, 9), (101, 7), (700, 11)]                  # (bucket, symbols of probability 1 at its start)
+    cdf = [0]
+    for b, k in clusters:
+        cdf.append(b << shift)                                         # one wide symbol up to the bucket's first quantile ...
+        for _ in range(k):
+            cdf.append(cdf[-1] + 1)                                    # ... then k symbols of probability 1 inside the bucket
+    cdf.append(1 << P)
+    cdf = np.array(sorted(set(cdf)), dtype=np.uint32)
+    n_sym = len(cdf) - 1
+    model = B.Model.from_cdf(cdf, lo, P)
+    rng = np.random.default_rng(5)
+    n_streams, n_per = 128, 32 * 6 + 3
+    sym = (rng.integers(0, n_sym, size=(n_streams, n_per)) + lo).astype(np.int32)      # uniform over SYMBOLS: mostly the tiny ones
+    if coder == "ans":
+        want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+        enc = B.ans_encode(dev(sym), model, (32, 64, P))
+        dec, st = B.ans_decode(enc, model, n_per)
+    else:
+        want_words, want_n, _ = O.rc_encode_batch(sym, lo, cdf, P)
+        enc = B.range_encode(dev(sym), model, (32, 64, P))
+        dec, st = B.range_decode(enc, model, n_per)
+    torch.cuda.synchronize()
+    words, n_words, _ = enc.to_numpy()
+    assert n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), s
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    # ... and through the compiler-scheduled paths (a partial wave, 16-bit index images do not apply here)
+    few = dev(sym[:37, :50].copy())
+    if coder == "ans":
+        dec2, _ = B.ans_decode(B.ans_encode(few, model, (32, 64, P)), model, 50)
+    else:
+        dec2, _ = B.range_decode(B.range_encode(few, model, (32, 64, P)), model, 50)
+    assert torch.equal(dec2, few)
+
+
 def test_tuned_stride(B, O, tmp_path, monkeypatch):
     """batched.tuned_stride: max_words for small batches without measuring; for a batch of 2^26 symbols a stride from the
     candidate list, remembered per shape; and stride="tuned" changes where the slabs lie, never what is in them."""
