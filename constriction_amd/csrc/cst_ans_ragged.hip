@@ -6,9 +6,21 @@
 // that is one device round trip per document; here it is one launch for all of them:
 //     symbols of stream s   = d_symbols[d_sym_offsets[s] .. d_sym_offsets[s + 1])        (a CSR-style ragged array)
 //     words of stream s     = d_words[off(s) .. off(s) + d_n_words[s]),  off(s) = d_word_offsets ? d_word_offsets[s] : s * stride
-// One lane per stream, a wave runs as many steps as its longest stream (the others idle behind a predicate: sort or bucket
-// the documents by length if they differ by orders of magnitude); tables stay in HBM / L2 (short streams: staging 2^P
-// entries per workgroup would cost more than the lookups), words go through the per-lane LDS rings of the other kernels.
+// One lane per stream, a wave runs as many steps as its longest stream (the others idle behind a predicate).  These batches
+// are bound by the LATENCY of a step, not by throughput (a document's steps are a chain and few waves are resident), so the
+// kernels keep everything a step waits for within the CU:
+//   * tables in LDS (STAGED: the encoder's 16-byte entries / the decoder's cdf + 16-byte bucket entries with second-level
+//     tables, DecLut in cst_common.hpp) whenever they fit in 64 KiB -- a few KiB to 42 KiB per workgroup, staged once;
+//     larger alphabets read them from HBM / L2;
+//   * symbols in GROUPS OF EIGHT: the encoder codes the (len mod 8) symbols at the end of a row first, then whole groups
+//     from two 16-byte loads per lane issued a full group ahead; the decoder collects eight symbols in registers and
+//     stores them as two 16-byte pieces;
+//   * one memory point per group: a gfx9 wave has ONE counter for its loads and stores (vmcnt) and the compiler waits for
+//     all of them wherever it cannot count what a divergent branch issued, so every group first consumes what was
+//     requested a whole group earlier (next symbols / landed word chunks), THEN issues this group's requests and stores,
+//     then runs its eight steps out of LDS and registers.  The per-step form of round 3's first version (a symbol load, a
+//     table read from L2, a chunk store or load per step) paid a memory round trip per step: 0.5-1 us per symbol.
+// Words go through the per-lane LDS rings of the other kernels.
 // Every stream's words are those of cst_ans_encode_batch for that stream alone (stack.rs:835-849, 891-895; 1070-1100).
 #include "cst_ans_kernels.hpp"
 
@@ -39,11 +51,33 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-template <int W, int S>
+typedef int32_t rv4i __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) rv4i_unaligned { rv4i v; };      // 16-byte access at a 4-byte boundary
+
+constexpr size_t kRaggedRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;
+constexpr int kRaggedGroup = 8;                  // symbols per memory point (<= kAhead / 2 - 4: see the decoder's window)
+constexpr size_t kRaggedStageLimit = 64 * 1024;  // tables up to this size are staged in LDS
+
+// "the values requested a group ago are needed HERE": the compiler puts its wait in front of this (everything outstanding
+// is a whole group old by then) instead of behind the requests and stores of the new group
+__device__ __forceinline__ void consume(rv4i& a, rv4i& b) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+
+// FAST (W = 32, P >= 8): the hand-scheduled coder steps of the other kernels (32-bit halves, cst_ans_asm.hpp)
+template <int W, int S, bool STAGED, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
+    if constexpr (FAST) { if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap(); }     // step<true> forms ring addresses with and/or
+    const EncEntry* table = a.enc;
+    if constexpr (STAGED) {
+        EncEntry* t = reinterpret_cast<EncEntry*>(smem + kRaggedRingBytes);
+        for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) t[i] = a.enc[i];
+        table = t;
+        __syncthreads();
+    }
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s - lane >= a.n_streams) return;
     const bool active = s < a.n_streams;
@@ -57,12 +91,34 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
     EncLane<W, S> L;
     L.init(a.words_out + slab_lo, (uint32_t)(slab_n > 0xffffffffull ? 0xffffffffull : slab_n), ring, lane);
     const int32_t* row = a.symbols_in + sym_lo;
-    const uint32_t mx = wave_max_u32(len);
-    // encode_iid_symbols_reverse: last symbol first (stack.rs:835-849); one step pushes at most one word, one scheduled point
-    // per step moves every complete 16-byte chunk out of the ring
-    for (uint32_t k = mx; k-- > 0;) {
-        if (k < len) L.template step<false>(a.enc[enc_index(row[k], a.min_symbol, nsym, L.bad)], P);
-        L.flush_chunks();
+    auto entry = [&](int32_t v) { return table[enc_index(v, a.min_symbol, nsym, L.bad)]; };
+    // encode_iid_symbols_reverse: last symbol first (stack.rs:835-849).  The (len mod 8) symbols at the END of the row one by
+    // one (all their loads in flight at once), so that what remains is whole groups
+    const uint32_t pre = len & (uint32_t)(kRaggedGroup - 1);
+    if (__any(pre != 0)) {
+        int32_t v[kRaggedGroup - 1];
+#pragma unroll
+        for (int j = 0; j < kRaggedGroup - 1; ++j) v[j] = (uint32_t)j < pre ? row[len - 1u - (uint32_t)j] : 0;
+#pragma unroll
+        for (int j = 0; j < kRaggedGroup - 1; ++j)
+            if ((uint32_t)j < pre) L.template step<FAST>(entry(v[j]), P);
+    }
+    const uint32_t ng = len / kRaggedGroup;                     // whole groups, coded from the last one down
+    const uint32_t mxg = wave_max_u32(ng);
+    const rv4i_unaligned* g4 = reinterpret_cast<const rv4i_unaligned*>(row);        // group g = pieces 2g, 2g + 1
+    rv4i n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
+    if (ng > 0) { n0 = g4[2 * ng - 2].v; n1 = g4[2 * ng - 1].v; }
+    for (uint32_t g = 0; g < mxg; ++g) {
+        consume(n0, n1);                    // group g's symbols (requested a group ago) -- and every older store
+        const rv4i c0 = n0, c1 = n1;
+        if (g + 1 < ng) { n0 = g4[2 * (ng - g) - 4].v; n1 = g4[2 * (ng - g) - 3].v; }
+        L.flush_chunks();                   // complete 16-byte chunks of the words of earlier groups: ring -> slab (at most 3)
+        if (g < ng) {
+            const EncEntry e7 = entry(c1.w), e6 = entry(c1.z), e5 = entry(c1.y), e4 = entry(c1.x);
+            const EncEntry e3 = entry(c0.w), e2 = entry(c0.z), e1 = entry(c0.y), e0 = entry(c0.x);
+            L.template step<FAST>(e7, P); L.template step<FAST>(e6, P); L.template step<FAST>(e5, P); L.template step<FAST>(e4, P);
+            L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
+        }
     }
     uint32_t n_words = 0;
     int32_t status = L.finish(true, nsym, n_words);
@@ -72,83 +128,151 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
     a.status[s] = status;
 }
 
-template <int W, int S>
+// what both decoding kernels share: the tables (staged or not), the lane's coder, its window primed
+constexpr int kRaggedDecSlots = 32, kRaggedDecAhead = 24;      // 8 KiB of ring per wave: two workgroups per CU next to 42 KiB of tables
+constexpr size_t kRaggedDecRingBytes = (size_t)(kBlock / kWave) * kRaggedDecSlots * kWave * 4;
+template <int W, int S, bool STAGED, bool FAST>
+struct RaggedDecoder {
+    DecLut lut{};
+    const uint32_t* cdf;
+    const uint16_t* bucket;
+    DecLane<W, S, kRaggedDecSlots, kRaggedDecAhead> L;
+    WordSlice ws;
+    bool active;
+    size_t s;
+    int lane;
+
+    // returns false for the lanes of a wave without streams (after the only barrier)
+    __device__ __forceinline__ bool init(const RaggedArgs& a, unsigned char* smem) {
+        lane = threadIdx.x & (kWave - 1);
+        uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave);
+        cdf = a.cdf; bucket = a.bucket;
+        if constexpr (STAGED) {
+            stage_decoder_tables<kDecBucket, true, true>(smem + kRaggedDecRingBytes, a.precision, nullptr, nullptr, a.cdf, a.bucket, a.bucket_bits,
+                                                         a.n_symbols, lut, cdf, bucket);
+            __syncthreads();
+        }
+        s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (s - lane >= a.n_streams) return false;
+        active = s < a.n_streams;
+        ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
+        L.init(a.words_in + ws.off, ws.n, ring, lane);
+        L.read_initial_state();
+        L.in.prime();
+        wave_lds_fence();
+        return true;
+    }
+    __device__ __forceinline__ uint32_t step(const RaggedArgs& a) {
+        return ans_decode_step<W, S, kDecBucket, FAST>(L, lut, cdf, bucket, a.precision - a.bucket_bits, a.n_symbols, a.precision);
+    }
+};
+
+template <int W, int S, bool STAGED, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_decode_ragged_kernel(const RaggedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s - lane >= a.n_streams) return;
-    const bool active = s < a.n_streams;
-    const int P = a.precision;
-    const int bucket_shift = P - a.bucket_bits;
-    const uint64_t sym_lo = active ? a.sym_offsets[s] : 0, sym_hi = active ? a.sym_offsets[s + 1] : 0;
+    static_assert(2 * kRaggedGroup <= kRaggedDecAhead - 4, "a group may consume kRaggedGroup words before the chunks requested at its start land");
+    RaggedDecoder<W, S, STAGED, FAST> D;
+    if (!D.init(a, smem)) return;
+    const uint64_t sym_lo = D.active ? a.sym_offsets[D.s] : 0, sym_hi = D.active ? a.sym_offsets[D.s + 1] : 0;
     const bool too_long = sym_hi - sym_lo > 0xffffffffull || sym_hi < sym_lo;
     const uint32_t len = too_long ? 0u : (uint32_t)(sym_hi - sym_lo);
-    DecLane<W, S> L;
-    const WordSlice ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
-    L.init(a.words_in + ws.off, ws.n, ring, lane);
-    L.read_initial_state();
-    L.in.prime();
-    wave_lds_fence();
-    const DecLut lut{};                                  // no staged image: cdf + bucket index straight from HBM / L2
     int32_t* row = a.symbols_out + sym_lo;
     const uint32_t mx = wave_max_u32(len);
-    for (uint32_t k = 0; k < mx; ++k) {
-        if (k < len) row[k] = a.min_symbol + (int32_t)ans_decode_step<W, S, kDecBucket, false>(L, lut, a.cdf, a.bucket, bucket_shift, a.n_symbols, P);
-        L.in.advance_window();
+    int32_t o[kRaggedGroup];
+#pragma unroll
+    for (int j = 0; j < kRaggedGroup; ++j) o[j] = 0;
+    // symbols k0 - 8 .. k0 - 1 (decoded by the previous group) -> HBM: two 16-byte pieces, or one by one at the end of a row
+    auto store_group = [&](uint32_t k0) {
+        if (k0 < kRaggedGroup || k0 - kRaggedGroup >= len) return;
+        const uint32_t b = k0 - kRaggedGroup;
+        if (k0 <= len) {
+            rv4i_unaligned* d = reinterpret_cast<rv4i_unaligned*>(row + b);
+            d[0].v = rv4i{o[0], o[1], o[2], o[3]};
+            d[1].v = rv4i{o[4], o[5], o[6], o[7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRaggedGroup; ++j)
+                if (b + (uint32_t)j < len) row[b + (uint32_t)j] = o[j];
+        }
+    };
+    for (uint32_t k0 = 0; k0 < mx; k0 += kRaggedGroup) {
+        D.L.in.land_pending();              // the chunks requested a group ago (a group consumes at most 8 of the >= 12 words landed below it)
+        store_group(k0);
+        D.L.in.advance_window();            // (nothing pending: requests only)
+#pragma unroll
+        for (int j = 0; j < kRaggedGroup; ++j)
+            if (k0 + (uint32_t)j < len) o[j] = a.min_symbol + (int32_t)D.step(a);
     }
-    if (!active) return;
-    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (too_long ? (int32_t)CST_STREAM_CAPACITY : L.status);
+    store_group((mx + kRaggedGroup - 1) / kRaggedGroup * kRaggedGroup);
+    if (!D.active) return;
+    a.status[D.s] = D.ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (too_long ? (int32_t)CST_STREAM_CAPACITY : D.L.status);
 }
 
 // The reference's index stores no lengths: a document ends where its terminator symbol is decoded (tests/issue52.rs:63-80).
 // First pass of that: every stream is decoded until `eof_index` appears (or `max_symbols` were decoded: CST_STREAM_CAPACITY,
 // the output a caller would size from it could not hold more), nothing is stored but the count -- terminator included.  A
 // prefix sum of the counts is the d_sym_offsets of cst_ans_decode_ragged.
-template <int W, int S>
+template <int W, int S, bool STAGED, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_count_until_kernel(const RaggedArgs a, uint32_t eof_index, uint64_t max_symbols, uint64_t* lengths) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s - lane >= a.n_streams) return;
-    const bool active = s < a.n_streams;
-    const int P = a.precision;
-    const int bucket_shift = P - a.bucket_bits;
-    DecLane<W, S> L;
-    const WordSlice ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
-    L.init(a.words_in + ws.off, ws.n, ring, lane);
-    L.read_initial_state();
-    L.in.prime();
-    wave_lds_fence();
-    const DecLut lut{};
+    RaggedDecoder<W, S, STAGED, FAST> D;
+    if (!D.init(a, smem)) return;
     uint64_t n = 0;
-    bool done = !active || ws.bad || L.status != CST_STREAM_OK || max_symbols == 0;
+    bool done = !D.active || D.ws.bad || D.L.status != CST_STREAM_OK || max_symbols == 0;
     bool found = false;
     while (__any(!done)) {
-        if (!done) {
-            const uint32_t idx = ans_decode_step<W, S, kDecBucket, false>(L, lut, a.cdf, a.bucket, bucket_shift, a.n_symbols, P);
-            ++n;
-            found = idx == eof_index;
-            done = found || n >= max_symbols;
+        D.L.in.advance_window();            // lands what the previous group requested, requests for this one
+#pragma unroll
+        for (int j = 0; j < kRaggedGroup; ++j) {
+            if (!done) {
+                const uint32_t idx = D.step(a);
+                ++n;
+                found = idx == eof_index;
+                done = found || n >= max_symbols;
+            }
         }
-        L.in.advance_window();
     }
-    if (!active) return;
-    lengths[s] = n;
-    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : (L.status != CST_STREAM_OK ? L.status : (found ? (int32_t)CST_STREAM_OK : (int32_t)CST_STREAM_CAPACITY));
+    if (!D.active) return;
+    lengths[D.s] = n;
+    a.status[D.s] = D.ws.bad ? (int32_t)CST_STREAM_INVALID_DATA
+                             : (D.L.status != CST_STREAM_OK ? D.L.status : (found ? (int32_t)CST_STREAM_OK : (int32_t)CST_STREAM_CAPACITY));
 }
 
-template <typename K>
-static cst_status ragged_launch(K kernel, const RaggedArgs& a, hipStream_t hs) {
+static size_t ragged_encode_table_bytes(const cst_model* m) { return (((size_t)m->n_symbols * sizeof(EncEntry)) + 15) & ~(size_t)15; }
+static size_t ragged_decode_table_bytes(const cst_model* m) {
+    const size_t cdf = (((size_t)m->n_symbols + 1) * 4 + 15) & ~(size_t)15;
+    return cdf + (bucket16_usable(m->n_symbols, m->precision) ? ((size_t)16 << m->bucket_bits) + kSubAreaBytes
+                                                               : ((((size_t)2 << m->bucket_bits) + 15) & ~(size_t)15));
+}
+
+template <typename K, typename... Extra>
+static cst_status ragged_launch(K kernel, const RaggedArgs& a, size_t ring_bytes, size_t table_bytes, hipStream_t hs, Extra... extra) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks == 0) return CST_OK;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    const size_t lds = (size_t)(kBlock / kWave) * kRingWords * 4;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    const size_t lds = ring_bytes + table_bytes;
+    if (lds > 64 * 1024)
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, extra...);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
+
+// (W, S) by the preset, STAGED by the size of the tables, FAST where the hand-scheduled steps apply
+#define CST_RAGGED_DISPATCH(KERNEL, RING_BYTES, TABLE_BYTES, ...)                                                                   \
+    do {                                                                                                                             \
+        const size_t tb_ = (TABLE_BYTES);                                                                                            \
+        const bool staged_ = tb_ <= kRaggedStageLimit;                                                                               \
+        const size_t t_ = staged_ ? tb_ : 0;                                                                                         \
+        if (cfg.word_bits != 32)                                                                                                     \
+            return staged_ ? ragged_launch(KERNEL<16, 32, true, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__)                        \
+                           : ragged_launch(KERNEL<16, 32, false, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__);                      \
+        if (model->precision >= 8)                                                                                                   \
+            return staged_ ? ragged_launch(KERNEL<32, 64, true, true>, a, RING_BYTES, t_, hs, ##__VA_ARGS__)                         \
+                           : ragged_launch(KERNEL<32, 64, false, true>, a, RING_BYTES, t_, hs, ##__VA_ARGS__);                       \
+        return staged_ ? ragged_launch(KERNEL<32, 64, true, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__)                            \
+                       : ragged_launch(KERNEL<32, 64, false, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__);                          \
+    } while (0)
 
 cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
                              size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
@@ -157,40 +281,35 @@ cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const
     a.symbols_in = d_symbols; a.sym_offsets = d_sym_offsets; a.n_streams = n_streams; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_out = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_out = d_n_words; a.status = d_status;
-    if (cfg.word_bits == 32) return ragged_launch(ans_encode_ragged_kernel<32, 64>, a, hs);
-    return ragged_launch(ans_encode_ragged_kernel<16, 32>, a, hs);
+    CST_RAGGED_DISPATCH(ans_encode_ragged_kernel, kRaggedRingBytes, ragged_encode_table_bytes(model));
 }
 
-cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
-                             size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
-                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, hipStream_t hs) {
-    RaggedArgs a{};
-    a.symbols_out = d_symbols; a.sym_offsets = d_sym_offsets; a.n_streams = n_streams; a.cdf = model->d_cdf; a.bucket = model->d_bucket;
-    a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
-    a.words_in = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_in = d_n_words; a.status = d_status;
-    a.words_capacity = words_capacity;
-    if (cfg.word_bits == 32) return ragged_launch(ans_decode_ragged_kernel<32, 64>, a, hs);
-    return ragged_launch(ans_decode_ragged_kernel<16, 32>, a, hs);
-}
-
-cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
-                           size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
-                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, hipStream_t hs) {
+static RaggedArgs ragged_decode_args(const cst_model* model, const uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
+                                     size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t* d_status) {
     RaggedArgs a{};
     a.n_streams = n_streams; a.cdf = model->d_cdf; a.bucket = model->d_bucket;
     a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_in = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_in = d_n_words; a.status = d_status;
     a.words_capacity = words_capacity;
-    const size_t blocks = (n_streams + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    const size_t lds = (size_t)(kBlock / kWave) * kRingWords * 4;
-    const uint32_t eof_index = (uint32_t)eof_symbol - (uint32_t)model->min_symbol;
-    if (cfg.word_bits == 32)
-        hipLaunchKernelGGL((ans_count_until_kernel<32, 64>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, eof_index, (uint64_t)max_symbols, d_lengths);
-    else
-        hipLaunchKernelGGL((ans_count_until_kernel<16, 32>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, eof_index, (uint64_t)max_symbols, d_lengths);
-    CST_HIP_TRY(hipGetLastError());
-    return CST_OK;
+    return a;
 }
+
+cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                             size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, hipStream_t hs) {
+    RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status);
+    a.symbols_out = d_symbols; a.sym_offsets = d_sym_offsets;
+    CST_RAGGED_DISPATCH(ans_decode_ragged_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model));
+}
+
+cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                           size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
+                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, hipStream_t hs) {
+    const RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status);
+    const uint32_t eof_index = (uint32_t)eof_symbol - (uint32_t)model->min_symbol;
+    const uint64_t mx = (uint64_t)max_symbols;
+    CST_RAGGED_DISPATCH(ans_count_until_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model), eof_index, mx, d_lengths);
+}
+#undef CST_RAGGED_DISPATCH
 
 } // namespace cst
