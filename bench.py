@@ -298,6 +298,59 @@ def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100,
     return entry
 
 
+def ragged_config(B, reps, check, n_docs=100_000, n_sym=64, precision=24):
+    """Many small coders in one launch (the reference's second usage pattern, tests/issue52.rs:27-80: one DefaultAnsCoder per
+    document of a compressed index, a shared model): 100 000 documents of 20 .. 2000 symbols (log-uniform lengths, seeded),
+    a 64-symbol categorical model at P = 24, `cst_ans_{encode,decode}_ragged`.  Algorithmic bytes per direction: 4 per symbol +
+    4 per compressed word + 16 per document (its two offsets).  These batches are bound by the latency of the longest
+    document's chain, not by traffic: the fractions are reported for completeness.  Check: every 50th document's words
+    against the CPU oracle coding that document alone; all decoded symbols against the input."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(SEED)
+    w = 0.93 ** np.arange(n_sym)
+    prob = np.maximum(1, np.floor(w / w.sum() * ((1 << precision) - n_sym)).astype(np.int64))
+    prob[0] += (1 << precision) - int(prob.sum())
+    cdf = np.concatenate([[0], np.cumsum(prob)]).astype(np.uint32)
+    model = B.Model.from_cdf(cdf, 0, precision)
+    lengths = np.exp(rng.uniform(np.log(20), np.log(2000), n_docs)).astype(np.int64)
+    offsets = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    n_total = int(offsets[-1])
+    gen = torch.Generator(device="cuda").manual_seed(SEED)
+    q = torch.randint(0, 1 << precision, (n_total,), generator=gen, device="cuda", dtype=torch.int64)
+    flat = (torch.searchsorted(torch.from_numpy(cdf.astype(np.int64)).cuda(), q, right=True) - 1).to(torch.int32)
+    del q
+    off_d = torch.from_numpy(offsets).cuda()
+    cfg = (32, 64, precision)
+    enc = B.ans_encode_ragged(flat, off_d, model, cfg)
+    decoded, status = B.ans_decode_ragged(enc, model, off_d)
+    enc_ms = event_ms(lambda: B.ans_encode_ragged(flat, off_d, model, cfg), reps)
+    dec_ms = event_ms(lambda: B.ans_decode_ragged(enc, model, off_d, out=decoded), reps)
+    total_words = int(enc.n_words.sum().item())
+    byts = 4 * n_total + 4 * total_words + 16 * n_docs
+    entry = {"workload": f"many small coders (tests/issue52.rs pattern): {n_docs} documents of 20..2000 symbols in one launch, {n_sym}-symbol categorical model",
+             "coder": "ans", "config": list(cfg), "streams": n_docs, "symbols_total": n_total,
+             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_total / (enc_ms + dec_ms) / 1e3, 1),
+             "ns_per_document": [round(enc_ms * 1e6 / n_docs, 2), round(dec_ms * 1e6 / n_docs, 2)],
+             "words_per_stream": round(total_words / n_docs, 2),
+             "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    if check:
+        ok = bool(torch.equal(decoded, flat)) and int(enc.status.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
+        if ok:
+            h_flat, n_words = flat.cpu().numpy(), enc.n_words.cpu().numpy()
+            h_words, h_woff = enc.words.cpu().numpy().view(np.uint32), enc.word_offsets.cpu().numpy()
+            for d in range(0, n_docs, 50):
+                doc = h_flat[offsets[d]: offsets[d + 1]]
+                want, n, st = O.ans_encode_batch(doc[None, :], 0, cdf, precision, 32, 64)
+                if st[0] != 0 or n[0] != n_words[d] or not np.array_equal(want[0, : n[0]], h_words[h_woff[d]: h_woff[d] + n[0]]):
+                    ok = False
+                    break
+            entry["bit_exact_scope"] = f"every 50th of {n_docs} documents: words and counts vs CPU oracle; all decoded symbols vs input"
+        entry["bit_exact"] = ok
+    return entry
+
+
 def other_configs(B, rank, world, dist, args, reps=5):
     """Every other single-GPU configuration of BASELINE.json, same clock, same checks (see the module docstring)."""
     out = []
@@ -357,6 +410,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
         add("C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
         del sym3, m3, cdfs
         out.append(per_symbol_config(B, reps, check))
+        try:
+            out.append(ragged_config(B, reps, check))
+        except Exception as exc:      # noqa: BLE001
+            out.append({"workload": "many small coders (ragged)", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
     del sym12
     torch.cuda.empty_cache()
     # C5 shard: 131 072 streams per GPU, compaction, gather of the packed words to rank 0

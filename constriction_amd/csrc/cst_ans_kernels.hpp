@@ -960,7 +960,9 @@ __device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, c
         // Unconditional ring read, issued BEFORE the table lookup so that the lookup's own wait covers it.
         // volatile: the load stays HERE (the optimiser would otherwise sink it into a branch on `refill` and put the LDS
         // latency back on the critical path) and stays visible to the compiler's lgkmcnt bookkeeping
-        next_word = *reinterpret_cast<const volatile uint32_t*>(L.in.slot(L.in.rd - 1u + L.in.shift));
+        // (through the LDS address space explicitly: address-space inference leaves a volatile access alone, and as a
+        // generic access this was a flat_load -- which waits for the wave's outstanding global loads and stores, too)
+        next_word = *(const volatile lds_u32*)L.in.slot(L.in.rd - 1u + L.in.shift);
     } else {
         next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);   // ignored if no refill
     }

@@ -142,25 +142,26 @@ struct RaggedDecoder {
     size_t s;
     int lane;
 
-    // returns false for the lanes of a wave without streams (after the only barrier)
-    __device__ __forceinline__ bool init(const RaggedArgs& a, unsigned char* smem) {
-        lane = threadIdx.x & (kWave - 1);
-        uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave);
+    // every thread of the workgroup: the tables (the only barriers)
+    __device__ __forceinline__ void stage(const RaggedArgs& a, unsigned char* smem) {
         cdf = a.cdf; bucket = a.bucket;
         if constexpr (STAGED) {
             stage_decoder_tables<kDecBucket, true, true>(smem + kRaggedDecRingBytes, a.precision, nullptr, nullptr, a.cdf, a.bucket, a.bucket_bits,
                                                          a.n_symbols, lut, cdf, bucket);
             __syncthreads();
         }
+        lane = threadIdx.x & (kWave - 1);
         s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (s - lane >= a.n_streams) return false;
         active = s < a.n_streams;
+    }
+    __device__ __forceinline__ bool wave_has_streams(const RaggedArgs& a) const { return s - lane < a.n_streams; }
+    // the lane's coder on its slice of the words, window primed
+    __device__ __forceinline__ void start(const RaggedArgs& a, uint32_t* ring) {
         ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
         L.init(a.words_in + ws.off, ws.n, ring, lane);
         L.read_initial_state();
         L.in.prime();
         wave_lds_fence();
-        return true;
     }
     __device__ __forceinline__ uint32_t step(const RaggedArgs& a) {
         return ans_decode_step<W, S, kDecBucket, FAST>(L, lut, cdf, bucket, a.precision - a.bucket_bits, a.n_symbols, a.precision);
@@ -172,7 +173,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_ragged_kernel(const RaggedA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(2 * kRaggedGroup <= kRaggedDecAhead - 4, "a group may consume kRaggedGroup words before the chunks requested at its start land");
     RaggedDecoder<W, S, STAGED, FAST> D;
-    if (!D.init(a, smem)) return;
+    D.stage(a, smem);
+    if (!D.wave_has_streams(a)) return;
+    D.start(a, reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave));
     const uint64_t sym_lo = D.active ? a.sym_offsets[D.s] : 0, sym_hi = D.active ? a.sym_offsets[D.s + 1] : 0;
     const bool too_long = sym_hi - sym_lo > 0xffffffffull || sym_hi < sym_lo;
     const uint32_t len = too_long ? 0u : (uint32_t)(sym_hi - sym_lo);
@@ -216,7 +219,9 @@ template <int W, int S, bool STAGED, bool FAST>
 __global__ __launch_bounds__(kBlock) void ans_count_until_kernel(const RaggedArgs a, uint32_t eof_index, uint64_t max_symbols, uint64_t* lengths) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RaggedDecoder<W, S, STAGED, FAST> D;
-    if (!D.init(a, smem)) return;
+    D.stage(a, smem);
+    if (!D.wave_has_streams(a)) return;
+    D.start(a, reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave));
     uint64_t n = 0;
     bool done = !D.active || D.ws.bad || D.L.status != CST_STREAM_OK || max_symbols == 0;
     bool found = false;
