@@ -113,3 +113,48 @@ def test_ragged_status_and_bounds(B, O):
     assert torch.equal(dec[off[3]: off[4]], ref[off[3]: off[4]]) and torch.equal(dec[: off[1]], ref[: off[1]])
     empty = B.ans_encode_ragged(torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), model, (32, 64, P))
     assert empty.n_words.numel() == 0
+
+
+@pytest.mark.parametrize("cfg,n_sym", [((32, 64, 6), 40), ((16, 32, 5), 20), ((32, 64, 16), 5000), ((32, 64, 20), 20000), ((16, 32, 16), 5000),
+                                       ((32, 64, 22), 1000), ((32, 64, 24), 256)],
+                         ids=lambda v: "W%dS%dP%d" % v if isinstance(v, tuple) else "n%d" % v)
+def test_ragged_kernel_variants(B, O, cfg, n_sym):
+    """Every variant of the ragged kernels (cst_ans_ragged.hip): the generic coder steps (P < 8, 16-bit words) and the
+    hand-scheduled ones, encoder tables in LDS (<= 4096 symbols) and in HBM, decoder tables as 16-byte bucket entries in LDS
+    (<= 1024 symbols), as cdf + 16-bit bucket index in LDS, and in HBM (more than 64 KiB of cdf) -- documents whose lengths
+    cover every residue of the group of eight, a partial last wave; words of every 5th document and the terminator-delimited
+    decode against the oracle's coder for that document alone."""
+    W, S, P = cfg
+    rng = np.random.default_rng(n_sym + P)
+    lo = -3
+    w = rng.gamma(0.3, 1.0, n_sym) + 1e-9
+    p = np.maximum(1, np.floor(w / w.sum() * ((1 << P) - n_sym)).astype(np.int64))
+    p[int(np.argmax(p))] += (1 << P) - int(p.sum())
+    cdf = np.concatenate([[0], np.cumsum(p)]).astype(np.uint32)
+    model = B.Model.from_cdf(cdf, lo, P)
+    lengths = np.concatenate([np.arange(0, 41), rng.integers(0, 700, 150)])
+    eof = lo + int(np.argmin(p))
+    docs = []
+    for n in lengths:
+        d = lo + rng.choice(n_sym, size=int(n), p=p / p.sum()).astype(np.int32)
+        d[d == eof] = lo + int(np.argmax(p))
+        docs.append(np.concatenate([[eof], d]).astype(np.int32))          # coded in reverse: the terminator is decoded last
+    flat, offsets = B.ragged(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model, cfg)
+    torch.cuda.synchronize()
+    assert (enc.status.cpu().numpy() == 0).all()
+    n_words = enc.n_words.cpu().numpy()
+    for s in range(0, len(docs), 5):
+        want, st = oracle_words(O, docs[s], lo, cdf, cfg)
+        assert st == 0 and n_words[s] == len(want) and enc.stream(s).tolist() == want.tolist(), f"stream {s} of {len(docs[s])} symbols"
+    dec, status = B.ans_decode_ragged(enc, model, offsets)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all() and torch.equal(dec, flat)
+    # decoding yields the document from its first symbol on: a stream that STARTS with the terminator is one symbol long for
+    # ans_decode_until -- so code the documents reversed (terminator last in decoding order)
+    rdocs = [d[::-1].copy() for d in docs]
+    rflat, roff = B.ragged(rdocs)
+    renc = B.ans_encode_ragged(rflat, roff, model, cfg)
+    dec2, off2, status2 = B.ans_decode_until(renc, model, eof)
+    torch.cuda.synchronize()
+    assert (status2.cpu().numpy() == 0).all() and torch.equal(off2, roff) and torch.equal(dec2, rflat)
