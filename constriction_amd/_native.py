@@ -80,6 +80,9 @@ SIGNATURES = {
     "cst_ans_encode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _vp, _vp, _vp]),
     "cst_ans_decode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _vp, _vp]),
     "cst_ans_count_until": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _i32, _z, _vp, _vp, _vp]),
+    "cst_ans_encode_ragged_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _vp, _z, _vp, _vp, _vp]),
+    "cst_ans_decode_ragged_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _vp, _vp, _vp]),
+    "cst_ans_count_until_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _i32, _z, _vp, _vp, _vp]),
     "cst_compact_scratch_bytes": (_z, [_z]),
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
     "cst_rccl_get_unique_id": (_i32, [_vp]),

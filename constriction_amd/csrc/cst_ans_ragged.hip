@@ -43,7 +43,17 @@ struct RaggedArgs {
     const uint32_t* n_words_in;
     int32_t* status;
     uint64_t words_capacity;
+    const uint32_t* order;           // null, or [n_streams]: lane slot i codes stream order[i] (streams of similar length side by side)
 };
+
+// lane slot -> stream: the slot itself, or order[slot] (an entry that is not a stream leaves its lane idle)
+__device__ __forceinline__ size_t ragged_stream(const RaggedArgs& a, size_t slot, bool& active) {
+    active = slot < a.n_streams;
+    if (!active || !a.order) return slot;
+    const size_t s = a.order[slot];
+    active = s < a.n_streams;
+    return s;
+}
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -78,9 +88,10 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
         table = t;
         __syncthreads();
     }
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s - lane >= a.n_streams) return;
-    const bool active = s < a.n_streams;
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot - lane >= a.n_streams) return;
+    bool active;
+    const size_t s = ragged_stream(a, slot, active);
     const int P = a.precision;
     const uint32_t nsym = (uint32_t)a.n_symbols;
     const uint64_t sym_lo = active ? a.sym_offsets[s] : 0, sym_hi = active ? a.sym_offsets[s + 1] : 0;
@@ -139,7 +150,7 @@ struct RaggedDecoder {
     DecLane<W, S, kRaggedDecSlots, kRaggedDecAhead> L;
     WordSlice ws;
     bool active;
-    size_t s;
+    size_t s, slot;
     int lane;
 
     // every thread of the workgroup: the tables (the only barriers)
@@ -151,10 +162,10 @@ struct RaggedDecoder {
             __syncthreads();
         }
         lane = threadIdx.x & (kWave - 1);
-        s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        active = s < a.n_streams;
+        slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        s = ragged_stream(a, slot, active);
     }
-    __device__ __forceinline__ bool wave_has_streams(const RaggedArgs& a) const { return s - lane < a.n_streams; }
+    __device__ __forceinline__ bool wave_has_streams(const RaggedArgs& a) const { return slot - lane < a.n_streams; }
     // the lane's coder on its slice of the words, window primed
     __device__ __forceinline__ void start(const RaggedArgs& a, uint32_t* ring) {
         ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
@@ -281,8 +292,9 @@ static cst_status ragged_launch(K kernel, const RaggedArgs& a, size_t ring_bytes
 
 cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
                              size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
-                             uint32_t* d_n_words, int32_t* d_status, hipStream_t hs) {
+                             uint32_t* d_n_words, int32_t* d_status, const uint32_t* d_order, hipStream_t hs) {
     RaggedArgs a{};
+    a.order = d_order;
     a.symbols_in = d_symbols; a.sym_offsets = d_sym_offsets; a.n_streams = n_streams; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_out = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_out = d_n_words; a.status = d_status;
@@ -290,8 +302,9 @@ cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const
 }
 
 static RaggedArgs ragged_decode_args(const cst_model* model, const uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
-                                     size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t* d_status) {
+                                     size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t* d_status, const uint32_t* d_order) {
     RaggedArgs a{};
+    a.order = d_order;
     a.n_streams = n_streams; a.cdf = model->d_cdf; a.bucket = model->d_bucket;
     a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_in = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_in = d_n_words; a.status = d_status;
@@ -301,16 +314,16 @@ static RaggedArgs ragged_decode_args(const cst_model* model, const uint32_t* d_w
 
 cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                              size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
-                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, hipStream_t hs) {
-    RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status);
+                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, const uint32_t* d_order, hipStream_t hs) {
+    RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status, d_order);
     a.symbols_out = d_symbols; a.sym_offsets = d_sym_offsets;
     CST_RAGGED_DISPATCH(ans_decode_ragged_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model));
 }
 
 cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                            size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
-                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, hipStream_t hs) {
-    const RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status);
+                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, const uint32_t* d_order, hipStream_t hs) {
+    const RaggedArgs a = ragged_decode_args(model, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, d_status, d_order);
     const uint32_t eof_index = (uint32_t)eof_symbol - (uint32_t)model->min_symbol;
     const uint64_t mx = (uint64_t)max_symbols;
     CST_RAGGED_DISPATCH(ans_count_until_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model), eof_index, mx, d_lengths);

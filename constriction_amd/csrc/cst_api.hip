@@ -310,40 +310,65 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     return decode_dispatch<16, 32>(a, layout, hs);
 }
 
-cst_status cst_ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
-                                 size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
-                                 uint32_t* d_n_words, int32_t* d_status, void* stream) {
+static bool ragged_order_ok(const uint32_t* d_order, size_t n_streams) { return !d_order || n_streams <= 0xffffffffull; }
+
+cst_status cst_ans_encode_ragged_ordered(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                                         size_t n_streams, const uint32_t* d_order, uint32_t* d_words, const uint64_t* d_word_offsets,
+                                         size_t stride_words, uint32_t* d_n_words, int32_t* d_status, void* stream) {
     if (!model || !config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;      // one shared table (the pattern of tests/issue52.rs)
     if (n_streams == 0) return CST_OK;
-    if (!d_sym_offsets || !d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_sym_offsets || !d_words || !d_n_words || !d_status || !ragged_order_ok(d_order, n_streams)) return CST_ERR_INVALID_ARGUMENT;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     return ans_encode_ragged(model, cfg, d_symbols, d_sym_offsets, n_streams, d_words, d_word_offsets, stride_words, d_n_words, d_status,
-                             (hipStream_t)stream);
+                             d_order, (hipStream_t)stream);
+}
+
+cst_status cst_ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                                 size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
+                                 uint32_t* d_n_words, int32_t* d_status, void* stream) {
+    return cst_ans_encode_ragged_ordered(model, cfg, d_symbols, d_sym_offsets, n_streams, nullptr, d_words, d_word_offsets, stride_words,
+                                         d_n_words, d_status, stream);
+}
+
+cst_status cst_ans_decode_ragged_ordered(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                                         size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                                         const uint64_t* d_sym_offsets, size_t n_streams, const uint32_t* d_order, int32_t* d_status,
+                                         void* stream) {
+    if (!model || !config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (!d_sym_offsets || !d_n_words || !d_status || !ragged_order_ok(d_order, n_streams)) return CST_ERR_INVALID_ARGUMENT;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    return ans_decode_ragged(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols, d_sym_offsets,
+                             n_streams, d_status, d_order, (hipStream_t)stream);
 }
 
 cst_status cst_ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                                  size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
                                  const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, void* stream) {
+    return cst_ans_decode_ragged_ordered(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols,
+                                         d_sym_offsets, n_streams, nullptr, d_status, stream);
+}
+
+cst_status cst_ans_count_until_ordered(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                                       size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams,
+                                       const uint32_t* d_order, int32_t eof_symbol, size_t max_symbols, uint64_t* d_lengths,
+                                       int32_t* d_status, void* stream) {
     if (!model || !config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
-    if (!d_sym_offsets || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_n_words || !d_lengths || !d_status || !ragged_order_ok(d_order, n_streams)) return CST_ERR_INVALID_ARGUMENT;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
-    return ans_decode_ragged(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols, d_sym_offsets,
-                             n_streams, d_status, (hipStream_t)stream);
+    return ans_count_until(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, eof_symbol, max_symbols,
+                           d_lengths, d_status, d_order, (hipStream_t)stream);
 }
 
 cst_status cst_ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                                size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams,
                                int32_t eof_symbol, size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, void* stream) {
-    if (!model || !config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
-    if (model->per_stream) return CST_ERR_INVALID_ARGUMENT;
-    if (n_streams == 0) return CST_OK;
-    if (!d_n_words || !d_lengths || !d_status) return CST_ERR_INVALID_ARGUMENT;
-    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
-    return ans_count_until(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, eof_symbol, max_symbols,
-                           d_lengths, d_status, (hipStream_t)stream);
+    return cst_ans_count_until_ordered(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, nullptr,
+                                       eof_symbol, max_symbols, d_lengths, d_status, stream);
 }
 
 size_t cst_compact_scratch_bytes(size_t n_streams) {

@@ -160,13 +160,13 @@ cst_status ans_decode_per_stream(const cst_model* model, cst_coder_config cfg, c
 // cst_ans_ragged.hip: streams of different lengths (arguments checked by the C entry points in cst_api.hip)
 cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
                              size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
-                             uint32_t* d_n_words, int32_t* d_status, hipStream_t hs);
+                             uint32_t* d_n_words, int32_t* d_status, const uint32_t* d_order, hipStream_t hs);
 cst_status ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                              size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
-                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, hipStream_t hs);
+                             const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, const uint32_t* d_order, hipStream_t hs);
 cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
                            size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
-                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, hipStream_t hs);
+                           size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, const uint32_t* d_order, hipStream_t hs);
 
 // trimmed-packed-row coder launches (cst_ans_pt.hip); return CST_ERR_INVALID_ARGUMENT if the shape is not theirs
 bool pt_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, size_t n_per_stream);

@@ -272,6 +272,27 @@ cst_status cst_ans_count_until(const cst_model *model, cst_coder_config cfg, con
                                const uint32_t *d_n_words, size_t n_streams, int32_t eof_symbol, size_t max_symbols,
                                uint64_t *d_lengths, int32_t *d_status, void *stream);
 
+/* The same three calls with a SCHEDULE: lane slot i of the launch codes stream d_order[i] (uint32 [n_streams], a permutation of
+ * 0 .. n_streams - 1; NULL = the identity, i.e. the calls above).  A wave of 64 slots runs as long as its longest stream, so a
+ * batch whose lengths differ by orders of magnitude should put streams of similar length side by side, longest first:
+ * d_order = the stream indices sorted by length (or, for the decoders, by d_n_words) in descending order.  Results (words,
+ * counts, symbols, status, all indexed by STREAM as above) do not depend on the order; an entry that is not a stream index
+ * leaves its slot idle, a stream that no entry names is not coded.  1 000 000 documents of 20 .. 2000 symbols: encode
+ * 2.0 -> 1.3 ms, decode 4.9 -> 1.4 ms (scripts/bench_ragged_big.py). */
+cst_status cst_ans_encode_ragged_ordered(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                         const uint64_t *d_sym_offsets, size_t n_streams, const uint32_t *d_order,
+                                         uint32_t *d_words, const uint64_t *d_word_offsets, size_t stride_words,
+                                         uint32_t *d_n_words, int32_t *d_status, void *stream);
+cst_status cst_ans_decode_ragged_ordered(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                         const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
+                                         const uint32_t *d_n_words, int32_t *d_symbols, const uint64_t *d_sym_offsets,
+                                         size_t n_streams, const uint32_t *d_order, int32_t *d_status, void *stream);
+cst_status cst_ans_count_until_ordered(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                       const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
+                                       const uint32_t *d_n_words, size_t n_streams, const uint32_t *d_order,
+                                       int32_t eof_symbol, size_t max_symbols, uint64_t *d_lengths, int32_t *d_status,
+                                       void *stream);
+
 /* Checkpointed streams -- the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139; test :1456-1548) for the
  * batched coder.  The encoder notes, in front of every chunk of `ckpt_interval` symbols, what `AnsCoder::pos()` returns
  * there: d_ckpt_pos[s][j] = words in the bulk, d_ckpt_state[s][j] = coder state once symbols [j * interval, n) are

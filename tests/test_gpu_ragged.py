@@ -158,3 +158,45 @@ def test_ragged_kernel_variants(B, O, cfg, n_sym):
     dec2, off2, status2 = B.ans_decode_until(renc, model, eof)
     torch.cuda.synchronize()
     assert (status2.cpu().numpy() == 0).all() and torch.equal(off2, roff) and torch.equal(dec2, rflat)
+
+
+def test_ragged_schedule_does_not_change_results(B, O):
+    """`*_ragged_ordered`: lane slot i codes stream order[i].  Sorted by length, shuffled, or the identity: the same words,
+    counts, symbols and status per STREAM; an entry that is not a stream index leaves its slot idle (its stream is not
+    coded, nothing outside the arrays is touched)."""
+    P, lo, cfg = 24, 0, (32, 64, 24)
+    rng = np.random.default_rng(5)
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(50) * 0.5), P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    lengths = np.exp(rng.uniform(np.log(1), np.log(1500), 700)).astype(np.int64)
+    docs = [rng.integers(0, 50, int(n)).astype(np.int32) for n in lengths]
+    flat, offsets = B.ragged(docs)
+    ref = B.ans_encode_ragged(flat, offsets, model, cfg, order=None)
+    ref_dec, ref_st = B.ans_decode_ragged(ref, model, offsets, order=None)
+    assert ref.order is None and torch.equal(ref_dec, flat)
+    perm = torch.from_numpy(rng.permutation(len(docs)).astype(np.int32)).cuda()
+    for order in ("sorted", perm):
+        enc = B.ans_encode_ragged(flat, offsets, model, cfg, order=order)
+        torch.cuda.synchronize()
+        assert enc.order is not None and sorted(enc.order.cpu().tolist()) == list(range(len(docs)))
+        assert torch.equal(enc.n_words, ref.n_words) and torch.equal(enc.status, ref.status)
+        for s in range(0, len(docs), 9):
+            assert enc.stream(s).tolist() == ref.stream(s).tolist()
+        for dec_order in ("auto", None, "sorted"):
+            dec, st = B.ans_decode_ragged(enc, model, offsets, order=dec_order)
+            assert torch.equal(dec, flat) and torch.equal(st, ref_st)
+    srt = B.ragged_order(torch.from_numpy(lengths).cuda())
+    assert np.all(np.diff(lengths[srt.cpu().numpy()]) <= 0)
+    # entries that are no stream indices: their slots idle, the streams they displaced keep what the buffers held
+    bad = torch.arange(len(docs), dtype=torch.int32, device="cuda")
+    bad[3] = -1
+    bad[10] = len(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model, cfg, order=bad)
+    torch.cuda.synchronize()
+    keep = np.ones(len(docs), bool); keep[[3, 10]] = False
+    assert torch.equal(enc.n_words[torch.from_numpy(keep).cuda()], ref.n_words[torch.from_numpy(keep).cuda()])
+    out = torch.full_like(flat, -7)
+    dec, st = B.ans_decode_ragged(ref, model, offsets, out=out, order=bad)
+    off = offsets.cpu().numpy()
+    assert (dec[off[3]: off[4]] == -7).all() and (dec[off[10]: off[11]] == -7).all()
+    assert torch.equal(dec[off[11]:], flat[off[11]:]) and torch.equal(dec[: off[3]], flat[: off[3]])
