@@ -91,7 +91,11 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     DecLane<32, 64, kDecRingSlots, kDecAhead> L;
     const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, se, a.words_capacity);
     L.init(a.words + ws.off, ws.n, ring, lane);
-    L.read_initial_state();
+    // CST_FLAG_RAW_STATE: the coder continues from (d_state, d_n_words) -- AnsCoder::seek, stack.rs:1107-1139; the chunks of a
+    // checkpointed stream are such coders (cst_ans_ckpt.hip) -- instead of reading its state from the end of the words
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    if (raw) L.state = a.state[se];
+    else L.read_initial_state();
     L.in.prime();
     wave_lds_fence();
 
@@ -239,6 +243,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_kernel(const AnsDecodeA
     }
     if (!active) return;
     a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+    if (raw) {
+        a.state[s] = (uint64_t)L.state;
+        if (a.n_words_out) a.n_words_out[s] = L.in.rd;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,7 +439,7 @@ cst_status ans_encode_wide(const AnsEncodeArgs& a, cst_layout layout, hipStream_
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (layout == CST_LAYOUT_SYMBOL_MAJOR && (a.n_streams % 4 != 0 || a.n_streams < (size_t)kWave)) return false;
     return cfg.word_bits == 32 && a.precision > 12 && a.precision <= 24 &&
-           bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && !(a.flags & CST_FLAG_RAW_STATE) &&
+           bucket16_usable(a.n_symbols, a.precision) && a.bucket && a.cdf && (!(a.flags & CST_FLAG_RAW_STATE) || a.state) &&
            (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && b16_lds_bytes(a.n_symbols, a.bucket_bits) <= 160 * 1024;
 }
