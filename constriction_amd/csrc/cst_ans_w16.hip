@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     W16Lane L;
     const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, se, a.words_capacity);
     L.init(a.words + ws.off, ws.n, ring, lane);
-    L.read_initial_state();
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;       // the coder continues from (d_state, d_n_words): AnsCoder::seek, stack.rs:1107-1139
+    if (raw) L.state = (uint32_t)a.state[se];
+    else L.read_initial_state();
     L.prime();
     wave_lds_fence();
 
@@ -280,6 +282,10 @@ __global__ __launch_bounds__(kBlock) void ans_decode_w16_kernel(const AnsDecodeA
     }
     if (!active) return;
     a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+    if (raw) {
+        a.state[s] = (uint64_t)L.state;
+        if (a.n_words_out) a.n_words_out[s] = L.rd;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -477,7 +483,7 @@ cst_status ans_encode_w16(const AnsEncodeArgs& a, cst_layout layout, hipStream_t
 bool w16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (layout == CST_LAYOUT_SYMBOL_MAJOR && (a.n_streams % 4 != 0 || a.n_streams < (size_t)kWave)) return false;
     return cfg.word_bits == 16 && cfg.state_bits == 32 && a.precision >= 8 && a.precision <= 12 &&
-           a.dec_cp && a.dec_idx && !(a.flags & CST_FLAG_RAW_STATE) && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
+           a.dec_cp && a.dec_idx && (!(a.flags & CST_FLAG_RAW_STATE) || a.state) && (layout == CST_LAYOUT_SYMBOL_MAJOR || a.n_per_stream % 4 == 0) &&
            (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
 }
 
