@@ -27,7 +27,7 @@ def dev(a):
 
 
 @pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
-@pytest.mark.parametrize("n_streams,n_per,interval", [(1, 96, 32), (3, 120, 40), (70, 64, 64), (5, 100, 1), (2, 90, 100)])
+@pytest.mark.parametrize("n_streams,n_per,interval", [(1, 96, 32), (3, 120, 40), (70, 64, 64), (5, 100, 1), (2, 90, 100), (67, 1200, 400)])
 def test_checkpoints_are_pos_and_state_of_the_reference_coder(B, O, cfg, n_streams, n_per, interval):
     W, S, P = cfg
     cdf = O.GaussianModel(-30, 30, 1.5, 6.0, P, 32 if W == 32 else 16).cdf_table()
