@@ -140,8 +140,39 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
 }
 
 // what both decoding kernels share: the tables (staged or not), the lane's coder, its window primed
+// The decoders' memory point in two halves with a FIXED shape (the idea of RingReader::advance_window_fixed): all kRaggedChunks
+// chunk slots land unconditionally -- a slot without a request lands in the lane's dump rows -- so that the compiler knows
+// nothing is in flight into pend[] when the next requests overwrite it.  With the conditional landing of advance_window() it
+// protected every pend[] register with a vmcnt(0) right in front of its load, i.e. it waited for the symbol stores and the
+// previous chunk request just issued: a memory round trip per requested chunk, 720 cycles per step on a lone wave.
+constexpr int kRaggedChunks = 3;                 // a group consumes at most 8 words: two chunks and a ragged one
+template <class R>
+__device__ __forceinline__ void ring_land_all(R& in, uint32_t* dump) {
+#pragma unroll
+    for (int k = 0; k < kRaggedChunks; ++k) {
+        uint32_t* b = in.pend_pos[k] >= 0 ? in.slot((uint32_t)in.pend_pos[k]) : dump;
+        b[0] = in.pend[k].x; b[kWave] = in.pend[k].y; b[2 * kWave] = in.pend[k].z; b[3 * kWave] = in.pend[k].w;
+    }
+}
+template <int AHEAD, class R>
+__device__ __forceinline__ void ring_request(R& in) {
+    const uint32_t top = in.rd + in.shift;
+    const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
+#pragma unroll
+    for (int k = 0; k < kRaggedChunks; ++k) {
+        if (in.lo_issued > want_lo) {
+            in.lo_issued -= 4;
+            in.pend_pos[k] = (int32_t)in.lo_issued;
+            in.pend[k] = *reinterpret_cast<const uint4*>(in.base16 + in.lo_issued);
+        } else {
+            in.pend_pos[k] = -1;
+        }
+    }
+}
+
 constexpr int kRaggedDecSlots = 32, kRaggedDecAhead = 24;      // 8 KiB of ring per wave: two workgroups per CU next to 42 KiB of tables
-constexpr size_t kRaggedDecRingBytes = (size_t)(kBlock / kWave) * kRaggedDecSlots * kWave * 4;
+constexpr size_t kRaggedDumpBytes = (size_t)(kBlock / kWave) * 4 * kWave * 4;          // per lane four words nobody reads
+constexpr size_t kRaggedDecRingBytes = (size_t)(kBlock / kWave) * kRaggedDecSlots * kWave * 4 + kRaggedDumpBytes;
 template <int W, int S, bool STAGED, bool FAST>
 struct RaggedDecoder {
     DecLut lut{};
@@ -152,6 +183,7 @@ struct RaggedDecoder {
     bool active;
     size_t s, slot;
     int lane;
+    uint32_t* dump;
 
     // every thread of the workgroup: the tables (the only barriers)
     __device__ __forceinline__ void stage(const RaggedArgs& a, unsigned char* smem) {
@@ -174,6 +206,8 @@ struct RaggedDecoder {
         L.in.prime();
         wave_lds_fence();
     }
+    __device__ __forceinline__ void land() { ring_land_all(L.in, dump); }
+    __device__ __forceinline__ void request() { ring_request<kRaggedDecAhead>(L.in); }
     __device__ __forceinline__ uint32_t step(const RaggedArgs& a) {
         return ans_decode_step<W, S, kDecBucket, FAST>(L, lut, cdf, bucket, a.precision - a.bucket_bits, a.n_symbols, a.precision);
     }
@@ -187,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_ragged_kernel(const RaggedA
     D.stage(a, smem);
     if (!D.wave_has_streams(a)) return;
     D.start(a, reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave));
+    D.dump = reinterpret_cast<uint32_t*>(smem + kRaggedDecRingBytes - kRaggedDumpBytes) + (threadIdx.x >> 6) * (4 * kWave) + D.lane;
     const uint64_t sym_lo = D.active ? a.sym_offsets[D.s] : 0, sym_hi = D.active ? a.sym_offsets[D.s + 1] : 0;
     const bool too_long = sym_hi - sym_lo > 0xffffffffull || sym_hi < sym_lo;
     const uint32_t len = too_long ? 0u : (uint32_t)(sym_hi - sym_lo);
@@ -210,9 +245,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_ragged_kernel(const RaggedA
         }
     };
     for (uint32_t k0 = 0; k0 < mx; k0 += kRaggedGroup) {
-        D.L.in.land_pending();              // the chunks requested a group ago (a group consumes at most 8 of the >= 12 words landed below it)
+        D.land();                           // the chunks requested a group ago (a group consumes at most 8 of the >= 12 words landed below it)
         store_group(k0);
-        D.L.in.advance_window();            // (nothing pending: requests only)
+        D.request();
 #pragma unroll
         for (int j = 0; j < kRaggedGroup; ++j)
             if (k0 + (uint32_t)j < len) o[j] = a.min_symbol + (int32_t)D.step(a);
@@ -233,11 +268,13 @@ __global__ __launch_bounds__(kBlock) void ans_count_until_kernel(const RaggedArg
     D.stage(a, smem);
     if (!D.wave_has_streams(a)) return;
     D.start(a, reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * (kRaggedDecSlots * kWave));
+    D.dump = reinterpret_cast<uint32_t*>(smem + kRaggedDecRingBytes - kRaggedDumpBytes) + (threadIdx.x >> 6) * (4 * kWave) + D.lane;
     uint64_t n = 0;
     bool done = !D.active || D.ws.bad || D.L.status != CST_STREAM_OK || max_symbols == 0;
     bool found = false;
     while (__any(!done)) {
-        D.L.in.advance_window();            // lands what the previous group requested, requests for this one
+        D.land();                           // what the previous group requested
+        D.request();
 #pragma unroll
         for (int j = 0; j < kRaggedGroup; ++j) {
             if (!done) {

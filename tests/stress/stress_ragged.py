@@ -30,7 +30,10 @@ while time.time() < t_end:
         eof = lo + int(np.argmin(p))
         docs = [np.concatenate([d[d != eof], [eof]]).astype(np.int32) for d in docs]
     flat, offsets = B.ragged(docs)
-    enc = B.ans_encode_ragged(flat, offsets, model, (W, S, P))
+    # a third of the cases with a schedule (lane slot i codes stream order[i]): sorted by length, or a random permutation
+    r = rng.random()
+    order = None if r < 0.67 else ("sorted" if r < 0.84 else torch.from_numpy(rng.permutation(n_docs).astype(np.int32)).cuda())
+    enc = B.ans_encode_ragged(flat, offsets, model, (W, S, P), order=order)
     torch.cuda.synchronize()
     assert int(enc.status.abs().sum()) == 0
     n_words = enc.n_words.cpu().numpy()
