@@ -11,8 +11,11 @@
  *   - lazy categorical: src/stream/model/categorical/lazy_contiguous.rs:228-331 is restated line by line and pinned by
  *     the reference's own vectors (tests/python/test_lazy_f32.py, test_lazy_f64.py -> tests/golden/lazy_vectors.json).
  *   - perfect categorical: src/stream/model/categorical.rs:56-177 restated; `log1p` is the reference's EXPLICIT
- *     dependency `libm::log1p` (libm 0.2.16, Cargo.lock; == musl log1p.c), restated below.  The reference holds no
- *     compressed vector for a perfect table: "parity unpinned" beyond this restatement.
+ *     dependency `libm::log1p` (libm 0.2.16, Cargo.lock; == musl log1p.c), restated below.  Pinned (round 4) by the
+ *     known answers of the reference's own unit tests (contiguous.rs:709-731 the 37-entry fixed point at P = 32,
+ *     :735-833 KL(perfect) < KL(fast) for f64 and f32 inputs, :836-873 the issue-#20 inputs): tests/golden/
+ *     perfect_categorical.json, tests/test_model_families_cpu.py::test_perfect_quantisation_reference_known_answers.
+ *     The reference holds no COMPRESSED vector coded with a perfect table.
  *   - Laplace / Cauchy / Binomial: the distributions live in the un-vendored crate probability 0.20.3 (-> special
  *     0.10.3 -> libm 0.2.16); its published formulas are restated (Laplace::distribution, Cauchy::distribution,
  *     Binomial::distribution = regularised incomplete beta by Algorithm AS 63 + ln_beta from libm::lgamma_r).  The

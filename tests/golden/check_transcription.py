@@ -57,7 +57,31 @@ def main():
                 print(f"MISMATCH {vec['id']}: none of {variants} found in {vec['source']}")
                 bad += 1
     print(f"checked {len(data['vectors'])} vectors, {bad} mismatches")
+    bad += check_perfect()
     return 1 if bad else 0
+
+
+def check_perfect():
+    """perfect_categorical.json: every number of every histogram / probability list must occur, in order, in the cited lines"""
+    data = json.loads((HERE / "perfect_categorical.json").read_text())
+    bad = 0
+    for vec in data["vectors"]:
+        path, _, lines = vec["source"].partition(":")
+        lo, _, hi = lines.partition("-")
+        src = (REF / path).read_text().splitlines()
+        window = " ".join(src[int(lo) - 1: int(hi)])
+        numbers = re.findall(r"\d+\.\d+e-?\d+|\d+\.\d+|\d+", window.replace("u32", ""))
+        if "hist" in vec:
+            want = [str(v) for v in vec["hist"]]
+        else:
+            want = [float(v) for v in vec["probs"]]
+            numbers = [float(t) for t in numbers]
+        it = iter(numbers)
+        if not all(any(w == t for t in it) for w in want):
+            print(f"MISMATCH {vec['id']}: values not found in order in {vec['source']}")
+            bad += 1
+    print(f"checked {len(data['vectors'])} perfect-quantisation vectors, {bad} mismatches")
+    return bad
 
 
 if __name__ == "__main__":

@@ -168,3 +168,69 @@ def test_family_cdf_formulas():
     # the leak keeps every symbol at >= 1 unit even 10^6 scales out in the tail
     far = O.leaky_family_cdf(O.FAMILY_LAPLACE, 0, 1 << 16, 0.0, 1e-3).astype(np.int64)
     assert (np.diff(far) >= 1).all() and far[-1] == 1 << 24
+
+
+# ---- the reference's own known answers for `perfectly_quantized_probabilities` (tests/golden/perfect_categorical.json) ----
+def _perfect_vectors():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).parent / "golden" / "perfect_categorical.json").read_text())["vectors"]
+
+
+def _weights(cdf, P):
+    """symbol_table()'s probabilities: differences of the cumulatives, the last one against 2^P (which wraps to 0 in a
+    u32 at P = 32, contiguous.rs:301-313)"""
+    c = cdf.astype(np.int64).copy()
+    c[-1] = 1 << P
+    return np.diff(c)
+
+
+def _verify_iterable_entropy_model(weights, hist, P, tol):
+    """src/stream/model.rs:1016-1060 in numpy: the weights sum to 2^P, none is zero, sorting by weight is compatible with
+    sorting by the histogram, and the KL divergence (model.rs:689-708, f64) is below `tol`; returns the KL divergence"""
+    hist = np.asarray(hist, dtype=np.float64)
+    assert len(weights) == len(hist) and int(weights.sum()) == 1 << P and (weights > 0).all()
+    order = np.lexsort((hist, weights))              # sort_unstable_by on (weight, hist) pairs
+    assert (np.diff(hist[order]) >= 0).all()
+    p = hist / hist.sum()
+    nz = p > 0
+    kl = float(np.sum(p[nz] * (np.log2(p[nz]) - np.log2(weights[nz].astype(np.float64)))) + P)
+    assert kl < tol, kl
+    return kl
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+@pytest.mark.parametrize("vec", _perfect_vectors(), ids=lambda v: v["id"])
+def test_perfect_quantisation_reference_known_answers(vec, impl):
+    """contiguous.rs:709-731 (a 37-entry histogram that already sums to 2^32 comes back unchanged), :735-833 (the perfect
+    quantisation has a smaller KL divergence than the fast one, f64 and f32 inputs, P = 32 and the default 24), :836-873
+    (the two inputs of issue #20 converge) -- through the oracle AND through the library's host function."""
+    dtype = np.float32 if vec["dtype"] == "f32" else np.float64
+
+    def perfect(p, P):
+        if impl == "oracle":
+            return O.categorical_perfect_cdf(p, P)
+        rc, out = _product_perfect(p, P)             # F: Into<f64>: the f32 values, widened
+        assert rc == 0
+        return out
+
+    if vec["expect"] == "weights_equal_hist":
+        hist = np.array(vec["hist"], dtype=np.uint64)
+        assert int(hist.sum()) == 1 << 32
+        cdf = perfect(hist.astype(dtype), vec["precision"])
+        assert _weights(cdf, vec["precision"]).tolist() == hist.tolist()
+    elif vec["expect"] == "kl_perfect_below_kl_fast":
+        hist = np.array(vec["hist"], dtype=np.uint64)
+        assert int(hist.sum()) != 1 << 32
+        probs = hist.astype(dtype)
+        for P in vec["precisions"]:
+            kl_fast = _verify_iterable_entropy_model(_weights(O.categorical_fast_cdf(probs, P), P), hist, P, vec["kl_tolerance"])
+            kl_perfect = _verify_iterable_entropy_model(_weights(perfect(probs, P), P), hist, P, vec["kl_tolerance"])
+            assert kl_perfect < kl_fast, (P, kl_perfect, kl_fast)
+    else:
+        probs = np.array(vec["probs"], dtype=dtype)
+        P = vec["precision"]
+        w = _weights(perfect(probs, P), P)
+        if vec["expect"].endswith("within_1"):
+            assert -1 <= int(w[0]) - int(w[2]) <= 1
+        _verify_iterable_entropy_model(w, probs, P, vec["kl_tolerance"])
