@@ -7,8 +7,10 @@
 //                               their final positions on the root (every peer uses its own xGMI link to the root), then
 //                               one small kernel on the root turns local offsets into global ones;
 //   (3) cst_scatter_rccl      : the inverse, for decoding on the ranks what one rank holds.
-// librccl is opened at first use (dlopen "librccl.so.1"): the coder library itself has no link-time dependency on it.
+// librccl is opened at first use (dlopen "librccl.so.1", or the path in CST_RCCL_LIB): the coder library itself has no
+// link-time dependency on it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -33,9 +35,18 @@ static const RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return;
+        // CST_RCCL_LIB names the library to open instead (a site's own RCCL build; the test double of
+        // tests/rccl_double/, which lets 2-3 processes on ONE GPU run the exchange: real RCCL refuses duplicate devices)
+        const char* override_path = getenv("CST_RCCL_LIB");
+        void* h = nullptr;
+        if (override_path && *override_path) {
+            h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+            if (!h) return;                       // a named library that does not load is an error, not a reason to fall back
+        } else {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return;
+        }
 #define CST_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name))
         CST_SYM(GetUniqueId, "ncclGetUniqueId"); CST_SYM(CommInitRank, "ncclCommInitRank"); CST_SYM(CommDestroy, "ncclCommDestroy");
         CST_SYM(AllGather, "ncclAllGather"); CST_SYM(Send, "ncclSend"); CST_SYM(Recv, "ncclRecv");
