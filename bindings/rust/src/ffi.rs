@@ -1,0 +1,882 @@
+//! Raw `extern "C"` declarations of libconstriction_amd.so -- GENERATED from include/constriction_amd.h by
+//! scripts/gen_rust_ffi.py; do not edit.  One declaration per entry point of the header, in header order, with the
+//! header's comments (which cite the reference interface each call replaces).  C enums are `i32` aliases with
+//! constants: a value the library adds later must not be undefined behaviour on the Rust side.
+#![allow(non_camel_case_types, dead_code, clippy::too_many_arguments)]
+use core::ffi::{c_char, c_void};
+
+pub const CST_ABI_VERSION: i32 = 3;
+
+/// `cst_status`
+pub type CstStatus = i32;
+pub const CST_OK: CstStatus = 0;
+pub const CST_ERR_INVALID_ARGUMENT: CstStatus = -1;
+pub const CST_ERR_HIP: CstStatus = -2;
+pub const CST_ERR_NO_DEVICE: CstStatus = -3;
+pub const CST_ERR_MODEL: CstStatus = -4;
+pub const CST_ERR_OUT_OF_MEMORY: CstStatus = -5;
+
+/// `cst_stream_status`
+pub type CstStreamStatus = i32;
+pub const CST_STREAM_OK: CstStreamStatus = 0;
+pub const CST_STREAM_IMPOSSIBLE_SYMBOL: CstStreamStatus = 1;
+pub const CST_STREAM_CAPACITY: CstStreamStatus = 2;
+pub const CST_STREAM_INVALID_DATA: CstStreamStatus = 3;
+pub const CST_STREAM_OUT_OF_DATA: CstStreamStatus = 4;
+
+/// `cst_layout`
+pub type CstLayout = i32;
+pub const CST_LAYOUT_STREAM_MAJOR: CstLayout = 0;
+pub const CST_LAYOUT_SYMBOL_MAJOR: CstLayout = 1;
+
+/// `cst_family`
+pub type CstFamily = i32;
+pub const CST_FAMILY_LAPLACE: CstFamily = 1;
+pub const CST_FAMILY_CAUCHY: CstFamily = 2;
+pub const CST_FAMILY_BINOMIAL: CstFamily = 3;
+
+pub const CST_FLAG_NONE: u32 = 0;
+pub const CST_FLAG_RAW_STATE: u32 = 1;
+
+/// `cst_model`: opaque, device-resident model image
+#[repr(C)]
+pub struct CstModel {
+    _private: [u8; 0],
+}
+
+/// `cst_coder_config`
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct CstCoderConfig {
+    pub word_bits: i32,
+    pub state_bits: i32,
+    pub precision: i32,
+}
+
+/// `cst_range_state`
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct CstRangeState {
+    pub lower: u64,
+    pub range: u64,
+    pub point: u64,
+    pub inverted_n: u32,
+    pub inverted_first: u32,
+    pub position: u64,
+}
+
+/// `cst_chain_heads`
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct CstChainHeads {
+    pub remainders_head: u64,
+    pub compressed_head: u32,
+    pub reserved: u32,
+}
+
+#[link(name = "constriction_amd")]
+extern "C" {
+    /// ABI version of the loaded library (== CST_ABI_VERSION of the header it was built from).
+    pub fn cst_abi_version() -> i32;
+
+    /// Number of visible gfx950 devices, or a negative cst_status.
+    pub fn cst_device_count() -> i32;
+
+    /// Text of the most recent HIP error seen by the calling thread ("" if none).
+    pub fn cst_last_hip_error() -> *const c_char;
+
+    /// Upper bound on the words one stream can produce, min(n, ceil(n*P/W)) + S/W, rounded up to a whole number of
+    /// 64-byte units so that slabs laid out at this stride from a 64-byte aligned base are all 64-byte aligned (the
+    /// encoder then writes whole aligned 64-byte groups).  Any other stride remains legal.
+    /// (At most one word per symbol: src/stream/stack.rs:1035-1040; final state: stack.rs:891-895.)
+    pub fn cst_ans_max_words(n_symbols: usize, cfg: CstCoderConfig) -> usize;
+
+    /// Same bound for the range coder: one word per symbol (queue.rs:671-702) + seal words (queue.rs:498-522), rounded
+    /// up to 64-byte units in the same way (the hand-scheduled encoder needs 64-byte aligned slabs).
+    pub fn cst_range_max_words(n_symbols: usize, cfg: CstCoderConfig) -> usize;
+
+    /// One table shared by all streams, from a host cdf[n_symbols+1] (any tabulated model: the
+    /// "fast" categorical tables of src/stream/model/categorical.rs:16-54, a LeakyQuantizer table, ...).
+    pub fn cst_model_create_table(
+        precision: i32,
+        min_symbol: i32,
+        n_symbols: i32,
+        h_cdf: *const u32,
+        out: *mut *mut CstModel,
+    ) -> CstStatus;
+
+    /// One shared table = LeakyQuantizer<f64,i32,u{prob_bits},P>(min..=max) x Gaussian(mean,std),
+    /// i.e. constriction.stream.model.QuantizedGaussian(min, max, mean, std)
+    /// (src/stream/model/quantize.rs:284-308, 525-568; src/pybindings/stream/model.rs:649-660).
+    /// The table is computed ON DEVICE in bit-exact f64.  prob_bits = 32 for W=32, 16 for W=16.
+    pub fn cst_model_create_gaussian(
+        precision: i32,
+        min_symbol: i32,
+        max_symbol: i32,
+        mean: f64,
+        std: f64,
+        stream: *mut c_void,
+        out: *mut *mut CstModel,
+    ) -> CstStatus;
+
+    /// One table PER STREAM (BASELINE config C3): stream s uses Gaussian(d_means[s], d_stds[s]).
+    /// d_means/d_stds are device arrays of n_streams doubles.  Per-stream tables are coded from LDS: precision <= 16 and
+    /// a support of at most 1023 symbols (larger ones make the coding calls return CST_ERR_INVALID_ARGUMENT; shared
+    /// tables have no such limit).
+    pub fn cst_model_create_gaussian_per_stream(
+        precision: i32,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n_streams: usize,
+        stream: *mut c_void,
+        out: *mut *mut CstModel,
+    ) -> CstStatus;
+
+    /// A tabulated model over an ARBITRARY alphabet of distinct i32 symbols (NonContiguousCategoricalEncoderModel /
+    /// NonContiguousLookupDecoderModel, src/stream/model/categorical/{non_contiguous,lookup_noncontiguous}.rs:429-470, 602-646):
+    /// h_symbols[i] is the symbol with left cumulative h_cdf[i].  The model proper works on the indices 0..n-1; the two
+    /// kernels below translate (in place if wanted): encode = cst_symbols_to_indices + cst_ans_encode_batch (a symbol that is
+    /// not in the alphabet becomes index n, which the coder reports as CST_STREAM_IMPOSSIBLE_SYMBOL), decode =
+    /// cst_ans_decode_batch + cst_indices_to_symbols.
+    pub fn cst_model_create_table_noncontiguous(
+        precision: i32,
+        n_symbols: i32,
+        h_symbols: *const i32,
+        h_cdf: *const u32,
+        out: *mut *mut CstModel,
+    ) -> CstStatus;
+
+    pub fn cst_symbols_to_indices(
+        model: *const CstModel,
+        d_symbols: *const i32,
+        count: usize,
+        d_indices: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_indices_to_symbols(
+        model: *const CstModel,
+        d_indices: *const i32,
+        count: usize,
+        d_symbols: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_model_destroy(model: *mut CstModel) -> CstStatus;
+
+    /// Introspection (tests, and get_cdf for host-side tooling).
+    pub fn cst_model_precision(model: *const CstModel) -> i32;
+
+    pub fn cst_model_min_symbol(model: *const CstModel) -> i32;
+
+    pub fn cst_model_n_symbols(model: *const CstModel) -> i32;
+
+    pub fn cst_model_n_tables(model: *const CstModel) -> usize;
+
+    /// Copies table `index`'s cdf[n_symbols+1] to host (synchronises `stream`).
+    pub fn cst_model_get_cdf(model: *const CstModel, index: usize, h_cdf: *mut u32, stream: *mut c_void) -> CstStatus;
+
+    /// Copies the cdfs of tables [first, first + count) -- (n_symbols + 1) entries each, back to back -- into DEVICE memory,
+    /// asynchronously on `stream` (e.g. to draw test symbols from per-stream models without a host round trip).
+    pub fn cst_model_copy_cdfs(
+        model: *const CstModel,
+        first: usize,
+        count: usize,
+        d_cdfs: *mut u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// LeakyQuantizer<f64,i32,u32,P>(min..=max) x family(a[row], b[row]) tabulated on the device, one row of
+    /// (max - min + 2) left cumulatives per parameter pair (src/stream/model/quantize.rs:284-308, 525-568 over the
+    /// `probability` crate's Laplace / Cauchy / Binomial CDFs, evaluated with the libm-crate algorithms in bit-exact f64).
+    /// Laplace: a = mean, b = scale.  Cauchy: a = loc, b = scale.  Binomial: a = p, d_b unused (may be NULL), min_symbol
+    /// must be 0 and max_symbol = n; with d_n_per_row != NULL row r is the model over 0..=d_n_per_row[r] (<= max_symbol)
+    /// and entries past its own 2^P repeat 2^P (the family form `Binomial()` with per-symbol n).  d_bad (optional, one
+    /// int32 per row) is set to 1 where a row is not strictly increasing, i.e. where the reference panics
+    /// (quantize.rs:560-566).  The rows feed cst_model_create_table / the *_rows_batch / *_cp_batch entry points.
+    pub fn cst_family_cdf_rows(
+        family: i32,
+        precision: i32,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_a: *const f64,
+        d_b: *const f64,
+        d_n_per_row: *const i32,
+        n_rows: usize,
+        d_rows: *mut u32,
+        d_bad: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Categorical(probabilities, perfect=True): `perfectly_quantized_probabilities` + cumulation
+    /// (src/stream/model/categorical.rs:56-177, contiguous.rs:301-313) for Probability = u32.  HOST function (a sequential
+    /// greedy search); h_probs are f64 (f32 inputs widened by the caller, as `F: Into<f64>` does); writes h_cdf[n + 1].
+    /// CST_ERR_MODEL where the reference returns Err (n < 2, negative / non-normalisable probabilities).
+    pub fn cst_categorical_perfect_cdf(h_probs: *const f64, n: usize, precision: i32, h_cdf: *mut u32) -> CstStatus;
+
+    /// test hooks: the elementary functions behind the two calls above as the device evaluates them
+    /// (which: 0 log, 1 log1p, 2 atan, 3 lgamma for x > 0, 4 exp), and the host's log1p
+    pub fn cst_debug_family_fn(
+        which: i32,
+        d_x: *const f64,
+        d_out: *mut f64,
+        n: usize,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_debug_host_log1p(x: f64) -> f64;
+
+    /// Replaces, for every stream s in [0, n_streams):
+    ///     let mut coder = AnsCoder::new();                             src/stream/stack.rs:249
+    ///     coder.encode_iid_symbols_reverse(symbols[s], &model)?;       src/stream/stack.rs:835-849
+    ///     out[s] = coder.into_compressed();                            src/stream/stack.rs:891-895
+    /// (Python: AnsCoder().encode_reverse(symbols, model); get_compressed(),
+    ///  src/pybindings/stream/stack.rs:529-591, 411-429.)
+    ///
+    /// d_symbols   int32 [n_streams][n_per_stream] (or transposed, see layout)
+    /// d_words     uint32 slabs: stream s writes d_words[s*stride_words ...], in emission order
+    /// d_n_words   out: words written per stream
+    /// d_state     uint64 [n_streams] in/out, only with CST_FLAG_RAW_STATE (else may be NULL)
+    /// d_status    out: cst_stream_status per stream.  On IMPOSSIBLE_SYMBOL / CAPACITY the stream's
+    ///             n_words is 0 and its slab content is unspecified.
+    pub fn cst_ans_encode_batch(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_state: *mut u64,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Replaces, for every stream s:
+    ///     let mut coder = AnsCoder::from_compressed(words[s])?;        src/stream/stack.rs:299-318, 440-462
+    ///     symbols[s] = coder.decode_iid_symbols(n_per_stream, &model)  src/stream/mod.rs:1016-1031, stack.rs:1070-1100
+    /// (Python: AnsCoder(compressed).decode(model, n), src/pybindings/stream/stack.rs:217-241, 688-752.)
+    ///
+    /// The words of stream s are d_words[off(s) .. off(s) + d_n_words[s]) with
+    ///     off(s) = d_offsets ? d_offsets[s] : s * stride_words
+    /// so both the slab layout written by cst_ans_encode_batch and the packed layout written by
+    /// cst_compact_words decode without a copy.  Decoding past the end of a stream is legal and
+    /// deterministic, exactly as in the reference (stack.rs:1062-1065).
+    /// Memory safety on corrupt metadata (the reference's decoder pops from a Vec and cannot leave it, src/backends.rs:495-507):
+    /// `words_capacity` = the number of uint32 slots behind d_words.  A stream whose slice [off(s), off(s) + d_n_words[s])
+    /// leaves the buffer -- or, in slab form, whose d_n_words[s] exceeds stride_words (checked always) -- is decoded as an
+    /// EMPTY stream and reports CST_STREAM_INVALID_DATA; nothing outside the buffer is read.  words_capacity = 0 means
+    /// "unknown": the caller vouches for the packed offsets as in ABI 2.  (The kernels read whole aligned 16-byte chunks:
+    /// up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; a capacity that is
+    /// the true size of a hipMalloc'ed buffer satisfies this.)  Every decode entry point below takes the same argument.
+    /// The model must have been created on the current device (CST_ERR_INVALID_ARGUMENT otherwise).
+    /// With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
+    /// count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).
+    pub fn cst_ans_decode_batch(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_state: *mut u64,
+        d_n_words_out: *mut u32,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Streams of DIFFERENT lengths -- thousands of small coders with a shared model in one launch: the reference's "compressed
+    /// index" pattern (tests/issue52.rs:27-60, 63-80: one DefaultAnsCoder per document, `encode_symbol` per character last to
+    /// first, `into_compressed`; `from_compressed` + `decode_symbol` per document), which costs one device round trip per document
+    /// through the single-coder binding.
+    ///     symbols of stream s = d_symbols[d_sym_offsets[s] .. d_sym_offsets[s + 1])      (d_sym_offsets: uint64 [n_streams + 1])
+    ///     slab of stream s    = d_words[d_word_offsets[s] .. d_word_offsets[s + 1])      (uint64 [n_streams + 1]; a slab of
+    ///                           cst_ans_max_words(length of s, cfg) words always suffices), or, with d_word_offsets = NULL,
+    ///                           d_words[s * stride_words .. + stride_words)
+    /// Every stream's words, count and status are those of cst_ans_encode_batch / the reference coder for that stream alone; the
+    /// decoder takes the same offsets (only d_word_offsets[s] and d_n_words[s] are read) or a packed layout, with the bounds
+    /// check of cst_ans_decode_batch.  Shared-table models, stream-major symbols, any preset.  A wave of 64 consecutive streams
+    /// runs as long as its longest one.
+    pub fn cst_ans_encode_ragged(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        d_words: *mut u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_ragged(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The reference's index stores no lengths: a document ends where its terminator symbol is decoded
+    /// (tests/issue52.rs:63-80, `core::iter::from_fn(|| { let id = coder.decode_symbol(..); alphabet.get(id) })`).  This is
+    /// the first pass of that: every stream is decoded until `eof_symbol` appears, nothing is stored but the number of
+    /// symbols decoded, terminator included (d_lengths, uint64 [n_streams]); a stream without a terminator among its first
+    /// `max_symbols` symbols reports CST_STREAM_CAPACITY and max_symbols.  An exclusive prefix sum of d_lengths is the
+    /// d_sym_offsets of cst_ans_decode_ragged.
+    pub fn cst_ans_count_until(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        n_streams: usize,
+        eof_symbol: i32,
+        max_symbols: usize,
+        d_lengths: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The same three calls with a SCHEDULE: lane slot i of the launch codes stream d_order[i] (uint32 [n_streams], a permutation of
+    /// 0 .. n_streams - 1; NULL = the identity, i.e. the calls above).  A wave of 64 slots runs as long as its longest stream, so a
+    /// batch whose lengths differ by orders of magnitude should put streams of similar length side by side, longest first:
+    /// d_order = the stream indices sorted by length (or, for the decoders, by d_n_words) in descending order.  Results (words,
+    /// counts, symbols, status, all indexed by STREAM as above) do not depend on the order; an entry that is not a stream index
+    /// leaves its slot idle, a stream that no entry names is not coded.  1 000 000 documents of 20 .. 2000 symbols: encode
+    /// 2.0 -> 1.3 ms, decode 4.9 -> 1.4 ms (scripts/bench_ragged_big.py).
+    pub fn cst_ans_encode_ragged_ordered(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        d_order: *const u32,
+        d_words: *mut u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_ragged_ordered(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        d_order: *const u32,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_count_until_ordered(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        n_streams: usize,
+        d_order: *const u32,
+        eof_symbol: i32,
+        max_symbols: usize,
+        d_lengths: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Checkpointed streams -- the reference's Pos / Seek jump tables (src/stream/stack.rs:1107-1139; test :1456-1548) for the
+    /// batched coder.  The encoder notes, in front of every chunk of `ckpt_interval` symbols, what `AnsCoder::pos()` returns
+    /// there: d_ckpt_pos[s][j] = words in the bulk, d_ckpt_state[s][j] = coder state once symbols [j * interval, n) are
+    /// encoded (n_chunks = ceil(n_per_stream / interval) entries per stream).  The compressed words are exactly those of
+    /// cst_ans_encode_batch.  The decoder then treats every (stream, chunk) as an independent coder --
+    /// `AnsCoder::seek(pos, state)` + interval decoded symbols -- so that ONE long stream (BASELINE config C1) spreads over
+    /// n_chunks lanes: it is the ordinary batched decode of n_streams * n_chunks virtual streams (stream-major symbols,
+    /// shared-table models, n_per_stream a multiple of the interval; d_status has n_streams * n_chunks entries;
+    /// d_scratch: cst_ckpt_scratch_bytes(...) bytes, contents irrelevant).
+    pub fn cst_ans_encode_batch_ckpt(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_state: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ckpt_scratch_bytes(n_streams: usize, n_per_stream: usize, ckpt_interval: usize) -> usize;
+
+    pub fn cst_ans_decode_batch_ckpt(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        ckpt_interval: usize,
+        d_ckpt_pos: *const u32,
+        d_ckpt_state: *const u64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
+    /// concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled
+    /// look-back, fused with the copy), fully asynchronous on `stream`: no host synchronisation, no allocation.
+    ///   d_offsets        out: offsets[s] = first word of stream s in the packed buffer; offsets[n_streams] = total words
+    ///   d_packed         may be NULL to compute the offsets only
+    ///   packed_capacity  words available at d_packed (an upper bound such as n_streams * stride_words always suffices);
+    ///                    a stream that would end beyond it is not copied -- the caller sees offsets[n_streams] > capacity
+    ///   d_scratch        cst_compact_scratch_bytes(n_streams) bytes of device memory, contents irrelevant on entry
+    /// (The reference has no counterpart: its coders each own a Vec<u32>; this is the container layout of
+    ///  src/pybindings/stream/stack.rs:149-166 -- little-endian u32 words, one offset per message.)
+    pub fn cst_compact_scratch_bytes(n_streams: usize) -> usize;
+
+    pub fn cst_compact_words(
+        d_words: *const u32,
+        stride_words: usize,
+        d_n_words: *const u32,
+        n_streams: usize,
+        d_offsets: *mut u64,
+        d_packed: *mut u32,
+        packed_capacity: usize,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// multi-GPU: gather of the packed compressed words of every rank to one root over RCCL / xGMI (BASELINE config C5).
+    /// One process per GPU; streams shard in contiguous blocks and no collective touches the coding path; this is the only
+    /// exchange step.  The library opens librccl at first use (no link-time dependency); `comm` is an ncclComm_t -- the
+    /// caller's own, or one made with the two helpers below from an id that rank 0 creates and the caller's launcher
+    /// distributes (128 bytes).  (No reference counterpart: its coders are single-threaded host objects.)
+    pub fn cst_rccl_get_unique_id(h_id: *mut c_void) -> CstStatus;
+
+    pub fn cst_rccl_comm_init(h_id: *const c_void, n_ranks: i32, rank: i32, out_comm: *mut *mut c_void) -> CstStatus;
+
+    /// on the current device
+    pub fn cst_rccl_comm_destroy(comm: *mut c_void) -> CstStatus;
+
+    /// Step 1 (every rank, asynchronous on `stream`): d_sizes[2 * n_ranks] (device, uint64) receives (n_streams, total_words)
+    /// of every rank, in rank order; d_offsets is the rank's own offsets[n_streams_local + 1] from cst_compact_words.
+    pub fn cst_gather_sizes_rccl(
+        comm: *mut c_void,
+        n_ranks: i32,
+        rank: i32,
+        d_offsets: *const u64,
+        n_streams_local: usize,
+        d_sizes: *mut u64,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Step 2 (every rank): h_sizes = host copy of d_sizes.  Root: d_all_packed (capacity >= sum of words) receives the packed
+    /// words of all ranks in rank order, d_all_offsets[sum of streams + 1] their global offsets; other ranks pass NULL for
+    /// both.  Grouped point-to-point transfers straight into their final positions, asynchronous on `stream` on every
+    /// rank.  A failing transfer never leaves an RCCL group open: the group is closed first, then the error is returned.
+    pub fn cst_gather_rccl(
+        comm: *mut c_void,
+        n_ranks: i32,
+        rank: i32,
+        root: i32,
+        d_packed: *const u32,
+        d_offsets: *const u64,
+        h_sizes: *const u64,
+        d_all_packed: *mut u32,
+        d_all_offsets: *mut u64,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The inverse (decoding on the ranks what one rank holds): the root passes the packed words of all ranks'
+    /// streams in rank order and their global offsets[sum of streams + 1] (NULL on the other ranks); every rank receives its
+    /// own words in d_packed (capacity >= h_sizes[2 * rank + 1]) and d_offsets[n_streams_local + 1] rebased to start at 0 --
+    /// what the `d_offsets` form of cst_ans_decode_batch / cst_range_decode_batch takes.  h_sizes as above, on every rank.
+    pub fn cst_scatter_rccl(
+        comm: *mut c_void,
+        n_ranks: i32,
+        rank: i32,
+        root: i32,
+        d_all_packed: *const u32,
+        d_all_offsets: *const u64,
+        h_sizes: *const u64,
+        d_packed: *mut u32,
+        d_offsets: *mut u64,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// per-symbol quantized Gaussians: the reference's flagship Python call
+    ///     coder.encode_reverse(symbols, QuantizedGaussian(min, max), means, stds)
+    ///     coder.decode(QuantizedGaussian(min, max), means, stds)
+    /// (src/pybindings/stream/stack.rs:567-588, 733-751; src/pybindings/stream/model/internals.rs:188-249)
+    /// d_means / d_stds have the same shape and layout as d_symbols (f64; f32 callers widen first,
+    /// src/pybindings/mod.rs:211-216).  std <= 0 or a non-finite parameter yields
+    /// CST_STREAM_IMPOSSIBLE_SYMBOL for that stream (the reference panics: pybindings/stream/model.rs:654-657).
+    pub fn cst_ans_encode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_symbols: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_state: *mut u64,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_state: *mut u64,
+        d_n_words_out: *mut u32,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Per-symbol models given explicitly (any model family with per-symbol parameters, e.g.
+    /// Categorical(perfect=False) with a probability matrix, src/pybindings/stream/model/internals.rs:188-249):
+    ///   encode: d_left / d_prob hold EncoderModel::left_cumulative_and_probability of every symbol
+    ///           (same shape/layout as the symbol matrix; prob == 0 marks an impossible symbol);
+    ///   decode: d_cdf_rows holds one cdf[n_symbols+1] row per coded symbol, row index = element index of the
+    ///           symbol matrix (s*n_per_stream + t, or t*n_streams + s for CST_LAYOUT_SYMBOL_MAJOR).
+    pub fn cst_ans_encode_cp_batch(
+        cfg: CstCoderConfig,
+        d_left: *const u32,
+        d_prob: *const u32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_state: *mut u64,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_rows_batch(
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_cdf_rows: *const u32,
+        n_symbols: i32,
+        min_symbol: i32,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_state: *mut u64,
+        d_n_words_out: *mut u32,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// d_rstate (may be NULL unless CST_FLAG_RAW_STATE) is in/out with CST_FLAG_RAW_STATE: the encoder then starts
+    /// from it and appends no seal words, the decoder does not re-read `point` and continues at ->position.
+    pub fn cst_range_encode_batch(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_decode_batch(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Per-symbol-model variants of the range coder (same argument meaning as the cst_ans_* twins).
+    pub fn cst_range_encode_cp_batch(
+        cfg: CstCoderConfig,
+        d_left: *const u32,
+        d_prob: *const u32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_encode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_symbols: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_decode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_decode_rows_batch(
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_cdf_rows: *const u32,
+        n_symbols: i32,
+        min_symbol: i32,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_chain_encode_cp_batch(
+        cfg: CstCoderConfig,
+        d_left: *const u32,
+        d_prob: *const u32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_pop_words: *const u32,
+        d_pop_offsets: *const u64,
+        pop_stride: usize,
+        d_n_pop: *mut u32,
+        d_push_words: *mut u32,
+        push_stride: usize,
+        d_n_push: *mut u32,
+        d_heads: *mut CstChainHeads,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_chain_encode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_symbols: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_pop_words: *const u32,
+        d_pop_offsets: *const u64,
+        pop_stride: usize,
+        d_n_pop: *mut u32,
+        d_push_words: *mut u32,
+        push_stride: usize,
+        d_n_push: *mut u32,
+        d_heads: *mut CstChainHeads,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_chain_decode_gaussian_batch(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_pop_words: *const u32,
+        d_pop_offsets: *const u64,
+        pop_stride: usize,
+        d_n_pop: *mut u32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_push_words: *mut u32,
+        push_stride: usize,
+        d_n_push: *mut u32,
+        d_heads: *mut CstChainHeads,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// explicit cdf rows [n_symbols + 1] per coded symbol; row_stride = n_symbols + 1, or 0 for ONE row shared by every
+    /// symbol (a concrete model: decode_iid_symbols)
+    pub fn cst_chain_decode_rows_batch(
+        cfg: CstCoderConfig,
+        d_pop_words: *const u32,
+        d_pop_offsets: *const u64,
+        pop_stride: usize,
+        d_n_pop: *mut u32,
+        d_cdf_rows: *const u32,
+        row_stride: usize,
+        n_symbols: i32,
+        min_symbol: i32,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_push_words: *mut u32,
+        push_stride: usize,
+        d_n_push: *mut u32,
+        d_heads: *mut CstChainHeads,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The per-symbol entry points above take their scratch (16 B per symbol for encoding; 1 KiB per symbol of cdf rows, at
+    /// most 64 MiB at a time, for decoding fewer than 64 streams) from a stream-ordered memory pool that the LIBRARY owns (one
+    /// per device, created at first use; the device's default pool is never touched) and that keeps freed memory
+    /// (re-allocating 4 GiB per call cost more than coding them).  This hands it back: synchronises the device and trims the
+    /// library's pool.
+    pub fn cst_release_scratch() -> CstStatus;
+
+    /// bit-exact f64 special functions on device (test hooks for the model kernels)
+    /// out[i] = erf(x[i]) resp. Gaussian cdf, evaluated by the same device code the table kernels use.
+    pub fn cst_debug_erf(d_x: *const f64, d_out: *mut f64, n: usize, stream: *mut c_void) -> CstStatus;
+
+    /// the same erf as the per-symbol kernels evaluate it (one Horner recurrence over per-lane coefficients from LDS)
+    pub fn cst_debug_erf_tab(d_x: *const f64, d_out: *mut f64, n: usize, stream: *mut c_void) -> CstStatus;
+
+    /// The per-symbol kernels evaluate the Gaussian left cumulative through a FAST erf and fall back to the bit-exact one
+    /// wherever free_weight * cdf lies so close to an integer that the difference could change the truncation (cst_math.hpp);
+    /// the integer is the reference's in every case.  Hooks: which = 0: out[i] = fast erf(x[i]); 1: |fast - exact|.
+    pub fn cst_debug_erf_fast(which: i32, d_x: *const f64, d_out: *mut f64, n: usize, stream: *mut c_void) -> CstStatus;
+
+    /// left cumulative of symbol index d_index[i] (0 .. n_symbols) under Gaussian(d_means[i], d_stds[i]) both ways:
+    /// d_counts[0] += results that differ (must stay 0), d_counts[1] += exact fallbacks taken (caller zeroes d_counts).
+    pub fn cst_debug_gaussian_left_quick(
+        precision: i32,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_index: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n: usize,
+        d_counts: *mut u64,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_debug_gaussian_lcp(
+        precision: i32,
+        prob_bits: i32,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_symbols: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        d_left: *mut u32,
+        d_prob: *mut u32,
+        n: usize,
+        stream: *mut c_void,
+    ) -> CstStatus;
+}
