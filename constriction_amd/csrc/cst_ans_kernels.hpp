@@ -1340,6 +1340,9 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
 }
 
 // small-footprint kernels for batches of more than one wave per SIMD (cst_ans_small.hip)
+// producer / consumer waves for batches of at most one wave of streams per SIMD (cst_ans_pc.hip)
+bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
+cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs);
 bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 bool small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_small(const AnsEncodeArgs& a, hipStream_t hs);

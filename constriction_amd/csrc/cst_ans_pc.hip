@@ -1,0 +1,141 @@
+// cst_ans_pc.hip -- the shared-table ANS encoder (W,S) = (32,64), 8 <= P <= 12, as PRODUCER and CONSUMER waves (round 4).
+//
+// 65 536 streams (BASELINE config C2) are one wave per SIMD, and a lone wave issues one instruction per ~4.4 cycles whatever
+// the instruction is.  In ans_encode_kernel (cst_ans_kernels.hpp) the coder chain's wave also stages the symbol tiles
+// (8 x ds_write_b128 per tile: 36 cycles each from one wave), reads complete word groups back from its ring, stores them and
+// requests the next tiles: a quarter of the kernel, all of it issue and LDS-store time of that one wave and none of it memory
+// time (scripts/ablate_encoder.sh: 0.228 ms without the tile work, 0.275 ms with it, whatever the stores look like).  Here a
+// workgroup is EIGHT waves for 256 streams: waves 0-3 (one per SIMD) run nothing but the coder steps -- the generated statement
+// cst_encode_loop_pc.inc -- and waves 4-7, their partners on the same SIMDs, do everything else in plain C++:
+//     helper, per tile:  next tile's symbols registers -> LDS tile buffer (requested three tiles earlier), request a later one,
+//                        one complete 64-byte group below the write position the coder last published ring -> slab, s_barrier.
+//     coder, per tile:   32 steps, candidate words into the lane's 64-slot LDS ring as before; once per tile: publish the
+//                        write position, lgkmcnt(0), s_barrier.
+// The SIMD's VALU is what the two waves share (a VALU instruction of either occupies it for 4 cycles), so the helper is kept
+// nearly free of VALU work -- a dozen instructions per tile; its LDS, vector-memory and scalar instructions issue beside the
+// coder's VALU stream.
+// The barrier sits at the top of the coder's quad 1: every read of the current tile's row has returned (the helper may
+// overwrite that buffer with the tile after next) and the helper has finished the next tile (quads 1 and 0 read ahead into it).
+// Same recurrence (stack.rs:1014-1048), same slabs, same words, counts and status as ans_encode_kernel; shapes this kernel
+// does not take (partial workgroups, rows that are not whole cache-line aligned tiles, unaligned slabs, large alphabets) stay
+// where they were.
+#include <cstdlib>
+
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+constexpr int kPcThreads = 2 * kBlock;                                   // 4 coder waves + 4 helper waves
+constexpr int kPcWaves = kBlock / kWave;
+constexpr size_t kPcTableBytes = 16 * 1024;                              // the encoder table (<= 1024 symbols), in front of the 16-KiB aligned rings
+constexpr size_t kPcRingWaveBytes = (size_t)kRingSlots * kWave * 4;      // 64 slots [slot][lane]: 16 KiB, 16-KiB aligned
+constexpr size_t kPcTileBytes = (size_t)kWave * kTileStride * 4;         // 9 KiB per tile buffer
+constexpr size_t kPcHandWaveBytes = 4 * kWave * 4;                       // coder -> helper: write position (every tile); state (lo, hi), largest table index (at the end)
+constexpr size_t kPcRingOff = kPcTableBytes;
+constexpr size_t kPcTileOff = kPcRingOff + kPcWaves * kPcRingWaveBytes;
+constexpr size_t kPcHandOff = kPcTileOff + kPcWaves * 2 * kPcTileBytes;
+constexpr size_t kPcLdsBytes = kPcHandOff + kPcWaves * kPcHandWaveBytes;
+static_assert(kPcLdsBytes <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void ans_encode_pc_coder_loop(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, const uint32_t (&tile_row_addr)[2],
+                                                         uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_helper_loop(uint32_t& flushed, const uint32_t (&tile_tr_addr)[2], uint32_t ring_lane_addr,
+                                                          uint32_t publish_addr, uint32_t cap, uint32_t slab_off, const void* words_base,
+                                                          uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_pc_helper.inc"
+}
+
+// LDS hand-off between the two halves of a workgroup: this wave's LDS operations have completed, then the barrier.  (Not
+// __syncthreads(): its fence would also wait for the helper's symbol loads, which are requested tiles ahead on purpose.)
+__device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const bool helper = wave >= kPcWaves;
+    const int cw = wave & (kPcWaves - 1);               // coder wave `cw` and helper wave `cw + 4` share a SIMD and 64 streams
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t N = a.n_per_stream;
+    const uint32_t n_t = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms));
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
+    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = pack_entry(a.enc[i], P);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
+    int32_t* tile[2] = {reinterpret_cast<int32_t*>(smem + kPcTileOff + (2 * cw) * kPcTileBytes),
+                        reinterpret_cast<int32_t*>(smem + kPcTileOff + (2 * cw + 1) * kPcTileBytes)};
+    uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcHandOff + cw * kPcHandWaveBytes);
+
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave;      // (the launcher only takes whole workgroups)
+    const size_t s = s0 + lane;
+
+    if (!helper) {
+        uint32_t lo = 0, hi = 0;
+        int32_t smin = a.min_symbol, smax = a.min_symbol;
+        if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
+        const uint32_t row_addr[2] = {lds_addr(tile[0] + lane * kTileStride), lds_addr(tile[1] + lane * kTileStride)};
+        pc_barrier();                                   // table and the first tile are in LDS
+        ans_encode_pc_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane),
+                                 lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, n_t);
+        // largest raw table index seen: a symbol below min_symbol wraps to a huge one
+        hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
+        hand[3 * kWave + lane] = max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol);
+        pc_barrier();                                   // the last window and the final state are published
+        return;
+    }
+
+    // ---- helper ----
+    EncLane<32, 64> L;
+    L.init(a.words + s * a.stride_words, (uint32_t)a.stride_words, ring, lane);
+    hand[lane] = 0;                                     // nothing published yet
+    uint32_t goff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (size_t)(n_t - 1) * kTileSyms);
+    const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+    const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+    const uint32_t tr_addr[2] = {lds_addr(tile[0]) + tr_off, lds_addr(tile[1]) + tr_off};
+    uint32_t flushed = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the statement keeps its own book from here
+    ans_encode_pc_helper_loop(flushed, tr_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)a.stride_words,
+                              (uint32_t)(s * a.stride_words * 4), a.words, symbols_base, n_t, goff);
+    pc_barrier();                                       // the coder has published its last write position and the final state
+    L.out.flushed = flushed;
+    L.out.wr = hand[lane];
+    L.state = ((uint64_t)hand[2 * kWave + lane] << 32) | hand[kWave + lane];
+    L.bad = hand[3 * kWave + lane];
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(!raw, nsym, n_words);
+    if (raw) a.state[s] = (uint64_t)L.state;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// Whole workgroups of 256 streams, at most one per CU (more streams than that: the two-waves-per-SIMD kernels of
+// cst_ans_small.hip), rows that are whole 128-byte aligned tiles, 64-byte aligned slabs of whole 64-byte groups.
+bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
+    if (getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs)
+    if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (a.n_streams == 0 || a.n_streams % kBlock != 0 || a.n_streams > (size_t)device_cus * kBlock) return false;
+    if (a.n_per_stream % kTileSyms != 0 || a.n_per_stream < 2 * kTileSyms || a.n_per_stream >= (1u << 24)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
+    if (a.n_streams * a.stride_words * 4 >= 0x100000000ull || 64 * a.n_per_stream * 4 >= 0x100000000ull) return false;   // 32-bit offsets
+    return (size_t)a.n_symbols * sizeof(EncEntry) <= kPcTableBytes;
+}
+
+cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs) {
+    const size_t blocks = a.n_streams / kBlock;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
+    hipLaunchKernelGGL(ans_encode_pc_kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+} // namespace cst

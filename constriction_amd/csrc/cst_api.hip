@@ -273,6 +273,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
     if (small_encode_usable(a, cfg, layout, model->cu_count)) return ans_encode_small(a, hs);   // more than one wave per SIMD
+    if (pc_encode_usable(a, cfg, layout, model->cu_count)) return ans_encode_pc(a, hs);        // one wave per SIMD: coder + helper waves
     if (w16_encode_usable(a, cfg, layout)) return ans_encode_w16(a, layout, hs);                        // SmallAnsCoder preset
     if (wide_encode_usable(a, cfg, layout)) return ans_encode_wide(a, layout, hs);                      // 12 < P <= 24
     if (cfg.word_bits == 32) return encode_dispatch<32, 64>(a, layout, hs);

@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generates constriction_amd/csrc/cst_encode_loop_pc.inc: the CODER half of the producer / consumer form of the (32,64),
+P <= 12 ANS encoder (cst_ans_pc.hip, round 4).
+
+65 536 streams are one wave per SIMD, and a lone wave issues one instruction per ~4.4 cycles whatever it is: in
+cst_encode_loop.inc the coder chain's wave also stages the symbol tiles (8 x 16-byte LDS stores of one wave: 36 cycles
+each), reads complete word groups back from its ring, stores them and requests the next tiles -- a quarter of the kernel
+(scripts/ablate_encoder.sh: 0.228 ms without the tile work against 0.275 ms with it, all of it issue and LDS-store time of
+the one wave, none of it memory time).  Here a second wave of the same workgroup -- the HELPER, compiler-scheduled C++ in
+cst_ans_pc.hip, on the same SIMD -- does all of that, and the wave generated below runs nothing but the coder steps:
+
+    quad g:  request the symbols of quad g-2 (one 16-B LDS read of the lane's tile row), fetch the four 16-B table
+             entries of quad g-1, fold quad g's symbols into smin / smax (the range check), run quad g's four steps.
+    words:   every step writes its candidate word to the lane's 64-slot LDS ring (layout [slot][lane]) and advances the
+             write position if the word was really emitted (stack.rs:1035-1040), as in cst_encode_loop.inc.
+    hand-off, once per tile at the top of quad 1 (every read of the current tile's row has returned by then):
+             publish the write position, s_waitcnt lgkmcnt(0), s_barrier.
+             Behind the barrier the helper has finished staging the NEXT tile into the other tile buffer (the coder's
+             quads 1 and 0 already read it), may overwrite THIS tile's buffer with the tile after that, and moves complete
+             64-byte groups below the published position from the ring to the slab.
+             (A first version gave the coder per-tile OUT windows -- one VALU instruction less per step -- that the helper
+             copied into its own ring: the SIMD's VALU is what both waves share, and the helper's 13 pushes per tile cost
+             more of it than the coder saved: 0.296 ms against 0.278 for the one-wave kernel.)
+Two tile buffers alternate; the loop body holds two tiles.
+
+Run:  python scripts/gen_encode_loop_pc.py
+"""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from asmgen import Asm  # noqa: E402
+
+CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
+OUT = CSRC / "cst_encode_loop_pc.inc"
+NO_BARRIER = bool(os.environ.get("GEN_NO_BARRIER"))     # timing experiment only (races with the helper)
+PRIO = int(os.environ.get("GEN_PRIO", "2"))             # s_setprio of the coder's wave (0 = leave it alone)
+
+
+def regs(base, n=4):
+    return [f"v{base + i}" for i in range(n)]
+
+
+def tup(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+S = [regs(100 + 4 * i) for i in range(4)]
+S_T = [tup(100 + 4 * i) for i in range(4)]
+E = [[regs(116 + 16 * e + 4 * i) for i in range(4)] for e in range(2)]
+E_T = [[tup(116 + 16 * e + 4 * i) for i in range(4)] for e in range(2)]
+A0, A1, W0, W1, U0, U1, T0, T1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(148, 160))
+A_T, W_T, U_T, T_T, SM_T, Q_T = (tup(148 + 2 * i, 2) for i in range(6))
+RR, KK, CK, RA, EA0, EA1, WR = (f"v{r}" for r in range(160, 167))
+SD = "s[84:85]"
+CLOBBERS = [f"v{r}" for r in range(100, 167)] + ["s82", "s84", "s85", "vcc", "memory"]
+ROW = ["%[row0]", "%[row1]"]
+SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD"
+
+
+def step(a, e0, e1, m0, m1):
+    """One coder step (stack.rs:1035-1045) on a packed table entry (see scripts/gen_encode_loop.py: step())."""
+    a.i(f"v_cmp_ge_u32_sdwa vcc, %[hi], {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
+    a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
+    a.i(f"v_lshlrev_b32 {RA}, 8, {WR}")
+    a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
+    a.i(f"v_cndmask_b32_e64 {A0}, %[lo], %[hi], vcc")
+    a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
+    a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
+    a.i(f"v_addc_co_u32 {WR}, vcc, 0, {WR}, vcc")
+    a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
+    a.i(f"v_mad_u64_u32 {U_T}, vcc, {A1}, {m0}, {W_T}", "U = a1*m0 + hi32(a0*m0)   (< 2^64)")
+    a.i(f"v_mad_u64_u32 {T_T}, vcc, {A0}, {m1}, {U_T}", "T = a0*m1 + U, carry -> vcc")
+    a.i(f"v_mov_b32 {SM0}, {T1}")
+    a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc", "[T_hi, carry]")
+    a.i(f"v_mad_u64_u32 {Q_T}, vcc, {A1}, {m1}, {SM_T}", "q_est in {q - 1, q}")
+    a.i(f"v_mul_u32_u24_sdwa {RR}, {Q0}, {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "low 24 bits of q_est times p")
+    a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est modulo 2^24")
+    a.i(f"v_cmp_ge_u32_sdwa vcc, {RR}, {e1} src0_sel:WORD_0 src1_sel:WORD_0", "fix <=> q = q_est + 1")
+    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}", "A + q_lo * k")
+    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}", "      + (q_hi * k) << 32")
+    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + k")
+    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {CK}")
+    a.i(f"v_addc_co_u32 %[hi], vcc, 0, {U1}, vcc")
+
+
+def read_syms(a, g, buf, quad):
+    a.ds(f"ds_read_b128 {S_T[g % 4]}, {ROW[buf]} offset:{16 * quad}", f"S{g}")
+
+
+def fetch_entries(a, g):
+    x, y, z, w = S[g % 4]
+    for i, sym in enumerate((w, z, y, x)):       # consumption order: .w first
+        ea = (EA0, EA1)[i & 1]
+        a.i(f"v_lshl_add_u32 {ea}, {sym}, 4, %[tbl]")
+        a.ds(f"ds_read_b128 {E_T[g % 2][i]}, {ea}", f"E{g}")
+
+
+def fold_minmax(a, g):
+    """the range check: a symbol outside the model's support reads a garbage entry (harmless: LDS never faults) and flags its
+    stream at the end.  (Tried: one v_max3_u32 per two table ADDRESSES with the table at LDS address 0 -- half the
+    instructions, but (symbol - min) << 4 wraps for |symbol - min| >= 2^28 and such a symbol then passes as a valid one.)"""
+    x, y, z, w = S[g % 4]
+    a.i(f"v_max3_i32 %[smax], %[smax], {x}, {y}")
+    a.i(f"v_max3_i32 %[smax], %[smax], {z}, {w}")
+    a.i(f"v_min3_i32 %[smin], %[smin], {x}, {y}")
+    a.i(f"v_min3_i32 %[smin], %[smin], {z}, {w}")
+
+
+def hand_off(a):
+    a.ds(f"ds_write_b32 %[pub], {WR}", "cnt", "words emitted so far")
+    a.wait_lds_all("they are in the ring, and every read of this tile's row has returned")
+    if not NO_BARRIER:
+        a.i("s_barrier")
+
+
+def half(a, h, g0):
+    """one tile in tile buffer h, global quad indices g0 .. g0+7 stand for quads 7 .. 0"""
+    a.i(f"; ---- tile in buffer {h}")
+    for j in range(8):
+        g, quad = g0 + j, 7 - j
+        if quad == 1:
+            hand_off(a)
+        if f"S{g + 1}" in a.lds:
+            a.wait_lds(f"S{g + 1}", f"quad {quad}: symbols of the next quad are back", cap=True)
+        far = quad - 2
+        read_syms(a, g + 2, h if far >= 0 else 1 - h, far if far >= 0 else far + 8)
+        fetch_entries(a, g + 1)
+        if f"E{g}" in a.lds:
+            a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
+        fold_minmax(a, g)
+        for c, p, m0, m1 in E[g % 2]:
+            step(a, c, p, m0, m1)
+
+
+def gen():
+    a = Asm()
+    a.i(f"v_mov_b32 {W1}, 0")
+    if PRIO:
+        a.i(f"s_setprio {PRIO}", "the coder chain's wave goes first on its SIMD; the helper fills the gaps")
+    a.i(f"v_mov_b32 {WR}, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
+    read_syms(a, 0, 0, 7)
+    read_syms(a, 1, 0, 6)
+    a.wait_lds("S0")
+    fetch_entries(a, 0)
+    a.i("1:")
+    first = len(a.events)
+    half(a, 0, 0)
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_eq_u32 s82, 0")
+    a.i("s_cbranch_scc1 2f")
+    half(a, 1, 8)
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.i("s_cbranch_scc1 1b")
+    ren = {"S16": "S0", "S17": "S1", "E16": "E0"}
+    lds_back = [ren.get(t, t) for t in a.lds]
+    lds_end, vm_end, notes = a.verify_loop(first, lds_back, a.vm, passes=1)
+    lds_end = [ren.get(t, t) for t in lds_end]
+    assert lds_end == lds_back and vm_end == a.vm, (lds_end, lds_back)
+    a.i("2:")
+    a.ds(f"ds_write_b32 %[pub], {WR}", "cnt", "all words of the main loop")
+    a.wait_lds_all()
+    return a, notes
+
+
+def main():
+    a, notes = gen()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Coder half of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_coder_loop in cst_ans_pc.hip."]
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
+           '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
+           '      [twoP] "v"(1u << P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
+           "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
+    OUT.write_text(a.render(header, ops))
+    print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the HELPER half (cst_encode_loop_pc_helper.inc): everything but the coder steps, with as few VALU instructions as possible
+# (the SIMD's VALU is what the two waves share; LDS, vector-memory and scalar instructions issue beside the coder's VALU
+# stream).  hipcc's version of the same C++ took 107 VALU instructions per tile (copies of the prefetched registers, 64-bit
+# address arithmetic, flat_* stores into the tile buffers) and waited vmcnt(0) in front of every staging.
+#   window i (between the coder's barriers i - 1 and i):
+#       tile i + 1: registers -> tile buffer (i + 1) & 1 (requested three windows earlier; free since barrier i - 1),
+#       request tile i + 4 into the registers just freed (three register sets, so a window is 6 = lcm(2, 3) long),
+#       one complete 64-byte group below the write position published at barrier i - 1: ring -> slab,
+#       s_waitcnt lgkmcnt(0), s_barrier.
+# Past the last tile the statement keeps re-requesting and re-staging tile n - 1 (nobody reads those buffers any more).
+# ---------------------------------------------------------------------------------------------------------------------
+OUT_HELPER = CSRC / "cst_encode_loop_pc_helper.inc"
+NSETS = int(os.environ.get("GEN_NSETS", "3"))           # register sets of prefetched tiles: a tile is requested NSETS windows before it is staged
+HBASE = 234 - 32 * NSETS
+SETS = "ABCDE"[:NSETS]
+HR = {n: [tup(HBASE + 32 * i + 4 * k) for k in range(8)] for i, n in enumerate(SETS)}
+HFD = [(tup(234 + 4 * k, 2), tup(236 + 4 * k, 2), tup(234 + 4 * k)) for k in range(4)]
+HWR, HNCH, HLIM, HFADDR, HFOFF = (f"v{r}" for r in range(250, 255))
+HSAVE = "s[86:87]"
+H_CLOBBERS = [f"v{r}" for r in range(HBASE, 255)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "memory"]
+HTR = ["%[tr0]", "%[tr1]"]
+
+
+def h_advance_base(a):
+    """s[80:81] -> symbols of the next tile to request; stays on the last one (the FIRST 32 symbols of the rows) once every
+    tile has been requested"""
+    a.i("s_cmp_lg_u32 s83, 0")
+    a.i("s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s89, 1, 0")
+    a.i("s_sub_u32 s80, s80, s88")
+    a.i("s_subb_u32 s81, s81, 0")
+    a.i("s_sub_u32 s83, s83, s89")
+
+
+def h_load_set(a, name):
+    for k in range(8):
+        a.vmem(f"global_load_dwordx4 {HR[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
+    h_advance_base(a)
+
+
+def h_stage_set(a, name, buf):
+    a.wait_vm(f"ld{name}", f"symbols in set {name} have arrived")
+    for k in range(8):
+        a.ds(f"ds_write_b128 {HTR[buf]}, {HR[name][k]} offset:{1152 * k}", "tl")
+
+
+def h_flush(a):
+    """one complete 64-byte group below the published write position: ring -> slab (64-byte aligned slabs of whole groups)"""
+    a.ds(f"ds_read_b32 {HWR}, %[pub]", "pub")
+    a.wait_lds("pub")
+    a.i(f"v_sub_u32 {HNCH}, {HWR}, %[flushed]")
+    a.i(f"v_lshrrev_b32 {HNCH}, 4, {HNCH}", "whole 16-word groups pending: 0 or 1")
+    for k in range(4):
+        a.i(f"v_add_lshl_u32 {HFADDR}, %[flushed], {4 * k}, 8")
+        a.i(f"v_and_or_b32 {HFADDR}, {HFADDR}, %[c3f00], %[lanebase]")
+        a.ds(f"ds_read2st64_b32 {HFD[k][0]}, {HFADDR} offset1:1", "fl")
+        a.ds(f"ds_read2st64_b32 {HFD[k][1]}, {HFADDR} offset0:2 offset1:3", "fl")
+    a.i(f"v_add_u32 {HLIM}, 16, %[flushed]")
+    a.i(f"v_lshl_add_u32 {HFOFF}, %[flushed], 2, %[slaboff]")
+    a.i(f"v_cmp_le_u32 vcc, {HLIM}, %[cap]", "group inside the slab")
+    a.i(f"v_cmp_ne_u32 {HSAVE}, 0, {HNCH}")
+    a.i(f"s_and_b64 vcc, vcc, {HSAVE}")
+    a.wait_lds("fl")
+    a.i(f"s_and_saveexec_b64 {HSAVE}, vcc")
+    for k in range(4):
+        a.vmem(f"global_store_dwordx4 {HFOFF}, {HFD[k][2]}, %[wbase] offset:{16 * k}", "st")
+    a.i(f"s_mov_b64 exec, {HSAVE}")
+    a.i(f"v_lshl_add_u32 %[flushed], {HNCH}, 4, %[flushed]")
+
+
+HABL = set((os.environ.get("GEN_HABL") or "").split("+")) - {""}      # timing experiments (results wrong): noflush, nostage, noloads
+
+
+PAIRS = bool(os.environ.get("GEN_PAIRS"))     # experiment: request TWO tiles (256 contiguous bytes per row) every other window (needs NSETS = 5)
+
+
+def h_window(a, w):
+    name, buf = SETS[(w + 1) % NSETS], (w + 1) & 1
+    if PAIRS:
+        a.i(f"; ---- window {w}: set {name} -> tile buffer {buf}")
+        h_stage_set(a, name, buf)
+        if w % 2 == 0:
+            h_load_set(a, SETS[w % NSETS])
+            h_load_set(a, name)
+        h_flush(a)
+        a.wait_lds_all("the tile is staged")
+        a.i("s_barrier")
+        return
+    a.i(f"; ---- window {w}: set {name} -> tile buffer {buf}")
+    if "nostage" not in HABL:
+        if "noloads" in HABL:
+            for k in range(8):
+                a.ds(f"ds_write_b128 {HTR[buf]}, {HR[name][k]} offset:{1152 * k}", "tl")
+        else:
+            h_stage_set(a, name, buf)
+    if "noloads" not in HABL:
+        h_load_set(a, name)
+    if "noflush" not in HABL:
+        h_flush(a)
+    a.wait_lds_all("the tile is staged")
+    a.i("s_barrier")
+
+
+def gen_helper():
+    a = Asm()
+    a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST full tile of stream s0: tile 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "windows left")
+    a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
+    for n in SETS:
+        h_load_set(a, n)
+    h_stage_set(a, "A", 0)
+    if not PAIRS:
+        h_load_set(a, "A")
+    a.wait_lds_all("tile 0 is staged (and the table, by everybody)")
+    a.i("s_barrier")
+    a.i("1:")
+    first = len(a.events)
+    period = NSETS * 2 if NSETS % 2 else NSETS
+    for w in range(period):
+        h_window(a, w)
+        a.i("s_sub_u32 s82, s82, 1")
+        if w < period - 1:
+            a.i("s_cmp_eq_u32 s82, 0")
+            a.i("s_cbranch_scc1 2f")
+        else:
+            a.i("s_cmp_lg_u32 s82, 0")
+            a.i("s_cbranch_scc1 1b")
+    lds_end, vm_end, notes = a.verify_loop(first, a.lds, a.vm, passes=1)
+    assert HABL or (lds_end == a.lds and vm_end == a.vm), (vm_end, a.vm)
+    a.i("2:")
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all()
+    return a, notes
+
+
+def main_helper():
+    a, notes = gen_helper()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Helper half of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_helper_loop in cst_ans_pc.hip."]
+    ops = ['    : [flushed] "+v"(flushed)',
+           '    : [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr),',
+           '      [cap] "v"(cap), [slaboff] "v"(slab_off), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base), [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in H_CLOBBERS) + ");"]
+    OUT_HELPER.write_text(a.render(header, ops))
+    print(f"wrote {OUT_HELPER} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+
+
+def main_all():
+    main()
+    main_helper()
+
+
+if __name__ == "__main__":
+    main_all()

@@ -127,3 +127,14 @@ def test_wait_bookkeeping_rejects_unreachable_counts():
     except AssertionError:
         return
     raise AssertionError("lgkmcnt operand > 15 must be rejected")
+
+
+def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
+    """the coder and helper halves of the producer / consumer encoder (cst_ans_pc.hip)"""
+    for var in ("GEN_NO_BARRIER", "GEN_PRIO", "GEN_HABL", "GEN_NSETS", "GEN_PAIRS"):
+        monkeypatch.delenv(var, raising=False)
+    mod = _load("gen_encode_loop_pc")
+    mod.OUT, mod.OUT_HELPER = tmp_path / "coder.inc", tmp_path / "helper.inc"
+    mod.main_all()
+    assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
+    assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()
