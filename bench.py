@@ -157,34 +157,62 @@ def cpu_tables(lo, hi, mu, sigma, precision):
 
 def cpu_baseline(cdf, symbols_host, repeats=3):
     """Times the CPU oracle (kind "port": the repo's C restatement of the reference arithmetic, -O3 -march=native,
-    one disjoint block of streams per thread) on this box's host cores, on the SAME symbols the GPU coded."""
+    one disjoint block of streams per thread) on this box's host cores, on the SAME symbols the GPU coded.
+    Output buffers are allocated once and written by an untimed first pass (each thread touches its own block first, pinned to
+    one logical CPU: the pages of a block live on its thread's NUMA node), so a timed pass measures coding, not the kernel's
+    page-fault path (round 3 allocated a gigabyte of zero pages inside the timed region: all-core decode ran at half the
+    encoder's rate although one thread decodes as fast as it encodes)."""
     from oracle import oracle as O
     cores = host_cores()
     lut = O.lookup_from_cdf(cdf, P)
 
     def run(sym, threads):
-        best = None
+        os.environ["CST_ORACLE_PIN"] = "1" if threads > 1 else "0"
+        enc_out = O.ans_encode_batch(sym, LO, cdf, P, W, S, n_threads=threads, native=True)                       # untimed: first touch
+        dec_out = O.ans_decode_batch(enc_out[0], enc_out[1], N_PER, LO, cdf, P, W, S, lookup=lut, n_threads=threads, native=True)
+        best_e = best_d = None
         for _ in range(repeats):
             t0 = time.perf_counter()
-            words, n_words, status = O.ans_encode_batch(sym, LO, cdf, P, W, S, n_threads=threads, native=True)
+            words, n_words, status = O.ans_encode_batch(sym, LO, cdf, P, W, S, n_threads=threads, native=True, out=enc_out)
             t1 = time.perf_counter()
-            dec, dstatus = O.ans_decode_batch(words, n_words, N_PER, LO, cdf, P, W, S, lookup=lut, n_threads=threads, native=True)
+            dec, dstatus = O.ans_decode_batch(words, n_words, N_PER, LO, cdf, P, W, S, lookup=lut, n_threads=threads, native=True, out=dec_out)
             t2 = time.perf_counter()
-            if best is None or (t2 - t0) < sum(best):
-                best = (t1 - t0, t2 - t1)
+            best_e = (t1 - t0) if best_e is None else min(best_e, t1 - t0)
+            best_d = (t2 - t1) if best_d is None else min(best_d, t2 - t1)
+        os.environ["CST_ORACLE_PIN"] = "0"
         assert np.array_equal(dec, sym) and not status.any() and not dstatus.any()
-        return sym.size, best[0], best[1]
+        return sym.size, best_e, best_d
 
     n, te, td = run(symbols_host, cores)
-    n1, te1, td1 = run(symbols_host[: max(64, min(1024, len(symbols_host)))], 1)
+    n1, te1, td1 = run(symbols_host[: max(64, min(2048, len(symbols_host)))], 1)
+    enc_rate, dec_rate, enc1, dec1 = n / te / 1e6, n / td / 1e6, n1 / te1 / 1e6, n1 / td1 / 1e6
     return {
         "value": round(n / (te + td) / 1e6, 2), "unit": "Msymbols/s", "cores": cores, "kind": "port",
-        "sample": f"{len(symbols_host)} of {N_STREAMS} streams x {N_PER} symbols (the GPU's own input), {cores} threads, best of "
-                  f"{repeats} (encode {n / te / 1e6:.0f} + decode {n / td / 1e6:.0f} Msym/s); "
+        "sample": f"{len(symbols_host)} of {N_STREAMS} streams x {N_PER} symbols (the GPU's own input), {cores} pinned threads, buffers allocated "
+                  f"and first touched outside the timed region, best of {repeats} (encode {enc_rate:.0f} + decode {dec_rate:.0f} Msym/s); "
                   f"1 thread: {n1 / (te1 + td1) / 1e6:.1f} Msym/s "
                   f"({te1 / n1 * 1e9:.1f} ns/sym encode, {td1 / n1 * 1e9:.1f} ns/sym decode)",
         "single_thread_value": round(n1 / (te1 + td1) / 1e6, 2),
+        "encode_Msymbols_per_s": round(enc_rate, 1), "decode_Msymbols_per_s": round(dec_rate, 1),
+        "scaling_efficiency": {"encode": round(enc_rate / (cores * enc1), 3), "decode": round(dec_rate / (cores * dec1), 3),
+                               "what": f"all-thread rate / ({cores} x the one-thread rate); {cores} hardware threads = the box's logical CPUs"},
     }
+
+
+def model_entropy_bits(cdf, precision):
+    """entropy_base2 of a quantized model (src/stream/model.rs:576-591): the bit rate an optimal coder reaches on symbols drawn
+    from the model itself, which is how every batch here is drawn"""
+    p = np.diff(np.asarray(cdf, dtype=np.float64)) / float(1 << precision)
+    p = p[p > 0]
+    return float(-(p * np.log2(p)).sum())
+
+
+def rate_report(total_words, n_sym, word_bits, entropy_bits):
+    """bits per symbol of the compressed words (final state words included, as in get_compressed) against the model's entropy:
+    the reference's own headline figure (README: "bit-rate overhead")"""
+    bps = word_bits * total_words / n_sym
+    return {"bits_per_symbol": round(bps, 5), "model_entropy_bits": round(entropy_bits, 5),
+            "overhead_vs_entropy": round(bps / entropy_bits - 1.0, 6)}
 
 
 def event_ms(fn, reps):
@@ -222,7 +250,7 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded, **kw), reps)
     total_words = enc.total_words()
     n_sym = n_streams * n_per
-    byts = 4 * n_sym + 4 * total_words
+    byts = 4 * n_sym + (cfg[0] // 8) * total_words       # algorithmic: W-bit words (16-bit words sit in 32-bit slots: the TRAFFIC is larger)
     entry = {
         "workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
         "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
@@ -231,6 +259,8 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
         "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
     }
+    if cdf_host is not None and np.asarray(cdf_host).ndim == 1:
+        entry.update(rate_report(total_words, n_sym, cfg[0], model_entropy_bits(cdf_host, cfg[2])))
     if check:
         ok = bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
         if ok and cdf_host is not None:
@@ -351,6 +381,119 @@ def ragged_config(B, reps, check, n_docs=100_000, n_sym=64, precision=24):
     return entry
 
 
+def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3):
+    """the same batch from HOST memory and back -- what the reference's bindings do around every call (they copy
+    the numpy input in, src/pybindings/mod.rs:240-243, and the compressed words out, pybindings/stream/stack.rs:422-427).
+        encode leg:  pinned host symbols -> H2D -> cst_ans_encode_batch -> cst_compact_words -> D2H of the packed words
+        decode leg:  pinned host words + offsets -> H2D -> cst_ans_decode_batch -> D2H of the symbols
+    in `n_chunks` chunks of streams over `n_hip_streams` HIP streams, so that the copies of one chunk overlap the kernels of
+    another.  Never part of `value`: the link, not the coder, sets these numbers."""
+    n_streams, n_per = symbols.shape
+    per = n_streams // n_chunks
+    cfg = (W, S, P)
+    host_sym = torch.empty((n_streams, n_per), dtype=torch.int32, pin_memory=True)
+    host_sym.copy_(symbols)
+    stride = B.max_words(n_per, cfg)
+    host_words = torch.empty(n_streams * stride, dtype=torch.int32, pin_memory=True)
+    host_off = torch.empty((n_chunks, per + 1), dtype=torch.int64, pin_memory=True)
+    host_back = torch.empty((n_streams, n_per), dtype=torch.int32, pin_memory=True)
+    streams = [torch.cuda.Stream() for _ in range(n_hip_streams)]
+    dsym = [torch.empty((per, n_per), dtype=torch.int32, device="cuda") for _ in range(n_hip_streams)]
+    encs = [B.ans_encode(dsym[k], model, cfg) for k in range(n_hip_streams)]
+    packs = [B.compact(encs[k]) for k in range(n_hip_streams)]
+    dwords = [torch.empty(per * stride, dtype=torch.int32, device="cuda") for _ in range(n_hip_streams)]
+    doff = [torch.empty(per + 1, dtype=torch.int64, device="cuda") for _ in range(n_hip_streams)]
+    dnw = [torch.empty(per, dtype=torch.int32, device="cuda") for _ in range(n_hip_streams)]
+    torch.cuda.synchronize()
+    totals = [0] * n_chunks
+
+    def encode_leg():
+        for c in range(n_chunks):
+            k = c % n_hip_streams
+            with torch.cuda.stream(streams[k]):
+                dsym[k].copy_(host_sym[c * per:(c + 1) * per], non_blocking=True)
+                B.ans_encode(dsym[k], model, cfg, out=encs[k])
+                B.compact(encs[k], out=packs[k])
+                host_off[c].copy_(packs[k][1], non_blocking=True)
+                streams[k].synchronize()                       # (this stream only: the chunk's word count decides the size of its copy)
+                totals[c] = int(host_off[c, -1])
+                base = c * per * stride
+                host_words[base: base + totals[c]].copy_(packs[k][0][: totals[c]], non_blocking=True)
+        torch.cuda.synchronize()
+
+    def decode_leg():
+        for c in range(n_chunks):
+            k = c % n_hip_streams
+            with torch.cuda.stream(streams[k]):
+                base = c * per * stride
+                dwords[k][: totals[c]].copy_(host_words[base: base + totals[c]], non_blocking=True)
+                doff[k].copy_(host_off[c], non_blocking=True)
+                dnw[k].copy_(doff[k][1:] - doff[k][:-1])
+                B.ans_decode((dwords[k], dnw[k]), model, n_per, offsets=doff[k], config=cfg, out=dsym[k])
+                host_back[c * per:(c + 1) * per].copy_(dsym[k], non_blocking=True)
+        torch.cuda.synchronize()
+
+    def wall(fn):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+    encode_leg()
+    te = wall(encode_leg)
+    td = wall(decode_leg)
+    ok = bool(torch.equal(host_back, host_sym))
+    n_sym = n_streams * n_per
+    words_bytes = 4 * sum(totals)
+    return {"what": f"pinned host memory -> device -> host, {n_chunks} chunks of {per} streams over {n_hip_streams} HIP streams; best of {reps}",
+            "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
+            "Msymbols_per_s": round(n_sym / (te + td) / 1e6, 1),
+            "encode_link_GBps": round((4 * n_sym + words_bytes) / te / 1e9, 1), "decode_link_GBps": round((4 * n_sym + words_bytes) / td / 1e9, 1),
+            "bit_exact": ok}
+
+
+def c1_config(B, check):
+    """BASELINE config C1: ONE stream of 10^6 symbols, QuantizedGaussian(-50, 50, 3.2, 9.6) at P = 24 -- through the drop-in
+    single coder (constriction_amd.stream.stack.AnsCoder: host arrays in, host arrays out, like the reference's Python API) and
+    through the checkpointed batched calls (jump tables every 1000 symbols: the decoder runs on 1000 lanes)."""
+    from oracle import oracle as O
+    from constriction_amd.stream import stack, model as M
+    lo, hi, mean, std, prec, n = -50, 50, 3.2, 9.6, 24, 1_000_000
+    cdf = O.GaussianModel(lo, hi, mean, std, prec, 32).cdf_table()
+    sym = O.synth_symbols(0xC0FFEE, 0, 1, n, lo, cdf, prec)[0]
+    entry = {"workload": "C1: one stream of 1 000 000 symbols, QuantizedGaussian(-50,50,3.2,9.6), DefaultAnsCoder (32,64,24)", "coder": "ans",
+             "config": [32, 64, prec], "streams": 1, "symbols_per_stream": n}
+    fam = M.QuantizedGaussian(lo, hi, mean, std)
+    coder = stack.AnsCoder()
+    coder.encode_reverse(sym[:1000], fam)                                          # (first call: library and tables warm)
+    coder = stack.AnsCoder()
+    t0 = time.perf_counter()
+    coder.encode_reverse(sym, fam)
+    words = coder.get_compressed()
+    t1 = time.perf_counter()
+    out = stack.AnsCoder(words).decode(fam, n)
+    t2 = time.perf_counter()
+    entry["dropin_encode_ns_per_symbol"] = round((t1 - t0) / n * 1e9, 1)
+    entry["dropin_decode_ns_per_symbol"] = round((t2 - t1) / n * 1e9, 1)
+    entry.update(rate_report(len(words), n, 32, model_entropy_bits(cdf, prec)))
+    model = B.Model.quantized_gaussian(lo, hi, mean, std, prec)
+    dsym = torch.from_numpy(sym[None, :].copy()).cuda()
+    enc, ck = B.ans_encode_checkpointed(dsym, model, 1000, (32, 64, prec))
+    dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n)
+    entry["checkpointed_encode_ms"] = round(event_ms(lambda: B.ans_encode_checkpointed(dsym, model, 1000, (32, 64, prec)), 3), 3)
+    entry["checkpointed_decode_ms"] = round(event_ms(lambda: B.ans_decode_checkpointed(enc, ck, model, n), 3), 3)
+    ok = bool(np.array_equal(out, sym)) and bool(torch.equal(dec[0].cpu(), torch.from_numpy(sym))) and int(dstatus.abs().sum().item()) == 0
+    if check and ok:
+        want_words, want_n, _ = O.ans_encode_batch(sym[None, :], lo, cdf, prec)
+        ok = words.tolist() == want_words[0, : want_n[0]].tolist() and enc.stream(0).tolist() == words.tolist()
+        entry["bit_exact_scope"] = "drop-in and checkpointed words vs CPU oracle, decoded symbols vs input"
+    entry["bit_exact"] = ok
+    return entry
+
+
 def other_configs(B, rank, world, dist, args, reps=5):
     """Every other single-GPU configuration of BASELINE.json, same clock, same checks (see the module docstring)."""
     out = []
@@ -377,6 +520,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
     cdf12_dev = torch.from_numpy(cdf12.astype(np.int64)).cuda()
     sym12 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, cdf12_dev, 12)
     if world == 1:
+        try:
+            out.append(c1_config(B, check))
+        except Exception as exc:      # noqa: BLE001
+            out.append({"workload": "C1: one stream of 1 000 000 symbols", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         symT = sym12.t().contiguous()
         add("C2 as symbols[t][stream] (symbol-major layout)", "ans", (32, 64, 12), m12, symT, reps, check, cdf12,
                           layout="symbol_major")
@@ -502,6 +649,7 @@ def main():
     ap.add_argument("--c5-streams", type=int, default=C5_STREAMS, help="streams per GPU of the C5 shard entry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host -> device -> host leg (pinned buffers, chunked over HIP streams)")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` block")
     ap.add_argument("--graph", action="store_true", help="replay the timed step as a HIP graph instead of launching eagerly")
     ap.add_argument("--slab-stride", default="tuned",
@@ -623,6 +771,12 @@ def main():
 
     packed, offsets = B.compact(enc)
     compact_ms = event_ms(lambda: B.compact(enc, out=(packed, offsets)), 5)
+    e2e = None
+    if world == 1 and not args.no_end_to_end:
+        try:
+            e2e = end_to_end(B, model, symbols)
+        except Exception as exc:      # noqa: BLE001
+            e2e = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # The timed steps decode what the encoder has just written.  For the record, the same two kernels after a 1-GiB fill
     # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):
@@ -687,7 +841,7 @@ def main():
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "bit_exact": ok, "bit_exact_scope": scope, "launch": launch_mode,
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4), "after_cache_flush": cold,
-            "words_per_stream": round(total_words / n_streams, 2),
+            "words_per_stream": round(total_words / n_streams, 2), "rate": rate_report(total_words, n_sym, W, model_entropy_bits(cdf, P)),
             "slab_stride_words": int(enc.words.shape[1]), "slab_stride_source": args.slab_stride,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -697,6 +851,8 @@ def main():
                          "encode_GBps": round(bytes_per_launch / (enc_ms * 1e-3) / 1e9, 1),
                          "decode_GBps": round(bytes_per_launch / (dec_ms * 1e-3) / 1e9, 1)},
         }
+        if e2e is not None:
+            line["end_to_end"] = e2e
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["rccl_ranks_seen"] = ranks_seen

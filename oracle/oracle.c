@@ -18,11 +18,14 @@
  * Each function cites the reference file:line it follows (paths relative to
  * /root/reference/).  Plain C99, no dependencies, compile with -ffp-contract=off.
  */
+#define _GNU_SOURCE            /* pthread_setaffinity_np (cpu_baseline leg only) */
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
 
 #define API __attribute__((visibility("default")))
 
@@ -678,6 +681,7 @@ typedef struct {
     uint32_t *n_words;           /* [n_streams] */
     int32_t *status;             /* [n_streams] */
     size_t s_begin, s_end;
+    int thread_index;            /* -1: the caller's own thread */
 } batch_job_t;
 
 static void encode_one_stream(const batch_job_t *j, size_t s)
@@ -736,8 +740,21 @@ static void decode_one_stream(const batch_job_t *j, size_t s)
     }
 }
 
-static void *encode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; for (size_t s = j->s_begin; s < j->s_end; s++) encode_one_stream(j, s); return NULL; }
-static void *decode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; for (size_t s = j->s_begin; s < j->s_end; s++) decode_one_stream(j, s); return NULL; }
+static void pin_self(int i);
+static void *encode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; pin_self(j->thread_index); for (size_t s = j->s_begin; s < j->s_end; s++) encode_one_stream(j, s); return NULL; }
+static void *decode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; pin_self(j->thread_index); for (size_t s = j->s_begin; s < j->s_end; s++) decode_one_stream(j, s); return NULL; }
+
+/* CST_ORACLE_PIN=1 (bench.py's cpu_baseline leg): thread i stays on logical CPU i mod (online CPUs), so that a thread keeps the
+ * pages it touched first on its own NUMA node and is not migrated in the middle of a timed pass. */
+static void pin_self(int i)
+{
+    const char *e = getenv("CST_ORACLE_PIN");
+    if (!e || *e != '1' || i < 0) return;
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) return;
+    cpu_set_t set; CPU_ZERO(&set); CPU_SET((int)(i % n), &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
 
 static void run_threads(batch_job_t *proto, int n_threads, void *(*fn)(void *))
 {
@@ -750,6 +767,7 @@ static void run_threads(batch_job_t *proto, int n_threads, void *(*fn)(void *))
         jobs[i] = *proto;
         jobs[i].s_begin = (size_t)i * per < proto->n_streams ? (size_t)i * per : proto->n_streams;
         jobs[i].s_end = jobs[i].s_begin + per < proto->n_streams ? jobs[i].s_begin + per : proto->n_streams;
+        jobs[i].thread_index = n_threads == 1 ? -1 : i;
         if (n_threads == 1) fn(&jobs[i]); else pthread_create(&th[i], NULL, fn, &jobs[i]);
     }
     if (n_threads > 1) for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);

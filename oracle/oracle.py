@@ -561,29 +561,40 @@ def slab_stride(n_per_stream, P, W=32, S=64):
     return min(n_per_stream, (n_per_stream * P + W - 1) // W) + S // W
 
 
-def ans_encode_batch(symbols, lo, cdf, P, W=32, S=64, stride=None, n_threads=1, native=False):
+def ans_encode_batch(symbols, lo, cdf, P, W=32, S=64, stride=None, n_threads=1, native=False, out=None):
+    """out = (words, n_words, status) of an earlier call: reuse those buffers (bench.py's cpu_baseline leg keeps the
+    allocation and the first touch of a gigabyte of pages out of its timed region)"""
     symbols = np.ascontiguousarray(symbols, dtype=np.int32)
     n_streams, n = symbols.shape
     cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
     per_stream = cdf.ndim == 2
     n_sym = cdf.shape[-1] - 1
     stride = stride or slab_stride(n, P, W, S)
-    words = np.zeros((n_streams, stride), dtype=np.uint32)
-    n_words = np.zeros(n_streams, dtype=np.uint32)
-    status = np.zeros(n_streams, dtype=np.int32)
+    if out is not None:
+        words, n_words, status = out
+        assert words.shape == (n_streams, stride) and words.dtype == np.uint32 and words.flags.c_contiguous
+    else:
+        words = np.zeros((n_streams, stride), dtype=np.uint32)
+        n_words = np.zeros(n_streams, dtype=np.uint32)
+        status = np.zeros(n_streams, dtype=np.int32)
     load(native).cst_oracle_ans_encode_batch(W, S, P, symbols.reshape(-1), n_streams, n, lo, n_sym, cdf.reshape(-1),
                                              int(per_stream), words.reshape(-1), stride, n_words, status, n_threads)
     return words, n_words, status
 
 
-def ans_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64, lookup=None, n_threads=1, native=False):
+def ans_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64, lookup=None, n_threads=1, native=False, out=None):
+    """out = (decoded, status) of an earlier call: reuse those buffers (see ans_encode_batch)"""
     words = np.ascontiguousarray(words, dtype=np.uint32)
     n_streams, stride = words.shape
     cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
     per_stream = cdf.ndim == 2
     n_sym = cdf.shape[-1] - 1
-    out = np.zeros((n_streams, n_per_stream), dtype=np.int32)
-    status = np.zeros(n_streams, dtype=np.int32)
+    if out is not None:
+        out, status = out
+        assert out.shape == (n_streams, n_per_stream) and out.dtype == np.int32 and out.flags.c_contiguous
+    else:
+        out = np.zeros((n_streams, n_per_stream), dtype=np.int32)
+        status = np.zeros(n_streams, dtype=np.int32)
     lut_ptr = None
     if lookup is not None:
         lookup = np.ascontiguousarray(lookup, dtype=np.uint16)
