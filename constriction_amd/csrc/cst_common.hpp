@@ -93,7 +93,7 @@ struct PtMeta {
     uint16_t pad;
 };
 constexpr int kPtBucketBits = 7, kPtBuckets = 1 << kPtBucketBits;
-constexpr int kPtRowPad = 5;          // sentinel entries behind every decoder row (the decoder reads six entries at a time)
+constexpr int kPtRowPad = 7;          // sentinel entries behind every decoder row (the decoder reads eight entries at a time)
 constexpr uint32_t kPtRunMark = 0xfffu;
 
 } // namespace cst

@@ -24,7 +24,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_pt_decode_loop.inc"
+OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / "cst_pt_decode_loop.inc"
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kPtAhead - 1
@@ -32,8 +32,17 @@ AHEAD_M1 = 23         # kPtAhead - 1
 N0, N1 = "v100", "v101"            # v[100:101] = N
 DD = "v102"                        # v[102:103] = [q - c (0 for a run), 0]
 PR, T0, T1, TT, R0, WD, RA, R1, QK, RA2 = (f"v{r}" for r in range(104, 114))
-X = ["v116", "v117", "v118", "v119", "v126", "v127"]
-X_T, X45_T = "v[116:119]", "v[126:127]"
+# GEN_PT_WINDOW=8 (round 4, measured and NOT adopted): EIGHT consecutive entries per look -- seven candidates + the one that
+# says "further on" -- with the answer taken as the entry of the SMALLEST wrapping distance key - entry (entries above the key
+# wrap to huge distances, the 0xffffffff sentinels behind a row to key + 1, more than any real distance): 7 subtractions + 3
+# v_min3_u32 instead of compare / select pairs, and the distance itself is (q - c) << 20 | ..., so the step's v_sub for q - c is
+# gone.  The continuation rounds of the six-entry window cost 17 % of the kernel (0.22 rounds per wave step on the C3 tables,
+# DESIGN.md 3.8), but the lanes that need them sit in the crowded tails of wide models (8 - 16 entries per bucket), where
+# seven candidates fall short as five do: 0.716 - 0.719 ms against 0.710 ms at 65 536 x 4096 (same box, alternating runs).
+WINDOW = int(os.environ.get("GEN_PT_WINDOW", "6"))
+X = ["v116", "v117", "v118", "v119", "v126", "v127"] if WINDOW == 6 else ["v116", "v117", "v118", "v119", "v172", "v173", "v174", "v175"]
+X_T, X45_T = "v[116:119]", ("v[126:127]" if WINDOW == 6 else "v[172:175]")
+DM, DM2 = "v176", "v177"
 E, PM1, D, IDXA, TS, IDX = (f"v{r}" for r in range(120, 126))
 SYM = [f"v{128 + k}" for k in range(8)]
 XO = [(f"v[{136 + 4 * k}:{139 + 4 * k}]") for k in range(4)]
@@ -41,7 +50,7 @@ PEND = [(f"v[{152 + 4 * k}:{155 + 4 * k}]", [f"v{152 + 4 * k + j}" for j in rang
 LAND = [f"v{164 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v167", "v168", "v169", "v170"
 SD, SAVE, M2, MORE, RUN, M3, M4 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[76:77]", "s[78:79]"
-CLOBBERS = [f"v{r}" for r in range(100, 171)] + [f"s{r}" for r in range(76, 94)] + ["vcc", "scc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 178)] + [f"s{r}" for r in range(76, 94)] + ["vcc", "scc", "memory"]
 
 
 def wait_if_pending(a, tag, comment=None):
@@ -72,45 +81,82 @@ def step(a, j):
     sym_reg = SYM[(quad % 2) * 4 + pos]
     a.wait_lds("l1", f"---- step {j}: first candidate is back")
     a.i(f"v_lshl_add_u32 {RA2}, {R0}, 3, %[rowaddr]")
-    a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "six consecutive entries from the aligned pair that holds the first candidate")
-    a.ds(f"ds_read_b64 {X45_T}, {RA2} offset:16", "x")
-    if pos == 0 and j > 0:
-        base = ((quad - 1) % 2) * 4
-        a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
-    a.wait_lds("x")
-    a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
-    a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
-    a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
-    a.i(f"v_cndmask_b32 {E}, {X[0]}, {X[1]}, vcc")
-    a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
-    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[2]}, {M2}")
-    a.i(f"v_cmp_le_u32_e64 {MORE}, {X[5]}, {QK}", "sixth entry <= q: the bin lies further on")
-    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[3]}, {M3}")
-    a.i(f"s_cmp_lg_u64 {MORE}, 0")
-    a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[4]}, {M4}")
-    a.i("s_branch 4f" if os.environ.get("GEN_NO_MORE") else "s_cbranch_scc0 4f")      # (GEN_NO_MORE: timing experiment only)
-    # wave-uniform continuation for the lanes in MORE (the others re-read their six entries and keep E)
-    a.i("3:")
-    a.i(f"v_cndmask_b32_e64 {TS}, 0, 16, {MORE}")
-    a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fifth entry (8-byte aligned)")
-    a.i(f"ds_read2_b64 {X_T}, {RA2} offset1:1")
-    a.i(f"ds_read_b64 {X45_T}, {RA2} offset:16")
-    a.i("s_waitcnt lgkmcnt(0)")
-    a.i(f"v_cmp_le_u32 vcc, {X[2]}, {QK}", "(the first two are known to be <= q)")
-    a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
-    a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
-    a.i(f"v_cndmask_b32 {TS}, {X[1]}, {X[2]}, vcc")
-    a.i(f"v_cmp_le_u32_e64 {M2}, {X[5]}, {QK}")
-    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[3]}, {M3}")
-    a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[4]}, {M4}")
-    a.i(f"v_cndmask_b32_e64 {E}, {E}, {TS}, {MORE}")
-    a.i(f"s_and_b64 {MORE}, {MORE}, {M2}")
-    a.i(f"s_cmp_lg_u64 {MORE}, 0")
-    a.i("s_cbranch_scc1 3b")
-    a.i("4:")
-    a.i(f"v_sub_u32 {D}, {QK}, {E}")
-    a.i(f"v_bfe_u32 {PM1}, {E}, 8, 12", "p - 1, or the run mark")
-    a.i(f"v_lshrrev_b32 {D}, 20, {D}", "q - c")
+    if WINDOW == 8:
+        a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "eight consecutive entries from the aligned pair that holds the first candidate")
+        a.ds(f"ds_read2_b64 {X45_T}, {RA2} offset0:2 offset1:3", "x")
+        if pos == 0 and j > 0:
+            base = ((quad - 1) % 2) * 4
+            a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+        a.wait_lds("x")
+        a.i(f"v_cmp_le_u32_e64 {MORE}, {X[7]}, {QK}", "eighth entry <= q: the bin lies further on")
+        for i in range(7):
+            a.i(f"v_sub_u32 {X[i]}, {QK}, {X[i]}", "wrapping distance: small and >= 0 for the entries at or below the key" if i == 0 else None)
+        a.i(f"v_min3_u32 {DM}, {X[0]}, {X[1]}, {X[2]}")
+        a.i(f"s_cmp_lg_u64 {MORE}, 0")
+        a.i(f"v_min3_u32 {DM}, {DM}, {X[3]}, {X[4]}")
+        a.i(f"v_min3_u32 {DM}, {DM}, {X[5]}, {X[6]}")
+        a.i("s_branch 4f" if os.environ.get("GEN_NO_MORE") else "s_cbranch_scc0 4f")      # (GEN_NO_MORE: timing experiment only)
+        # wave-uniform continuation for the lanes in MORE (the others re-read their eight entries and keep their distance)
+        a.i("3:")
+        a.i(f"v_cndmask_b32_e64 {TS}, 0, 24, {MORE}")
+        a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the seventh entry (8-byte aligned)")
+        a.i(f"ds_read2_b64 {X_T}, {RA2} offset1:1")
+        a.i(f"ds_read2_b64 {X45_T}, {RA2} offset0:2 offset1:3")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_cmp_le_u32_e64 {M2}, {X[7]}, {QK}")
+        for i in range(7):
+            a.i(f"v_sub_u32 {X[i]}, {QK}, {X[i]}")
+        a.i(f"v_min3_u32 {DM2}, {X[0]}, {X[1]}, {X[2]}")
+        a.i(f"v_min3_u32 {DM2}, {DM2}, {X[3]}, {X[4]}")
+        a.i(f"v_min3_u32 {DM2}, {DM2}, {X[5]}, {X[6]}")
+        a.i(f"v_min_u32 {DM}, {DM}, {DM2}", "(a lane that did not move read the same entries again)")
+        a.i(f"s_and_b64 {MORE}, {MORE}, {M2}")
+        a.i(f"s_cmp_lg_u64 {MORE}, 0")
+        a.i("s_cbranch_scc1 3b")
+        a.i("4:")
+        a.i(f"v_sub_u32 {E}, {QK}, {DM}", "the entry itself")
+        a.i(f"v_bfe_u32 {PM1}, {E}, 8, 12", "p - 1, or the run mark")
+        a.i(f"v_lshrrev_b32 {D}, 20, {DM}", "q - c")
+    else:
+        a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "six consecutive entries from the aligned pair that holds the first candidate")
+        a.ds(f"ds_read_b64 {X45_T}, {RA2} offset:16", "x")
+        if pos == 0 and j > 0:
+            base = ((quad - 1) % 2) * 4
+            a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+        a.wait_lds("x")
+        a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
+        a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
+        a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
+        a.i(f"v_cndmask_b32 {E}, {X[0]}, {X[1]}, vcc")
+        a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
+        a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[2]}, {M2}")
+        a.i(f"v_cmp_le_u32_e64 {MORE}, {X[5]}, {QK}", "sixth entry <= q: the bin lies further on")
+        a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[3]}, {M3}")
+        a.i(f"s_cmp_lg_u64 {MORE}, 0")
+        a.i(f"v_cndmask_b32_e64 {E}, {E}, {X[4]}, {M4}")
+        a.i("s_branch 4f" if os.environ.get("GEN_NO_MORE") else "s_cbranch_scc0 4f")      # (GEN_NO_MORE: timing experiment only)
+        # wave-uniform continuation for the lanes in MORE (the others re-read their six entries and keep E)
+        a.i("3:")
+        a.i(f"v_cndmask_b32_e64 {TS}, 0, 16, {MORE}")
+        a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fifth entry (8-byte aligned)")
+        a.i(f"ds_read2_b64 {X_T}, {RA2} offset1:1")
+        a.i(f"ds_read_b64 {X45_T}, {RA2} offset:16")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_cmp_le_u32 vcc, {X[2]}, {QK}", "(the first two are known to be <= q)")
+        a.i(f"v_cmp_le_u32_e64 {M3}, {X[3]}, {QK}")
+        a.i(f"v_cmp_le_u32_e64 {M4}, {X[4]}, {QK}")
+        a.i(f"v_cndmask_b32 {TS}, {X[1]}, {X[2]}, vcc")
+        a.i(f"v_cmp_le_u32_e64 {M2}, {X[5]}, {QK}")
+        a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[3]}, {M3}")
+        a.i(f"v_cndmask_b32_e64 {TS}, {TS}, {X[4]}, {M4}")
+        a.i(f"v_cndmask_b32_e64 {E}, {E}, {TS}, {MORE}")
+        a.i(f"s_and_b64 {MORE}, {MORE}, {M2}")
+        a.i(f"s_cmp_lg_u64 {MORE}, 0")
+        a.i("s_cbranch_scc1 3b")
+        a.i("4:")
+        a.i(f"v_sub_u32 {D}, {QK}, {E}")
+        a.i(f"v_bfe_u32 {PM1}, {E}, 8, 12", "p - 1, or the run mark")
+        a.i(f"v_lshrrev_b32 {D}, 20, {D}", "q - c")
     a.i(f"v_cmp_eq_u32_e64 {RUN}, {PM1}, %[fff]", "run of unit probabilities: (c, p) = (q, 1)")
     a.i(f"v_add_u32 {PR}, 1, {PM1}")
     a.i(f"v_cndmask_b32_e64 {DD}, {D}, 0, {RUN}")
