@@ -1340,6 +1340,14 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
 }
 
 // small-footprint kernels for batches of more than one wave per SIMD (cst_ans_small.hip)
+// the rest of the reference's (Word, State, PRECISION) grid, compiler-scheduled (cst_ans_generic.hip)
+bool generic_config(cst_coder_config c);
+cst_status ans_encode_generic(const cst_model* m, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                              cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
+                              int32_t* d_status, uint32_t flags, hipStream_t hs);
+cst_status ans_decode_generic(const cst_model* m, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                              size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                              cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, hipStream_t hs);
 // producer / consumer waves for batches of at most one wave of streams per SIMD (cst_ans_pc.hip)
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs);

@@ -255,11 +255,14 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
                                 uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
-    if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if ((!config_supported(cfg) && !generic_config(cfg)) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    if (generic_config(cfg))       // the rest of the reference's type grid (stack.rs:1293-1356): one compiler-scheduled kernel
+        return ans_encode_generic(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status,
+                                  flags, (hipStream_t)stream);
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))   // one table per stream (config C3), compact rows
         return ans_encode_pt(model, cfg, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, d_state, d_status,
                              flags, (hipStream_t)stream);
@@ -286,11 +289,14 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
                                 uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream) {
     if (!model || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
-    if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
+    if ((!config_supported(cfg) && !generic_config(cfg)) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    if (generic_config(cfg))
+        return ans_decode_generic(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream,
+                                  layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))
         return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream,
                              d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);

@@ -238,10 +238,10 @@ __global__ void debug_lcp_kernel(int P, int prob_bits, int32_t lo, int32_t hi, c
 
 static bool cdf_valid(const uint32_t* cdf, int n, int P) {
     if (cdf[0] != 0u) return false;
-    if ((uint64_t)cdf[n] != ((uint64_t)1 << P)) return false;
-    for (int i = 0; i < n; ++i)
+    if (cdf[n] != (uint32_t)((uint64_t)1 << P)) return false;         // (2^32 wraps to 0: Probability = u32 at PRECISION = 32)
+    for (int i = 0; i + 1 < n; ++i)
         if (cdf[i + 1] <= cdf[i]) return false;
-    return true;
+    return P == 32 ? true : cdf[n] > cdf[n - 1];
 }
 
 // Derive the encoder entries, decoder lookup and bucket index from a validated host cdf and
@@ -258,6 +258,7 @@ static cst_status upload_shared_tables(cst_model* m, const uint32_t* cdf) {
     CST_HIP_TRY(hipMalloc(&m->d_enc, sizeof(EncEntry) * (size_t)n));
     CST_HIP_TRY(hipMemcpy(m->d_enc, enc.data(), sizeof(EncEntry) * (size_t)n, hipMemcpyHostToDevice));
 
+    if (P > 24) return CST_OK;     // 24 < P <= 32 is coded by cst_ans_generic.hip from the cumulatives alone
     if (P <= 16) {
         const size_t total = (size_t)1 << P;
         std::vector<uint32_t> cp(total);
@@ -308,7 +309,10 @@ cst_status cst_model_create_table(int32_t precision, int32_t min_symbol, int32_t
                                   cst_model** out) {
     if (!out || !h_cdf) return CST_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (cst_status st = check_model_args(precision, n_symbols)) return st;
+    // (a table may have up to 32 bits of precision -- the u32 / PRECISION = 32 corner of the reference's grid, stack.rs:1293-1296;
+    //  the model families below stop at 24, the Python API's precision)
+    if (precision > 24 && precision <= 32) { if (n_symbols < 2 || n_symbols > 65536) return CST_ERR_MODEL; }
+    else if (cst_status st = check_model_args(precision, n_symbols)) return st;
     if ((int64_t)min_symbol + n_symbols - 1 > INT32_MAX) return CST_ERR_INVALID_ARGUMENT;
     if (!cdf_valid(h_cdf, n_symbols, precision)) return CST_ERR_MODEL;
     int ndev = 0;

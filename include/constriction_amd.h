@@ -19,8 +19,10 @@
  *      (32,64,24) DefaultAnsCoder + the Python API        src/stream/stack.rs:139
  *      (32,64,12) benches/lookup.rs:32-34, BASELINE config C2/C3
  *      (16,32,12) SmallAnsCoder                            src/stream/stack.rs:153
- *    Supported: W=32,S=64,1<=P<=24 and W=16,S=32,1<=P<=16.  Compressed words are always
- *    stored one per uint32_t slot (W=16 words occupy the low half).
+ *    Supported: W=32,S=64,1<=P<=24 and W=16,S=32,1<=P<=16 (hand-scheduled kernels, every entry point), and -- through
+ *    cst_ans_encode_batch / cst_ans_decode_batch with table models -- the rest of the reference's type grid
+ *    (src/stream/stack.rs:1293-1356): W=32,S=64,24<P<=32; W=16,S=64,P<=16; W=8 with S=64, 32 or 16, P<=8.  Compressed
+ *    words are always stored one per uint32_t slot (narrower words occupy the low bits).
  */
 #ifndef CONSTRICTION_AMD_H
 #define CONSTRICTION_AMD_H
