@@ -491,10 +491,13 @@ def ans_decode_ragged(encoded: RaggedBatch, model: Model, sym_offsets: torch.Ten
     return _to_symbols(model, out), status
 
 
-def ans_decode_until(encoded: RaggedBatch, model: Model, eof_symbol: int, max_symbols: int = 1 << 20):
+def ans_decode_until(encoded: RaggedBatch, model: Model, eof_symbol: int, max_symbols: Optional[int] = None):
     """Streams whose length is not stored: every stream is decoded until `eof_symbol` (tests/issue52.rs:63-80).  Two launches
     -- count, prefix sum, decode.  Returns (symbols flat, sym_offsets [n + 1], status); the terminator is the last symbol of
-    every stream; status CAPACITY (2): no terminator among the first max_symbols symbols."""
+    every stream; status CAPACITY (2): no terminator among the first max_symbols symbols -- such a stream (corrupt data, a wrong
+    eof_symbol) decodes to NO symbols: its length is 0 in sym_offsets, so that a batch of bad documents cannot ask for
+    n_streams x max_symbols symbols of output.  max_symbols defaults to 2^20."""
+    max_symbols = (1 << 20) if max_symbols is None else int(max_symbols)
     if model.noncontiguous:
         raise ValueError("ans_decode_until: contiguous alphabets only")
     n_streams = encoded.n_words.numel()
@@ -506,6 +509,7 @@ def ans_decode_until(encoded: RaggedBatch, model: Model, eof_symbol: int, max_sy
                                                 encoded.words.numel(), _ptr(encoded.n_words), n_streams,
                                                 _ptr(order) if order is not None else None, int(eof_symbol), int(max_symbols),
                                                 _ptr(lengths), _ptr(status), _stream_ptr()), "cst_ans_count_until_ordered")
+    lengths = torch.where(status != 0, torch.zeros_like(lengths), lengths)      # (a stream without a terminator is not decoded)
     sym_offsets = torch.zeros(n_streams + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lengths, 0, out=sym_offsets[1:])
     symbols, status2 = ans_decode_ragged(encoded, model, sym_offsets, order=order)

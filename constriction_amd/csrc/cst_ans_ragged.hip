@@ -98,7 +98,10 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
     const bool too_long = sym_hi - sym_lo > 0xffffffffull || sym_hi < sym_lo;
     const uint32_t len = too_long ? 0u : (uint32_t)(sym_hi - sym_lo);
     const uint64_t slab_lo = !active ? 0 : (a.word_offsets ? a.word_offsets[s] : (uint64_t)s * a.stride_words);
-    const uint64_t slab_n = !active ? 0 : (a.word_offsets ? a.word_offsets[s + 1] - slab_lo : (uint64_t)a.stride_words);
+    // (offsets that run backwards -- corrupt metadata -- give the stream a slab of NO words: it reports CST_STREAM_CAPACITY and
+    //  writes nothing, instead of an "unbounded" slab over its neighbours)
+    const uint64_t slab_hi = !active ? 0 : (a.word_offsets ? a.word_offsets[s + 1] : 0);
+    const uint64_t slab_n = !active ? 0 : (a.word_offsets ? (slab_hi >= slab_lo ? slab_hi - slab_lo : 0) : (uint64_t)a.stride_words);
     EncLane<W, S> L;
     L.init(a.words_out + slab_lo, (uint32_t)(slab_n > 0xffffffffull ? 0xffffffffull : slab_n), ring, lane);
     const int32_t* row = a.symbols_in + sym_lo;
@@ -298,6 +301,17 @@ static size_t ragged_decode_table_bytes(const cst_model* m) {
                                                                : ((((size_t)2 << m->bucket_bits) + 15) & ~(size_t)15));
 }
 
+// largest dynamic LDS allocation of a workgroup on the current device (cached per process: the library targets one kind of GPU)
+static size_t device_lds_limit() {
+    static const size_t limit = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+            return (size_t)64 * 1024;
+        return (size_t)v;
+    }();
+    return limit;
+}
+
 template <typename K, typename... Extra>
 static cst_status ragged_launch(K kernel, const RaggedArgs& a, size_t ring_bytes, size_t table_bytes, hipStream_t hs, Extra... extra) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
@@ -315,7 +329,8 @@ static cst_status ragged_launch(K kernel, const RaggedArgs& a, size_t ring_bytes
 #define CST_RAGGED_DISPATCH(KERNEL, RING_BYTES, TABLE_BYTES, ...)                                                                   \
     do {                                                                                                                             \
         const size_t tb_ = (TABLE_BYTES);                                                                                            \
-        const bool staged_ = tb_ <= kRaggedStageLimit;                                                                               \
+        /* the tables are staged if they fit beside the rings in what THIS device gives a workgroup (gfx950: 160 KiB) */             \
+        const bool staged_ = tb_ <= kRaggedStageLimit && (RING_BYTES) + tb_ <= device_lds_limit();                                   \
         const size_t t_ = staged_ ? tb_ : 0;                                                                                         \
         if (cfg.word_bits != 32)                                                                                                     \
             return staged_ ? ragged_launch(KERNEL<16, 32, true, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__)                        \

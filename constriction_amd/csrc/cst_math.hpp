@@ -246,6 +246,8 @@ __device__ inline double erf_exact_tab(double x, const double2* tab) {
 
 constexpr double kErfFastBound = 0x1p-46;    // assumed (and tested) bound on |erf_fast_poly - erf_exact_tab|
 constexpr double kLeftGuard = 0x1p-20;       // >= 2^24 * kErfFastBound / 2 + rounding of the two products, with room to spare
+constexpr int kQuickMaxPrecision = 24;       // the guard is sound for free_weight <= 2^24 only: callers of the *_quick functions keep P <= 24
+                                             // (check_model_args, config_supported, and the debug hook below enforce it)
 
 // 1 / b to 2^-48 (v_rcp_f64 is good to 2^-24.4 on gfx950, scripts/microbench/rcp_f64_error.hip; one Newton step): enough wherever the consumer has slack of its own -- the argument of the fast erf (an
 // argument off by 2^-48 moves erf by < 2^-49), quotients that are corrected by their exact remainder

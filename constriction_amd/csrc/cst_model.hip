@@ -530,7 +530,7 @@ cst_status cst_debug_erf_fast(int32_t which, const double* d_x, double* d_out, s
 
 cst_status cst_debug_gaussian_left_quick(int32_t precision, int32_t min_symbol, int32_t max_symbol, const int32_t* d_index,
                                          const double* d_means, const double* d_stds, size_t n, uint64_t* d_counts, void* stream) {
-    if (!d_index || !d_means || !d_stds || !d_counts || precision < 1 || precision > 32 || max_symbol <= min_symbol) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_index || !d_means || !d_stds || !d_counts || precision < 1 || precision > kQuickMaxPrecision || max_symbol <= min_symbol) return CST_ERR_INVALID_ARGUMENT;
     if (n == 0) return CST_OK;
     hipLaunchKernelGGL(debug_left_quick_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, precision, min_symbol,
                        (int32_t)((int64_t)max_symbol - min_symbol + 1), d_index, d_means, d_stds, n, reinterpret_cast<unsigned long long*>(d_counts));

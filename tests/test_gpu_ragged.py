@@ -80,13 +80,17 @@ def test_ragged_like_the_reference_index(B, O):
     dec2, off2, status2 = B.ans_decode_until(enc, model, eof)
     torch.cuda.synchronize()
     assert (status2.cpu().numpy() == 0).all() and torch.equal(off2, offsets) and torch.equal(dec2, dec)
-    # a limit below the longest document: those streams report CAPACITY and the limit, the others are unaffected
+    # a limit below the longest document: those streams report CAPACITY and decode to NOTHING (a batch of documents without a
+    # terminator -- corrupt data, a wrong eof symbol -- must not ask for n_streams x max_symbols symbols), the others are unaffected
     dec3, off3, status3 = B.ans_decode_until(enc, model, eof, max_symbols=100)
     lens, lens3 = np.diff(off), np.diff(off3.cpu().numpy())
-    assert lens3.tolist() == np.minimum(lens, 100).tolist()
+    assert lens3.tolist() == np.where(lens > 100, 0, lens).tolist()
     assert status3.cpu().tolist() == [2 if n > 100 else 0 for n in lens]
     o3 = dec3.cpu().numpy()
     assert all(o3[off3[s]: off3[s + 1]].tolist() == out[off[s]: off[s] + lens3[s]].tolist() for s in range(len(docs)))
+    # no document has a terminator at all (a wrong eof symbol): nothing is decoded, every stream says so
+    dec4, off4, status4 = B.ans_decode_until(enc, model, eof + 5, max_symbols=1 << 16)
+    assert dec4.numel() == 0 and int(off4[-1]) == 0 and (status4.cpu().numpy() == 2).all()
 
 
 def test_ragged_status_and_bounds(B, O):
@@ -113,6 +117,24 @@ def test_ragged_status_and_bounds(B, O):
     assert torch.equal(dec[off[3]: off[4]], ref[off[3]: off[4]]) and torch.equal(dec[: off[1]], ref[: off[1]])
     empty = B.ans_encode_ragged(torch.zeros(0, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), model, (32, 64, P))
     assert empty.n_words.numel() == 0
+    # word offsets that run BACKWARDS (corrupt metadata on the encoder side): that stream gets a slab of no words -- CAPACITY,
+    # nothing written -- instead of an "unbounded" one over its neighbours
+    import ctypes as C
+    from constriction_amd import _native as N
+    flat, offsets = good
+    n = offsets.numel() - 1
+    woff = torch.tensor([0, 64, 32, 512, 1024], dtype=torch.int64, device="cuda")      # stream 1: [64, 32)
+    words = torch.full((2048,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    n_words = torch.zeros(n, dtype=torch.int32, device="cuda")
+    status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    N.check(N.lib().cst_ans_encode_ragged(model._h, N.CoderConfig(32, 64, P), p(flat), p(offsets), n, p(words), p(woff), 0, p(n_words), p(status), None),
+            "cst_ans_encode_ragged")
+    torch.cuda.synchronize()
+    assert status.cpu().tolist()[1] == 2 and n_words.cpu().tolist()[1] == 0
+    assert status.cpu().tolist()[0] == 0 and status.cpu().tolist()[3] == 0
+    w = words.cpu().numpy()
+    assert (w[1024:] == 0x5A5A5A5A).all() and (w[32:64][n_words.cpu().numpy()[0]:] == 0x5A5A5A5A).all()
 
 
 @pytest.mark.parametrize("cfg,n_sym", [((32, 64, 6), 40), ((16, 32, 5), 20), ((32, 64, 16), 5000), ((32, 64, 20), 20000), ((16, 32, 16), 5000),
