@@ -9,9 +9,10 @@ emits the counts, so that moving an instruction cannot silently break a wait.
 
 Run:  python scripts/gen_decode_loop.py   (rewrites the .inc; the .inc is checked in)
 """
+import os
 from pathlib import Path
 
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop.inc"
+OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / "cst_decode_loop.inc"
 OUT_SM = OUT.with_name("cst_decode_loop_sm.inc")
 # SYMBOL_MAJOR (cst_decode_loop_sm.inc): symbols[t][stream].  Only the way the previous tile leaves differs: quad k reads
 # tile[32 (k & 1) + 4 (lane & 7) + c][(lane >> 3) + 8 (k >> 1)], c = 0..3 (four ds_read_b32, two lanes per bank) and stores the
@@ -29,6 +30,7 @@ K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits =
 AHEAD_M1 = 23         # kDecAhead - 1  (want_lo = max(rd + shift - kDecAhead, 0) = sat_sub(rd + (shift-1), kDecAhead-1))
 
 
+import os
 import sys
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
