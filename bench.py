@@ -755,7 +755,8 @@ def main():
     n_sym = n_streams * N_PER
     # algorithmic bytes per launch: 4 B per int32 symbol + 4 B per compressed word, each way
     bytes_per_launch = 4 * n_sym + 4 * total_words
-    dominant, dom_ms = ("ans_encode_kernel", enc_ms) if enc_ms >= dec_ms else ("ans_decode_kernel", dec_ms)
+    # (the C2 shape takes the producer / consumer encoder, cst_ans_pc.hip: coder waves + helper waves)
+    dominant, dom_ms = ("ans_encode_pc_kernel", enc_ms) if enc_ms >= dec_ms else ("ans_decode_kernel", dec_ms)
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
 
     ok = True
@@ -826,7 +827,7 @@ def main():
                 traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this command, scripts/pmc_all.sh)"
             except Exception:
                 traffic = None
-        dom_cold_ms = cold["encode_ms"] if dominant == "ans_encode_kernel" else cold["decode_ms"]
+        dom_cold_ms = cold["encode_ms"] if dominant == "ans_encode_pc_kernel" else cold["decode_ms"]
         line = {
             "metric": "Msymbols/s encode+decode, 64k x 4k-symbol streams, bit-exact vs CPU",
             "value": round(world * n_sym * args.steps / elapsed / 1e6, 1),

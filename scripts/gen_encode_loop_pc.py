@@ -204,6 +204,10 @@ H_CLOBBERS = [f"v{r}" for r in range(HBASE, 255)] + [f"s{r}" for r in range(80, 
 HTR = ["%[tr0]", "%[tr1]"]
 
 
+HLOAD_MOD = os.environ.get("GEN_HLOAD_MOD", "nt")       # cache policy of the symbol loads (experiment: "", "sc0", "sc1", "sc0 sc1", "nt sc1" ...)
+HSTORE_MOD = os.environ.get("GEN_HSTORE_MOD", "")       # ... and of the word stores
+
+
 def h_advance_base(a):
     """s[80:81] -> symbols of the next tile to request; stays on the last one (the FIRST 32 symbols of the rows) once every
     tile has been requested"""
@@ -217,7 +221,7 @@ def h_advance_base(a):
 
 def h_load_set(a, name):
     for k in range(8):
-        a.vmem(f"global_load_dwordx4 {HR[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
+        a.vmem(f"global_load_dwordx4 {HR[name][k]}, %[goff{k}], s[80:81] {HLOAD_MOD}".rstrip(), f"ld{name}")
     h_advance_base(a)
 
 
@@ -246,7 +250,7 @@ def h_flush(a):
     a.wait_lds("fl")
     a.i(f"s_and_saveexec_b64 {HSAVE}, vcc")
     for k in range(4):
-        a.vmem(f"global_store_dwordx4 {HFOFF}, {HFD[k][2]}, %[wbase] offset:{16 * k}", "st")
+        a.vmem(f"global_store_dwordx4 {HFOFF}, {HFD[k][2]}, %[wbase] offset:{16 * k} {HSTORE_MOD}".rstrip(), "st")
     a.i(f"s_mov_b64 exec, {HSAVE}")
     a.i(f"v_lshl_add_u32 %[flushed], {HNCH}, 4, %[flushed]")
 
