@@ -20,11 +20,17 @@ g = ROOT / "gpurun_out"
 
 
 def pmc(dirname):
-    rows = list(csv.DictReader(open(g / dirname / "pmc_counter_collection.csv")))
+    """counter averages per kernel over its FULL-SIZE dispatches only (largest grid): one kernel name serves several workloads
+    of a bench run -- the headline batch, the end-to-end leg's chunks of an eighth of it, the tuner's launches -- and an average
+    over all of them describes none"""
+    rows = [r for r in csv.DictReader(open(g / dirname / "pmc_counter_collection.csv")) if "cst::" in r["Kernel_Name"]]
+    biggest = collections.defaultdict(int)
+    for r in rows:
+        biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r["Grid_Size"]))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k = r["Kernel_Name"]
-        if "cst::" in k:
+        if int(r["Grid_Size"]) == biggest[k]:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
@@ -43,10 +49,24 @@ bench = json.loads((g / f"{tag}_stats" / "bench.json").read_text())
 # holds the first launches and bench.py's three `after_cache_flush` launches per headline kernel)
 import statistics
 durations = collections.defaultdict(list)
+by_grid = collections.defaultdict(list)
 trace = g / f"{tag}_stats" / "bench_kernel_trace.csv"
 if trace.exists():
     for r in csv.DictReader(open(trace)):
-        durations[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        if "cst::" in r["Kernel_Name"]:
+            by_grid[(r["Kernel_Name"], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    top = collections.defaultdict(int)
+    for (k, gs) in by_grid:
+        top[k] = max(top[k], gs)
+    for (k, gs), v in by_grid.items():
+        if gs == top[k]:
+            durations[k] = v            # full-size dispatches only
+    # one row per (kernel, grid size): the --stats table averages over every workload a kernel name serves
+    with open(out / f"{tag}_kernel_stats_by_grid.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Grid_Size_X", "Calls", "AverageUs", "MedianUs", "MinUs", "MaxUs"])
+        for (k, gs), v in sorted(by_grid.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k.split("(")[0].replace("void ", ""), gs, len(v), round(sum(v) / len(v), 1), round(statistics.median(v), 1), round(min(v), 1), round(max(v), 1)])
 
 fetch, write, l2 = pmc(f"{tag}_fetch"), pmc(f"{tag}_write"), pmc(f"{tag}_l2")
 traffic = {}
@@ -57,7 +77,9 @@ lines = [f"# {tag}: rocprofv3 summary of `python bench.py --steps 20 --warmup 3 
          "`ans_*_pt_kernel` = C3 (per-stream tables); `ans_*_small_kernel` = C5 shard (131072 streams); `compact_kernel` = packing.", "",
          f"bench line: value = {bench['value']} Msym/s, encode {bench['encode_ms']} ms, decode {bench['decode_ms']} ms, "
          f"algorithmic bytes/launch = {bench['roofline']['algorithmic_bytes_per_launch']}", "",
-         "| kernel | calls | avg us (--stats) / median us (trace) | FETCH_SIZE KiB | x2 corrected GiB | WRITE_SIZE KiB | HBM bytes/launch (corr.) | algorithmic | L2 hit |",
+         "Counters and medians are over a kernel's FULL-SIZE dispatches (largest grid) only; `--stats` averages are over all its launches",
+         f"(`profiles/{tag}_kernel_stats_by_grid.csv` has one row per kernel and grid size).", "",
+         "| kernel | calls | avg us (--stats) / median us (trace, full size) | FETCH_SIZE KiB | x2 corrected GiB | WRITE_SIZE KiB | HBM bytes/launch (corr.) | algorithmic | L2 hit |",
          "|---|---|---|---|---|---|---|---|---|"]
 for r in ours:
     k = r["Name"]

@@ -45,7 +45,10 @@ lines = [f"# {tag}: SQ counters of the coder kernels at 65 536 streams x 4096 sy
          "",
          "Collected with `scripts/final_profiles.sh` (`scripts/pmc_all.sh`, `pmc_c3.sh`, `pmc_per_symbol.sh`: rocprofv3 --pmc, several passes per",
          "kernel, counters never share a run with a trace).  Per symbol and WAVE: cycle counters x 4 / (waves x 4096 symbols), instruction",
-         "counters / (waves x 4096).  One wave per SIMD (1024 waves) except the fused per-symbol encoder (2048 waves of 32 streams).",
+         "counters / (waves x 4096).  One wave per SIMD (1024 waves) except the fused per-symbol encoder (2048 waves of 32 streams)",
+         "and the producer / consumer encoder `ans_encode_pc_kernel` (2048 waves: a CODER and a HELPER wave per 64 streams; its row is the",
+         "average over both kinds -- per pair: twice the instruction counts, i.e. 23.6 VALU + 2.8 LDS per symbol, nearly all of the VALU",
+         "in the coder; the helper's share of the wave cycles is mostly WAIT_ANY, parked at the per-tile barrier).",
          "",
          "| configuration | kernel | wave cycles | VALU instr | VALU cycles | LDS instr | LDS cycles | SALU instr | WAIT_ANY | WAIT_INST_ANY | LDS bank-conflict cycles |",
          "|---|---|---|---|---|---|---|---|---|---|---|"]
