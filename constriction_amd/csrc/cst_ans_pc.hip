@@ -48,10 +48,75 @@ __device__ __forceinline__ void ans_encode_pc_helper_loop(uint32_t& flushed, con
 #include "cst_encode_loop_pc_helper.inc"
 }
 
+__device__ __forceinline__ void ans_encode_pc_loader_loop(const uint32_t (&tile_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
+                                                          uint32_t n_tiles, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_pc_loader.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_storer_loop(uint32_t (&flushed)[2], const uint32_t (&ring_lane_addr)[2], const uint32_t (&publish_addr)[2],
+                                                          uint32_t cap, const uint32_t (&slab_off)[2], const void* words_base, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_storer.inc"
+}
+
 // LDS hand-off between the two halves of a workgroup: this wave's LDS operations have completed, then the barrier.  (Not
 // __syncthreads(): its fence would also wait for the helper's symbol loads, which are requested tiles ahead on purpose.)
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// the helper waves of a workgroup split by role: waves 4, 5 load and stage the tiles of coder waves (0, 1), (2, 3); waves 6, 7
+// flush their rings and finish their streams
+__device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned char* smem, int wave, int lane, uint32_t n_t) {
+    const size_t N = a.n_per_stream;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
+    if (wave < kPcWaves + 2) {                          // ---- loader ----
+        uint32_t goff[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (size_t)(n_t - 1) * kTileSyms);
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+        const uint32_t t0 = lds_addr(smem + kPcTileOff + (2 * cw0) * kPcTileBytes) + tr_off;
+        const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcTileBytes};
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N * 4));
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
+        ans_encode_pc_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
+        pc_barrier();
+        return;
+    }
+    // ---- storer ----
+    uint32_t* ring[2]; uint32_t* hand[2];
+    uint32_t ring_addr[2], pub_addr[2], slab_off[2], flushed[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        ring[c] = reinterpret_cast<uint32_t*>(smem + kPcRingOff + (cw0 + c) * kPcRingWaveBytes);
+        hand[c] = reinterpret_cast<uint32_t*>(smem + kPcHandOff + (cw0 + c) * kPcHandWaveBytes);
+        hand[c][lane] = 0;                              // nothing published yet
+        ring_addr[c] = lds_addr(ring[c] + lane);
+        pub_addr[c] = lds_addr(hand[c] + lane);
+        slab_off[c] = (uint32_t)((s0 + c * kWave + lane) * a.stride_words * 4);
+    }
+    ans_encode_pc_storer_loop(flushed, ring_addr, pub_addr, (uint32_t)a.stride_words, slab_off, a.words, n_t);
+    pc_barrier();                                       // the coders have published their last write positions and final states
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const size_t s = s0 + c * kWave + lane;
+        EncLane<32, 64> L;
+        L.init(a.words + s * a.stride_words, (uint32_t)a.stride_words, ring[c], lane);
+        L.out.flushed = flushed[c];
+        L.out.wr = hand[c][lane];
+        L.state = ((uint64_t)hand[c][2 * kWave + lane] << 32) | hand[c][kWave + lane];
+        L.bad = hand[c][3 * kWave + lane];
+        uint32_t n_words = 0;
+        const int32_t status = L.finish(!raw, (uint32_t)a.n_symbols, n_words);
+        if (raw) a.state[s] = (uint64_t)L.state;
+        a.status[s] = status;
+        a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+    }
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -89,7 +154,9 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
         return;
     }
 
-    // ---- helper ----
+    if (SPLIT) { pc_split_helper(a, smem, wave, lane, n_t); return; }
+
+    // ---- helper (combined: loads, staging and flush of its own coder wave) ----
     EncLane<32, 64> L;
     L.init(a.words + s * a.stride_words, (uint32_t)a.stride_words, ring, lane);
     hand[lane] = 0;                                     // nothing published yet
@@ -132,8 +199,10 @@ bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout l
 
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs) {
     const size_t blocks = a.n_streams / kBlock;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
-    hipLaunchKernelGGL(ans_encode_pc_kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a);
+    static const bool combined = getenv("CST_PC_COMBINED") != nullptr;      // (A/B runs: every helper wave loads AND stores)
+    auto kernel = combined ? ans_encode_pc_kernel<false> : ans_encode_pc_kernel<true>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

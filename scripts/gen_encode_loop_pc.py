@@ -250,12 +250,14 @@ def h_flush(a):
     a.wait_lds("fl")
     a.i(f"s_and_saveexec_b64 {HSAVE}, vcc")
     for k in range(4):
+        if "nostores" in HABL:
+            break
         a.vmem(f"global_store_dwordx4 {HFOFF}, {HFD[k][2]}, %[wbase] offset:{16 * k} {HSTORE_MOD}".rstrip(), "st")
     a.i(f"s_mov_b64 exec, {HSAVE}")
     a.i(f"v_lshl_add_u32 %[flushed], {HNCH}, 4, %[flushed]")
 
 
-HABL = set((os.environ.get("GEN_HABL") or "").split("+")) - {""}      # timing experiments (results wrong): noflush, nostage, noloads
+HABL = set((os.environ.get("GEN_HABL") or "").split("+")) - {""}      # timing experiments (results wrong): noflush, nostage, noloads, nostores
 
 
 PAIRS = bool(os.environ.get("GEN_PAIRS"))     # experiment: request TWO tiles (256 contiguous bytes per row) every other window (needs NSETS = 5)
@@ -335,9 +337,235 @@ def main_helper():
         print("  note:", n)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# SPLIT helpers (cst_encode_loop_pc_loader.inc / cst_encode_loop_pc_storer.inc).  Loads and stores of one wave retire through
+# ONE in-order counter (vmcnt): the combined helper's wait for a tile requested three windows ago also waits for the word
+# stores it issued in between, and a store's acknowledgement under load takes longer than a window (measured: helper without
+# its loads 0.251 ms, without its stores 0.254 ms, with both 0.275 ms).  So the four helper waves of a workgroup split by ROLE
+# instead of by stream: waves 4 and 5 only LOAD and stage (each for two coder waves), waves 6 and 7 only FLUSH (each for two
+# coder waves).  A loader's vmcnt sees loads only; a storer never waits for its stores inside the loop.
+# ---------------------------------------------------------------------------------------------------------------------
+OUT_LOADER = CSRC / "cst_encode_loop_pc_loader.inc"
+OUT_STORER = CSRC / "cst_encode_loop_pc_storer.inc"
+LSETS = int(os.environ.get("GEN_LSETS", "2"))           # register sets per coder wave in a loader (a tile is requested LSETS windows before it is staged)
+LBASE = 228 - 64 * LSETS
+LR = {(c, i): [tup(LBASE + 32 * (LSETS * c + i) + 4 * k) for k in range(8)] for c in range(2) for i in range(LSETS)}
+L_CLOBBERS = [f"v{r}" for r in range(LBASE, 228)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "memory"]
+PAIR_TILE_OFF = 2 * 64 * 36 * 4                          # the partner coder's two tile buffers follow this one's
+
+
+def l_load(a, i):
+    for c in range(2):
+        base = "s[80:81]" if c == 0 else "s[84:85]"
+        for k in range(8):
+            if "noloads" not in HABL:
+                a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
+    a.i("s_cmp_lg_u32 s83, 0")
+    a.i(f"s_cselect_b32 s88, {'0' if 'loadsame' in HABL else '0x80'}, 0")
+    a.i("s_cselect_b32 s89, 1, 0")
+    a.i("s_sub_u32 s80, s80, s88")
+    a.i("s_subb_u32 s81, s81, 0")
+    a.i("s_sub_u32 s84, s84, s88")
+    a.i("s_subb_u32 s85, s85, 0")
+    a.i("s_sub_u32 s83, s83, s89")
+
+
+def l_stage(a, i, buf):
+    for c in range(2):
+        if "noloads" not in HABL:
+            a.wait_vm(f"ld{c}{i}", f"coder {c}: symbols in set {i} have arrived")
+        for k in range(8):
+            a.ds(f"ds_write_b128 {HTR[buf]}, {LR[(c, i)][k]} offset:{PAIR_TILE_OFF * c + 1152 * k}", "tl")
+
+
+def gen_loader():
+    a = Asm()
+    a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST full tile of the pair's first stream: tile 0")
+    a.i("s_add_u32 s84, s80, %[rowblock]", "... and of the second coder wave's first stream")
+    a.i("s_addc_u32 s85, s81, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "windows left")
+    a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
+    for i in range(LSETS):
+        l_load(a, i)
+    l_stage(a, 0, 0)
+    l_load(a, 0)
+    a.wait_lds_all("tile 0 is staged (and the table, by everybody)")
+    a.i("s_barrier")
+    a.i("1:")
+    first = len(a.events)
+    period = LSETS * 2 if LSETS % 2 else LSETS
+    for w in range(period):
+        i, buf = (w + 1) % LSETS, (w + 1) & 1
+        a.i(f"; ---- window {w}: sets {i} -> tile buffers {buf}")
+        l_stage(a, i, buf)
+        l_load(a, i)
+        a.wait_lds_all("the tiles are staged")
+        a.i("s_barrier")
+        a.i("s_sub_u32 s82, s82, 1")
+        if w < period - 1:
+            a.i("s_cmp_eq_u32 s82, 0")
+            a.i("s_cbranch_scc1 2f")
+        else:
+            a.i("s_cmp_lg_u32 s82, 0")
+            a.i("s_cbranch_scc1 1b")
+    lds_end, vm_end, notes = a.verify_loop(first, a.lds, a.vm, passes=1)
+    assert HABL or (lds_end == a.lds and vm_end == a.vm), (vm_end, a.vm)
+    a.i("2:")
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all()
+    return a, notes
+
+
+SQUAD = not os.environ.get("GEN_SROW")                  # lanes 4 j .. 4 j + 3 store the four 16-byte chunks of stream 16 k + j's group (one 64-byte request), k = 0 .. 3
+SFD = {c: [(tup(196 + 16 * c + 4 * k, 2), tup(198 + 16 * c + 4 * k, 2), tup(196 + 16 * c + 4 * k)) for k in range(4)] for c in range(2)}
+SWR, SNCH, SLIM, SFADDR, SFOFF, SXQ, SCOL0, SQOFF0 = ({c: f"v{r + 12 * c}" for c in range(2)} for r in range(228, 236))
+SXS = {c: [f"v{236 + 12 * c + k}" for k in range(4)] for c in range(2)}
+SC4I, SBPA = "v252", "v253"
+SSAVE = {0: "s[86:87]", 1: "s[88:89]"}
+SQBASE = ["%[wbase]", "s[90:91]", "s[92:93]", "s[94:95]"]
+S_CLOBBERS = [f"v{r}" for r in range(196, 254)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "memory"]
+
+
+def s_flush_rows(a):
+    """for both coder waves of the pair: one complete 64-byte group below the published write position, ring -> slab;
+    every lane its own stream's group (four 16-byte pieces of ~26 different cache lines per store instruction)"""
+    for c in range(2):
+        a.ds(f"ds_read_b32 {SWR[c]}, %[pub{c}]", f"pub{c}")
+    for c in range(2):
+        a.wait_lds(f"pub{c}")
+        a.i(f"v_sub_u32 {SNCH[c]}, {SWR[c]}, %[flushed{c}]")
+        a.i(f"v_lshrrev_b32 {SNCH[c]}, 4, {SNCH[c]}", "whole 16-word groups pending: 0 or 1")
+        for k in range(4):
+            a.i(f"v_add_lshl_u32 {SFADDR[c]}, %[flushed{c}], {4 * k}, 8")
+            a.i(f"v_and_or_b32 {SFADDR[c]}, {SFADDR[c]}, %[c3f00], %[lanebase{c}]")
+            a.ds(f"ds_read2st64_b32 {SFD[c][k][0]}, {SFADDR[c]} offset1:1", f"fl{c}")
+            a.ds(f"ds_read2st64_b32 {SFD[c][k][1]}, {SFADDR[c]} offset0:2 offset1:3", f"fl{c}")
+        a.i(f"v_add_u32 {SLIM[c]}, 16, %[flushed{c}]")
+        a.i(f"v_lshl_add_u32 {SFOFF[c]}, %[flushed{c}], 2, %[slaboff{c}]")
+        if "storesame" in HABL:
+            a.i(f"v_mov_b32 {SFOFF[c]}, %[slaboff{c}]")
+    for c in range(2):
+        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap]", "group inside the slab")
+        a.i(f"v_cmp_ne_u32 {SSAVE[c]}, 0, {SNCH[c]}")
+        a.i(f"s_and_b64 vcc, vcc, {SSAVE[c]}")
+        a.wait_lds(f"fl{c}")
+        a.i(f"s_and_saveexec_b64 {SSAVE[c]}, vcc")
+        for k in range(4):
+            if "nostores" in HABL:
+                break
+            a.vmem(f"global_store_dwordx4 {SFOFF[c]}, {SFD[c][k][2]}, %[wbase] offset:{16 * k} {HSTORE_MOD}".rstrip(), "st")
+        a.i(f"s_mov_b64 exec, {SSAVE[c]}")
+        a.i(f"v_lshl_add_u32 %[flushed{c}], {SNCH[c]}, 4, %[flushed{c}]")
+
+
+def s_quad_invariants(a):
+    """what depends on the lane only: lane 4 j + i moves chunk i of the streams 16 k + j"""
+    a.i(f"v_mbcnt_lo_u32_b32 {SC4I}, -1, 0")
+    a.i(f"v_mbcnt_hi_u32_b32 {SC4I}, -1, {SC4I}", "lane")
+    a.i(f"v_and_b32 {SBPA}, 0xfc, {SC4I}", "4 (lane >> 2): ds_bpermute address of stream (lane >> 2)")
+    for c in range(2):
+        a.i(f"v_lshlrev_b32 {SCOL0[c]}, 2, {SC4I}")
+        a.i(f"v_sub_u32 {SCOL0[c]}, %[lanebase{c}], {SCOL0[c]}", f"ring of coder wave {c}")
+        a.i(f"v_add_u32 {SCOL0[c]}, {SCOL0[c]}, {SBPA}", "ring column of stream (lane >> 2)")
+        a.ds(f"ds_bpermute_b32 {SQOFF0[c]}, {SBPA}, %[slaboff{c}]", "bp0")
+    a.i(f"v_and_b32 {SC4I}, 3, {SC4I}")
+    a.i(f"v_lshlrev_b32 {SC4I}, 2, {SC4I}", "4 (lane & 3): first of this lane's four words in a group")
+    a.i("v_readlane_b32 s88, %[slaboff0], 16")
+    a.i("v_readlane_b32 s89, %[slaboff0], 0")
+    a.i("s_sub_u32 s88, s88, s89", "bytes from stream s to stream s + 16 (slabs are equally spaced)")
+    a.i("s_mov_b64 s[90:91], %[wbase]")
+    a.i("s_add_u32 s90, s90, s88")
+    a.i("s_addc_u32 s91, s91, 0")
+    a.i("s_add_u32 s92, s90, s88")
+    a.i("s_addc_u32 s93, s91, 0")
+    a.i("s_add_u32 s94, s92, s88")
+    a.i("s_addc_u32 s95, s93, 0")
+    a.wait_lds("bp0")
+    for c in range(2):
+        a.i(f"v_lshl_add_u32 {SQOFF0[c]}, {SC4I}, 2, {SQOFF0[c]}", "slab offset of stream (lane >> 2) + 16 (lane & 3)")
+
+
+def s_flush_quads(a):
+    """for both coder waves of the pair: the complete 64-byte groups below the published write positions, ring -> slab;
+    lanes 4 j .. 4 j + 3 move the group of stream 16 k + j (one 64-byte request), k = 0 .. 3"""
+    for c in range(2):
+        a.ds(f"ds_read_b32 {SWR[c]}, %[pub{c}]", f"pub{c}")
+    for c in range(2):
+        a.wait_lds(f"pub{c}")
+        a.i(f"v_sub_u32 {SNCH[c]}, {SWR[c]}, %[flushed{c}]")
+        a.i(f"v_add_u32 {SLIM[c]}, 16, %[flushed{c}]")
+        a.i(f"v_lshrrev_b32 {SNCH[c]}, 4, {SNCH[c]}", "whole 16-word groups pending: 0 or 1")
+        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap]", "group inside the slab")
+        a.i(f"v_cndmask_b32_e64 {SLIM[c]}, 0, {SNCH[c]}, vcc")
+        a.i(f"v_lshl_or_b32 {SXQ[c]}, {SLIM[c]}, 31, %[flushed{c}]", "flush position | (a group leaves) << 31")
+        for k in range(4):
+            a.ds(f"ds_bpermute_b32 {SXS[c][k]}, {SBPA}, {SXQ[c]} offset:{64 * k}", f"bp{c}", f"... of stream {16 * k} + (lane >> 2)")
+        a.i(f"v_lshl_add_u32 %[flushed{c}], {SNCH[c]}, 4, %[flushed{c}]", "(a group outside the slab is dropped: the stream ends CAPACITY)")
+    for c in range(2):
+        a.wait_lds(f"bp{c}")
+        for k in range(4):
+            a.i(f"v_add_lshl_u32 {SFADDR[c]}, {SXS[c][k]}, {SC4I}, 8", "(bit 31 leaves)")
+            a.i(f"v_and_or_b32 {SFADDR[c]}, {SFADDR[c]}, %[c3f00], {SCOL0[c]}")
+            a.ds(f"ds_read2_b32 {SFD[c][k][0]}, {SFADDR[c]} offset0:{16 * k} offset1:{64 + 16 * k}", f"fl{c}")
+            a.ds(f"ds_read2_b32 {SFD[c][k][1]}, {SFADDR[c]} offset0:{128 + 16 * k} offset1:{192 + 16 * k}", f"fl{c}")
+    for c in range(2):
+        a.wait_lds(f"fl{c}")
+        for k in range(4):
+            a.i(f"v_lshl_add_u32 {SFOFF[c]}, {SXS[c][k]}, 2, {SQOFF0[c]}")
+            if "storesame" in HABL:
+                a.i(f"v_mov_b32 {SFOFF[c]}, {SQOFF0[c]}")
+            a.i(f"v_cmp_gt_i32 vcc, 0, {SXS[c][k]}")
+            a.i(f"s_and_saveexec_b64 {SSAVE[c]}, vcc")
+            if "nostores" not in HABL:
+                a.vmem(f"global_store_dwordx4 {SFOFF[c]}, {SFD[c][k][2]}, {SQBASE[k]} {HSTORE_MOD}".rstrip(), "st")
+            a.i(f"s_mov_b64 exec, {SSAVE[c]}")
+
+
+def gen_storer():
+    a = Asm()
+    a.i("s_mov_b32 s82, %[ntiles]", "windows left")
+    if SQUAD:
+        s_quad_invariants(a)
+    a.wait_lds_all("nothing published yet (and the table, by everybody)")
+    a.i("s_barrier")
+    a.i("1:")
+    (s_flush_quads if SQUAD else s_flush_rows)(a)
+    a.wait_lds_all()
+    a.i("s_barrier")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.i("s_cbranch_scc1 1b")
+    a.wait_vm_all("the stores of the loop (the wave's last groups follow from C++)")
+    return a, []
+
+
+def main_split():
+    a, notes = gen_loader()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Loader wave of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_loader_loop in cst_ans_pc.hip."]
+    ops = ['    :',
+           '    : [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]), [sbase] "s"(symbols_base), [rowblock] "s"(row_block_bytes), [ntiles] "s"(n_tiles),',
+           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in L_CLOBBERS) + ");"]
+    OUT_LOADER.write_text(a.render(header, ops))
+    print(f"wrote {OUT_LOADER} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+    a, notes = gen_storer()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Storer wave of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_storer_loop in cst_ans_pc.hip."]
+    ops = ['    : [flushed0] "+v"(flushed[0]), [flushed1] "+v"(flushed[1])',
+           '    : [lanebase0] "v"(ring_lane_addr[0]), [lanebase1] "v"(ring_lane_addr[1]), [pub0] "v"(publish_addr[0]), [pub1] "v"(publish_addr[1]),',
+           '      [cap] "v"(cap), [slaboff0] "v"(slab_off[0]), [slaboff1] "v"(slab_off[1]), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base), [ntiles] "s"(n_tiles)',
+           "    : " + ", ".join(f'"{c}"' for c in S_CLOBBERS) + ");"]
+    OUT_STORER.write_text(a.render(header, ops))
+    print(f"wrote {OUT_STORER} ({a.n_instr()} instructions incl. prologue)")
+
+
 def main_all():
     main()
     main_helper()
+    main_split()
 
 
 if __name__ == "__main__":

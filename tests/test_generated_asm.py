@@ -131,10 +131,13 @@ def test_wait_bookkeeping_rejects_unreachable_counts():
 
 def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
     """the coder and helper halves of the producer / consumer encoder (cst_ans_pc.hip)"""
-    for var in ("GEN_NO_BARRIER", "GEN_PRIO", "GEN_HABL", "GEN_NSETS", "GEN_PAIRS"):
+    for var in ("GEN_NO_BARRIER", "GEN_PRIO", "GEN_HABL", "GEN_NSETS", "GEN_PAIRS", "GEN_LSETS", "GEN_HLOAD_MOD", "GEN_HSTORE_MOD"):
         monkeypatch.delenv(var, raising=False)
     mod = _load("gen_encode_loop_pc")
     mod.OUT, mod.OUT_HELPER = tmp_path / "coder.inc", tmp_path / "helper.inc"
+    mod.OUT_LOADER, mod.OUT_STORER = tmp_path / "loader.inc", tmp_path / "storer.inc"
     mod.main_all()
+    for name in ("loader", "storer"):
+        assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()
