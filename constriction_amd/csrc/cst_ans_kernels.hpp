@@ -1351,6 +1351,9 @@ cst_status ans_decode_generic(const cst_model* m, cst_coder_config cfg, const ui
 // producer / consumer waves for batches of at most one wave of streams per SIMD (cst_ans_pc.hip)
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs);
+// lane-quad word loads for the P <= 12 decoder (cst_ans_dq.hip)
+bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
+cst_status ans_decode_dq(const AnsDecodeArgs& a, hipStream_t hs);
 bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 bool small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_small(const AnsEncodeArgs& a, hipStream_t hs);

@@ -313,6 +313,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
     if (b16_decode_usable(a, cfg, layout)) return ans_decode_b16(a, layout, hs);                        // 12 < P <= 24
     if (w16_decode_usable(a, cfg, layout)) return ans_decode_w16(a, layout, hs);                        // SmallAnsCoder preset
+    if (dq_decode_usable(a, cfg, layout)) return ans_decode_dq(a, hs);                                  // P <= 12, whole aligned tiles: lane-quad word loads
     if (cfg.word_bits == 32) return decode_dispatch<32, 64>(a, layout, hs);
     return decode_dispatch<16, 32>(a, layout, hs);
 }

@@ -39,6 +39,12 @@ from asmgen import Asm  # noqa: E402
 import os
 NO_STORE = bool(os.environ.get("GEN_NO_STORE"))
 NO_LOAD = bool(os.environ.get("GEN_NO_LOAD"))
+# experiment: the previous tile's eight stores in steps 1 .. 8, right behind the chunk requests, instead of one per quad: the
+# end-of-tile wait for the chunks also waits for every OLDER store (one in-order counter), and the last store of a tile is
+# then 1.75 tiles old instead of 1.06
+EARLY_STORES = bool(os.environ.get("GEN_EARLY_STORES"))
+# experiment: the three chunk requests at the top of quads 0, 1, 2 instead of back to back at the top of the tile
+SPREAD_LOADS = bool(os.environ.get("GEN_SPREAD_LOADS"))
 
 
 def gen():
@@ -52,7 +58,8 @@ def gen():
     PEND = [(f"v[{148 + 4 * k}:{151 + 4 * k}]", [f"v{148 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
     LAND = [f"v{160 + k}" for k in range(K_CHUNKS)]
     WANT, TMP, TADDR, TOFF = "v163", "v164", "v165", "v166"
-    clobbers = [f"v{r}" for r in range(120, 167)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "memory"]
+    X2 = "v[168:171]"
+    clobbers = [f"v{r}" for r in range(120, 172 if EARLY_STORES else 167)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "memory"]
     SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
 
     a.i("v_mov_b32 v123, 0")
@@ -63,7 +70,7 @@ def gen():
     # ---- window: request the chunks this tile's successor may need (landed at the end of this iteration) ----
     a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
     a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kDecAhead, 0)")
-    for k in range(K_CHUNKS):
+    def request_chunk(k):
         a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
         a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
         a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
@@ -77,6 +84,10 @@ def gen():
         else:
             a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase] {os.environ.get('GEN_LOAD_MOD', '').replace('+', ' ')}".rstrip(), f"chunk{k}")
         a.i("s_mov_b64 exec, s[86:87]")
+
+    if not SPREAD_LOADS:
+        for k in range(K_CHUNKS):
+            request_chunk(k)
 
     # ---- first lookup of the tile ----
     a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
@@ -111,7 +122,11 @@ def gen():
         a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
         a.ds(f"ds_read_b32 {WD}, {RA}", "w")
         a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
-        if pos == 1 and SYMBOL_MAJOR:
+        if EARLY_STORES:
+            assert not SYMBOL_MAJOR
+            if j < 8:
+                a.ds(f"ds_read_b128 {X2 if j % 2 else X}, %[trprev] offset:{1152 * j}", "x", f"previous tile, rows (lane>>3)+{8 * j}")
+        elif pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
                 a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x",
                      f"previous tile, stream 32*{quad & 1}+4*(lane&7)+{c}, symbol (lane>>3)+{8 * (quad >> 1)}")
@@ -121,7 +136,13 @@ def gen():
         a.i(f"v_min_u32 {R1}, 1, %[rd]")
         a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
         a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
-        if pos == 2:
+        if SPREAD_LOADS and pos == 0 and quad < K_CHUNKS:
+            request_chunk(quad)      # (after the step's last reader of vcc)
+        if EARLY_STORES:
+            if 1 <= j <= 8:     # x was issued in the step before and is covered by this step's lgkmcnt(0)
+                k = j - 1
+                a.vmem(f"global_store_dwordx4 %[goff{k}], {X2 if k % 2 else X}, s[80:81] {STORE_MOD}".rstrip(), f"store{k}")
+        elif pos == 2:
             # x was issued in step pos 1 and is covered by this step's lgkmcnt(0)
             if NO_STORE:
                 a.vm.append(f"store{quad}")
@@ -151,6 +172,8 @@ def gen():
 def main():
     global SYMBOL_MAJOR
     for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
+        if SYMBOL_MAJOR and EARLY_STORES:
+            continue
         emit(out)
 
 

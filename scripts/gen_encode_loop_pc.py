@@ -348,6 +348,7 @@ def main_helper():
 OUT_LOADER = CSRC / "cst_encode_loop_pc_loader.inc"
 OUT_STORER = CSRC / "cst_encode_loop_pc_storer.inc"
 LSETS = int(os.environ.get("GEN_LSETS", "2"))           # register sets per coder wave in a loader (a tile is requested LSETS windows before it is staged)
+LSLEEP = int(os.environ.get("GEN_LSLEEP", "0"))         # experiment: spread a window's 16 requests over the window (64 LSLEEP cycles after each)
 LBASE = 228 - 64 * LSETS
 LR = {(c, i): [tup(LBASE + 32 * (LSETS * c + i) + 4 * k) for k in range(8)] for c in range(2) for i in range(LSETS)}
 L_CLOBBERS = [f"v{r}" for r in range(LBASE, 228)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "memory"]
@@ -360,6 +361,8 @@ def l_load(a, i):
         for k in range(8):
             if "noloads" not in HABL:
                 a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
+                if LSLEEP:
+                    a.i(f"s_sleep {LSLEEP}")
     a.i("s_cmp_lg_u32 s83, 0")
     a.i(f"s_cselect_b32 s88, {'0' if 'loadsame' in HABL else '0x80'}, 0")
     a.i("s_cselect_b32 s89, 1, 0")

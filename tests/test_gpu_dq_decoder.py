@@ -1,0 +1,85 @@
+"""GPU parity tests of the lane-quad form of the (32,64), P <= 12 ANS decoder (constriction_amd/csrc/cst_ans_dq.hip: 64-byte
+word groups moved by four lanes, opt-in with CST_DQ_DECODER=1): symbols and status of every stream against the CPU oracle and
+against ans_decode_kernel, slabs and the packed layout (streams that start anywhere inside a 64-byte segment), decoding past the
+end of the data, empty and invalid streams."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _dq(fn):
+    os.environ["CST_DQ_DECODER"] = "1"
+    try:
+        return fn()
+    finally:
+        del os.environ["CST_DQ_DECODER"]
+
+
+@pytest.mark.parametrize("P", [8, 11, 12])
+@pytest.mark.parametrize("n_streams,n_per", [(64, 64), (192, 96), (512, 160), (1024, 992), (320, 4096)])
+def test_dq_decoder_matches_the_oracle_and_the_lane_decoder(B, O, P, n_streams, n_per):
+    lo, hi = -60, 60
+    cdf = O.GaussianModel(lo, hi, 2.5, 7.0 if P > 8 else 9.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(0xD0 + P, 0, n_streams, n_per, lo, cdf, P)
+    if n_per >= 992:
+        sym[5, :] = lo + 60                      # (a stream of the most probable symbol only: next to no words)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    extra = 0 if n_per % 64 else 32               # (decoding past the end of the data is legal: stack.rs:1062-1065)
+    want, want_st = O.ans_decode_batch(words, n_words, n_per + extra, lo, cdf, P)
+    packed, offsets = B.compact(enc)
+    for source, kw in ((enc, {}), ((packed, enc.n_words), {"offsets": offsets, "config": (32, 64, P)})):
+        got, st = _dq(lambda: B.ans_decode(source, model, n_per + extra, **kw))
+        ref, ref_st = B.ans_decode(source, model, n_per + extra, **kw)
+        torch.cuda.synchronize()
+        assert st.cpu().numpy().tolist() == want_st.tolist() == ref_st.cpu().numpy().tolist()
+        assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(ref.cpu().numpy(), want)
+        assert np.array_equal(got.cpu().numpy()[:, :n_per], sym)
+
+
+def test_dq_decoder_empty_and_invalid_streams(B, O):
+    """a stream without words decodes from state 0, a stream whose last word is 0 is invalid data (stack.rs:299-318)"""
+    P, n_streams, n_per, lo = 12, 128, 128, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(91, 0, n_streams, n_per, lo, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, _ = enc.to_numpy()
+    words = words.copy(); n_words = n_words.copy()
+    n_words[3] = 0
+    n_words[64] = 1
+    words[77, n_words[77] - 1] = 0
+    want, want_st = O.ans_decode_batch(words, n_words, n_per, lo, cdf, P)
+    src = (dev(words.view(np.int32)), dev(n_words.view(np.int32)))
+    got, st = _dq(lambda: B.ans_decode(src, model, n_per, config=(32, 64, P)))
+    torch.cuda.synchronize()
+    assert st.cpu().numpy().tolist() == want_st.tolist() and want_st[77] != 0
+    ok = want_st == 0
+    assert np.array_equal(got.cpu().numpy()[ok], want[ok])
