@@ -28,4 +28,19 @@ es, ds = [], []
 for rep in range(8):
     es.append(bench.event_ms(lambda: enc_f(sym, m, (W, S, P), layout, out=enc), 10))
     ds.append(bench.event_ms(lambda: dec_f(enc, m, k, layout, out=dec), 10))
-print(f"{os.environ.get('AB_LIB', '').split('/')[-1]} stride {enc.words.shape[1]} {coder} ({W},{S},{P}) {k} {layout}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}")
+cold = ""
+if os.environ.get("COLD"):                         # COLD=1: the same launches after a 1-GiB fill each (nothing of the batch in L2 / Infinity Cache)
+    flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+
+    def after_flush(fn):
+        ts = []
+        for _ in range(6):
+            flush.fill_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return min(ts), float(np.median(ts))
+    ce, cd = after_flush(lambda: enc_f(sym, m, (W, S, P), layout, out=enc)), after_flush(lambda: dec_f(enc, m, k, layout, out=dec))
+    cold = f"  COLD encode min {ce[0]:.3f} med {ce[1]:.3f} decode min {cd[0]:.3f} med {cd[1]:.3f}"
+print(f"{os.environ.get('AB_LIB', '').split('/')[-1]} stride {enc.words.shape[1]} {coder} ({W},{S},{P}) {k} {layout}: encode min {min(es):.3f} med {np.median(es):.3f}  decode min {min(ds):.3f} med {np.median(ds):.3f} ms  ok={bool(torch.equal(dec, sym))}{cold}")
