@@ -6,13 +6,17 @@
 // requests the next tiles: a quarter of the kernel, all of it issue and LDS-store time of that one wave and none of it memory
 // time (scripts/ablate_encoder.sh: 0.228 ms without the tile work, 0.275 ms with it, whatever the stores look like).  Here a
 // workgroup is EIGHT waves for 256 streams: waves 0-3 (one per SIMD) run nothing but the coder steps -- the generated statement
-// cst_encode_loop_pc.inc -- and waves 4-7, their partners on the same SIMDs, do everything else in plain C++:
-//     helper, per tile:  next tile's symbols registers -> LDS tile buffer (requested three tiles earlier), request a later one,
-//                        one complete 64-byte group below the write position the coder last published ring -> slab, s_barrier.
+// cst_encode_loop_pc.inc -- and waves 4-7, their partners on the same SIMDs, do everything else (generated statements, too):
+//     loader (waves 4, 5; each for two coder waves), per tile:  next tile's symbols registers -> LDS tile buffer (requested two
+//                        tiles earlier), request a later one, s_barrier                          cst_encode_loop_pc_loader.inc
+//     storer (waves 6, 7; each for two coder waves), per tile:  one complete 64-byte group below the write position the coder
+//                        last published ring -> slab (lane quads: whole 64-byte segments), s_barrier   cst_encode_loop_pc_storer.inc
 //     coder, per tile:   32 steps, candidate words into the lane's 64-slot LDS ring as before; once per tile: publish the
 //                        write position, lgkmcnt(0), s_barrier.
-// The SIMD's VALU is what the two waves share (a VALU instruction of either occupies it for 4 cycles), so the helper is kept
-// nearly free of VALU work -- a dozen instructions per tile; its LDS, vector-memory and scalar instructions issue beside the
+// (CST_PC_COMBINED=1: the first form, every helper wave loading, staging and flushing for its own coder wave --
+// cst_encode_loop_pc_helper.inc; 1.5 % slower)
+// The SIMD's VALU is what the two waves share (a VALU instruction of either occupies it for 4 cycles), so the helpers are kept
+// nearly free of VALU work -- a dozen instructions per tile; their LDS, vector-memory and scalar instructions issue beside the
 // coder's VALU stream.
 // The barrier sits at the top of the coder's quad 1: every read of the current tile's row has returned (the helper may
 // overwrite that buffer with the tile after next) and the helper has finished the next tile (quads 1 and 0 read ahead into it).

@@ -141,3 +141,13 @@ def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
         assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()
+
+
+def test_lane_quad_decoder_loop_is_in_sync(tmp_path, monkeypatch):
+    """the main loop of the opt-in lane-quad decoder (cst_ans_dq.hip)"""
+    for var in ("GEN_NO_STORE", "GEN_NO_LOAD", "GEN_DQ_SPREAD"):
+        monkeypatch.delenv(var, raising=False)
+    mod = _load("gen_decode_loop_dq")
+    mod.OUT = tmp_path / "dq.inc"
+    mod.main()
+    assert (tmp_path / "dq.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_dq.inc").read_text()
