@@ -675,6 +675,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not args.plumbing:
+        if os.environ.get("CST_BENCH_SHARE_GPU"):        # dry runs of the N > 1 path on a one-GPU box (--backend gloo --no-gather)
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

@@ -236,6 +236,8 @@ constexpr uint32_t kTileLutBytes = 32768;    // cp[4096] + sym[4096]
 constexpr int kTileAsmChunks = 3;            // 32 symbols of <= 12 bits: at most 12 words = 3 chunks per tile
 constexpr uint32_t kTileDumpBytes = (kBlock / kWave) * 4 * kWave * 4;   // landing area of unused chunk slots
 constexpr uint32_t kTileSymOffset = 16384;
+constexpr uint32_t kTileKOffset = 32768;     // K[4096]: the refill thresholds of the main loops (stage_tile_tables<true>)
+constexpr uint32_t kTileLutKBytes = 49152;
 
 #define CST_DEC_STEP(TOPW, SYM, TAIL)                                                                               \
     "s_waitcnt lgkmcnt(" #TOPW ")\n\t"                                                                              \

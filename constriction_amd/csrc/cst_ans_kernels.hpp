@@ -1083,18 +1083,34 @@ constexpr bool decode_uses_tile_asm(int W, int S, int MODE, bool LUT_IN_LDS, int
 }
 
 // LDS image for ans_decode_tile32: cp[2^P] at +0, decoded symbols (int32) at +kTileSymOffset
+// WITH_K: a third table at +kTileKOffset for the main loops of scripts/gen_decode_loop.py (K_PRED):
+//     K[q] = floor((2^32 - 1 - (q - c)) / p)   --   (state >> P) * p + (q - c) < 2^32  <=>  state >> P <= K[q]
+// i.e. stack.rs:1091's `state < 2^32` (refill) decided by ONE 32-bit compare against the table instead of the 64-bit product.
+template <bool WITH_K = false>
 __device__ __forceinline__ void stage_tile_tables(unsigned char* lds, int P, const uint32_t* dec_cp, const uint16_t* dec_idx,
                                                   int32_t min_symbol, DecLut& lut) {
     uint32_t* l = reinterpret_cast<uint32_t*>(lds);
     int32_t* x = reinterpret_cast<int32_t*>(lds + kTileSymOffset);
     const int n = 1 << P;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { l[i] = dec_cp[i]; x[i] = min_symbol + (int32_t)dec_idx[i]; }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t e = dec_cp[i];
+        l[i] = e; x[i] = min_symbol + (int32_t)dec_idx[i];
+        if constexpr (WITH_K) {
+            const uint32_t c = e & 0xffffu, p = e >> 16;           // (p >= 1: every quantile lies in a bin)
+            reinterpret_cast<uint32_t*>(lds + kTileKOffset)[i] = (0xffffffffu - ((uint32_t)i - c)) / (p ? p : 1u);
+        }
+    }
     lut.cp = l; lut.idx = nullptr; lut.sym = x; lut.min_symbol = min_symbol;
 }
 
 // LDS bytes of a decode workgroup that uses the hand-scheduled tile decoder:
-// [rings 4 x 8 KiB][cp + sym tables 32 KiB][two symbol tiles per wave][dump rows]
-constexpr size_t kDecTileAsmLdsBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4 + kTileLutBytes +
+// [rings 4 x 8 KiB][cp + sym tables 32 KiB (+ K: 48 KiB)][two symbol tiles per wave][dump rows]
+#ifdef CST_DEC_KPRED      // (experiment: scripts/gen_decode_loop.py, K_PRED)
+constexpr bool kDecKPred = true;
+#else
+constexpr bool kDecKPred = false;
+#endif
+constexpr size_t kDecTileAsmLdsBytes = (size_t)(kBlock / kWave) * kDecRingSlots * kWave * 4 + (kDecKPred ? kTileLutKBytes : kTileLutBytes) +
                                        2 * (size_t)(kBlock / kWave) * kWave * kTileStride * 4 + kTileDumpBytes;
 
 // LDS layout: [word rings: one per wave, aligned to their size][tables][symbol tiles][dump rows (tile asm only)]
@@ -1117,8 +1133,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_kernel(const AnsDecodeArgs 
     const uint16_t* bucket = a.bucket;
     size_t lds_off;
     if constexpr (TILE_ASM) {
-        stage_tile_tables(smem + kRingBytes, P, a.dec_cp, a.dec_idx, a.min_symbol, lut);
-        lds_off = kTileLutBytes;
+        stage_tile_tables<kDecKPred>(smem + kRingBytes, P, a.dec_cp, a.dec_idx, a.min_symbol, lut);
+        lds_off = kDecKPred ? kTileLutKBytes : kTileLutBytes;
     } else {
         lds_off = stage_decoder_tables<MODE, LUT_IN_LDS>(smem + kRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                          a.n_symbols, lut, cdf, bucket);

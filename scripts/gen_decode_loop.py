@@ -45,6 +45,17 @@ NO_LOAD = bool(os.environ.get("GEN_NO_LOAD"))
 EARLY_STORES = bool(os.environ.get("GEN_EARLY_STORES"))
 # experiment: the three chunk requests at the top of quads 0, 1, 2 instead of back to back at the top of the tile
 SPREAD_LOADS = bool(os.environ.get("GEN_SPREAD_LOADS"))
+# K_PRED (experiment, GEN_KPRED=1; the kernel must stage the third table: -DCST_DEC_KPRED): the refill decision without the
+# 64-bit product on the way to the next lookup.
+#   N = (state >> P) * p + (q - c) < 2^32   <=>   state >> P < 2^32  and  low32(state >> P) <= K[q],  K[q] = floor((2^32 - 1 - (q - c)) / p)
+# K[q] sits next to cp[q] in LDS, and the LOW word of N -- all the next lookup needs -- is two 24-bit multiplies: from one table
+# entry to the next lookup the DEPENDENT chain is shift, mad24, shift-add, select, and, address (6 full-rate instructions)
+# instead of shift, 64-bit mad (quarter rate), mad24, compare, select, and, address; the exact 64-bit product still runs, for
+# the state's high word, in the shadow of the next lookup.  Bit-exact (271 batch tests) and SLOWER: 0.294 - 0.300 ms against
+# 0.256 (gpurun_out/r04_kpred_ab.txt).  A lone wave issues one instruction per ~4.3 cycles whether it depends on the previous
+# one or not, so what counts between the entry's arrival and the next lookup's issue is the NUMBER of instructions there
+# (9 before, 12 + a second table read with this form), not their dependent depth; the step is one LDS latency + that section.
+K_PRED = bool(os.environ.get("GEN_KPRED"))
 
 
 def gen():
@@ -58,8 +69,11 @@ def gen():
     PEND = [(f"v[{148 + 4 * k}:{151 + 4 * k}]", [f"v{148 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
     LAND = [f"v{160 + k}" for k in range(K_CHUNKS)]
     WANT, TMP, TADDR, TOFF = "v163", "v164", "v165", "v166"
-    X2 = "v[168:171]"
-    clobbers = [f"v{r}" for r in range(120, 172 if EARLY_STORES else 167)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "memory"]
+    X2 = "v[172:175]"
+    KQ, BH, M1, M2 = "v130", "v143", "v167", "v168"
+    ELIG = "s[88:89]"
+    clobbers = [f"v{r}" for r in range(120, 176 if EARLY_STORES else (169 if K_PRED else 167))] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87"] + \
+               (["s88", "s89"] if K_PRED else []) + ["vcc", "memory"]
     SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
 
     a.i("v_mov_b32 v123, 0")
@@ -93,6 +107,8 @@ def gen():
     a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
     a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
     a.ds(f"ds_read_b32 {CP}, {LA}", "cp")
+    if K_PRED:
+        a.ds(f"ds_read_b32 {KQ}, {LA} offset:32768", "k")
     a.ds(f"ds_read_b32 {SYM[0]}, {LA} offset:16384", "sym0")
     a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
@@ -100,28 +116,60 @@ def gen():
     a.i(f"v_min_u32 {R1}, 1, %[rd]")
     a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
     a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+    if K_PRED:
+        a.i(f"v_lshrrev_b32 {BH}, 24, {T0}")
+        a.i(f"v_cmp_lt_u32 {ELIG}, {T1}, {R1}", "a refill is possible <=> state >> P < 2^32 and words remain")
 
     for j in range(32):
         quad, pos = divmod(j, 4)
         # symbol j+1 goes to: quad registers alternate between SYM[0:4] and SYM[4:8]; symbol 32 to the spare
         nxt = j + 1
         sym_reg = SYM[8] if nxt == 32 else SYM[(nxt // 4 % 2) * 4 + nxt % 4]
-        a.wait_lds("cp", f"---- step {j}: entry is back")
-        a.i(f"v_sub_u32_sdwa {D}, {Q}, {CP} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "q - c")
-        a.i(f"v_lshrrev_b32 {PR}, 16, {CP}", "p")
-        a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
-        a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
-        a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
-        a.wait_lds_all("candidate word (and everything older) is back")
-        a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
-        a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
-        a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
-        a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
-        a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
-        a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
-        a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
-        a.ds(f"ds_read_b32 {WD}, {RA}", "w")
-        a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
+        if K_PRED:
+            a.wait_lds("k", f"---- step {j}: entry and K are back")
+            a.i(f"v_lshrrev_b32 {PR}, 16, {CP}", "p")
+            a.i(f"v_sub_u32_sdwa {D}, {Q}, {CP} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "q - c")
+            a.i(f"v_cmp_le_u32 vcc, {T0}, {KQ}", "low32(state >> P) * p + (q - c) < 2^32")
+            a.i(f"v_mad_u32_u24 {M1}, {T0}, {PR}, {D}", "low word of N = (state >> P) * p + (q - c): the factor's low 24 bits ...")
+            a.i(f"v_mul_u32_u24 {M2}, {BH}, {PR}", "... and its bits 24..31")
+            a.i(f"v_lshl_add_u32 {M1}, {M2}, 24, {M1}")
+            a.wait_lds_all("candidate word (and everything older) is back")
+            if os.environ.get("GEN_K_SALU"):      # (measured slower: the VALU -> SALU -> VALU round trip of the mask sits on the chain)
+                a.i(f"s_and_b64 vcc, vcc, {ELIG}", "refill <=> N < 2^32 and words remain")
+                a.i(f"v_cndmask_b32 %[lo], {M1}, {WD}, vcc")
+            else:
+                a.i(f"v_cndmask_b32_e64 {M2}, {M1}, {WD}, {ELIG}", "the word, if a refill is possible at all")
+                a.i(f"v_cndmask_b32 %[lo], {M1}, {M2}, vcc")
+            a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
+            a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
+            a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
+            a.ds(f"ds_read_b32 {KQ}, {LA} offset:32768", "k")
+            # in the shadow of that lookup: the state's high word from the exact product, the next step's operands
+            if not os.environ.get("GEN_K_SALU"):
+                a.i(f"s_and_b64 vcc, vcc, {ELIG}", "refill <=> N < 2^32 and words remain")
+            a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
+            a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
+            a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+            a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+            a.ds(f"ds_read_b32 {WD}, {RA}", "w")
+            a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
+        else:
+            a.wait_lds("cp", f"---- step {j}: entry is back")
+            a.i(f"v_sub_u32_sdwa {D}, {Q}, {CP} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "q - c")
+            a.i(f"v_lshrrev_b32 {PR}, 16, {CP}", "p")
+            a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
+            a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+            a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
+            a.wait_lds_all("candidate word (and everything older) is back")
+            a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
+            a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
+            a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
+            a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
+            a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
+            a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
+            a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
+            a.ds(f"ds_read_b32 {WD}, {RA}", "w")
+            a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
         if EARLY_STORES:
             assert not SYMBOL_MAJOR
             if j < 8:
@@ -132,10 +180,19 @@ def gen():
                      f"previous tile, stream 32*{quad & 1}+4*(lane&7)+{c}, symbol (lane>>3)+{8 * (quad >> 1)}")
         elif pos == 1:
             a.ds(f"ds_read_b128 {X}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
-        a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
-        a.i(f"v_min_u32 {R1}, 1, %[rd]")
-        a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
-        a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        if K_PRED:
+            a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+            a.i(f"v_min_u32 {R1}, 1, %[rd]")
+            a.i(f"v_cndmask_b32 %[hi], {N1}, {M1}, vcc")
+            a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+            a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+            a.i(f"v_lshrrev_b32 {BH}, 24, {T0}")
+            a.i(f"v_cmp_lt_u32 {ELIG}, {T1}, {R1}")
+        else:
+            a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
+            a.i(f"v_min_u32 {R1}, 1, %[rd]")
+            a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+            a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
         if SPREAD_LOADS and pos == 0 and quad < K_CHUNKS:
             request_chunk(quad)      # (after the step's last reader of vcc)
         if EARLY_STORES:
