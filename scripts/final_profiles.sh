@@ -14,3 +14,11 @@ python scripts/bench_dropin_single_stream.py 2>&1 | grep -v amdgpu.ids > gpurun_
 scripts/microbench/bin/encstep > gpurun_out/${tag}_encstep.txt 2>&1
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 400 gpurun_out/${tag}_bench.json
+# the summaries are made HERE (gpurun merges at most 64 MiB back, the raw rocprofv3 outputs are more): profiles/<tag>_* of this
+# copy go home as gpurun_out/<tag>_profiles/, the raw directories stay behind
+python scripts/make_profile_summary.py $tag > gpurun_out/${tag}_summary.log 2>&1
+python scripts/make_sq_counters_md.py $tag >> gpurun_out/${tag}_summary.log 2>&1
+python scripts/collect_profiles.py $tag >> gpurun_out/${tag}_summary.log 2>&1
+mkdir -p gpurun_out/${tag}_profiles && cp profiles/${tag}_* profiles/traffic.json gpurun_out/${tag}_profiles/ 2>/dev/null
+find gpurun_out -mindepth 1 -maxdepth 1 -type d ! -name "${tag}_profiles" -exec rm -rf {} +
+du -sh gpurun_out
