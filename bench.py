@@ -429,7 +429,7 @@ def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3):
                 dwords[k][: totals[c]].copy_(host_words[base: base + totals[c]], non_blocking=True)
                 doff[k].copy_(host_off[c], non_blocking=True)
                 dnw[k].copy_(doff[k][1:] - doff[k][:-1])
-                B.ans_decode((dwords[k], dnw[k]), model, n_per, offsets=doff[k], config=cfg, out=dsym[k])
+                B.ans_decode((dwords[k], dnw[k]), model, n_per, offsets=doff[k], config=cfg, out=dsym[k], cold=True)   # (the words have just come over PCIe)
                 host_back[c * per:(c + 1) * per].copy_(dsym[k], non_blocking=True)
         torch.cuda.synchronize()
 
@@ -796,7 +796,11 @@ def main():
         return total / reps
     cold = {"encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc)), 4),
             "decode_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded)), 4),
-            "what": "same kernels, a 1-GiB fill before every launch (nothing of the batch left in L2 or the Infinity Cache)"}
+            "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True)), 4),
+            "what": "same kernels, a 1-GiB fill before every launch (nothing of the batch left in L2 or the Infinity Cache); "
+                    "decode_cold_words_hint_ms: the call made with CST_FLAG_COLD_WORDS, i.e. by a caller who knows that (lane-quad word "
+                    "loads, cst_ans_dq.hip)"}
+    cold["hint_bit_exact"] = bool(torch.equal(decoded, symbols))
     del flush
 
     # N > 1: every rank's own kernel times and how many ranks RCCL really connected (a scaling run diagnoses itself)

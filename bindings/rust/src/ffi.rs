@@ -37,6 +37,7 @@ pub const CST_FAMILY_BINOMIAL: CstFamily = 3;
 
 pub const CST_FLAG_NONE: u32 = 0;
 pub const CST_FLAG_RAW_STATE: u32 = 1;
+pub const CST_FLAG_COLD_WORDS: u32 = 2;
 
 /// `cst_model`: opaque, device-resident model image
 #[repr(C)]

@@ -30,6 +30,7 @@ FAMILY_LAPLACE, FAMILY_CAUCHY, FAMILY_BINOMIAL = 1, 2, 3
 
 FLAG_NONE = 0
 FLAG_RAW_STATE = 1
+FLAG_COLD_WORDS = 2
 
 
 class BackendUnavailable(RuntimeError):

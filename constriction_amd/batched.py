@@ -358,10 +358,12 @@ def ans_roundtrip_launcher(symbols: torch.Tensor, model: Model, encoded: Encoded
 
 
 def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None, config=None):
+               out: Optional[torch.Tensor] = None, config=None, cold: bool = False):
     """One AnsCoder per stream: from_compressed + decode_iid_symbols (stack.rs:299-318, mod.rs:1016-1031).
 
-    `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout."""
+    `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout.  `cold=True` (CST_FLAG_COLD_WORDS,
+    a hint): the words are not expected in the GPU's caches -- they came from the host or a peer, not from an encode call
+    just before."""
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
         stride = words.shape[1]
@@ -377,8 +379,8 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
     N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
-                                         _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status), N.FLAG_NONE,
-                                         _stream_ptr()), "cst_ans_decode_batch")
+                                         _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status),
+                                         N.FLAG_COLD_WORDS if cold else N.FLAG_NONE, _stream_ptr()), "cst_ans_decode_batch")
     return _to_symbols(model, out), status
 
 

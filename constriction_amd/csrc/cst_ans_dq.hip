@@ -132,11 +132,13 @@ __global__ __launch_bounds__(kBlock) void ans_decode_dq_kernel(const AnsDecodeAr
 
 // Whole waves, rows that are whole 128-byte aligned tiles (at least two), every stream's words within 2 GiB of the buffer.
 bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    // Opt-in (CST_DQ_DECODER=1).  Measured on one MI355X, 65 536 x 4096 at P = 12 (gpurun_out/r04_dq_first.txt): 0.330 ms against
-    // ans_decode_kernel's 0.366 at a slab stride of 103 x 64 bytes, but 0.281 against 0.270 at 97 x 64 and 0.272 against 0.255
-    // at 128 x 64 -- the quad loads make the worst strides cheaper and every other one dearer (the tile's read-back burst,
-    // the position exchange), and the stride sensitivity stays: it is not the number of requests per load instruction.
-    if (!getenv("CST_DQ_DECODER")) return false;
+    // Taken on request: CST_FLAG_COLD_WORDS of the call, or CST_DQ_DECODER=1 (A/B runs).  Measured on one MI355X, 65 536 x 4096 at
+    // P = 12, slab strides of 97 / 103 / 130 x 64 bytes (gpurun_out/r04_dq_cold.txt): words from HBM (a 1-GiB fill before the
+    // launch) 0.349 / 0.343 / 0.326 ms against ans_decode_kernel's 0.405 / 0.411 / 0.367; cache-resident words 0.287 / 0.337 /
+    // 0.274 against 0.296 / 0.368 / 0.255 -- whole 64-byte segments are what single reads among 4 TB/s of writes should look
+    // like (scripts/microbench/rw_mix.hip shows the same without any decoder), the tile's read-back burst and the position
+    // exchange are what it costs where the words sit in the caches at a well-chosen stride.
+    if (!(a.flags & CST_FLAG_COLD_WORDS) && !getenv("CST_DQ_DECODER")) return false;
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (!a.dec_cp || !a.dec_idx) return false;
     if (a.n_streams == 0 || a.n_streams % kWave != 0) return false;

@@ -76,6 +76,12 @@ typedef struct cst_coder_config {
  * Used by the single-coder drop-in object to continue an existing coder
  * (AnsCoder::encode_symbols_reverse on a non-empty coder, src/stream/stack.rs:784-849). */
 #define CST_FLAG_RAW_STATE 1u
+/* decode (a hint; results do not depend on it): the compressed words are NOT expected in the GPU's caches -- they arrived by
+ * DMA from the host or a peer, or were written long ago -- as opposed to words an encode call has just left there.  The
+ * (32,64), P <= 12 decoder then reads them as whole 64-byte segments moved by lane quads (cst_ans_dq.hip): 11 - 17 % faster on
+ * words that come from HBM, 7 % slower on cache-resident ones at a well-chosen slab stride.  Other kernels
+ * ignore it. */
+#define CST_FLAG_COLD_WORDS 2u
 
 /* ------------------------------------------------------------------------------------------
  * library / device

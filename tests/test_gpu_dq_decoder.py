@@ -1,5 +1,5 @@
 """GPU parity tests of the lane-quad form of the (32,64), P <= 12 ANS decoder (constriction_amd/csrc/cst_ans_dq.hip: 64-byte
-word groups moved by four lanes, opt-in with CST_DQ_DECODER=1): symbols and status of every stream against the CPU oracle and
+word groups moved by four lanes; taken with CST_FLAG_COLD_WORDS -- `cold=True` -- or CST_DQ_DECODER=1): symbols and status of every stream against the CPU oracle and
 against ans_decode_kernel, slabs and the packed layout (streams that start anywhere inside a 64-byte segment), decoding past the
 end of the data, empty and invalid streams."""
 import os
@@ -83,3 +83,22 @@ def test_dq_decoder_empty_and_invalid_streams(B, O):
     assert st.cpu().numpy().tolist() == want_st.tolist() and want_st[77] != 0
     ok = want_st == 0
     assert np.array_equal(got.cpu().numpy()[ok], want[ok])
+
+
+def test_cold_words_hint_decodes_the_same(B, O):
+    """CST_FLAG_COLD_WORDS is a hint: the same symbols and status with and without it (and it is the lane-quad kernel that ran:
+    its LDS footprint of 136 KiB shows up as one workgroup per CU -- not observable from here, so the check is the results)"""
+    P, n_streams, n_per, lo = 12, 1024, 1024, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(5, 0, n_streams, n_per, lo, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    hot, st_hot = B.ans_decode(enc, model, n_per)
+    cold, st_cold = B.ans_decode(enc, model, n_per, cold=True)
+    torch.cuda.synchronize()
+    assert torch.equal(hot, cold) and torch.equal(st_hot, st_cold) and np.array_equal(cold.cpu().numpy(), sym)
+    # a shape the lane-quad kernel does not take (a partial wave): the hint is ignored
+    enc2 = B.ans_encode(dev(sym[:100]), model, (32, 64, P))
+    d2, s2 = B.ans_decode(enc2, model, n_per, cold=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(d2.cpu().numpy(), sym[:100]) and (s2.cpu().numpy() == 0).all()
