@@ -145,6 +145,66 @@ float run(int* sym, const uint32_t* words, size_t stride, int* sink, char* flush
     return best;
 }
 
+// The ENCODER's traffic: every tile a wave requests the 128-byte pieces of its 64 symbol rows (8 x global_load_dwordx4 nt, never
+// waited for) and stores complete groups of compressed words to the streams' slabs, walking them upwards:
+// EMODE 0 no stores; 1: 64-byte groups by lane quads (4 passes, a stream has one ready with probability 0.35 per tile);
+// 2: 128-byte lines by lane octets (8 passes, probability 0.175); 3: 16-byte chunks, every lane its own stream (3 x 0.47)
+template <int EMODE, bool LOADS, int SLEEP>
+__global__ __launch_bounds__(256) void ke(const int* __restrict__ sym, uint32_t* __restrict__ words, size_t stride, int* sink) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int* row = sym + (wave * 64 + (lane >> 3)) * (size_t)kN + 4 * (lane & 7);
+    constexpr int G = EMODE == 1 ? 4 : (EMODE == 2 ? 8 : 1);
+    constexpr int PASSES = G;
+    uint32_t pos[PASSES], rng[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const size_t s = wave * 64 + (size_t)p * (64 / G) + lane / G;
+        pos[p] = 0; rng[p] = (uint32_t)s * 2654435761u + 12345u;
+    }
+    for (int t = 0; t < kTiles; ++t) {
+        if (LOADS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int* src = row + (size_t)(8 * q) * kN + 32 * (kTiles - 1 - t);
+                asm volatile("global_load_dwordx4 v[200:203], %0, off nt" :: "v"(src) : "memory", "v200", "v201", "v202", "v203");
+            }
+        }
+        if (EMODE) {
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const size_t s = wave * 64 + (size_t)p * (64 / G) + lane / G;
+#pragma unroll
+                for (int c = 0; c < (EMODE == 3 ? 3 : 1); ++c) {
+                    rng[p] = rng[p] * 1664525u + 1013904223u;
+                    const uint32_t thr = EMODE == 1 ? 350u : (EMODE == 2 ? 175u : 470u);
+                    if ((rng[p] >> 16) % 1000u < thr && pos[p] + 4u * G <= 800u) {
+                        v4i v = {t, p, lane, (int)wave};
+                        *reinterpret_cast<v4i*>(words + s * stride + pos[p] + 4 * (lane % G)) = v;
+                        pos[p] += 4 * G;
+                    }
+                }
+            }
+        }
+        if (SLEEP) __builtin_amdgcn_s_sleep(64);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EMODE, bool LOADS, int SL>
+float rune(const int* sym, uint32_t* words, size_t stride, int* sink, char* flush) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((ke<EMODE, LOADS, SL>), dim3(kStreams / 256), dim3(256), 0, 0, sym, words, stride, sink);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
 template <int MODE, bool NT, int SL>
 float runx(int* sym, const uint32_t* words, size_t stride, int* sink, char* flush, bool cold) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -190,6 +250,16 @@ int main(int argc, char** argv) {
                    runx<4, false, SL>(sym, words, st, sink, flush, cold), runx<5, false, SL>(sym, words, st, sink, flush, cold),
                    runx<6, false, SL>(sym, words, st, sink, flush, cold));
         }
+    }
+    printf("\nthe ENCODER's traffic (1 GiB of symbol rows read 128 bytes at a time, nt; word groups stored to the slabs), back-to-back launches:\n");
+    for (size_t st : strides) {
+        if (st > 2048) continue;
+        printf("stride %4zu words: loads only %.3f | stores only: 16-byte chunks %.3f  64-byte quads %.3f  128-byte octets %.3f | loads + 16-byte chunks %.3f  + 64-byte quads %.3f  + 128-byte octets %.3f"
+               "   | unpaced: loads only %.3f  + quads %.3f  + octets %.3f\n", st,
+               rune<0, true, SL>(sym, words, st, sink, flush),
+               rune<3, false, SL>(sym, words, st, sink, flush), rune<1, false, SL>(sym, words, st, sink, flush), rune<2, false, SL>(sym, words, st, sink, flush),
+               rune<3, true, SL>(sym, words, st, sink, flush), rune<1, true, SL>(sym, words, st, sink, flush), rune<2, true, SL>(sym, words, st, sink, flush),
+               rune<0, true, 0>(sym, words, st, sink, flush), rune<1, true, 0>(sym, words, st, sink, flush), rune<2, true, 0>(sym, words, st, sink, flush));
     }
     return 0;
 }
