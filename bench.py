@@ -785,10 +785,13 @@ def main():
     # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):
     flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 
-    def after_flush_ms(fn, reps=3):
+    def after_flush_ms(fn, reps=3, clean=False):
         total = 0.0
         for _ in range(reps):
-            flush.fill_(1)
+            if clean:
+                flush.view(torch.int32).sum()      # a 1-GiB READ: the caches end up full of clean lines
+            else:
+                flush.fill_(1)                     # a 1-GiB fill: ... of DIRTY lines, whose write-back the launch then shares HBM with
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); fn(); e1.record()
             torch.cuda.synchronize()
@@ -801,6 +804,11 @@ def main():
                     "decode_cold_words_hint_ms: the call made with CST_FLAG_COLD_WORDS, i.e. by a caller who knows that (lane-quad word "
                     "loads, cst_ans_dq.hip)"}
     cold["hint_bit_exact"] = bool(torch.equal(decoded, symbols))
+    cold["after_a_1GiB_read_instead"] = {
+        "encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc), clean=True), 4),
+        "decode_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded), clean=True), 4),
+        "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True), clean=True), 4),
+        "what": "the same with the caches full of clean lines (a fill leaves 288 MiB of dirty lines whose write-back competes with the launch)"}
     del flush
 
     # N > 1: every rank's own kernel times and how many ranks RCCL really connected (a scaling run diagnoses itself)

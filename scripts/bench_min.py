@@ -35,7 +35,10 @@ if os.environ.get("COLD"):                         # COLD=1: the same launches a
     def after_flush(fn):
         ts = []
         for _ in range(6):
-            flush.fill_(1)
+            if os.environ.get("COLD") == "read":       # a 1-GiB READ instead of a fill: the caches end up full of CLEAN lines
+                flush.view(torch.int32).sum()
+            else:
+                flush.fill_(1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); fn(); e1.record()
             torch.cuda.synchronize()
