@@ -102,3 +102,39 @@ def test_cold_words_hint_decodes_the_same(B, O):
     d2, s2 = B.ans_decode(enc2, model, n_per, cold=True)
     torch.cuda.synchronize()
     assert np.array_equal(d2.cpu().numpy(), sym[:100]) and (s2.cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("flags", [1, 1 | 2])           # CST_FLAG_RAW_STATE, without and with CST_FLAG_COLD_WORDS
+def test_batched_decoders_continue_from_a_raw_state(B, O, flags):
+    """CST_FLAG_RAW_STATE at batch shapes (AnsCoder::decode_symbols on a coder that has already decoded: stack.rs:1070-1100):
+    the two halves of every row decoded by two calls -- state and word count handed from one to the next -- are the row"""
+    import ctypes as C
+    from constriction_amd import _native as N
+    P, n_streams, n_per, lo = 12, 256, 512, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(321, 0, n_streams, n_per, lo, cdf, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and (n_words >= 2).all()
+    # from_compressed by hand (stack.rs:440-462): the last word, then the one before (a state of two words here)
+    state = np.array([(int(words[s, n_words[s] - 1]) << 32) | int(words[s, n_words[s] - 2]) for s in range(n_streams)], dtype=np.uint64)
+    assert (state >= (1 << 32)).all()
+    d_state, d_n = dev(state.view(np.int64)), dev((n_words - 2).astype(np.int32))
+    d_n_out = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    d_status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    half = n_per // 2
+    outs = []
+    for _ in range(2):
+        out = torch.empty((n_streams, half), dtype=torch.int32, device="cuda")
+        N.check(N.lib().cst_ans_decode_batch(model._h, N.CoderConfig(32, 64, P), C.c_void_p(enc.words.data_ptr()), None, enc.words.shape[1],
+                                             enc.words.numel(), C.c_void_p(d_n.data_ptr()), C.c_void_p(out.data_ptr()), n_streams, half, 0,
+                                             C.c_void_p(d_state.data_ptr()), C.c_void_p(d_n_out.data_ptr()), C.c_void_p(d_status.data_ptr()),
+                                             flags, None), "cst_ans_decode_batch")
+        torch.cuda.synchronize()
+        assert (d_status.cpu().numpy() == 0).all()
+        d_n.copy_(d_n_out)
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(outs, axis=1), sym)
+    assert (d_n.cpu().numpy() == 0).all()                # every word consumed
