@@ -728,6 +728,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the GPU leaves the host-side setup at idle clocks: ~30 ms of the same launches first (the stride tuner does that as a side
+    # effect, `--slab-stride default` does not: 20 steps right behind 3 warmup steps measured the ramp, 0.61 instead of 0.56 ms)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.03:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()

@@ -154,6 +154,8 @@ def gen():
             a.ds(f"ds_write_b128 %[rowcur], v[{134 + base}:{137 + base}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
     a.wait_lds_all("---- end of tile: the tile is complete in LDS")
     for k in range(8):
+        if os.environ.get("GEN_DQ_NOXT"):       # timing experiment (results wrong): what the read-back burst costs
+            break
         a.ds(f"ds_read_b128 {XT[k]}, %[tr] offset:{1152 * k}", "x", f"this tile, rows (lane>>3)+{8 * k} (leaves during the next one)")
     a.wait_vm("chunk3", "the group loads are older than this tile's stores")
     for p in range(4):
