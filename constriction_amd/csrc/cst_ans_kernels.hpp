@@ -438,30 +438,14 @@ struct RingReader {
     }
 
     // blocking top-up of the window from wherever it stands (used once, between the first tile and the main loop)
-    // (every missing chunk is requested before the first one is waited for, as in prime(): the loop form paid one memory round
-    // trip per chunk -- three behind a first tile that consumed its twelve words -- once per kernel)
     __device__ __forceinline__ void refill_blocking() {
         const uint32_t top = rd + shift;
         const uint32_t want_lo = top > (uint32_t)AHEAD ? top - AHEAD : 0u;
-        constexpr int KMAX = AHEAD / 4 + 2;       // the window is never further behind than that
-        const uint32_t from = lo_issued;
-        uint4 v[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (from > want_lo + 4u * (uint32_t)k) v[k] = *reinterpret_cast<const uint4*>(base16 + (from - 4u * (uint32_t)(k + 1)));
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (from > want_lo + 4u * (uint32_t)k) {
-                lo_issued = from - 4u * (uint32_t)(k + 1);
-                uint32_t* b = slot(lo_issued);
-                b[0] = v[k].x; b[kWave] = v[k].y; b[2 * kWave] = v[k].z; b[3 * kWave] = v[k].w;
-            }
-        }
-        while (lo_issued > want_lo) {             // (not reached: kept so that the window is complete whatever AHEAD and the caller are)
+        while (lo_issued > want_lo) {
             lo_issued -= 4;
-            const uint4 w = *reinterpret_cast<const uint4*>(base16 + lo_issued);
+            const uint4 v = *reinterpret_cast<const uint4*>(base16 + lo_issued);
             uint32_t* b = slot(lo_issued);
-            b[0] = w.x; b[kWave] = w.y; b[2 * kWave] = w.z; b[3 * kWave] = w.w;
+            b[0] = v.x; b[kWave] = v.y; b[2 * kWave] = v.z; b[3 * kWave] = v.w;
         }
     }
 
