@@ -54,20 +54,30 @@ A0, A1, W0, W1, U0, U1, T0, T1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(148, 
 A_T, W_T, U_T, T_T, SM_T, Q_T = (tup(148 + 2 * i, 2) for i in range(6))
 RR, KK, CK, RA, EA0, EA1, WR = (f"v{r}" for r in range(160, 167))
 SD = "s[84:85]"
-CLOBBERS = [f"v{r}" for r in range(100, 167)] + ["s82", "s84", "s85", "vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 170)] + ["s82", "s84", "s85", "vcc", "memory"]
 ROW = ["%[row0]", "%[row1]"]
 SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD"
 
 
+LO, HI = "v168", "v169"          # the coder state lives in a register pair inside the statement: the step's last instruction writes both halves
+ST_T = tup(168, 2)
+OLD_TAIL = bool(os.environ.get("GEN_OLD_TAIL"))     # the step's tail as it was until round 4 (A + q k + c: two instructions more)
+
+
 def step(a, e0, e1, m0, m1):
-    """One coder step (stack.rs:1035-1045) on a packed table entry (see scripts/gen_encode_loop.py: step())."""
-    a.i(f"v_cmp_ge_u32_sdwa vcc, %[hi], {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
-    a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
+    """One coder step (stack.rs:1035-1045) on a packed table entry (see scripts/gen_encode_loop.py: step()).
+    The new state is  q 2^P + r + c  with q = floor(A / p), r = A mod p.  From the estimate q_est in {q - 1, q} and
+    r_est = A - q_est p in [0, 2 p):   q 2^P + r + c = q_est 2^P + r_est + (fix ? c + 2^P - p : c),   fix <=> r_est >= p
+    -- ONE 64-bit mad (q_est_lo x 2^P + [r_est + c', q_est_hi << P]) where round 3 computed A + q (2^P - p) + c' with a mad, a
+    24-bit mad and a 64-bit add: two instructions less on a wave that pays for every instruction it issues."""
+    a.i(f"v_cmp_ge_u32_sdwa vcc, {HI}, {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
+    if OLD_TAIL:
+        a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
     a.i(f"v_lshlrev_b32 {RA}, 8, {WR}")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
-    a.i(f"v_cndmask_b32_e64 {A0}, %[lo], %[hi], vcc")
-    a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
-    a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
+    a.i(f"v_cndmask_b32_e64 {A0}, {LO}, {HI}, vcc")
+    a.i(f"v_cndmask_b32_e64 {A1}, {HI}, 0, vcc")
+    a.ds(f"ds_write_b32 {RA}, {LO}", "W", "candidate word, always written")
     a.i(f"v_addc_co_u32 {WR}, vcc, 0, {WR}, vcc")
     a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
     a.i(f"v_mad_u64_u32 {U_T}, vcc, {A1}, {m0}, {W_T}", "U = a1*m0 + hi32(a0*m0)   (< 2^64)")
@@ -78,11 +88,17 @@ def step(a, e0, e1, m0, m1):
     a.i(f"v_mul_u32_u24_sdwa {RR}, {Q0}, {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "low 24 bits of q_est times p")
     a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est modulo 2^24")
     a.i(f"v_cmp_ge_u32_sdwa vcc, {RR}, {e1} src0_sel:WORD_0 src1_sel:WORD_0", "fix <=> q = q_est + 1")
-    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}", "A + q_lo * k")
-    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}", "      + (q_hi * k) << 32")
-    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + k")
-    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {CK}")
-    a.i(f"v_addc_co_u32 %[hi], vcc, 0, {U1}, vcc")
+    if OLD_TAIL:
+        a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}", "A + q_lo * k")
+        a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}", "      + (q_hi * k) << 32")
+        a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + k")
+        a.i(f"v_add_co_u32 {LO}, vcc, {U0}, {CK}")
+        a.i(f"v_addc_co_u32 {HI}, vcc, 0, {U1}, vcc")
+        return
+    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + 2^P - p")
+    a.i(f"v_lshlrev_b32 {A1}, %[P], {Q1}", "q_est_hi << P   (q < 2^(64 - P))")
+    a.i(f"v_add_u32_sdwa {A0}, {RR}, {CK} {SDWA} src0_sel:WORD_0 src1_sel:DWORD", "r_est + c'   (< 2^15)")
+    a.i(f"v_mad_u64_u32 {ST_T}, {SD}, {Q0}, %[twoP], {A_T}", "state = q_est 2^P + r_est + c'")
 
 
 def read_syms(a, g, buf, quad):
@@ -137,6 +153,8 @@ def half(a, h, g0):
 def gen():
     a = Asm()
     a.i(f"v_mov_b32 {W1}, 0")
+    a.i(f"v_mov_b32 {LO}, %[lo]")
+    a.i(f"v_mov_b32 {HI}, %[hi]")
     if PRIO:
         a.i(f"s_setprio {PRIO}", "the coder chain's wave goes first on its SIMD; the helper fills the gaps")
     a.i(f"v_mov_b32 {WR}, 0")
@@ -162,6 +180,8 @@ def gen():
     assert lds_end == lds_back and vm_end == a.vm, (lds_end, lds_back)
     a.i("2:")
     a.ds(f"ds_write_b32 %[pub], {WR}", "cnt", "all words of the main loop")
+    a.i(f"v_mov_b32 %[lo], {LO}")
+    a.i(f"v_mov_b32 %[hi], {HI}")
     a.wait_lds_all()
     return a, notes
 
@@ -172,7 +192,7 @@ def main():
               "// Coder half of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_coder_loop in cst_ans_pc.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
-           '      [twoP] "v"(1u << P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
     OUT.write_text(a.render(header, ops))
     print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
