@@ -85,7 +85,10 @@ E = [[regs(180 + 16 * e + 4 * i) for i in range(4)] for e in range(2)]
 E_T = [[tup(180 + 16 * e + 4 * i) for i in range(4)] for e in range(2)]
 A0, A1, W0, W1, U0, U1, T0, T1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(212, 224))
 A_T, W_T, U_T, T_T, SM_T, Q_T = (tup(212 + 2 * i, 2) for i in range(6))
-RR, PSHL, KK, CK, RA, EA = (f"v{r}" for r in range(224, 230))
+RR, PSHL, LO, HI, RA, EA = (f"v{r}" for r in range(224, 230))     # (LO, HI): the coder state, a register pair inside the statement
+ST_T = tup(226, 2)
+CK = "v255"
+KK = None                            # (k = 2^P - p had a register until round 4: the step no longer needs it)
 FD = [(tup(230 + 4 * k, 2), tup(232 + 4 * k, 2), tup(230 + 4 * k)) for k in range(4)]
 NCH, LIM, FADDR, FOFF = "v246", "v247", "v248", "v249"
 # quad flush: X = flush position | pending << 31 of the lane's own stream; XS[k] = the same of stream 16 k + (lane >> 2);
@@ -111,11 +114,10 @@ def step(a, e0, e1, m0, m1):
         emit  <=>  (state >> (64 - P)) >= p  <=>  (hi >> 16) >= p << (16 - P)    (P <= 12)
         A = emit ? state >> 32 : state;  q_est = mulhi64(A, m) in {q - 1, q};  r_est = A - q_est * p  (< 2p < 2^13: its low 16 bits
         follow from the low 24 bits of q_est alone, one v_mul_u32_u24);  fix <=> r_est >= p
-        state' = (q << P) + c + r = A + q_est * (2^P - p) + (fix ? c + 2^P - p : c)
-    22 VALU instructions + the ring write.  A lone wave executes one instruction after another, dependent or not
+        state' = (q << P) + c + r = (q_est << P) + r_est + (fix ? c + 2^P - p : c)
+    20 VALU instructions + the ring write.  A lone wave executes one instruction after another, dependent or not
     (4.0 cycles of issue + 0.3-1 of operand fetch each: DESIGN.md 3.8), so what counts is the NUMBER of instructions."""
-    a.i(f"v_cmp_ge_u32_sdwa vcc, %[hi], {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
-    a.i(f"v_sub_u32_sdwa {KK}, %[twoP], {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "k = 2^P - p")
+    a.i(f"v_cmp_ge_u32_sdwa vcc, {HI}, {e1} src0_sel:WORD_1 src1_sel:WORD_1", "emit <=> (state >> (64 - P)) >= p")
     if LOCAL_RING:
         a.i(f"v_lshl_add_u32 {RA}, %[wr], 8, %[lanebase]")
     elif ADDR_MODE == "bfe":                    # two instructions, no SGPR operand
@@ -127,9 +129,9 @@ def step(a, e0, e1, m0, m1):
     else:
         a.i(f"v_lshlrev_b32 {RA}, 8, %[wr]")
         a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
-    a.i(f"v_cndmask_b32_e64 {A0}, %[lo], %[hi], vcc")
-    a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
-    a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
+    a.i(f"v_cndmask_b32_e64 {A0}, {LO}, {HI}, vcc")
+    a.i(f"v_cndmask_b32_e64 {A1}, {HI}, 0, vcc")
+    a.ds(f"ds_write_b32 {RA}, {LO}", "W", "candidate word, always written")
     a.i(f"v_addc_co_u32 %[wr], vcc, 0, %[wr], vcc")
     # q_est = floor(A * m / 2^64) = a1*m1 + floor((a1*m0 + a0*m1 + hi32(a0*m0)) / 2^32), the middle sum taken to 65 bits
     a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
@@ -141,11 +143,13 @@ def step(a, e0, e1, m0, m1):
     a.i(f"v_mul_u32_u24_sdwa {RR}, {Q0}, {e1} {SDWA} src0_sel:DWORD src1_sel:WORD_0", "low 24 bits of q_est times p")
     a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est modulo 2^24")
     a.i(f"v_cmp_ge_u32_sdwa vcc, {RR}, {e1} src0_sel:WORD_0 src1_sel:WORD_0", "fix <=> q = q_est + 1")
-    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}", "A + q_lo * k")
-    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}", "      + (q_hi * k) << 32")
-    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + k")
-    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {CK}")
-    a.i(f"v_addc_co_u32 %[hi], vcc, 0, {U1}, vcc")
+    # state' = q 2^P + r + c = q_est 2^P + r_est + (fix ? c + 2^P - p : c): ONE 64-bit mad on [r_est + c', q_est_hi << P]
+    # (until round 4: A + q_est (2^P - p) + c' with a 64-bit mad, a 24-bit mad, a 64-bit add and the subtraction for 2^P - p:
+    # two instructions more)
+    a.i(f"v_cndmask_b32_sdwa {CK}, {e0}, {e0}, vcc {SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + 2^P - p")
+    a.i(f"v_lshlrev_b32 {A1}, %[P], {Q1}", "q_est_hi << P   (q < 2^(64 - P))")
+    a.i(f"v_add_u32_sdwa {A0}, {RR}, {CK} {SDWA} src0_sel:WORD_0 src1_sel:DWORD", "r_est + c'   (< 2^15)")
+    a.i(f"v_mad_u64_u32 {ST_T}, {SD}, {Q0}, %[twoP], {A_T}", "state = q_est 2^P + r_est + c'")
 
 
 def read_syms(a, g, buf, quad):
@@ -353,6 +357,8 @@ def half(a, h, g0):
 def gen():
     a = Asm()
     a.i(f"v_mov_b32 {W1}, 0")
+    a.i(f"v_mov_b32 {LO}, %[lo]")
+    a.i(f"v_mov_b32 {HI}, %[hi]")
     if QUAD_FLUSH:
         quad_flush_invariants(a)
     if ADDR_MODE == "vmask":
@@ -392,6 +398,8 @@ def gen():
     lds_end = [ren.get(t, t) for t in lds_end]
     assert ABL or (lds_end == lds_back and vm_end == a.vm), (lds_end, lds_back, vm_end, a.vm)
     a.i("2:")
+    a.i(f"v_mov_b32 %[lo], {LO}")
+    a.i(f"v_mov_b32 %[hi], {HI}")
     if "shortdrain" in ABL:
         a.i("v_and_b32 %[flushed], -16, %[wr]")
     a.wait_vm_all("nothing may land in the scratch registers after the statement")
@@ -423,7 +431,7 @@ def emit(out, single, symbol_major=False):
         ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
                '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),']
     ops += ['      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
-            '      [tbl] "s"(table_addr_biased), [twoP] "v"(1u << P), [c3f00] "s"(' + ("ring_mask" if single else (RING_MASK + "u" if RING_MASK else "0x3f00u")) + '), [wbase] "s"(words_base),',
+            '      [tbl] "s"(table_addr_biased), [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(' + ("ring_mask" if single else (RING_MASK + "u" if RING_MASK else "0x3f00u")) + '), [wbase] "s"(words_base),',
             '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
             '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
             "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
