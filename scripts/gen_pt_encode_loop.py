@@ -38,12 +38,14 @@ S_T = [tup(BASE + 64 + 4 * i) for i in range(4)]
 E = [[regs(BASE + 80 + 16 * e + 4 * i) for i in range(4)] for e in range(2)]      # {c, p, m_lo, m_hi} per symbol
 A0, A1, W0, W1, U0, U1, T0, T1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(BASE + 112, BASE + 124))
 A_T, W_T, U_T, T_T, SM_T, Q_T = (tup(BASE + 112 + 2 * i, 2) for i in range(6))
-RR, PSHL, KK, CK, RA, EA = (f"v{r}" for r in range(BASE + 124, BASE + 130))
+RR, PSHL, LO, HI, RA, EA = (f"v{r}" for r in range(BASE + 124, BASE + 130))      # (LO, HI): the coder state, a register pair inside the statement
+ST_T = tup(BASE + 126, 2)
+CK = "v254"
 FD = [(tup(BASE + 130 + 4 * k, 2), tup(BASE + 132 + 4 * k, 2), tup(BASE + 130 + 4 * k)) for k in range(4)]
 NCH, LIM, FADDR, FOFF = (f"v{r}" for r in range(BASE + 146, BASE + 150))
 EW = [regs(BASE + 150 + 8 * e, 8) for e in range(2)]         # (c[t], c[t+1]) of the four symbols of two quads
 SD, SAVE = "s[84:85]", "s[86:87]"
-CLOBBERS = [f"v{r}" for r in range(BASE, BASE + 166)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(BASE, BASE + 167)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "memory"]
 # ONE tile buffer per wave (the second one of gen_encode_loop.py costs 36 KiB of LDS the rows need): the next tile is
 # staged between the last read of the current tile (quad 0's symbols, requested in quad 3) and the first read of the
 # next one (its quad 7, requested in quad 2) -- one wave's LDS operations execute in order.
@@ -53,15 +55,14 @@ SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD"
 
 
 def step(a, c, p, m0, m1):
+    """gen_encode_loop_wide.py's step: state' = q_est 2^P + min(r_est, r_est - p) + c + (fix ? 2^P : 0) as one 64-bit mad"""
     a.i(f"v_lshlrev_b32 {PSHL}, %[shP], {p}", "p << (32 - P)")
-    a.i(f"v_sub_u32 {KK}, %[twoP], {p}", "k = 2^P - p")
     a.i(f"v_lshlrev_b32 {RA}, 8, %[wr]")
-    a.i(f"v_cmp_ge_u32 vcc, %[hi], {PSHL}", "emit <=> (state >> (64 - P)) >= p")
+    a.i(f"v_cmp_ge_u32 vcc, {HI}, {PSHL}", "emit <=> (state >> (64 - P)) >= p")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
-    a.i(f"v_add_u32 {CK}, {c}, {KK}")
-    a.i(f"v_cndmask_b32_e64 {A0}, %[lo], %[hi], vcc")
-    a.i(f"v_cndmask_b32_e64 {A1}, %[hi], 0, vcc")
-    a.ds(f"ds_write_b32 {RA}, %[lo]", "W", "candidate word, always written")
+    a.i(f"v_cndmask_b32_e64 {A0}, {LO}, {HI}, vcc")
+    a.i(f"v_cndmask_b32_e64 {A1}, {HI}, 0, vcc")
+    a.ds(f"ds_write_b32 {RA}, {LO}", "W", "candidate word, always written")
     a.i(f"v_addc_co_u32 %[wr], vcc, 0, %[wr], vcc")
     # q_est = floor(A * m / 2^64) = a1*m1 + floor((a1*m0 + a0*m1 + hi32(a0*m0)) / 2^32), the middle sum taken to 65 bits
     a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
@@ -71,13 +72,14 @@ def step(a, c, p, m0, m1):
     a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc", "[T_hi, carry]")
     a.i(f"v_mad_u64_u32 {Q_T}, vcc, {A1}, {m1}, {SM_T}", "q_est in {q - 1, q}")
     a.i(f"v_mul_lo_u32 {RR}, {Q0}, {p}")
-    a.i(f"v_sub_u32 {RR}, {A0}, {RR}")
+    a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est")
+    a.i(f"v_sub_u32 {CK}, {RR}, {p}", "r_est - p   (wraps if r_est < p)")
     a.i(f"v_cmp_ge_u32 vcc, {RR}, {p}", "fix <=> q = q_est + 1")
-    a.i(f"v_mad_u64_u32 {U_T}, {SD}, {Q0}, {KK}, {A_T}")
-    a.i(f"v_mad_u32_u24 {U1}, {Q1}, {KK}, {U1}")
-    a.i(f"v_cndmask_b32 {RR}, {c}, {CK}, vcc")
-    a.i(f"v_add_co_u32 %[lo], vcc, {U0}, {RR}")
-    a.i(f"v_addc_co_u32 %[hi], vcc, 0, {U1}, vcc")
+    a.i(f"v_min_u32 {RR}, {RR}, {CK}", "r")
+    a.i(f"v_cndmask_b32 {CK}, 0, %[twoPv], vcc", "fix 2^P")
+    a.i(f"v_lshlrev_b32 {A1}, %[P], {Q1}", "q_est_hi << P")
+    a.i(f"v_add3_u32 {A0}, {RR}, {c}, {CK}", "r + c + fix 2^P")
+    a.i(f"v_mad_u64_u32 {ST_T}, {SD}, {Q0}, %[twoP], {A_T}", "state = q_est 2^P + r + c + fix 2^P")
 
 
 def read_syms(a, g, buf, quad):
@@ -196,6 +198,8 @@ def half(a, h, g0):
 def gen():
     a = Asm()
     a.i(f"v_mov_b32 {W1}, 0")
+    a.i(f"v_mov_b32 {LO}, %[lo]")
+    a.i(f"v_mov_b32 {HI}, %[hi]")
     a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST full tile of stream s0")
     a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
     a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
@@ -230,6 +234,8 @@ def gen():
     lds_end = [ren.get(t, t) for t in lds_end]
     assert lds_end == lds_back and vm_end == a.vm, (lds_end, lds_back, vm_end, a.vm)
     a.i("2:")
+    a.i(f"v_mov_b32 %[lo], {LO}")
+    a.i(f"v_mov_b32 %[hi], {HI}")
     a.wait_vm_all("nothing may land in the scratch registers after the statement")
     a.wait_lds_all()
     return a, notes
@@ -243,7 +249,7 @@ def main():
            '    : [row0] "v"(tile_row_addr), [tr0] "v"(tile_tr_addr),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [alo] "v"(sym_lo), [bhi] "v"(sym_hi), [rowb] "v"(row_addr_biased),',
-           '      [recip] "s"(recip_addr), [minsym] "s"(min_symbol), [shP] "s"(32u - P), [twoP] "s"(1u << P), [c3f00] "s"(ring_mask), [wbase] "s"(words_base),',
+           '      [recip] "s"(recip_addr), [minsym] "s"(min_symbol), [shP] "s"(32u - P), [P] "s"(P), [twoP] "s"(1u << P), [twoPv] "v"(1u << P), [c3f00] "s"(ring_mask), [wbase] "s"(words_base),',
            '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
