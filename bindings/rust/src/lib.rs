@@ -519,7 +519,7 @@ impl BatchedAnsCoder {
         Ok(out)
     }
 
-    fn decode_iid(&self, src: WordSource, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
+    fn decode_iid(&self, src: WordSource, n_per_stream: usize, model: &DeviceModel, flags: u32, stream: &Stream) -> Result<DecodedBatch> {
         let n_streams = src.n_streams();
         let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams * n_per_stream)?, status: DeviceBuffer::new(n_streams)? };
         check(unsafe {
@@ -538,7 +538,7 @@ impl BatchedAnsCoder {
                 core::ptr::null_mut(),
                 core::ptr::null_mut(),
                 out.status.as_mut_ptr(),
-                ffi::CST_FLAG_NONE,
+                flags,
                 stream.as_raw(),
             )
         })?;
@@ -548,12 +548,13 @@ impl BatchedAnsCoder {
     /// Per stream: `AnsCoder::from_compressed(words[s])?.decode_iid_symbols(n_per_stream, &model)`
     /// (src/stream/stack.rs:299-318, 440-462; src/stream/mod.rs:1016-1031).
     pub fn decode_iid_symbols(&self, encoded: &EncodedBatch, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
-        self.decode_iid(WordSource::Slabs(encoded), n_per_stream, model, stream)
+        self.decode_iid(WordSource::Slabs(encoded), n_per_stream, model, ffi::CST_FLAG_NONE, stream)
     }
 
-    /// The same from a packed batch (e.g. one that arrived through [`Communicator::scatter`]).
+    /// The same from a packed batch (e.g. one that arrived through [`Communicator::scatter`] or from the host: words that are
+    /// not in the GPU's caches, which is what `CST_FLAG_COLD_WORDS` tells the decoder).
     pub fn decode_iid_symbols_packed(&self, packed: &PackedBatch, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
-        self.decode_iid(WordSource::Packed(packed), n_per_stream, model, stream)
+        self.decode_iid(WordSource::Packed(packed), n_per_stream, model, ffi::CST_FLAG_COLD_WORDS, stream)
     }
 
     /// Per stream: `decode_symbols(models)` with one quantized Gaussian per symbol (src/stream/mod.rs:893-908; Python
