@@ -56,6 +56,14 @@ SPREAD_LOADS = bool(os.environ.get("GEN_SPREAD_LOADS"))
 # one or not, so what counts between the entry's arrival and the next lookup's issue is the NUMBER of instructions there
 # (9 before, 12 + a second table read with this form), not their dependent depth; the step is one LDS latency + that section.
 K_PRED = bool(os.environ.get("GEN_KPRED"))
+# EARLY_ELIG (experiment): N = (state >> P) p + (q - c) < 2^32  <=>  state >> P < 2^32 and the
+# 64-bit mad's own high word is 0 -- so the test "state >> P < 2^32 and words remain" moves in front of the lookup's return (it only
+# needs the state), the 24-bit mad for the high word of N behind the next lookup's issue, and the section between a table entry's
+# arrival and the next lookup is 8 instructions instead of 9.
+# ... bit-exact, and 4.7 % SLOWER (0.265 against 0.253 ms, gpurun_out/r04_elig.txt): the two instructions it adds behind the lookup's issue
+# cost more than the one it removes in front of it -- the shadow of the lookup is full.  Kept as an experiment (GEN_ELIG=1).
+EARLY_ELIG = not K_PRED and bool(os.environ.get("GEN_ELIG"))
+ABL_R1 = bool(os.environ.get("GEN_ABL_R1"))      # timing experiment: no min(rd, 1) per step (right only while no stream runs out of words)
 
 
 def gen():
@@ -73,10 +81,12 @@ def gen():
     KQ, BH, M1, M2 = "v130", "v143", "v167", "v168"
     ELIG = "s[88:89]"
     clobbers = [f"v{r}" for r in range(120, 176 if EARLY_STORES else (169 if K_PRED else 167))] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87"] + \
-               (["s88", "s89"] if K_PRED else []) + ["vcc", "memory"]
+               (["s88", "s89"] if K_PRED or EARLY_ELIG else []) + ["vcc", "memory"]
     SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
 
     a.i("v_mov_b32 v123, 0")
+    if ABL_R1:
+        a.i(f"v_mov_b32 {R1}, 1")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     a.i("1:", None)
@@ -113,12 +123,19 @@ def gen():
     a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
     a.ds(f"ds_read_b32 {WD}, {RA}", "w")
-    a.i(f"v_min_u32 {R1}, 1, %[rd]")
+    if EARLY_ELIG:
+        a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+        a.i(f"v_cmp_eq_u32_e64 {ELIG}, 0, {T1}")
+    if not ABL_R1:
+        a.i(f"v_min_u32 {R1}, 1, %[rd]")
     a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
-    a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+    if not EARLY_ELIG:
+        a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
     if K_PRED:
         a.i(f"v_lshrrev_b32 {BH}, 24, {T0}")
         a.i(f"v_cmp_lt_u32 {ELIG}, {T1}, {R1}", "a refill is possible <=> state >> P < 2^32 and words remain")
+    if EARLY_ELIG:
+        a.i(f"v_cndmask_b32_e64 {R1}, 0, {R1}, {ELIG}", "1 if a refill is possible (state >> P < 2^32 and words remain), else 0")
 
     for j in range(32):
         quad, pos = divmod(j, 4)
@@ -157,14 +174,17 @@ def gen():
             a.wait_lds("cp", f"---- step {j}: entry is back")
             a.i(f"v_sub_u32_sdwa {D}, {Q}, {CP} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0", "q - c")
             a.i(f"v_lshrrev_b32 {PR}, 16, {CP}", "p")
-            a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)")
-            a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
+            a.i(f"v_mad_u64_u32 v[120:121], {SD}, {T0}, {PR}, v[122:123]", "N = (state >> P) * p + (q - c)" + ("   (without the high word of state >> P)" if EARLY_ELIG else ""))
+            if not EARLY_ELIG:
+                a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
             a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
             a.wait_lds_all("candidate word (and everything older) is back")
             a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
             a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
             a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
             a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
+            if EARLY_ELIG:
+                a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}", "the high word of N, in the shadow of the lookup")
             a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
             a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
             a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
@@ -190,9 +210,17 @@ def gen():
             a.i(f"v_cmp_lt_u32 {ELIG}, {T1}, {R1}")
         else:
             a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
-            a.i(f"v_min_u32 {R1}, 1, %[rd]")
-            a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
-            a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+            if EARLY_ELIG:
+                a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
+                a.i(f"v_cmp_eq_u32_e64 {ELIG}, 0, {T1}")
+                a.i(f"v_min_u32 {R1}, 1, %[rd]")
+                a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+                a.i(f"v_cndmask_b32_e64 {R1}, 0, {R1}, {ELIG}", "1 if a refill is possible, else 0")
+            else:
+                if not ABL_R1:
+                    a.i(f"v_min_u32 {R1}, 1, %[rd]")
+                a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
+                a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
         if SPREAD_LOADS and pos == 0 and quad < K_CHUNKS:
             request_chunk(quad)      # (after the step's last reader of vcc)
         if EARLY_STORES:
