@@ -551,13 +551,29 @@ def gen_storer():
         s_quad_invariants(a)
     a.wait_lds_all("nothing published yet (and the table, by everybody)")
     a.i("s_barrier")
+    burst = int(os.environ.get("GEN_SBURST", "0"))      # experiment: flush only every `burst`-th window, `burst` groups then
     a.i("1:")
-    (s_flush_quads if SQUAD else s_flush_rows)(a)
-    a.wait_lds_all()
-    a.i("s_barrier")
-    a.i("s_sub_u32 s82, s82, 1")
-    a.i("s_cmp_lg_u32 s82, 0")
-    a.i("s_cbranch_scc1 1b")
+    if burst:
+        for w in range(burst):
+            if w == burst - 1:
+                for _ in range(burst):
+                    (s_flush_quads if SQUAD else s_flush_rows)(a)
+            a.wait_lds_all()
+            a.i("s_barrier")
+            a.i("s_sub_u32 s82, s82, 1")
+            if w < burst - 1:
+                a.i("s_cmp_eq_u32 s82, 0")
+                a.i("s_cbranch_scc1 2f")
+        a.i("s_cmp_lg_u32 s82, 0")
+        a.i("s_cbranch_scc1 1b")
+        a.i("2:")
+    else:
+        (s_flush_quads if SQUAD else s_flush_rows)(a)
+        a.wait_lds_all()
+        a.i("s_barrier")
+        a.i("s_sub_u32 s82, s82, 1")
+        a.i("s_cmp_lg_u32 s82, 0")
+        a.i("s_cbranch_scc1 1b")
     a.wait_vm_all("the stores of the loop (the wave's last groups follow from C++)")
     return a, []
 
