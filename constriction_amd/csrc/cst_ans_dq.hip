@@ -145,6 +145,9 @@ bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout l
     if (a.n_per_stream % kTileSyms != 0 || a.n_per_stream < 2 * kTileSyms || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if (64 * a.n_per_stream * 4 >= 0x100000000ull) return false;                                   // 32-bit row offsets within a wave
+    // the lanes address their words as 32-bit byte offsets from a.words: the span must be KNOWN (packed offsets with
+    // words_capacity = 0, "the caller vouches", could point anywhere: those batches stay on the kernel with 64-bit offsets)
+    if (a.offsets && a.words_capacity == 0) return false;
     const uint64_t span = a.offsets ? a.words_capacity : (uint64_t)a.n_streams * a.stride_words;   // words the lanes address relative to a.words
     return span * 4 + 256 < 0x80000000ull;
 }

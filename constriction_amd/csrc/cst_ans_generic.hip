@@ -82,15 +82,17 @@ __global__ __launch_bounds__(kBlock) void ans_decode_generic_kernel(const Generi
     uint64_t len = ws.n;
     int32_t status = ws.bad ? CST_STREAM_INVALID_DATA : CST_STREAM_OK;
     const uint64_t thresh = 1ull << (S - W), qmask = P == 32 ? 0xffffffffull : ((1ull << P) - 1ull);
+    const uint32_t wmask = W == 32 ? 0xffffffffu : ((1u << W) - 1u);
     uint64_t st = 0;
     if (raw) {
         st = a.state[s];
     } else if (len > 0) {                                      // read_initial_state, stack.rs:440-462
-        const uint32_t first = in[--len];
+        // a Word of the reference cannot carry bits above W: whatever else sits in a 32-bit slot is not part of the word
+        const uint32_t first = in[--len] & wmask;
         if (first == 0u) { status = CST_STREAM_INVALID_DATA; len = 0; }
         else {
             st = first;
-            while (len > 0) { st = (st << W) | in[--len]; if (st >= thresh) break; }
+            while (len > 0) { st = (st << W) | (in[--len] & wmask); if (st >= thresh) break; }
         }
     }
     const int n = a.n_symbols;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_generic_kernel(const Generi
         const uint32_t c = a.cdf[lo], p = a.cdf[lo + 1] - c;
         a.symbols_out[sym_index(a, s, t)] = a.min_symbol + lo;
         st = (st >> P) * (uint64_t)p + (uint64_t)(q - c);
-        if (st < thresh && len > 0) st = (st << W) | in[--len];   // decoding past the end is legal: no refill, stack.rs:1062-1065
+        if (st < thresh && len > 0) st = (st << W) | (in[--len] & wmask);   // decoding past the end is legal: no refill, stack.rs:1062-1065
     }
     if (raw) a.state[s] = st;
     if (a.n_words_out) a.n_words_out[s] = (uint32_t)len;

@@ -93,7 +93,9 @@ struct PtMeta {
     uint16_t pad;
 };
 constexpr int kPtBucketBits = 7, kPtBuckets = 1 << kPtBucketBits;
-constexpr int kPtRowPad = 7;          // sentinel entries behind every decoder row (the decoder reads eight entries at a time)
+constexpr int kPtRowPad = 5;          // sentinel entries behind every decoder row: the decoder reads SIX entries at a time from the
+                                      // aligned pair that holds its first candidate (scripts/gen_pt_decode_loop.py, WINDOW = 6; the
+                                      // measured-and-not-adopted GEN_PT_WINDOW=8 needs 7 here)
 constexpr uint32_t kPtRunMark = 0xfffu;
 
 } // namespace cst

@@ -237,8 +237,11 @@ cst_status cst_ans_encode_batch(const cst_model *model, cst_coder_config cfg, co
  * leaves the buffer -- or, in slab form, whose d_n_words[s] exceeds stride_words (checked always) -- is decoded as an
  * EMPTY stream and reports CST_STREAM_INVALID_DATA; nothing outside the buffer is read.  words_capacity = 0 means
  * "unknown": the caller vouches for the packed offsets as in ABI 2.  (The kernels read whole aligned 16-byte chunks:
- * up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; a capacity that is
- * the true size of a hipMalloc'ed buffer satisfies this.)  Every decode entry point below takes the same argument.
+ * up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; with
+ * CST_FLAG_COLD_WORDS whole aligned 64-byte groups: up to 60 bytes either side, inside the allocation that holds d_words
+ * -- hipMalloc aligns and pads allocations to 256 bytes -- and that decoder is only taken when the span of the words is known,
+ * i.e. never for packed offsets with words_capacity = 0.  A capacity that is the true size of a hipMalloc'ed buffer
+ * satisfies both.)  Every decode entry point below takes the same argument.
  * The model must have been created on the current device (CST_ERR_INVALID_ARGUMENT otherwise).
  * With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
  * count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).

@@ -1,10 +1,13 @@
-"""GPU parity tests of the chain coder: the drop-in `constriction_amd.stream.chain.ChainCoder` against the reference's own
-vectors (tests/python/test_constriction.py:58-126, test_docexamples.py:932-995) and against the CPU oracle
+"""GPU parity tests of the chain coder: the drop-in `constriction_amd.stream.chain.ChainCoder` against the reference's
+vectors, kept as data in tests/golden/chain_vectors.json (each entry cites its source), and against the CPU oracle
 (oracle.ChainCoder = src/stream/chain.rs restated), and the batched C entry points for many chains at once."""
-import ctypes as C
+import json
+from pathlib import Path
 
 import numpy as np
 import pytest
+
+import golden_util
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -25,82 +28,71 @@ def O():
     return oracle
 
 
-def test_chain_independence(constriction):
-    data = np.array([0x80d14131, 0xdda97c6c, 0x5017a640, 0x01170a3e], np.uint32)
-    probabilities = np.array([[0.1, 0.7, 0.1, 0.1], [0.2, 0.2, 0.1, 0.5], [0.2, 0.1, 0.4, 0.3]])
-    model = constriction.stream.model.Categorical(perfect=False)
-    chain = constriction.stream.chain.ChainCoder(data, False, True)
-    assert np.all(chain.decode(model, probabilities) == [0, 3, 3])
-    probabilities[0, :] = np.array([0.09, 0.71, 0.1, 0.1])
-    chain = constriction.stream.chain.ChainCoder(data, False, True)
-    assert np.all(chain.decode(model, probabilities) == [1, 3, 3])
+def _chain_vectors():
+    with open(Path(__file__).parent / "golden" / "chain_vectors.json") as f:
+        return json.load(f)["vectors"]
 
 
-def test_chain_gaussian(constriction, O):
-    rng = np.random.RandomState(123)
-    original_data = rng.randint(2**32, size=100, dtype=np.uint32)
-    decoder = constriction.stream.chain.ChainCoder(original_data, seal=True)
-    model = constriction.stream.model.QuantizedGaussian(-100, 100)
-    means = np.arange(50, dtype=np.float64)
-    stds = np.array([10.0] * 50, dtype=np.float64)
-    symbols = decoder.decode(model, means, stds)
-
-    want = O.ChainCoder(original_data, seal=True)
-    models = [O.GaussianModel(-100, 100, m, s, 24, 32) for m, s in zip(means, stds)]
-    assert symbols.tolist() == want.decode(models).tolist()
-
-    remainders_prefix, remainders_suffix = decoder.get_remainders()
-    wp, ws = want.get_remainders()
-    assert remainders_prefix.tolist() == wp.tolist() and remainders_suffix.tolist() == ws.tolist()
-    assert len(remainders_prefix) + len(remainders_suffix) < len(original_data)
-
-    encoder1 = constriction.stream.chain.ChainCoder(remainders_suffix, is_remainders=True)
-    encoder1.encode_reverse(symbols, model, means, stds)
-    recovered_prefix1, recovered_suffix1 = encoder1.get_data(unseal=True)
-    assert len(recovered_prefix1) == 0
-    assert np.all(np.concatenate((remainders_prefix, recovered_suffix1)) == original_data)
-
-    remainders = np.concatenate((remainders_prefix, remainders_suffix))
-    encoder2 = constriction.stream.chain.ChainCoder(remainders, is_remainders=True)
-    encoder2.encode_reverse(symbols, model, means, stds)
-    assert np.all(np.concatenate(encoder2.get_data(unseal=True)) == original_data)
-
-    encoder3 = decoder
-    encoder3.encode_reverse(symbols, model, means, stds)
-    recovered_prefix3, recovered_suffix3 = encoder3.get_data(unseal=True)
-    assert len(recovered_prefix3) == 0
-    assert np.all(recovered_suffix3 == original_data)
+def _dropin_model(M, spec):
+    """(model, per-symbol parameter arrays) of the drop-in for a model spec of tests/golden/chain_vectors.json"""
+    kind = spec["kind"]
+    if kind == "categorical_fast_rows":
+        return M.Categorical(perfect=False), (np.array(spec["probs"], np.float64),)
+    if kind == "gaussian":
+        return M.QuantizedGaussian(spec["lo"], spec["hi"]), (np.array(spec["means"]), np.array(spec["stds"]))
+    stats = pytest.importorskip("scipy.stats")
+    lo, hi = spec["lo"], spec["hi"]
+    if kind == "scipy_cauchy":
+        frozen = stats.cauchy(loc=spec["loc"], scale=spec["scale"])
+        return M.CustomModel(frozen.cdf, frozen.ppf, lo, hi), ()
+    if kind == "scipy_cauchy_family":
+        return (M.CustomModel(lambda x, a, b: stats.cauchy.cdf(x, a, b), lambda x, a, b: stats.cauchy.ppf(x, a, b), lo, hi),
+                (np.array(spec["locs"]), np.array(spec["scales"])))
+    if kind == "scipy_binom_family":
+        n = spec["n"]
+        return (M.CustomModel(lambda x, p: stats.binom.cdf(x, n=n, p=p), lambda x, p: stats.binom.ppf(x, n=n, p=p), lo, hi),
+                (np.array(spec["ps"]),))
+    raise ValueError(kind)
 
 
-def test_custom_model_chain(constriction):
-    scipy_stats = pytest.importorskip("scipy.stats")
-    compressed = np.array([0xa5dd25f7, 0xfaef49b5, 0xd5b12228, 0x156ceb98, 0x71a0a92b,
-                           0x99e6d365, 0x2eebfadb, 0x404a567b, 0xf6cbdc09, 0xe63f3848], dtype=np.uint32)
-    model_scipy = scipy_stats.cauchy(loc=10.3, scale=5.8)
-    model = constriction.stream.model.CustomModel(model_scipy.cdf, model_scipy.ppf, -100, 100)
-    coder = constriction.stream.chain.ChainCoder(compressed, False, False)
-    symbols = coder.decode(model, 4)
-    assert np.all(symbols == np.array([18, 6, 33, 59]))
-    coder.encode_reverse(symbols, model)
-    assert np.all(np.hstack(coder.get_data()) == compressed)
-
-    model = constriction.stream.model.CustomModel(lambda x, loc, scale: scipy_stats.cauchy.cdf(x, loc, scale),
-                                                  lambda x, loc, scale: scipy_stats.cauchy.ppf(x, loc, scale), -100, 100)
-    params = np.array([(7.3, 3.9), (11.5, 5.2), (-3.2, 4.9), (25.9, 7.1)])
-    coder = constriction.stream.chain.ChainCoder(compressed, False, False)
-    symbols = coder.decode(model, params[:, 0].copy(), params[:, 1].copy())
-    assert np.all(symbols == np.array([13, 7, 16, 85]))
-    coder.encode_reverse(symbols, model, params[:, 0].copy(), params[:, 1].copy())
-    assert np.all(np.hstack(coder.get_data()) == compressed)
-
-    model = constriction.stream.model.CustomModel(lambda x, params: scipy_stats.binom.cdf(x, n=10, p=params),
-                                                  lambda x, params: scipy_stats.binom.ppf(x, n=10, p=params), 0, 10)
-    success_probabilities = np.array([0.3, 0.7, 0.2, 0.6])
-    coder = constriction.stream.chain.ChainCoder(compressed, False, False)
-    symbols = coder.decode(model, success_probabilities)
-    assert np.all(symbols == np.array([4, 6, 4, 9]))
-    coder.encode_reverse(symbols, model, success_probabilities)
-    assert np.all(np.hstack(coder.get_data()) == compressed)
+@pytest.mark.parametrize("vec", _chain_vectors(), ids=lambda v: v["name"])
+def test_chain_reference_vectors(constriction, O, vec):
+    """Every vector of tests/golden/chain_vectors.json through the drop-in: the symbols the reference expects (and the
+    oracle's, where the oracle has the model), and -- `restore` -- every way of putting them back restores the words."""
+    Chain, M = constriction.stream.chain.ChainCoder, constriction.stream.model
+    words = np.array(vec["words"], np.uint32)
+    model, params = _dropin_model(M, vec["model"])
+    args = params if params else (vec["n"],)
+    coder = Chain(words, False, vec["seal"])
+    got = coder.decode(model, *args)
+    if vec["symbols"] is not None:
+        assert got.tolist() == vec["symbols"]
+    if vec["model"]["kind"] in ("gaussian", "categorical_fast_rows"):
+        omodels, _ = golden_util.models_for({"model": vec["model"]}, 24, O)
+        want = O.ChainCoder(words, seal=vec["seal"])
+        assert got.tolist() == want.decode(omodels).tolist()
+        for mine, theirs in zip(coder.get_remainders(), want.get_remainders()):
+            assert mine.tolist() == theirs.tolist()
+    if not vec.get("restore"):
+        return
+    prefix, suffix = coder.get_remainders()
+    if vec.get("shrinks"):
+        assert len(prefix) + len(suffix) < len(words)
+    unseal = vec["seal"]
+    # (a) the coder that decoded them takes them back
+    coder.encode_reverse(got, model, *params)
+    back = coder.get_data(unseal=unseal)
+    assert np.concatenate(back).tolist() == words.tolist()
+    if vec["seal"]:
+        assert len(back[0]) == 0
+        # (b) a coder made of all remainders, (c) one made of the suffix alone (the prefix was never touched)
+        whole = Chain(np.concatenate((prefix, suffix)), is_remainders=True)
+        whole.encode_reverse(got, model, *params)
+        assert np.concatenate(whole.get_data(unseal=True)).tolist() == words.tolist()
+        tail = Chain(suffix, is_remainders=True)
+        tail.encode_reverse(got, model, *params)
+        head, rest = tail.get_data(unseal=True)
+        assert len(head) == 0 and np.concatenate((prefix, rest)).tolist() == words.tolist()
 
 
 @pytest.mark.parametrize("kind", ["gaussian", "table", "rows"])

@@ -60,3 +60,44 @@ def test_restore_many(W, S, P, words, n):
         c.encode_reverse(symbols, models)
         a, b = c.get_data()
         assert np.array_equal(np.concatenate((pre, a, b)), compressed)
+
+
+def _vector_models(spec, P=24):
+    """oracle models for a model spec of tests/golden/chain_vectors.json (the scipy ones tabulated through the LeakyQuantizer)"""
+    import golden_util
+    kind = spec["kind"]
+    if kind in ("gaussian", "categorical_fast_rows"):
+        return golden_util.models_for({"model": spec}, P, O)[0]
+    stats = pytest.importorskip("scipy.stats")
+    lo, hi = spec["lo"], spec["hi"]
+    table = lambda cdf: O.TableModel(golden_util.leaky_table(cdf, lo, hi, P), lo, P)
+    if kind == "scipy_cauchy":
+        return table(stats.cauchy(loc=spec["loc"], scale=spec["scale"]).cdf)
+    if kind == "scipy_cauchy_family":
+        return [table(lambda x, a=a, b=b: stats.cauchy.cdf(x, a, b)) for a, b in zip(spec["locs"], spec["scales"])]
+    if kind == "scipy_binom_family":
+        return [table(lambda x, p=p: stats.binom.cdf(x, n=spec["n"], p=p)) for p in spec["ps"]]
+    raise ValueError(kind)
+
+
+def _load_chain_vectors():
+    import json
+    from pathlib import Path
+    with open(Path(__file__).parent / "golden" / "chain_vectors.json") as f:
+        return json.load(f)["vectors"]
+
+
+@pytest.mark.parametrize("vec", _load_chain_vectors(), ids=lambda v: v["name"])
+def test_chain_vectors_through_the_oracle(vec):
+    """tests/golden/chain_vectors.json pins oracle.ChainCoder: expected symbols of the reference's tests, words restored."""
+    words = np.array(vec["words"], np.uint32)
+    models = _vector_models(vec["model"])
+    coder = O.ChainCoder(words, seal=vec["seal"])
+    got = coder.decode(models) if isinstance(models, list) else coder.decode(models, vec["n"])
+    if vec["symbols"] is not None:
+        assert got.tolist() == vec["symbols"]
+    if "ans_symbols" in vec:       # the same words through the stack coder: EVERY symbol depends on the first model there
+        assert O.AnsCoder(words, seal=True).decode(models).tolist() == vec["ans_symbols"]
+    if vec.get("restore"):
+        coder.encode_reverse(got, models)
+        assert np.concatenate(coder.get_data(unseal=vec["seal"])).tolist() == words.tolist()
