@@ -78,6 +78,9 @@ SIGNATURES = {
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
     "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
+    "cst_range_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
+    "cst_range_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
+    "cst_range_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_ans_encode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _vp, _vp, _vp]),
     "cst_ans_decode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _vp, _vp]),
     "cst_ans_count_until": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _i32, _z, _vp, _vp, _vp]),
@@ -141,7 +144,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.cst_abi_version() != 3:
+    if lib.cst_abi_version() != 4:
         raise BackendUnavailable("ABI version mismatch between _native.py and libconstriction_amd.so")
     _lib = lib
     return lib

@@ -755,26 +755,41 @@ class Checkpoints:
 
 
 def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, config=(32, 64, 24), layout="stream_major",
-                            stride: Optional[int] = None):
+                            stride: Optional[int] = None, out=None):
     """ans_encode + a checkpoint in front of every `interval` symbols.  Returns (EncodedBatch, Checkpoints); the words are
-    those of ans_encode."""
+    those of ans_encode.  Models with one table per stream are taken too (stream-major): see DESIGN.md 4.12 (sub-lanes).
+    out: (EncodedBatch, Checkpoints) of an earlier call with the same shapes, to code into the same buffers."""
     symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
-    stride = stride or max_words(n_per, config)
     dev = symbols.device
-    out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
-                       torch.empty(n_streams, dtype=torch.int32, device=dev),
-                       torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
     n_chunks = (n_per + interval - 1) // interval
-    ck = Checkpoints(int(interval), torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
-                     torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
+    if out is not None:
+        out, ck = out
+        stride = out.words.shape[1]
+        if ck.interval != int(interval) or tuple(ck.pos.shape) != (n_streams, n_chunks):
+            raise ValueError("out: checkpoints of another shape")
+    else:
+        stride = stride or max_words(n_per, config)
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+        ck = Checkpoints(int(interval), torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
+                         torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
     N.check(N.lib().cst_ans_encode_batch_ckpt(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), stride,
                                               _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status),
                                               _stream_ptr()), "cst_ans_encode_batch_ckpt")
     return out, ck
 
 
-def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None):
+def _ckpt_scratch(kind, dev, nbytes):
+    key = (kind, dev.index)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf
+
+
+def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None):
     """Decodes every chunk on its own lane (AnsCoder.seek(pos, state) + `interval` symbols per chunk).
     Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
     n_streams = encoded.n_words.numel()
@@ -782,10 +797,65 @@ def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, mod
     n_chunks = checkpoints.pos.shape[1]
     if out is None:
         out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
-    status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
     L = N.lib()
-    scratch = torch.empty(L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval), dtype=torch.uint8, device=dev)
+    scratch = _ckpt_scratch("ans_ckpt", dev, L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
     N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
                                         encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
                                         n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()), "cst_ans_decode_batch_ckpt")
+    return _to_symbols(model, out), status
+
+
+@dataclass
+class RangeCheckpoints:
+    """RangeEncoder.pos() in front of every chunk (queue.rs:182-196): words emitted so far incl. held-back ones, and the state"""
+    interval: int
+    pos: torch.Tensor        # int32 [n_streams, n_chunks]
+    lower: torch.Tensor      # int64 [n_streams, n_chunks]  (uint64 values)
+    range: torch.Tensor      # int64 [n_streams, n_chunks]
+
+
+def range_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, config=(32, 64, 12), layout="stream_major",
+                              stride: Optional[int] = None, out=None):
+    """range_encode + a jump point in front of every `interval` symbols.  Returns (EncodedBatch, RangeCheckpoints); the words
+    are those of range_encode."""
+    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    dev = symbols.device
+    n_chunks = (n_per + interval - 1) // interval
+    if out is not None:
+        out, ck = out
+        stride = out.words.shape[1]
+        if ck.interval != int(interval) or tuple(ck.pos.shape) != (n_streams, n_chunks):
+            raise ValueError("out: checkpoints of another shape")
+    else:
+        stride = stride or range_max_words(n_per, config)
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+        ck = RangeCheckpoints(int(interval), *(torch.zeros((n_streams, n_chunks), dtype=dt, device=dev)
+                                               for dt in (torch.int32, torch.int64, torch.int64)))
+    N.check(N.lib().cst_range_encode_batch_ckpt(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), stride,
+                                                _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.lower), _ptr(ck.range),
+                                                _ptr(out.status), _stream_ptr()), "cst_range_encode_batch_ckpt")
+    return out, ck
+
+
+def range_decode_checkpointed(encoded: EncodedBatch, checkpoints: RangeCheckpoints, model: Model, n_per_stream: int, out=None, status=None):
+    """Every chunk on its own lane: RangeDecoder.seek(pos, (lower, range)) + `interval` symbols per chunk.
+    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
+    n_streams = encoded.n_words.numel()
+    dev = encoded.words.device
+    n_chunks = checkpoints.pos.shape[1]
+    if out is None:
+        out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
+    L = N.lib()
+    scratch = _ckpt_scratch("range_ckpt", dev, L.cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
+    N.check(L.cst_range_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
+                                          encoded.words.numel(), _ptr(encoded.n_words), checkpoints.interval, _ptr(checkpoints.pos),
+                                          _ptr(checkpoints.lower), _ptr(checkpoints.range), _ptr(out), n_streams, n_per_stream,
+                                          _ptr(scratch), _ptr(status), _stream_ptr()), "cst_range_decode_batch_ckpt")
     return _to_symbols(model, out), status

@@ -86,6 +86,21 @@ __global__ void ckpt_offsets_kernel(const uint64_t* __restrict__ offsets, size_t
     out[v] = offsets ? offsets[s] : s * stride_words;
 }
 
+// decoding WITHOUT the jump points (the words are the plain encoder's): chunk 0's jump point is the whole stream --
+// pos[s][0] words in the bulk, state[s][0] the final coder state
+__global__ void ckpt_whole_stream_kernel(const uint32_t* __restrict__ pos, const uint64_t* __restrict__ state, size_t n_streams, size_t n_chunks,
+                                         uint32_t* __restrict__ n_words, uint64_t* __restrict__ st) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    n_words[s] = pos[s * n_chunks];
+    st[s] = state[s * n_chunks];
+}
+
+__global__ void ckpt_spread_status_kernel(const int32_t* __restrict__ per_stream, size_t n_streams, size_t n_chunks, int32_t* __restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_streams * n_chunks) out[v] = per_stream[v / n_chunks];
+}
+
 } // namespace cst
 
 using namespace cst;
@@ -98,11 +113,18 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cf
                                      int32_t* d_status, void* stream) {
     if (!model || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
     if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
-    if (!config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision) return CST_ERR_INVALID_ARGUMENT;
     if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+    if (model->per_stream) {
+        // one table per stream (config C3): the compact-row encoder notes the jump points on its way (cst_ans_pt.hip), at
+        // the speed of the plain encoder for chunks of whole 32-symbol tiles
+        if (!pt_usable(model, cfg, layout, n_per_stream) || model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+        return ans_encode_pt_ckpt(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, ckpt_interval, d_ckpt_pos,
+                                  d_ckpt_state, d_status, (hipStream_t)stream);
+    }
     CkptEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision; a.words = d_words;
@@ -139,6 +161,28 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
     if (n_streams == 0 || n_per_stream == 0) return CST_OK;
     const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
     hipStream_t hs = (hipStream_t)stream;
+    if (model->per_stream) {
+        if (!d_symbols || !config_supported(cfg) || cfg.precision != model->precision || model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        // the lanes of a stream share its table in LDS: two waves per SIMD (cst_ans_pt.hip, ans_decode_pt_sub_kernel)
+        if (n_chunks >= 2 && pt_sub_usable(model, cfg, n_streams, n_per_stream, ckpt_interval))
+            return ans_decode_pt_sub(model, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos, d_ckpt_state, d_symbols,
+                                     n_streams, n_per_stream, d_status, hs);
+        // any other shape: the jump points are side information -- decode the streams whole (the first one IS the whole stream)
+        uint64_t* w_state = reinterpret_cast<uint64_t*>(d_scratch);
+        uint32_t* w_n = reinterpret_cast<uint32_t*>(w_state + n_streams);
+        int32_t* w_status = reinterpret_cast<int32_t*>(w_n + n_streams);
+        hipLaunchKernelGGL(ckpt_whole_stream_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, hs, d_ckpt_pos, d_ckpt_state, n_streams,
+                           n_chunks, w_n, w_state);
+        CST_HIP_TRY(hipGetLastError());
+        const cst_status rc = cst_ans_decode_batch(model, cfg, d_words, d_offsets, stride_words, words_capacity, w_n, d_symbols, n_streams, n_per_stream,
+                                                   CST_LAYOUT_STREAM_MAJOR, w_state, nullptr, w_status, CST_FLAG_RAW_STATE, stream);
+        if (rc != CST_OK) return rc;
+        hipLaunchKernelGGL(ckpt_spread_status_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, w_status, n_streams, n_chunks, d_status);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    }
     uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
     uint64_t* v_state = v_offsets + n_virtual;
     hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);

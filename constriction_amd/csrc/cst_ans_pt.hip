@@ -52,6 +52,12 @@ struct PtArgs {
     int32_t* status;
     uint32_t flags;
     uint64_t words_capacity;   // decode: uint32 slots behind `words_in` (0 = unknown): see word_slice
+    // jump points (Pos / Seek, stack.rs:1107-1139): [n_streams][n_chunks] (words in the bulk, coder state) in front of every
+    // chunk of `interval` symbols; written by the checkpointing encoder, read by the sub-lane decoder
+    uint32_t* ckpt_pos;
+    uint64_t* ckpt_state;
+    size_t interval, n_chunks;
+    int32_t sub_shift;         // sub-lane decoder: log2(lanes per stream)
 };
 
 // Main loop of the decoder for P = 12: all full tiles of a FULL wave in one asm statement (generated, with its wait
@@ -85,12 +91,44 @@ __device__ __forceinline__ void pt_encode_tiles_loop(uint32_t& lo, uint32_t& hi,
 #include "cst_pt_encode_loop.inc"
 }
 
+// ... the same with jump points (GEN_PT_CK=1 of the generator): every ck_tiles tiles the lanes store (wr, state) at element
+// ck_index of the two checkpoint arrays and step to the chunk in front
+__device__ __forceinline__ void pt_encode_tiles_loop_ck(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                        int32_t& smax, uint32_t& ck_index, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                        uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off, uint32_t sym_lo,
+                                                        uint32_t sym_hi, uint32_t row_addr_biased, uint32_t recip_addr, int32_t min_symbol,
+                                                        uint32_t P, uint32_t ring_mask, const void* words_base, uint64_t symbols_base,
+                                                        uint32_t n_tiles, const void* ck_pos_base, const void* ck_state_base,
+                                                        uint32_t ck_tiles, const uint32_t (&goff)[8]) {
+#include "cst_pt_encode_loop_ck.inc"
+}
+
+// Main loop of the SUB-LANE decoder (GEN_PT_SUB=1 of scripts/gen_pt_decode_loop.py): the same chain, the symbol tile in bytes
+__device__ __forceinline__ void pt_decode_tiles_loop_sub(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
+                                                         uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
+                                                         uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
+                                                         uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                         uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                         const uint32_t (&goff)[8], bool plain_stores) {
+    if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_pt_decode_loop_sub.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_pt_decode_loop_sub.inc"
+#undef CST_STORE_MOD
+    }
+}
+
 // copies this block's rows into LDS (coalesced, 4 bytes per lane)
 __device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* src, uint32_t n_words) {
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) rows_l[i] = src[i];
 }
 
 // LDS layout: [word rings, 8 KiB per wave][reciprocals 8 B x 2^P][symbol tiles][rows]
+// CK: note a jump point in front of every chunk of a.interval symbols (a.ckpt_pos / a.ckpt_state)
+template <bool CK>
 __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -139,17 +177,26 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
     };
 
     const int32_t* my = a.symbols_in + (active ? s : 0) * N;
-    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_in) & 15) == 0);
+    // (jump points lie on tile boundaries or the tiles are not used: chunks of 32 k symbols are the fast case)
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_in) & 15) == 0) && (!CK || a.interval % kTileSyms == 0);
     const size_t n_full = vec ? N / kTileSyms : 0;
+    // AnsCoder::pos() once symbols [t, N) are encoded, if a chunk starts at t
+    auto note_jump_point = [&](size_t t) {
+        if (CK && active && t % a.interval == 0) {
+            a.ckpt_pos[s * a.n_chunks + t / a.interval] = L.out.wr;
+            a.ckpt_state[s * a.n_chunks + t / a.interval] = (uint64_t)L.state;
+        }
+    };
     // ragged top part [32 * n_full, N): direct reads
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
         const int32_t v = active ? my[t] : a.min_symbol;
         L.template step<true>(entry_of(v), P);
         L.flush_chunks();
+        note_jump_point(t);
     }
     bool done = false;
-    if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24)) {
+    if (n_full > 0 && s0 + kWave <= a.n_streams && N < (1u << 24) && (!CK || (N % kTileSyms == 0 && a.n_streams * a.n_chunks < (1u << 28)))) {
         // ---- main loop as one asm statement (full wave, 64-byte aligned slabs of whole 64-byte groups, 32-bit offsets) ----
         const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words_out));
         const bool ok = slab_off + 4ull * L.out.cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
@@ -166,10 +213,19 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
             int32_t smin = a.min_symbol, smax = a.min_symbol;
             const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-            pt_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, lds_addr(tile + lane * kTileStride), lds_addr(tile) + tr_off,
-                                 L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A, lds_addr(recip), a.min_symbol,
-                                 (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out, symbols_base,
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            if constexpr (CK) {
+                uint32_t ck_index = (uint32_t)(s * a.n_chunks + a.n_chunks - 1);        // the last chunk's jump point comes first
+                pt_encode_tiles_loop_ck(lo, hi, L.out.wr, L.out.flushed, smin, smax, ck_index, lds_addr(tile + lane * kTileStride),
+                                        lds_addr(tile) + tr_off, L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A,
+                                        lds_addr(recip), a.min_symbol, (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out,
+                                        symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), a.ckpt_pos, a.ckpt_state,
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a.interval / kTileSyms)), goff);
+            } else {
+                pt_encode_tiles_loop(lo, hi, L.out.wr, L.out.flushed, smin, smax, lds_addr(tile + lane * kTileStride), lds_addr(tile) + tr_off,
+                                     L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A, lds_addr(recip), a.min_symbol,
+                                     (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out, symbols_base,
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
+            }
             L.state = ((uint64_t)hi << 32) | lo;
             // fold the extremes into `bad` (largest raw table index): a symbol below min_symbol wraps to a huge index
             L.bad = max(L.bad, max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol));
@@ -201,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
                 L.template step<true>(e3, P); L.template step<true>(e2, P); L.template step<true>(e1, P); L.template step<true>(e0, P);
                 e3 = n3; e2 = n2; e1 = n1; e0 = n0;
             }
+            note_jump_point(tb * kTileSyms);
         }
     }
 
@@ -360,6 +417,167 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// SUB-LANE decoder (round 5): k = 2^sub_shift jump points per stream, every (stream, chunk) pair on its own lane.
+//
+// ans_decode_pt_kernel runs ONE wave per SIMD (its rings, tiles and rows fill the LDS) and spends 183 of its 392 cycles per
+// symbol waiting for its two dependent LDS round trips (profiles/r04_sq_counters.md).  The reference's own remedy for "one
+// coder decodes strictly in order" is the jump table of Pos / Seek (stack.rs:1107-1139): the encoder notes (words in the
+// bulk, state) in front of every chunk, and AnsCoder::seek(pos, state) resumes there.  So a workgroup here is EIGHT waves
+// (two per SIMD: one wave's lookups are in flight while its sibling issues) for 512 / k streams, lane v decoding chunk
+// v % k of stream v / k; the k lanes of a stream share that stream's row and bucket index in LDS, so the tables cost what
+// they cost the plain kernel (less: fewer streams per workgroup for k > 2).  What pays for the second set of rings is
+// the symbol tile: bytes instead of int32 (GEN_PT_SUB of the generator), one landing area for unused chunk slots.
+// LDS layout: [word rings, 8 KiB per wave][bucket index 128 B per stream][byte tiles 2304 B per wave][dump 1 KiB][rows]
+// The symbol matrix [n_streams][N] is the matrix [n_streams * k][N / k] of the virtual streams; words, counts and status are
+// those of any other decoder of these words (the jump points are side information).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSubThreads = 512;
+constexpr int kSubWaves = kSubThreads / kWave;
+constexpr size_t kSubRingBytes = (size_t)kSubWaves * kPtRingSlots * kWave * 4;        // 64 KiB
+constexpr int kSubTileRow = 36;                                                        // bytes between the rows of a byte tile
+constexpr size_t kSubTileBytes = (size_t)kWave * kSubTileRow;                          // 2304 B per wave
+constexpr size_t kSubDumpBytes = 4 * kWave * 4;                                        // ONE landing area (never read)
+
+__global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const PtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    const int ks = a.sub_shift;
+    // Wave w of the grid decodes chunk w % k of the 64 streams of group w / k: the lanes of a wave are 64 DIFFERENT streams at the
+    // same chunk, so their symbol rows lie a whole stream apart, like the plain decoder's (lanes that were the chunks of one
+    // stream -- rows n_per_stream / k apart -- measured 10-20 % slower at k = 4: 4-KiB strides meet in the memory channels).
+    // A workgroup's eight waves are the k chunks of 8 / k groups (k <= 8) or eight chunks of one group (k = 16).
+    const size_t wave_global = (size_t)blockIdx.x * kSubWaves + wave_in_block;
+    const uint32_t chunk = (uint32_t)(wave_global & (((size_t)1 << ks) - 1));
+    const size_t s0 = (wave_global >> ks) * kWave;
+    const size_t block_s0 = (((size_t)blockIdx.x * kSubWaves) >> ks) * kWave;
+    if (block_s0 >= a.n_streams) return;                               // (the whole workgroup)
+    const uint32_t S = (uint32_t)max(kSubWaves >> ks, 1) * kWave;     // streams whose tables this workgroup stages
+    const size_t l1_bytes = (size_t)S * kPtBuckets;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kPtRingSlots * kWave);
+    uint8_t* l1_l = smem + kSubRingBytes;
+    uint8_t* tile = smem + kSubRingBytes + l1_bytes + (size_t)wave_in_block * kSubTileBytes;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kSubRingBytes + l1_bytes + kSubWaves * kSubTileBytes) + lane;
+    uint32_t* rows_l = reinterpret_cast<uint32_t*>(smem + kSubRingBytes + l1_bytes + kSubWaves * kSubTileBytes + kSubDumpBytes);
+
+    const size_t block_s1 = block_s0 + S < a.n_streams ? block_s0 + S : a.n_streams;
+    const int bshift = P - kPtBucketBits;
+    {   // bucket index of the workgroup's streams, interleaved in groups of G = 2^bshift streams (see ans_decode_pt_kernel)
+        const size_t have = (block_s1 - block_s0) * kPtBuckets;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.l1 + block_s0 * kPtBuckets);
+        for (uint32_t i = threadIdx.x; i < l1_bytes / 4; i += blockDim.x) {
+            const uint32_t w = (size_t)i * 4 < have ? src[i] : 0u;
+            const uint32_t j = (4 * i) / kPtBuckets, k = (4 * i) % kPtBuckets;
+            uint8_t* d = l1_l + (((j >> bshift) * kPtBuckets) << bshift) + (j & ((1u << bshift) - 1u));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[(k + b) << bshift] = (uint8_t)(w >> (8 * b));
+        }
+    }
+    // the rows of streams [block_s0, block_s1): a contiguous piece of their block of kBlock tables (rows lie back to back)
+    const size_t mb = block_s0 / kBlock;
+    const uint32_t first_off = a.meta[block_s0].dec_off;
+    {
+        const uint32_t bb = a.block_base[mb];
+        const uint32_t end = (block_s1 % kBlock != 0 && block_s1 < a.n_streams) ? bb + a.meta[block_s1].dec_off : a.block_base[mb + 1];
+        pt_stage_rows(rows_l, a.rows_dec + bb + first_off, end - (bb + first_off));
+    }
+    __syncthreads();
+
+    if (s0 >= a.n_streams) return;
+    const size_t s_lane = s0 + lane;
+    const bool active = s_lane < a.n_streams;
+    const size_t s = active ? s_lane : block_s0;
+    const size_t v = (s << ks) + chunk;                               // index of (stream, chunk) in the jump table and in d_status
+    const uint32_t ls = (uint32_t)(s - block_s0);                     // the lane's stream within the workgroup
+    const size_t N = a.n_per_stream;
+    const size_t K = a.interval;                                      // symbols per chunk
+    const uint32_t qmask = (1u << P) - 1u;
+    const uint32_t bucket_mask = (uint32_t)(kPtBuckets - 1) << bshift;
+    const PtMeta mt = a.meta[s];
+    const uint32_t* rowp = rows_l + (mt.dec_off - first_off);        // 8-byte aligned
+    const uint32_t row_addr = lds_addr(rowp);
+    const uint8_t* l1p = l1_l + (((ls >> bshift) * kPtBuckets) << bshift) + (ls & ((1u << bshift) - 1u));
+
+    DecLane<32, 64, kPtRingSlots, kPtAhead> L;
+    // AnsCoder::seek(pos, state): the words in front of the jump point, checked against the slab / the buffer like any count
+    const WordSlice ws = active ? word_slice_n(a.offsets, a.stride_words, a.ckpt_pos[v], s, a.words_capacity) : WordSlice{0, 0u, false};
+    L.init(a.words_in + ws.off, ws.n, ring, lane);
+    L.state = active && !ws.bad ? a.ckpt_state[v] : 0;
+    L.in.prime();
+    wave_lds_fence();
+    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+
+    auto decode_one = [&]() -> int32_t {         // as in ans_decode_pt_kernel
+        const uint32_t q = lo & qmask;
+        const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
+        uint32_t r0 = l1p[q & bucket_mask];
+        const uint32_t qk = (q << 20) | 0xffffeu;
+        uint32_t e;
+        for (int guard = 0;; ++guard) {
+            const uint2* pr = reinterpret_cast<const uint2*>(rowp) + r0;
+            const uint2 x01 = pr[0], x23 = pr[1], x45 = pr[2];
+            e = x01.y <= qk ? x01.y : x01.x;
+            e = x23.x <= qk ? x23.x : e;
+            e = x23.y <= qk ? x23.y : e;
+            e = x45.x <= qk ? x45.x : e;
+            const bool more = x45.y <= qk;
+            if (!__any(more) || guard > 64) break;
+            r0 += more ? 2u : 0u;
+        }
+        const uint32_t pm1 = (e >> 8) & 0xfffu;
+        const bool run = pm1 == kPtRunMark;
+        const uint32_t d = q - (e >> 20);
+        const uint32_t p = run ? 1u : pm1 + 1u;
+        const uint32_t qc = run ? 0u : d;
+        const uint32_t idx = (e & 0xffu) + (run ? d : 0u);
+        const uint32_t s_lo = __builtin_amdgcn_alignbit(hi, lo, P), s_hi = hi >> P;
+        const uint64_t t = (uint64_t)s_lo * p + (uint64_t)qc;
+        const uint32_t t_lo = (uint32_t)t;
+        const uint32_t t_hi = __umul24(s_hi, p) + (uint32_t)(t >> 32);
+        const bool refill = t_hi == 0u && L.in.rd > 0u;
+        lo = refill ? next_word : t_lo;
+        hi = refill ? t_lo : t_hi;
+        L.in.rd -= refill ? 1u : 0u;
+        return a.min_symbol + (int32_t)idx;
+    };
+
+    int32_t* row = a.symbols_out + s * N + (size_t)chunk * K;
+    const size_t n_full = K / kTileSyms;
+    size_t t_done = 0;
+    if (P == 12 && n_full > 0 && s0 + kWave <= a.n_streams && K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0 && N < (1u << 24)) {
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words_in) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
+        if ((lds_addr(ring) & (uint32_t)(kPtRingSlots * kWave * 4 - 1)) != 0 || (lds_addr(l1_l) & (uint32_t)((kPtBuckets << bshift) - 1)) != 0) __builtin_trap();
+        if (!__any(!off_ok)) {
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            const uint32_t tr_off = (uint32_t)((lane >> 3) * kSubTileRow + 4 * (lane & 7));
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols_out + s0 * N + (size_t)chunk * K);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+            pt_decode_tiles_loop_sub(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kPtRingSlots - 1) * kWave * 4), (uint32_t)P,
+                                     a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                     lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                     lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff, plain_stores);
+            t_done = n_full * kTileSyms;
+        }
+    }
+    for (size_t t = t_done; t < K; ++t) {          // shapes the statement does not take: symbol by symbol (correct, slow)
+        const int32_t sym = decode_one();
+        if (active) row[t] = sym;
+        L.in.advance_window();
+    }
+    if (!active) return;
+    a.status[v] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+}
+
 static size_t pt_lds_bytes(const cst_model* m, bool encode) {
     return encode ? kPtRingBytes + ((size_t)8 << m->precision) + kPtTileBytes + 2 * ((size_t)m->pt_max_enc + 4)
                   : kPtRingBytes + kPtL1Bytes + kPtTileBytes + kPtDumpBytes + 4 * ((size_t)m->pt_max_dec + 4);
@@ -394,7 +612,60 @@ cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int
     a.meta = model->d_pt_meta; a.rows_enc = model->d_pt_enc; a.block_base = model->d_pt_block_base; a.recip = model->d_recip;
     a.words_out = d_words; a.stride_words = stride_words; a.n_words_out_enc = d_n_words; a.state = d_state; a.status = d_status;
     a.flags = flags;
-    return pt_launch(ans_encode_pt_kernel, a, pt_lds_bytes(model, true), hs);
+    return pt_launch(ans_encode_pt_kernel<false>, a, pt_lds_bytes(model, true), hs);
+}
+
+// ans_encode_pt + a jump point in front of every chunk of `interval` symbols (the caller checked the arguments)
+cst_status ans_encode_pt_ckpt(const cst_model* model, const int32_t* d_symbols, size_t n_streams, size_t n_per_stream, uint32_t* d_words,
+                              size_t stride_words, uint32_t* d_n_words, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
+                              int32_t* d_status, hipStream_t hs) {
+    if (model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+    PtArgs a{};
+    a.symbols_in = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
+    a.meta = model->d_pt_meta; a.rows_enc = model->d_pt_enc; a.block_base = model->d_pt_block_base; a.recip = model->d_recip;
+    a.words_out = d_words; a.stride_words = stride_words; a.n_words_out_enc = d_n_words; a.status = d_status;
+    a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.interval = interval; a.n_chunks = (n_per_stream + interval - 1) / interval;
+    return pt_launch(ans_encode_pt_kernel<true>, a, pt_lds_bytes(model, true), hs);
+}
+
+static size_t pt_sub_lds_bytes(const cst_model* m, int sub_shift) {
+    const size_t S = (size_t)((kSubWaves >> sub_shift) > 1 ? (kSubWaves >> sub_shift) : 1) * kWave;        // streams per workgroup
+    return kSubRingBytes + S * kPtBuckets + kSubWaves * kSubTileBytes + kSubDumpBytes + 4 * ((size_t)m->pt_max_dec + 4);
+}
+
+// k lanes per stream (k = n_per_stream / interval a power of two, 2 <= k <= 16), tables that fit next to eight waves' rings
+bool pt_sub_usable(const cst_model* m, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval) {
+    if (!m->pt_ok || cfg.word_bits != 32 || m->precision < 8 || m->precision > 12 || m->n_tables != n_streams) return false;
+    if (interval == 0 || n_per_stream % interval != 0) return false;
+    const size_t k = n_per_stream / interval;
+    if (k < 2 || k > 16 || (k & (k - 1)) != 0 || n_streams * k > 0x7fffffffull) return false;
+    int ks = 0;
+    while (((size_t)1 << ks) < k) ++ks;
+    return pt_sub_lds_bytes(m, ks) <= 160 * 1024;
+}
+
+cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                             size_t words_capacity, size_t interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
+                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs) {
+    PtArgs a{};
+    const size_t k = n_per_stream / interval;
+    int ks = 0;
+    while (((size_t)1 << ks) < k) ++ks;
+    a.words_capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    a.symbols_out = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
+    a.meta = model->d_pt_meta; a.rows_dec = model->d_pt_dec; a.l1 = model->d_pt_l1;
+    a.block_base = model->d_pt_block_base + (n_streams + kBlock - 1) / kBlock + 1;
+    a.words_in = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.status = d_status;
+    a.ckpt_pos = const_cast<uint32_t*>(d_ckpt_pos); a.ckpt_state = const_cast<uint64_t*>(d_ckpt_state);
+    a.interval = interval; a.n_chunks = k; a.sub_shift = ks;
+    const size_t lds = pt_sub_lds_bytes(model, ks);
+    const size_t blocks = ((((n_streams + kWave - 1) / kWave) << ks) + kSubWaves - 1) / kSubWaves;       // a wave = 64 streams x one chunk
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_pt_sub_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ans_decode_pt_sub_kernel, dim3((unsigned)blocks), dim3(kSubThreads), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,

@@ -180,6 +180,15 @@ cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uin
                          size_t n_per_stream, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags,
                          hipStream_t hs);
 
+// ... with jump points (Pos / Seek): the checkpointing encoder and the sub-lane decoder (k lanes per stream, two waves per SIMD)
+cst_status ans_encode_pt_ckpt(const cst_model* model, const int32_t* d_symbols, size_t n_streams, size_t n_per_stream, uint32_t* d_words,
+                              size_t stride_words, uint32_t* d_n_words, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
+                              int32_t* d_status, hipStream_t hs);
+bool pt_sub_usable(const cst_model* model, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval);
+cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                             size_t words_capacity, size_t interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
+                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs);
+
 // Where stream s's compressed words lie in the caller's buffer -- CHECKED.  The reference's decoder cannot read out of
 // bounds (its backend is a Vec: src/backends.rs:495-507); here the counts and offsets are caller data, so a slice
 // [off, off + n) that leaves the buffer of `capacity` words (0 = capacity unknown, the caller vouches) or, in slab form,
@@ -191,6 +200,16 @@ __device__ __forceinline__ WordSlice word_slice(const uint64_t* offsets, size_t 
     WordSlice w;
     w.off = offsets ? offsets[s] : (uint64_t)s * stride;
     w.n = n_words[s];
+    w.bad = (!offsets && stride != 0 && w.n > stride) || (capacity != 0 && (w.off > capacity || w.n > capacity - w.off));
+    if (w.bad) { w.off = 0; w.n = 0; }
+    return w;
+}
+
+// ... with the count given (a jump point: the words in front of it)
+__device__ __forceinline__ WordSlice word_slice_n(const uint64_t* offsets, size_t stride, uint32_t n, size_t s, uint64_t capacity) {
+    WordSlice w;
+    w.off = offsets ? offsets[s] : (uint64_t)s * stride;
+    w.n = n;
     w.bad = (!offsets && stride != 0 && w.n > stride) || (capacity != 0 && (w.off > capacity || w.n > capacity - w.off));
     if (w.bad) { w.off = 0; w.n = 0; }
     return w;

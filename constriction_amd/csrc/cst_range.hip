@@ -296,6 +296,80 @@ static cst_status range_decode_ws(const RangeDecodeArgs& a, cst_layout layout, h
     return range_decode_m<W, S, kDecBucket, false>(a, layout, 0, hs);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Jump points for any preset (the hand-scheduled (32,64) kernels are in cst_range_fast.hip): one lane per stream, symbols read
+// straight from HBM, RangeEncoder::pos() = (bulk.len() + num_inverted, (lower, range)) noted in front of every chunk
+// (queue.rs:182-196); and the decoder's way back to the ordinary batched decode: every (stream, chunk) pair becomes a virtual
+// stream that continues at its jump point (RangeDecoder::seek, queue.rs:911-926 = CST_FLAG_RAW_STATE with a position).
+// ------------------------------------------------------------------------------------------------------------------
+template <int W, int S>
+__global__ __launch_bounds__(kBlock) void range_encode_ckpt_generic_kernel(const RangeEncodeArgs a, const RangeCkptOut ck, cst_layout layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t stride_t = layout == CST_LAYOUT_SYMBOL_MAJOR ? a.n_streams : 1;
+    const int32_t* my = a.symbols + (active ? (layout == CST_LAYOUT_SYMBOL_MAJOR ? s : s * N) : 0);
+    RangeEncLane<W, S> L;
+    L.init(a.words + (active ? s : 0) * a.stride_words,
+           active ? (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words) : 0u, ring, lane);
+    int countdown = 4 * groups_per_point(W, P);
+    for (size_t t = 0; t < N; ++t) {
+        if (active && t % ck.interval == 0) {
+            const size_t k = s * ck.n_chunks + t / ck.interval;
+            ck.pos[k] = L.out.wr + L.inv_n; ck.lower[k] = (uint64_t)L.lower; ck.range[k] = (uint64_t)L.range;
+        }
+        const int32_t v = active ? my[t * stride_t] : a.min_symbol;
+        const EncEntry e = a.enc[enc_index(v, a.min_symbol, nsym, L.bad)];
+        L.step(e.c, e.p, P);
+        if (--countdown == 0) { countdown = 4 * groups_per_point(W, P); L.out.flush_chunks(); }
+    }
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// virtual stream v = (stream v / k, chunk v % k): where its words lie, and the decoder state RangeDecoder::seek leaves
+template <int W, int S>
+__global__ void range_ckpt_virtual_kernel(const uint32_t* __restrict__ words, const uint64_t* __restrict__ offsets, size_t stride_words,
+                                          uint64_t capacity, const uint32_t* __restrict__ n_words, const uint32_t* __restrict__ ckpt_pos,
+                                          const uint64_t* __restrict__ ckpt_lower, const uint64_t* __restrict__ ckpt_range, size_t n_streams,
+                                          size_t n_chunks, uint64_t* __restrict__ v_offsets, uint32_t* __restrict__ v_n, cst_range_state* __restrict__ v_state) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    const size_t s = v / n_chunks;
+    const WordSlice ws = word_slice(offsets, stride_words, n_words, s, capacity);
+    const uint32_t pos0 = ckpt_pos[v] < ws.n ? ckpt_pos[v] : ws.n;
+    uint64_t pt = 0;
+    uint32_t pos = pos0;
+    int num_read = 0;
+    while (pos < ws.n) {                                          // read_point, queue.rs:847-868
+        pt = ((pt << (W % 64)) | (uint64_t)words[ws.off + pos++]) & (S == 64 ? ~0ull : ((1ull << (S % 64)) - 1ull));
+        if (++num_read == S / W) break;
+    }
+    if (num_read < S / W && num_read != 0) pt = (pt << (S - num_read * W)) & (S == 64 ? ~0ull : ((1ull << (S % 64)) - 1ull));
+    cst_range_state r{};
+    r.lower = ckpt_lower[v]; r.range = ckpt_range[v]; r.point = pt; r.position = pos;
+    v_state[v] = r;
+    v_offsets[v] = offsets ? offsets[s] : (uint64_t)s * stride_words;   // (the decoder checks the slice again: a bad one stays bad)
+    v_n[v] = n_words[s];
+}
+
+// a jump point beyond its stream's words is caller data gone wrong: that chunk reports INVALID_DATA
+__global__ void range_ckpt_flag_kernel(const uint32_t* __restrict__ n_words, const uint32_t* __restrict__ ckpt_pos, size_t n_streams, size_t n_chunks,
+                                       int32_t* __restrict__ status) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    if (ckpt_pos[v] > n_words[v / n_chunks]) status[v] = CST_STREAM_INVALID_DATA;
+}
+
 } // namespace cst
 
 using namespace cst;
@@ -344,6 +418,82 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, layout, hs);
     if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
     return range_decode_ws<16, 32>(a, layout, hs);
+}
+
+cst_status cst_range_encode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
+                                       size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                       size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_lower, uint64_t* d_ckpt_range,
+                                       int32_t* d_status, void* stream) {
+    if (!model || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (layout != CST_LAYOUT_STREAM_MAJOR && layout != CST_LAYOUT_SYMBOL_MAJOR) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+    RangeEncodeArgs a{};
+    a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
+    RangeCkptOut ck{d_ckpt_pos, d_ckpt_lower, d_ckpt_range, ckpt_interval, (n_per_stream + ckpt_interval - 1) / ckpt_interval};
+    hipStream_t hs = (hipStream_t)stream;
+    if (cfg.word_bits == 32 && range_encode_ckpt_fast_usable(a, layout)) return range_encode_ckpt_fast(a, ck, hs);
+    const size_t blocks = (n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    const size_t lds = (size_t)(kBlock / kWave) * kRingWords * 4;
+    if (cfg.word_bits == 32) hipLaunchKernelGGL((range_encode_ckpt_generic_kernel<32, 64>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, ck, layout);
+    else hipLaunchKernelGGL((range_encode_ckpt_generic_kernel<16, 32>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, ck, layout);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+size_t cst_range_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval) {
+    if (ckpt_interval == 0) return 0;
+    return (sizeof(cst_range_state) + 16) * n_streams * ((n_per_stream + ckpt_interval - 1) / ckpt_interval) + 16;
+}
+
+cst_status cst_range_decode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                       size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t ckpt_interval,
+                                       const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_lower, const uint64_t* d_ckpt_range,
+                                       int32_t* d_symbols, size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status,
+                                       void* stream) {
+    if (!model || !d_n_words || !d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range || !d_scratch || !d_status || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;      // whole chunks only: rows of the virtual matrix
+    if (!config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    if (!d_symbols || !d_words) return CST_ERR_INVALID_ARGUMENT;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+    const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
+    if (n_virtual > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    RangeDecodeArgs a{};
+    a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
+    a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
+    a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status; a.words_capacity = capacity;
+    a.ckpt_pos = d_ckpt_pos; a.ckpt_lower = d_ckpt_lower; a.ckpt_range = d_ckpt_range; a.interval = ckpt_interval; a.n_chunks = n_chunks;
+    // k lanes per stream on the hand-scheduled statements, two waves per SIMD (cst_range_fast.hip)
+    if (cfg.word_bits == 32 && range_decode_sub_usable(a)) return range_decode_sub(a, hs);
+    // any other preset / alphabet: the ordinary batched decode of the virtual streams, continued at their jump points
+    cst_range_state* v_state = reinterpret_cast<cst_range_state*>(d_scratch);
+    uint64_t* v_offsets = reinterpret_cast<uint64_t*>(v_state + n_virtual);
+    uint32_t* v_n = reinterpret_cast<uint32_t*>(v_offsets + n_virtual);
+    const dim3 grid((unsigned)((n_virtual + 255) / 256));
+    if (cfg.word_bits == 32)
+        hipLaunchKernelGGL((range_ckpt_virtual_kernel<32, 64>), grid, dim3(256), 0, hs, d_words, d_offsets, stride_words, capacity, d_n_words, d_ckpt_pos,
+                           d_ckpt_lower, d_ckpt_range, n_streams, n_chunks, v_offsets, v_n, v_state);
+    else
+        hipLaunchKernelGGL((range_ckpt_virtual_kernel<16, 32>), grid, dim3(256), 0, hs, d_words, d_offsets, stride_words, capacity, d_n_words, d_ckpt_pos,
+                           d_ckpt_lower, d_ckpt_range, n_streams, n_chunks, v_offsets, v_n, v_state);
+    CST_HIP_TRY(hipGetLastError());
+    const cst_status rc = cst_range_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, v_n, d_symbols, n_virtual, ckpt_interval,
+                                                 CST_LAYOUT_STREAM_MAJOR, v_state, d_status, CST_FLAG_RAW_STATE, stream);
+    if (rc != CST_OK) return rc;
+    hipLaunchKernelGGL(range_ckpt_flag_kernel, grid, dim3(256), 0, hs, d_n_words, d_ckpt_pos, n_streams, n_chunks, d_status);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 } // extern "C"

@@ -662,4 +662,388 @@ cst_status range_encode_fast(const RangeEncodeArgs& a, cst_layout layout, hipStr
     return a.precision <= 16 ? go(range_encode_fast_kernel<1, false>) : go(range_encode_fast_kernel<2, false>);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Jump points (round 5): RangeEncoder::pos() / RangeDecoder::seek (queue.rs:172-196, 900-926; the reference's test :1333-1396).
+// The encoder notes (words emitted including held-back ones, lower, range) in front of every chunk of `interval` symbols; the
+// decoder runs every (stream, chunk) pair on its own lane -- k lanes per stream, EIGHT waves per workgroup, two per SIMD: a lone
+// wave spends a third of the range decoder's cycles waiting for its table entry and cannot issue the ~46 VALU instructions of
+// a step any faster than one per ~4.3 cycles (profiles/r04_sq_counters.md).  The words are those of the plain encoder.
+// ------------------------------------------------------------------------------------------------------------------
+template <int FLUSHES>
+__device__ __forceinline__ void range_encode_tiles_loop_ck(uint32_t& lo0, uint32_t& lo1, uint32_t& rg0, uint32_t& rg1, uint32_t& lw,
+                                                           uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax, uint32_t& slow,
+                                                           uint32_t& ck_index, const uint32_t (&tile_row_addr)[2],
+                                                           const uint32_t (&tile_tr_addr)[2], uint32_t ring_lane_addr, uint32_t cap,
+                                                           uint32_t slab_off, uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                           uint64_t symbols_base, uint32_t n_tiles, const void* ck_pos_base,
+                                                           const void* ck_lower_base, const void* ck_range_base, uint32_t ck_tiles,
+                                                           const uint32_t (&goff)[8]) {
+    if constexpr (FLUSHES == 1) {
+#include "cst_range_encode_loop_ck.inc"
+    } else {
+#include "cst_range_encode_loop_2f_ck.inc"
+    }
+}
+
+template <int FLUSHES>
+__global__ __launch_bounds__(kBlock) void range_encode_ckpt_kernel(const RangeEncodeArgs a, const RangeCkptOut ck) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * kRingWords;
+    CumProb* table = reinterpret_cast<CumProb*>(smem + kFastRingBytes);
+    int32_t* tile = reinterpret_cast<int32_t*>(smem + kFastRingBytes + table_bytes) + wave_in_block * (kWave * kTileStride);
+    if ((lds_addr(ring) & (kRingWords * 4u - 1u)) != 0) __builtin_trap();
+    for (int i = threadIdx.x; i < a.n_symbols; i += blockDim.x) table[i] = CumProb{a.enc[i].c, a.enc[i].p};
+    __syncthreads();
+
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t s0 = wave * kWave;
+    if (s0 >= a.n_streams) return;
+    const size_t s = s0 + lane;
+    const bool active = s < a.n_streams;
+    const size_t N = a.n_per_stream;
+    const int P = a.precision;
+    const uint32_t nsym = (uint32_t)a.n_symbols;
+    const size_t se = active ? s : a.n_streams - 1;          // (lanes beyond the last stream repeat it: see range_encode_fast_kernel)
+    uint32_t* slab = a.words + se * a.stride_words;
+    const uint32_t cap = (uint32_t)(a.stride_words > 0xffffffffull ? 0xffffffffull : a.stride_words);
+
+    RangeEncHeld L;
+    L.init(slab, cap, ring, lane);
+    L.owner = active;
+    bool done = false;
+    const uint64_t slab_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.out.base16) - reinterpret_cast<const unsigned char*>(a.words));
+    const bool ok = slab_off + 4ull * cap < 0x100000000ull && (reinterpret_cast<uintptr_t>(L.out.base16) & 63) == 0 &&
+                    (cap & 15u) == 0 && L.out.shift == 0;
+    if (N >= (size_t)kTileSyms && N % kTileSyms == 0 && ck.interval % kTileSyms == 0 && N < (1u << 24) && a.n_streams * ck.n_chunks < (1u << 28) &&
+        !__any(!ok)) {
+        const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+        uint32_t goff[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+        int32_t* tile_b = tile + (kBlock / kWave) * (kWave * kTileStride);
+        const uint32_t row_addr[2] = {lds_addr(tile + lane * kTileStride), lds_addr(tile_b + lane * kTileStride)};
+        const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
+        uint32_t lo0 = 0, lo1 = 0, rg0 = 0xffffffffu, rg1 = 0xffffffffu, lw = 0, wr = 0xffffffffu, flushed = 0, slow = 0;
+        uint32_t ck_index = (uint32_t)(se * ck.n_chunks);
+        int32_t smin = a.min_symbol, smax = a.min_symbol;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+        range_encode_tiles_loop_ck<FLUSHES>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, ck_index, row_addr, tr_addr, L.out.lane_addr,
+                                            cap, (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
+                                            symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms)), ck.pos, ck.lower,
+                                            ck.range, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ck.interval / kTileSyms)), goff);
+        if (__builtin_amdgcn_readfirstlane(slow) == 0) {
+            L.lower = ((uint64_t)lo1 << 32) | lo0; L.range = ((uint64_t)rg1 << 32) | rg0; L.lw = lw;
+            L.out.wr = wr; L.out.flushed = flushed;
+            L.bad = max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol);
+            done = true;
+        } else {
+            L.init(slab, cap, ring, lane);      // (rare: a carry had to travel) the wave's streams again, with the C++ step
+            L.owner = active;
+            wave_lds_fence();
+        }
+    }
+    if (!done) {
+        // any other shape: symbol by symbol (correct, slow)
+        const int32_t* row = a.symbols + se * N;
+        for (size_t t = 0; t < N; ++t) {
+            if (active && t % ck.interval == 0) {
+                const size_t k = s * ck.n_chunks + t / ck.interval;
+                ck.pos[k] = (uint32_t)((int32_t)L.out.wr + 1); ck.lower[k] = L.lower; ck.range[k] = L.range;
+            }
+            const CumProb e = table[enc_index(row[t], a.min_symbol, nsym, L.bad)];
+            L.step(e.c, e.p, P);
+            if ((t & 7) == 7) L.flush();
+        }
+    }
+    uint32_t n_words = 0;
+    const int32_t status = L.finish(nsym, n_words);
+    if (!active) return;
+    a.status[s] = status;
+    a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+bool range_encode_ckpt_fast_usable(const RangeEncodeArgs& a, cst_layout layout) {
+    return layout == CST_LAYOUT_STREAM_MAJOR && range_encode_fast_usable(a, layout);
+}
+
+cst_status range_encode_ckpt_fast(const RangeEncodeArgs& a, const RangeCkptOut& ck, hipStream_t hs) {
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    const size_t lds = kFastRingBytes + table_bytes + 2 * kFastTileBytes;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, ck);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 16 ? go(range_encode_ckpt_kernel<1>) : go(range_encode_ckpt_kernel<2>);
+}
+
+// ---- sub-lane decoder ----
+constexpr int kRsThreads = 512;
+constexpr int kRsWaves = kRsThreads / kWave;
+constexpr size_t kRsRingBytes = (size_t)kRsWaves * kRdSlots * kWave * 4;      // 64 KiB
+constexpr int kRsTileRow = 36;                                                  // bytes between the rows of a byte tile
+constexpr size_t kRsTileBytes = (size_t)kWave * kRsTileRow;                     // 2304 B per wave and buffer
+constexpr size_t kRsDumpBytes = 4 * kWave * 4;                                  // ONE landing area for unused chunk slots (never read)
+
+template <bool ENDS, bool B16>
+__device__ __forceinline__ void range_decode_tiles_loop_sub(uint32_t& x0, uint32_t& x1, uint32_t& rg0, uint32_t& rg1, uint32_t& pos,
+                                                            uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
+                                                            uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
+                                                            uint32_t lut_addr, uint32_t qmax, uint32_t P, uint32_t ring_mask,
+                                                            const void* words_base, uint32_t delta_hi, uint64_t store_base,
+                                                            uint32_t lens, uint32_t endr, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                            uint32_t words_off, [[maybe_unused]] uint32_t bucket_shift,
+                                                            [[maybe_unused]] uint32_t cdf_addr, int32_t min_symbol,
+                                                            [[maybe_unused]] uint32_t c_field_mask, [[maybe_unused]] uint32_t index_shift,
+                                                            bool plain_stores) {
+    if constexpr (B16 && ENDS) {
+        if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_b16_sub_ends.inc"
+#undef CST_STORE_MOD
+        } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16_sub_ends.inc"
+#undef CST_STORE_MOD
+        }
+    } else if constexpr (B16) {
+        if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_b16_sub.inc"
+#undef CST_STORE_MOD
+        } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_b16_sub.inc"
+#undef CST_STORE_MOD
+        }
+    } else if constexpr (ENDS) {
+        if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_sub_ends.inc"
+#undef CST_STORE_MOD
+        } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_sub_ends.inc"
+#undef CST_STORE_MOD
+        }
+    } else {
+        if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_range_decode_loop_sub.inc"
+#undef CST_STORE_MOD
+        } else {
+#define CST_STORE_MOD "nt"
+#include "cst_range_decode_loop_sub.inc"
+#undef CST_STORE_MOD
+        }
+    }
+}
+
+// LDS layout: [word rings, 8 KiB per wave][tables][byte tiles A, 2304 B per wave][byte tiles B][dump 1 KiB]
+// P <= 12: cp[q] = c | p << 16 at +0, the symbol INDEX of quantile q (int32) at +16384; B16: cdf, bucket entries, second level
+template <bool B16>
+__global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const RangeDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    const size_t n_q = (size_t)1 << P;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kRdSlots * kWave);
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem + kRsRingBytes);
+    int32_t* idxt = reinterpret_cast<int32_t*>(smem + kRsRingBytes + kTileSymOffset);
+    DecLut blut{};
+    const uint32_t* cdf = a.cdf;
+    const uint16_t* bucket = a.bucket;
+    size_t table_bytes = kTileLutBytes;
+    if constexpr (B16) {
+        table_bytes = stage_decoder_tables<kDecBucket, true, true>(smem + kRsRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+                                                             a.n_symbols, blut, cdf, bucket);
+        table_bytes = (table_bytes + 15) & ~(size_t)15;
+    } else {
+        for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {
+            lut[q] = a.dec_cp[q];
+            idxt[q] = (int32_t)a.dec_idx[q];
+        }
+    }
+    unsigned char* tile = smem + kRsRingBytes + table_bytes + (size_t)wave_in_block * kRsTileBytes;
+    unsigned char* tile_b = tile + kRsWaves * kRsTileBytes;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kRsRingBytes + table_bytes + 2 * kRsWaves * kRsTileBytes) + lane;
+    if ((lds_addr(ring) & (uint32_t)(kRdSlots * kWave * 4 - 1)) != 0) __builtin_trap();
+    __syncthreads();
+
+    // A wave decodes ONE chunk of 64 different streams (symbol rows a whole stream apart, like the plain decoder's).  The grid
+    // visits the chunks one after another -- all groups of 64 streams at chunk 0, then at chunk 1, ...: with the k chunks of a
+    // group in one workgroup instead (CST_SUB_ORDER=0) k = 4 measured 0.395 instead of 0.365 ms at P = 12, 0.472 / 0.438 at P = 24,
+    // k = 2 the same (one MI355X, 65 536 x 4096).
+    const size_t wave_global = (size_t)blockIdx.x * kRsWaves + wave_in_block;
+    const size_t n_groups = (a.n_streams + kWave - 1) / kWave;
+    const bool chunk_major = (a.flags & 0x100u) == 0;
+    const size_t chunk = chunk_major ? wave_global / n_groups : wave_global % a.n_chunks;
+    const size_t s0 = (chunk_major ? wave_global % n_groups : wave_global / a.n_chunks) * kWave;
+    if (chunk >= a.n_chunks || s0 >= a.n_streams) return;
+    const bool active = s0 + lane < a.n_streams;
+    const size_t s = active ? s0 + lane : a.n_streams - 1;        // the lanes of a partial wave beyond its last stream repeat that stream
+    const size_t ve = s * a.n_chunks + chunk;                     // (stream, chunk) in the jump table and in d_status
+    const size_t v = ve;
+    const size_t N = a.n_per_stream;
+    const size_t K = a.interval;                                  // symbols per chunk
+    const size_t n_full = K / kTileSyms;
+    const int bucket_shift = P - a.bucket_bits;
+    // the whole stream's words: a lane reads on past its chunk (the point register looks two words ahead), never past the stream
+    const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
+    const uint32_t* my_words = a.words + ws.off;
+    const uint32_t my_len = ws.n;
+    const uint32_t pos0 = a.ckpt_pos[ve];
+    const bool bad_pos = pos0 > my_len;                           // a jump point outside its stream: caller data, flagged
+    const uint64_t lower0 = a.ckpt_lower[ve], range0 = a.ckpt_range[ve];
+
+    RangeDecLane<32, 64, kRdSlots, kRdAhead> L;
+    L.init_at(my_words, my_len, pos0, lower0, range0, ring, lane);
+    L.in.prime();
+    wave_lds_fence();
+
+    auto step = [&]() -> int32_t {                                // the exact step (queue.rs:968-1033); returns the symbol
+        const uint32_t q = L.peek_quantile(P);
+        uint32_t c, p;
+        int32_t sym;
+        if constexpr (B16) {
+            uint32_t idx;
+            lookup_quantile<kDecBucket>(q, blut, cdf, bucket, bucket_shift, a.n_symbols, idx, c, p);
+            sym = a.min_symbol + (int32_t)idx;
+        } else {
+            const uint32_t cp = lut[q];
+            c = cp & 0xffffu; p = cp >> 16;
+            sym = a.min_symbol + idxt[q];
+        }
+        const uint32_t w = L.in.peek();
+        L.in.pos += L.advance(c, p, P, w, L.in.pos < L.in.len) ? 1u : 0u;
+        return sym;
+    };
+
+    bool tiles_done = false;
+    int32_t* out_row = a.symbols + s * N + chunk * K;
+    {
+        const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+        const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+        const bool off_ok = w_off + 4ull * ((uint64_t)my_len + 8) < 0x80000000ull;
+        if (n_full > 0 && K % kTileSyms == 0 && N < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && !__any(!off_ok)) {
+            const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
+            uint32_t goff[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
+            auto leave_offsets = [&](uint32_t row_cur_addr) {      // the statements read their store offsets from the lane's row
+                uint32_t* cur = reinterpret_cast<uint32_t*>((row_cur_addr == lds_addr(tile + lane * kRsTileRow) ? tile : tile_b) + lane * kRsTileRow);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cur[k] = goff[k];
+                wave_lds_fence();
+            };
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statements keep their own book from here
+            const uint32_t shift = L.in.shift;
+            const uint64_t x_in = (uint64_t)L.point - (uint64_t)L.lower;          // the statements carry x = point - lower
+            uint32_t x0 = (uint32_t)x_in, x1 = (uint32_t)(x_in >> 32), rg0 = (uint32_t)L.range, rg1 = (uint32_t)(L.range >> 32);
+            uint32_t pos = L.in.pos + shift, hi_issued = L.in.hi_issued;
+            const uint32_t lens = my_len + shift, endr = (lens + 3u) & ~3u;
+            const uint32_t tr_off = (uint32_t)((lane >> 3) * kRsTileRow + 4 * (lane & 7));
+            uint32_t row_cur = lds_addr(tile + lane * kRsTileRow), row_prev = lds_addr(tile_b + lane * kRsTileRow);
+            uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
+            uint32_t tiles = (uint32_t)n_full, ginc = 0, bad = 0, bad2 = 0;
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + chunk * K);
+            const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+            const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((((N * 4) % 128 != 0 || (sb & 127) != 0)) ? 1 : 0)) != 0;
+            const uint32_t qmax = (1u << P) - 1u, ring_mask = (uint32_t)(kRdSlots - 1) << 8;
+            const uint32_t delta_hi = P <= 16 ? 0x3e100000u : 0x3e900000u;   // 2^-30, 2^-22 (see range_decode_fast_kernel)
+            const uint32_t lut_addr = B16 ? lds_addr(blut.b16) : lds_addr(lut);
+            const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
+            const uint32_t idx_shift = B16 ? (uint32_t)blut.idx_shift : 24u, idx_mask = (1u << idx_shift) - 1u;
+            leave_offsets(row_cur);
+            range_decode_tiles_loop_sub<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
+                                                    qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, lens, endr,
+                                                    lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                                    (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), cdf_addr, a.min_symbol, idx_mask, idx_shift,
+                                                    plain_stores);
+            tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
+            if (tiles > 0) {
+                const uint32_t done = (uint32_t)n_full - tiles;
+                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
+                leave_offsets(row_cur);
+                range_decode_tiles_loop_sub<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
+                                                       lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, lens, endr,
+                                                       lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), cdf_addr, a.min_symbol, idx_mask,
+                                                       idx_shift, plain_stores);
+            }
+            if (__builtin_amdgcn_readfirstlane(bad | bad2) == 0) {
+                // the last tile is still in LDS (buffer A if it has an even index): bytes -> int32 symbols -> HBM
+                wave_lds_fence();
+                const unsigned char* last = ((n_full - 1) & 1) ? tile_b : tile;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
+                    const uint32_t pk = *reinterpret_cast<const uint32_t*>(last + ((lane >> 3) + 8 * k) * kRsTileRow + 4 * (lane & 7));
+                    v4i t;
+                    t.x = a.min_symbol + (int32_t)(pk & 0xffu); t.y = a.min_symbol + (int32_t)((pk >> 8) & 0xffu);
+                    t.z = a.min_symbol + (int32_t)((pk >> 16) & 0xffu); t.w = a.min_symbol + (int32_t)(pk >> 24);
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(a.symbols + (s0 + R) * N + chunk * K + (n_full - 1) * kTileSyms + 4 * (lane & 7)));
+                }
+                wave_lds_fence();
+                tiles_done = true;
+            } else {
+                // a quantile estimate failed its check, or the data are invalid: this wave's chunks again, exactly
+                L.init_at(my_words, my_len, pos0, lower0, range0, ring, lane);
+                L.in.prime();
+                wave_lds_fence();
+            }
+        }
+    }
+    if (!tiles_done) {
+        for (size_t t = 0; t < K; ++t) {          // shapes the statements do not take, and the exact repeat: symbol by symbol
+            const int32_t sym = step();
+            if (active) out_row[t] = sym;
+            if ((t & 3) == 3) { L.in.fill_blocking(); wave_lds_fence(); }
+        }
+    }
+    if (!active) return;
+    a.status[v] = (ws.bad || bad_pos) ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+}
+
+static size_t range_decode_sub_lds(const RangeDecodeArgs& a) {
+    const size_t tables = a.precision <= 12 ? (size_t)kTileLutBytes : ((b16_tables_bytes(a.n_symbols, a.bucket_bits) + 15) & ~(size_t)15);
+    return kRsRingBytes + tables + 2 * kRsWaves * kRsTileBytes + kRsDumpBytes;
+}
+
+// (32,64), table decoders (8 <= P <= 12) or bucket entries (P <= 24), alphabets of at most 256 symbols (the tile holds bytes)
+bool range_decode_sub_usable(const RangeDecodeArgs& a) {
+    const bool table = a.precision >= 8 && a.precision <= 12 && a.dec_cp && a.dec_idx;
+    const bool entries = a.precision > 12 && a.precision <= 24 && bucket16_usable(a.n_symbols, a.precision) && a.cdf && a.bucket;
+    if (!(table || entries) || a.n_symbols > 256 || a.n_chunks == 0 || a.n_streams > 0x7fffffffull / a.n_chunks) return false;
+    return range_decode_sub_lds(a) <= 160 * 1024;
+}
+
+cst_status range_decode_sub(const RangeDecodeArgs& a, hipStream_t hs) {
+    const size_t lds = range_decode_sub_lds(a);
+    const size_t blocks = ((a.n_streams + kWave - 1) / kWave * a.n_chunks + kRsWaves - 1) / kRsWaves;      // a wave = 64 streams x one chunk
+    RangeDecodeArgs b = a;
+    const char* order = getenv("CST_SUB_ORDER");
+    if (order && order[0] == '0') b.flags |= 0x100u;            // (A/B runs: the chunks of a group side by side)
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kRsThreads), lds, hs, b);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 12 ? go(range_decode_sub_kernel<false>) : go(range_decode_sub_kernel<true>);
+}
+
 } // namespace cst

@@ -40,6 +40,18 @@ struct RangeDecodeArgs {
     cst_range_state* rstate;
     uint32_t flags;
     uint64_t words_capacity;  // uint32 slots behind `words` (0 = unknown): see word_slice
+    // jump points (RangeEncoder::pos / RangeDecoder::seek, queue.rs:172-196, 900-926), [n_streams][n_chunks]: the sub-lane decoder
+    const uint32_t* ckpt_pos;
+    const uint64_t* ckpt_lower;
+    const uint64_t* ckpt_range;
+    size_t interval, n_chunks;
+};
+
+struct RangeCkptOut {         // what the checkpointing encoders note in front of every chunk of `interval` symbols
+    uint32_t* pos;
+    uint64_t* lower;
+    uint64_t* range;
+    size_t interval, n_chunks;
 };
 
 // cst_range_fast.hip: the hand-scheduled (32,64) kernels; `*_usable` says whether a call qualifies
@@ -47,6 +59,11 @@ bool range_encode_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
 cst_status range_encode_fast(const RangeEncodeArgs& a, cst_layout layout, hipStream_t hs);
 bool range_decode_fast_usable(const RangeDecodeArgs& a, cst_layout layout);
 cst_status range_decode_fast(const RangeDecodeArgs& a, cst_layout layout, hipStream_t hs);
+// ... with jump points: the encoder that notes them on its way, the decoder with k lanes per stream (two waves per SIMD)
+bool range_encode_ckpt_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
+cst_status range_encode_ckpt_fast(const RangeEncodeArgs& a, const RangeCkptOut& ck, hipStream_t hs);
+bool range_decode_sub_usable(const RangeDecodeArgs& a);
+cst_status range_decode_sub(const RangeDecodeArgs& a, hipStream_t hs);
 
 // Forward-reading counterpart of RingReader (queue semantics).
 template <int SLOTS = kRingSlots, int AHEAD = kAhead>
@@ -73,8 +90,8 @@ struct RingReaderFwd {
     }
 
     __device__ __forceinline__ void prime() {
-        hi_issued = shift & ~3u;
-        fill_blocking();
+        hi_issued = (pos + shift) & ~3u;      // (nothing in front of the read position is ever read: a coder that continues
+        fill_blocking();                      //  at a jump point or a raw position does not walk there from word 0)
     }
 
     // everything the window wants, now (no chunk may be pending)
@@ -223,6 +240,22 @@ struct RangeDecLane {
     __device__ __forceinline__ void init(const uint32_t* words, uint32_t len, uint32_t* wave_ring, int lane_) {
         in.init(words, len, wave_ring, lane_);
         lower = 0; range = (st_t)~(st_t)0; status = CST_STREAM_OK;
+        st_t pt = 0;
+        int num_read = 0;
+        while (in.pos < in.len) {
+            pt = (st_t)((pt << (W % S)) | (st_t)in.word_direct(in.pos++));
+            if (++num_read == S / W) break;
+        }
+        if (num_read < S / W && num_read != 0) pt = (st_t)(pt << (S - num_read * W));
+        point = pt;
+    }
+
+    // RangeDecoder::seek((pos, (lower, range))), queue.rs:911-926: continue reading at word `pos0`, read_point, take the state
+    __device__ __forceinline__ void init_at(const uint32_t* words, uint32_t len, uint32_t pos0, st_t lower0, st_t range0,
+                                            uint32_t* wave_ring, int lane_) {
+        in.init(words, len, wave_ring, lane_);
+        in.pos = pos0 < len ? pos0 : len;
+        lower = lower0; range = range0; status = CST_STREAM_OK;
         st_t pt = 0;
         int num_read = 0;
         while (in.pos < in.len) {

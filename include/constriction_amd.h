@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CST_ABI_VERSION 3
+#define CST_ABI_VERSION 4
 
 typedef enum cst_status {
     CST_OK = 0,
@@ -312,7 +312,14 @@ cst_status cst_ans_count_until_ordered(const cst_model *model, cst_coder_config 
  * `AnsCoder::seek(pos, state)` + interval decoded symbols -- so that ONE long stream (BASELINE config C1) spreads over
  * n_chunks lanes: it is the ordinary batched decode of n_streams * n_chunks virtual streams (stream-major symbols,
  * shared-table models, n_per_stream a multiple of the interval; d_status has n_streams * n_chunks entries;
- * d_scratch: cst_ckpt_scratch_bytes(...) bytes, contents irrelevant). */
+ * d_scratch: cst_ckpt_scratch_bytes(...) bytes, contents irrelevant).
+ * ABI 4: jump points as SUB-LANES of a batch.  Many streams gain from them too: a decoder of 65 536 streams runs one wave per
+ * SIMD and waits for its table lookups; with k = n_per_stream / interval jump points per stream the same words decode on k
+ * lanes per stream, two waves per SIMD.  Models with one table per stream (config C3; stream-major, the compact-row shapes of
+ * cst_model_create_gaussian_per_stream) are taken by both calls: the encoder notes the jump points at the speed of
+ * cst_ans_encode_batch when the chunks are whole 32-symbol tiles, the decoder runs k = 2, 4, 8 or 16 lanes per stream that
+ * share the stream's table in on-chip memory.  Any other k decodes the streams whole: the jump points are side information,
+ * the symbols and the per-chunk status (the stream's status, repeated) are the same. */
 cst_status cst_ans_encode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
                                      size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
                                      size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
@@ -323,6 +330,27 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cf
                                      const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_state, int32_t *d_symbols,
                                      size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
                                      void *stream);
+
+/* The same for the range coder: RangeEncoder::pos() / RangeDecoder::seek (src/stream/queue.rs:172-196, 900-926; test
+ * :1333-1396).  A jump point is (d_ckpt_pos[s][j] = words emitted so far INCLUDING held-back ones, (d_ckpt_lower[s][j],
+ * d_ckpt_range[s][j]) = RangeCoderState) in front of chunk j; seeking continues reading at word `pos`, re-reads `point` from
+ * there and takes the state.  The words are exactly those of cst_range_encode_batch.  Shared-table models, any preset and
+ * layout on the encoder side (the hand-scheduled (32,64) kernel for stream-major batches notes the jump points on its way);
+ * the decoder wants stream-major symbols and n_per_stream a multiple of the interval, takes the whole streams' counts
+ * (d_n_words: a lane reads past its chunk, never past its stream) and writes n_streams * n_chunks status entries; a jump point
+ * beyond its stream's words reports CST_STREAM_INVALID_DATA for that chunk.  d_scratch: cst_range_ckpt_scratch_bytes(...). */
+cst_status cst_range_encode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                       size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                       size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
+                                       uint32_t *d_ckpt_pos, uint64_t *d_ckpt_lower, uint64_t *d_ckpt_range,
+                                       int32_t *d_status, void *stream);
+size_t cst_range_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval);
+cst_status cst_range_decode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                       const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
+                                       const uint32_t *d_n_words, size_t ckpt_interval, const uint32_t *d_ckpt_pos,
+                                       const uint64_t *d_ckpt_lower, const uint64_t *d_ckpt_range, int32_t *d_symbols,
+                                       size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
+                                       void *stream);
 
 /* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
  * concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled

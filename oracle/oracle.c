@@ -541,6 +541,13 @@ API orc_enc_t *cst_oracle_rc_encoder_new(int W, int S) /* queue.rs:96-104: lower
 }
 API void cst_oracle_rc_encoder_free(orc_enc_t *e) { if (e) { free(e->bulk); free(e); } }
 
+/* Pos for RangeEncoder (queue.rs:182-196): bulk.pos() + num_inverted, and the coder state (lower, range) */
+API size_t cst_oracle_rc_encoder_pos(const orc_enc_t *e, uint64_t *lower, uint64_t *range)
+{
+    *lower = e->lower; *range = e->range;
+    return e->len + e->inverted_n;
+}
+
 /* encode_symbol (queue.rs:612-705).  Returns 0, or 1 if range would become zero. */
 API int cst_oracle_rc_encode_cp(orc_enc_t *e, uint32_t left, uint32_t prob, int P)
 {
@@ -864,4 +871,90 @@ API void cst_oracle_rc_decode_batch(int W, int S, int P, int32_t *decoded, size_
         }
         cst_oracle_rc_decoder_free(d);
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Jump tables: the reference's Pos / Seek for both coders.
+ *   AnsCoder::pos() = (bulk.len(), state)                      stack.rs:1130-1139;  seek: truncate the bulk to `pos`,
+ *                                                              set the state                         stack.rs:1117-1128
+ *   RangeEncoder::pos() = (bulk.len() + num_inverted, state)   queue.rs:182-196;    RangeDecoder::seek: continue reading at
+ *                                                              `pos`, read_point, set (lower, range) queue.rs:911-926
+ * These drivers note a jump point in front of every chunk of `interval` symbols (chunk j = symbols [j * interval, ...)),
+ * the way the reference's own tests build their jump tables (stack.rs:1470-1500, queue.rs:1345-1356), and decode single
+ * chunks from them.  Shared table or one table per stream, like the batched drivers above.
+ * ---------------------------------------------------------------------------------------- */
+API void cst_oracle_ans_jump_table(int W, int S, int P, const int32_t *symbols, size_t n_streams, size_t n_per_stream, int32_t lo,
+                                   int n_sym, const uint32_t *cdf, int per_stream_tables, size_t interval, uint32_t *pos,
+                                   uint64_t *state)
+{
+    const size_t n_chunks = (n_per_stream + interval - 1) / interval;
+    for (size_t s = 0; s < n_streams; s++) {
+        const uint32_t *row = per_stream_tables ? cdf + s * (size_t)(n_sym + 1) : cdf;
+        const int32_t *x = symbols + s * n_per_stream;
+        size_t len = 0;
+        uint64_t st = 0;
+        for (size_t t = n_per_stream; t-- > 0;) {           /* encode_symbol, stack.rs:1014-1048 (symbols last to first) */
+            const int64_t i = (int64_t)x[t] - lo;
+            const uint32_t c = row[i], p = row[i + 1] - c;
+            if ((st >> (S - P)) >= p) { len++; st >>= W; }
+            st = ((st / p) << P) | (c + st % p);
+            if (t % interval == 0) { pos[s * n_chunks + t / interval] = (uint32_t)len; state[s * n_chunks + t / interval] = st; }
+        }
+    }
+}
+
+/* AnsCoder::seek(pos, state) on the words of one stream, then `n` symbols (stack.rs:1117-1128, 1070-1100) */
+API void cst_oracle_ans_decode_from(int W, int S, int P, const uint32_t *words, size_t pos, uint64_t state, int32_t *decoded, size_t n,
+                                    int32_t lo, int n_sym, const uint32_t *cdf)
+{
+    size_t len = pos;
+    uint64_t st = state;
+    const uint64_t qmask = ((uint64_t)1 << P) - 1, thresh = (uint64_t)1 << (S - W);
+    for (size_t t = 0; t < n; t++) {
+        const uint32_t q = (uint32_t)(st & qmask);
+        int a = 0, b = n_sym - 1;
+        while (a < b) { const int m = a + (b - a + 1) / 2; if (cdf[m] <= q) a = m; else b = m - 1; }
+        decoded[t] = lo + a;
+        st = (st >> P) * (cdf[a + 1] - cdf[a]) + (q - cdf[a]);
+        if (st < thresh && len > 0) st = (st << W) | words[--len];
+    }
+}
+
+API void cst_oracle_rc_jump_table(int W, int S, int P, const int32_t *symbols, size_t n_streams, size_t n_per_stream, int32_t lo,
+                                  int n_sym, const uint32_t *cdf, size_t interval, uint32_t *pos, uint64_t *lower, uint64_t *range)
+{
+    const size_t n_chunks = (n_per_stream + interval - 1) / interval;
+    (void)n_sym;                                              /* (symbols are taken as valid: the callers encoded them before) */
+    for (size_t s = 0; s < n_streams; s++) {
+        orc_enc_t *e = cst_oracle_rc_encoder_new(W, S);
+        for (size_t t = 0; t < n_per_stream; t++) {
+            if (t % interval == 0) {                          /* RangeEncoder::pos() in front of the chunk, queue.rs:188-195 */
+                const size_t k = s * n_chunks + t / interval;
+                pos[k] = (uint32_t)(e->len + e->inverted_n); lower[k] = e->lower; range[k] = e->range;
+            }
+            const int64_t i = (int64_t)symbols[s * n_per_stream + t] - lo;
+            cst_oracle_rc_encode_cp(e, cdf[i], cdf[i + 1] - cdf[i], P);
+        }
+        cst_oracle_rc_encoder_free(e);
+    }
+}
+
+/* RangeDecoder::seek((pos, (lower, range))) on the words of one stream, then `n` symbols (queue.rs:911-926, 968-1033).
+ * Returns 0, or 3 on DecoderFrontendError::InvalidData. */
+API int cst_oracle_rc_decode_from(int W, int S, int P, const uint32_t *words, size_t n_words, size_t pos, uint64_t lower, uint64_t range,
+                                  int32_t *decoded, size_t n, int32_t lo, int n_sym, const uint32_t *cdf)
+{
+    orc_dec_t *d = cst_oracle_rc_decoder_new(W, S, words + (pos < n_words ? pos : n_words), pos < n_words ? n_words - pos : 0);   /* bulk.seek(pos) + read_point */
+    d->lower = lower; d->range = range;
+    int status = 0;
+    for (size_t t = 0; t < n; t++) {
+        const uint32_t q = cst_oracle_rc_peek_quantile(d, P);
+        if (q == 0xffffffffu) { status = 3; break; }
+        int a = 0, b = n_sym - 1;
+        while (a < b) { const int m = a + (b - a + 1) / 2; if (cdf[m] <= q) a = m; else b = m - 1; }
+        decoded[t] = lo + a;
+        cst_oracle_rc_decode_advance(d, cdf[a], cdf[a + 1] - cdf[a], P);
+    }
+    cst_oracle_rc_decoder_free(d);
+    return status;
 }

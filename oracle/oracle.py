@@ -20,6 +20,7 @@ _HERE = Path(__file__).resolve().parent
 _LIBS: dict = {}
 
 u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -82,6 +83,7 @@ def load(native: bool = False):
         "cst_oracle_rc_encoder_new": (vp, [i, i]),
         "cst_oracle_rc_encoder_free": (None, [vp]),
         "cst_oracle_rc_encode_cp": (i, [vp, u, u, i]),
+        "cst_oracle_rc_encoder_pos": (z, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "cst_oracle_rc_get_compressed": (z, [vp, vp]),
         "cst_oracle_rc_decoder_new": (vp, [i, i, u32p, z]),
         "cst_oracle_rc_decoder_free": (None, [vp]),
@@ -93,6 +95,10 @@ def load(native: bool = False):
         "cst_oracle_synth_symbols": (None, [u64, z, z, z, i32, i, u32p, i, i, i32p]),
         "cst_oracle_rc_encode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
         "cst_oracle_rc_decode_batch": (None, [i, i, i, i32p, z, z, i32, i, u32p, u32p, z, u32p, i32p]),
+        "cst_oracle_ans_jump_table": (None, [i, i, i, i32p, z, z, i32, i, u32p, i, z, u32p, u64p]),
+        "cst_oracle_ans_decode_from": (None, [i, i, i, u32p, z, u64, i32p, z, i32, i, u32p]),
+        "cst_oracle_rc_jump_table": (None, [i, i, i, i32p, z, z, i32, i, u32p, z, u32p, u64p, u64p]),
+        "cst_oracle_rc_decode_from": (i, [i, i, i, u32p, z, z, u64, u64, i32p, z, i32, i, u32p]),
         # oracle_families.c
         "cst_oracle_log": (d, [d]),
         "cst_oracle_log1p": (d, [d]),
@@ -381,6 +387,12 @@ class RangeEncoder:
             if lib.cst_oracle_rc_encode_cp(self._h, l, p, P):
                 raise KeyError("impossible symbol")
 
+    def pos(self):
+        """(words emitted incl. held-back ones, (lower, range)): RangeEncoder::pos, queue.rs:182-196"""
+        lo, rg = C.c_uint64(), C.c_uint64()
+        n = load().cst_oracle_rc_encoder_pos(self._h, C.byref(lo), C.byref(rg))
+        return (int(n), (int(lo.value), int(rg.value)))
+
     def get_compressed(self):
         lib = load()
         n = lib.cst_oracle_rc_get_compressed(self._h, None)
@@ -580,6 +592,51 @@ def ans_encode_batch(symbols, lo, cdf, P, W=32, S=64, stride=None, n_threads=1, 
     load(native).cst_oracle_ans_encode_batch(W, S, P, symbols.reshape(-1), n_streams, n, lo, n_sym, cdf.reshape(-1),
                                              int(per_stream), words.reshape(-1), stride, n_words, status, n_threads)
     return words, n_words, status
+
+
+def ans_jump_table(symbols, lo, cdf, P, interval, W=32, S=64):
+    """AnsCoder::pos() in front of every chunk of `interval` symbols (stack.rs:1130-1139): (pos [n_streams, n_chunks] uint32,
+    state [n_streams, n_chunks] uint64).  cdf: one table or one per stream."""
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    n_streams, n = symbols.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    n_chunks = (n + interval - 1) // interval
+    pos = np.zeros((n_streams, n_chunks), np.uint32)
+    state = np.zeros((n_streams, n_chunks), np.uint64)
+    load().cst_oracle_ans_jump_table(W, S, P, symbols.reshape(-1), n_streams, n, lo, cdf.shape[-1] - 1, cdf.reshape(-1), int(cdf.ndim == 2),
+                                     interval, pos.reshape(-1), state.reshape(-1))
+    return pos, state
+
+
+def ans_decode_from(words, pos, state, n, lo, cdf, P, W=32, S=64):
+    """AnsCoder::seek(pos, state) + n symbols on ONE stream's words (stack.rs:1117-1128)"""
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    out = np.zeros(n, np.int32)
+    load().cst_oracle_ans_decode_from(W, S, P, words, int(pos), int(state), out, n, lo, len(cdf) - 1, cdf)
+    return out
+
+
+def range_jump_table(symbols, lo, cdf, P, interval, W=32, S=64):
+    """RangeEncoder::pos() in front of every chunk (queue.rs:182-196): (pos, lower, range), each [n_streams, n_chunks]"""
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    n_streams, n = symbols.shape
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    n_chunks = (n + interval - 1) // interval
+    pos = np.zeros((n_streams, n_chunks), np.uint32)
+    lower, rng = np.zeros((n_streams, n_chunks), np.uint64), np.zeros((n_streams, n_chunks), np.uint64)
+    load().cst_oracle_rc_jump_table(W, S, P, symbols.reshape(-1), n_streams, n, lo, len(cdf) - 1, cdf, interval, pos.reshape(-1),
+                                    lower.reshape(-1), rng.reshape(-1))
+    return pos, lower, rng
+
+
+def range_decode_from(words, pos, lower, rng, n, lo, cdf, P, W=32, S=64):
+    """RangeDecoder::seek((pos, (lower, range))) + n symbols on ONE stream's words (queue.rs:911-926); returns (symbols, status)"""
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    out = np.zeros(n, np.int32)
+    st = load().cst_oracle_rc_decode_from(W, S, P, words, len(words), int(pos), int(lower), int(rng), out, n, lo, len(cdf) - 1, cdf)
+    return out, st
 
 
 def ans_decode_batch(words, n_words, n_per_stream, lo, cdf, P, W=32, S=64, lookup=None, n_threads=1, native=False, out=None):

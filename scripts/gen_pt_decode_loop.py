@@ -24,7 +24,17 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / "cst_pt_decode_loop.inc"
+# GEN_PT_SUB=1 (round 5): the loop of the SUB-LANE decoder (ans_decode_pt_sub_kernel: k jump points per stream, 512-thread
+# workgroups, two waves per SIMD).  What a second resident wave costs is LDS, so the symbol tile holds BYTES: the decoded
+# index (< 256 on this path) goes into byte `pos` of the quad's register with one SDWA add (dst_sel:BYTE_n,
+# UNUSED_PRESERVE: the same instruction count as the v_add3 of the int32 tile; the v_and that isolated the index is gone,
+# the select for runs takes its slot between the vcc write and its reader), a quad is ONE ds_write_b32, rows are 36 bytes
+# apart (2304 bytes per wave instead of 9216), and the tile leaves as int32 symbols: each 4-byte piece read back is widened
+# by four SDWA adds of min_symbol (src1_sel:BYTE_n) in front of its 16-byte store.
+SUB = bool(os.environ.get("GEN_PT_SUB"))
+SUB_ROW = 36          # bytes between the rows of the byte tile (9 dwords: the lanes' quad writes hit 64 different banks)
+OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / \
+    ("cst_pt_decode_loop_sub.inc" if SUB else "cst_pt_decode_loop.inc")
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kPtAhead - 1
@@ -45,6 +55,8 @@ X_T, X45_T = "v[116:119]", ("v[126:127]" if WINDOW == 6 else "v[172:175]")
 DM, DM2 = "v176", "v177"
 E, PM1, D, IDXA, TS, IDX = (f"v{r}" for r in range(120, 126))
 SYM = [f"v{128 + k}" for k in range(8)]
+PK = ["v128", "v129"]                     # SUB: the packed quads (even / odd quad)
+XB = [f"v{130 + k}" for k in range(4)]    # SUB: 4-byte pieces of the byte tile, read back transposed
 XO = [(f"v[{136 + 4 * k}:{139 + 4 * k}]") for k in range(4)]
 PEND = [(f"v[{152 + 4 * k}:{155 + 4 * k}]", [f"v{152 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
 LAND = [f"v{164 + k}" for k in range(K_CHUNKS)]
@@ -71,14 +83,18 @@ def tail(a, sym_reg, first=False):
     a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
     a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
     a.i(f"v_lshl_or_b32 {QK}, %[lo], 20, %[fffe]", "search key: every entry of a bin <= q compares <=")
-    if not first:
+    if not first and SUB:
+        pk, pos = sym_reg
+        a.i(f"v_add_u32_sdwa {pk}, {E}, {IDXA} dst_sel:BYTE_{pos} dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD",
+            "decoded index -> its byte of the quad")
+    elif not first:
         a.i(f"v_cndmask_b32_e64 {IDXA}, 0, {D}, {RUN}", "inside a run: index + (q - c)")
         a.i(f"v_add3_u32 {sym_reg}, {IDX}, {IDXA}, %[minsym]", "decoded symbol")
 
 
 def step(a, j):
     quad, pos = divmod(j, 4)
-    sym_reg = SYM[(quad % 2) * 4 + pos]
+    sym_reg = (PK[quad % 2], pos) if SUB else SYM[(quad % 2) * 4 + pos]
     a.wait_lds("l1", f"---- step {j}: first candidate is back")
     a.i(f"v_lshl_add_u32 {RA2}, {R0}, 3, %[rowaddr]")
     if WINDOW == 8:
@@ -86,7 +102,10 @@ def step(a, j):
         a.ds(f"ds_read2_b64 {X45_T}, {RA2} offset0:2 offset1:3", "x")
         if pos == 0 and j > 0:
             base = ((quad - 1) % 2) * 4
-            a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+            if SUB:
+                a.ds(f"ds_write_b32 %[rowcur], {PK[(quad - 1) % 2]} offset:{4 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+            else:
+                a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
         a.wait_lds("x")
         a.i(f"v_cmp_le_u32_e64 {MORE}, {X[7]}, {QK}", "eighth entry <= q: the bin lies further on")
         for i in range(7):
@@ -122,7 +141,10 @@ def step(a, j):
         a.ds(f"ds_read_b64 {X45_T}, {RA2} offset:16", "x")
         if pos == 0 and j > 0:
             base = ((quad - 1) % 2) * 4
-            a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+            if SUB:
+                a.ds(f"ds_write_b32 %[rowcur], {PK[(quad - 1) % 2]} offset:{4 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
+            else:
+                a.ds(f"ds_write_b128 %[rowcur], v[{128 + base}:{131 + base}] offset:{16 * (quad - 1)}", "tile", f"symbols {4 * quad - 4}..{4 * quad - 1}")
         a.wait_lds("x")
         a.i(f"v_cmp_le_u32 vcc, {X[1]}, {QK}")
         a.i(f"v_cmp_le_u32_e64 {M2}, {X[2]}, {QK}")
@@ -165,7 +187,10 @@ def step(a, j):
     a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
     a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
     wait_if_pending(a, "w", "candidate word is back")      # (older than the entries: normally retired with them)
-    a.i(f"v_and_b32 {IDX}, 0xff, {E}", "(one instruction between a VALU write of vcc and its VALU reader)")
+    if SUB:
+        a.i(f"v_cndmask_b32_e64 {IDXA}, 0, {D}, {RUN}", "inside a run: index + (q - c)   (one instruction between a VALU write of vcc and its VALU reader)")
+    else:
+        a.i(f"v_and_b32 {IDX}, 0xff, {E}", "(one instruction between a VALU write of vcc and its VALU reader)")
     a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
     a.i(f"v_and_or_b32 {TT}, %[lo], %[bmask], %[l1base]", "bucket of the next quantile (index interleaved by lane)")
     a.ds(f"ds_read_u8 {R0}, {TT}", "l1", "<- end of the serial chain")
@@ -204,13 +229,29 @@ def gen():
         step(a, j)
 
     # ---- end of tile: last quad -> tile row, tile -> HBM, chunks -> ring ----
-    a.ds(f"ds_write_b128 %[rowcur], v[132:135] offset:112", "tile", "symbols 28..31")
+    if SUB:
+        a.ds(f"ds_write_b32 %[rowcur], {PK[1]} offset:28", "tile", "symbols 28..31")
+    else:
+        a.ds(f"ds_write_b128 %[rowcur], v[132:135] offset:112", "tile", "symbols 28..31")
     a.wait_lds("tile")
     for half in range(2):
         for k in range(4):
-            a.ds(f"ds_read_b128 {XO[k]}, %[trcur] offset:{1152 * (4 * half + k)}", "xo", f"rows (lane>>3)+{8 * (4 * half + k)}")
-        a.wait_lds("xo")
+            if SUB:
+                a.ds(f"ds_read_b32 {XB[k]}, %[trcur] offset:{8 * SUB_ROW * (4 * half + k)}", "xo", f"rows (lane>>3)+{8 * (4 * half + k)}")
+            else:
+                a.ds(f"ds_read_b128 {XO[k]}, %[trcur] offset:{1152 * (4 * half + k)}", "xo", f"rows (lane>>3)+{8 * (4 * half + k)}")
         for k in range(4):
+            if SUB:
+                if f"xo" in a.lds:
+                    n_after = 3 - k                      # pieces requested after piece k
+                    a.events.append(("wait_lds", None, n_after))
+                    a.lds = a.lds[len(a.lds) - n_after:] if n_after else []
+                    a.i(f"s_waitcnt lgkmcnt({n_after})", f"piece {k} is back")
+                for b in range(4):
+                    a.i(f"v_add_u32_sdwa v{136 + 4 * k + b}, %[minsym], {XB[k]} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{b}",
+                        "index -> int32 symbol" if b == 0 else None)
+            elif k == 0:
+                a.wait_lds("xo")
             a.vmem(f"global_store_dwordx4 %[goff{4 * half + k}], {XO[k]}, s[80:81] \" CST_STORE_MOD \"", "store")
     a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
     for k in range(K_CHUNKS):

@@ -20,7 +20,15 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_pt_encode_loop.inc"
+import os
+
+# GEN_PT_CK=1 (round 5): the same loop with JUMP POINTS -- the reference's Pos side information (stack.rs:1107-1139): every
+# `cktiles` tiles (one chunk of the stream) the lanes note (words in the bulk, coder state) = AnsCoder::pos() in front of that
+# chunk.  A scalar countdown and a branch per tile; the three instructions of a checkpoint run k times per stream, end with
+# vmcnt(0) (they are not in the generator's book: waiting for MORE than the book knows is always safe) and cost nothing
+# measurable.  The compressed words are those of the plain loop.
+CKPT = bool(os.environ.get("GEN_PT_CK"))
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / ("cst_pt_encode_loop_ck.inc" if CKPT else "cst_pt_encode_loop.inc")
 
 
 def regs(base, n=4):
@@ -45,7 +53,8 @@ FD = [(tup(BASE + 130 + 4 * k, 2), tup(BASE + 132 + 4 * k, 2), tup(BASE + 130 + 
 NCH, LIM, FADDR, FOFF = (f"v{r}" for r in range(BASE + 146, BASE + 150))
 EW = [regs(BASE + 150 + 8 * e, 8) for e in range(2)]         # (c[t], c[t+1]) of the four symbols of two quads
 SD, SAVE = "s[84:85]", "s[86:87]"
-CLOBBERS = [f"v{r}" for r in range(BASE, BASE + 167)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(BASE, BASE + 167)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89"] + \
+    (["s90"] if CKPT else []) + ["vcc", "memory"]
 # ONE tile buffer per wave (the second one of gen_encode_loop.py costs 36 KiB of LDS the rows need): the next tile is
 # staged between the last read of the current tile (quad 0's symbols, requested in quad 3) and the first read of the
 # next one (its quad 7, requested in quad 2) -- one wave's LDS operations execute in order.
@@ -195,6 +204,23 @@ def half(a, h, g0):
             a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 4, %[flushed]")
 
 
+def checkpoint(a, label):
+    """after the last step of a tile: is this tile the first of a chunk?  then (wr, state) is that chunk's jump point"""
+    if not CKPT:
+        return
+    a.i("s_sub_u32 s90, s90, 1")
+    a.i("s_cmp_lg_u32 s90, 0")
+    a.i(f"s_cbranch_scc1 {label}f")
+    a.i(f"v_lshlrev_b32 {CK}, 2, %[ckidx]")
+    a.i(f"global_store_dword {CK}, %[wr], %[ckpos]", "pos: words in the bulk")
+    a.i(f"v_lshlrev_b32 {CK}, 3, %[ckidx]")
+    a.i(f"global_store_dwordx2 {CK}, {ST_T}, %[ckstate]", "the coder state there")
+    a.i("v_add_u32 %[ckidx], -1, %[ckidx]", "the chunk in front of this one is next")
+    a.i("s_mov_b32 s90, %[cktiles]")
+    a.i("s_waitcnt vmcnt(0)")
+    a.i(f"{label}:")
+
+
 def gen():
     a = Asm()
     a.i(f"v_mov_b32 {W1}, 0")
@@ -203,6 +229,8 @@ def gen():
     a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST full tile of stream s0")
     a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
     a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
+    if CKPT:
+        a.i("s_mov_b32 s90, %[cktiles]", "tiles until the next jump point")
     load_set(a, "A")                  # last tile
     load_set(a, "B")                  # the one before
     stage_set(a, "A", 0)
@@ -219,10 +247,12 @@ def gen():
     a.i("1:")
     first = len(a.events)
     half(a, 0, 0)
+    checkpoint(a, 5)
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_eq_u32 s82, 0")
     a.i("s_cbranch_scc1 2f")
     half(a, 1, 8)
+    checkpoint(a, 6)
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.i("s_cbranch_scc1 1b")
@@ -245,12 +275,14 @@ def main():
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_pt_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled per-stream-table ANS encoder: see pt_encode_tiles_loop in cst_ans_pt.hip."]
-    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)' +
+           (', [ckidx] "+v"(ck_index)' if CKPT else ""),
            '    : [row0] "v"(tile_row_addr), [tr0] "v"(tile_tr_addr),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [alo] "v"(sym_lo), [bhi] "v"(sym_hi), [rowb] "v"(row_addr_biased),',
            '      [recip] "s"(recip_addr), [minsym] "s"(min_symbol), [shP] "s"(32u - P), [P] "s"(P), [twoP] "s"(1u << P), [twoPv] "v"(1u << P), [c3f00] "s"(ring_mask), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),',
+           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' +
+           (' [ckpos] "s"(ck_pos_base), [ckstate] "s"(ck_state_base), [cktiles] "s"(ck_tiles),' if CKPT else ""),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
     OUT.write_text(a.render(header, ops))

@@ -25,12 +25,20 @@ and decodes what the main one left.
 
 Run:  python scripts/gen_range_decode_loop.py   (rewrites the .inc files; they are checked in)
 """
+import os
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
+# GEN_RANGE_SUB=1 (round 5): the loops of the SUB-LANE decoder (range_decode_sub_kernel: k jump points per stream, eight waves
+# per workgroup, two per SIMD).  As for the ANS sub-lane decoder (gen_pt_decode_loop.py, GEN_PT_SUB) the second wave is paid for
+# by symbol tiles of BYTES: a step leaves its symbol INDEX (< 256) with ds_write_b8 in the lane's 36-byte row; the previous
+# tile's pieces are read back four bytes at a time and widened by four SDWA adds of min_symbol in front of their 16-byte store.
+# Written to cst_range_decode_loop{,_b16}_sub{,_ends}.inc (stream-major only).
+SUB = bool(os.environ.get("GEN_RANGE_SUB"))
+SUB_ROW = 36
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
 OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
@@ -54,6 +62,7 @@ FS, FS0, FX, FX0, RC, EST, C2P32, DELTA, NE = (tup(132 + 2 * i) for i in range(9
 Q, LA, C, PR, WD, RA, CP, POS, HI = (f"v{r}" for r in range(150, 159))
 SYM = [f"v{160 + k}" for k in range(8)]                                                  # two quads
 XT = tup(172, 4)
+XB = "v171"           # SUB: four index bytes of the previous tile
 PEND = [(tup(176 + 4 * k, 4), [f"v{176 + 4 * k + j}" for j in range(4)]) for k in range(K_CHUNKS)]
 LAND = [f"v{188 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v191", "v192", "v193", "v194"
@@ -135,8 +144,12 @@ def gen(ends):
     # the eight store offsets wait in the lane's row of the CURRENT tile buffer (gen_decode_loop_b16.py: rows of any length,
     # partial waves and the symbol-major mapping are the kernel's business; it writes them in front of EACH of the two
     # statements, whose current buffer differs)
-    a.ds(f"ds_read_b128 {tup(196, 4)}, %[rowcur]", "goff")
-    a.ds(f"ds_read_b128 {tup(200, 4)}, %[rowcur] offset:16", "goff")
+    if SUB:
+        for k in range(8):
+            a.ds(f"ds_read_b32 {GOFF[k]}, %[rowcur] offset:{4 * k}", "goff")
+    else:
+        a.ds(f"ds_read_b128 {tup(196, 4)}, %[rowcur]", "goff")
+        a.ds(f"ds_read_b128 {tup(200, 4)}, %[rowcur] offset:16", "goff")
     a.wait_lds_all("the store offsets")
     a.i(f"s_mov_b64 {BAD}, 0")
     a.i("s_mov_b64 s[80:81], %[gbase]", "where the PREVIOUS tile goes (first tile of all: onto itself, rewritten one tile later)")
@@ -204,16 +217,29 @@ def gen(ends):
         if B16:
             a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-            a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
+            if SUB:
+                a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, 0, {IDX}, {V2}", "the decoded symbol's index")
+            else:
+                a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
         if pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
                 a.ds(f"ds_read_b32 v{172 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
+        elif pos == 1 and SUB:
+            a.ds(f"ds_read_b32 {XB}, %[trprev] offset:{8 * SUB_ROW * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         elif pos == 1:
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
-            # XT was read in step pos 1 and is covered by this step's lgkmcnt(0)
+            # XT / XB was read in step pos 1 and is covered by this step's lgkmcnt(0)
+            if SUB:
+                for b in range(4):
+                    a.i(f"v_add_u32_sdwa v{172 + b}, %[minsym], {XB} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{b}",
+                        "index -> int32 symbol" if b == 0 else None)
             a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
-        if pos == 3:
+        if pos == 3 and SUB:
+            base = 160 + (quad % 2) * 4
+            for b in range(4):
+                a.ds(f"ds_write_b8 %[rowcur], v{base + b} offset:{4 * quad + b}", "tile", f"symbols {4 * quad}..{4 * quad + 3}" if b == 0 else None)
+        elif pos == 3:
             base = 160 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
         if (j + 1) % 32 in halves and j != 31:
@@ -312,7 +338,7 @@ def gen(ends):
 
 def main():
     global B16, SYMBOL_MAJOR
-    for sm, b16 in ((False, False), (False, True), (True, False), (True, True)):
+    for sm, b16 in (((False, False), (False, True)) if SUB else ((False, False), (False, True), (True, False), (True, True))):
         B16, SYMBOL_MAJOR = b16, sm
         for ends in (False, True):
             a = gen(ends)
@@ -325,10 +351,13 @@ def main():
                    '    : [lut] "s"(lut_addr), [qmax] "s"(qmax), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [dhi] "s"(delta_hi),',
                    '      [gbase] "s"(store_base), [lens] "v"(lens), [endr] "v"(endr), [lanebase] "v"(ring_lane_addr),',
                    '      [dump] "v"(dump_addr), [woff] "v"(words_off)' +
-                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "v"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else '') +
+                   (', [bsh] "s"(bucket_shift), [cdf] "s"(cdf_addr), [minsym] "v"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift)' if b16 else
+                    (', [minsym] "v"(min_symbol)' if SUB else '')) +
                    (', [tilestep] "s"(tile_step_bytes)' if sm else ''),
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
             out = OUT[(b16, ends)]
+            if SUB:
+                out = out.with_name(out.name.replace("_ends.inc", "_sub_ends.inc") if ends else out.name.replace(".inc", "_sub.inc"))
             if sm:
                 out = out.with_name(out.name.replace(".inc", "_sm.inc"))
                 header[1] = header[1].replace(": see", ", symbols[t][stream]: see")

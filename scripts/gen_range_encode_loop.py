@@ -22,12 +22,18 @@ Variants: one word group (16 words) leaves per tile (P <= 16: a tile emits at mo
 
 Run:  python scripts/gen_range_encode_loop.py   (rewrites the .inc files; they are checked in)
 """
+import os
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
+# GEN_RANGE_CK=1 (round 5): the stream-major loops with JUMP POINTS -- RangeEncoder::pos() (queue.rs:182-196: words emitted
+# including held-back ones, and the coder state (lower, range)) noted in front of every chunk of `cktiles` tiles: a scalar
+# countdown and a branch at the top of every tile, four instructions + three stores k times per stream.  The held word counts:
+# pos = wr + 1 (wr is -1 until the first word exists).  Written to cst_range_encode_loop{,_2f}_ck.inc; the words are the plain loop's.
+CKPT = bool(os.environ.get("GEN_RANGE_CK"))
 CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
 OUT = {(1, False): CSRC / "cst_range_encode_loop.inc", (2, False): CSRC / "cst_range_encode_loop_2f.inc",
        (1, True): CSRC / "cst_range_encode_loop_sm.inc", (2, True): CSRC / "cst_range_encode_loop_2f_sm.inc"}
@@ -61,7 +67,7 @@ RA, EA = "v228", "v229"
 FD = [(tup(230 + 4 * k, 2), tup(232 + 4 * k, 2), tup(230 + 4 * k)) for k in range(4)]
 NCH, LIM, FADDR, FOFF = "v246", "v247", "v248", "v249"
 CARRY, SAVE, OVF, SLOW, JUNK, MASK = "s[84:85]", "s[86:87]", "s[90:91]", "s[92:93]", "s[94:95]", "s[96:97]"
-CLOBBERS = [f"v{r}" for r in range(100, 250)] + [f"s{r}" for r in range(80, 98)] + ["vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 250)] + [f"s{r}" for r in range(80, 98)] + (["s78"] if CKPT else []) + ["vcc", "memory"]
 ROW = ["%[row0]", "%[row1]"]          # the lane's own row in tile buffer 0 / 1
 TR = ["%[tr0]", "%[tr1]"]             # transposed write address in tile buffer 0 / 1
 
@@ -169,10 +175,30 @@ def store_one(a, k):
         a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 4, %[flushed]")
 
 
+def jump_point(a, label):
+    """top of a tile, before its first step: does a chunk start here?  then note RangeEncoder::pos() (the stores are not in
+    the generator's book: they end with vmcnt(0), and waiting for more than the book knows is always safe)"""
+    a.i("s_sub_u32 s78, s78, 1")
+    a.i("s_cmp_lg_u32 s78, 0")
+    a.i(f"s_cbranch_scc1 {label}f")
+    a.i(f"v_add_u32 {RA}, 1, %[wr]", "pos = words so far, the held one included")
+    a.i(f"v_lshlrev_b32 {EA}, 2, %[ckidx]")
+    a.i(f"global_store_dword {EA}, {RA}, %[ckpos]")
+    a.i(f"v_lshlrev_b32 {EA}, 3, %[ckidx]")
+    a.i(f"global_store_dwordx2 {EA}, {LO_T}, %[cklower]")
+    a.i(f"global_store_dwordx2 {EA}, {tup(214, 2)}, %[ckrange]")
+    a.i("v_add_u32 %[ckidx], 1, %[ckidx]")
+    a.i("s_mov_b32 s78, %[cktiles]")
+    a.i("s_waitcnt vmcnt(0)")
+    a.i(f"{label}:")
+
+
 def half(a, h, g0):
     """one tile: register set / tile buffer h (0 = A), global quad indices g0 .. g0+7 are its quads 0 .. 7"""
     own, other = "AB"[h], "AB"[1 - h]
     a.i(f"; ---- tile in buffer {h} (symbols came from set {own})")
+    if CKPT:
+        jump_point(a, 7 + h)
     # what follows step s of the tile (s = 0 .. 31)
     after = {}
     for k in range(4):
@@ -224,6 +250,8 @@ def gen():
     a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the FIRST tile of stream s0")
     a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
     a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
+    if CKPT:
+        a.i("s_mov_b32 s78, 1", "the first tile starts chunk 0")
     load_set(a, "A")                  # first tile
     load_set(a, "B")                  # the one after
     stage_set(a, "A", 0)
@@ -264,23 +292,27 @@ def emit(flushes, symbol_major=False):
     header = ["// GENERATED by scripts/gen_range_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
               f"// Main loop of the hand-scheduled (32,64) range encoder, {flushes} word group(s) per tile: see cst_range_fast.hip."]
     ops = ['    : [lo0] "+v"(lo0), [lo1] "+v"(lo1), [rg0] "+v"(rg0), [rg1] "+v"(rg1), [lw] "+v"(lw), [wr] "+v"(wr), [flushed] "+v"(flushed),',
-           '      [smin] "+v"(smin), [smax] "+v"(smax), [slow] "=v"(slow)',
+           '      [smin] "+v"(smin), [smax] "+v"(smax), [slow] "=v"(slow)' + (', [ckidx] "+v"(ck_index)' if CKPT else ''),
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [tbl] "s"(table_addr_biased), [P] "s"(P), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
+           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else '') +
+           (' [ckpos] "s"(ck_pos_base), [cklower] "s"(ck_lower_base), [ckrange] "s"(ck_range_base), [cktiles] "s"(ck_tiles),' if CKPT else ''),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
     if symbol_major:
         header[1] = header[1].replace(": see", ", symbols[t][stream]: see")
-    OUT[(flushes, symbol_major)].write_text(a.render(header, ops))
-    print(f"wrote {OUT[(flushes, symbol_major)]} ({a.n_instr()} instructions incl. prologue)")
+    out = OUT[(flushes, symbol_major)]
+    if CKPT:
+        out = out.with_name(out.name.replace(".inc", "_ck.inc"))
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
 
 
 def main():
-    for sm in (False, True):
+    for sm in ((False,) if CKPT else (False, True)):
         emit(1, sm)
         emit(2, sm)
 

@@ -78,3 +78,76 @@ def test_config_c1_one_stream_of_a_million_symbols(B, O):
     assert int(st1[0]) == 0 and np.array_equal(dec1.cpu().numpy(), sym)
     print(f"C1 decode: {e0.elapsed_time(e1):.2f} ms on 1000 lanes (checkpoints), {e1.elapsed_time(e2):.2f} ms on one lane")
     assert e0.elapsed_time(e1) * 20 < e1.elapsed_time(e2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: jump points for ONE TABLE PER STREAM (config C3) -- the compact-row encoder notes them on its way, the sub-lane
+# decoder runs k lanes per stream that share the stream's table in LDS (cst_ans_pt.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _c3_model(B, O, n_streams, lo, hi, P, seed):
+    rng = np.random.default_rng(seed)
+    mu = -10 + 20 * rng.random(n_streams)
+    sigma = np.exp(np.log(0.5) + rng.random(n_streams) * np.log(32))
+    model = B.Model.quantized_gaussian_per_stream(lo, hi, dev(mu), dev(sigma), P)
+    cdfs = np.stack([O.GaussianModel(lo, hi, m, s, P, 32).cdf_table() for m, s in zip(mu, sigma)])
+    return model, cdfs
+
+
+@pytest.mark.parametrize("n_streams,n_per,interval", [
+    (256, 256, 64),      # k = 4: one full workgroup of the sub-lane decoder, chunks of whole tiles
+    (128, 512, 256),     # k = 2
+    (1024, 1024, 128),   # k = 8, several workgroups
+    (300, 256, 64),      # partial last wave of streams (and of virtual streams)
+    (70, 128, 32),       # k = 4, one-tile chunks, fewer streams than a workgroup holds
+    (64, 1024, 64),      # k = 16
+    (130, 96, 24),       # k = 4, chunks that are NOT whole tiles: per-symbol paths on both sides
+    (5, 96, 32),         # k = 3: not a power of two -> decoded whole (the jump points are side information)
+    (3, 96, 96),         # k = 1
+    (67, 200, 64),       # interval does not divide n: encode only
+], ids=lambda v: str(v))
+def test_per_stream_jump_points(B, O, n_streams, n_per, interval):
+    lo, hi, P = -127, 127, 12
+    cfg = (32, 64, P)
+    model, cdfs = _c3_model(B, O, n_streams, lo, hi, P, seed=n_streams * 7 + n_per + interval)
+    sym = O.synth_symbols(0xC0FFEE, 0, n_streams, n_per, lo, cdfs, P, per_stream_tables=True)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdfs, P)
+    want_pos, want_state = O.ans_jump_table(sym, lo, cdfs, P, interval)
+    enc, ck = B.ans_encode_checkpointed(dev(sym), model, interval, cfg)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+    assert np.array_equal(ck.pos.cpu().numpy().view(np.uint32), want_pos)
+    assert np.array_equal(ck.state.cpu().numpy().view(np.uint64), want_state)
+    if n_per % interval:
+        return
+    dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per)
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all()
+    assert np.array_equal(dec.cpu().numpy(), sym)
+    # ... and the words decode the same without the jump points
+    plain, pstatus = B.ans_decode(enc, model, n_per)
+    assert (pstatus.cpu().numpy() == 0).all() and torch.equal(plain, dec)
+
+
+def test_per_stream_jump_points_corrupt_positions(B, O):
+    """positions are caller data: one that leaves its slab flags THAT chunk and reads nothing (as every count does)"""
+    lo, hi, P, n_streams, n_per, interval = -127, 127, 12, 256, 256, 64
+    model, cdfs = _c3_model(B, O, n_streams, lo, hi, P, seed=99)
+    sym = O.synth_symbols(1, 0, n_streams, n_per, lo, cdfs, P, per_stream_tables=True)
+    enc, ck = B.ans_encode_checkpointed(dev(sym), model, interval, (32, 64, P))
+    bad = [(0, 1), (17, 3), (255, 0)]
+    for s, j in bad:
+        ck.pos[s, j] = 0x7fffffff
+    dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per)
+    torch.cuda.synchronize()
+    st = dstatus.cpu().numpy()
+    got = dec.cpu().numpy()
+    for s in range(n_streams):
+        for j in range(n_per // interval):
+            if (s, j) in bad:
+                assert st[s, j] == 3
+            else:
+                assert st[s, j] == 0 and np.array_equal(got[s, j * interval:(j + 1) * interval], sym[s, j * interval:(j + 1) * interval])
