@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code, clippy::too_many_arguments)]
 use core::ffi::{c_char, c_void};
 
-pub const CST_ABI_VERSION: i32 = 3;
+pub const CST_ABI_VERSION: i32 = 4;
 
 /// `cst_status`
 pub type CstStatus = i32;
@@ -273,8 +273,11 @@ extern "C" {
     /// leaves the buffer -- or, in slab form, whose d_n_words[s] exceeds stride_words (checked always) -- is decoded as an
     /// EMPTY stream and reports CST_STREAM_INVALID_DATA; nothing outside the buffer is read.  words_capacity = 0 means
     /// "unknown": the caller vouches for the packed offsets as in ABI 2.  (The kernels read whole aligned 16-byte chunks:
-    /// up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; a capacity that is
-    /// the true size of a hipMalloc'ed buffer satisfies this.)  Every decode entry point below takes the same argument.
+    /// up to 12 bytes before the first and after the last word of a stream are touched, never interpreted; with
+    /// CST_FLAG_COLD_WORDS whole aligned 64-byte groups: up to 60 bytes either side, inside the allocation that holds d_words
+    /// -- hipMalloc aligns and pads allocations to 256 bytes -- and that decoder is only taken when the span of the words is known,
+    /// i.e. never for packed offsets with words_capacity = 0.  A capacity that is the true size of a hipMalloc'ed buffer
+    /// satisfies both.)  Every decode entry point below takes the same argument.
     /// The model must have been created on the current device (CST_ERR_INVALID_ARGUMENT otherwise).
     /// With CST_FLAG_RAW_STATE the initial state comes from d_state and the remaining state and word
     /// count are written back to d_state / d_n_words_out (d_n_words_out may alias nothing; NULL = discard).
@@ -424,6 +427,13 @@ extern "C" {
     /// n_chunks lanes: it is the ordinary batched decode of n_streams * n_chunks virtual streams (stream-major symbols,
     /// shared-table models, n_per_stream a multiple of the interval; d_status has n_streams * n_chunks entries;
     /// d_scratch: cst_ckpt_scratch_bytes(...) bytes, contents irrelevant).
+    /// ABI 4: jump points as SUB-LANES of a batch.  Many streams gain from them too: a decoder of 65 536 streams runs one wave per
+    /// SIMD and waits for its table lookups; with k = n_per_stream / interval jump points per stream the same words decode on k
+    /// lanes per stream, two waves per SIMD.  Models with one table per stream (config C3; stream-major, the compact-row shapes of
+    /// cst_model_create_gaussian_per_stream) are taken by both calls: the encoder notes the jump points at the speed of
+    /// cst_ans_encode_batch when the chunks are whole 32-symbol tiles, the decoder runs k = 2, 4, 8 or 16 lanes per stream that
+    /// share the stream's table in on-chip memory.  Any other k decodes the streams whole: the jump points are side information,
+    /// the symbols and the per-chunk status (the stream's status, repeated) are the same.
     pub fn cst_ans_encode_batch_ckpt(
         model: *const CstModel,
         cfg: CstCoderConfig,
@@ -453,6 +463,54 @@ extern "C" {
         ckpt_interval: usize,
         d_ckpt_pos: *const u32,
         d_ckpt_state: *const u64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The same for the range coder: RangeEncoder::pos() / RangeDecoder::seek (src/stream/queue.rs:172-196, 900-926; test
+    /// :1333-1396).  A jump point is (d_ckpt_pos[s][j] = words emitted so far INCLUDING held-back ones, (d_ckpt_lower[s][j],
+    /// d_ckpt_range[s][j]) = RangeCoderState) in front of chunk j; seeking continues reading at word `pos`, re-reads `point` from
+    /// there and takes the state.  The words are exactly those of cst_range_encode_batch.  Shared-table models, any preset and
+    /// layout on the encoder side (the hand-scheduled (32,64) kernel for stream-major batches notes the jump points on its way);
+    /// the decoder wants stream-major symbols and n_per_stream a multiple of the interval, takes the whole streams' counts
+    /// (d_n_words: a lane reads past its chunk, never past its stream) and writes n_streams * n_chunks status entries; a jump point
+    /// beyond its stream's words reports CST_STREAM_INVALID_DATA for that chunk.  d_scratch: cst_range_ckpt_scratch_bytes(...).
+    pub fn cst_range_encode_batch_ckpt(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_lower: *mut u64,
+        d_ckpt_range: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_ckpt_scratch_bytes(n_streams: usize, n_per_stream: usize, ckpt_interval: usize) -> usize;
+
+    pub fn cst_range_decode_batch_ckpt(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *const u32,
+        d_ckpt_lower: *const u64,
+        d_ckpt_range: *const u64,
         d_symbols: *mut i32,
         n_streams: usize,
         n_per_stream: usize,

@@ -277,7 +277,7 @@ pub struct EncodedBatch {
 impl EncodedBatch {
     fn allocate(n_streams: usize, stride_words: usize, config: CoderConfig) -> Result<Self> {
         Ok(EncodedBatch {
-            words: DeviceBuffer::new(n_streams * stride_words)?,
+            words: DeviceBuffer::new(n_streams.checked_mul(stride_words).ok_or(Error::InvalidArgument)?)?,
             n_words: DeviceBuffer::new(n_streams)?,
             status: DeviceBuffer::new(n_streams)?,
             stride_words,
@@ -420,7 +420,7 @@ impl BatchedAnsCoder {
         model: &DeviceModel,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        if symbols.len() < n_streams * n_per_stream {
+        if symbols.len() < n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)? {
             return Err(Error::InvalidArgument);
         }
         let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
@@ -457,7 +457,7 @@ impl BatchedAnsCoder {
         n_per_stream: usize,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if symbols.len() < count || means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -494,7 +494,7 @@ impl BatchedAnsCoder {
         n_per_stream: usize,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if left.len() < count || prob.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -521,7 +521,7 @@ impl BatchedAnsCoder {
 
     fn decode_iid(&self, src: WordSource, n_per_stream: usize, model: &DeviceModel, flags: u32, stream: &Stream) -> Result<DecodedBatch> {
         let n_streams = src.n_streams();
-        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams * n_per_stream)?, status: DeviceBuffer::new(n_streams)? };
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?, status: DeviceBuffer::new(n_streams)? };
         check(unsafe {
             ffi::cst_ans_decode_batch(
                 model.as_raw(),
@@ -569,7 +569,7 @@ impl BatchedAnsCoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -611,7 +611,7 @@ impl BatchedAnsCoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if cdf_rows.len() < count * (n_symbols + 1) {
             return Err(Error::InvalidArgument);
         }
@@ -644,7 +644,11 @@ impl BatchedAnsCoder {
     /// Streams of different lengths in one launch -- one `DefaultAnsCoder` per document with a shared model, the
     /// reference's tests/issue52.rs:27-60.  `sym_offsets[n_streams + 1]` delimits the symbols of every stream;
     /// `word_offsets[n_streams + 1]` its slab (`max_words(length)` words always suffice).
-    pub fn encode_ragged(
+    ///
+    /// # Safety
+    /// The offsets are DEVICE memory: this wrapper cannot check them.  Every `sym_offsets` pair must lie inside `symbols`, every
+    /// slab `[word_offsets[s], word_offsets[s + 1])` inside `words`, in ascending order.
+    pub unsafe fn encode_ragged(
         &self,
         symbols: &DeviceBuffer<i32>,
         sym_offsets: &DeviceBuffer<u64>,
@@ -678,7 +682,11 @@ impl BatchedAnsCoder {
     }
 
     /// The decoder of [`BatchedAnsCoder::encode_ragged`] (tests/issue52.rs:63-80 with known lengths).
-    pub fn decode_ragged(
+    ///
+    /// # Safety
+    /// As for `encode_ragged`: `sym_offsets` (device memory) must delimit ranges inside `symbols`.  The word slices ARE checked
+    /// on the device against `words.len()` (`words_capacity` of the C ABI).
+    pub unsafe fn decode_ragged(
         &self,
         words: &DeviceBuffer<u32>,
         word_offsets: &DeviceBuffer<u64>,
@@ -723,12 +731,12 @@ impl BatchedAnsCoder {
         model: &DeviceModel,
         stream: &Stream,
     ) -> Result<(EncodedBatch, Checkpoints)> {
-        if interval == 0 || symbols.len() < n_streams * n_per_stream {
+        if interval == 0 || symbols.len() < n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)? {
             return Err(Error::InvalidArgument);
         }
         let n_chunks = (n_per_stream + interval - 1) / interval;
         let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
-        let mut ckpt = Checkpoints { pos: DeviceBuffer::new(n_streams * n_chunks)?, state: DeviceBuffer::new(n_streams * n_chunks)?, interval };
+        let mut ckpt = Checkpoints { pos: DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)?, state: DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)?, interval };
         check(unsafe {
             ffi::cst_ans_encode_batch_ckpt(
                 model.as_raw(),
@@ -762,7 +770,7 @@ impl BatchedAnsCoder {
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
         let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
-        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams * n_per_stream)?, status: DeviceBuffer::new(n_streams * n_chunks)? };
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?, status: DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)? };
         let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
         check(unsafe {
             ffi::cst_ans_decode_batch_ckpt(
@@ -792,6 +800,14 @@ impl BatchedAnsCoder {
 pub struct Checkpoints {
     pub pos: DeviceBuffer<u32>,
     pub state: DeviceBuffer<u64>,
+    pub interval: usize,
+}
+
+/// `RangeEncoder::pos()` of every stream in front of every chunk (src/stream/queue.rs:172-196).
+pub struct RangeCheckpoints {
+    pub pos: DeviceBuffer<u32>,
+    pub lower: DeviceBuffer<u64>,
+    pub range: DeviceBuffer<u64>,
     pub interval: usize,
 }
 
@@ -825,7 +841,7 @@ impl BatchedRangeEncoder {
         model: &DeviceModel,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        if symbols.len() < n_streams * n_per_stream {
+        if symbols.len() < n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)? {
             return Err(Error::InvalidArgument);
         }
         let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
@@ -849,6 +865,53 @@ impl BatchedRangeEncoder {
         Ok(out)
     }
 
+    /// Encoding with jump tables: what `RangeEncoder::pos()` returns in front of every chunk of `interval` symbols
+    /// (`Pos`, src/stream/queue.rs:172-196: words emitted so far including held-back ones, and `RangeCoderState`); the words are
+    /// those of `encode_iid_symbols`.
+    pub fn encode_iid_symbols_with_checkpoints(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch, RangeCheckpoints)> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if interval == 0 || symbols.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = (n_per_stream + interval - 1) / interval;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut ckpt = RangeCheckpoints {
+            pos: DeviceBuffer::new(n_points)?,
+            lower: DeviceBuffer::new(n_points)?,
+            range: DeviceBuffer::new(n_points)?,
+            interval,
+        };
+        check(unsafe {
+            ffi::cst_range_encode_batch_ckpt(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.lower.as_mut_ptr(),
+                ckpt.range.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        Ok((out, ckpt))
+    }
+
     /// Per stream: `encode_symbols(symbols[s].zip(models))` with one quantized Gaussian per symbol (Python
     /// `RangeEncoder.encode(symbols, QuantizedGaussian(lo, hi), means, stds)`, src/pybindings/stream/queue.rs:343-410).
     pub fn encode_symbols(
@@ -861,7 +924,7 @@ impl BatchedRangeEncoder {
         n_per_stream: usize,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if symbols.len() < count || means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -898,7 +961,7 @@ impl BatchedRangeEncoder {
         n_per_stream: usize,
         stream: &Stream,
     ) -> Result<EncodedBatch> {
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if left.len() < count || prob.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -940,7 +1003,7 @@ impl BatchedRangeDecoder {
     /// (src/stream/queue.rs:847-868, 968-1033); `InvalidData` is reported per stream.
     pub fn decode_iid_symbols(&self, encoded: &EncodedBatch, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams * n_per_stream)?, status: DeviceBuffer::new(n_streams)? };
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?, status: DeviceBuffer::new(n_streams)? };
         check(unsafe {
             ffi::cst_range_decode_batch(
                 model.as_raw(),
@@ -963,6 +1026,53 @@ impl BatchedRangeDecoder {
         Ok(out)
     }
 
+    /// `RangeDecoder::seek((pos, state))` + `interval` decoded symbols for EVERY chunk at once (`Seek`, src/stream/queue.rs:900-926):
+    /// k lanes per stream -- two resident waves per SIMD where the plain decoder has one.
+    pub fn decode_iid_symbols_from_checkpoints(
+        &self,
+        encoded: &EncodedBatch,
+        checkpoints: &RangeCheckpoints,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<DecodedBatch> {
+        let n_streams = encoded.n_streams;
+        if checkpoints.interval == 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        if checkpoints.pos.len() < n_points || checkpoints.lower.len() < n_points || checkpoints.range.len() < n_points {
+            return Err(Error::InvalidArgument);
+        }
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_points)? };
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
+        check(unsafe {
+            ffi::cst_range_decode_batch_ckpt(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                checkpoints.interval,
+                checkpoints.pos.as_ptr(),
+                checkpoints.lower.as_ptr(),
+                checkpoints.range.as_ptr(),
+                out.symbols.as_mut_ptr(),
+                n_streams,
+                n_per_stream,
+                scratch.as_mut_ptr() as *mut c_void,
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(out)
+    }
+
     /// Per stream: `decode_symbols(models)` with one quantized Gaussian per symbol
     /// (src/pybindings/stream/queue.rs:598-661).
     pub fn decode_symbols(
@@ -975,7 +1085,7 @@ impl BatchedRangeDecoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -1016,7 +1126,7 @@ impl BatchedRangeDecoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if cdf_rows.len() < count * (n_symbols + 1) {
             return Err(Error::InvalidArgument);
         }
@@ -1086,7 +1196,7 @@ impl BatchedChainCoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = chains.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -1129,7 +1239,7 @@ impl BatchedChainCoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = chains.n_streams;
-        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams * n_per_stream)?, status: DeviceBuffer::new(n_streams)? };
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?, status: DeviceBuffer::new(n_streams)? };
         check(unsafe {
             ffi::cst_chain_decode_rows_batch(
                 self.config,
@@ -1168,7 +1278,7 @@ impl BatchedChainCoder {
         stream: &Stream,
     ) -> Result<DeviceBuffer<i32>> {
         let n_streams = chains.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if symbols.len() < count || means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
@@ -1209,7 +1319,7 @@ impl BatchedChainCoder {
         stream: &Stream,
     ) -> Result<DeviceBuffer<i32>> {
         let n_streams = chains.n_streams;
-        let count = n_streams * n_per_stream;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         if left.len() < count || prob.len() < count {
             return Err(Error::InvalidArgument);
         }
