@@ -272,6 +272,65 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     return entry, enc
 
 
+def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, ks=(2, 4)):
+    """Decode with k JUMP POINTS per stream (the reference's Pos / Seek side information, stack.rs:1107-1139, queue.rs:172-196,
+    900-926): the encoder notes them on its way, the decoder runs k lanes per stream -- two resident waves per SIMD where the
+    plain decoder of a 65 536-stream batch has one.  The words are the plain encoder's (compared), the jump tables of sampled
+    streams are compared with the CPU oracle's, every chunk's symbols with the input.  Algorithmic bytes as for the plain entry
+    (the jump table adds 12 k or 20 k bytes to a stream's 16 KiB of symbols)."""
+    from oracle import oracle as O
+    n_streams, n_per = symbols.shape
+    ans = coder == "ans"
+    enc_ck = B.ans_encode_checkpointed if ans else B.range_encode_checkpointed
+    dec_ck = B.ans_decode_checkpointed if ans else B.range_decode_checkpointed
+    plain = (B.ans_encode if ans else B.range_encode)(symbols, model, cfg)
+    decoded = torch.empty_like(symbols)
+    plain_dec_ms = event_ms(lambda: (B.ans_decode if ans else B.range_decode)(plain, model, n_per, out=decoded), reps)
+    total_words = plain.total_words()
+    byts = 4 * n_streams * n_per + (cfg[0] // 8) * total_words
+    entry = {"workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
+             "plain_decode_ms": round(plain_dec_ms, 4), "by_k": {}}
+    ok = True
+    for k in ks:
+        interval = n_per // k
+        pair = enc_ck(symbols, model, interval, cfg)
+        enc, ck = pair
+        status = torch.empty((n_streams, k), dtype=torch.int32, device=symbols.device)
+        decoded.zero_()
+        e_ms = event_ms(lambda: enc_ck(symbols, model, interval, cfg, out=pair), reps)
+        d_ms = event_ms(lambda: dec_ck(enc, ck, model, n_per, out=decoded, status=status), reps)
+        entry["by_k"][str(k)] = {"encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4),
+                                 "decode_frac": round(byts / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                 "decode_speedup": round(plain_dec_ms / d_ms, 3)}
+        if check:
+            good = bool(torch.equal(decoded, symbols)) and int(status.abs().sum().item()) == 0 and int(enc.status.abs().sum().item()) == 0
+            good = good and bool(torch.equal(enc.n_words, plain.n_words))
+            w = min(int(plain.words.shape[1]), int(enc.words.shape[1]), 512)
+            used = torch.arange(w, device=symbols.device)[None, :] < plain.n_words[:, None]  # (the first 512 words of every stream)
+            good = good and bool(((enc.words[:, :w] == plain.words[:, :w]) | ~used).all())
+            if good and cdf_host is not None:
+                rows = sorted({0, 1, 63, 64, n_streams // 2, n_streams - 1})
+                host = symbols[rows].cpu().numpy()
+                tabs = np.asarray(cdf_host)
+                tab = tabs[rows] if tabs.ndim == 2 else tabs
+                if ans:
+                    pos, state = O.ans_jump_table(host, lo, tab, cfg[2], interval)
+                    good = np.array_equal(ck.pos[rows].cpu().numpy().view(np.uint32), pos) and \
+                        np.array_equal(ck.state[rows].cpu().numpy().view(np.uint64), state)
+                else:
+                    pos, lower, rng = O.range_jump_table(host, lo, tab, cfg[2], interval)
+                    good = np.array_equal(ck.pos[rows].cpu().numpy().view(np.uint32), pos) and \
+                        np.array_equal(ck.lower[rows].cpu().numpy().view(np.uint64), lower) and \
+                        np.array_equal(ck.range[rows].cpu().numpy().view(np.uint64), rng)
+            ok = ok and bool(good)
+        del pair, enc, ck
+    if check:
+        entry["bit_exact"] = ok
+        entry["bit_exact_scope"] = ("every chunk's symbols vs input, counts and the first 512 words of every stream vs the plain encoder's (themselves "
+                                    "compared with the CPU oracle in the plain entry), jump tables of six streams vs the CPU oracle")
+    return entry
+
+
 def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100, hi=100):
     """f1: every symbol its own f64 (mean, std) -- coder.encode_reverse(symbols, QuantizedGaussian(lo, hi),
     means, stds) / coder.decode(family, means, stds), src/pybindings/stream/stack.rs:567-588, 733-751 -- for all streams at
@@ -516,6 +575,13 @@ def other_configs(B, rank, world, dist, args, reps=5):
             entry = {"workload": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
         out.append(entry)
 
+    def jump(name, *a, **k):
+        try:
+            entry = jump_config(B, name, *a, **k)
+        except Exception as exc:      # noqa: BLE001
+            entry = {"workload": name, "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False}
+        out.append(entry)
+
     m12, cdf12 = gaussian(12)
     cdf12_dev = torch.from_numpy(cdf12.astype(np.int64)).cuda()
     sym12 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, cdf12_dev, 12)
@@ -534,6 +600,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
         add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
         add("C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         add("C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        jump("C2 decode with k jump points per stream (small-footprint decoder on 65 536 k virtual streams; the jump points come from the "
+             "one-lane-per-stream checkpointing encoder)", "ans", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        jump("C4 range coder, P = 12: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        jump("C4 range coder, P = 24: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         del sym24, m24
         symT = sym12.t().contiguous()
         add("C4 range coder, P = 12, symbols[t][stream] (symbol-major layout)", "range", (32, 64, 12), m12, symT, reps, check, cdf12,
@@ -555,6 +625,8 @@ def other_configs(B, rank, world, dist, args, reps=5):
         sym3 = synth_symbols_per_stream(SEED, rank * N_STREAMS, N_PER, -127, m3.cdfs_device(), 12)
         cdfs = cpu_tables(-127, 127, mu, sigma, 12) if check else None
         add("C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
+        jump("C3: decode with k jump points per stream (sub-lane decoder: the lanes of a stream share its table in LDS)", "ans", (32, 64, 12),
+             m3, sym3, reps, check, cdfs, lo=-127, ks=(2, 4, 8))
         del sym3, m3, cdfs
         out.append(per_symbol_config(B, reps, check))
         try:

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
     if (getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs)
     if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
-    if (a.n_streams == 0 || a.n_streams % kBlock != 0 || a.n_streams > (size_t)device_cus * kBlock) return false;
+    (void)device_cus;     // (more than one workgroup per CU: they run one after another, cst_api.hip asks the small-footprint kernels first)
+    if (a.n_streams == 0 || a.n_streams % kBlock != 0) return false;
     if (a.n_per_stream % kTileSyms != 0 || a.n_per_stream < 2 * kTileSyms || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;

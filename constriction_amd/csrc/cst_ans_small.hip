@@ -251,7 +251,18 @@ static size_t small_encode_lds(const AnsEncodeArgs& a) {
 }
 
 // More streams than one wave per SIMD of this device, and a shape the small-footprint kernels take?
+// CST_SMALL_KERNELS=0 / =enc / =dec (A/B runs): never take the small-footprint kernels / only the encoder / only the decoder
+static bool small_allowed(bool encode) {
+    const char* e = getenv("CST_SMALL_KERNELS");
+    if (!e) return true;
+    if (e[0] == '0') return false;
+    if (e[0] == 'e') return encode;
+    if (e[0] == 'd') return !encode;
+    return true;
+}
+
 bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
+    if (!small_allowed(true)) return false;
     if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (a.n_per_stream % 4 != 0 || (reinterpret_cast<uintptr_t>(a.symbols) & 15) != 0) return false;
     if (a.n_streams <= (size_t)device_cus * kBlock) return false;
@@ -259,6 +270,7 @@ bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layou
 }
 
 bool small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
+    if (!small_allowed(false)) return false;
     if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (a.n_per_stream % 4 != 0 || (reinterpret_cast<uintptr_t>(a.symbols) & 15) != 0) return false;
     if (!a.dec_cp || !a.dec_idx || a.n_symbols > 256) return false;
