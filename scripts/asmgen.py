@@ -11,6 +11,16 @@ import os
 import re
 
 
+# Code placement (round 5).  One s_nop in front of the producer / consumer encoder's loop -- the same instructions four bytes
+# further on -- cost 10 % (0.275 -> 0.303 ms, profiles/r04_placement.txt): these loops are 8 - 12 KiB of straight-line code, and
+# which of their 8-byte instructions straddle the 64-byte lines of the instruction cache is decided by where the loop starts.  So
+# every generated loop head ("1:") sits on a 64-byte boundary (.p2align 6: the assembler pads with s_nop, executed once per
+# statement): an edit upstream of a loop no longer moves it.  GEN_ALIGN=0 switches the directive off, GEN_ALIGN_PAD=n puts n more
+# s_nop behind it (the phase experiment: scripts/placement_ab.sh).
+ALIGN = int(os.environ.get("GEN_ALIGN", "6"))
+ALIGN_PAD = int(os.environ.get("GEN_ALIGN_PAD", "0"))
+
+
 class Asm:
     def __init__(self):
         self.lines = []
@@ -19,6 +29,10 @@ class Asm:
         self.events = []   # ("lds"|"vm", tag) issues and ("wait_lds"|"wait_vm", tag, operand) waits, in program order
 
     def i(self, text, comment=None):
+        if text == "1:" and ALIGN:
+            self.lines.append((f".p2align {ALIGN}", "loop head on a 64-byte boundary: see asmgen.py"))
+            for _ in range(ALIGN_PAD):
+                self.lines.append(("s_nop 0", None))
         self.lines.append((text, comment))
 
     def ds(self, text, tag, comment=None):
@@ -107,4 +121,4 @@ class Asm:
         return "\n".join(out) + "\n"
 
     def n_instr(self):
-        return sum(1 for t, _ in self.lines if not t.endswith(":") and not t.startswith(";"))
+        return sum(1 for t, _ in self.lines if not t.endswith(":") and not t.startswith(";") and not t.startswith("."))

@@ -39,7 +39,7 @@ from asmgen import Asm  # noqa: E402
 # Written to cst_range_decode_loop{,_b16}_sub{,_ends}.inc (stream-major only).
 SUB = bool(os.environ.get("GEN_RANGE_SUB"))
 SUB_ROW = 36
-CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
+CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
 OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
 # SYMBOL_MAJOR (the same four files with _sm): symbols[t][stream], the staging of gen_decode_loop.py's SYMBOL_MAJOR (whole lines): quad k of the

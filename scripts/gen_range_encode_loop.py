@@ -34,7 +34,7 @@ from asmgen import Asm  # noqa: E402
 # countdown and a branch at the top of every tile, four instructions + three stores k times per stream.  The held word counts:
 # pos = wr + 1 (wr is -1 until the first word exists).  Written to cst_range_encode_loop{,_2f}_ck.inc; the words are the plain loop's.
 CKPT = bool(os.environ.get("GEN_RANGE_CK"))
-CSRC = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc"
+CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
 OUT = {(1, False): CSRC / "cst_range_encode_loop.inc", (2, False): CSRC / "cst_range_encode_loop_2f.inc",
        (1, True): CSRC / "cst_range_encode_loop_sm.inc", (2, True): CSRC / "cst_range_encode_loop_2f_sm.inc"}
 FLUSHES = 1

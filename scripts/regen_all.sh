@@ -1,0 +1,10 @@
+#!/bin/bash
+# Regenerates every checked-in main-loop statement (constriction_amd/csrc/*.inc) from its generator, variants included.
+set -e
+cd "$(dirname "$0")/.."
+for g in scripts/gen_*loop*.py; do python "$g" > /dev/null; done
+GEN_PT_SUB=1 python scripts/gen_pt_decode_loop.py > /dev/null
+GEN_PT_CK=1 python scripts/gen_pt_encode_loop.py > /dev/null
+GEN_RANGE_CK=1 python scripts/gen_range_encode_loop.py > /dev/null
+GEN_RANGE_SUB=1 python scripts/gen_range_decode_loop.py > /dev/null
+git status --short constriction_amd/csrc | grep '\.inc' | wc -l

@@ -151,3 +151,44 @@ def test_lane_quad_decoder_loop_is_in_sync(tmp_path, monkeypatch):
     mod.OUT = tmp_path / "dq.inc"
     mod.main()
     assert (tmp_path / "dq.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_dq.inc").read_text()
+
+
+def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):
+    """round 5: the checkpointing encoders (GEN_PT_CK, GEN_RANGE_CK) and the byte-tile loops of the sub-lane decoders
+    (GEN_PT_SUB, GEN_RANGE_SUB) are the same generators run with a knob"""
+    csrc = ROOT / "constriction_amd" / "csrc"
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT", "GEN_PT_WINDOW", "GEN_NO_MORE"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("GEN_PT_SUB", "1")
+    assert _regenerate(_load("gen_pt_decode_loop"), tmp_path, "cst_pt_decode_loop_sub.inc") == (csrc / "cst_pt_decode_loop_sub.inc").read_text()
+    monkeypatch.delenv("GEN_PT_SUB")
+    monkeypatch.setenv("GEN_PT_CK", "1")
+    assert _regenerate(_load("gen_pt_encode_loop"), tmp_path, "cst_pt_encode_loop_ck.inc") == (csrc / "cst_pt_encode_loop_ck.inc").read_text()
+    monkeypatch.delenv("GEN_PT_CK")
+    monkeypatch.setenv("GEN_RANGE_CK", "1")
+    mod = _load("gen_range_encode_loop")
+    mod.OUT = {key: tmp_path / path.name for key, path in mod.OUT.items()}
+    mod.main()
+    for name in ("cst_range_encode_loop_ck.inc", "cst_range_encode_loop_2f_ck.inc"):
+        assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
+    monkeypatch.delenv("GEN_RANGE_CK")
+    monkeypatch.setenv("GEN_RANGE_SUB", "1")
+    mod = _load("gen_range_decode_loop")
+    mod.OUT = {key: tmp_path / path.name for key, path in mod.OUT.items()}
+    mod.main()
+    for name in ("cst_range_decode_loop_sub.inc", "cst_range_decode_loop_sub_ends.inc", "cst_range_decode_loop_b16_sub.inc",
+                 "cst_range_decode_loop_b16_sub_ends.inc"):
+        assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
+
+
+def test_every_loop_head_is_pinned_to_a_cache_line():
+    """code placement is worth +-10 % on these loops (profiles/r04_placement.txt): every generated statement carries
+    `.p2align 6` directly in front of its loop head, so that an edit upstream of a loop cannot move it (asmgen.py)"""
+    incs = sorted((ROOT / "constriction_amd" / "csrc").glob("*.inc"))
+    statements = [p for p in incs if "asm volatile(" in p.read_text()]
+    assert len(statements) >= 40
+    for p in statements:
+        lines = [ln.split("//")[0].strip() for ln in p.read_text().splitlines()]
+        heads = [i for i, ln in enumerate(lines) if ln == '"1:\\n"']
+        assert len(heads) == 1, p.name
+        assert lines[heads[0] - 1] == '".p2align 6\\n\\t"', p.name
