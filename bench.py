@@ -488,7 +488,7 @@ def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3):
                 dwords[k][: totals[c]].copy_(host_words[base: base + totals[c]], non_blocking=True)
                 doff[k].copy_(host_off[c], non_blocking=True)
                 dnw[k].copy_(doff[k][1:] - doff[k][:-1])
-                B.ans_decode((dwords[k], dnw[k]), model, n_per, offsets=doff[k], config=cfg, out=dsym[k], cold=True)   # (the words have just come over PCIe)
+                B.ans_decode((dwords[k], dnw[k]), model, n_per, offsets=doff[k], config=cfg, out=dsym[k])   # (packed words without provenance -- they have just come over PCIe: the library reads them as cold)
                 host_back[c * per:(c + 1) * per].copy_(dsym[k], non_blocking=True)
         torch.cuda.synchronize()
 
@@ -835,8 +835,12 @@ def main():
     n_sym = n_streams * N_PER
     # algorithmic bytes per launch: 4 B per int32 symbol + 4 B per compressed word, each way
     bytes_per_launch = 4 * n_sym + 4 * total_words
-    # (the C2 shape takes the producer / consumer encoder, cst_ans_pc.hip: coder waves + helper waves)
-    dominant, dom_ms = ("ans_encode_pc_kernel", enc_ms) if enc_ms >= dec_ms else ("ans_decode_kernel", dec_ms)
+    # which kernels the dispatcher took for this shape on this box (the C2 shape: the producer / consumer encoder, cst_ans_pc.hip)
+    B.ans_encode(symbols, model, (W, S, P), out=enc)
+    enc_kernel = B.last_kernel()
+    B.ans_decode(enc, model, N_PER, out=decoded, cold=False)
+    dec_kernel = B.last_kernel()
+    dominant, dom_ms = (enc_kernel, enc_ms) if enc_ms >= dec_ms else (dec_kernel, dec_ms)
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
 
     ok = True
@@ -875,16 +879,23 @@ def main():
             torch.cuda.synchronize()
             total += e0.elapsed_time(e1)
         return total / reps
+    # words WITHOUT provenance: the same buffers as a caller holds them who got the words from the host, a peer or a file (the
+    # library then decides for itself: batched._words_are_cold)
+    foreign = B.EncodedBatch(enc.words, enc.n_words, enc.status, enc.config)
     cold = {"encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc)), 4),
-            "decode_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded)), 4),
+            "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded)), 4),
+            "decode_kernel": B.last_kernel(),
+            "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False)), 4),
             "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True)), 4),
-            "what": "same kernels, a 1-GiB fill before every launch (nothing of the batch left in L2 or the Infinity Cache); "
-                    "decode_cold_words_hint_ms: the call made with CST_FLAG_COLD_WORDS, i.e. by a caller who knows that (lane-quad word "
-                    "loads, cst_ans_dq.hip)"}
+            "what": "same batch, a 1-GiB fill before every launch (nothing of it left in L2 or the Infinity Cache).  decode_ms: the default "
+                    "call on words whose provenance the library does not know (as they arrive from the host, a peer, a file): it takes the "
+                    "lane-quad decoder (cst_ans_dq.hip) by itself; decode_chunk_loads_ms: the decoder of the timed steps forced (cold=False); "
+                    "decode_cold_words_hint_ms: CST_FLAG_COLD_WORDS passed explicitly"}
     cold["hint_bit_exact"] = bool(torch.equal(decoded, symbols))
     cold["after_a_1GiB_read_instead"] = {
         "encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc), clean=True), 4),
-        "decode_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded), clean=True), 4),
+        "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded), clean=True), 4),
+        "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False), clean=True), 4),
         "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True), clean=True), 4),
         "what": "the same with the caches full of clean lines (a fill leaves 288 MiB of dirty lines whose write-back competes with the launch)"}
     del flush
@@ -919,7 +930,7 @@ def main():
                 traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this command, scripts/pmc_all.sh)"
             except Exception:
                 traffic = None
-        dom_cold_ms = cold["encode_ms"] if dominant == "ans_encode_pc_kernel" else cold["decode_ms"]
+        dom_cold_ms = cold["encode_ms"] if dominant == enc_kernel else cold["decode_ms"]
         line = {
             "metric": "Msymbols/s encode+decode, 64k x 4k-symbol streams, bit-exact vs CPU",
             "value": round(world * n_sym * args.steps / elapsed / 1e6, 1),

@@ -86,6 +86,11 @@ extern "C" {
     /// Text of the most recent HIP error seen by the calling thread ("" if none).
     pub fn cst_last_hip_error() -> *const c_char;
 
+    /// ABI 4, diagnostics: the kernel family the calling thread's last batched coder call (cst_ans_* / cst_range_* _batch and their
+    /// _ckpt forms) launched -- "ans_encode_pc_kernel", "ans_decode_dq_kernel", "range_decode_sub_kernel", ... ; "" before any.
+    /// The dispatcher picks by shape, alignment and flags; a profile or a benchmark that labels its numbers asks here.
+    pub fn cst_last_kernel_name() -> *const c_char;
+
     /// Upper bound on the words one stream can produce, min(n, ceil(n*P/W)) + S/W, rounded up to a whole number of
     /// 64-byte units so that slabs laid out at this stride from a 64-byte aligned base are all 64-byte aligned (the
     /// encoder then writes whole aligned 64-byte groups).  Any other stride remains legal.

@@ -131,6 +131,11 @@ pub fn abi_matches() -> bool {
     unsafe { ffi::cst_abi_version() == ffi::CST_ABI_VERSION }
 }
 
+/// The kernel family this thread's last batched coder call launched (diagnostics: the dispatcher picks by shape and flags).
+pub fn last_kernel_name() -> String {
+    unsafe { std::ffi::CStr::from_ptr(ffi::cst_last_kernel_name()) }.to_string_lossy().into_owned()
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // entropy models
 // ---------------------------------------------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ SIGNATURES = {
     "cst_abi_version": (_i32, []),
     "cst_device_count": (_i32, []),
     "cst_last_hip_error": (C.c_char_p, []),
+    "cst_last_kernel_name": (C.c_char_p, []),
     "cst_ans_max_words": (_z, [_z, CoderConfig]),
     "cst_range_max_words": (_z, [_z, CoderConfig]),
     "cst_model_create_table": (_i32, [_i32, _i32, _i32, _vp, C.POINTER(_vp)]),

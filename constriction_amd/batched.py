@@ -209,6 +209,36 @@ class EncodedBatch:
                 self.status.cpu().numpy())
 
 
+# Provenance of compressed words (round 5).  The (32,64), P <= 12 decoder has two ways of reading its words: 16-byte chunks per
+# lane (fastest on words that sit in the GPU's caches: what an encode call on the same HIP stream has just left there) and
+# whole 64-byte segments by lane quads (CST_FLAG_COLD_WORDS, cst_ans_dq.hip: 11 - 17 % faster on words that come from HBM -- by
+# DMA from the host, from a peer, from a file, or simply written long ago).  The C ABI takes a flag; this layer KNOWS where its
+# words come from: ans_encode stamps the EncodedBatch it fills, any later encode on that stream takes the stamp's currency away,
+# and words that arrive as plain tensors (packed + offsets, scatter results, container files) never had one.  Batches whose words
+# alone exceed the chip's 256-MiB memory-side cache are cold whatever their history.
+_INFINITY_CACHE_BYTES = 256 << 20
+_launch_serial = [0]
+_last_encode = {}        # HIP stream -> serial of the last encode launched on it
+
+
+def _stamp_fresh(out) -> None:
+    _launch_serial[0] += 1
+    out._fresh = (torch.cuda.current_stream().cuda_stream, _launch_serial[0])
+    _last_encode[out._fresh[0]] = _launch_serial[0]
+
+
+def _words_are_cold(encoded) -> bool:
+    fresh = getattr(encoded, "_fresh", None)
+    if fresh is None or fresh[0] != torch.cuda.current_stream().cuda_stream or _last_encode.get(fresh[0]) != fresh[1]:
+        return True
+    return int(encoded.n_words.numel()) * int(encoded.words.shape[1]) * 4 > 3 * _INFINITY_CACHE_BYTES   # (slabs are ~1/3 used)
+
+
+def last_kernel() -> str:
+    """the kernel family this thread's last batched coder call launched (cst_last_kernel_name)"""
+    return N.lib().cst_last_kernel_name().decode()
+
+
 def max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
     return N.load_library().cst_ans_max_words(n_per_stream, _cfg(*config))
 
@@ -325,6 +355,7 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
     N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
                                          out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
                                          _stream_ptr()), "cst_ans_encode_batch")
+    _stamp_fresh(out)
     return out
 
 
@@ -358,12 +389,13 @@ def ans_roundtrip_launcher(symbols: torch.Tensor, model: Model, encoded: Encoded
 
 
 def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None, config=None, cold: bool = False):
+               out: Optional[torch.Tensor] = None, config=None, cold: Optional[bool] = None):
     """One AnsCoder per stream: from_compressed + decode_iid_symbols (stack.rs:299-318, mod.rs:1016-1031).
 
-    `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout.  `cold=True` (CST_FLAG_COLD_WORDS,
-    a hint): the words are not expected in the GPU's caches -- they came from the host or a peer, not from an encode call
-    just before."""
+    `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout.  `cold` (CST_FLAG_COLD_WORDS, a hint
+    that never changes results): are the words NOT expected in the GPU's caches?  Default None = decided by provenance: hot only
+    if `encoded` is the EncodedBatch that the last ans_encode on this HIP stream filled (and small enough to have stayed in the
+    caches); words that came from the host, a peer or a file -- plain tensors, packed + offsets -- are cold."""
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
         stride = words.shape[1]
@@ -371,6 +403,8 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
         words, n_words = encoded
         stride = words.shape[1] if words.dim() == 2 else 0
         config = config or (32, 64, 12)
+    if cold is None:
+        cold = _words_are_cold(encoded) if isinstance(encoded, EncodedBatch) else True
     n_streams = n_words.numel()
     dev = words.device
     if out is None:

@@ -122,8 +122,8 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cf
         // one table per stream (config C3): the compact-row encoder notes the jump points on its way (cst_ans_pt.hip), at
         // the speed of the plain encoder for chunks of whole 32-symbol tiles
         if (!pt_usable(model, cfg, layout, n_per_stream) || model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
-        return ans_encode_pt_ckpt(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, ckpt_interval, d_ckpt_pos,
-                                  d_ckpt_state, d_status, (hipStream_t)stream);
+        return note_kernel("ans_encode_pt_kernel<ckpt>", ans_encode_pt_ckpt(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words,
+                                                                             ckpt_interval, d_ckpt_pos, d_ckpt_state, d_status, (hipStream_t)stream));
     }
     CkptEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.enc = model->d_enc;
@@ -167,8 +167,8 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
         if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
         // the lanes of a stream share its table in LDS: two waves per SIMD (cst_ans_pt.hip, ans_decode_pt_sub_kernel)
         if (n_chunks >= 2 && pt_sub_usable(model, cfg, n_streams, n_per_stream, ckpt_interval))
-            return ans_decode_pt_sub(model, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos, d_ckpt_state, d_symbols,
-                                     n_streams, n_per_stream, d_status, hs);
+            return note_kernel("ans_decode_pt_sub_kernel", ans_decode_pt_sub(model, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos,
+                                                                              d_ckpt_state, d_symbols, n_streams, n_per_stream, d_status, hs));
         // any other shape: the jump points are side information -- decode the streams whole (the first one IS the whole stream)
         uint64_t* w_state = reinterpret_cast<uint64_t*>(d_scratch);
         uint32_t* w_n = reinterpret_cast<uint32_t*>(w_state + n_streams);

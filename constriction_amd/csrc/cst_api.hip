@@ -10,6 +10,9 @@ namespace cst {
 
 static thread_local std::string g_last_error;
 
+static thread_local const char* g_last_kernel = "";
+cst_status note_kernel(const char* name, cst_status rc) { g_last_kernel = name; return rc; }
+
 void set_hip_error(hipError_t e, const char* what) {
     char buf[512];
     std::snprintf(buf, sizeof buf, "%s: %s (%d)", what ? what : "hip", hipGetErrorString(e), (int)e);
@@ -225,6 +228,8 @@ extern "C" {
 
 int32_t cst_abi_version(void) { return CST_ABI_VERSION; }
 
+const char* cst_last_kernel_name(void) { return g_last_kernel; }
+
 int32_t cst_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -261,26 +266,26 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     if (generic_config(cfg))       // the rest of the reference's type grid (stack.rs:1293-1356): one compiler-scheduled kernel
-        return ans_encode_generic(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status,
-                                  flags, (hipStream_t)stream);
+        return note_kernel("ans_encode_generic_kernel", ans_encode_generic(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words,
+                                                                            d_n_words, d_state, d_status, flags, (hipStream_t)stream));
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))   // one table per stream (config C3), compact rows
-        return ans_encode_pt(model, cfg, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, d_state, d_status,
-                             flags, (hipStream_t)stream);
+        return note_kernel("ans_encode_pt_kernel", ans_encode_pt(model, cfg, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words, d_state,
+                                                                  d_status, flags, (hipStream_t)stream));
     if (model->per_stream)   // ... full rows (any supported shape)
-        return ans_encode_per_stream(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words,
-                                     d_state, d_status, flags, (hipStream_t)stream);
+        return note_kernel("ans_encode_per_stream_kernel", ans_encode_per_stream(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words,
+                                                                                  d_n_words, d_state, d_status, flags, (hipStream_t)stream));
     AnsEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.status = d_status;
     a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
-    if (small_encode_usable(a, cfg, layout, model->cu_count)) return ans_encode_small(a, hs);   // more than one wave per SIMD
-    if (pc_encode_usable(a, cfg, layout, model->cu_count)) return ans_encode_pc(a, hs);        // one wave per SIMD: coder + helper waves
-    if (w16_encode_usable(a, cfg, layout)) return ans_encode_w16(a, layout, hs);                        // SmallAnsCoder preset
-    if (wide_encode_usable(a, cfg, layout)) return ans_encode_wide(a, layout, hs);                      // 12 < P <= 24
-    if (cfg.word_bits == 32) return encode_dispatch<32, 64>(a, layout, hs);
-    return encode_dispatch<16, 32>(a, layout, hs);
+    if (small_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_small_kernel", ans_encode_small(a, hs));   // more than one wave per SIMD
+    if (pc_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_pc_kernel", ans_encode_pc(a, hs));           // one wave per SIMD: coder + helper waves
+    if (w16_encode_usable(a, cfg, layout)) return note_kernel("ans_encode_w16_kernel", ans_encode_w16(a, layout, hs));               // SmallAnsCoder preset
+    if (wide_encode_usable(a, cfg, layout)) return note_kernel("ans_encode_wide_kernel", ans_encode_wide(a, layout, hs));            // 12 < P <= 24
+    if (cfg.word_bits == 32) return note_kernel("ans_encode_kernel", encode_dispatch<32, 64>(a, layout, hs));
+    return note_kernel("ans_encode_kernel", encode_dispatch<16, 32>(a, layout, hs));
 }
 
 cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
@@ -295,14 +300,14 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
     if (generic_config(cfg))
-        return ans_decode_generic(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream,
-                                  layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
+        return note_kernel("ans_decode_generic_kernel", ans_decode_generic(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols,
+                                                                            n_streams, n_per_stream, layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream));
     if (model->per_stream && pt_usable(model, cfg, layout, n_per_stream))
-        return ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream,
-                             d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
+        return note_kernel("ans_decode_pt_kernel", ans_decode_pt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams,
+                                                                  n_per_stream, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream));
     if (model->per_stream)
-        return ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams,
-                                     n_per_stream, layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream);
+        return note_kernel("ans_decode_per_stream_kernel", ans_decode_per_stream(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols,
+                                                                                  n_streams, n_per_stream, layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream));
     AnsDecodeArgs a{};
     a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = d_symbols;
     a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
@@ -310,12 +315,12 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
-    if (small_decode_usable(a, cfg, layout, model->cu_count)) return ans_decode_small(a, hs);   // more than one wave per SIMD
-    if (b16_decode_usable(a, cfg, layout)) return ans_decode_b16(a, layout, hs);                        // 12 < P <= 24
-    if (w16_decode_usable(a, cfg, layout)) return ans_decode_w16(a, layout, hs);                        // SmallAnsCoder preset
-    if (dq_decode_usable(a, cfg, layout)) return ans_decode_dq(a, hs);                                  // P <= 12, whole aligned tiles: lane-quad word loads
-    if (cfg.word_bits == 32) return decode_dispatch<32, 64>(a, layout, hs);
-    return decode_dispatch<16, 32>(a, layout, hs);
+    if (small_decode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_decode_small_kernel", ans_decode_small(a, hs));   // more than one wave per SIMD
+    if (b16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_b16_kernel", ans_decode_b16(a, layout, hs));               // 12 < P <= 24
+    if (w16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_w16_kernel", ans_decode_w16(a, layout, hs));               // SmallAnsCoder preset
+    if (dq_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_dq_kernel", ans_decode_dq(a, hs));                          // P <= 12, whole aligned tiles: lane-quad word loads
+    if (cfg.word_bits == 32) return note_kernel("ans_decode_kernel", decode_dispatch<32, 64>(a, layout, hs));
+    return note_kernel("ans_decode_kernel", decode_dispatch<16, 32>(a, layout, hs));
 }
 
 static bool ragged_order_ok(const uint32_t* d_order, size_t n_streams) { return !d_order || n_streams <= 0xffffffffull; }

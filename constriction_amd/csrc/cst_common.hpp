@@ -140,6 +140,8 @@ namespace cst {
 
 // thread-local record of the last HIP failure (cst_last_hip_error)
 void set_hip_error(hipError_t e, const char* what);
+// thread-local record of which kernel family the last coder call of this thread launched (cst_last_kernel_name); returns rc
+cst_status note_kernel(const char* name, cst_status rc);
 
 #define CST_HIP_TRY(expr)                                      \
     do {                                                       \

@@ -392,9 +392,9 @@ cst_status cst_range_encode_batch(const cst_model* model, cst_coder_config cfg, 
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
-    if (cfg.word_bits == 32 && range_encode_fast_usable(a, layout)) return range_encode_fast(a, layout, hs);
-    if (cfg.word_bits == 32) return range_encode_ws<32, 64>(a, layout, hs);
-    return range_encode_ws<16, 32>(a, layout, hs);
+    if (cfg.word_bits == 32 && range_encode_fast_usable(a, layout)) return note_kernel("range_encode_fast_kernel", range_encode_fast(a, layout, hs));
+    if (cfg.word_bits == 32) return note_kernel("range_encode_kernel", range_encode_ws<32, 64>(a, layout, hs));
+    return note_kernel("range_encode_kernel", range_encode_ws<16, 32>(a, layout, hs));
 }
 
 cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words,
@@ -415,9 +415,9 @@ cst_status cst_range_decode_batch(const cst_model* model, cst_coder_config cfg, 
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
     a.rstate = d_rstate; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
-    if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return range_decode_fast(a, layout, hs);
-    if (cfg.word_bits == 32) return range_decode_ws<32, 64>(a, layout, hs);
-    return range_decode_ws<16, 32>(a, layout, hs);
+    if (cfg.word_bits == 32 && range_decode_fast_usable(a, layout)) return note_kernel("range_decode_fast_kernel", range_decode_fast(a, layout, hs));
+    if (cfg.word_bits == 32) return note_kernel("range_decode_kernel", range_decode_ws<32, 64>(a, layout, hs));
+    return note_kernel("range_decode_kernel", range_decode_ws<16, 32>(a, layout, hs));
 }
 
 cst_status cst_range_encode_batch_ckpt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,
@@ -437,7 +437,7 @@ cst_status cst_range_encode_batch_ckpt(const cst_model* model, cst_coder_config 
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
     RangeCkptOut ck{d_ckpt_pos, d_ckpt_lower, d_ckpt_range, ckpt_interval, (n_per_stream + ckpt_interval - 1) / ckpt_interval};
     hipStream_t hs = (hipStream_t)stream;
-    if (cfg.word_bits == 32 && range_encode_ckpt_fast_usable(a, layout)) return range_encode_ckpt_fast(a, ck, hs);
+    if (cfg.word_bits == 32 && range_encode_ckpt_fast_usable(a, layout)) return note_kernel("range_encode_ckpt_kernel", range_encode_ckpt_fast(a, ck, hs));
     const size_t blocks = (n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
     const size_t lds = (size_t)(kBlock / kWave) * kRingWords * 4;
@@ -475,7 +475,7 @@ cst_status cst_range_decode_batch_ckpt(const cst_model* model, cst_coder_config 
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status; a.words_capacity = capacity;
     a.ckpt_pos = d_ckpt_pos; a.ckpt_lower = d_ckpt_lower; a.ckpt_range = d_ckpt_range; a.interval = ckpt_interval; a.n_chunks = n_chunks;
     // k lanes per stream on the hand-scheduled statements, two waves per SIMD (cst_range_fast.hip)
-    if (cfg.word_bits == 32 && range_decode_sub_usable(a)) return range_decode_sub(a, hs);
+    if (cfg.word_bits == 32 && range_decode_sub_usable(a)) return note_kernel("range_decode_sub_kernel", range_decode_sub(a, hs));
     // any other preset / alphabet: the ordinary batched decode of the virtual streams, continued at their jump points
     cst_range_state* v_state = reinterpret_cast<cst_range_state*>(d_scratch);
     uint64_t* v_offsets = reinterpret_cast<uint64_t*>(v_state + n_virtual);

@@ -138,3 +138,45 @@ def test_batched_decoders_continue_from_a_raw_state(B, O, flags):
         outs.append(out.cpu().numpy())
     assert np.array_equal(np.concatenate(outs, axis=1), sym)
     assert (d_n.cpu().numpy() == 0).all()                # every word consumed
+
+
+def test_cold_words_are_recognised_by_provenance(B, O):
+    """batched.ans_decode decides by itself how to read the words (round 5): chunk loads for the EncodedBatch the last ans_encode
+    on this stream filled, whole 64-byte segments by lane quads for everything else -- and the choice never changes a result."""
+    P, n_streams, n_per = 12, 256, 256
+    cdf = O.GaussianModel(-50, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, -50, P)
+    sym = torch.from_numpy(O.synth_symbols(9, 0, n_streams, n_per, -50, cdf, P)).cuda()
+    other = torch.from_numpy(O.synth_symbols(10, 0, n_streams, n_per, -50, cdf, P)).cuda()
+    enc = B.ans_encode(sym, model, (32, 64, P))
+    d0, s0 = B.ans_decode(enc, model, n_per)
+    assert B.last_kernel() == "ans_decode_kernel"                      # fresh: the encoder has just left them in the caches
+    d1, _ = B.ans_decode(enc, model, n_per)
+    assert B.last_kernel() == "ans_decode_kernel"                      # (reading them does not make them colder)
+    enc_other = B.ans_encode(other, model, (32, 64, P))
+    d2, s2 = B.ans_decode(enc, model, n_per)
+    assert B.last_kernel() == "ans_decode_dq_kernel"                   # another batch went through the caches since
+    d3, _ = B.ans_decode(enc_other, model, n_per)
+    assert B.last_kernel() == "ans_decode_kernel"
+    foreign = B.EncodedBatch(enc.words.clone(), enc.n_words.clone(), enc.status, enc.config)     # words that came from elsewhere
+    d4, s4 = B.ans_decode(foreign, model, n_per)
+    assert B.last_kernel() == "ans_decode_dq_kernel"
+    packed, offsets = B.compact(enc)
+    d5, s5 = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets)
+    assert B.last_kernel() == "ans_decode_dq_kernel"
+    d6, _ = B.ans_decode(foreign, model, n_per, cold=False)
+    assert B.last_kernel() == "ans_decode_kernel"
+    d7, _ = B.ans_decode(enc_other, model, n_per, cold=True)
+    assert B.last_kernel() == "ans_decode_dq_kernel"
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.default_stream())
+        d8, _ = B.ans_decode(enc_other, model, n_per)                   # another HIP stream: no claim about its caches' history
+        assert B.last_kernel() == "ans_decode_dq_kernel"
+    torch.cuda.synchronize()
+    for d in (d0, d1, d2, d4, d5, d6):
+        assert torch.equal(d, sym)
+    for d in (d3, d7, d8):
+        assert torch.equal(d, other)
+    for s in (s0, s2, s4, s5):
+        assert int(s.abs().sum()) == 0
