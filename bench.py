@@ -107,9 +107,33 @@ def synth_symbols_per_stream(seed, stream_begin, n_per, lo, cdf_rows, precision,
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per scheduling period (cgroup cpu.max / cfs_quota_us), or None if unlimited.
+    The GPU boxes of this pool show 256 logical CPUs and a quota of 16: a pass of 256 threads spends the period's 1.6 CPU-seconds
+    in ~6 ms and is then SUSPENDED until the next 100-ms period -- which is what round 4's "decode scales to 4 % of ideal" was
+    (scripts/cpu_scaling.py, profiles/r05_cpu_scaling.txt: up to 32 threads the port scales at 0.94 - 0.99 per thread, the decoder
+    like the encoder; beyond the quota a pass runs at whatever is left of the period's budget, 3 - 21 Gsym/s from run to run)."""
+    try:
+        p = Path("/sys/fs/cgroup/cpu.max")
+        if p.exists():
+            quota, period = p.read_text().split()[:2]
+            return None if quota == "max" else float(quota) / float(period)
+        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        return None if q <= 0 else q / int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
     """host threads this rank may use for the oracle checks: the box's cores shared among the ranks of the job"""
     return max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
+
+
+def baseline_threads():
+    """threads of the cpu_baseline leg: the logical CPUs the container can keep busy (its CPU quota, if it has one)"""
+    q = cpu_quota()
+    n = host_cores()
+    return n if q is None else max(1, min(n, int(q + 0.5)))
 
 
 def _blocks(n, parts):
@@ -163,7 +187,7 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
     page-fault path (round 3 allocated a gigabyte of zero pages inside the timed region: all-core decode ran at half the
     encoder's rate although one thread decodes as fast as it encodes)."""
     from oracle import oracle as O
-    cores = host_cores()
+    cores = baseline_threads()
     lut = O.lookup_from_cdf(cdf, P)
 
     def run(sym, threads):
@@ -195,7 +219,11 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
         "single_thread_value": round(n1 / (te1 + td1) / 1e6, 2),
         "encode_Msymbols_per_s": round(enc_rate, 1), "decode_Msymbols_per_s": round(dec_rate, 1),
         "scaling_efficiency": {"encode": round(enc_rate / (cores * enc1), 3), "decode": round(dec_rate / (cores * dec1), 3),
-                               "what": f"all-thread rate / ({cores} x the one-thread rate); {cores} hardware threads = the box's logical CPUs"},
+                               "what": f"{cores}-thread rate / ({cores} x the one-thread rate)"},
+        "logical_cpus": os.cpu_count(), "cgroup_cpu_quota": cpu_quota(),
+        "threads_note": "threads = min(logical CPUs, the container's CPU quota): more threads than the quota are suspended by the scheduler "
+                        "for the rest of every 100-ms period once its budget is spent (profiles/r05_cpu_scaling.txt); on a box without a "
+                        "quota every logical CPU is used",
     }
 
 
@@ -331,6 +359,35 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
     return entry
 
 
+def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
+    """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8): the
+    matrix is widened / narrowed on the device next to the coder call (cst_ans_*_batch_sym).  Algorithmic bytes: 1 B per symbol
+    + 4 B per word each way; the TRAFFIC of this form is 1 + 4 + 4 B per symbol (conversion kernel + coder kernel), which is why
+    the entry's fractions are low -- the saving is on the link (`end_to_end.int8_symbols`), not here."""
+    n_streams, n_per = symbols.shape
+    cfg = (W, S, P)
+    narrow = symbols.to(dtype)
+    nb = narrow.element_size()
+    enc = B.ans_encode(narrow, model, cfg)
+    decoded = torch.empty_like(narrow)
+    enc_ms = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
+    dec_ms = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
+    total_words = enc.total_words()
+    byts = nb * n_streams * n_per + 4 * total_words
+    entry = {"workload": f"C2 with {str(dtype).replace('torch.', '')} symbol matrices (widened / narrowed on the device next to the coder call)",
+             "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
+             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_streams * n_per / (enc_ms + dec_ms) / 1e3, 1),
+             "algorithmic_bytes_per_symbol": round(byts / (n_streams * n_per), 3),
+             "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    if check:
+        plain = B.ans_encode(symbols, model, cfg)
+        used = torch.arange(plain.words.shape[1], device=symbols.device)[None, :] < plain.n_words[:, None]
+        entry["bit_exact"] = bool(torch.equal(decoded, narrow)) and bool(torch.equal(enc.n_words, plain.n_words)) and \
+            bool(((enc.words == plain.words) | ~used).all()) and int(enc.status.abs().sum().item()) == 0
+        entry["bit_exact_scope"] = "words and counts of every stream vs the int32 call's (compared with the CPU oracle in the headline check), decoded symbols vs input"
+    return entry
+
+
 def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100, hi=100):
     """f1: every symbol its own f64 (mean, std) -- coder.encode_reverse(symbols, QuantizedGaussian(lo, hi),
     means, stds) / coder.decode(family, means, stds), src/pybindings/stream/stack.rs:567-588, 733-751 -- for all streams at
@@ -440,24 +497,26 @@ def ragged_config(B, reps, check, n_docs=100_000, n_sym=64, precision=24):
     return entry
 
 
-def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3):
+def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3, dtype=torch.int32):
     """the same batch from HOST memory and back -- what the reference's bindings do around every call (they copy
     the numpy input in, src/pybindings/mod.rs:240-243, and the compressed words out, pybindings/stream/stack.rs:422-427).
         encode leg:  pinned host symbols -> H2D -> cst_ans_encode_batch -> cst_compact_words -> D2H of the packed words
         decode leg:  pinned host words + offsets -> H2D -> cst_ans_decode_batch -> D2H of the symbols
     in `n_chunks` chunks of streams over `n_hip_streams` HIP streams, so that the copies of one chunk overlap the kernels of
-    another.  Never part of `value`: the link, not the coder, sets these numbers."""
+    another.  Never part of `value`: the link, not the coder, sets these numbers.  dtype torch.int8 / int16: the symbol matrices
+    cross the link in the narrow type and are widened / narrowed on the device (cst_ans_*_batch_sym)."""
     n_streams, n_per = symbols.shape
     per = n_streams // n_chunks
     cfg = (W, S, P)
-    host_sym = torch.empty((n_streams, n_per), dtype=torch.int32, pin_memory=True)
-    host_sym.copy_(symbols)
+    sym_bytes = torch.empty((), dtype=dtype).element_size()
+    host_sym = torch.empty((n_streams, n_per), dtype=dtype, pin_memory=True)
+    host_sym.copy_(symbols.to(dtype))
     stride = B.max_words(n_per, cfg)
     host_words = torch.empty(n_streams * stride, dtype=torch.int32, pin_memory=True)
     host_off = torch.empty((n_chunks, per + 1), dtype=torch.int64, pin_memory=True)
-    host_back = torch.empty((n_streams, n_per), dtype=torch.int32, pin_memory=True)
+    host_back = torch.empty((n_streams, n_per), dtype=dtype, pin_memory=True)
     streams = [torch.cuda.Stream() for _ in range(n_hip_streams)]
-    dsym = [torch.empty((per, n_per), dtype=torch.int32, device="cuda") for _ in range(n_hip_streams)]
+    dsym = [torch.empty((per, n_per), dtype=dtype, device="cuda") for _ in range(n_hip_streams)]
     encs = [B.ans_encode(dsym[k], model, cfg) for k in range(n_hip_streams)]
     packs = [B.compact(encs[k]) for k in range(n_hip_streams)]
     dwords = [torch.empty(per * stride, dtype=torch.int32, device="cuda") for _ in range(n_hip_streams)]
@@ -508,9 +567,11 @@ def end_to_end(B, model, symbols, n_chunks=8, n_hip_streams=3, reps=3):
     n_sym = n_streams * n_per
     words_bytes = 4 * sum(totals)
     return {"what": f"pinned host memory -> device -> host, {n_chunks} chunks of {per} streams over {n_hip_streams} HIP streams; best of {reps}",
+            "symbol_dtype": str(dtype).replace("torch.", ""),
             "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
             "Msymbols_per_s": round(n_sym / (te + td) / 1e6, 1),
-            "encode_link_GBps": round((4 * n_sym + words_bytes) / te / 1e9, 1), "decode_link_GBps": round((4 * n_sym + words_bytes) / td / 1e9, 1),
+            "encode_link_GBps": round((sym_bytes * n_sym + words_bytes) / te / 1e9, 1),
+            "decode_link_GBps": round((sym_bytes * n_sym + words_bytes) / td / 1e9, 1),
             "bit_exact": ok}
 
 
@@ -595,6 +656,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
                           layout="symbol_major")
         del symT
         add("C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
+        try:
+            out.append(narrow_config(B, m12, sym12, reps, check))
+        except Exception as exc:      # noqa: BLE001
+            out.append({"workload": "C2 with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         m24, cdf24 = gaussian(24)
         sym24 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, torch.from_numpy(cdf24.astype(np.int64)).cuda(), 24)
         add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
@@ -862,6 +927,10 @@ def main():
             e2e = end_to_end(B, model, symbols)
         except Exception as exc:      # noqa: BLE001
             e2e = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        try:      # the same with int8 symbol matrices (the alphabet has 101 symbols): a quarter of the symbol bytes on the link
+            e2e["int8_symbols"] = end_to_end(B, model, symbols, dtype=torch.int8)
+        except Exception as exc:      # noqa: BLE001
+            e2e["int8_symbols"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # The timed steps decode what the encoder has just written.  For the record, the same two kernels after a 1-GiB fill
     # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):

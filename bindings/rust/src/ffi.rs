@@ -305,6 +305,71 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// ABI 4: NARROW symbol matrices.  The reference's coders are generic over the symbol type (`Symbol: PrimInt + ...`,
+    /// src/stream/model/quantize.rs:229-255); the kernels here code int32 matrices.  What a narrow matrix saves is the LINK: a batch
+    /// that comes from and returns to host memory is bound by PCIe, and int8 symbols are a quarter of its bytes.  symbol_bytes = 1, 2
+    /// (signed two's complement) or 4; the narrow types are widened / narrowed on the device next to the coder call through
+    /// d_scratch (cst_symbols_scratch_bytes(...) bytes, 0 for symbol_bytes = 4; contents irrelevant).  Words, counts and status are
+    /// those of the int32 calls on the widened values; an encoder symbol outside the model's support is an impossible symbol as ever,
+    /// a decoder whose model's support does not fit the type returns CST_ERR_INVALID_ARGUMENT.  The two conversions are exported on
+    /// their own for the other coders (range, per-symbol, checkpointed calls take int32).
+    pub fn cst_symbols_widen(
+        d_in: *const c_void,
+        symbol_bytes: i32,
+        n: usize,
+        d_out: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_symbols_narrow(
+        d_in: *const i32,
+        n: usize,
+        d_out: *mut c_void,
+        symbol_bytes: i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_symbols_scratch_bytes(n_streams: usize, n_per_stream: usize, symbol_bytes: i32) -> usize;
+
+    pub fn cst_ans_encode_batch_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_state: *mut u64,
+        d_status: *mut i32,
+        flags: u32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_batch_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_state: *mut u64,
+        d_n_words_out: *mut u32,
+        d_status: *mut i32,
+        flags: u32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     /// Streams of DIFFERENT lengths -- thousands of small coders with a shared model in one launch: the reference's "compressed
     /// index" pattern (tests/issue52.rs:27-60, 63-80: one DefaultAnsCoder per document, `encode_symbol` per character last to
     /// first, `into_compressed`; `from_compressed` + `decode_symbol` per document), which costs one device round trip per document

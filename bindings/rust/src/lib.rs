@@ -126,6 +126,33 @@ pub fn device_count() -> Result<usize> {
     Ok(n as usize)
 }
 
+/// Symbol types narrower than `i32` that the batched coders take (ABI 4: `cst_ans_*_batch_sym`, `cst_symbols_widen` / `_narrow`).
+pub trait NarrowSymbol: Copy {
+    const BYTES: i32;
+}
+impl NarrowSymbol for i8 {
+    const BYTES: i32 = 1;
+}
+impl NarrowSymbol for i16 {
+    const BYTES: i32 = 2;
+}
+
+/// Widens a narrow symbol matrix to `i32` on the device (for the coders that take `i32` only: range, per-symbol, checkpointed calls).
+pub fn widen_symbols<T: NarrowSymbol>(narrow: &DeviceBuffer<T>, wide: &mut DeviceBuffer<i32>, stream: &Stream) -> Result<()> {
+    if wide.len() < narrow.len() {
+        return Err(Error::InvalidArgument);
+    }
+    check(unsafe { ffi::cst_symbols_widen(narrow.as_ptr() as *const c_void, T::BYTES, narrow.len(), wide.as_mut_ptr(), stream.as_raw()) })
+}
+
+/// Narrows decoded `i32` symbols on the device (values outside the type are clamped: the caller checked the model's support).
+pub fn narrow_symbols<T: NarrowSymbol>(wide: &DeviceBuffer<i32>, narrow: &mut DeviceBuffer<T>, stream: &Stream) -> Result<()> {
+    if narrow.len() < wide.len() {
+        return Err(Error::InvalidArgument);
+    }
+    check(unsafe { ffi::cst_symbols_narrow(wide.as_ptr(), wide.len(), narrow.as_mut_ptr() as *mut c_void, T::BYTES, stream.as_raw()) })
+}
+
 /// `true` if the loaded library was built from the header this crate was generated from.
 pub fn abi_matches() -> bool {
     unsafe { ffi::cst_abi_version() == ffi::CST_ABI_VERSION }
@@ -447,6 +474,85 @@ impl BatchedAnsCoder {
             )
         })?;
         Ok(out)
+    }
+
+    /// `encode_iid_symbols_reverse` for a NARROW symbol type (`i8` / `i16`: the reference's coders are generic over `Symbol`,
+    /// src/stream/model/quantize.rs:229-255).  The matrix is widened on the device next to the coder call; what it saves is the
+    /// link to the host.  Words, counts and status are those of the `i32` call on the widened values.
+    pub fn encode_iid_symbols_reverse_narrow<T: NarrowSymbol>(
+        &self,
+        symbols: &DeviceBuffer<T>,
+        n_streams: usize,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<EncodedBatch> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if symbols.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_symbols_scratch_bytes(n_streams, n_per_stream, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_ans_encode_batch_sym(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr() as *const c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                core::ptr::null_mut(),
+                out.status.as_mut_ptr(),
+                ffi::CST_FLAG_NONE,
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(out)
+    }
+
+    /// `decode_iid_symbols` into a NARROW symbol type; the model's support must fit it (`InvalidArgument` otherwise).
+    pub fn decode_iid_symbols_narrow<T: NarrowSymbol>(
+        &self,
+        encoded: &EncodedBatch,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(DeviceBuffer<T>, DeviceBuffer<i32>)> {
+        let n_streams = encoded.n_streams;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        let mut symbols: DeviceBuffer<T> = DeviceBuffer::new(count)?;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams)?;
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_symbols_scratch_bytes(n_streams, n_per_stream, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_ans_decode_batch_sym(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                symbols.as_mut_ptr() as *mut c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                core::ptr::null_mut(),
+                core::ptr::null_mut(),
+                status.as_mut_ptr(),
+                ffi::CST_FLAG_NONE,
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?;
+        Ok((symbols, status))
     }
 
     /// Per stream: `encode_symbols_reverse(symbols[s].zip(models))` with one leakily quantized Gaussian per SYMBOL --

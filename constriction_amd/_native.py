@@ -79,6 +79,11 @@ SIGNATURES = {
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
     "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
+    "cst_symbols_widen": (_i32, [_vp, _i32, _z, _vp, _vp]),
+    "cst_symbols_narrow": (_i32, [_vp, _z, _vp, _i32, _vp]),
+    "cst_symbols_scratch_bytes": (_z, [_z, _z, _i32]),
+    "cst_ans_encode_batch_sym": (_i32, [_vp, CoderConfig, _vp, _i32, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "cst_ans_decode_batch_sym": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _i32, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp, _vp]),
     "cst_range_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_range_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
     "cst_range_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),

@@ -21,6 +21,9 @@ from . import _native as N
 PRESETS = {"default": (32, 64, 24), "lookup": (32, 64, 12), "small": (16, 32, 12)}
 
 
+_SYMBOL_BYTES = {torch.int8: 1, torch.int16: 2, torch.int32: 4}
+
+
 def _cfg(W, S, P):
     return N.CoderConfig(W, S, P)
 
@@ -344,7 +347,15 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout) if out is None else None
-    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
+    if narrow != 4:
+        # int8 / int16 symbol matrices (the reference's Symbol is generic, quantize.rs:229-255): widened on the device next to the
+        # coder call -- what they save is the link to the host (cst_ans_encode_batch_sym)
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
+        symbols = _require_cuda(symbols, symbols.dtype, "symbols")
+    else:
+        symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         stride = stride or max_words(n_per, config)
@@ -352,9 +363,16 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
                            torch.empty(n_streams, dtype=torch.int32, device=dev),
                            torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
-    N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
-                                         out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
-                                         _stream_ptr()), "cst_ans_encode_batch")
+    if narrow != 4:
+        L = N.lib()
+        scratch = _ckpt_scratch(("widen", torch.cuda.current_stream().cuda_stream), symbols.device, L.cst_symbols_scratch_bytes(n_streams, n_per, narrow))
+        N.check(L.cst_ans_encode_batch_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words),
+                                           out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE, _ptr(scratch),
+                                           _stream_ptr()), "cst_ans_encode_batch_sym")
+    else:
+        N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
+                                             out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
+                                             _stream_ptr()), "cst_ans_encode_batch")
     _stamp_fresh(out)
     return out
 
@@ -389,8 +407,10 @@ def ans_roundtrip_launcher(symbols: torch.Tensor, model: Model, encoded: Encoded
 
 
 def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None, config=None, cold: Optional[bool] = None):
+               out: Optional[torch.Tensor] = None, config=None, cold: Optional[bool] = None, dtype=torch.int32):
     """One AnsCoder per stream: from_compressed + decode_iid_symbols (stack.rs:299-318, mod.rs:1016-1031).
+    dtype (or the dtype of `out`): torch.int32, or int16 / int8 for a narrow symbol matrix (narrowed on the device next to the
+    decoder call: cst_ans_decode_batch_sym; the model's support must fit the type).
 
     `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout.  `cold` (CST_FLAG_COLD_WORDS, a hint
     that never changes results): are the words NOT expected in the GPU's caches?  Default None = decided by provenance: hot only
@@ -409,9 +429,21 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     dev = words.device
     if out is None:
         shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
-        out = torch.empty(shape, dtype=torch.int32, device=dev)
+        out = torch.empty(shape, dtype=dtype, device=dev)
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
+    narrow = _SYMBOL_BYTES.get(out.dtype)
+    if narrow is None:
+        raise TypeError("decoded symbols are int32, int16 or int8")
+    if narrow != 4:
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only")
+        L = N.lib()
+        scratch = _ckpt_scratch(("narrow", torch.cuda.current_stream().cuda_stream), dev, L.cst_symbols_scratch_bytes(n_streams, n_per_stream, narrow))
+        N.check(L.cst_ans_decode_batch_sym(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
+                                           _ptr(out), narrow, n_streams, n_per_stream, lay, None, None, _ptr(status),
+                                           N.FLAG_COLD_WORDS if cold else N.FLAG_NONE, _ptr(scratch), _stream_ptr()), "cst_ans_decode_batch_sym")
+        return out, status
     N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                          _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status),
                                          N.FLAG_COLD_WORDS if cold else N.FLAG_NONE, _stream_ptr()), "cst_ans_decode_batch")
@@ -816,6 +848,7 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
 
 
 def _ckpt_scratch(kind, dev, nbytes):
+    """a scratch buffer per purpose and device (per HIP stream where calls on several streams may overlap), grown on demand"""
     key = (kind, dev.index)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:

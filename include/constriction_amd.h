@@ -257,6 +257,27 @@ cst_status cst_ans_decode_batch(const cst_model *model, cst_coder_config cfg, co
                                 uint64_t *d_state, uint32_t *d_n_words_out, int32_t *d_status,
                                 uint32_t flags, void *stream);
 
+/* ABI 4: NARROW symbol matrices.  The reference's coders are generic over the symbol type (`Symbol: PrimInt + ...`,
+ * src/stream/model/quantize.rs:229-255); the kernels here code int32 matrices.  What a narrow matrix saves is the LINK: a batch
+ * that comes from and returns to host memory is bound by PCIe, and int8 symbols are a quarter of its bytes.  symbol_bytes = 1, 2
+ * (signed two's complement) or 4; the narrow types are widened / narrowed on the device next to the coder call through
+ * d_scratch (cst_symbols_scratch_bytes(...) bytes, 0 for symbol_bytes = 4; contents irrelevant).  Words, counts and status are
+ * those of the int32 calls on the widened values; an encoder symbol outside the model's support is an impossible symbol as ever,
+ * a decoder whose model's support does not fit the type returns CST_ERR_INVALID_ARGUMENT.  The two conversions are exported on
+ * their own for the other coders (range, per-symbol, checkpointed calls take int32). */
+cst_status cst_symbols_widen(const void *d_in, int32_t symbol_bytes, size_t n, int32_t *d_out, void *stream);
+cst_status cst_symbols_narrow(const int32_t *d_in, size_t n, void *d_out, int32_t symbol_bytes, void *stream);
+size_t cst_symbols_scratch_bytes(size_t n_streams, size_t n_per_stream, int32_t symbol_bytes);
+cst_status cst_ans_encode_batch_sym(const cst_model *model, cst_coder_config cfg, const void *d_symbols, int32_t symbol_bytes,
+                                    size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                    size_t stride_words, uint32_t *d_n_words, uint64_t *d_state, int32_t *d_status,
+                                    uint32_t flags, void *d_scratch, void *stream);
+cst_status cst_ans_decode_batch_sym(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                    const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
+                                    const uint32_t *d_n_words, void *d_symbols, int32_t symbol_bytes, size_t n_streams,
+                                    size_t n_per_stream, cst_layout layout, uint64_t *d_state, uint32_t *d_n_words_out,
+                                    int32_t *d_status, uint32_t flags, void *d_scratch, void *stream);
+
 /* Streams of DIFFERENT lengths -- thousands of small coders with a shared model in one launch: the reference's "compressed
  * index" pattern (tests/issue52.rs:27-60, 63-80: one DefaultAnsCoder per document, `encode_symbol` per character last to
  * first, `into_compressed`; `from_compressed` + `decode_symbol` per document), which costs one device round trip per document

@@ -689,6 +689,7 @@ typedef struct {
     int32_t *status;             /* [n_streams] */
     size_t s_begin, s_end;
     int thread_index;            /* -1: the caller's own thread */
+    int32_t *sink;               /* decode diagnostics: write every stream's symbols HERE instead of into `decoded` */
 } batch_job_t;
 
 static void encode_one_stream(const batch_job_t *j, size_t s)
@@ -726,6 +727,7 @@ static void decode_one_stream(const batch_job_t *j, size_t s)
     const uint32_t *in = j->words + s * j->stride;
     size_t len = j->n_words[s];
     int32_t *y = j->decoded + s * j->n_per_stream;
+    if (j->sink) y = j->sink;                  /* (scaling diagnostics only: every stream of a thread into the same 16 KiB) */
     uint64_t st = 0;
     j->status[s] = 0;
     if (len > 0) {
@@ -749,7 +751,34 @@ static void decode_one_stream(const batch_job_t *j, size_t s)
 
 static void pin_self(int i);
 static void *encode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; pin_self(j->thread_index); for (size_t s = j->s_begin; s < j->s_end; s++) encode_one_stream(j, s); return NULL; }
-static void *decode_worker(void *arg) { batch_job_t *j = (batch_job_t *)arg; pin_self(j->thread_index); for (size_t s = j->s_begin; s < j->s_end; s++) decode_one_stream(j, s); return NULL; }
+static void *decode_worker(void *arg)
+{
+    batch_job_t *j = (batch_job_t *)arg;
+    pin_self(j->thread_index);
+    /* CST_ORACLE_DECODE_SINK=1 (scripts/cpu_scaling.py): the decoder WITHOUT its gigabyte of output -- what is left is the coder */
+    const char *e = getenv("CST_ORACLE_DECODE_SINK");
+    if (e && *e == '1') j->sink = (int32_t *)malloc(sizeof(int32_t) * (j->n_per_stream ? j->n_per_stream : 1));
+    for (size_t s = j->s_begin; s < j->s_end; s++) decode_one_stream(j, s);
+    if (j->sink) { free(j->sink); j->sink = NULL; }
+    return NULL;
+}
+
+/* the box's store bandwidth with the same threads and pinning: every thread fills its own block (scripts/cpu_scaling.py) */
+typedef struct { unsigned char *p; size_t n; int idx; } fill_job_t;
+static void *fill_worker(void *arg) { fill_job_t *f = (fill_job_t *)arg; pin_self(f->idx); memset(f->p, f->idx & 0xff, f->n); return NULL; }
+API void cst_oracle_fill_threads(unsigned char *dst, size_t bytes, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    fill_job_t *jobs = (fill_job_t *)malloc(sizeof(fill_job_t) * n_threads);
+    size_t per = (bytes / n_threads) & ~(size_t)4095;
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i].p = dst + (size_t)i * per; jobs[i].n = per; jobs[i].idx = n_threads == 1 ? -1 : i;
+        if (n_threads == 1) fill_worker(&jobs[i]); else pthread_create(&th[i], NULL, fill_worker, &jobs[i]);
+    }
+    if (n_threads > 1) for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(th); free(jobs);
+}
 
 /* CST_ORACLE_PIN=1 (bench.py's cpu_baseline leg): thread i stays on logical CPU i mod (online CPUs), so that a thread keeps the
  * pages it touched first on its own NUMA node and is not migrated in the middle of a timed pass. */

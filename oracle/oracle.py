@@ -99,6 +99,7 @@ def load(native: bool = False):
         "cst_oracle_ans_decode_from": (None, [i, i, i, u32p, z, u64, i32p, z, i32, i, u32p]),
         "cst_oracle_rc_jump_table": (None, [i, i, i, i32p, z, z, i32, i, u32p, z, u32p, u64p, u64p]),
         "cst_oracle_rc_decode_from": (i, [i, i, i, u32p, z, z, u64, u64, i32p, z, i32, i, u32p]),
+        "cst_oracle_fill_threads": (None, [vp, z, i]),
         # oracle_families.c
         "cst_oracle_log": (d, [d]),
         "cst_oracle_log1p": (d, [d]),
