@@ -264,7 +264,7 @@ def event_ms(fn, reps):
     return float(np.median([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
 
 
-def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major", stride=None):
+def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, lo=LO, layout="stream_major", stride=None, packed16=False):
     """One entry of the `configs` block: kernel times of encode and decode (HIP events), achieved fraction of the HBM
     roofline (algorithmic bytes 4 B / symbol + 4 B / word per direction), bit-exactness of every stream.
     layout "symbol_major": `symbols` is [n_per, n_streams]."""
@@ -272,7 +272,10 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     enc_fn = B.ans_encode if coder == "ans" else B.range_encode
     dec_fn = B.ans_decode if coder == "ans" else B.range_decode
     kw = {} if layout == "stream_major" else {"layout": layout}
-    enc = enc_fn(symbols, model, cfg, stride=stride, **kw)      # stride "tuned": batched.tuned_stride, like the headline batch
+    if packed16:       # CST_FLAG_PACKED_W16: two 16-bit words per slot (the stride tuner measures the unpacked form: default stride here)
+        enc = enc_fn(symbols, model, cfg, packed16=True)
+    else:
+        enc = enc_fn(symbols, model, cfg, stride=stride, **kw)      # stride "tuned": batched.tuned_stride, like the headline batch
     decoded = torch.empty_like(symbols)
     enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc, **kw), reps)
     dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded, **kw), reps)
@@ -656,6 +659,8 @@ def other_configs(B, rank, world, dist, args, reps=5):
                           layout="symbol_major")
         del symT
         add("C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
+        add("C2 with 16-bit words, PACKED two per slot as the reference's Vec<u16> (CST_FLAG_PACKED_W16)", "ans", (16, 32, 12), m12, sym12, reps, check,
+            cdf12, packed16=True)
         try:
             out.append(narrow_config(B, m12, sym12, reps, check))
         except Exception as exc:      # noqa: BLE001

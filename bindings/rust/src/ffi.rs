@@ -38,6 +38,7 @@ pub const CST_FAMILY_BINOMIAL: CstFamily = 3;
 pub const CST_FLAG_NONE: u32 = 0;
 pub const CST_FLAG_RAW_STATE: u32 = 1;
 pub const CST_FLAG_COLD_WORDS: u32 = 2;
+pub const CST_FLAG_PACKED_W16: u32 = 4;
 
 /// `cst_model`: opaque, device-resident model image
 #[repr(C)]
@@ -608,6 +609,21 @@ extern "C" {
         n_streams: usize,
         d_offsets: *mut u64,
         d_packed: *mut u32,
+        packed_capacity: usize,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// The same for slabs of PACKED 16-bit words (CST_FLAG_PACKED_W16): stride, counts, offsets and capacity in 16-bit words; the
+    /// packed buffer is the concatenation of every stream's Vec<u16>.  Two kernels (the scan of cst_compact_words + a halfword
+    /// gather), same scratch.
+    pub fn cst_compact_words16(
+        d_words16: *const u16,
+        stride_words: usize,
+        d_n_words: *const u32,
+        n_streams: usize,
+        d_offsets: *mut u64,
+        d_packed16: *mut u16,
         packed_capacity: usize,
         d_scratch: *mut c_void,
         stream: *mut c_void,

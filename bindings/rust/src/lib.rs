@@ -366,6 +366,41 @@ pub fn compact(encoded: EncodedBatch, stream: &Stream) -> Result<PackedBatch> {
     Ok(PackedBatch { words: packed, offsets, n_words: encoded.n_words, n_streams: n, config: encoded.config })
 }
 
+/// Slabs of PACKED 16-bit words (`CST_FLAG_PACKED_W16`: the `(16, 32)` preset with its words as the reference's `Vec<u16>`,
+/// src/stream/stack.rs:153): every count, stride and offset is in 16-bit words.
+pub struct EncodedBatch16 {
+    pub words: DeviceBuffer<u16>,
+    pub n_words: DeviceBuffer<u32>,
+    pub status: DeviceBuffer<i32>,
+    pub n_streams: usize,
+    pub stride_words: usize,
+    pub config: CoderConfig,
+}
+
+/// `EncodedBatch16` -> the concatenation of every stream's `Vec<u16>` plus `offsets[n_streams + 1]` (in 16-bit words).
+pub fn compact16(encoded: &EncodedBatch16, stream: &Stream) -> Result<(DeviceBuffer<u16>, DeviceBuffer<u64>)> {
+    let n = encoded.n_streams;
+    let capacity = n.checked_mul(encoded.stride_words).ok_or(Error::InvalidArgument)?;
+    let mut packed: DeviceBuffer<u16> = DeviceBuffer::new(capacity)?;
+    let mut offsets: DeviceBuffer<u64> = DeviceBuffer::new(n + 1)?;
+    let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_compact_scratch_bytes(n) })?;
+    check(unsafe {
+        ffi::cst_compact_words16(
+            encoded.words.as_ptr(),
+            encoded.stride_words,
+            encoded.n_words.as_ptr(),
+            n,
+            offsets.as_mut_ptr(),
+            packed.as_mut_ptr(),
+            capacity,
+            scratch.as_mut_ptr() as *mut c_void,
+            stream.as_raw(),
+        )
+    })?;
+    stream.synchronize()?; // (the scratch buffer is dropped on return)
+    Ok((packed, offsets))
+}
+
 /// Where a decoder finds the words of stream `s`.
 enum WordSource<'a> {
     Slabs(&'a EncodedBatch),
@@ -470,6 +505,78 @@ impl BatchedAnsCoder {
                 core::ptr::null_mut(),
                 out.status.as_mut_ptr(),
                 ffi::CST_FLAG_NONE,
+                stream.as_raw(),
+            )
+        })?;
+        Ok(out)
+    }
+
+    /// `SmallAnsCoder::encode_iid_symbols_reverse` + `into_compressed()` with the words PACKED as the reference holds them -- a
+    /// `Vec<u16>` per stream (src/stream/stack.rs:153), two words per 32-bit slot (`CST_FLAG_PACKED_W16`; `self.config` must be
+    /// the `(16, 32)` preset).  Half the word bytes of the unpacked form cross HBM.
+    pub fn encode_iid_symbols_reverse_packed16(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        n_streams: usize,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<EncodedBatch16> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if symbols.len() < count || self.config.word_bits != 16 {
+            return Err(Error::InvalidArgument);
+        }
+        let stride = self.max_words(n_per_stream);
+        let mut out = EncodedBatch16 {
+            words: DeviceBuffer::new(n_streams.checked_mul(stride).ok_or(Error::InvalidArgument)?)?,
+            n_words: DeviceBuffer::new(n_streams)?,
+            status: DeviceBuffer::new(n_streams)?,
+            n_streams,
+            stride_words: stride,
+            config: self.config,
+        };
+        check(unsafe {
+            ffi::cst_ans_encode_batch(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr() as *mut u32,
+                stride,
+                out.n_words.as_mut_ptr(),
+                core::ptr::null_mut(),
+                out.status.as_mut_ptr(),
+                ffi::CST_FLAG_PACKED_W16,
+                stream.as_raw(),
+            )
+        })?;
+        Ok(out)
+    }
+
+    /// The decoder of `encode_iid_symbols_reverse_packed16`.
+    pub fn decode_iid_symbols_packed16(&self, encoded: &EncodedBatch16, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
+        let n_streams = encoded.n_streams;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_streams)? };
+        check(unsafe {
+            ffi::cst_ans_decode_batch(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr() as *const u32,
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                out.symbols.as_mut_ptr(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                core::ptr::null_mut(),
+                core::ptr::null_mut(),
+                out.status.as_mut_ptr(),
+                ffi::CST_FLAG_PACKED_W16,
                 stream.as_raw(),
             )
         })?;

@@ -31,6 +31,7 @@ FAMILY_LAPLACE, FAMILY_CAUCHY, FAMILY_BINOMIAL = 1, 2, 3
 FLAG_NONE = 0
 FLAG_RAW_STATE = 1
 FLAG_COLD_WORDS = 2
+FLAG_PACKED_W16 = 4
 
 
 class BackendUnavailable(RuntimeError):
@@ -79,6 +80,7 @@ SIGNATURES = {
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
     "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
+    "cst_compact_words16": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
     "cst_symbols_widen": (_i32, [_vp, _i32, _z, _vp, _vp]),
     "cst_symbols_narrow": (_i32, [_vp, _z, _vp, _i32, _vp]),
     "cst_symbols_scratch_bytes": (_z, [_z, _z, _i32]),

@@ -203,12 +203,18 @@ class EncodedBatch:
     def total_words(self) -> int:
         return int(self.n_words.to(torch.int64).sum().item())
 
+    @property
+    def packed16(self) -> bool:
+        """(16,32) words two per 32-bit slot, as the reference's Vec<u16> (CST_FLAG_PACKED_W16): `words` is an int16 tensor and
+        every count, stride and offset is in 16-bit words"""
+        return self.words.dtype == torch.int16
+
     def stream(self, s: int) -> np.ndarray:
         n = int(self.n_words[s].item())
-        return self.words[s, :n].cpu().numpy().view(np.uint32)
+        return self.words[s, :n].cpu().numpy().view(np.uint16 if self.packed16 else np.uint32)
 
     def to_numpy(self):
-        return (self.words.cpu().numpy().view(np.uint32), self.n_words.cpu().numpy().view(np.uint32),
+        return (self.words.cpu().numpy().view(np.uint16 if self.packed16 else np.uint32), self.n_words.cpu().numpy().view(np.uint32),
                 self.status.cpu().numpy())
 
 
@@ -234,7 +240,7 @@ def _words_are_cold(encoded) -> bool:
     fresh = getattr(encoded, "_fresh", None)
     if fresh is None or fresh[0] != torch.cuda.current_stream().cuda_stream or _last_encode.get(fresh[0]) != fresh[1]:
         return True
-    return int(encoded.n_words.numel()) * int(encoded.words.shape[1]) * 4 > 3 * _INFINITY_CACHE_BYTES   # (slabs are ~1/3 used)
+    return int(encoded.n_words.numel()) * int(encoded.words.shape[1]) * encoded.words.element_size() > 3 * _INFINITY_CACHE_BYTES   # (slabs are ~1/3 used)
 
 
 def last_kernel() -> str:
@@ -340,9 +346,11 @@ def _layout_shape(symbols: torch.Tensor, layout: str):
 
 
 def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-               stride=None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+               stride=None, out: Optional[EncodedBatch] = None, packed16: bool = False) -> EncodedBatch:
     """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895).
-    stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride)."""
+    stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride).
+    packed16 (the (16,32) preset only): the words two per 32-bit slot, as the reference's Vec<u16> (CST_FLAG_PACKED_W16) -- the
+    batch's `words` is then an int16 tensor; ans_decode and compact recognise it."""
     if isinstance(stride, str):
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
@@ -360,18 +368,19 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
     if out is None:
         stride = stride or max_words(n_per, config)
         dev = symbols.device
-        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int16 if packed16 else torch.int32, device=dev),
                            torch.empty(n_streams, dtype=torch.int32, device=dev),
                            torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+    flags = N.FLAG_PACKED_W16 if out.packed16 else N.FLAG_NONE
     if narrow != 4:
         L = N.lib()
         scratch = _ckpt_scratch(("widen", torch.cuda.current_stream().cuda_stream), symbols.device, L.cst_symbols_scratch_bytes(n_streams, n_per, narrow))
         N.check(L.cst_ans_encode_batch_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words),
-                                           out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE, _ptr(scratch),
+                                           out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags, _ptr(scratch),
                                            _stream_ptr()), "cst_ans_encode_batch_sym")
     else:
         N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
-                                             out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
+                                             out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags,
                                              _stream_ptr()), "cst_ans_encode_batch")
     _stamp_fresh(out)
     return out
@@ -435,6 +444,7 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     narrow = _SYMBOL_BYTES.get(out.dtype)
     if narrow is None:
         raise TypeError("decoded symbols are int32, int16 or int8")
+    flags = (N.FLAG_COLD_WORDS if cold else N.FLAG_NONE) | (N.FLAG_PACKED_W16 if words.dtype == torch.int16 else N.FLAG_NONE)
     if narrow != 4:
         if model.noncontiguous:
             raise ValueError("narrow symbol matrices: contiguous alphabets only")
@@ -442,11 +452,11 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
         scratch = _ckpt_scratch(("narrow", torch.cuda.current_stream().cuda_stream), dev, L.cst_symbols_scratch_bytes(n_streams, n_per_stream, narrow))
         N.check(L.cst_ans_decode_batch_sym(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                            _ptr(out), narrow, n_streams, n_per_stream, lay, None, None, _ptr(status),
-                                           N.FLAG_COLD_WORDS if cold else N.FLAG_NONE, _ptr(scratch), _stream_ptr()), "cst_ans_decode_batch_sym")
+                                           flags, _ptr(scratch), _stream_ptr()), "cst_ans_decode_batch_sym")
         return out, status
     N.check(N.lib().cst_ans_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                          _ptr(out), n_streams, n_per_stream, lay, None, None, _ptr(status),
-                                         N.FLAG_COLD_WORDS if cold else N.FLAG_NONE, _stream_ptr()), "cst_ans_decode_batch")
+                                         flags, _stream_ptr()), "cst_ans_decode_batch")
     return _to_symbols(model, out), status
 
 
@@ -610,11 +620,12 @@ def compact(encoded: EncodedBatch, capacity: Optional[int] = None, out=None):
         packed, offsets = out
     else:
         capacity = capacity if capacity is not None else n_streams * encoded.words.shape[1]
-        packed = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+        packed = torch.empty(max(capacity, 1), dtype=encoded.words.dtype, device=dev)
         offsets = torch.empty(n_streams + 1, dtype=torch.int64, device=dev)
-    N.check(N.lib().cst_compact_words(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
-                                      _ptr(offsets), _ptr(packed), packed.numel(), _ptr(_compact_scratch(dev, n_streams)),
-                                      _stream_ptr()), "cst_compact_words")
+    fn = N.lib().cst_compact_words16 if encoded.packed16 else N.lib().cst_compact_words       # (packed 16-bit words: everything in halfwords)
+    N.check(fn(_ptr(encoded.words), encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
+               _ptr(offsets), _ptr(packed), packed.numel(), _ptr(_compact_scratch(dev, n_streams)),
+               _stream_ptr()), "cst_compact_words")
     if (out is not None or capacity is not None) and int(offsets[-1].item()) > packed.numel():
         raise ValueError(f"compact: {int(offsets[-1].item())} words do not fit the packed buffer of {packed.numel()} words")
     return packed, offsets

@@ -265,6 +265,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_PACKED_W16) && (generic_config(cfg) || model->per_stream)) return CST_ERR_INVALID_ARGUMENT;
     if (generic_config(cfg))       // the rest of the reference's type grid (stack.rs:1293-1356): one compiler-scheduled kernel
         return note_kernel("ans_encode_generic_kernel", ans_encode_generic(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words,
                                                                             d_n_words, d_state, d_status, flags, (hipStream_t)stream));
@@ -280,6 +281,10 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.status = d_status;
     a.flags = flags;
     hipStream_t hs = (hipStream_t)stream;
+    if (flags & CST_FLAG_PACKED_W16) {     // the reference's Vec<u16>: two words per slot, every count in 16-bit words
+        if (!w16pk_usable(model, cfg, layout) || (flags & CST_FLAG_RAW_STATE)) return CST_ERR_INVALID_ARGUMENT;
+        return note_kernel("ans_encode_w16pk_kernel", ans_encode_w16pk(a, hs));
+    }
     if (small_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_small_kernel", ans_encode_small(a, hs));   // more than one wave per SIMD
     if (pc_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_pc_kernel", ans_encode_pc(a, hs));           // one wave per SIMD: coder + helper waves
     if (w16_encode_usable(a, cfg, layout)) return note_kernel("ans_encode_w16_kernel", ans_encode_w16(a, layout, hs));               // SmallAnsCoder preset
@@ -299,6 +304,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     if ((flags & CST_FLAG_RAW_STATE) && !d_state) return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    if ((flags & CST_FLAG_PACKED_W16) && (generic_config(cfg) || model->per_stream)) return CST_ERR_INVALID_ARGUMENT;
     if (generic_config(cfg))
         return note_kernel("ans_decode_generic_kernel", ans_decode_generic(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols,
                                                                             n_streams, n_per_stream, layout, d_state, d_n_words_out, d_status, flags, (hipStream_t)stream));
@@ -315,6 +321,10 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
     hipStream_t hs = (hipStream_t)stream;
+    if (flags & CST_FLAG_PACKED_W16) {
+        if (!w16pk_usable(model, cfg, layout)) return CST_ERR_INVALID_ARGUMENT;
+        return note_kernel("ans_decode_w16pk_kernel", ans_decode_w16pk(a, hs));
+    }
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_decode_small_kernel", ans_decode_small(a, hs));   // more than one wave per SIMD
     if (b16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_b16_kernel", ans_decode_b16(a, layout, hs));               // 12 < P <= 24
     if (w16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_w16_kernel", ans_decode_w16(a, layout, hs));               // SmallAnsCoder preset

@@ -191,6 +191,13 @@ cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, co
                              size_t words_capacity, size_t interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
                              int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs);
 
+// (16,32) with packed words (CST_FLAG_PACKED_W16, cst_ans_w16pk.hip): two 16-bit words per 32-bit slot, every count in 16-bit words
+struct AnsEncodeArgs;
+struct AnsDecodeArgs;
+bool w16pk_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout);
+cst_status ans_encode_w16pk(const AnsEncodeArgs& a, hipStream_t hs);
+cst_status ans_decode_w16pk(const AnsDecodeArgs& a, hipStream_t hs);
+
 // Where stream s's compressed words lie in the caller's buffer -- CHECKED.  The reference's decoder cannot read out of
 // bounds (its backend is a Vec: src/backends.rs:495-507); here the counts and offsets are caller data, so a slice
 // [off, off + n) that leaves the buffer of `capacity` words (0 = capacity unknown, the caller vouches) or, in slab form,

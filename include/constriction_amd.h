@@ -82,6 +82,14 @@ typedef struct cst_coder_config {
  * words that come from HBM, 7 % slower on cache-resident ones at a well-chosen slab stride.  Other kernels
  * ignore it. */
 #define CST_FLAG_COLD_WORDS 2u
+/* ABI 4, the (16,32) preset only (SmallAnsCoder, src/stream/stack.rs:153: the reference holds its words in a Vec<u16>): the
+ * compressed words are PACKED, two per uint32 slot -- d_words is an array of uint16_t (little endian, exactly the bytes of the
+ * reference's Vec<u16>), and stride_words, d_n_words, d_offsets, words_capacity all count 16-bit words.  Without the flag every
+ * word of this preset occupies a uint32 slot (low half), which doubles the word bytes the kernels move.  cst_ans_encode_batch
+ * and cst_ans_decode_batch take it for shared-table models, stream-major symbols, 8 <= precision <= 12 (anything else:
+ * CST_ERR_INVALID_ARGUMENT); the slabs pack with cst_compact_words16.  The fast path wants 64-byte aligned slabs
+ * (stride_words a multiple of 32: cst_ans_max_words rounds to that). */
+#define CST_FLAG_PACKED_W16 4u
 
 /* ------------------------------------------------------------------------------------------
  * library / device
@@ -392,6 +400,12 @@ size_t cst_compact_scratch_bytes(size_t n_streams);
 cst_status cst_compact_words(const uint32_t *d_words, size_t stride_words, const uint32_t *d_n_words,
                              size_t n_streams, uint64_t *d_offsets, uint32_t *d_packed,
                              size_t packed_capacity, void *d_scratch, void *stream);
+/* The same for slabs of PACKED 16-bit words (CST_FLAG_PACKED_W16): stride, counts, offsets and capacity in 16-bit words; the
+ * packed buffer is the concatenation of every stream's Vec<u16>.  Two kernels (the scan of cst_compact_words + a halfword
+ * gather), same scratch. */
+cst_status cst_compact_words16(const uint16_t *d_words16, size_t stride_words, const uint32_t *d_n_words,
+                               size_t n_streams, uint64_t *d_offsets, uint16_t *d_packed16,
+                               size_t packed_capacity, void *d_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * multi-GPU: gather of the packed compressed words of every rank to one root over RCCL / xGMI (BASELINE config C5).

@@ -15,16 +15,24 @@ values ([position][lane] halfwords, 8 KiB per wave as before), written by four d
 
 Run:  python scripts/gen_decode_loop_w16.py   (rewrites the .inc; the .inc is checked in)
 """
+import os
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop_w16.inc"
+# GEN_W16_PACKED=1 (round 5, CST_FLAG_PACKED_W16): two words per 32-bit slot in HBM, as the reference's Vec<u16> (stack.rs:153).
+# A 16-byte chunk then carries EIGHT words: half as many chunk loads per symbol -- the loads were what this decoder waited for
+# (SQ_WAIT_INST_ANY 55 - 60 cycles per symbol).  Two chunk slots per half tile instead of three, lo_issued moves by 8, the byte
+# offset of a chunk is 2 lo_issued, and a chunk lands with eight ds_write_b16 (low halves with ds_write_b16, high halves with
+# ds_write_b16_d16_hi).  Written to cst_decode_loop_w16_pk.inc (stream-major).
+PACKED = bool(os.environ.get("GEN_W16_PACKED"))
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / ("cst_decode_loop_w16_pk.inc" if PACKED else "cst_decode_loop_w16.inc")
 
-K_CHUNKS = 3          # window chunks requested per HALF tile (16 symbols * 12 bits = 12 words = 3 chunks)
-AHEAD_M1 = 39         # kW16Ahead - 1: 12 words of this half, 24 of the two halves until the chunks have landed, + a chunk
+CHUNK = 8 if PACKED else 4     # words per 16-byte chunk
+K_CHUNKS = 2 if PACKED else 3  # window chunks requested per HALF tile (16 symbols * 12 bits = 12 words)
+AHEAD_M1 = 43 if PACKED else 39    # kW16Ahead - 1: 12 words of this half, 24 of the two halves until the chunks have landed, + a chunk
 
 
 def tup(base, n=4):
@@ -54,12 +62,12 @@ def gen():
         a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kW16Ahead, 0)")
         for k in range(K_CHUNKS):
             a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"set {st}, chunk slot {k}: needed?")
-            a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+            a.i(f"v_cndmask_b32_e64 {TMP}, 0, {CHUNK}, vcc")
             a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
             a.i(f"v_lshlrev_b32 {TADDR}, 7, %[lo_issued]")
             a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
             a.i(f"v_cndmask_b32 {LAND[st][k]}, %[dump], {TADDR}, vcc", "landing address: ring position or the dump rows")
-            a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
+            a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], {1 if PACKED else 2}, %[woff]")
             a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
             a.vmem(f"global_load_dwordx4 {PEND[st][k][0]}, {TOFF}, %[wbase]", f"chunk{st}{k}")
             a.i(f"s_mov_b64 exec, {SAVE}")
@@ -69,7 +77,11 @@ def gen():
         a.wait_vm(f"chunk{st}{K_CHUNKS - 1}", f"set {st} was requested a tile ago")
         for k in range(K_CHUNKS):
             for i, r in enumerate(PEND[st][k][1]):
-                a.ds(f"ds_write_b16 {LAND[st][k]}, {r} offset:{128 * i}", "land")
+                if PACKED:
+                    a.ds(f"ds_write_b16 {LAND[st][k]}, {r} offset:{256 * i}", "land")
+                    a.ds(f"ds_write_b16_d16_hi {LAND[st][k]}, {r} offset:{256 * i + 128}", "land")
+                else:
+                    a.ds(f"ds_write_b16 {LAND[st][k]}, {r} offset:{128 * i}", "land")
 
     def lookup(sym_reg):
         a.i(f"v_and_b32 {Q}, %[mask], %[st]", "quantile")
@@ -153,7 +165,7 @@ def gen():
 
 def main():
     global SYMBOL_MAJOR
-    for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
+    for SYMBOL_MAJOR, out in (((False, OUT),) if PACKED else ((False, OUT), (True, OUT_SM))):
         emit(out)
     SYMBOL_MAJOR = False
 

@@ -14,6 +14,7 @@ stay zero without masking the word.
 
 Run:  python scripts/gen_encode_loop_w16.py   (rewrites the .inc; the .inc is checked in)
 """
+import os
 import sys
 from pathlib import Path
 
@@ -21,7 +22,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import gen_encode_loop as G  # noqa: E402
 from asmgen import Asm  # noqa: E402
 
-OUT = G.CSRC / "cst_encode_loop_w16.inc"
+# GEN_W16_PACKED=1 (round 5, CST_FLAG_PACKED_W16): the slab holds the words as the reference does -- a Vec<u16>, two words per
+# 32-bit slot (stack.rs:153) -- so a 64-byte group is THIRTY-TWO words and at most one leaves per tile (32 symbols emit at most
+# 24).  The ring keeps one word per 32-bit slot (upper halves zero: ds_write_b16 into a zeroed ring); the flush reads eight
+# 4-word chunks per group (quads 7, 6 and 4, 3 as before), packs pairs with v_lshl_or_b32 (16 VALU per group: 0.4 per symbol)
+# and stores 32 bytes at quad 5 and 32 at quad 2.  A chunk read late is never overwritten: word flushed + 4 c is written again
+# when wr reaches flushed + 64 + 4 c, and wr - flushed stays below 55 + 12.  Written to cst_encode_loop_w16_pk.inc.
+PACKED = bool(os.environ.get("GEN_W16_PACKED"))
+OUT = G.CSRC / ("cst_encode_loop_w16_pk.inc" if PACKED else "cst_encode_loop_w16.inc")
 A_, SH, QE, R_, T_, CKS = (f"v{r}" for r in range(212, 218))
 RA, NCH, LIM, FADDR, FOFF, FD, SAVE = G.RA, G.NCH, G.LIM, G.FADDR, G.FOFF, G.FD, G.SAVE
 
@@ -41,6 +49,44 @@ def step(a, e0, e1, e2, e3):
     a.i(f"v_lshl_add_u32 {T_}, {QE}, %[P], {R_}", "(q_est << P) + r_est")
     a.i(f"v_cndmask_b32_sdwa {CKS}, {e0}, {e0}, vcc {G.SDWA} src0_sel:WORD_0 src1_sel:WORD_1", "c, or c + 2^P - p")
     a.i(f"v_add_u32 %[st], {T_}, {CKS}")
+
+
+def packed_reads(a, ks, decide):
+    """chunks `ks` (4 words each, two per quad) of the 32-word group at `flushed`"""
+    if decide:
+        a.i(f"v_sub_u32 {NCH}, %[wr], %[flushed]")
+        a.i(f"v_lshrrev_b32 {NCH}, 5, {NCH}")
+        a.i(f"v_min_u32 {NCH}, 1, {NCH}", "whole 32-word groups to move now: 0 or 1")
+    for k in ks:
+        a.i(f"v_add_lshl_u32 {FADDR}, %[flushed], {4 * k}, 8")
+        a.i(f"v_and_or_b32 {FADDR}, {FADDR}, %[c3f00], %[lanebase]")
+        a.ds(f"ds_read2st64_b32 {FD[k % 4][0]}, {FADDR} offset1:1", "fl")
+        a.ds(f"ds_read2st64_b32 {FD[k % 4][1]}, {FADDR} offset0:2 offset1:3", "fl")
+
+
+def packed_store(a, second):
+    """16 words in FD (four chunks of four) -> eight dwords -> two 16-byte stores at byte 0 / 32 of the group"""
+    if not second:
+        a.i(f"v_add_u32 {LIM}, 32, %[flushed]")
+        a.i(f"v_lshl_add_u32 {FOFF}, %[flushed], 1, %[slaboff]", "(two bytes per word)")
+        a.i(f"v_cmp_le_u32 vcc, {LIM}, %[cap]", "group inside the slab (cap % 32 == 0 on this path)")
+        a.i(f"v_cmp_ne_u32 {SAVE}, 0, {NCH}")
+        a.i(f"s_and_b64 {MASK}, vcc, {SAVE}")
+    a.wait_lds("fl", cap=True)
+    for pair in range(2):
+        b = 230 + 8 * pair                   # chunks 2 pair and 2 pair + 1 sit in v[b : b + 7]
+        for j in range(4):
+            a.i(f"v_lshl_or_b32 v{b + j}, v{b + 2 * j + 1}, 16, v{b + 2 * j}", "two words per slot" if pair == 0 and j == 0 else None)
+    a.i(f"s_mov_b64 {SAVE}, exec")
+    a.i(f"s_mov_b64 exec, {MASK}")
+    for pair in range(2):
+        a.vmem(f"global_store_dwordx4 {FOFF}, v[{230 + 8 * pair}:{233 + 8 * pair}], %[wbase] offset:{32 * int(second) + 16 * pair}", "st")
+    a.i(f"s_mov_b64 exec, {SAVE}")
+    if second:
+        a.i(f"v_lshl_add_u32 %[flushed], {NCH}, 5, %[flushed]")
+
+
+MASK = "s[90:91]"
 
 
 def group_reads(a, ks, decide):
@@ -83,7 +129,9 @@ def half(a, h, g0):
         G.fetch_entries(a, g + 1)
         if f"E{g}" in a.lds:
             a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
-        if quad in (7, 6, 4, 3):
+        if quad in (7, 6, 4, 3) and PACKED:
+            packed_reads(a, {7: (0, 1), 6: (2, 3), 4: (4, 5), 3: (6, 7)}[quad], quad == 7)
+        elif quad in (7, 6, 4, 3):
             # two 64-byte word groups may leave per tile: decided at quads 7 and 4 (12 and 20 symbols apart: at most 9 and
             # 15 words are produced in between)
             group_reads(a, (0, 1) if quad in (7, 4) else (2, 3), quad in (7, 4))
@@ -91,11 +139,11 @@ def half(a, h, g0):
         for e in G.E[g % 2]:
             step(a, *e)
         if quad == 5:
-            group_store(a)
+            packed_store(a, False) if PACKED else group_store(a)
         if quad == 2:
             # second word group -> slab; next tile's symbols -> the other tile buffer; request tile - 3 into the freed
             # registers (every store of a tile is issued before its loads)
-            group_store(a)
+            packed_store(a, True) if PACKED else group_store(a)
             a.wait_lds(f"E{g + 1}", "(early: keeps the eight tile writes below within lgkmcnt's range of 15)")
             G.stage_set(a, other, 1 - h)
             G.load_set(a, other)
@@ -141,7 +189,8 @@ OUT_SM = OUT.with_name("cst_encode_loop_w16_sm.inc")
 
 def main():
     emit(OUT, False)
-    emit(OUT_SM, True)              # symbols[t][stream]: gen_encode_loop.py's SYMBOL_MAJOR staging
+    if not PACKED:
+        emit(OUT_SM, True)          # symbols[t][stream]: gen_encode_loop.py's SYMBOL_MAJOR staging
 
 
 def emit(out, symbol_major):

@@ -11,9 +11,9 @@ ROOT = Path(__file__).resolve().parents[1]
 HEADER = ROOT / "include" / "constriction_amd.h"
 OUT = ROOT / "bindings" / "rust" / "src" / "ffi.rs"
 
-SCALARS = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "size_t": "usize", "double": "f64",
+SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint16_t": "u16", "int64_t": "i64", "uint64_t": "u64", "size_t": "usize", "double": "f64",
            "cst_status": "CstStatus", "cst_layout": "CstLayout", "cst_coder_config": "CstCoderConfig"}
-POINTEES = {"void": "c_void", "char": "c_char", "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "double": "f64",
+POINTEES = {"void": "c_void", "char": "c_char", "int32_t": "i32", "uint32_t": "u32", "uint16_t": "u16", "int64_t": "i64", "uint64_t": "u64", "double": "f64",
             "cst_model": "CstModel", "cst_range_state": "CstRangeState", "cst_chain_heads": "CstChainHeads"}
 STRUCT_NAMES = {"cst_coder_config": "CstCoderConfig", "cst_range_state": "CstRangeState", "cst_chain_heads": "CstChainHeads"}
 ENUM_ALIASES = {"cst_status": "CstStatus", "cst_stream_status": "CstStreamStatus", "cst_layout": "CstLayout", "cst_family": "CstFamily"}

@@ -181,6 +181,16 @@ def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):
         assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
 
 
+def test_packed_w16_loops_are_in_sync(tmp_path, monkeypatch):
+    """CST_FLAG_PACKED_W16: the (16,32) loops with two words per slot (GEN_W16_PACKED)"""
+    csrc = ROOT / "constriction_amd" / "csrc"
+    for var in ("GEN_NO_LGKM", "GEN_NO_VMWAIT"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("GEN_W16_PACKED", "1")
+    assert _regenerate(_load("gen_decode_loop_w16"), tmp_path, "cst_decode_loop_w16_pk.inc") == (csrc / "cst_decode_loop_w16_pk.inc").read_text()
+    assert _regenerate(_load("gen_encode_loop_w16"), tmp_path, "cst_encode_loop_w16_pk.inc") == (csrc / "cst_encode_loop_w16_pk.inc").read_text()
+
+
 def test_every_loop_head_is_pinned_to_a_cache_line():
     """code placement is worth +-10 % on these loops (profiles/r04_placement.txt): every generated statement carries
     `.p2align 6` directly in front of its loop head, so that an edit upstream of a loop cannot move it (asmgen.py)"""
