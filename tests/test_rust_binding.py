@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[1]
 HEADER = ROOT / "include" / "constriction_amd.h"
 RUST = ROOT / "bindings" / "rust"
 
-RUST_TO_C = {"i32": "int32_t", "u32": "uint32_t", "i64": "int64_t", "u64": "uint64_t", "usize": "size_t", "f64": "double",
+RUST_TO_C = {"i32": "int32_t", "u32": "uint32_t", "u16": "uint16_t", "i64": "int64_t", "u64": "uint64_t", "usize": "size_t", "f64": "double",
              "c_void": "void", "c_char": "char", "CstModel": "cst_model", "CstRangeState": "cst_range_state",
              "CstChainHeads": "cst_chain_heads", "CstCoderConfig": "cst_coder_config", "CstStatus": "cst_status", "CstLayout": "cst_layout"}
 
