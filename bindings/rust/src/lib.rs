@@ -703,6 +703,96 @@ impl BatchedAnsCoder {
         Ok(out)
     }
 
+    /// `encode_symbols_reverse` + `pos()` in front of every chunk of `interval` symbols (a multiple of 16 that divides the row
+    /// length; batches of at least 16 384 streams): the jump table of the reference's flagship call.
+    pub fn encode_symbols_reverse_with_checkpoints(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        support: RangeInclusive<i32>,
+        means: &DeviceBuffer<f64>,
+        stds: &DeviceBuffer<f64>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch, Checkpoints)> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if interval == 0 || symbols.len() < count || means.len() < count || stds.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_points = n_streams.checked_mul((n_per_stream + interval - 1) / interval).ok_or(Error::InvalidArgument)?;
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut ckpt = Checkpoints { pos: DeviceBuffer::new(n_points)?, state: DeviceBuffer::new(n_points)?, interval };
+        check(unsafe {
+            ffi::cst_ans_encode_gaussian_batch_ckpt(
+                self.config,
+                *support.start(),
+                *support.end(),
+                symbols.as_ptr(),
+                means.as_ptr(),
+                stds.as_ptr(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.state.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        Ok((out, ckpt))
+    }
+
+    /// `seek(pos, state)` + `decode_symbols` of one chunk's models, for every chunk at once: two resident waves per SIMD where
+    /// the plain per-symbol decoder of a 65 536-stream batch has one.
+    pub fn decode_symbols_from_checkpoints(
+        &self,
+        encoded: &EncodedBatch,
+        checkpoints: &Checkpoints,
+        support: RangeInclusive<i32>,
+        means: &DeviceBuffer<f64>,
+        stds: &DeviceBuffer<f64>,
+        n_per_stream: usize,
+        stream: &Stream,
+    ) -> Result<DecodedBatch> {
+        let n_streams = encoded.n_streams;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if checkpoints.interval == 0 || means.len() < count || stds.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_points = n_streams.checked_mul((n_per_stream + checkpoints.interval - 1) / checkpoints.interval).ok_or(Error::InvalidArgument)?;
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_points)? };
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
+        check(unsafe {
+            ffi::cst_ans_decode_gaussian_batch_ckpt(
+                self.config,
+                *support.start(),
+                *support.end(),
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                checkpoints.interval,
+                checkpoints.pos.as_ptr(),
+                checkpoints.state.as_ptr(),
+                means.as_ptr(),
+                stds.as_ptr(),
+                out.symbols.as_mut_ptr(),
+                n_streams,
+                n_per_stream,
+                scratch.as_mut_ptr() as *mut c_void,
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(out)
+    }
+
     /// `encode_symbols_reverse` with the models given as `(left_cumulative, probability)` per symbol (any family).
     pub fn encode_symbols_reverse_with_cp(
         &self,

@@ -937,3 +937,50 @@ def range_decode_checkpointed(encoded: EncodedBatch, checkpoints: RangeCheckpoin
                                           _ptr(checkpoints.lower), _ptr(checkpoints.range), _ptr(out), n_streams, n_per_stream,
                                           _ptr(scratch), _ptr(status), _stream_ptr()), "cst_range_decode_batch_ckpt")
     return _to_symbols(model, out), status
+
+
+def ans_encode_gaussian_checkpointed(symbols, min_symbol, max_symbol, means, stds, interval: int, config=(32, 64, 24),
+                                     stride: Optional[int] = None, out=None):
+    """ans_encode_gaussian + a jump point in front of every `interval` symbols (a multiple of 16 that divides the row length;
+    batches of at least 16 384 streams, stream-major).  Returns (EncodedBatch, Checkpoints); the words are ans_encode_gaussian's."""
+    symbols = _require_cuda(symbols, torch.int32, "symbols")
+    n_streams, n_per, lay = _layout_shape(symbols, "stream_major")
+    means, stds = _gaussian_args(symbols.shape, means, stds)
+    dev = symbols.device
+    n_chunks = (n_per + interval - 1) // interval
+    if out is not None:
+        out, ck = out
+    else:
+        stride = stride or max_words(n_per, config)
+        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev),
+                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+        ck = Checkpoints(int(interval), torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
+                         torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
+    N.check(N.lib().cst_ans_encode_gaussian_batch_ckpt(_cfg(*config), int(min_symbol), int(max_symbol), _ptr(symbols), _ptr(means), _ptr(stds),
+                                                       n_streams, n_per, lay, _ptr(out.words), out.words.shape[1], _ptr(out.n_words),
+                                                       int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status), _stream_ptr()),
+            "cst_ans_encode_gaussian_batch_ckpt")
+    return out, ck
+
+
+def ans_decode_gaussian_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, min_symbol, max_symbol, means, stds, out=None, status=None):
+    """Every chunk on its own lane: AnsCoder.seek(pos, state) + decode(QuantizedGaussian(min, max), means[chunk], stds[chunk]).
+    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
+    if means.dim() != 2:
+        raise ValueError("means must be 2-d")
+    n_streams, n_per = means.shape
+    means, stds = _gaussian_args(means.shape, means, stds)
+    dev = encoded.words.device
+    n_chunks = checkpoints.pos.shape[1]
+    if out is None:
+        out = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
+    L = N.lib()
+    scratch = _ckpt_scratch("ans_ckpt", dev, L.cst_ckpt_scratch_bytes(n_streams, n_per, checkpoints.interval))
+    N.check(L.cst_ans_decode_gaussian_batch_ckpt(_cfg(*encoded.config), int(min_symbol), int(max_symbol), _ptr(encoded.words), None,
+                                                 encoded.words.shape[1], encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos),
+                                                 _ptr(checkpoints.state), _ptr(means), _ptr(stds), _ptr(out), n_streams, n_per, _ptr(scratch),
+                                                 _ptr(status), _stream_ptr()), "cst_ans_decode_gaussian_batch_ckpt")
+    return out, status

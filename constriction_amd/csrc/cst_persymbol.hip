@@ -293,6 +293,10 @@ struct GaussianFusedArgs {
     cst_range_state* rstate;
     int32_t* status;
     uint32_t flags;
+    // ANS jump points (Pos, stack.rs:1130-1139), [n_streams][n_chunks], noted where a chunk of `interval` symbols starts; or null
+    uint32_t* ckpt_pos;
+    uint64_t* ckpt_state;
+    size_t interval, n_chunks;
 };
 
 // floor(2^64 / p) for 2 <= p <= 2^24 through two f64 quotients, each corrected by its exact remainder:
@@ -500,6 +504,13 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
                     if (e.p == 0) bad = 1;
                     else if (!bad) LR.step(e.c, e.p, P);
                 }
+            }
+        }
+        if constexpr (KIND == kAns) {
+            // AnsCoder::pos() in front of a chunk: the symbols from t0 on are encoded (chunks are whole tiles: the launcher checks)
+            if (a.ckpt_pos && active && t0 % a.interval == 0) {
+                a.ckpt_pos[s * a.n_chunks + t0 / a.interval] = LA.out.wr;
+                a.ckpt_state[s * a.n_chunks + t0 / a.interval] = (uint64_t)LA.state;
             }
         }
         // at most kFuTile new words per stream and tile: whole chunks leave here (<= 19 pending before, < 4 after)
@@ -836,14 +847,45 @@ __device__ __noinline__ void store_symbol_tile(int32_t* sym, size_t n_streams, s
 // from HBM is requested ONE TILE (16 symbols ~ 40 000 cycles of model search) before it is used, with coalesced loads
 // where the layout allows: per-lane loads issued a symbol ahead exposed ~2300 cycles of latency per symbol (half the
 // kernel's time: rocprofv3 SQ_WAIT_ANY), because a wave-wide load of 64 different cache lines takes longer than a symbol.
-constexpr int kParTile = 16;
 constexpr int kParStride = kWave + 1;                 // doubles per tile row: conflict-free writes (stream-major) and reads
-constexpr int kWordWindow = 32;                       // slots per stream, position p lives in slot p % 32
-constexpr size_t kLaneDecWaveBytes = (size_t)kWave * kTileStride * 4 + 2 * (size_t)kParTile * kParStride * 8 + (size_t)kWordWindow * kWave * 4;
-constexpr size_t kLaneDecLdsBytes = kErfTabBytes + (size_t)(kBlock / kWave) * kLaneDecWaveBytes;
+// Two geometries (round 5).  BIG: parameter tiles of 16 symbols, a 32-slot word window, a 32-symbol output tile -- 34 KiB of LDS per
+// wave, four waves per CU: right while a batch has one wave per SIMD anyway (65 536 streams).  SMALL: tiles of 8, a 16-slot window, a
+// 16-symbol output tile (rows of 20 words) -- 17 KiB per wave, EIGHT waves per workgroup and CU: with more than one wave of streams
+// per SIMD (more than 65 536 streams: e.g. a batch decoded through jump points) the second wave covers what a lone wave waits for
+// (690 of its 1970 cycles per symbol, profiles/r04_sq_counters.md).
+template <bool SMALL> struct LaneGeo {
+    static constexpr int kParTile = SMALL ? 8 : 16;
+    static constexpr int kWordWindow = 2 * kParTile;          // slots per stream, position p lives in slot p % kWordWindow
+    static constexpr int kOutSyms = SMALL ? 16 : kTileSyms;   // symbols per output tile
+    static constexpr int kOutStride = SMALL ? 20 : kTileStride;
+    static constexpr int kThreads = SMALL ? 512 : kBlock;
+    static constexpr size_t kWaveBytes = (size_t)kWave * kOutStride * 4 + 2 * (size_t)kParTile * kParStride * 8 + (size_t)kWordWindow * kWave * 4;
+    static constexpr size_t kLdsBytes = kErfTabBytes + (size_t)(kThreads / kWave) * kWaveBytes;
+};
 
-template <int W, int S, int KIND>
-__global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerSymbolDecodeArgs a) {
+// 16-symbol output tile of the SMALL geometry -> HBM: piece (lane & 3) of rows (lane >> 2) + 16 k, 64-byte row segments
+__device__ __noinline__ void store_symbol_tile16(int32_t* sym, size_t n_streams, size_t N, size_t s0, size_t t0, int lane, const int32_t* tile, bool vec) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t r = (size_t)(lane >> 2) + 16 * k;
+        if (s0 + r >= n_streams) continue;
+        const int32_t* src = tile + r * 20 + 4 * (lane & 3);
+        int32_t* dst = sym + (s0 + r) * N + t0 + 4 * (lane & 3);
+        if (vec) {
+            const int4 v = *reinterpret_cast<const int4*>(src);
+            v4i t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+            __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(dst));
+        } else {
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+    }
+}
+
+template <int W, int S, int KIND, bool SMALL = false>
+__global__ __launch_bounds__(LaneGeo<SMALL>::kThreads) void decode_gaussian_lane_kernel(const PerSymbolDecodeArgs a) {
+    using G = LaneGeo<SMALL>;
+    constexpr int kParTile = G::kParTile, kWordWindow = G::kWordWindow, kOutSyms = G::kOutSyms, kOutStride = G::kOutStride;
+    constexpr size_t kLaneDecWaveBytes = G::kWaveBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* erf_tab = reinterpret_cast<double2*>(smem);
     erf_tab_fill(erf_tab, threadIdx.x, blockDim.x);
@@ -851,7 +893,7 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
     const int lane = threadIdx.x & (kWave - 1);
     unsigned char* mine = smem + kErfTabBytes + (size_t)(threadIdx.x >> 6) * kLaneDecWaveBytes;
     int32_t* tile = reinterpret_cast<int32_t*>(mine);
-    double* par_mu = reinterpret_cast<double*>(mine + (size_t)kWave * kTileStride * 4);
+    double* par_mu = reinterpret_cast<double*>(mine + (size_t)kWave * kOutStride * 4);
     double* par_sd = par_mu + kParTile * kParStride;
     uint32_t* win = reinterpret_cast<uint32_t*>(par_sd + kParTile * kParStride);
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1024,18 +1066,19 @@ __global__ __launch_bounds__(kBlock) void decode_gaussian_lane_kernel(const PerS
                 if (active) *sym_p = sym;
                 sym_p += stride_t;
             } else {
-                tile[lane * kTileStride + (t % kTileSyms)] = sym;
-                if (t % kTileSyms == kTileSyms - 1) {
+                tile[lane * kOutStride + (t % kOutSyms)] = sym;
+                if (t % kOutSyms == kOutSyms - 1) {
                     wave_lds_fence();
-                    store_symbol_tile(a.symbols, a.n_streams, N, s0, t - (kTileSyms - 1), lane, tile, vec);
+                    if constexpr (SMALL) store_symbol_tile16(a.symbols, a.n_streams, N, s0, t - (kOutSyms - 1), lane, tile, vec);
+                    else store_symbol_tile(a.symbols, a.n_streams, N, s0, t - (kOutSyms - 1), lane, tile, vec);
                     wave_lds_fence();
                 }
             }
         }
     }
     if (!symbol_major) {
-        const size_t done = N - N % kTileSyms;
-        if (active) for (size_t t = done; t < N; ++t) a.symbols[se * N + t] = tile[lane * kTileStride + (t % kTileSyms)];
+        const size_t done = N - N % kOutSyms;
+        if (active) for (size_t t = done; t < N; ++t) a.symbols[se * N + t] = tile[lane * kOutStride + (t % kOutSyms)];
     }
     if (!active) return;
     a.status[s] = status;
@@ -1446,11 +1489,16 @@ template <int KIND>
 static cst_status encode_gaussian_fused(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
                                         const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                         uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
-                                        cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, hipStream_t hs) {
+                                        cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, hipStream_t hs,
+                                        size_t ckpt_interval = 0, uint32_t* d_ckpt_pos = nullptr, uint64_t* d_ckpt_state = nullptr) {
     if (cst_status st = check_common(cfg, layout)) return st;
     if (!d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && (KIND == kAns ? (void*)d_state : (void*)d_rstate) == nullptr) return CST_ERR_INVALID_ARGUMENT;
     GaussianFusedArgs a{};
+    if (ckpt_interval) {
+        a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.interval = ckpt_interval;
+        a.n_chunks = (n_per_stream + ckpt_interval - 1) / ckpt_interval;
+    }
     a.symbols = d_symbols; a.means = d_means; a.stds = d_stds; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
     a.layout = layout; a.precision = cfg.precision; a.lo = min_symbol; a.hi = max_symbol;
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.rstate = d_rstate;
@@ -1526,14 +1574,28 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
     if (KIND == kChain && a.n_streams < (size_t)kWave && a.n_per_stream >= 64 && a.n_streams * a.n_per_stream < ((size_t)1 << 31))
         return decode_chains_in_three(cfg, a, gaussian, hs);
     if (gaussian && a.n_streams >= (size_t)kWave) {      // enough streams to give every lane its own
-        const size_t lane_blocks = (a.n_streams + kBlock - 1) / kBlock;
-        if (cfg.word_bits == 32) {
-            CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gaussian_lane_kernel<32, 64, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLaneDecLdsBytes));
-            hipLaunchKernelGGL((decode_gaussian_lane_kernel<32, 64, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), kLaneDecLdsBytes, hs, a);
+        // more streams than one wave per SIMD: the small geometry, eight waves per CU (CST_LANE_GEO=big|small forces one: A/B runs)
+        int cus = 256;
+        { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
+        const char* geo = getenv("CST_LANE_GEO");
+        const bool small = KIND != kChain && (geo ? geo[0] == 's' : a.n_streams > (size_t)cus * kBlock);
+        auto go = [&](auto kernel, int threads, size_t lds) -> cst_status {
+            const size_t lane_blocks = (a.n_streams + threads - 1) / threads;
+            CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kernel, dim3((unsigned)lane_blocks), dim3(threads), lds, hs, a);
+            return CST_OK;
+        };
+        cst_status rc;
+        if constexpr (KIND != kChain) {
+            if (small) rc = cfg.word_bits == 32 ? go(decode_gaussian_lane_kernel<32, 64, KIND, true>, LaneGeo<true>::kThreads, LaneGeo<true>::kLdsBytes)
+                                                : go(decode_gaussian_lane_kernel<16, 32, KIND, true>, LaneGeo<true>::kThreads, LaneGeo<true>::kLdsBytes);
+            else rc = cfg.word_bits == 32 ? go(decode_gaussian_lane_kernel<32, 64, KIND, false>, LaneGeo<false>::kThreads, LaneGeo<false>::kLdsBytes)
+                                          : go(decode_gaussian_lane_kernel<16, 32, KIND, false>, LaneGeo<false>::kThreads, LaneGeo<false>::kLdsBytes);
         } else {
-            CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gaussian_lane_kernel<16, 32, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLaneDecLdsBytes));
-            hipLaunchKernelGGL((decode_gaussian_lane_kernel<16, 32, KIND>), dim3((unsigned)lane_blocks), dim3(kBlock), kLaneDecLdsBytes, hs, a);
+            rc = cfg.word_bits == 32 ? go(decode_gaussian_lane_kernel<32, 64, KIND, false>, LaneGeo<false>::kThreads, LaneGeo<false>::kLdsBytes)
+                                     : go(decode_gaussian_lane_kernel<16, 32, KIND, false>, LaneGeo<false>::kThreads, LaneGeo<false>::kLdsBytes);
         }
+        if (rc != CST_OK) return rc;
     } else if (KIND != kChain && gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
         if constexpr (KIND != kChain) return decode_gaussian_by_rows<KIND>(cfg, a, hs);
     } else if (gaussian) {
@@ -1652,6 +1714,50 @@ cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
         hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
                            max_symbol, d_symbols, d_means, d_stds, n, out);
     });
+}
+
+// Jump points for the reference's flagship call (every symbol its own (mean, std)): the fused encoder notes AnsCoder::pos() in
+// front of every chunk of `ckpt_interval` symbols (a multiple of the kernel's 16-symbol tile), and the decoder runs every
+// (stream, chunk) pair as a coder of its own -- the per-symbol parameters are a matrix of the symbols' shape, so chunk j of stream
+// s is row s * n_chunks + j of all three matrices viewed as [n_streams * n_chunks][interval].  What that buys: the lane decoder of
+// 65 536 streams is ONE wave per SIMD and spends a third of its cycles waiting; with two jump points per stream the small-geometry
+// kernel (LaneGeo<true>) runs two.
+cst_status cst_ans_encode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                              const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream,
+                                              cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                              size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, int32_t* d_status, void* stream) {
+    if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0 || ckpt_interval % kFuTile != 0 || n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;
+    if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
+    if (n_streams == 0) return CST_OK;
+    return encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words, stride_words,
+                                       d_n_words, nullptr, nullptr, d_status, CST_FLAG_NONE, (hipStream_t)stream, ckpt_interval, d_ckpt_pos, d_ckpt_state);
+}
+
+__global__ void gaussian_ckpt_offsets_kernel(const uint64_t* __restrict__ offsets, size_t stride_words, size_t n_streams, size_t n_chunks,
+                                             const uint64_t* __restrict__ state_in, uint64_t* __restrict__ v_offsets, uint64_t* __restrict__ v_state) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    const size_t s = v / n_chunks;
+    v_offsets[v] = offsets ? offsets[s] : s * stride_words;
+    v_state[v] = state_in[v];                  // (the raw decode updates its state array)
+}
+
+cst_status cst_ans_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
+                                              const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, size_t ckpt_interval,
+                                              const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state, const double* d_means, const double* d_stds,
+                                              int32_t* d_symbols, size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status, void* stream) {
+    if (!d_ckpt_pos || !d_ckpt_state || !d_scratch || !d_status || ckpt_interval == 0 || n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
+    uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
+    uint64_t* v_state = v_offsets + n_virtual;
+    hipLaunchKernelGGL(gaussian_ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_offsets, stride_words,
+                       n_streams, n_chunks, d_ckpt_state, v_offsets, v_state);
+    CST_HIP_TRY(hipGetLastError());
+    const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    return cst_ans_decode_gaussian_batch(cfg, min_symbol, max_symbol, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_means, d_stds, d_symbols, n_virtual,
+                                         ckpt_interval, CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
 }
 
 cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,

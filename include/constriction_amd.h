@@ -365,6 +365,24 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cf
                                      size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
                                      void *stream);
 
+/* The same for the reference's flagship call, every symbol its own (mean, std) (cst_ans_encode_gaussian_batch): the fused encoder
+ * notes the jump points (batches of at least 16 384 streams; ckpt_interval a multiple of 16 that divides n_per_stream), and the
+ * decoder runs every (stream, chunk) pair as a coder of its own -- the parameter matrices have the symbols' shape, so a chunk's
+ * models are a row of the [n_streams * n_chunks][interval] view of d_means / d_stds.  Stream-major.  With two jump points per
+ * stream a 65 536-stream batch decodes with two resident waves per SIMD (3.4 -> 2.6 ms at 4096 symbols per stream).
+ * d_scratch: cst_ckpt_scratch_bytes(...). */
+cst_status cst_ans_encode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                              const int32_t *d_symbols, const double *d_means, const double *d_stds,
+                                              size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                              size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
+                                              uint32_t *d_ckpt_pos, uint64_t *d_ckpt_state, int32_t *d_status, void *stream);
+cst_status cst_ans_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                              const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                              size_t words_capacity, size_t ckpt_interval, const uint32_t *d_ckpt_pos,
+                                              const uint64_t *d_ckpt_state, const double *d_means, const double *d_stds,
+                                              int32_t *d_symbols, size_t n_streams, size_t n_per_stream, void *d_scratch,
+                                              int32_t *d_status, void *stream);
+
 /* The same for the range coder: RangeEncoder::pos() / RangeDecoder::seek (src/stream/queue.rs:172-196, 900-926; test
  * :1333-1396).  A jump point is (d_ckpt_pos[s][j] = words emitted so far INCLUDING held-back ones, (d_ckpt_lower[s][j],
  * d_ckpt_range[s][j]) = RangeCoderState) in front of chunk j; seeking continues reading at word `pos`, re-reads `point` from

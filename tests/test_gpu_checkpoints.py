@@ -151,3 +151,31 @@ def test_per_stream_jump_points_corrupt_positions(B, O):
                 assert st[s, j] == 3
             else:
                 assert st[s, j] == 0 and np.array_equal(got[s, j * interval:(j + 1) * interval], sym[s, j * interval:(j + 1) * interval])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# jump points for per-symbol Gaussians (the reference's flagship call): cst_ans_{encode,decode}_gaussian_batch_ckpt
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n_streams,n_per,interval", [(64, 64, 16), (130, 96, 32), (70, 128, 64), (256, 48, 48)], ids=lambda v: str(v))
+def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, monkeypatch):
+    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")          # the fused encoder on small batches (it is the one that notes jump points)
+    rng = np.random.default_rng(n_streams + n_per)
+    mu = rng.uniform(-30, 30, (n_streams, n_per)); sd = np.exp(rng.uniform(-1, 3, (n_streams, n_per)))
+    sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), -100, 100).astype(np.int32)
+    enc, ck = B.ans_encode_gaussian_checkpointed(dev(sym), -100, 100, dev(mu), dev(sd), interval)
+    plain = B.ans_encode_gaussian(dev(sym), -100, 100, dev(mu), dev(sd))
+    torch.cuda.synchronize()
+    assert (enc.status.cpu().numpy() == 0).all() and torch.equal(enc.n_words, plain.n_words)
+    pos, state = ck.pos.cpu().numpy().view(np.uint32), ck.state.cpu().numpy().view(np.uint64)
+    for s in (0, n_streams // 2, n_streams - 1):
+        assert enc.stream(s).tolist() == plain.stream(s).tolist()
+        for j in range(n_per // interval):
+            c = O.AnsCoder()
+            c.encode_gaussian_reverse(sym[s, j * interval:], -100, 100, mu[s, j * interval:], sd[s, j * interval:], 24, 32)
+            assert (int(pos[s, j]), int(state[s, j])) == c.pos(), (s, j)
+            if j == 0:
+                assert enc.stream(s).tolist() == c.get_compressed().tolist()
+    dec, dstatus = B.ans_decode_gaussian_checkpointed(enc, ck, -100, 100, dev(mu), dev(sd))
+    torch.cuda.synchronize()
+    assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
