@@ -424,8 +424,28 @@ def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100,
              "words_per_stream": round(total_words / n_streams, 2), "algorithmic_bytes_per_symbol": round(byts / n_sym, 3),
              "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    # the same batch decoded through two jump points per stream (cst_ans_*_gaussian_batch_ckpt: the fused encoder notes them, the
+    # small-geometry lane decoder runs two waves per SIMD on the 131 072 (stream, chunk) pairs); words are the plain call's
+    jump_ok = True
+    try:
+        pair = B.ans_encode_gaussian_checkpointed(sym, lo, hi, mu, sd, n_per // 2, cfg)
+        st2 = torch.empty((n_streams, 2), dtype=torch.int32, device=dev)
+        dec2 = torch.zeros_like(sym)
+        je = event_ms(lambda: B.ans_encode_gaussian_checkpointed(sym, lo, hi, mu, sd, n_per // 2, cfg, out=pair), reps)
+        jd = event_ms(lambda: B.ans_decode_gaussian_checkpointed(pair[0], pair[1], lo, hi, mu, sd, out=dec2, status=st2), reps)
+        entry["with_2_jump_points"] = {"encode_ms": round(je, 4), "decode_ms": round(jd, 4), "decode_speedup": round(dec_ms / jd, 3),
+                                       "decode_frac": round(byts / (jd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if check:
+            used = torch.arange(min(512, int(enc.words.shape[1])), device=dev)[None, :] < enc.n_words[:, None]
+            w = used.shape[1]
+            jump_ok = bool(torch.equal(dec2, sym)) and int(st2.abs().sum().item()) == 0 and bool(torch.equal(pair[0].n_words, enc.n_words)) and \
+                bool(((pair[0].words[:, :w] == enc.words[:, :w]) | ~used).all())
+        del pair, st2, dec2
+    except Exception as exc:      # noqa: BLE001
+        entry["with_2_jump_points"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        jump_ok = False
     if check:
-        ok = bool(torch.equal(decoded, sym)) and int(enc.status.abs().sum().item()) == 0
+        ok = bool(torch.equal(decoded, sym)) and int(enc.status.abs().sum().item()) == 0 and jump_ok
         if ok:
             words, n_words, _ = enc.to_numpy()
             h_sym, h_mu, h_sd = sym.cpu().numpy(), mu.cpu().numpy(), sd.cpu().numpy()
