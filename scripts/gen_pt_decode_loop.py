@@ -70,13 +70,17 @@ def wait_if_pending(a, tag, comment=None):
         a.wait_lds(tag, comment)
 
 
-def tail(a, sym_reg, first=False):
-    """everything of a step that is off the chain; issued behind the bucket read of the NEXT step"""
+def tail(a, sym_reg, first=False, last=False):
+    """everything of a step that is off the chain; issued behind the bucket read of the NEXT step.
+    last: the tile's last step -- the candidate word of the NEXT tile's first refill may be in a chunk that only lands at the end of
+    this tile (two tiles in a row that consume their 12 words: data above ~11.5 bits per symbol), so its ring read waits until the
+    landing is done (round 5: it used to be issued here, and read a stale slot -- tests/test_gpu_max_rate.py)."""
     if not first:
         a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc", "rd -= refill")
     a.i(f"v_add_lshl_u32 {RA}, %[rd], %[shm1], 8")
     a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
-    a.ds(f"ds_read_b32 {WD}, {RA}", "w", "candidate word of the next refill")
+    if not last:
+        a.ds(f"ds_read_b32 {WD}, {RA}", "w", "candidate word of the next refill")
     if not first:
         a.i(f"v_cndmask_b32 %[hi], {N1}, {N0}, vcc")
     a.i(f"v_min_u32 {R1}, 1, %[rd]")
@@ -194,7 +198,7 @@ def step(a, j):
     a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
     a.i(f"v_and_or_b32 {TT}, %[lo], %[bmask], %[l1base]", "bucket of the next quantile (index interleaved by lane)")
     a.ds(f"ds_read_u8 {R0}, {TT}", "l1", "<- end of the serial chain")
-    tail(a, sym_reg)
+    tail(a, sym_reg, last=(j == 31))
 
 
 def gen():
@@ -262,13 +266,15 @@ def gen():
     a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
-    a.wait_lds("land", "landed chunks visible to the next tile; the bucket and ring reads of its first step are older")
+    a.wait_lds("land", "landed chunks visible to the next tile; the bucket read of its first step is older")
+    a.ds(f"ds_read_b32 {WD}, {RA}", "w", "candidate word of the next tile's first refill: only now, behind the landing")
     a.i("s_cbranch_scc1 1b")
     # the back edge must leave the queues as the loop entry found them (modulo completed operations)
     lds_end, vm_end, notes = a.verify_loop(first, list(a.lds), list(a.vm), passes=1)
     assert lds_end == a.lds and vm_end == a.vm, (lds_end, a.lds, vm_end, a.vm)
-    assert [t for t in lds_entry if t not in ("l1", "w")] == [] and a.lds == [], (lds_entry, a.lds)
+    assert [t for t in lds_entry if t not in ("l1", "w")] == [] and a.lds == ["w"], (lds_entry, a.lds)
     a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all("(the candidate word requested for a tile that does not come)")
     return a, notes
 
 

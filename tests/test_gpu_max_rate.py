@@ -1,0 +1,113 @@
+"""Adversarial RATES (round 5): data made of symbols of probability 2^-P -- P bits each, the most a symbol can cost -- with a likely
+symbol here and there, so that the words are consumed at the maximum the decoders' word windows are sized for (12 words per 32-symbol
+tile at (32,64,12), 24 at P = 24 and for 16-bit words) and the refills fall on every phase of a tile.  All-tail data alone emits on the
+same steps tile after tile and missed a stale read of the first refill candidate of a tile in the per-stream-table decoder (found in
+round 5: wrong symbols at position 1 of a tile, only above ~11.5 bits per symbol).  Every decoder family, against the input and the
+CPU oracle's words."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def spiky_cdf(n, P):
+    """symbol 0 takes everything the n - 1 others (probability 2^-P each) leave"""
+    cdf = np.zeros(n + 1, np.uint32)
+    cdf[1] = (1 << P) - (n - 1)
+    cdf[2:] = cdf[1] + np.arange(1, n, dtype=np.uint32)
+    return cdf
+
+
+def high_rate_symbols(rng, n_streams, n_per, n, frac):
+    tails = rng.integers(1, n, (n_streams, n_per), dtype=np.int32)
+    return np.where(rng.random((n_streams, n_per)) < frac, 0, tails).astype(np.int32)
+
+
+CASES = [(coder, cfg) for coder in ("ans", "range") for cfg in ((32, 64, 12), (32, 64, 24), (32, 64, 16), (16, 32, 12), (32, 64, 8))]
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("coder,cfg", CASES, ids=lambda v: v if isinstance(v, str) else "W%dS%dP%d" % v)
+def test_shared_table_decoders_at_the_maximum_rate(B, O, coder, cfg, frac):
+    W, S, P = cfg
+    n = 101 if P >= 8 else 16
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + P)
+    sym = high_rate_symbols(rng, 192, 2048, n, frac)
+    if coder == "ans":
+        want_words, want_n, _ = O.ans_encode_batch(sym, 0, cdf, P, W, S)
+        enc = B.ans_encode(dev(sym), model, cfg)
+    else:
+        want_words, want_n, _ = O.rc_encode_batch(sym, 0, cdf, P, W, S)
+        enc = B.range_encode(dev(sym), model, cfg)
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in (0, 77, 191):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    checks = []
+    if coder == "ans":
+        checks.append(("plain", *B.ans_decode(enc, model, 2048, cold=False)))
+        checks.append(("cold", *B.ans_decode(enc, model, 2048, cold=True)))
+        symT = dev(np.ascontiguousarray(sym.T))
+        encT = B.ans_encode(symT, model, cfg, layout="symbol_major")
+        dT, sT = B.ans_decode(encT, model, 2048, layout="symbol_major")
+        checks.append(("symbol-major", dT.t().contiguous(), sT))
+        if W == 16:
+            pk = B.ans_encode(dev(sym), model, cfg, packed16=True)
+            checks.append(("packed16", *B.ans_decode(pk, model, 2048)))
+        e2, ck = B.ans_encode_checkpointed(dev(sym), model, 512, cfg)
+        d2, s2 = B.ans_decode_checkpointed(e2, ck, model, 2048)
+        checks.append(("jump points", d2, s2))
+    else:
+        checks.append(("plain", *B.range_decode(enc, model, 2048)))
+        e2, ck = B.range_encode_checkpointed(dev(sym), model, 512, cfg)
+        d2, s2 = B.range_decode_checkpointed(e2, ck, model, 2048)
+        checks.append(("jump points", d2, s2))
+    torch.cuda.synchronize()
+    for name, dec, st in checks:
+        assert int(st.abs().sum()) == 0, name
+        assert np.array_equal(dec.cpu().numpy(), sym), name
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.03, 0.1, 0.3])
+def test_per_stream_table_decoders_at_the_maximum_rate(B, O, frac):
+    n, k, P = 320, 2048, 12
+    rng = np.random.default_rng(int(frac * 100))
+    mu_h, sd_h = rng.uniform(-5, 5, n), rng.uniform(0.4, 0.8, n)
+    model = B.Model.quantized_gaussian_per_stream(-127, 127, dev(mu_h), dev(sd_h), P)
+    tails = rng.choice(np.concatenate([np.arange(-127, -40), np.arange(40, 128)]), (n, k)).astype(np.int32)
+    likely = np.rint(mu_h)[:, None].astype(np.int32) + np.zeros((n, k), np.int32)
+    sym = np.where(rng.random((n, k)) < frac, likely, tails).astype(np.int32)
+    cdfs = np.stack([O.GaussianModel(-127, 127, a, b, P, 32).cdf_table() for a, b in zip(mu_h, sd_h)])
+    want_words, want_n, _ = O.ans_encode_batch(sym, -127, cdfs, P)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in (0, 100, 319):
+        assert words[s, : n_words[s]].tolist() == want_words[s, : want_n[s]].tolist()
+    dec, st = B.ans_decode(enc, model, k)
+    assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), "plain"
+    for chunks in (4, 8):
+        e2, ck = B.ans_encode_checkpointed(dev(sym), model, k // chunks, (32, 64, P))
+        d2, s2 = B.ans_decode_checkpointed(e2, ck, model, k)
+        assert int(s2.abs().sum()) == 0 and np.array_equal(d2.cpu().numpy(), sym), f"k = {chunks}"

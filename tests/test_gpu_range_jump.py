@@ -41,13 +41,14 @@ SHAPES = [
 ]
 
 
+# (symbol-major: the encoder side only, a few shapes)
+LAYOUT_SHAPES = [("stream_major", *sh) for sh in SHAPES] + [("symbol_major", *sh) for sh in SHAPES if sh[:2] in ((256, 256), (300, 256), (3, 96))]
+
+
 @pytest.mark.parametrize("cfg", [(32, 64, 12), (32, 64, 24), (32, 64, 16), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
-@pytest.mark.parametrize("n_streams,n_per,interval", SHAPES, ids=lambda v: str(v))
-@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
-def test_range_jump_points(B, O, cfg, n_streams, n_per, interval, layout):
+@pytest.mark.parametrize("layout,n_streams,n_per,interval", LAYOUT_SHAPES, ids=lambda v: str(v))
+def test_range_jump_points(B, O, cfg, layout, n_streams, n_per, interval):
     W, S, P = cfg
-    if layout == "symbol_major" and (n_streams, n_per) not in ((256, 256), (300, 256), (3, 96)):
-        pytest.skip("symbol-major: encoder side only, a few shapes")
     lo = -30
     cdf = O.GaussianModel(lo, 30, 1.5, 6.0, P, 32 if W == 32 else 16).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
