@@ -121,6 +121,24 @@ __device__ __forceinline__ void pt_decode_tiles_loop_sub(uint32_t& lo, uint32_t&
     }
 }
 
+// ... and for sixteen waves per workgroup (GEN_PT_SUB=2): 16-slot rings, the window moves every half tile, registers v48 - v125
+__device__ __forceinline__ void pt_decode_tiles_loop_sub16(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
+                                                           uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
+                                                           uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
+                                                           uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                           uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                           const uint32_t (&goff)[8], bool plain_stores) {
+    if (plain_stores) {
+#define CST_STORE_MOD ""
+#include "cst_pt_decode_loop_sub16.inc"
+#undef CST_STORE_MOD
+    } else {
+#define CST_STORE_MOD "nt"
+#include "cst_pt_decode_loop_sub16.inc"
+#undef CST_STORE_MOD
+    }
+}
+
 // copies this block's rows into LDS (coalesced, 4 bytes per lane)
 __device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* src, uint32_t n_words) {
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) rows_l[i] = src[i];
@@ -433,14 +451,24 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
 // The symbol matrix [n_streams][N] is the matrix [n_streams * k][N / k] of the virtual streams; words, counts and status are
 // those of any other decoder of these words (the jump points are side information).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kSubThreads = 512;
-constexpr int kSubWaves = kSubThreads / kWave;
-constexpr size_t kSubRingBytes = (size_t)kSubWaves * kPtRingSlots * kWave * 4;        // 64 KiB
+// WAVES = 8: 32-slot rings (cst_pt_decode_loop_sub.inc), two waves per SIMD.  WAVES = 16: 16-slot rings, the window moves every half
+// tile (cst_pt_decode_loop_sub16.inc), four waves per SIMD -- for k >= 8 jump points per stream, whose 128 or 64 streams per
+// workgroup leave room for sixteen rings: 64 + 16 + 36 + 1 + rows KiB.
+// (8 waves with the 16-slot rings: k = 2, whose 256 streams per workgroup do not fit beside eight 32-slot rings on wide tables)
+template <int WAVES, bool RING16> struct SubGeo {
+    static constexpr int kThreads = WAVES * kWave;
+    static constexpr int kSlots = RING16 ? 16 : kPtRingSlots;
+    static constexpr int kAhead = RING16 ? 12 : kPtAhead;
+    static constexpr size_t kRingBytes = (size_t)WAVES * kSlots * kWave * 4;
+};
 constexpr int kSubTileRow = 36;                                                        // bytes between the rows of a byte tile
 constexpr size_t kSubTileBytes = (size_t)kWave * kSubTileRow;                          // 2304 B per wave
 constexpr size_t kSubDumpBytes = 4 * kWave * 4;                                        // ONE landing area (never read)
 
-__global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const PtArgs a) {
+template <int WAVES, bool RING16>
+__global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const PtArgs a) {
+    constexpr int kSubWaves = WAVES, kSlots = SubGeo<WAVES, RING16>::kSlots;
+    constexpr size_t kSubRingBytes = SubGeo<WAVES, RING16>::kRingBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const Pt
     if (block_s0 >= a.n_streams) return;                               // (the whole workgroup)
     const uint32_t S = (uint32_t)max(kSubWaves >> ks, 1) * kWave;     // streams whose tables this workgroup stages
     const size_t l1_bytes = (size_t)S * kPtBuckets;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kPtRingSlots * kWave);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kSlots * kWave);
     uint8_t* l1_l = smem + kSubRingBytes;
     uint8_t* tile = smem + kSubRingBytes + l1_bytes + (size_t)wave_in_block * kSubTileBytes;
     uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kSubRingBytes + l1_bytes + kSubWaves * kSubTileBytes) + lane;
@@ -501,7 +529,7 @@ __global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const Pt
     const uint32_t row_addr = lds_addr(rowp);
     const uint8_t* l1p = l1_l + (((ls >> bshift) * kPtBuckets) << bshift) + (ls & ((1u << bshift) - 1u));
 
-    DecLane<32, 64, kPtRingSlots, kPtAhead> L;
+    DecLane<32, 64, kSlots, SubGeo<WAVES, RING16>::kAhead> L;
     // AnsCoder::seek(pos, state): the words in front of the jump point, checked against the slab / the buffer like any count
     const WordSlice ws = active ? word_slice_n(a.offsets, a.stride_words, a.ckpt_pos[v], s, a.words_capacity) : WordSlice{0, 0u, false};
     L.init(a.words_in + ws.off, ws.n, ring, lane);
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const Pt
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words_in) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
-        if ((lds_addr(ring) & (uint32_t)(kPtRingSlots * kWave * 4 - 1)) != 0 || (lds_addr(l1_l) & (uint32_t)((kPtBuckets << bshift) - 1)) != 0) __builtin_trap();
+        if ((lds_addr(ring) & (uint32_t)(kSlots * kWave * 4 - 1)) != 0 || (lds_addr(l1_l) & (uint32_t)((kPtBuckets << bshift) - 1)) != 0) __builtin_trap();
         if (!__any(!off_ok)) {
             uint32_t goff[8];
 #pragma unroll
@@ -562,10 +590,16 @@ __global__ __launch_bounds__(kSubThreads) void ans_decode_pt_sub_kernel(const Pt
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
             const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-            pt_decode_tiles_loop_sub(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kPtRingSlots - 1) * kWave * 4), (uint32_t)P,
-                                     a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
-                                     lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
-                                     lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff, plain_stores);
+            if constexpr (RING16)
+                pt_decode_tiles_loop_sub16(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kSlots - 1) * kWave * 4), (uint32_t)P,
+                                           a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                           lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                           lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff, plain_stores);
+            else
+                pt_decode_tiles_loop_sub(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kSlots - 1) * kWave * 4), (uint32_t)P,
+                                         a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                         lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                         lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff, plain_stores);
             t_done = n_full * kTileSyms;
         }
     }
@@ -629,20 +663,46 @@ cst_status ans_encode_pt_ckpt(const cst_model* model, const int32_t* d_symbols, 
     return pt_launch(ans_encode_pt_kernel<true>, a, pt_lds_bytes(model, true), hs);
 }
 
-static size_t pt_sub_lds_bytes(const cst_model* m, int sub_shift) {
-    const size_t S = (size_t)((kSubWaves >> sub_shift) > 1 ? (kSubWaves >> sub_shift) : 1) * kWave;        // streams per workgroup
-    return kSubRingBytes + S * kPtBuckets + kSubWaves * kSubTileBytes + kSubDumpBytes + 4 * ((size_t)m->pt_max_dec + 4);
+// rows of the S = max(waves / k, 1) * 64 streams of a workgroup: at most S / 64 times the largest 64-stream group (pt_max_dec64),
+// and never more than the largest block of kBlock streams
+static size_t pt_sub_rows_bytes(const cst_model* m, int waves, int sub_shift) {
+    const size_t groups = (size_t)((waves >> sub_shift) > 1 ? (waves >> sub_shift) : 1);
+    const size_t by_groups = groups * (size_t)m->pt_max_dec64, by_block = (size_t)m->pt_max_dec;
+    return 4 * ((by_groups < by_block ? by_groups : by_block) + 4);
 }
 
-// k lanes per stream (k = n_per_stream / interval a power of two, 2 <= k <= 16), tables that fit next to eight waves' rings
+static size_t pt_sub_lds_bytes(const cst_model* m, int waves, bool ring16, int sub_shift) {
+    const size_t S = (size_t)((waves >> sub_shift) > 1 ? (waves >> sub_shift) : 1) * kWave;        // streams per workgroup
+    return (size_t)waves * (ring16 ? 16 : kPtRingSlots) * kWave * 4 + S * kPtBuckets + (size_t)waves * kSubTileBytes + kSubDumpBytes +
+           pt_sub_rows_bytes(m, waves, sub_shift);
+}
+
+static int pt_sub_shift(size_t k) {
+    int ks = 0;
+    while (((size_t)1 << ks) < k) ++ks;
+    return ks;
+}
+
+// The geometry of a launch: sixteen waves per workgroup (four per SIMD, 16-slot rings) where k >= 8 jump points per stream leave
+// room for them; else eight waves with the 32-slot rings; else eight waves with the 16-slot rings (k = 2 on wide tables); 0 = none
+// fits.  (CST_PT_SUB_WAVES=8 never takes sixteen: A/B runs.)  The 16-slot statement is for P = 12.
+struct PtSubGeo { int waves; bool ring16; };
+static PtSubGeo pt_sub_geometry(const cst_model* m, int ks) {
+    const char* e = getenv("CST_PT_SUB_WAVES");
+    const bool p12 = m->precision == 12;
+    if (!(e && e[0] == '8') && ks >= 3 && p12 && pt_sub_lds_bytes(m, 16, true, ks) <= 160 * 1024) return {16, true};
+    if (pt_sub_lds_bytes(m, 8, false, ks) <= 160 * 1024) return {8, false};
+    if (p12 && pt_sub_lds_bytes(m, 8, true, ks) <= 160 * 1024) return {8, true};
+    return {0, false};
+}
+
+// k lanes per stream (k = n_per_stream / interval a power of two, 2 <= k <= 16), tables that fit next to the waves' rings
 bool pt_sub_usable(const cst_model* m, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval) {
     if (!m->pt_ok || cfg.word_bits != 32 || m->precision < 8 || m->precision > 12 || m->n_tables != n_streams) return false;
     if (interval == 0 || n_per_stream % interval != 0) return false;
     const size_t k = n_per_stream / interval;
     if (k < 2 || k > 16 || (k & (k - 1)) != 0 || n_streams * k > 0x7fffffffull) return false;
-    int ks = 0;
-    while (((size_t)1 << ks) < k) ++ks;
-    return pt_sub_lds_bytes(m, ks) <= 160 * 1024;
+    return pt_sub_geometry(m, pt_sub_shift(k)).waves != 0;
 }
 
 cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
@@ -650,8 +710,7 @@ cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, co
                              int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs) {
     PtArgs a{};
     const size_t k = n_per_stream / interval;
-    int ks = 0;
-    while (((size_t)1 << ks) < k) ++ks;
+    const int ks = pt_sub_shift(k);
     a.words_capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
     a.symbols_out = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
     a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
@@ -660,12 +719,18 @@ cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, co
     a.words_in = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.status = d_status;
     a.ckpt_pos = const_cast<uint32_t*>(d_ckpt_pos); a.ckpt_state = const_cast<uint64_t*>(d_ckpt_state);
     a.interval = interval; a.n_chunks = k; a.sub_shift = ks;
-    const size_t lds = pt_sub_lds_bytes(model, ks);
-    const size_t blocks = ((((n_streams + kWave - 1) / kWave) << ks) + kSubWaves - 1) / kSubWaves;       // a wave = 64 streams x one chunk
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_pt_sub_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ans_decode_pt_sub_kernel, dim3((unsigned)blocks), dim3(kSubThreads), lds, hs, a);
-    CST_HIP_TRY(hipGetLastError());
-    return CST_OK;
+    const PtSubGeo geo = pt_sub_geometry(model, ks);
+    if (geo.waves == 0) return CST_ERR_INVALID_ARGUMENT;
+    const size_t lds = pt_sub_lds_bytes(model, geo.waves, geo.ring16, ks);
+    const size_t blocks = ((((n_streams + kWave - 1) / kWave) << ks) + geo.waves - 1) / geo.waves;       // a wave = 64 streams x one chunk
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(geo.waves * kWave), lds, hs, a);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    if (geo.waves == 16) return go(ans_decode_pt_sub_kernel<16, true>);
+    return geo.ring16 ? go(ans_decode_pt_sub_kernel<8, true>) : go(ans_decode_pt_sub_kernel<8, false>);
 }
 
 cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,

@@ -134,6 +134,7 @@ struct cst_model {
     uint8_t* d_pt_l1 = nullptr;           // [n_tables][kPtBuckets] quantile bucket -> first candidate (position in the decoder row)
     uint32_t* d_pt_block_base = nullptr;  // [2][n_blocks + 1] first encoder / decoder row entry of every block of kBlock tables
     uint32_t pt_max_enc = 0, pt_max_dec = 0;   // largest block (entries): sizes the LDS image of a workgroup
+    uint32_t pt_max_dec64 = 0;                 // largest group of 64 consecutive tables' decoder rows (entries): the sub-lane decoder's workgroups
 };
 
 namespace cst {

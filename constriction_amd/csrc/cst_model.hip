@@ -92,6 +92,17 @@ __global__ __launch_bounds__(256) void pt_offsets_kernel(PtMeta* __restrict__ me
     if (threadIdx.x == 255) { enc_size[blockIdx.x] = se[255]; dec_size[blockIdx.x] = sd[255]; }
 }
 
+// decoder-row entries of every aligned group of 64 tables (the sub-lane decoder stages 64, 128 or 256 streams per workgroup): the largest
+__global__ void pt_group_max_kernel(const PtMeta* __restrict__ meta, size_t n_tables, const uint32_t* __restrict__ dec_size, uint32_t* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t s0 = g * 64;
+    if (s0 >= n_tables) return;
+    const size_t s1 = s0 + 64 < n_tables ? s0 + 64 : n_tables;
+    // rows lie back to back inside a block of kBlock tables (dec_off is relative to it); a group never straddles two blocks
+    const uint32_t end = (s1 % kBlock != 0 && s1 < n_tables) ? meta[s1].dec_off : dec_size[s0 / kBlock];
+    atomicMax(out, end - meta[s0].dec_off);
+}
+
 // pass 3, one thread per table: the rows and the quantile bucket index of the decoder
 __global__ void pt_fill_kernel(const uint32_t* __restrict__ cdf, size_t n_tables, int32_t n, int P, const PtMeta* __restrict__ meta,
                                const uint32_t* __restrict__ enc_base, const uint32_t* __restrict__ dec_base, uint16_t* __restrict__ enc,
@@ -142,6 +153,17 @@ static void build_pt_image(cst_model* m, hipStream_t hs) {
         hipLaunchKernelGGL(pt_offsets_kernel, dim3((unsigned)n_blocks), dim3(256), 0, hs, m->d_pt_meta, nt, d_size, d_size + n_blocks);
         ok = hipMemcpyAsync(h_size.data(), d_size, 8 * n_blocks, hipMemcpyDeviceToHost, hs) == hipSuccess &&
              hipStreamSynchronize(hs) == hipSuccess;
+    }
+    if (ok) {
+        uint32_t* d_max = nullptr;
+        ok = hipMalloc(&d_max, 4) == hipSuccess && hipMemsetAsync(d_max, 0, 4, hs) == hipSuccess;
+        if (ok) {
+            const size_t groups = (nt + 63) / 64;
+            hipLaunchKernelGGL(pt_group_max_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, hs, (const PtMeta*)m->d_pt_meta, nt,
+                               (const uint32_t*)(d_size + n_blocks), d_max);
+            ok = hipMemcpyAsync(&m->pt_max_dec64, d_max, 4, hipMemcpyDeviceToHost, hs) == hipSuccess && hipStreamSynchronize(hs) == hipSuccess;
+        }
+        if (d_max) (void)hipFree(d_max);
     }
     uint32_t* eb = h_base.data(), *db = h_base.data() + n_blocks + 1;
     if (ok) {

@@ -21,7 +21,7 @@ for rep in range(2):
     e = bench.event_ms(lambda: B.ans_encode(sym, m3, cfg, out=enc), 5)
     d = bench.event_ms(lambda: B.ans_decode(enc, m3, k, out=dec), 5)
     print(f"plain: encode {e:6.3f} ms decode {d:6.3f} ms ok={bool(torch.equal(dec, sym))}", flush=True)
-for chunks in (2, 4, 8):
+for chunks in (2, 4, 8, 16):
     interval = k // chunks
     enc2, ck = B.ans_encode_checkpointed(sym, m3, interval, cfg)
     same = bool(torch.equal(enc2.n_words, enc.n_words)) and bool(torch.equal(enc2.words[:, :600], enc.words[:, :600]))

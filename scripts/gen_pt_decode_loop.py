@@ -32,12 +32,21 @@ from asmgen import Asm  # noqa: E402
 # apart (2304 bytes per wave instead of 9216), and the tile leaves as int32 symbols: each 4-byte piece read back is widened
 # by four SDWA adds of min_symbol (src1_sel:BYTE_n) in front of its 16-byte store.
 SUB = bool(os.environ.get("GEN_PT_SUB"))
+# GEN_PT_SUB=2: the same for FOUR waves per SIMD (sixteen per workgroup).  The ring shrinks to 16 slots (4 KiB per wave), which
+# cannot hold two tiles' worth of words, so the window moves every HALF tile: 16 symbols consume at most 6 words, the ring keeps the 12
+# below the read position (two halves), two chunk slots are requested at steps 0 and 16 and landed after steps 15 and 31 -- a chunk
+# with words 4c .. 4c + 3 lands on the slots of words 4c + 16 ..., which lie at or above rd_top + 1 and are dead by then.  The first
+# refill candidate of the NEXT half is read behind the landing (it may be in the chunk that has just landed).  And the statement's
+# registers are renumbered from v100 - v177 down to v48 - v125: sixteen waves per workgroup leave every wave 128.
+SUB16 = os.environ.get("GEN_PT_SUB") == "2"
+REG_SHIFT = 52 if SUB16 else 0
 SUB_ROW = 36          # bytes between the rows of the byte tile (9 dwords: the lanes' quad writes hit 64 different banks)
 OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / \
-    ("cst_pt_decode_loop_sub.inc" if SUB else "cst_pt_decode_loop.inc")
+    ("cst_pt_decode_loop_sub16.inc" if SUB16 else "cst_pt_decode_loop_sub.inc" if SUB else "cst_pt_decode_loop.inc")
 
-K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
-AHEAD_M1 = 23         # kPtAhead - 1
+K_CHUNKS = 2 if SUB16 else 3      # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks) / per half tile
+AHEAD_M1 = 11 if SUB16 else 23    # kPtAhead - 1
+HALVES = (0, 16) if SUB16 else (0,)
 
 N0, N1 = "v100", "v101"            # v[100:101] = N
 DD = "v102"                        # v[102:103] = [q - c (0 for a run), 0]
@@ -99,7 +108,10 @@ def tail(a, sym_reg, first=False, last=False):
 def step(a, j):
     quad, pos = divmod(j, 4)
     sym_reg = (PK[quad % 2], pos) if SUB else SYM[(quad % 2) * 4 + pos]
-    a.wait_lds("l1", f"---- step {j}: first candidate is back")
+    if "l1" in a.lds:
+        a.wait_lds("l1", f"---- step {j}: first candidate is back")
+    else:
+        a.i(f"; ---- step {j}: (the landing's wait covered the bucket read)")
     a.i(f"v_lshl_add_u32 {RA2}, {R0}, 3, %[rowaddr]")
     if WINDOW == 8:
         a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "eight consecutive entries from the aligned pair that holds the first candidate")
@@ -198,7 +210,7 @@ def step(a, j):
     a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
     a.i(f"v_and_or_b32 {TT}, %[lo], %[bmask], %[l1base]", "bucket of the next quantile (index interleaved by lane)")
     a.ds(f"ds_read_u8 {R0}, {TT}", "l1", "<- end of the serial chain")
-    tail(a, sym_reg, last=(j == 31))
+    tail(a, sym_reg, last=(j == 31 or (SUB16 and j == 15)))
 
 
 def gen():
@@ -214,23 +226,37 @@ def gen():
     first = len(a.events)
     lds_entry, vm_entry = list(a.lds), list(a.vm)
 
-    # ---- window: request the chunks this tile's successor may need (landed at the end of this iteration) ----
-    a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
-    a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kPtAhead, 0)")
-    for k in range(K_CHUNKS):
-        a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
-        a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
-        a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
-        a.i(f"v_lshlrev_b32 {TADDR}, 8, %[lo_issued]")
-        a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
-        a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
-        a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
-        a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
-        a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
-        a.i(f"s_mov_b64 exec, {SAVE}")
+    def window_requests():
+        """request the chunks the next tile (half tile) may need; they land at the end of this one"""
+        a.i(f"v_add_u32 {WANT}, %[rd], %[shm1]")
+        a.i(f"v_sub_u32_e64 {WANT}, {WANT}, {AHEAD_M1} clamp", "want_lo = max(rd + shift - kPtAhead, 0)")
+        for k in range(K_CHUNKS):
+            a.i(f"v_cmp_gt_u32 vcc, %[lo_issued], {WANT}", f"chunk slot {k}: needed?")
+            a.i(f"v_cndmask_b32_e64 {TMP}, 0, 4, vcc")
+            a.i(f"v_sub_u32 %[lo_issued], %[lo_issued], {TMP}")
+            a.i(f"v_lshlrev_b32 {TADDR}, 8, %[lo_issued]")
+            a.i(f"v_and_or_b32 {TADDR}, {TADDR}, %[cmask], %[lanebase]")
+            a.i(f"v_cndmask_b32 {LAND[k]}, %[dump], {TADDR}, vcc", "landing address: ring slot or the dump rows")
+            a.i(f"v_lshl_add_u32 {TOFF}, %[lo_issued], 2, %[woff]")
+            a.i(f"s_and_saveexec_b64 {SAVE}, vcc")
+            a.vmem(f"global_load_dwordx4 {PEND[k][0]}, {TOFF}, %[wbase]", f"chunk{k}")
+            a.i(f"s_mov_b64 exec, {SAVE}")
+
+    def window_landing(comment):
+        a.wait_vm(f"chunk{K_CHUNKS - 1}", comment)
+        for k in range(K_CHUNKS):
+            r = PEND[k][1]
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
+            a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
 
     for j in range(32):
+        if j in HALVES:
+            window_requests()
         step(a, j)
+        if SUB16 and j == 15:
+            window_landing("---- middle of the tile: the first half's chunks land")
+            a.wait_lds("land", "visible before the second half reads its first candidate word")
+            a.ds(f"ds_read_b32 {WD}, {RA}", "w", "candidate word of step 16's refill: only now, behind the landing")
 
     # ---- end of tile: last quad -> tile row, tile -> HBM, chunks -> ring ----
     if SUB:
@@ -257,11 +283,7 @@ def gen():
             elif k == 0:
                 a.wait_lds("xo")
             a.vmem(f"global_store_dwordx4 %[goff{4 * half + k}], {XO[k]}, s[80:81] \" CST_STORE_MOD \"", "store")
-    a.wait_vm(f"chunk{K_CHUNKS - 1}", "the chunk loads are older than this tile's stores")
-    for k in range(K_CHUNKS):
-        r = PEND[k][1]
-        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[0]}, {r[1]} offset1:1", "land")
-        a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
+    window_landing("the chunk loads are older than this tile's stores")
     a.i("s_add_u32 s80, s80, 0x80")
     a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
@@ -289,7 +311,15 @@ def main():
            '      [dump] "v"(dump_addr), [woff] "v"(words_off), [rowcur] "v"(tile_row_addr), [trcur] "v"(tile_tr_addr),',
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-    OUT.write_text(a.render(header, ops))
+    text = a.render(header, ops)
+    if REG_SHIFT:
+        import re
+        def shift(m):
+            n = int(m.group(2))
+            return f"{m.group(1)}{n - REG_SHIFT}" if n >= 100 else m.group(0)
+        text = re.sub(r"(\bv\[?)(\d+)", shift, text)                     # v123, v[123
+        text = re.sub(r"(v\[\d+:)(\d+)", shift, text)                    # the upper end of v[123:126]
+    OUT.write_text(text)
     print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)

@@ -4,6 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 for g in scripts/gen_*loop*.py; do python "$g" > /dev/null; done
 GEN_PT_SUB=1 python scripts/gen_pt_decode_loop.py > /dev/null
+GEN_PT_SUB=2 python scripts/gen_pt_decode_loop.py > /dev/null
 GEN_PT_CK=1 python scripts/gen_pt_encode_loop.py > /dev/null
 GEN_RANGE_CK=1 python scripts/gen_range_encode_loop.py > /dev/null
 GEN_RANGE_SUB=1 python scripts/gen_range_decode_loop.py > /dev/null

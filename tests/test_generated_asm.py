@@ -161,6 +161,8 @@ def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):
         monkeypatch.delenv(var, raising=False)
     monkeypatch.setenv("GEN_PT_SUB", "1")
     assert _regenerate(_load("gen_pt_decode_loop"), tmp_path, "cst_pt_decode_loop_sub.inc") == (csrc / "cst_pt_decode_loop_sub.inc").read_text()
+    monkeypatch.setenv("GEN_PT_SUB", "2")                     # 16-slot rings, a window every half tile: four waves per SIMD
+    assert _regenerate(_load("gen_pt_decode_loop"), tmp_path, "cst_pt_decode_loop_sub16.inc") == (csrc / "cst_pt_decode_loop_sub16.inc").read_text()
     monkeypatch.delenv("GEN_PT_SUB")
     monkeypatch.setenv("GEN_PT_CK", "1")
     assert _regenerate(_load("gen_pt_encode_loop"), tmp_path, "cst_pt_encode_loop_ck.inc") == (csrc / "cst_pt_encode_loop_ck.inc").read_text()
