@@ -346,7 +346,13 @@ __device__ __forceinline__ void encode_step_inv(EncLane<32, 64, SLOTS>& L, uint3
     L.state = ((((uint64_t)qh << 32) | ql) << P) + (uint64_t)(int64_t)y;
 }
 
-template <int W, int S, int KIND>
+//
+// PAIR (stream-major matrices of whole tiles and whole waves: the launcher checks): a tile takes 64 bytes of each stream's
+// symbols -- half a 128-byte line whose other half is the NEXT tile's, and asked for a tile apart the line came from HBM twice
+// (6.60 GB counted against 5.57 GB algorithmic, profiles/r04_pmc_summary.md).  So the symbols of both tiles of a line are
+// requested together, a pair of tiles ahead, and parked lane by lane in the ring columns of lanes 32..63 (a wave codes
+// kFuStreams = 32 streams: no coder ever writes there), where the items pick them up one item ahead of their use.
+template <int W, int S, int KIND, bool PAIR = false>
 __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const GaussianFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1), wave_in_block = threadIdx.x >> 6;
@@ -385,17 +391,16 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
     //   base(lane) + it * item_stride + k * tile_stride      (both strides wave-uniform, in either layout)
     // and the items are requested in exactly that order, so one running index per lane replaces the per-item index arithmetic
     // (two 64-bit multiply-adds, bounds tests and their exec masks: ~25 VALU and ~15 SALU per item).
-    const bool walk = s0 + kFuStreams <= a.n_streams && N % kFuTile == 0;
+    const bool walk = PAIR || (s0 + kFuStreams <= a.n_streams && N % kFuTile == 0);
     const int64_t item_stride = symbol_major ? (int64_t)(kWave / kFuStreams) * (int64_t)a.n_streams : (int64_t)(kWave / kFuTile) * (int64_t)N;
     const int64_t tile_stride = symbol_major ? (int64_t)kFuTile * (int64_t)a.n_streams : (int64_t)kFuTile;
     const int64_t wrap_delta = (KIND == kAns ? -tile_stride : tile_stride) - (int64_t)(kFuIters - 1) * item_stride;
     int64_t e_req = symbol_major ? (int64_t)item_t(0) * (int64_t)a.n_streams + (int64_t)(s0 + (size_t)item_j(0))
                                  : (int64_t)(s0 + (size_t)item_j(0)) * (int64_t)N + (int64_t)item_t(0);
-    if (n_tiles > 0) e_req += (int64_t)tile_of(0) * tile_stride;
     auto request = [&](int slot, size_t k, int it) {
         if (walk) {
             ok_q[slot] = true;
-            sy_q[slot] = __builtin_nontemporal_load(a.symbols + e_req);
+            if constexpr (!PAIR) sy_q[slot] = __builtin_nontemporal_load(a.symbols + e_req);
             mu_q[slot] = __builtin_nontemporal_load(a.means + e_req);
             sd_q[slot] = __builtin_nontemporal_load(a.stds + e_req);
             e_req += it == kFuIters - 1 ? wrap_delta : item_stride;
@@ -427,20 +432,62 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
     }
     uint32_t bad = 0;
 
+    // PAIR: the symbols of tiles 2 m and 2 m + 1 (one 128-byte line per stream), item `it` of the even tile in [0][it]
+    int32_t sy_pair[2][kFuIters];
+    int32_t sy_cur = 0;
+    const int64_t sym_base = e_req;                           // item 0 of tile 0
+    auto stash_slot = [&](int half, int it) {
+        return ring + (((half * kFuIters + it) * 2 + (lane >> 5)) * kWave + kFuStreams + (lane & (kFuStreams - 1)));
+    };
+    auto pair_request = [&](size_t k_in_pair) {
+        const size_t even = k_in_pair & ~(size_t)1, odd = even + 1 < n_tiles ? even + 1 : even;
+        const int32_t* p0 = a.symbols + sym_base + (int64_t)even * tile_stride;
+        const int32_t* p1 = a.symbols + sym_base + (int64_t)odd * tile_stride;
+#pragma unroll
+        for (int it = 0; it < kFuIters; ++it) {
+            sy_pair[0][it] = __builtin_nontemporal_load(p0 + (int64_t)it * item_stride);
+            sy_pair[1][it] = __builtin_nontemporal_load(p1 + (int64_t)it * item_stride);
+        }
+    };
     if (n_tiles > 0) {
+        if constexpr (PAIR) pair_request(tile_of(0));
+        e_req += (int64_t)tile_of(0) * tile_stride;
 #pragma unroll
         for (int q = 0; q < kFuAhead; ++q) request(q, tile_of(0), q);
     }
-    for (size_t step = 0; step < n_tiles; ++step) {
+    size_t step = 0;
+    while (step < n_tiles) {
+      // the tiles coded before the next symbol request: both tiles of a line (PAIR), or all of them
+      size_t group_end = n_tiles;
+      if constexpr (PAIR) {
+          const size_t k = tile_of(step);
+          const bool two = KIND == kAns ? (k & 1) != 0 : k + 1 < n_tiles;       // (ANS walks down: an odd tile, then its even partner)
+          group_end = step + (two ? 2 : 1);
+#pragma unroll
+          for (int it = 0; it < kFuIters; ++it) {
+              *stash_slot(0, it) = (uint32_t)sy_pair[0][it];
+              *stash_slot(1, it) = (uint32_t)sy_pair[1][it];
+          }
+          pair_request(group_end < n_tiles ? tile_of(group_end) : k);          // (after the last pair: its own lines once more)
+      }
+      for (; step < group_end; ++step) {
         const size_t k = tile_of(step);
         wave_lds_fence();                                  // (the previous tile has been read)
+        const uint32_t* stash_k = stash_slot((int)(k & 1), 0);
+        if constexpr (PAIR) sy_cur = (int32_t)stash_k[0];
         // ---- phase A: entries of tile k ----
 #pragma unroll 1
         for (int it0 = 0; it0 < kFuIters; it0 += kFuAhead) {
 #pragma unroll
             for (int q = 0; q < kFuAhead; ++q) {
                 const int it = it0 + q;
-                const int32_t sy = ok_q[q] ? sy_q[q] : a.lo;            // (items past the matrix: never coded)
+                int32_t sy;
+                if constexpr (PAIR) {
+                    sy = sy_cur;
+                    sy_cur = (int32_t)stash_k[((it + 1) & (kFuIters - 1)) * 2 * kWave];     // (the next item's; wraps harmlessly)
+                } else {
+                    sy = ok_q[q] ? sy_q[q] : a.lo;                  // (items past the matrix: never coded)
+                }
                 const double m = ok_q[q] ? mu_q[q] : 0.0, sg = ok_q[q] ? sd_q[q] : 1.0;
                 if (it + kFuAhead < kFuIters) request(q, k, it + kFuAhead);
                 else if (step + 1 < n_tiles) request(q, tile_of(step + 1), it + kFuAhead - kFuIters);
@@ -515,6 +562,7 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
         }
         // at most kFuTile new words per stream and tile: whole chunks leave here (<= 19 pending before, < 4 after)
         if constexpr (KIND == kAns) LA.flush_chunks(); else LR.out.flush_chunks();
+      }
     }
 
     uint32_t n_words = 0;
@@ -1506,7 +1554,11 @@ static cst_status encode_gaussian_fused(cst_coder_config cfg, int32_t min_symbol
     const size_t per_block = (size_t)(kFuBlock / kWave) * kFuStreams;
     const size_t blocks = (n_streams + per_block - 1) / per_block;
     const size_t lds = kFuTabBytes + (size_t)(kFuBlock / kWave) * kFuWaveBytes;
-    if (cfg.word_bits == 32) {
+    const bool pair = layout == CST_LAYOUT_STREAM_MAJOR && n_streams % kFuStreams == 0 && n_per_stream % kFuTile == 0 && n_per_stream > 0;
+    if (cfg.word_bits == 32 && pair) {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_gaussian_fused_kernel<32, 64, KIND, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((encode_gaussian_fused_kernel<32, 64, KIND, true>), dim3((unsigned)blocks), dim3(kFuBlock), lds, hs, a);
+    } else if (cfg.word_bits == 32) {
         CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_gaussian_fused_kernel<32, 64, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((encode_gaussian_fused_kernel<32, 64, KIND>), dim3((unsigned)blocks), dim3(kFuBlock), lds, hs, a);
     } else {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): scripts/pmc_sublanes.sh <tag> -- SQ counters of the sub-lane decoders (round 5: k jump points per
-# stream, two waves per SIMD) next to the plain decoders of the same words: C3 (k = 4), range P = 12 and P = 24 (k = 2), at
+# stream, two waves per SIMD) next to the plain decoders of the same words: C3 (k = 8, four waves per SIMD), range P = 12 and P = 24 (k = 2), at
 # 65 536 x 4096.  Two rocprofv3 --pmc passes (counters never share a run with a trace) + one --kernel-trace --stats pass.
 # Output: gpurun_out/<tag>_sublane_counters.md (copy to profiles/).
 set -u
@@ -17,7 +17,7 @@ mu_d, sigma_d = bench.c3_parameters(bench.SEED, 0, n, k, "cuda")
 m3 = B.Model.quantized_gaussian_per_stream(-127, 127, mu_d, sigma_d, 12)
 sym = bench.synth_symbols_per_stream(bench.SEED, 0, k, -127, m3.cdfs_device(), 12)
 dec = torch.empty_like(sym)
-enc, ck = B.ans_encode_checkpointed(sym, m3, k // 4, (32, 64, 12))
+enc, ck = B.ans_encode_checkpointed(sym, m3, k // 8, (32, 64, 12))
 for _ in range(3):
     B.ans_decode(enc, m3, k, out=dec)
     B.ans_decode_checkpointed(enc, ck, m3, k, out=dec)

@@ -205,14 +205,16 @@ def test_fused_encoder_step_variants(B, O, P, monkeypatch):
 
 @pytest.mark.parametrize("coder", ["ans", "range"])
 @pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
-def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, monkeypatch):
+@pytest.mark.parametrize("n_per", [16, 32, 80, 96])
+def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, n_per, monkeypatch):
     """Full waves (a multiple of 32 streams) over rows of whole 16-symbol tiles: the fused Gaussian encoder then walks its three
     input matrices by adding strides to one running index per lane instead of computing every item's index (the shape of the
-    bench's f1 entry); 96 streams x 80 symbols in both layouts and both coders, words against the oracle."""
+    bench's f1 entry), and in stream-major matrices asks for the symbols of both tiles of a 128-byte line at once (one tile, one
+    pair, an odd and an even number of tiles); 96 streams in both layouts and both coders, words against the oracle."""
     monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")
     lo, hi, P = -100, 100, 24
-    n_streams, n_per = 96, 80
-    sym, mu, sd = workload(n_streams, n_per, lo, hi, 4242)
+    n_streams = 96
+    sym, mu, sd = workload(n_streams, n_per, lo, hi, 4242 + n_per)
     t = (lambda a: a.T) if layout == "symbol_major" else (lambda a: a)
     enc_fn = B.ans_encode_gaussian if coder == "ans" else B.range_encode_gaussian
     enc = enc_fn(dev(t(sym)), lo, hi, dev(t(mu)), dev(t(sd)), (32, 64, P), layout)
