@@ -676,6 +676,25 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// Every stream's words in REVERSED order: out[s][i] = in[s][n_words[s] - 1 - i].  The reference reads an ANS stream from
+    /// its END (a stack); `AnsCoder::from_reversed_compressed` (src/stream/stack.rs:734-748) and `Cursor::into_reversed`
+    /// (src/backends.rs:1424-1448; docs :774-803) are its coders over words stored last-written-first, the order in which a decoder
+    /// consumes them -- what a file or socket that is decoded while it arrives holds.  This entry point converts a batch between the
+    /// two orders (it is its own inverse); the decoders of this library take the reference's default order.
+    ///   d_offsets_in / d_offsets_out   packed layouts (offsets[s] = first word of stream s), or NULL for slabs `stride` words apart
+    /// In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream.
+    pub fn cst_words_reverse(
+        d_words_in: *const u32,
+        d_offsets_in: *const u64,
+        stride_in: usize,
+        d_n_words: *const u32,
+        n_streams: usize,
+        d_words_out: *mut u32,
+        d_offsets_out: *const u64,
+        stride_out: usize,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     /// multi-GPU: gather of the packed compressed words of every rank to one root over RCCL / xGMI (BASELINE config C5).
     /// One process per GPU; streams shard in contiguous blocks and no collective touches the coding path; this is the only
     /// exchange step.  The library opens librccl at first use (no link-time dependency); `comm` is an ncclComm_t -- the

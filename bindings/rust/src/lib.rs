@@ -366,6 +366,25 @@ pub fn compact(encoded: EncodedBatch, stream: &Stream) -> Result<PackedBatch> {
     Ok(PackedBatch { words: packed, offsets, n_words: encoded.n_words, n_streams: n, config: encoded.config })
 }
 
+/// Every stream's words in the opposite order, in place (its own inverse): between the reference's default order and the one
+/// `AnsCoder::from_reversed_compressed` / `Cursor::into_reversed` use (src/stream/stack.rs:734-748, src/backends.rs:1424-1448).
+pub fn reverse_words(encoded: &mut EncodedBatch, stream: &Stream) -> Result<()> {
+    let words = encoded.words.as_mut_ptr();
+    check(unsafe {
+        ffi::cst_words_reverse(
+            words as *const u32,
+            std::ptr::null(),
+            encoded.stride_words,
+            encoded.n_words.as_ptr(),
+            encoded.n_streams,
+            words,
+            std::ptr::null(),
+            encoded.stride_words,
+            stream.as_raw(),
+        )
+    })
+}
+
 /// Slabs of PACKED 16-bit words (`CST_FLAG_PACKED_W16`: the `(16, 32)` preset with its words as the reference's `Vec<u16>`,
 /// src/stream/stack.rs:153): every count, stride and offset is in 16-bit words.
 pub struct EncodedBatch16 {

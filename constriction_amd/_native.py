@@ -99,6 +99,7 @@ SIGNATURES = {
     "cst_ans_count_until_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _i32, _z, _vp, _vp, _vp]),
     "cst_compact_scratch_bytes": (_z, [_z]),
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
+    "cst_words_reverse": (_i32, [_vp, _vp, _z, _vp, _z, _vp, _vp, _z, _vp]),
     "cst_rccl_get_unique_id": (_i32, [_vp]),
     "cst_rccl_comm_init": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "cst_rccl_comm_destroy": (_i32, [_vp]),

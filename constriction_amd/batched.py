@@ -631,6 +631,30 @@ def compact(encoded: EncodedBatch, capacity: Optional[int] = None, out=None):
     return packed, offsets
 
 
+def reverse_words(encoded, offsets: Optional[torch.Tensor] = None, out=None):
+    """Every stream's words in the opposite order (its own inverse): from the reference's default order -- the LAST word of a
+    stream is the first an ANS decoder reads -- to the order `AnsCoder::from_reversed_compressed` / `Cursor::into_reversed`
+    (src/stream/stack.rs:734-748, src/backends.rs:1424-1448) use, first-read word first, and back.
+
+    `encoded`: an `EncodedBatch` of (32, 64) slabs -> a new `EncodedBatch` (or `out=encoded` for in place); or a tuple
+    `(packed int32 words, n_words)` with `offsets` int64[n_streams + 1] -> a packed tensor of the same layout."""
+    if isinstance(encoded, EncodedBatch):
+        if encoded.packed16:
+            raise ValueError("reverse_words: 32-bit words only")
+        n_streams = encoded.n_words.numel()
+        res = out if out is not None else EncodedBatch(torch.empty_like(encoded.words), encoded.n_words, encoded.status, encoded.config)
+        N.check(N.lib().cst_words_reverse(_ptr(encoded.words), None, encoded.words.shape[1], _ptr(encoded.n_words), n_streams,
+                                          _ptr(res.words), None, res.words.shape[1], _stream_ptr()), "cst_words_reverse")
+        return res
+    packed, n_words = encoded
+    if offsets is None:
+        raise ValueError("reverse_words: packed words need their offsets")
+    res = out if out is not None else torch.empty_like(packed)
+    N.check(N.lib().cst_words_reverse(_ptr(packed), _ptr(offsets), 0, _ptr(n_words), n_words.numel(), _ptr(res), _ptr(offsets), 0,
+                                      _stream_ptr()), "cst_words_reverse")
+    return res
+
+
 def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
     return N.load_library().cst_range_max_words(n_per_stream, _cfg(*config))
 

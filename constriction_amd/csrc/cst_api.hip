@@ -224,6 +224,23 @@ __global__ __launch_bounds__(kCompactThreads) void compact_kernel(const uint32_t
 
 using namespace cst;
 
+// a wave per stream swaps word i with word n - 1 - i (so the same buffer may be both sides)
+__global__ __launch_bounds__(kBlock) void words_reverse_kernel(const uint32_t* in, const uint64_t* __restrict__ off_in, size_t stride_in,
+                                                               const uint32_t* __restrict__ n_words, size_t n_streams, uint32_t* out,
+                                                               const uint64_t* __restrict__ off_out, size_t stride_out) {
+    const size_t s = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (s >= n_streams) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t n = n_words[s];
+    const uint32_t* src = in + (off_in ? (size_t)off_in[s] : s * stride_in);
+    uint32_t* dst = out + (off_out ? (size_t)off_out[s] : s * stride_out);
+    for (uint32_t i = (uint32_t)lane; i < (n + 1) / 2; i += kWave) {
+        const uint32_t a = src[i], b = src[n - 1 - i];
+        dst[i] = b;
+        dst[n - 1 - i] = a;
+    }
+}
+
 extern "C" {
 
 int32_t cst_abi_version(void) { return CST_ABI_VERSION; }
@@ -392,6 +409,18 @@ cst_status cst_ans_count_until(const cst_model* model, cst_coder_config cfg, con
                                int32_t eof_symbol, size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, void* stream) {
     return cst_ans_count_until_ordered(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, n_streams, nullptr,
                                        eof_symbol, max_symbols, d_lengths, d_status, stream);
+}
+
+cst_status cst_words_reverse(const uint32_t* d_words_in, const uint64_t* d_offsets_in, size_t stride_in, const uint32_t* d_n_words,
+                             size_t n_streams, uint32_t* d_words_out, const uint64_t* d_offsets_out, size_t stride_out, void* stream) {
+    if (n_streams == 0) return CST_OK;
+    if (!d_words_in || !d_words_out || !d_n_words) return CST_ERR_INVALID_ARGUMENT;
+    const size_t n_blocks = (n_streams + kBlock / kWave - 1) / (kBlock / kWave);
+    if (n_blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(words_reverse_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_words_in, d_offsets_in, stride_in,
+                       d_n_words, n_streams, d_words_out, d_offsets_out, stride_out);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 size_t cst_compact_scratch_bytes(size_t n_streams) {

@@ -425,6 +425,17 @@ cst_status cst_compact_words16(const uint16_t *d_words16, size_t stride_words, c
                                size_t n_streams, uint64_t *d_offsets, uint16_t *d_packed16,
                                size_t packed_capacity, void *d_scratch, void *stream);
 
+/* Every stream's words in REVERSED order: out[s][i] = in[s][n_words[s] - 1 - i].  The reference reads an ANS stream from
+ * its END (a stack); `AnsCoder::from_reversed_compressed` (src/stream/stack.rs:734-748) and `Cursor::into_reversed`
+ * (src/backends.rs:1424-1448; docs :774-803) are its coders over words stored last-written-first, the order in which a decoder
+ * consumes them -- what a file or socket that is decoded while it arrives holds.  This entry point converts a batch between the
+ * two orders (it is its own inverse); the decoders of this library take the reference's default order.
+ *   d_offsets_in / d_offsets_out   packed layouts (offsets[s] = first word of stream s), or NULL for slabs `stride` words apart
+ * In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream. */
+cst_status cst_words_reverse(const uint32_t *d_words_in, const uint64_t *d_offsets_in, size_t stride_in,
+                             const uint32_t *d_n_words, size_t n_streams, uint32_t *d_words_out,
+                             const uint64_t *d_offsets_out, size_t stride_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * multi-GPU: gather of the packed compressed words of every rank to one root over RCCL / xGMI (BASELINE config C5).
  * One process per GPU; streams shard in contiguous blocks and no collective touches the coding path; this is the only

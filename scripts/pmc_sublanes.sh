@@ -61,8 +61,8 @@ for f in glob.glob("gpurun_out/${tag}_sub_stats/*kernel_stats.csv"):
 norm = 65536 * 4096 / 64
 print("# ${tag}: SQ counters of the sub-lane decoders next to the plain decoders of the same words (65 536 x 4096)\n")
 print("scripts/pmc_sublanes.sh: rocprofv3 --pmc in two passes, medians over the launches of a kernel; per symbol and wave = counter / (1024 x 4096)")
-print("wave-symbols (cycle counters x 4: they count in units of four cycles).  C3: k = 4 jump points per stream; range: k = 2.  Two resident")
-print("waves per SIMD in the sub-lane kernels, one in the plain ones -- WAVE_CYCLES per wave-symbol is the residence time of a wave, the time")
+print("wave-symbols (cycle counters x 4: they count in units of four cycles).  C3: k = 8 jump points per stream (FOUR resident waves per SIMD); range: k = 2.  Two resident")
+print("waves per SIMD in the range sub-lane kernels, one in the plain ones -- WAVE_CYCLES per wave-symbol is the residence time of a wave, the time")
 print("per symbol of the SIMD is WAVE_CYCLES / resident waves.\n")
 cols = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES"]
 cyc = {"SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"}
