@@ -363,31 +363,53 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
 
 
 def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
-    """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8): the
-    matrix is widened / narrowed on the device next to the coder call (cst_ans_*_batch_sym).  Algorithmic bytes: 1 B per symbol
-    + 4 B per word each way; the TRAFFIC of this form is 1 + 4 + 4 B per symbol (conversion kernel + coder kernel), which is why
-    the entry's fractions are low -- the saving is on the link (`end_to_end.int8_symbols`), not here."""
+    """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8).
+    int8 (round 5): the hand-scheduled loops read / write the int8 matrix themselves (ans_encode_pc_n8_kernel / ans_decode_n8_kernel:
+    cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 B per symbol + 4 B per word each way, and that is the traffic; the
+    kernels are bound by instruction issue, not by HBM (one wave per SIMD: DESIGN.md 4.13), so their HBM fractions are low by
+    construction.  `conversion_path`: the same call with CST_NO_N8=1 -- widened / narrowed by a streaming kernel next to the int32
+    coder kernels (what int16 matrices and the shapes the native kernels do not take still use)."""
+    import os
     n_streams, n_per = symbols.shape
     cfg = (W, S, P)
     narrow = symbols.to(dtype)
     nb = narrow.element_size()
     enc = B.ans_encode(narrow, model, cfg)
+    enc_kernel = B.last_kernel()
     decoded = torch.empty_like(narrow)
+    B.ans_decode(enc, model, n_per, out=decoded)
+    dec_kernel = B.last_kernel()
     enc_ms = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
     dec_ms = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
     total_words = enc.total_words()
     byts = nb * n_streams * n_per + 4 * total_words
-    entry = {"workload": f"C2 with {str(dtype).replace('torch.', '')} symbol matrices (widened / narrowed on the device next to the coder call)",
+    native = enc_kernel.endswith("n8_kernel")
+    entry = {"workload": f"C2 with {str(dtype).replace('torch.', '')} symbol matrices " +
+                         ("(read / written by the coder loops themselves)" if native else "(widened / narrowed on the device next to the coder call)"),
              "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
+             "encode_kernel": enc_kernel, "decode_kernel": dec_kernel,
              "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_streams * n_per / (enc_ms + dec_ms) / 1e3, 1),
+             "slab_stride_words": int(enc.words.shape[1]),
              "algorithmic_bytes_per_symbol": round(byts / (n_streams * n_per), 3),
              "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    if native:
+        entry["bound"] = "instruction issue of one wave per SIMD (not HBM): see DESIGN.md 4.13"
     if check:
         plain = B.ans_encode(symbols, model, cfg)
         used = torch.arange(plain.words.shape[1], device=symbols.device)[None, :] < plain.n_words[:, None]
         entry["bit_exact"] = bool(torch.equal(decoded, narrow)) and bool(torch.equal(enc.n_words, plain.n_words)) and \
             bool(((enc.words == plain.words) | ~used).all()) and int(enc.status.abs().sum().item()) == 0
         entry["bit_exact_scope"] = "words and counts of every stream vs the int32 call's (compared with the CPU oracle in the headline check), decoded symbols vs input"
+    if native:
+        os.environ["CST_NO_N8"] = "1"
+        try:
+            c_enc = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
+            ck = B.last_kernel()
+            c_dec = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
+            entry["conversion_path"] = {"encode_ms": round(c_enc, 4), "decode_ms": round(c_dec, 4), "coder_kernels": [ck, B.last_kernel()],
+                                        "Msymbols_per_s": round(n_streams * n_per / (c_enc + c_dec) / 1e3, 1)}
+        finally:
+            del os.environ["CST_NO_N8"]
     return entry
 
 
@@ -732,6 +754,13 @@ def other_configs(B, rank, world, dist, args, reps=5):
                          stride="tuned" if args.slab_stride == "tuned" else None)
     packed, offsets = B.compact(enc5)
     e["compact_ms"] = round(event_ms(lambda: B.compact(enc5, out=(packed, offsets)), reps), 4)
+    if world == 1:
+        try:      # the shard as an int8 matrix: a quarter of the symbol bytes of a batch that never fits the caches
+            e8 = narrow_config(B, m12, sym5, reps, check)
+            e["int8_symbols"] = {k: e8[k] for k in ("encode_ms", "decode_ms", "Msymbols_per_s", "encode_kernel", "decode_kernel", "bit_exact",
+                                                    "conversion_path") if k in e8}
+        except Exception as exc:      # noqa: BLE001
+            e["int8_symbols"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if dist is not None and not args.no_gather:
         from constriction_amd import dist as D
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()

@@ -1367,6 +1367,11 @@ cst_status ans_decode_generic(const cst_model* m, cst_coder_config cfg, const ui
 // producer / consumer waves for batches of at most one wave of streams per SIMD (cst_ans_pc.hip)
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus);
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs);
+// int8 symbol matrices inside the loops (cst_ans_n8.hip)
+bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);
+cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs);
+bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
+cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs);
 // lane-quad word loads for the P <= 12 decoder (cst_ans_dq.hip)
 bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_dq(const AnsDecodeArgs& a, hipStream_t hs);

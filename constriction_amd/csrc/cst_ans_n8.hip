@@ -1,0 +1,131 @@
+// cst_ans_n8.hip -- the shared-table ANS coder (W,S) = (32,64), 8 <= P <= 12, on INT8 symbol matrices (round 5).
+//
+// The reference's coders are generic over the symbol type (`Symbol: PrimInt + AsPrimitive<Probability> + ...`,
+// src/stream/model/quantize.rs:229-255): the 101-symbol alphabet of config C2 travels as i8 there if the caller says so.  Until this
+// file a narrow matrix was widened / narrowed by a streaming kernel next to the coder call (cst_symbols.hip: 5 more bytes of HBM
+// traffic per symbol, 0.27 + 0.39 ms at 65 536 x 4096 on top of 0.25 + 0.25 ms of coding).  Here the int8 matrix is what the
+// hand-scheduled loops read and write:
+//   decode (ans_decode_n8_kernel, cst_decode_loop_n8.inc): a decoded quad is packed into one dword and written into the lane's row
+//     of a BYTE tile (rows of 128 symbols: one cache line of the matrix); a loop pass is four 32-symbol tiles, and the previous
+//     group of 128 symbols leaves in its shadow, eight whole 128-byte lines per store instruction, two stores per tile.
+// Same recurrence (stack.rs:1070-1100), same read positions, states and status as ans_decode_kernel; the symbols are its symbols
+// as int8 (the callers check that the model's support fits).  Shapes these kernels do not take (rows that are not whole aligned
+// 128-symbol groups, partial waves, symbol-major batches, int16) stay on the conversion path.
+#include <cstdlib>
+
+#include "cst_ans_kernels.hpp"
+
+namespace cst {
+
+constexpr int kN8GroupSyms = 128;                                          // symbols per row of a byte tile = one line of the matrix
+constexpr int kN8RowBytes = 132;                                           // + one word of padding: conflict-free b32 writes and reads
+constexpr size_t kN8Waves = kBlock / kWave;
+constexpr size_t kN8RingWaveBytes = (size_t)kDecRingSlots * kWave * 4;     // 8 KiB, 8-KiB aligned
+constexpr size_t kN8TileBytes = (size_t)kWave * kN8RowBytes;               // 8448 B per buffer and wave
+constexpr size_t kN8LutOff = kN8Waves * kN8RingWaveBytes;
+constexpr size_t kN8TileOff = kN8LutOff + kTileLutBytes;
+constexpr size_t kN8DumpOff = kN8TileOff + 2 * kN8Waves * kN8TileBytes;
+constexpr size_t kN8LdsBytes = kN8DumpOff + kTileDumpBytes;
+static_assert(kN8LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(kN8TileBytes % 4 == 0 && kN8TileOff % 16 == 0, "tile alignment");
+
+__device__ __forceinline__ void ans_decode_n8_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur,
+                                                   uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask,
+                                                   uint32_t P, uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t n_groups,
+                                                   uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
+                                                   const uint32_t (&goff)[8]) {
+#include "cst_decode_loop_n8.inc"
+}
+
+// LDS: [word rings: 4 x 8 KiB][cp + sym tables 32 KiB][two byte tiles per wave (all A, then all B)][dump rows]
+__global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    DecLut lut{};
+    stage_tile_tables(smem + kN8LutOff, P, a.dec_cp, a.dec_idx, a.min_symbol, lut);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + wave_in_block * kN8RingWaveBytes);
+    unsigned char* tile_a = smem + kN8TileOff + wave_in_block * kN8TileBytes;
+    unsigned char* tile_b = tile_a + kN8Waves * kN8TileBytes;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kN8DumpOff) + wave_in_block * (4 * kWave) + lane;
+    __syncthreads();
+
+    const size_t s0 = ((size_t)blockIdx.x * kBlock + (size_t)wave_in_block * kWave);
+    if (s0 >= a.n_streams) return;                       // (the launcher only takes whole waves)
+    const size_t s = s0 + lane;
+    const size_t N = a.n_per_stream;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);   // (the int8 matrix travels in the int32 field of the argument block)
+
+    DecLane<32, 64, kDecRingSlots, kDecAhead> L;
+    const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
+    L.init(a.words + ws.off, ws.n, ring, lane);
+    if (raw) L.state = a.state[s];
+    else L.read_initial_state();
+    L.in.prime();
+    wave_lds_fence();
+
+    if ((lds_addr(ring) & (uint32_t)(kN8RingWaveBytes - 1)) != 0) __builtin_trap();      // (ring addresses are formed with v_and_or)
+    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+    const uint32_t qmask = (1u << P) - 1u;
+    const uint32_t lut_addr = lds_addr(lut.cp), lane_addr = lds_addr(ring + lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): nothing of the prologue in flight when the statement keeps its own book
+    const uint32_t n_g = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kN8GroupSyms));
+
+    const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+    const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+    uint32_t goff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
+    const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
+    uint32_t row_cur = lds_addr(tile_a) + (uint32_t)(lane * kN8RowBytes), row_prev = lds_addr(tile_b) + (uint32_t)(lane * kN8RowBytes);
+    uint32_t tr_cur = lds_addr(tile_a) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
+    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * N);
+    const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+    ans_decode_n8_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P, kDecRingMask, words_base,
+                       store_base, n_g, L.in.shift - 1u, lane_addr, lds_addr(dump), w_off, goff);
+    // the last group is still in LDS: the statement swapped the buffers behind it, so it is the "previous" one
+    wave_lds_fence();
+    {
+        const unsigned char* last = ((n_g - 1) & 1) ? tile_b : tile_a;
+        int8_t* dst = out + s0 * N + (size_t)(n_g - 1) * kN8GroupSyms;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(last + ((lane >> 3) + 8 * k) * kN8RowBytes + 16 * (lane & 7));
+            v4i v;
+            v.x = (int)src[0]; v.y = (int)src[1]; v.z = (int)src[2]; v.w = (int)src[3];
+            __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(dst + goff[k]));
+        }
+    }
+
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+    if (raw) {
+        a.state[s] = ((uint64_t)hi << 32) | lo;
+        if (a.n_words_out) a.n_words_out[s] = L.in.rd;
+    }
+}
+
+// Whole waves, rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
+bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
+    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (!a.dec_cp || !a.dec_idx) return false;
+    if (a.n_streams == 0 || a.n_streams % kWave != 0) return false;
+    if (a.n_per_stream % kN8GroupSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
+    if (a.offsets && a.words_capacity == 0) return false;                                          // the lanes' 32-bit word offsets need a known span
+    const uint64_t span = a.offsets ? a.words_capacity : (uint64_t)a.n_streams * a.stride_words;
+    return span * 4 + 256 < 0x80000000ull;
+}
+
+cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_n8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8LdsBytes));
+    hipLaunchKernelGGL(ans_decode_n8_kernel, dim3((unsigned)blocks), dim3(kBlock), kN8LdsBytes, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+} // namespace cst

@@ -66,36 +66,17 @@ __device__ __forceinline__ void ans_encode_pc_storer_loop(uint32_t (&flushed)[2]
 // __syncthreads(): its fence would also wait for the helper's symbol loads, which are requested tiles ahead on purpose.)
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// the helper waves of a workgroup split by role: waves 4, 5 load and stage the tiles of coder waves (0, 1), (2, 3); waves 6, 7
-// flush their rings and finish their streams
-__device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned char* smem, int wave, int lane, uint32_t n_t) {
-    const size_t N = a.n_per_stream;
+// the storer waves (6, 7; each for the coder waves cw0, cw0 + 1): complete 64-byte groups ring -> slab while the coders run, then
+// the ends of the streams.  Shared by the int32 and the int8 kernel (their rings and hand-off areas look alike).
+__device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char* smem, int lane, int cw0, size_t s0, uint32_t n_t,
+                                          size_t ring_off, size_t hand_off_) {
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
-    const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
-    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
-    if (wave < kPcWaves + 2) {                          // ---- loader ----
-        uint32_t goff[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
-        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (size_t)(n_t - 1) * kTileSyms);
-        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
-                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-        const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
-        const uint32_t t0 = lds_addr(smem + kPcTileOff + (2 * cw0) * kPcTileBytes) + tr_off;
-        const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcTileBytes};
-        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N * 4));
-        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
-        ans_encode_pc_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
-        pc_barrier();
-        return;
-    }
-    // ---- storer ----
     uint32_t* ring[2]; uint32_t* hand[2];
     uint32_t ring_addr[2], pub_addr[2], slab_off[2], flushed[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        ring[c] = reinterpret_cast<uint32_t*>(smem + kPcRingOff + (cw0 + c) * kPcRingWaveBytes);
-        hand[c] = reinterpret_cast<uint32_t*>(smem + kPcHandOff + (cw0 + c) * kPcHandWaveBytes);
+        ring[c] = reinterpret_cast<uint32_t*>(smem + ring_off + (cw0 + c) * kPcRingWaveBytes);
+        hand[c] = reinterpret_cast<uint32_t*>(smem + hand_off_ + (cw0 + c) * kPcHandWaveBytes);
         hand[c][lane] = 0;                              // nothing published yet
         ring_addr[c] = lds_addr(ring[c] + lane);
         pub_addr[c] = lds_addr(hand[c] + lane);
@@ -118,6 +99,31 @@ __device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned
         a.status[s] = status;
         a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
     }
+}
+
+// the helper waves of a workgroup split by role: waves 4, 5 load and stage the tiles of coder waves (0, 1), (2, 3); waves 6, 7
+// flush their rings and finish their streams
+__device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned char* smem, int wave, int lane, uint32_t n_t) {
+    const size_t N = a.n_per_stream;
+    const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
+    if (wave < kPcWaves + 2) {                          // ---- loader ----
+        uint32_t goff[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (size_t)(n_t - 1) * kTileSyms);
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
+        const uint32_t t0 = lds_addr(smem + kPcTileOff + (2 * cw0) * kPcTileBytes) + tr_off;
+        const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcTileBytes};
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N * 4));
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
+        ans_encode_pc_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
+        pc_barrier();
+        return;
+    }
+    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcHandOff);
 }
 
 template <bool SPLIT>
@@ -186,6 +192,108 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
     if (raw) a.state[s] = (uint64_t)L.state;
     a.status[s] = status;
     a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// INT8 symbol matrices (round 5; scripts/gen_encode_loop_pc.py, "INT8 symbol matrices"): the same producer / consumer workgroup
+// over byte tiles.  A row of the matrix is int8 -- a 128-byte line is FOUR tiles -- so the loader stages whole lines (two row
+// blocks per window), the coder reads a quad as one dword and forms each table address with one SDWA shift of the sign-extended
+// byte against a 256-entry table centred at LDS address 2048.  A quarter of the symbol bytes from HBM, no conversion kernel, no
+// scratch; words, counts and status are those of the int32 kernels on the widened values.
+//   LDS: [table: 256 entries, symbol s at 2048 + 16 s][rings 4 x 16 KiB at 16 KiB][two line buffers per coder wave][hand-off]
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPcN8RowBytes = 132;                                        // 128 symbols + one word of padding (conflict-free b32 accesses)
+constexpr int kPcN8LineSyms = 128;
+constexpr size_t kPcN8LineBytes = (size_t)kWave * kPcN8RowBytes;          // 8448 B per line buffer
+constexpr size_t kPcN8TileOff = kPcRingOff + kPcWaves * kPcRingWaveBytes;
+constexpr size_t kPcN8HandOff = kPcN8TileOff + kPcWaves * 2 * kPcN8LineBytes;
+constexpr size_t kPcN8LdsBytes = kPcN8HandOff + kPcWaves * kPcHandWaveBytes;
+static_assert(kPcN8LdsBytes <= 160 * 1024 && 256 * sizeof(EncEntry) <= kPcTableBytes, "LDS budget");
+
+__device__ __forceinline__ void ans_encode_pc_n8_coder_loop(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, uint32_t line_row_addr,
+                                                            uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_n8.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_n8_loader_loop(const uint32_t (&line_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
+                                                             uint32_t n_tiles, const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_pc_loader_n8.inc"
+}
+
+__global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsEncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int cw = wave & (kPcWaves - 1);
+    const int P = a.precision;
+    const size_t N = a.n_per_stream;
+    const uint32_t n_t = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms));
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const int8_t* symbols = reinterpret_cast<const int8_t*>(a.symbols);      // (the int8 matrix travels in the int32 field of the argument block)
+
+    // the table, by symbol VALUE: entry of symbol s at 2048 + 16 s (a value outside the support: some harmless entry -- its
+    // stream is flagged by the range check and its words are never used)
+    if (lds_addr(smem) != 0) __builtin_trap();          // (the coder's table reads carry the table's address as an immediate)
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
+    for (int u = threadIdx.x; u < 256; u += kPcThreads) {
+        const int idx = (u - 128) - a.min_symbol;
+        table[u] = pack_entry(a.enc[(idx >= 0 && idx < a.n_symbols) ? idx : 0], P);
+    }
+
+    if (wave < kPcWaves) {                               // ---- coder ----
+        uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
+        uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcN8HandOff + cw * kPcHandWaveBytes);
+        const size_t s = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave + lane;
+        uint32_t lo = 0, hi = 0;
+        int32_t smin = 16 * a.min_symbol, smax = smin;  // (the statement folds the table ADDRESSES 16 * symbol)
+        if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
+        const uint32_t row_addr = lds_addr(smem + kPcN8TileOff + (2 * cw) * kPcN8LineBytes) + (uint32_t)(lane * kPcN8RowBytes);
+        pc_barrier();                                   // table and the first line are in LDS
+        ans_encode_pc_n8_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t);
+        hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
+        hand[3 * kWave + lane] = max((uint32_t)((smax >> 4) - a.min_symbol), (uint32_t)((smin >> 4) - a.min_symbol));
+        pc_barrier();                                   // the last window and the final state are published
+        return;
+    }
+    const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
+    if (wave < kPcWaves + 2) {                          // ---- loader ----
+        uint32_t goff[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + s0 * N + (N - kPcN8LineSyms));
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t t0 = lds_addr(smem + kPcN8TileOff + (2 * cw0) * kPcN8LineBytes) + (uint32_t)((lane >> 3) * kPcN8RowBytes + 16 * (lane & 7));
+        const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcN8LineBytes};
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N));
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
+        ans_encode_pc_n8_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
+        pc_barrier();
+        return;
+    }
+    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
+}
+
+// Whole workgroups of 256 streams, rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel.
+bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
+    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (a.n_streams == 0 || a.n_streams % kBlock != 0) return false;
+    if (a.n_per_stream % kPcN8LineSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
+    if (a.n_streams * a.stride_words * 4 >= 0x100000000ull) return false;                                                  // 32-bit slab offsets
+    if (a.n_symbols < 1 || a.n_symbols > 256 || a.min_symbol < -128 || a.min_symbol + a.n_symbols - 1 > 127) return false;
+    return true;
+}
+
+cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs) {
+    const size_t blocks = a.n_streams / kBlock;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_pc_n8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
+    hipLaunchKernelGGL(ans_encode_pc_n8_kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 // Whole workgroups of 256 streams, at most one per CU (more streams than that: the two-waves-per-SIMD kernels of

@@ -449,3 +449,44 @@ cst_status cst_compact_words(const uint32_t* d_words, size_t stride_words, const
 }
 
 } // extern "C"
+
+namespace cst {
+
+// int8 symbol matrices inside the hand-scheduled loops (cst_ans_n8.hip).  Returns false if the shape is not theirs (the caller
+// then converts next to the int32 kernels: cst_symbols.hip); otherwise *rc is the call's status.
+bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
+                           size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, size_t n_streams, size_t n_per_stream,
+                           cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream,
+                           cst_status* rc) {
+    if (!model || !d_n_words || !d_status || !d_symbols8 || n_streams == 0 || model->per_stream || model->d_symbol_of_index) return false;
+    if (!config_supported(cfg) || cfg.precision != model->precision || !on_model_device(model)) return false;
+    if ((flags & ~(uint32_t)(CST_FLAG_RAW_STATE | CST_FLAG_COLD_WORDS)) != 0 || ((flags & CST_FLAG_RAW_STATE) && !d_state)) return false;
+    AnsDecodeArgs a{};
+    a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words;
+    a.symbols = reinterpret_cast<int32_t*>(d_symbols8);
+    a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
+    a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
+    a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
+    a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
+    if (!n8_decode_usable(a, cfg, layout)) return false;
+    *rc = note_kernel("ans_decode_n8_kernel", ans_decode_n8(a, (hipStream_t)stream));
+    return true;
+}
+
+bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void* d_symbols8, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                       uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags,
+                       void* stream, cst_status* rc) {
+    if (!model || !d_words || !d_n_words || !d_status || !d_symbols8 || n_streams == 0 || model->per_stream || model->d_symbol_of_index) return false;
+    if (!config_supported(cfg) || cfg.precision != model->precision || !on_model_device(model)) return false;
+    if ((flags & ~(uint32_t)CST_FLAG_RAW_STATE) != 0 || ((flags & CST_FLAG_RAW_STATE) && !d_state)) return false;
+    AnsEncodeArgs a{};
+    a.symbols = reinterpret_cast<const int32_t*>(d_symbols8); a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.status = d_status;
+    a.flags = flags;
+    if (!pc_n8_encode_usable(a, cfg, layout)) return false;
+    *rc = note_kernel("ans_encode_pc_n8_kernel", ans_encode_pc_n8(a, (hipStream_t)stream));
+    return true;
+}
+
+} // namespace cst

@@ -133,7 +133,13 @@ cst_status cst_ans_encode_batch_sym(const cst_model* model, cst_coder_config cfg
     if (symbol_bytes == 4)
         return cst_ans_encode_batch(model, cfg, reinterpret_cast<const int32_t*>(d_symbols), n_streams, n_per_stream, layout, d_words, stride_words,
                                     d_n_words, d_state, d_status, flags, stream);
-    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || (!d_scratch && n_streams * n_per_stream > 0)) return CST_ERR_INVALID_ARGUMENT;
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2)) return CST_ERR_INVALID_ARGUMENT;
+    if (symbol_bytes == 1) {                   // int8 inside the hand-scheduled loops where the shape allows it (cst_ans_pc.hip): no scratch, no second kernel
+        cst_status rc8 = CST_OK;
+        if (ans_encode_n8_try(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status, flags, stream, &rc8))
+            return rc8;
+    }
+    if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
     int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
     const cst_status rc = cst_symbols_widen(d_symbols, symbol_bytes, n_streams * n_per_stream, wide, stream);
     if (rc != CST_OK) return rc;
@@ -147,8 +153,15 @@ cst_status cst_ans_decode_batch_sym(const cst_model* model, cst_coder_config cfg
     if (symbol_bytes == 4)
         return cst_ans_decode_batch(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, reinterpret_cast<int32_t*>(d_symbols),
                                     n_streams, n_per_stream, layout, d_state, d_n_words_out, d_status, flags, stream);
-    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || (!d_scratch && n_streams * n_per_stream > 0)) return CST_ERR_INVALID_ARGUMENT;
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2)) return CST_ERR_INVALID_ARGUMENT;
     if (!support_fits(model, symbol_bytes)) return CST_ERR_INVALID_ARGUMENT;      // a decoded symbol must be storable
+    if (symbol_bytes == 1) {                   // int8 inside the loops where the shape allows it (cst_ans_n8.hip): no scratch, no second kernel
+        cst_status rc = CST_OK;
+        if (ans_decode_n8_try(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+                              d_state, d_n_words_out, d_status, flags, stream, &rc))
+            return rc;
+    }
+    if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
     int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
     const cst_status rc = cst_ans_decode_batch(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, wide, n_streams, n_per_stream,
                                                layout, d_state, d_n_words_out, d_status, flags, stream);

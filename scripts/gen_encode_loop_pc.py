@@ -601,10 +601,216 @@ def main_split():
     print(f"wrote {OUT_STORER} ({a.n_instr()} instructions incl. prologue)")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# INT8 symbol matrices (round 5: cst_encode_loop_pc_n8.inc / cst_encode_loop_pc_loader_n8.inc, ans_encode_pc_n8_kernel).
+# A row of the matrix is int8, so a 128-byte line holds FOUR tiles.  The loader stages whole lines into byte tiles (rows of 128
+# symbols + 4 bytes of padding: 33 words, conflict-free for the b32 accesses of both sides), two row blocks per window; the coder
+# reads a quad as ONE dword and forms a table address per symbol with one SDWA shift of the sign-extended byte,
+#     v_lshlrev_b32_sdwa ea, 4, sext(quad) src1_sel:BYTE_k     ->     ds_read_b128 entry, ea offset:2048
+# against a 256-entry table centred at LDS address 2048 (the LDS address adder wraps: scripts/microbench/ds_wrap.hip) -- the
+# instruction the int32 form spends on  symbol * 16 + table.  The range check folds the four ADDRESSES (16 * symbol, signed)
+# instead of the four symbols.  Same steps, same ring, same hand-off; the storer waves are those of the int32 kernel.
+# The loop body still holds two tiles: the tile pointers live in two registers that leapfrog (one v_add per tile; every fourth
+# step jumps to the other line buffer: the jump alternates between J and 192 - J and comes from the scalar side).
+# ---------------------------------------------------------------------------------------------------------------------
+OUT_N8 = CSRC / "cst_encode_loop_pc_n8.inc"
+OUT_LOADER_N8 = CSRC / "cst_encode_loop_pc_loader_n8.inc"
+N8_ROW = 132                       # kN8RowBytes
+N8_LINEBUF = 64 * N8_ROW           # one line buffer of a coder wave: 8448 bytes
+S8 = [f"v{100 + i}" for i in range(4)]
+EA8 = [[f"v{104 + 4 * e + i}" for i in range(4)] for e in range(2)]
+PA, PB = "v112", "v113"
+N8_CLOBBERS = [f"v{r}" for r in range(100, 114)] + [f"v{r}" for r in range(116, 170)] + ["s82", "s83", "s84", "s85", "s86", "s87", "s88", "vcc", "memory"]
+
+
+def n8_read_syms(a, g, ptr, quad):
+    a.ds(f"ds_read_b32 {S8[g % 4]}, {ptr} offset:{4 * quad}", f"S{g}")
+
+
+def n8_fetch_entries(a, g):
+    for i, b in enumerate((3, 2, 1, 0)):       # consumption order: the quad's last symbol first
+        a.i(f"v_lshlrev_b32_sdwa {EA8[g % 2][i]}, %[four], sext({S8[g % 4]}) {SDWA} src0_sel:DWORD src1_sel:BYTE_{b}", "16 * symbol")
+        a.ds(f"ds_read_b128 {E_T[g % 2][i]}, {EA8[g % 2][i]} offset:2048", f"E{g}")
+
+
+def n8_fold_minmax(a, g):
+    """the range check, on the ADDRESSES 16 * symbol of the quad being coded (not on those fetched ahead: past the last tile they
+    are whatever the line buffer holds)"""
+    x, y, z, w = EA8[g % 2]
+    a.i(f"v_max3_i32 %[smax], %[smax], {x}, {y}")
+    a.i(f"v_max3_i32 %[smax], %[smax], {z}, {w}")
+    a.i(f"v_min3_i32 %[smin], %[smin], {x}, {y}")
+    a.i(f"v_min3_i32 %[smin], %[smin], {z}, {w}")
+
+
+def n8_half(a, cur, nxt, g0, delta):
+    """one tile at pointer `cur` (the next tile's at `nxt`), global quad indices g0 .. g0+7 stand for quads 7 .. 0"""
+    a.i(f"; ---- tile at {cur}")
+    for j in range(8):
+        g, quad = g0 + j, 7 - j
+        if quad == 1:
+            hand_off(a)
+        if f"S{g + 1}" in a.lds:
+            a.wait_lds(f"S{g + 1}", f"quad {quad}: symbols of the next quad are back", cap=True)
+        far = quad - 2
+        n8_read_syms(a, g + 2, cur if far >= 0 else nxt, far if far >= 0 else far + 8)
+        n8_fetch_entries(a, g + 1)
+        if f"E{g}" in a.lds:
+            a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
+        n8_fold_minmax(a, g)
+        for c, p, m0, m1 in E[g % 2]:
+            step(a, c, p, m0, m1)
+    a.i(f"v_add_u32 {cur}, {delta}, {nxt}", "leapfrog: the tile after the next")
+
+
+def gen_n8():
+    a = Asm()
+    a.i(f"v_mov_b32 {W1}, 0")
+    a.i(f"v_mov_b32 {LO}, %[lo]")
+    a.i(f"v_mov_b32 {HI}, %[hi]")
+    if PRIO:
+        a.i(f"s_setprio {PRIO}", "the coder chain's wave goes first on its SIMD; the helpers fill the gaps")
+    a.i(f"v_mov_b32 {WR}, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
+    a.i(f"v_add_u32 {PA}, 96, %[row0]", "tile 0: the last 32 symbols of the line in buffer 0")
+    a.i(f"v_add_u32 {PB}, 64, %[row0]")
+    a.i(f"s_mov_b32 s83, {N8_LINEBUF + 96}", "J: from the first tile of a line in buffer 0 to the last tile of the line in buffer 1 (192 - J: back)")
+    a.i("s_mov_b32 s86, 0", "tile pairs done, mod 2")
+    a.i("s_mov_b32 s87, -32")
+    n8_read_syms(a, 0, PA, 7)
+    n8_read_syms(a, 1, PA, 6)
+    a.wait_lds("S0")
+    n8_fetch_entries(a, 0)
+    a.i("1:")
+    first = len(a.events)
+    # tile A (even index i): the step behind it, P(i + 2) = P(i + 1) + d(i + 1), is -32 for i + 1 = 1 mod 4 and the jump for 3 mod 4
+    n8_half(a, PA, PB, 0, "s87")
+    a.i("s_xor_b32 s86, s86, 1")
+    a.i("s_sub_u32 s88, 192, s83")
+    a.i("s_cmp_eq_u32 s86, 1", "the NEXT pair's second tile is the first of its line: its successor lies in the other buffer")
+    a.i("s_cselect_b32 s87, s83, -32")
+    a.i("s_cmp_eq_u32 s86, 0", "a jump was just taken: the next one goes the other way")
+    a.i("s_cselect_b32 s83, s88, s83")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_eq_u32 s82, 0")
+    a.i("s_cbranch_scc1 2f")
+    n8_half(a, PB, PA, 8, "-32")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.i("s_cbranch_scc1 1b")
+    ren = {"S16": "S0", "S17": "S1", "E16": "E0"}
+    lds_back = [ren.get(t, t) for t in a.lds]
+    lds_end, vm_end, notes = a.verify_loop(first, lds_back, a.vm, passes=1)
+    lds_end = [ren.get(t, t) for t in lds_end]
+    assert lds_end == lds_back and vm_end == a.vm, (lds_end, lds_back)
+    a.i("2:")
+    a.ds(f"ds_write_b32 %[pub], {WR}", "cnt", "all words of the main loop")
+    a.i(f"v_mov_b32 %[lo], {LO}")
+    a.i(f"v_mov_b32 %[hi], {HI}")
+    a.wait_lds_all()
+    return a, notes
+
+
+def l8_load(a, i):
+    for c in range(2):
+        base = "s[80:81]" if c == 0 else "s[84:85]"
+        for k in range(8):
+            a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
+    a.i("s_cmp_lg_u32 s83, 0")
+    a.i("s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s89, 1, 0")
+    a.i("s_sub_u32 s80, s80, s88")
+    a.i("s_subb_u32 s81, s81, 0")
+    a.i("s_sub_u32 s84, s84, s88")
+    a.i("s_subb_u32 s85, s85, 0")
+    a.i("s_sub_u32 s83, s83, s89")
+
+
+def l8_stage(a, i, buf, blocks):
+    """row blocks `blocks` of the line in register set i -> line buffer `buf` of both coder waves"""
+    for c in range(2):
+        for k in blocks:
+            base = int(LR[(c, i)][k][2:].split(":")[0])
+            for j in range(4):
+                a.ds(f"ds_write_b32 {HTR[buf]}, v{base + j} offset:{2 * N8_LINEBUF * c + 8 * N8_ROW * k + 4 * j}", "tl")
+
+
+def gen_loader_n8():
+    assert LSETS == 2
+    a = Asm()
+    a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST line of the pair's first stream: line 0")
+    a.i("s_add_u32 s84, s80, %[rowblock]", "... and of the second coder wave's first stream")
+    a.i("s_addc_u32 s85, s81, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "windows left")
+    a.i("s_lshr_b32 s83, %[ntiles], 2")
+    a.i("s_sub_u32 s83, s83, 1", "lines left to request")
+    l8_load(a, 0)
+    l8_load(a, 1)
+    for c in range(2):
+        a.wait_vm(f"ld{c}0", f"coder {c}: line 0 has arrived")
+    l8_stage(a, 0, 0, range(8))
+    l8_load(a, 0)
+    a.wait_lds_all("line 0 is staged (and the table, by everybody)")
+    a.i("s_barrier")
+    a.i("1:")
+    first = len(a.events)
+    for w in range(8):
+        line, v = w // 4 + 1, w % 4
+        i = buf = line & 1
+        a.i(f"; ---- window {w}: set {i}, row blocks {2 * v}, {2 * v + 1} -> line buffers {buf}")
+        if v == 0:
+            for c in range(2):
+                a.wait_vm(f"ld{c}{i}", f"coder {c}: the line in set {i} has arrived")
+        l8_stage(a, i, buf, (2 * v, 2 * v + 1))
+        if v == 3:
+            l8_load(a, i)
+        a.wait_lds_all("the row blocks are staged")
+        a.i("s_barrier")
+        a.i("s_sub_u32 s82, s82, 1")
+        if w < 7:
+            a.i("s_cmp_eq_u32 s82, 0")
+            a.i("s_cbranch_scc1 2f")
+        else:
+            a.i("s_cmp_lg_u32 s82, 0")
+            a.i("s_cbranch_scc1 1b")
+    lds_end, vm_end, notes = a.verify_loop(first, a.lds, a.vm, passes=1)
+    assert lds_end == a.lds and vm_end == a.vm, (vm_end, a.vm)
+    a.i("2:")
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all()
+    return a, notes
+
+
+def main_n8():
+    a, notes = gen_n8()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Coder half of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_coder_loop in cst_ans_pc.hip."]
+    ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
+           '    : [row0] "v"(line_row_addr), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [four] "v"(4u),',
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
+           "    : " + ", ".join(f'"{c}"' for c in N8_CLOBBERS) + ");"]
+    OUT_N8.write_text(a.render(header, ops))
+    print(f"wrote {OUT_N8} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+    a, notes = gen_loader_n8()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Loader wave of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_loader_loop in cst_ans_pc.hip."]
+    ops = ['    :',
+           '    : [tr0] "v"(line_tr_addr[0]), [tr1] "v"(line_tr_addr[1]), [sbase] "s"(symbols_base), [rowblock] "s"(row_block_bytes), [ntiles] "s"(n_tiles),',
+           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in L_CLOBBERS) + ");"]
+    OUT_LOADER_N8.write_text(a.render(header, ops))
+    print(f"wrote {OUT_LOADER_N8} ({a.n_instr()} instructions incl. prologue)")
+    for n in notes:
+        print("  note:", n)
+
+
 def main_all():
     main()
     main_helper()
     main_split()
+    main_n8()
 
 
 if __name__ == "__main__":

@@ -111,3 +111,26 @@ def test_per_stream_table_decoders_at_the_maximum_rate(B, O, frac):
         e2, ck = B.ans_encode_checkpointed(dev(sym), model, k // chunks, (32, 64, P))
         d2, s2 = B.ans_decode_checkpointed(e2, ck, model, k)
         assert int(s2.abs().sum()) == 0 and np.array_equal(d2.cpu().numpy(), sym), f"k = {chunks}"
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("P", [12, 8])
+def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac):
+    """the loops that read / write int8 matrices themselves (cst_ans_n8.hip, ans_encode_pc_n8_kernel): 12 words per 32-symbol tile,
+    refills on every phase, four tiles per pass of the decoder's statement"""
+    n = 101
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + P + 7)
+    sym = high_rate_symbols(rng, 256, 2048, n, frac)
+    want_words, want_n, _ = O.ans_encode_batch(sym, 0, cdf, P, 32, 64)
+    d = dev(sym.astype(np.int8))
+    enc = B.ans_encode(d, model, (32, 64, P))
+    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(256):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    dec, st = B.ans_decode(enc, model, 2048, dtype=torch.int8)
+    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)

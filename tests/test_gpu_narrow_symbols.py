@@ -67,3 +67,137 @@ def test_narrow_matrices_report_what_int32_reports(B, O):
         B.ans_decode(ok, big, 64, dtype=torch.int8)
     dec, _ = B.ans_decode(ok, big, 64, dtype=torch.int16)          # ... but into int16
     assert dec.dtype == torch.int16
+
+
+# ---- int8 matrices INSIDE the hand-scheduled loops (round 5: cst_ans_n8.hip, ans_encode_pc_n8_kernel) ----
+
+def _aligned_i8(host):
+    """an int8 matrix on a 128-byte boundary (what the native kernels ask for; torch's allocator gives 512)"""
+    t = torch.from_numpy(np.ascontiguousarray(host)).to(torch.int8).cuda()
+    assert t.data_ptr() % 128 == 0
+    return t
+
+
+@pytest.mark.parametrize("P", [8, 10, 12])
+@pytest.mark.parametrize("support", [(-50, 50), (-128, 127), (5, 60), (-128, -100), (0, 0 + 1)], ids=lambda s: "%d..%d" % s)
+@pytest.mark.parametrize("n_streams,n_per", [(256, 128), (256, 256), (512, 384), (256, 4096), (768, 1152)])
+def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n_per):
+    """the kernels that read / write the int8 matrix themselves: words, counts and status of the CPU oracle on the widened values
+    (every stream), decoded symbols = the input.  Shapes: one line per row (no previous group to store, no second line to stage),
+    two lines, an odd number of lines, the headline row length, several workgroups."""
+    lo, hi = support
+    if hi - lo + 1 > (1 << P) // 2:
+        pytest.skip("alphabet too large for the precision")
+    cdf = O.GaussianModel(lo, hi, 0.3 * lo + 0.7 * hi - 20, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(1000 + P, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    d = _aligned_i8(sym)
+    enc = B.ans_encode(d, model, (32, 64, P))
+    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    out = torch.full((n_streams, n_per), 99, dtype=torch.int8, device="cuda")
+    dec, dstatus = B.ans_decode(enc, model, n_per, out=out)
+    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert dec.dtype == torch.int8 and (dstatus.cpu().numpy() == 0).all()
+    assert torch.equal(dec, d)
+    # ... and the int32 kernels agree on the same words
+    wide, _ = B.ans_decode(enc, model, n_per)
+    assert torch.equal(wide.to(torch.int8), d)
+
+
+def test_int8_native_kernels_report_what_int32_reports(B, O):
+    """impossible symbols in the native encoder (below and above the support, at the type's ends), invalid and empty streams in the
+    native decoder: the status of the int32 kernels, the other streams untouched"""
+    P, n_streams, n_per, lo = 12, 256, 256, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(66, 0, n_streams, n_per, lo, cdf, P).astype(np.int8)
+    want_words, want_n, _ = O.ans_encode_batch(sym.astype(np.int32), lo, cdf, P)
+    bad = sym.copy()
+    bad[3, 10] = 51; bad[69, 0] = -128; bad[70, 255] = 127; bad[255, 128] = -51
+    enc = B.ans_encode(_aligned_i8(bad), model, (32, 64, P))
+    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    torch.cuda.synchronize()
+    words, n_words, st = enc.to_numpy()
+    flagged = [3, 69, 70, 255]
+    assert (st[flagged] == 1).all() and (np.delete(st, flagged) == 0).all() and (n_words[flagged] == 0).all()
+    for s in range(n_streams):
+        if s not in flagged:
+            assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    # decoder: a stream without words decodes from state 0, a stream whose last word is 0 is invalid data (stack.rs:299-318)
+    good = B.ans_encode(_aligned_i8(sym), model, (32, 64, P))
+    torch.cuda.synchronize()
+    w, n, _ = good.to_numpy()
+    w = w.copy(); n = n.copy()
+    n[5] = 0; n[64] = 1; w[77, n[77] - 1] = 0
+    want, want_st = O.ans_decode_batch(w, n, n_per, lo, cdf, P)
+    src = (torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(n.view(np.int32)).cuda())
+    got, gst = B.ans_decode(src, model, n_per, config=(32, 64, P), dtype=torch.int8)
+    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert gst.cpu().numpy().tolist() == want_st.tolist() and want_st[77] != 0
+    ok = want_st == 0
+    assert np.array_equal(got.cpu().numpy()[ok], want[ok].astype(np.int8))
+
+
+def test_int8_native_decoder_packed_words_and_raw_state(B, O):
+    """the native decoder on the packed + offsets form (into_compressed's contiguous words) and continuing from a raw state
+    (CST_FLAG_RAW_STATE: the two halves of every row by two calls)"""
+    import ctypes as C
+    from constriction_amd import _native as N
+    P, n_streams, n_per, lo = 12, 256, 512, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(67, 0, n_streams, n_per, lo, cdf, P)
+    d = _aligned_i8(sym)
+    enc = B.ans_encode(d, model, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), dtype=torch.int8)
+    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert torch.equal(dec, d) and (st.cpu().numpy() == 0).all()
+    words, n_words, _ = enc.to_numpy()
+    state = np.array([(int(words[s, n_words[s] - 1]) << 32) | int(words[s, n_words[s] - 2]) for s in range(n_streams)], dtype=np.uint64)
+    d_state = torch.from_numpy(state.view(np.int64)).cuda()
+    d_n = torch.from_numpy((n_words - 2).astype(np.int32)).cuda()
+    d_n_out = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    d_status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    half = n_per // 2
+    outs = []
+    for _ in range(2):
+        out = torch.empty((n_streams, half), dtype=torch.int8, device="cuda")
+        N.check(N.lib().cst_ans_decode_batch_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(enc.words.data_ptr()), None, enc.words.shape[1],
+                                                 enc.words.numel(), C.c_void_p(d_n.data_ptr()), C.c_void_p(out.data_ptr()), 1, n_streams, half, 0,
+                                                 C.c_void_p(d_state.data_ptr()), C.c_void_p(d_n_out.data_ptr()), C.c_void_p(d_status.data_ptr()),
+                                                 1, None, None), "cst_ans_decode_batch_sym")
+        assert B.last_kernel() == "ans_decode_n8_kernel"
+        torch.cuda.synchronize()
+        assert (d_status.cpu().numpy() == 0).all()
+        d_n.copy_(d_n_out)
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(outs, axis=1), sym.astype(np.int8))
+    assert (d_n.cpu().numpy() == 0).all()
+
+
+def test_int8_shapes_the_native_kernels_do_not_take(B, O):
+    """rows that are not whole 128-symbol lines, partial workgroups, unaligned matrices: the conversion path, same results"""
+    P, lo = 12, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    for n_streams, n_per, skew in ((256, 100, 0), (100, 128, 0), (256, 128, 1)):
+        sym = O.synth_symbols(70 + n_per, 0, n_streams, n_per, lo, cdf, P)
+        want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+        flat = torch.zeros(n_streams * n_per + 256, dtype=torch.int8, device="cuda")
+        d = flat[skew: skew + n_streams * n_per].view(n_streams, n_per)
+        d.copy_(torch.from_numpy(sym).to(torch.int8))
+        enc = B.ans_encode(d, model, (32, 64, P))
+        assert B.last_kernel() != "ans_encode_pc_n8_kernel"
+        torch.cuda.synchronize()
+        words, n_words, status = enc.to_numpy()
+        assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+        out = flat.new_zeros(n_streams * n_per + 256)[skew: skew + n_streams * n_per].view(n_streams, n_per)
+        dec, _ = B.ans_decode(enc, model, n_per, out=out)
+        assert torch.equal(dec, d)
