@@ -1372,6 +1372,8 @@ bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layou
 cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs);
 bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs);
+bool n8_decode_small(const AnsDecodeArgs& a, int device_cus);
+cst_status ans_decode_small_n8(const AnsDecodeArgs& a, hipStream_t hs);
 // lane-quad word loads for the P <= 12 decoder (cst_ans_dq.hip)
 bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_dq(const AnsDecodeArgs& a, hipStream_t hs);

@@ -107,6 +107,89 @@ __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// More than one wave per SIMD (more than 256 streams per CU: config C5's shard, or the k x 65 536 virtual streams of a batch decoded
+// through jump points): the small-footprint decoder of cst_ans_small.hip over byte tiles.  ONE packed table  c | p << 12 | index << 24
+// (16 KiB, at most 256 symbols), the 32-slot ring and ONE byte tile per wave (16.25 KiB): eight waves per CU in 147 KiB.  The
+// decoded symbol leaves its step as a byte of the quad's register (the SDWA add that forms min_symbol + index writes byte `pos`
+// and preserves the others), the group of 128 symbols leaves at the end of its fourth tile (the sibling wave covers the stall).
+// With a quarter of the int32 decoder's output bytes the second wave is no longer spent on memory time: 131 072 x 4096 decode in
+// about 0.3 ms against 0.48 ms for ans_decode_n8_kernel and 0.60 - 0.68 ms for the int32 kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kN8SmThreads = 512;
+constexpr size_t kN8SmWaves = kN8SmThreads / kWave;
+constexpr size_t kN8SmLutBytes = (size_t)4 << 12;
+constexpr size_t kN8SmLutOff = kN8SmWaves * kN8RingWaveBytes;
+constexpr size_t kN8SmTileOff = kN8SmLutOff + kN8SmLutBytes;
+constexpr size_t kN8SmDumpOff = kN8SmTileOff + kN8SmWaves * kN8TileBytes;
+constexpr size_t kN8SmLdsBytes = kN8SmDumpOff + 4 * kWave * 4;
+static_assert(kN8SmLdsBytes <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void decode_groups_loop_small_n8(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t lut_addr,
+                                                            uint32_t mask, uint32_t ring_mask, uint32_t P, const void* words_base,
+                                                            uint64_t store_base, uint32_t n_tiles, int32_t min_symbol, uint32_t shift_minus_1,
+                                                            uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
+                                                            uint32_t tile_row_addr, uint32_t tile_tr_addr, const uint32_t (&goff)[8]) {
+#define CST_STORE_MOD "nt"
+#include "cst_decode_loop_small_n8.inc"
+#undef CST_STORE_MOD
+}
+
+// LDS: [word rings: 8 x 8 KiB][packed table 16 KiB][one byte tile per wave][one landing area for unused chunk slots]
+__global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const AnsDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = threadIdx.x >> 6;
+    const int P = a.precision;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + wave_in_block * kN8RingWaveBytes);
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem + kN8SmLutOff);
+    unsigned char* tile = smem + kN8SmTileOff + wave_in_block * kN8TileBytes;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kN8SmDumpOff) + lane;
+    if ((lds_addr(ring) & (uint32_t)(kN8RingWaveBytes - 1)) != 0) __builtin_trap();
+    // quantile -> c | p << 12 | index << 24   (lookup_contiguous.rs:564-605 as ONE table read; c, p < 2^12, index < 2^8)
+    for (int q = threadIdx.x; q < (1 << P); q += blockDim.x) {
+        const uint32_t cp = a.dec_cp[q];
+        lut[q] = (cp & 0xfffu) | ((cp >> 16) << 12) | ((uint32_t)a.dec_idx[q] << 24);
+    }
+    __syncthreads();
+
+    const size_t s0 = (size_t)blockIdx.x * kN8SmThreads + (size_t)wave_in_block * kWave;
+    if (s0 >= a.n_streams) return;                       // (the launcher only takes whole waves)
+    const size_t s = s0 + lane;
+    const size_t N = a.n_per_stream;
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);
+
+    DecLane<32, 64, kDecRingSlots, kDecAhead> L;
+    const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
+    L.init(a.words + ws.off, ws.n, ring, lane);
+    if (raw) L.state = a.state[s];
+    else L.read_initial_state();
+    L.in.prime();
+    wave_lds_fence();
+    uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
+
+    const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
+    const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
+    uint32_t goff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
+    const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
+    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * N);
+    const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the statement keeps its own book from here
+    decode_groups_loop_small_n8(lo, hi, L.in.rd, L.in.lo_issued, lds_addr(lut), (1u << P) - 1u, kDecRingMask, (uint32_t)P, words_base, store_base,
+                                (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kN8GroupSyms)), a.min_symbol, L.in.shift - 1u,
+                                lds_addr(ring + lane), lds_addr(dump), w_off, lds_addr(tile) + (uint32_t)(lane * kN8RowBytes), lds_addr(tile) + tr_off,
+                                goff);
+    a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
+    if (raw) {
+        a.state[s] = ((uint64_t)hi << 32) | lo;
+        if (a.n_words_out) a.n_words_out[s] = L.in.rd;
+    }
+}
+
 // Whole waves, rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
 bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
@@ -118,6 +201,22 @@ bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout l
     if (a.offsets && a.words_capacity == 0) return false;                                          // the lanes' 32-bit word offsets need a known span
     const uint64_t span = a.offsets ? a.words_capacity : (uint64_t)a.n_streams * a.stride_words;
     return span * 4 + 256 < 0x80000000ull;
+}
+
+// more streams than one wave per SIMD of this device (and a table the packed form holds): the small-footprint form
+bool n8_decode_small(const AnsDecodeArgs& a, int device_cus) {
+    const char* e = getenv("CST_SMALL_KERNELS");         // (A/B runs, as for cst_ans_small.hip: 0 / enc = never the small decoder)
+    if (e && (e[0] == '0' || e[0] == 'e')) return false;
+    return a.n_symbols <= 256 && a.n_streams > (size_t)device_cus * kBlock;
+}
+
+cst_status ans_decode_small_n8(const AnsDecodeArgs& a, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kN8SmThreads - 1) / kN8SmThreads;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_small_n8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8SmLdsBytes));
+    hipLaunchKernelGGL(ans_decode_small_n8_kernel, dim3((unsigned)blocks), dim3(kN8SmThreads), kN8SmLdsBytes, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs) {

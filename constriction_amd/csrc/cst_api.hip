@@ -469,7 +469,8 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
     if (!n8_decode_usable(a, cfg, layout)) return false;
-    *rc = note_kernel("ans_decode_n8_kernel", ans_decode_n8(a, (hipStream_t)stream));
+    if (n8_decode_small(a, model->cu_count)) *rc = note_kernel("ans_decode_small_n8_kernel", ans_decode_small_n8(a, (hipStream_t)stream));
+    else *rc = note_kernel("ans_decode_n8_kernel", ans_decode_n8(a, (hipStream_t)stream));
     return true;
 }
 

@@ -136,8 +136,9 @@ def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
     mod = _load("gen_encode_loop_pc")
     mod.OUT, mod.OUT_HELPER = tmp_path / "coder.inc", tmp_path / "helper.inc"
     mod.OUT_LOADER, mod.OUT_STORER = tmp_path / "loader.inc", tmp_path / "storer.inc"
+    mod.OUT_N8, mod.OUT_LOADER_N8 = tmp_path / "n8.inc", tmp_path / "loader_n8.inc"      # round 5: the int8 forms of coder and loader
     mod.main_all()
-    for name in ("loader", "storer"):
+    for name in ("loader", "storer", "n8", "loader_n8"):
         assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()
@@ -151,6 +152,15 @@ def test_lane_quad_decoder_loop_is_in_sync(tmp_path, monkeypatch):
     mod.OUT = tmp_path / "dq.inc"
     mod.main()
     assert (tmp_path / "dq.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_dq.inc").read_text()
+
+
+def test_int8_decoder_loop_is_in_sync(tmp_path, monkeypatch):
+    """the main loop of the decoder that writes int8 matrices itself (cst_ans_n8.hip)"""
+    monkeypatch.delenv("GEN_NO_STORE", raising=False)
+    mod = _load("gen_decode_loop_n8")
+    mod.OUT = tmp_path / "n8.inc"
+    mod.main()
+    assert (tmp_path / "n8.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_n8.inc").read_text()
 
 
 def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):

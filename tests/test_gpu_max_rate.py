@@ -134,3 +134,30 @@ def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac):
     dec, st = B.ans_decode(enc, model, 2048, dtype=torch.int8)
     assert B.last_kernel() == "ans_decode_n8_kernel"
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05])
+@pytest.mark.parametrize("dtype", ["int32", "int8"])
+def test_small_footprint_kernels_at_the_maximum_rate(B, O, dtype, frac):
+    """the kernels for more than one wave per SIMD (cst_ans_small.hip; int8: ans_decode_small_n8_kernel) are only taken by batches of
+    more streams than 256 per CU -- the other tests of this file never reach them.  Their decoder shared the stale first-candidate
+    read of the per-stream-table decoder (fixed in round 5: scripts/gen_decode_loop_small.py, tail(last=True))."""
+    from constriction_amd import _native as N
+    P, n = 12, 101
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_streams, n_per = cus * 256 + 512, 256
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + 99)
+    sym = high_rate_symbols(rng, n_streams, n_per, n, frac)
+    d = dev(sym if dtype == "int32" else sym.astype(np.int8))
+    enc = B.ans_encode(d, model, (32, 64, P))
+    dec, st = B.ans_decode(enc, model, n_per, dtype=d.dtype)
+    assert B.last_kernel() == ("ans_decode_small_kernel" if dtype == "int32" else "ans_decode_small_n8_kernel")
+    assert (st.cpu().numpy() == 0).all() and (enc.status.cpu().numpy() == 0).all()
+    wrong = (dec != d).any(dim=1).nonzero().flatten()
+    assert wrong.numel() == 0, f"{wrong.numel()} streams decode wrongly, first {wrong[:4].tolist()}"
+    words, n_words, _ = enc.to_numpy()
+    for s in (0, 4097, n_streams - 1):
+        w, nw, _ = O.ans_encode_batch(sym[s: s + 1], 0, cdf, P, 32, 64)
+        assert np.array_equal(words[s, : n_words[s]], w[0, : nw[0]]), f"stream {s}"
