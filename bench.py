@@ -317,10 +317,11 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
     plain = (B.ans_encode if ans else B.range_encode)(symbols, model, cfg)
     decoded = torch.empty_like(symbols)
     plain_dec_ms = event_ms(lambda: (B.ans_decode if ans else B.range_decode)(plain, model, n_per, out=decoded), reps)
+    plain_kernel = B.last_kernel()
     total_words = plain.total_words()
-    byts = 4 * n_streams * n_per + (cfg[0] // 8) * total_words
+    byts = symbols.element_size() * n_streams * n_per + (cfg[0] // 8) * total_words
     entry = {"workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
-             "plain_decode_ms": round(plain_dec_ms, 4), "by_k": {}}
+             "symbol_bytes": symbols.element_size(), "plain_decode_ms": round(plain_dec_ms, 4), "plain_decode_kernel": plain_kernel, "by_k": {}}
     ok = True
     for k in ks:
         interval = n_per // k
@@ -329,8 +330,9 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
         status = torch.empty((n_streams, k), dtype=torch.int32, device=symbols.device)
         decoded.zero_()
         e_ms = event_ms(lambda: enc_ck(symbols, model, interval, cfg, out=pair), reps)
+        e_kernel = B.last_kernel()
         d_ms = event_ms(lambda: dec_ck(enc, ck, model, n_per, out=decoded, status=status), reps)
-        entry["by_k"][str(k)] = {"encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4),
+        entry["by_k"][str(k)] = {"encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4), "kernels": [e_kernel, B.last_kernel()],
                                  "decode_frac": round(byts / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                  "decode_speedup": round(plain_dec_ms / d_ms, 3)}
         if check:
@@ -341,7 +343,7 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
             good = good and bool(((enc.words[:, :w] == plain.words[:, :w]) | ~used).all())
             if good and cdf_host is not None:
                 rows = sorted({0, 1, 63, 64, n_streams // 2, n_streams - 1})
-                host = symbols[rows].cpu().numpy()
+                host = symbols[rows].cpu().numpy().astype(np.int32)
                 tabs = np.asarray(cdf_host)
                 tab = tabs[rows] if tabs.ndim == 2 else tabs
                 if ans:
@@ -712,8 +714,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
         add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
         add("C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         add("C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
-        jump("C2 decode with k jump points per stream (small-footprint decoder on 65 536 k virtual streams; the jump points come from the "
-             "one-lane-per-stream checkpointing encoder)", "ans", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        jump("C2 decode with k jump points per stream (small-footprint decoder on 65 536 k virtual streams; the producer / consumer encoder "
+             "notes the jump points on its way)", "ans", (32, 64, 12), m12, sym12, reps, check, cdf12)
+        jump("C2 with int8 symbol matrices: decode with k jump points per stream (the loops read / write int8 themselves; 65 536 k virtual "
+             "streams on the small-footprint int8 decoder, two waves per SIMD)", "ans", (32, 64, 12), m12, sym12.to(torch.int8), reps, check, cdf12)
         jump("C4 range coder, P = 12: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         jump("C4 range coder, P = 24: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         del sym24, m24

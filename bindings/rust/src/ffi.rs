@@ -314,6 +314,11 @@ extern "C" {
     /// those of the int32 calls on the widened values; an encoder symbol outside the model's support is an impossible symbol as ever,
     /// a decoder whose model's support does not fit the type returns CST_ERR_INVALID_ARGUMENT.  The two conversions are exported on
     /// their own for the other coders (range, per-symbol, checkpointed calls take int32).
+    /// INT8 INSIDE THE LOOPS (round 5): symbol_bytes = 1 with the default preset (32,64), 8 <= P <= 12, a shared table, stream-major
+    /// rows that are whole 128-symbol lines of a 128-byte aligned matrix (encode: whole workgroups of 256 streams, 64-byte aligned
+    /// slabs with stride_words % 16 == 0; decode: whole waves of 64 streams, a known span of the words) is coded by kernels that read /
+    /// write the int8 matrix themselves -- no conversion, d_scratch is not touched and may be NULL; the same words, counts, status
+    /// (cst_last_kernel_name: "ans_encode_pc_n8_kernel" / "ans_decode_n8_kernel").  Every other shape takes the conversion.
     pub fn cst_symbols_widen(
         d_in: *const c_void,
         symbol_bytes: i32,
@@ -535,6 +540,60 @@ extern "C" {
         d_ckpt_pos: *const u32,
         d_ckpt_state: *const u64,
         d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    /// Round 5 (additions to ABI 4): jump points at the speed of the plain encoder, and for NARROW symbol matrices.
+    /// cst_ans_encode_batch_ckpt on a shared-table model, preset (32,64), 8 <= P <= 12, whole workgroups of 256 stream-major rows that
+    /// are whole aligned tiles, chunks of whole 32-symbol tiles that divide the rows: the producer / consumer encoder notes the jump
+    /// points on its way ("ans_encode_pc_kernel<ckpt>").  The _sym forms take symbol_bytes = 1, 2 or 4 as cst_ans_*_batch_sym do: an int8
+    /// matrix of whole 128-symbol lines is read by the encoder loops themselves ("ans_encode_pc_n8_kernel<ckpt>") and, chunk by chunk
+    /// (ckpt_interval a multiple of 128), written by the decoder loops -- k x n_streams virtual streams, two waves per SIMD from
+    /// 65 537 of them on ("ans_decode_small_n8_kernel"): 65 536 x 4096 at k = 2 decode in 0.17 ms against 0.24 ms whole.  Every other
+    /// shape converts next to the int32 calls.  d_scratch: cst_ckpt_sym_scratch_bytes(...) bytes for both calls (the encoder touches
+    /// it only when it converts; NULL is accepted where it does not).
+    pub fn cst_ans_encode_batch_ckpt_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_state: *mut u64,
+        d_status: *mut i32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ckpt_sym_scratch_bytes(
+        n_streams: usize,
+        n_per_stream: usize,
+        ckpt_interval: usize,
+        symbol_bytes: i32,
+    ) -> usize;
+
+    pub fn cst_ans_decode_batch_ckpt_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        ckpt_interval: usize,
+        d_ckpt_pos: *const u32,
+        d_ckpt_state: *const u64,
+        d_symbols: *mut c_void,
+        symbol_bytes: i32,
         n_streams: usize,
         n_per_stream: usize,
         d_scratch: *mut c_void,

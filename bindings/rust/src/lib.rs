@@ -1121,6 +1121,92 @@ impl BatchedAnsCoder {
         stream.synchronize()?; // (the scratch buffer is dropped on return)
         Ok(out)
     }
+
+    /// `encode_iid_symbols_reverse_with_checkpoints` for a NARROW symbol type (round 5: `cst_ans_encode_batch_ckpt_sym`).  An `i8`
+    /// matrix of whole 128-symbol lines is read by the encoder loops themselves, jump points noted on the way.
+    pub fn encode_iid_symbols_reverse_with_checkpoints_narrow<T: NarrowSymbol>(
+        &self,
+        symbols: &DeviceBuffer<T>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch, Checkpoints)> {
+        if interval == 0 || symbols.len() < n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)? {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = (n_per_stream + interval - 1) / interval;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut ckpt = Checkpoints { pos: DeviceBuffer::new(n_points)?, state: DeviceBuffer::new(n_points)?, interval };
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ckpt_sym_scratch_bytes(n_streams, n_per_stream, interval, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_ans_encode_batch_ckpt_sym(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr() as *const c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.state.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok((out, ckpt))
+    }
+
+    /// `decode_iid_symbols_from_checkpoints` into a NARROW symbol type (`cst_ans_decode_batch_ckpt_sym`): every chunk on its own
+    /// lane, `i8` chunks of whole 128-symbol lines written by the decoder loops themselves.
+    pub fn decode_iid_symbols_from_checkpoints_narrow<T: NarrowSymbol>(
+        &self,
+        encoded: &EncodedBatch,
+        checkpoints: &Checkpoints,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(DeviceBuffer<T>, DeviceBuffer<i32>)> {
+        let n_streams = encoded.n_streams;
+        if checkpoints.interval == 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
+        let mut symbols: DeviceBuffer<T> = DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)?;
+        let mut scratch: DeviceBuffer<u8> =
+            DeviceBuffer::new(unsafe { ffi::cst_ckpt_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_ans_decode_batch_ckpt_sym(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                checkpoints.interval,
+                checkpoints.pos.as_ptr(),
+                checkpoints.state.as_ptr(),
+                symbols.as_mut_ptr() as *mut c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                scratch.as_mut_ptr() as *mut c_void,
+                status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?;
+        Ok((symbols, status))
+    }
 }
 
 /// `(pos, state)` of every stream in front of every chunk: the reference's jump table.

@@ -860,7 +860,13 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
     """ans_encode + a checkpoint in front of every `interval` symbols.  Returns (EncodedBatch, Checkpoints); the words are
     those of ans_encode.  Models with one table per stream are taken too (stream-major): see DESIGN.md 4.12 (sub-lanes).
     out: (EncodedBatch, Checkpoints) of an earlier call with the same shapes, to code into the same buffers."""
-    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
+    if narrow != 4:        # int8 / int16 matrices (round 5: cst_ans_encode_batch_ckpt_sym; int8 lines are read by the encoder loops themselves)
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
+        symbols = _require_cuda(symbols, symbols.dtype, "symbols")
+    else:
+        symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     dev = symbols.device
     n_chunks = (n_per + interval - 1) // interval
@@ -876,6 +882,13 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
                            torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
         ck = Checkpoints(int(interval), torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
                          torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
+    if narrow != 4:
+        L = N.lib()
+        scratch = _ckpt_scratch(("ckpt_widen", torch.cuda.current_stream().cuda_stream), dev, L.cst_ckpt_sym_scratch_bytes(n_streams, n_per, int(interval), narrow))
+        N.check(L.cst_ans_encode_batch_ckpt_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words), stride,
+                                                _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status), _ptr(scratch),
+                                                _stream_ptr()), "cst_ans_encode_batch_ckpt_sym")
+        return out, ck
     N.check(N.lib().cst_ans_encode_batch_ckpt(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), stride,
                                               _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status),
                                               _stream_ptr()), "cst_ans_encode_batch_ckpt")
@@ -891,17 +904,32 @@ def _ckpt_scratch(kind, dev, nbytes):
     return buf
 
 
-def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None):
+def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None,
+                            dtype=torch.int32):
     """Decodes every chunk on its own lane (AnsCoder.seek(pos, state) + `interval` symbols per chunk).
-    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
+    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks]).  dtype (or the dtype of `out`): int32, or int16 / int8 for
+    a narrow symbol matrix (cst_ans_decode_batch_ckpt_sym: int8 chunks of whole 128-symbol lines are written by the decoder loops)."""
     n_streams = encoded.n_words.numel()
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
     if out is None:
-        out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
+        out = torch.empty((n_streams, n_per_stream), dtype=dtype, device=dev)
     if status is None:
         status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
     L = N.lib()
+    narrow = _SYMBOL_BYTES.get(out.dtype)
+    if narrow is None:
+        raise TypeError("decoded symbols are int32, int16 or int8")
+    if narrow != 4:
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only")
+        scratch = _ckpt_scratch(("ans_ckpt_sym", torch.cuda.current_stream().cuda_stream), dev,
+                                L.cst_ckpt_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, narrow))
+        N.check(L.cst_ans_decode_batch_ckpt_sym(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
+                                                encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out),
+                                                narrow, n_streams, n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()),
+                "cst_ans_decode_batch_ckpt_sym")
+        return out, status
     scratch = _ckpt_scratch("ans_ckpt", dev, L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
     N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
                                         encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,

@@ -125,6 +125,15 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cf
         return note_kernel("ans_encode_pt_kernel<ckpt>", ans_encode_pt_ckpt(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words,
                                                                              ckpt_interval, d_ckpt_pos, d_ckpt_state, d_status, (hipStream_t)stream));
     }
+    {   // whole workgroups of aligned rows with chunks of whole tiles: the producer / consumer encoder notes the jump points on its
+        // way (cst_ans_pc.hip, round 5) at the speed of cst_ans_encode_batch
+        AnsEncodeArgs e{};
+        e.symbols = d_symbols; e.n_streams = n_streams; e.n_per_stream = n_per_stream; e.enc = model->d_enc; e.n_symbols = model->n_symbols;
+        e.min_symbol = model->min_symbol; e.precision = model->precision; e.words = d_words; e.stride_words = stride_words;
+        e.n_words = d_n_words; e.state = nullptr; e.status = d_status; e.flags = 0;
+        if (pc_encode_ckpt_usable(e, cfg, layout, ckpt_interval))
+            return note_kernel("ans_encode_pc_kernel<ckpt>", ans_encode_pc_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+    }
     CkptEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision; a.words = d_words;
@@ -192,6 +201,75 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
     return cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR,
                                 v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+}
+
+// ---- narrow symbol matrices through jump points (round 5) ----
+
+cst_status cst_ans_encode_batch_ckpt_sym(const cst_model* model, cst_coder_config cfg, const void* d_symbols, int32_t symbol_bytes, size_t n_streams,
+                                         size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                         size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, int32_t* d_status, void* d_scratch,
+                                         void* stream) {
+    if (symbol_bytes == 4)
+        return cst_ans_encode_batch_ckpt(model, cfg, reinterpret_cast<const int32_t*>(d_symbols), n_streams, n_per_stream, layout, d_words, stride_words,
+                                         d_n_words, ckpt_interval, d_ckpt_pos, d_ckpt_state, d_status, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (symbol_bytes == 1 && d_symbols && !model->per_stream && !model->d_symbol_of_index && config_supported(cfg) && cfg.precision == model->precision) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        AnsEncodeArgs e{};
+        e.symbols = reinterpret_cast<const int32_t*>(d_symbols); e.n_streams = n_streams; e.n_per_stream = n_per_stream; e.enc = model->d_enc;
+        e.n_symbols = model->n_symbols; e.min_symbol = model->min_symbol; e.precision = model->precision; e.words = d_words;
+        e.stride_words = stride_words; e.n_words = d_n_words; e.state = nullptr; e.status = d_status; e.flags = 0;
+        if (pc_n8_encode_ckpt_usable(e, cfg, layout, ckpt_interval))      // the int8 matrix inside the loops, jump points on the way
+            return note_kernel("ans_encode_pc_n8_kernel<ckpt>", ans_encode_pc_n8_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+    }
+    if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
+    int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
+    const cst_status rc = cst_symbols_widen(d_symbols, symbol_bytes, n_streams * n_per_stream, wide, stream);
+    if (rc != CST_OK) return rc;
+    return cst_ans_encode_batch_ckpt(model, cfg, wide, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, ckpt_interval, d_ckpt_pos,
+                                     d_ckpt_state, d_status, stream);
+}
+
+size_t cst_ckpt_sym_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval, int32_t symbol_bytes) {
+    return cst_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) + cst_symbols_scratch_bytes(n_streams, n_per_stream, symbol_bytes) + 16;
+}
+
+cst_status cst_ans_decode_batch_ckpt_sym(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                         size_t stride_words, size_t words_capacity, size_t ckpt_interval, const uint32_t* d_ckpt_pos,
+                                         const uint64_t* d_ckpt_state, void* d_symbols, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
+                                         void* d_scratch, int32_t* d_status, void* stream) {
+    if (symbol_bytes == 4)
+        return cst_ans_decode_batch_ckpt(model, cfg, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos, d_ckpt_state,
+                                         reinterpret_cast<int32_t*>(d_symbols), n_streams, n_per_stream, d_scratch, d_status, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_ckpt_pos || !d_ckpt_state || !d_scratch || !d_status || ckpt_interval == 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    const size_t ck_bytes = (cst_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) + 15) & ~(size_t)15;
+    void* conv_scratch = reinterpret_cast<unsigned char*>(d_scratch) + ck_bytes;
+    if (model->per_stream) {
+        // one table per stream: the sub-lane decoders write int32 -- decode into the wide matrix, narrow behind them
+        int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(conv_scratch) + 15) & ~(uintptr_t)15);
+        const cst_status rc = cst_ans_decode_batch_ckpt(model, cfg, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos, d_ckpt_state,
+                                                        wide, n_streams, n_per_stream, d_scratch, d_status, stream);
+        if (rc != CST_OK) return rc;
+        return cst_symbols_narrow(wide, n_streams * n_per_stream, d_symbols, symbol_bytes, stream);
+    }
+    // shared table: the ordinary batched decode of the n_streams * n_chunks virtual streams (cst_ans_decode_batch_ckpt above), into
+    // the narrow matrix -- int8 rows of whole 128-symbol lines are written by the decoder loops themselves (cst_ans_n8.hip)
+    const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
+    hipStream_t hs = (hipStream_t)stream;
+    uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
+    uint64_t* v_state = v_offsets + n_virtual;
+    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);
+    CST_HIP_TRY(hipGetLastError());
+    CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));
+    const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    return cst_ans_decode_batch_sym(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, symbol_bytes, n_virtual, ckpt_interval,
+                                    CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, conv_scratch, stream);
 }
 
 } // extern "C"

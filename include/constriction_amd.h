@@ -370,6 +370,26 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cf
                                      size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
                                      void *stream);
 
+/* Round 5 (additions to ABI 4): jump points at the speed of the plain encoder, and for NARROW symbol matrices.
+ * cst_ans_encode_batch_ckpt on a shared-table model, preset (32,64), 8 <= P <= 12, whole workgroups of 256 stream-major rows that
+ * are whole aligned tiles, chunks of whole 32-symbol tiles that divide the rows: the producer / consumer encoder notes the jump
+ * points on its way ("ans_encode_pc_kernel<ckpt>").  The _sym forms take symbol_bytes = 1, 2 or 4 as cst_ans_*_batch_sym do: an int8
+ * matrix of whole 128-symbol lines is read by the encoder loops themselves ("ans_encode_pc_n8_kernel<ckpt>") and, chunk by chunk
+ * (ckpt_interval a multiple of 128), written by the decoder loops -- k x n_streams virtual streams, two waves per SIMD from
+ * 65 537 of them on ("ans_decode_small_n8_kernel"): 65 536 x 4096 at k = 2 decode in 0.17 ms against 0.24 ms whole.  Every other
+ * shape converts next to the int32 calls.  d_scratch: cst_ckpt_sym_scratch_bytes(...) bytes for both calls (the encoder touches
+ * it only when it converts; NULL is accepted where it does not). */
+cst_status cst_ans_encode_batch_ckpt_sym(const cst_model *model, cst_coder_config cfg, const void *d_symbols, int32_t symbol_bytes,
+                                         size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                         size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval, uint32_t *d_ckpt_pos,
+                                         uint64_t *d_ckpt_state, int32_t *d_status, void *d_scratch, void *stream);
+size_t cst_ckpt_sym_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval, int32_t symbol_bytes);
+cst_status cst_ans_decode_batch_ckpt_sym(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                         const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
+                                         size_t ckpt_interval, const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_state,
+                                         void *d_symbols, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
+                                         void *d_scratch, int32_t *d_status, void *stream);
+
 /* The same for the reference's flagship call, every symbol its own (mean, std) (cst_ans_encode_gaussian_batch): the fused encoder
  * notes the jump points (batches of at least 16 384 streams; ckpt_interval a multiple of 16 that divides n_per_stream), and the
  * decoder runs every (stream, chunk) pair as a coder of its own -- the parameter matrices have the symbols' shape, so a chunk's

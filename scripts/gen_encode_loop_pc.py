@@ -34,6 +34,7 @@ from asmgen import Asm  # noqa: E402
 
 CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
 OUT = CSRC / "cst_encode_loop_pc.inc"
+OUT_CK = CSRC / "cst_encode_loop_pc_ck.inc"         # ... noting jump points (round 5: see ck_hook below)
 NO_BARRIER = bool(os.environ.get("GEN_NO_BARRIER"))     # timing experiment only (races with the helper)
 PRIO = int(os.environ.get("GEN_PRIO", "2"))             # s_setprio of the coder's wave (0 = leave it alone)
 
@@ -131,7 +132,55 @@ def hand_off(a):
         a.i("s_barrier")
 
 
-def half(a, h, g0):
+# Jump points (round 5: cst_encode_loop_pc_ck.inc / cst_encode_loop_pc_n8_ck.inc).  The reference's `AnsCoder::pos()` (stack.rs:1107-1139)
+# in front of every chunk of K symbols, K a multiple of 32: a scalar countdown per tile; where a chunk starts the coder's wave
+# leaves the statement's straight line for six instructions -- (words emitted so far, state) to d_ckpt_pos[s][j] / d_ckpt_state[s][j],
+# j counting down -- and comes back.  The coder wave has no other vector-memory instruction, so there is no wait to keep.
+JUMP = False
+PO, SO = "v170", "v171"            # byte offsets of this lane's next jump point in the two arrays
+
+
+def ck_hook(a, site):
+    if not JUMP:
+        return
+    a.i("s_sub_u32 s89, s89, 1")
+    a.i("s_cmp_eq_u32 s89, 0")
+    a.i(f"s_cbranch_scc1 7{site}f", "a chunk starts here: note the jump point")
+    a.i(f"8{site}:")
+
+
+def ck_blocks(a, sites):
+    if not JUMP:
+        return
+    a.i("s_branch 9f")
+    for site in sites:
+        a.i(f"7{site}:")
+        a.i(f"global_store_dword {PO}, {WR}, %[ckpos]", "AnsCoder::pos(): words in the bulk ...")
+        a.i(f"global_store_dwordx2 {SO}, {ST_T}, %[ckstate]", "... and the coder state")
+        a.i(f"v_subrev_u32 {PO}, 4, {PO}")
+        a.i(f"v_subrev_u32 {SO}, 8, {SO}")
+        a.i("s_mov_b32 s89, %[cktiles]")
+        a.i(f"s_branch 8{site}b")
+    a.i("9:")
+
+
+def ck_prologue(a):
+    if not JUMP:
+        return
+    a.i(f"v_mov_b32 {PO}, %[ckposoff]")
+    a.i(f"v_mov_b32 {SO}, %[ckstateoff]")
+    a.i("s_mov_b32 s89, %[cktiles]", "tiles until the next jump point")
+
+
+def ck_clobbers():
+    return [PO, SO, "s89"] if JUMP else []
+
+
+def ck_operands():
+    return ', [ckpos] "s"(ckpt_pos), [ckstate] "s"(ckpt_state), [cktiles] "s"(ckpt_tiles), [ckposoff] "v"(ckpt_pos_off), [ckstateoff] "v"(ckpt_state_off)' if JUMP else ""
+
+
+def half(a, h, g0, site=0):
     """one tile in tile buffer h, global quad indices g0 .. g0+7 stand for quads 7 .. 0"""
     a.i(f"; ---- tile in buffer {h}")
     for j in range(8):
@@ -148,6 +197,7 @@ def half(a, h, g0):
         fold_minmax(a, g)
         for c, p, m0, m1 in E[g % 2]:
             step(a, c, p, m0, m1)
+    ck_hook(a, site)
 
 
 def gen():
@@ -159,17 +209,18 @@ def gen():
         a.i(f"s_setprio {PRIO}", "the coder chain's wave goes first on its SIMD; the helper fills the gaps")
     a.i(f"v_mov_b32 {WR}, 0")
     a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
+    ck_prologue(a)
     read_syms(a, 0, 0, 7)
     read_syms(a, 1, 0, 6)
     a.wait_lds("S0")
     fetch_entries(a, 0)
     a.i("1:")
     first = len(a.events)
-    half(a, 0, 0)
+    half(a, 0, 0, site=0)
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_eq_u32 s82, 0")
     a.i("s_cbranch_scc1 2f")
-    half(a, 1, 8)
+    half(a, 1, 8, site=1)
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.i("s_cbranch_scc1 1b")
@@ -183,19 +234,27 @@ def gen():
     a.i(f"v_mov_b32 %[lo], {LO}")
     a.i(f"v_mov_b32 %[hi], {HI}")
     a.wait_lds_all()
+    ck_blocks(a, (0, 1))
     return a, notes
 
 
 def main():
+    global JUMP
+    for JUMP, out in ((False, OUT), (True, OUT_CK)):
+        emit_coder(out)
+    JUMP = False
+
+
+def emit_coder(out):
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
               "// Coder half of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_coder_loop in cst_ans_pc.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
-           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
-           "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
-    OUT.write_text(a.render(header, ops))
-    print(f"wrote {OUT} ({a.n_instr()} instructions incl. prologue)")
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+           "    : " + ", ".join(f'"{c}"' for c in CLOBBERS + ck_clobbers()) + ");"]
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
 
@@ -643,7 +702,7 @@ def n8_fold_minmax(a, g):
     a.i(f"v_min3_i32 %[smin], %[smin], {z}, {w}")
 
 
-def n8_half(a, cur, nxt, g0, delta):
+def n8_half(a, cur, nxt, g0, delta, site=0):
     """one tile at pointer `cur` (the next tile's at `nxt`), global quad indices g0 .. g0+7 stand for quads 7 .. 0"""
     a.i(f"; ---- tile at {cur}")
     for j in range(8):
@@ -661,6 +720,7 @@ def n8_half(a, cur, nxt, g0, delta):
         for c, p, m0, m1 in E[g % 2]:
             step(a, c, p, m0, m1)
     a.i(f"v_add_u32 {cur}, {delta}, {nxt}", "leapfrog: the tile after the next")
+    ck_hook(a, site)
 
 
 def gen_n8():
@@ -677,6 +737,7 @@ def gen_n8():
     a.i(f"s_mov_b32 s83, {N8_LINEBUF + 96}", "J: from the first tile of a line in buffer 0 to the last tile of the line in buffer 1 (192 - J: back)")
     a.i("s_mov_b32 s86, 0", "tile pairs done, mod 2")
     a.i("s_mov_b32 s87, -32")
+    ck_prologue(a)
     n8_read_syms(a, 0, PA, 7)
     n8_read_syms(a, 1, PA, 6)
     a.wait_lds("S0")
@@ -684,7 +745,7 @@ def gen_n8():
     a.i("1:")
     first = len(a.events)
     # tile A (even index i): the step behind it, P(i + 2) = P(i + 1) + d(i + 1), is -32 for i + 1 = 1 mod 4 and the jump for 3 mod 4
-    n8_half(a, PA, PB, 0, "s87")
+    n8_half(a, PA, PB, 0, "s87", site=0)
     a.i("s_xor_b32 s86, s86, 1")
     a.i("s_sub_u32 s88, 192, s83")
     a.i("s_cmp_eq_u32 s86, 1", "the NEXT pair's second tile is the first of its line: its successor lies in the other buffer")
@@ -694,7 +755,7 @@ def gen_n8():
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_eq_u32 s82, 0")
     a.i("s_cbranch_scc1 2f")
-    n8_half(a, PB, PA, 8, "-32")
+    n8_half(a, PB, PA, 8, "-32", site=1)
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.i("s_cbranch_scc1 1b")
@@ -708,6 +769,7 @@ def gen_n8():
     a.i(f"v_mov_b32 %[lo], {LO}")
     a.i(f"v_mov_b32 %[hi], {HI}")
     a.wait_lds_all()
+    ck_blocks(a, (0, 1))
     return a, notes
 
 
@@ -781,18 +843,32 @@ def gen_loader_n8():
     return a, notes
 
 
+OUT_N8_CK = CSRC / "cst_encode_loop_pc_n8_ck.inc"
+
+
 def main_n8():
+    global JUMP
+    for JUMP, out in ((False, OUT_N8), (True, OUT_N8_CK)):
+        emit_n8_coder(out)
+    JUMP = False
+    emit_n8_loader()
+
+
+def emit_n8_coder(out):
     a, notes = gen_n8()
     header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
               "// Coder half of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_coder_loop in cst_ans_pc.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(line_row_addr), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [four] "v"(4u),',
-           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)',
-           "    : " + ", ".join(f'"{c}"' for c in N8_CLOBBERS) + ");"]
-    OUT_N8.write_text(a.render(header, ops))
-    print(f"wrote {OUT_N8} ({a.n_instr()} instructions incl. prologue)")
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+           "    : " + ", ".join(f'"{c}"' for c in N8_CLOBBERS + ck_clobbers()) + ");"]
+    out.write_text(a.render(header, ops))
+    print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
+
+
+def emit_n8_loader():
     a, notes = gen_loader_n8()
     header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
               "// Loader wave of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_loader_loop in cst_ans_pc.hip."]

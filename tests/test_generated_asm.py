@@ -54,6 +54,9 @@ def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
     assert (tmp_path / "c.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_sm.inc").read_text()
     text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small.inc").read_text()
+    monkeypatch.setenv("GEN_SMALL_N8", "1")                   # round 5: the same loop over byte tiles (int8 matrices)
+    text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small_n8.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small_n8.inc").read_text()
 
 
 def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
@@ -137,8 +140,9 @@ def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
     mod.OUT, mod.OUT_HELPER = tmp_path / "coder.inc", tmp_path / "helper.inc"
     mod.OUT_LOADER, mod.OUT_STORER = tmp_path / "loader.inc", tmp_path / "storer.inc"
     mod.OUT_N8, mod.OUT_LOADER_N8 = tmp_path / "n8.inc", tmp_path / "loader_n8.inc"      # round 5: the int8 forms of coder and loader
+    mod.OUT_CK, mod.OUT_N8_CK = tmp_path / "ck.inc", tmp_path / "n8_ck.inc"              # ... and the coders that note jump points
     mod.main_all()
-    for name in ("loader", "storer", "n8", "loader_n8"):
+    for name in ("loader", "storer", "n8", "loader_n8", "ck", "n8_ck"):
         assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()

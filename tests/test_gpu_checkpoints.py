@@ -179,3 +179,53 @@ def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, monke
     dec, dstatus = B.ans_decode_gaussian_checkpointed(enc, ck, -100, 100, dev(mu), dev(sd))
     torch.cuda.synchronize()
     assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+
+
+# ---- round 5: jump points at the speed of the plain encoder (producer / consumer encoder), and int8 matrices through them ----
+
+@pytest.mark.parametrize("dtype", ["int32", "int8"])
+@pytest.mark.parametrize("P", [12, 9])
+@pytest.mark.parametrize("n_streams,n_per,interval", [(256, 256, 128), (256, 1024, 256), (512, 768, 384), (256, 4096, 512), (256, 512, 512),
+                                                      (256, 256, 32), (256, 384, 96)])
+def test_producer_consumer_encoders_note_jump_points(B, O, dtype, P, n_streams, n_per, interval):
+    """cst_ans_encode_batch_ckpt / _ckpt_sym on shapes the producer / consumer encoders take: the words of the plain encoder, the
+    jump table of the CPU oracle (AnsCoder::pos() in front of every chunk: stack.rs:1107-1139) for EVERY stream, and the chunks
+    decoded on their own lanes (int8: by the decoder loops themselves where the chunks are whole 128-symbol lines)"""
+    lo = -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(500 + interval, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    want_pos, want_state = O.ans_jump_table(sym, lo, cdf, P, interval)
+    if dtype == "int8" and n_per % 128 != 0:
+        pytest.skip("int8 rows are whole 128-symbol lines")
+    d = dev(sym if dtype == "int32" else sym.astype(np.int8))
+    enc, ck = B.ans_encode_checkpointed(d, model, interval, (32, 64, P))
+    assert B.last_kernel() == ("ans_encode_pc_kernel<ckpt>" if dtype == "int32" else "ans_encode_pc_n8_kernel<ckpt>")
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    assert np.array_equal(ck.pos.cpu().numpy().astype(np.uint32), want_pos)
+    assert np.array_equal(ck.state.cpu().numpy().view(np.uint64), want_state)
+    dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=d.dtype)
+    if dtype == "int8" and interval % 128 == 0:
+        assert B.last_kernel() in ("ans_decode_n8_kernel", "ans_decode_small_n8_kernel")
+    assert dec.dtype == d.dtype and (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+def test_int8_jump_points_on_shapes_that_convert(B, O):
+    """int8 / int16 matrices whose shape the native kernels do not take: converted next to the int32 calls, same jump table"""
+    P, lo = 12, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    for dtype, n_streams, n_per, interval in ((torch.int8, 70, 120, 40), (torch.int16, 256, 256, 128), (torch.int8, 256, 192, 64)):
+        sym = O.synth_symbols(9, 0, n_streams, n_per, lo, cdf, P)
+        want_pos, want_state = O.ans_jump_table(sym, lo, cdf, P, interval)
+        d = dev(sym).to(dtype)
+        enc, ck = B.ans_encode_checkpointed(d, model, interval, (32, 64, P))
+        assert np.array_equal(ck.pos.cpu().numpy().astype(np.uint32), want_pos)
+        assert np.array_equal(ck.state.cpu().numpy().view(np.uint64), want_state)
+        dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=dtype)
+        assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)

@@ -161,3 +161,50 @@ def test_small_footprint_kernels_at_the_maximum_rate(B, O, dtype, frac):
     for s in (0, 4097, n_streams - 1):
         w, nw, _ = O.ans_encode_batch(sym[s: s + 1], 0, cdf, P, 32, 64)
         assert np.array_equal(words[s, : n_words[s]], w[0, : nw[0]]), f"stream {s}"
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.02, 0.2])
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("geo", ["big", "small"])
+def test_per_symbol_gaussian_decoders_at_the_maximum_rate(B, O, monkeypatch, coder, geo, frac):
+    """f1 (every symbol its own mean and std) at 24 bits per symbol: needle-thin models far from their symbol -- the leaky
+    quantizer's floor of 2^-24 -- with a likely symbol here and there; both geometries of the lane decoder (CST_LANE_GEO), both
+    coders, and the jump-point form of the ANS coder"""
+    monkeypatch.setenv("CST_LANE_GEO", geo)
+    rng = np.random.default_rng(int(frac * 1000) + 5)
+    n_streams, n_per, lo, hi = 128, 512, -100, 100
+    sym = rng.integers(60, 101, (n_streams, n_per)).astype(np.int32)
+    mu = np.full((n_streams, n_per), -90.0)
+    sd = np.full((n_streams, n_per), 0.05)
+    likely = rng.random((n_streams, n_per)) < frac
+    mu = np.where(likely, sym.astype(np.float64), mu)
+    sd = np.where(likely, 0.3, sd)
+    enc_f, dec_f = (B.ans_encode_gaussian, B.ans_decode_gaussian) if coder == "ans" else (B.range_encode_gaussian, B.range_decode_gaussian)
+    enc = enc_f(dev(sym), lo, hi, dev(mu), dev(sd))
+    dec, st = dec_f(enc, lo, hi, dev(mu), dev(sd))
+    assert (st.cpu().numpy() == 0).all() and (enc.status.cpu().numpy() == 0).all()
+    assert np.array_equal(dec.cpu().numpy(), sym)
+    if frac == 0.0:
+        assert float(enc.n_words.float().mean()) > 0.74 * n_per          # 24 bits per symbol: three words per four symbols
+    if coder == "ans":
+        for s in (0, 77, 127):
+            c = O.AnsCoder()
+            c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], 24, 32)
+            assert enc.stream(s).tolist() == c.get_compressed().tolist(), f"stream {s}"
+        e2, ck = B.ans_encode_gaussian_checkpointed(dev(sym), lo, hi, dev(mu), dev(sd), 128)
+        d2, s2 = B.ans_decode_gaussian_checkpointed(e2, ck, lo, hi, dev(mu), dev(sd))
+        assert (s2.cpu().numpy() == 0).all() and np.array_equal(d2.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.05])
+def test_ragged_decoder_at_the_maximum_rate(B, O, frac):
+    """many small coders in one launch (cst_ans_ragged.hip) on all-tail data"""
+    P, n = 24, 64
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + 3)
+    seqs = [high_rate_symbols(rng, 1, int(k), n, frac)[0] for k in rng.integers(1, 700, 300)]
+    symbols, offsets = B.ragged(seqs)
+    enc = B.ans_encode_ragged(symbols, offsets, model, (32, 64, P))
+    dec, st = B.ans_decode_ragged(enc, model, offsets)
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, symbols)
