@@ -266,7 +266,10 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
     EncEntry* table = reinterpret_cast<EncEntry*>(smem);
     for (int u = threadIdx.x; u < 256; u += kPcThreads) {
         const int idx = (u - 128) - a.min_symbol;
-        table[u] = pack_entry(a.enc[(idx >= 0 && idx < a.n_symbols) ? idx : 0], P);
+        const bool in_support = idx >= 0 && idx < a.n_symbols;
+        EncEntry e = pack_entry(a.enc[in_support ? idx : 0], P);
+        if (!in_support) e.c |= 0x8000u;                 // the range check's flag (c < 2^12 in a real entry): n8_fold_minmax of the generator
+        table[u] = e;
     }
 
     if (wave < kPcWaves) {                               // ---- coder ----
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
         uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcN8HandOff + cw * kPcHandWaveBytes);
         const size_t s = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave + lane;
         uint32_t lo = 0, hi = 0;
-        int32_t smin = 16 * a.min_symbol, smax = smin;  // (the statement folds the table ADDRESSES 16 * symbol)
+        int32_t smin = 0, smax = 0;                      // (the statement ORs the first words of the entries it codes into smax: bit 15 = outside the support)
         if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
         const uint32_t row_addr = lds_addr(smem + kPcN8TileOff + (2 * cw) * kPcN8LineBytes) + (uint32_t)(lane * kPcN8RowBytes);
         pc_barrier();                                   // table and the first line are in LDS
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
         else
             ans_encode_pc_n8_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t);
         hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
-        hand[3 * kWave + lane] = max((uint32_t)((smax >> 4) - a.min_symbol), (uint32_t)((smin >> 4) - a.min_symbol));
+        (void)smin;
+        hand[3 * kWave + lane] = (smax & 0x8000) ? 0xffffffffu : 0u;        // "largest table index seen": beyond every alphabet, or inside
         pc_barrier();                                   // the last window and the final state are published
         return;
     }

@@ -5,6 +5,9 @@ import os, sys
 from pathlib import Path
 import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+if os.environ.get("AB_LIB"):                       # an experimental build of the library (A/B runs on one box)
+    import constriction_amd._native as _N
+    _N.LIB_PATH = Path(os.environ["AB_LIB"]).resolve()
 import bench
 from constriction_amd import batched as B
 

@@ -26,6 +26,10 @@ from asmgen import Asm  # noqa: E402
 # the others: no instruction more than the int32 form), a quad is one ds_write_b32 into the lane's row of a byte tile -- rows of 128
 # symbols + 4 bytes of padding, one line of the matrix -- and the loop body is FOUR tiles: the group of 128 symbols leaves at the
 # end of the fourth (eight row blocks: four ds_read_b32 and one 16-byte store each).  16.25 KiB per wave: eight waves per CU.
+# (Tried and dropped: TWO tables -- cp[q] = c | p << 16 as in the big decoders and a byte table of symbols at LDS address 0 read with
+# ds_read_u8 straight from the quantile: 15.25 VALU per symbol instead of 17.  The D16 byte loads that would have merged two symbols per
+# register ZERO the other half on this chip (scripts/microbench/ds_d16.hip: SRAM-ECC), and the kernel ran in the same 0.350 ms with
+# the shorter step as with this one: the third LDS read per symbol costs what the two VALU instructions saved.)
 N8 = bool(os.environ.get("GEN_SMALL_N8"))
 N8_ROW = 132
 SUBTILES = 4 if N8 else 1
