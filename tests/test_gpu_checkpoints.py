@@ -1,10 +1,14 @@
 """GPU tests of checkpointed streams (cst_ans_encode_batch_ckpt / cst_ans_decode_batch_ckpt): the reference's Pos / Seek
 jump tables (src/stream/stack.rs:1107-1139, its test :1456-1548) for the batched coder, and BASELINE config C1 (ONE stream
 of 10^6 symbols, QuantizedGaussian(-50, 50, 3.2, 9.6), P = 24) decoded on a thousand lanes."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# (runs of the suite through the alternate kernel paths -- profiles/r05_alt_paths.txt -- do not take the kernels the tests name)
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED"))
 torch = pytest.importorskip("torch")
 
 
@@ -201,7 +205,7 @@ def test_producer_consumer_encoders_note_jump_points(B, O, dtype, P, n_streams, 
         pytest.skip("int8 rows are whole 128-symbol lines")
     d = dev(sym if dtype == "int32" else sym.astype(np.int8))
     enc, ck = B.ans_encode_checkpointed(d, model, interval, (32, 64, P))
-    assert B.last_kernel() == ("ans_encode_pc_kernel<ckpt>" if dtype == "int32" else "ans_encode_pc_n8_kernel<ckpt>")
+    assert ALT or B.last_kernel() == ("ans_encode_pc_kernel<ckpt>" if dtype == "int32" else "ans_encode_pc_n8_kernel<ckpt>")
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
@@ -211,7 +215,7 @@ def test_producer_consumer_encoders_note_jump_points(B, O, dtype, P, n_streams, 
     assert np.array_equal(ck.state.cpu().numpy().view(np.uint64), want_state)
     dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=d.dtype)
     if dtype == "int8" and interval % 128 == 0:
-        assert B.last_kernel() in ("ans_decode_n8_kernel", "ans_decode_small_n8_kernel")
+        assert ALT or B.last_kernel() in ("ans_decode_n8_kernel", "ans_decode_small_n8_kernel")
     assert dec.dtype == d.dtype and (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
 
 

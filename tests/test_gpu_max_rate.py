@@ -4,10 +4,14 @@ tile at (32,64,12), 24 at P = 24 and for 16-bit words) and the refills fall on e
 same steps tile after tile and missed a stale read of the first refill candidate of a tile in the per-stream-table decoder (found in
 round 5: wrong symbols at position 1 of a tile, only above ~11.5 bits per symbol).  Every decoder family, against the input and the
 CPU oracle's words."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# (runs of the suite through the alternate kernel paths -- profiles/r05_alt_paths.txt -- do not take the kernels the tests name)
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED"))
 torch = pytest.importorskip("torch")
 
 
@@ -126,13 +130,13 @@ def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac):
     want_words, want_n, _ = O.ans_encode_batch(sym, 0, cdf, P, 32, 64)
     d = dev(sym.astype(np.int8))
     enc = B.ans_encode(d, model, (32, 64, P))
-    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
     for s in range(256):
         assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
     dec, st = B.ans_decode(enc, model, 2048, dtype=torch.int8)
-    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
 
 
@@ -153,7 +157,7 @@ def test_small_footprint_kernels_at_the_maximum_rate(B, O, dtype, frac):
     d = dev(sym if dtype == "int32" else sym.astype(np.int8))
     enc = B.ans_encode(d, model, (32, 64, P))
     dec, st = B.ans_decode(enc, model, n_per, dtype=d.dtype)
-    assert B.last_kernel() == ("ans_decode_small_kernel" if dtype == "int32" else "ans_decode_small_n8_kernel")
+    assert ALT or B.last_kernel() == ("ans_decode_small_kernel" if dtype == "int32" else "ans_decode_small_n8_kernel")
     assert (st.cpu().numpy() == 0).all() and (enc.status.cpu().numpy() == 0).all()
     wrong = (dec != d).any(dim=1).nonzero().flatten()
     assert wrong.numel() == 0, f"{wrong.numel()} streams decode wrongly, first {wrong[:4].tolist()}"

@@ -1,10 +1,14 @@
 """GPU tests of narrow symbol matrices (ABI 4: cst_ans_encode_batch_sym / cst_ans_decode_batch_sym, cst_symbols_widen / _narrow):
 int8 / int16 matrices give the words of the int32 call on the widened values (the CPU oracle's), and decode back into the narrow
 type.  The reference's coders are generic over the symbol type (src/stream/model/quantize.rs:229-255)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# (runs of the suite through the alternate kernel paths -- profiles/r05_alt_paths.txt -- do not take the kernels the tests name)
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED"))
 torch = pytest.importorskip("torch")
 
 
@@ -94,7 +98,7 @@ def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n
     want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
     d = _aligned_i8(sym)
     enc = B.ans_encode(d, model, (32, 64, P))
-    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
@@ -102,7 +106,7 @@ def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n
         assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
     out = torch.full((n_streams, n_per), 99, dtype=torch.int8, device="cuda")
     dec, dstatus = B.ans_decode(enc, model, n_per, out=out)
-    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
     assert dec.dtype == torch.int8 and (dstatus.cpu().numpy() == 0).all()
     assert torch.equal(dec, d)
     # ... and the int32 kernels agree on the same words
@@ -121,7 +125,7 @@ def test_int8_native_kernels_report_what_int32_reports(B, O):
     bad = sym.copy()
     bad[3, 10] = 51; bad[69, 0] = -128; bad[70, 255] = 127; bad[255, 128] = -51
     enc = B.ans_encode(_aligned_i8(bad), model, (32, 64, P))
-    assert B.last_kernel() == "ans_encode_pc_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
     torch.cuda.synchronize()
     words, n_words, st = enc.to_numpy()
     flagged = [3, 69, 70, 255]
@@ -138,7 +142,7 @@ def test_int8_native_kernels_report_what_int32_reports(B, O):
     want, want_st = O.ans_decode_batch(w, n, n_per, lo, cdf, P)
     src = (torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(n.view(np.int32)).cuda())
     got, gst = B.ans_decode(src, model, n_per, config=(32, 64, P), dtype=torch.int8)
-    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
     assert gst.cpu().numpy().tolist() == want_st.tolist() and want_st[77] != 0
     ok = want_st == 0
     assert np.array_equal(got.cpu().numpy()[ok], want[ok].astype(np.int8))
@@ -157,7 +161,7 @@ def test_int8_native_decoder_packed_words_and_raw_state(B, O):
     enc = B.ans_encode(d, model, (32, 64, P))
     packed, offsets = B.compact(enc)
     dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), dtype=torch.int8)
-    assert B.last_kernel() == "ans_decode_n8_kernel"
+    assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
     assert torch.equal(dec, d) and (st.cpu().numpy() == 0).all()
     words, n_words, _ = enc.to_numpy()
     state = np.array([(int(words[s, n_words[s] - 1]) << 32) | int(words[s, n_words[s] - 2]) for s in range(n_streams)], dtype=np.uint64)
@@ -167,13 +171,14 @@ def test_int8_native_decoder_packed_words_and_raw_state(B, O):
     d_status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     half = n_per // 2
     outs = []
+    scratch = torch.empty(N.lib().cst_symbols_scratch_bytes(n_streams, half, 1), dtype=torch.uint8, device="cuda")   # (only the conversion path touches it)
     for _ in range(2):
         out = torch.empty((n_streams, half), dtype=torch.int8, device="cuda")
         N.check(N.lib().cst_ans_decode_batch_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(enc.words.data_ptr()), None, enc.words.shape[1],
                                                  enc.words.numel(), C.c_void_p(d_n.data_ptr()), C.c_void_p(out.data_ptr()), 1, n_streams, half, 0,
                                                  C.c_void_p(d_state.data_ptr()), C.c_void_p(d_n_out.data_ptr()), C.c_void_p(d_status.data_ptr()),
-                                                 1, None, None), "cst_ans_decode_batch_sym")
-        assert B.last_kernel() == "ans_decode_n8_kernel"
+                                                 1, C.c_void_p(scratch.data_ptr()), None), "cst_ans_decode_batch_sym")
+        assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
         torch.cuda.synchronize()
         assert (d_status.cpu().numpy() == 0).all()
         d_n.copy_(d_n_out)
@@ -194,7 +199,7 @@ def test_int8_shapes_the_native_kernels_do_not_take(B, O):
         d = flat[skew: skew + n_streams * n_per].view(n_streams, n_per)
         d.copy_(torch.from_numpy(sym).to(torch.int8))
         enc = B.ans_encode(d, model, (32, 64, P))
-        assert B.last_kernel() != "ans_encode_pc_n8_kernel"
+        assert ALT or B.last_kernel() != "ans_encode_pc_n8_kernel"
         torch.cuda.synchronize()
         words, n_words, status = enc.to_numpy()
         assert (status == 0).all() and n_words.tolist() == want_n.tolist()
