@@ -712,6 +712,12 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
 # ---------------------------------------------------------------------------------------------------------------------
 
 def _gaussian_args(symbols_shape, means, stds):
+    # float32 parameter matrices are widened, exactly as the reference's Python API does (PyReadonlyFloatArray::cast_f64,
+    # src/pybindings/mod.rs:187-214; its own doc example passes float32 arrays): the models are those of the widened values
+    if means.dtype == torch.float32:
+        means = means.to(torch.float64)
+    if stds.dtype == torch.float32:
+        stds = stds.to(torch.float64)
     means = _require_cuda(means, torch.float64, "means")
     stds = _require_cuda(stds, torch.float64, "stds")
     if tuple(means.shape) != tuple(symbols_shape) or tuple(stds.shape) != tuple(symbols_shape):

@@ -206,3 +206,48 @@ def test_int8_shapes_the_native_kernels_do_not_take(B, O):
         out = flat.new_zeros(n_streams * n_per + 256)[skew: skew + n_streams * n_per].view(n_streams, n_per)
         dec, _ = B.ans_decode(enc, model, n_per, out=out)
         assert torch.equal(dec, d)
+
+
+def test_int8_native_encoder_capacity_and_raw_state(B, O):
+    """the int8 encoder on slabs that are too small (CST_STREAM_CAPACITY, nothing written behind the slabs) and continuing from a given
+    state (CST_FLAG_RAW_STATE: AnsCoder::encode_symbols_reverse on a non-empty coder, stack.rs:784-849): the two halves of every row
+    coded by two calls are the row coded by one"""
+    import ctypes as C
+    from constriction_amd import _native as N
+    P, n_streams, n_per, lo = 12, 512, 512, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(78, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    d = _aligned_i8(sym)
+    lib, cfg = N.lib(), N.CoderConfig(32, 64, P)
+    stride = 32                                           # < the ~90 words a stream needs: every stream overflows its slab
+    guard = torch.full((n_streams * stride + 4096,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    n_words = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
+                                         C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "capacity")
+    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    torch.cuda.synchronize()
+    assert (want_n > stride).all() and (status.cpu().numpy() == 2).all() and (n_words.cpu().numpy() == 0).all()
+    assert (guard[n_streams * stride:].cpu().numpy() == 0x5A5A5A5A).all(), "words were written behind the last slab"
+    # raw state: the SECOND half of a row is coded first (encoding runs backwards), the first half continues behind its words
+    half = n_per // 2
+    second, first = d[:, half:].contiguous(), d[:, :half].contiguous()
+    assert second.data_ptr() % 128 == 0 and first.data_ptr() % 128 == 0
+    full = B.max_words(n_per, (32, 64, P))
+    st = torch.zeros(n_streams, dtype=torch.int64, device="cuda")
+    wa = torch.zeros((n_streams, full), dtype=torch.int32, device="cuda")
+    wb = torch.zeros((n_streams, full), dtype=torch.int32, device="cuda")
+    na, nb = torch.zeros(n_streams, dtype=torch.int32, device="cuda"), torch.zeros(n_streams, dtype=torch.int32, device="cuda")
+    for part, w, n in ((second, wa, na), (first, wb, nb)):
+        N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(part.data_ptr()), 1, n_streams, half, 0, C.c_void_p(w.data_ptr()), full,
+                                             C.c_void_p(n.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(status.data_ptr()), 1, None, None), "raw")
+        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    torch.cuda.synchronize()
+    a, b = wa.cpu().numpy().view(np.uint32), wb.cpu().numpy().view(np.uint32)
+    ka, kb, state = na.cpu().numpy(), nb.cpu().numpy(), st.cpu().numpy().view(np.uint64)
+    for s in range(n_streams):
+        tail = [int(state[s] & 0xffffffff), int(state[s] >> 32)] if state[s] >> 32 else [int(state[s])]      # into_compressed: the state's words
+        got = a[s, : ka[s]].tolist() + b[s, : kb[s]].tolist() + tail
+        assert got == want_words[s, : want_n[s]].tolist(), f"stream {s}"

@@ -229,3 +229,22 @@ def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, n_per, monkeypatch
             c = O.RangeEncoder(W=32, S=64)
             c.encode(sym[s], [O.GaussianModel(lo, hi, m, d, P, 32) for m, d in zip(mu[s], sd[s])], P)
         assert words[s, : n_words[s]].tolist() == c.get_compressed().tolist(), f"stream {s}"
+
+
+def test_float32_parameters_are_widened_as_the_reference_does(B, O):
+    """the reference's Python API takes float32 parameter arrays and casts them to f64 (src/pybindings/mod.rs:187-214; its doc
+    example passes float32): the batched calls do the same -- the words of the widened values, for both coders"""
+    lo, hi = -100, 100
+    sym, mu, sd = workload(130, 64, lo, hi, 21)
+    mu32, sd32 = mu.astype(np.float32), sd.astype(np.float32)
+    enc = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu32), dev(sd32))
+    dec, st = B.ans_decode_gaussian(enc, lo, hi, dev(mu32), dev(sd32))
+    torch.cuda.synchronize()
+    assert (enc.status.cpu().numpy() == 0).all() and (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    for s in (0, 64, 129):
+        c = O.AnsCoder()
+        c.encode_gaussian_reverse(sym[s], lo, hi, mu32[s].astype(np.float64), sd32[s].astype(np.float64), 24, 32)
+        assert enc.stream(s).tolist() == c.get_compressed().tolist(), f"stream {s}"
+    enc_r = B.range_encode_gaussian(dev(sym), lo, hi, dev(mu32), dev(sd32))
+    dec_r, st_r = B.range_decode_gaussian(enc_r, lo, hi, dev(mu32), dev(sd32))
+    assert (st_r.cpu().numpy() == 0).all() and np.array_equal(dec_r.cpu().numpy(), sym)
