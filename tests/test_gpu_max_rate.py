@@ -212,3 +212,105 @@ def test_ragged_decoder_at_the_maximum_rate(B, O, frac):
     enc = B.ans_encode_ragged(symbols, offsets, model, (32, 64, P))
     dec, st = B.ans_decode_ragged(enc, model, offsets)
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, symbols)
+
+
+# ---- the same rates on PACKED words: every stream starts at an arbitrary word of one buffer, so the word windows run at every
+# ---- alignment phase of their 16-byte chunks (slabs are 64-byte aligned: the tests above only see phase 0) ----
+
+def gapped(words, n_words, rng, max_gap=19):
+    """(packed int32 buffer, offsets int64[n + 1], n_words) with 0 .. max_gap - 1 words of junk in front of every stream"""
+    n_streams = len(n_words)
+    gaps = rng.integers(0, max_gap, n_streams)
+    offsets = np.zeros(n_streams + 1, np.int64)
+    offsets[1:] = np.cumsum(gaps + n_words)
+    offsets[:-1] += gaps                                   # stream s occupies [offsets[s], offsets[s] + n_words[s])
+    total = int((gaps + n_words).sum()) + 64
+    buf = rng.integers(1, 2 ** 32, total, dtype=np.uint64).astype(np.uint32)
+    for s in range(n_streams):
+        buf[offsets[s]: offsets[s] + n_words[s]] = words[s, : n_words[s]]
+    return dev(buf.view(np.int32)), dev(offsets), dev(n_words.astype(np.int32))
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("coder,cfg", CASES, ids=lambda v: v if isinstance(v, str) else "W%dS%dP%d" % v)
+def test_shared_table_decoders_at_the_maximum_rate_on_packed_words(B, O, coder, cfg, frac):
+    W, S, P = cfg
+    n = 101 if P >= 8 else 16
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + P + 31)
+    sym = high_rate_symbols(rng, 192, 2048, n, frac)
+    enc = (B.ans_encode if coder == "ans" else B.range_encode)(dev(sym), model, cfg)
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    if W == 16:
+        words = words.astype(np.uint32)                    # (one 16-bit word per 32-bit slot in the packed form too)
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
+    if coder == "ans":
+        for cold in (False, True):
+            dec, st = B.ans_decode((buf, nw), model, 2048, offsets=offsets, config=cfg, cold=cold)
+            assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), f"cold={cold} [{B.last_kernel()}]"
+        if W == 32 and P <= 12:
+            d8, st = B.ans_decode((buf, nw), model, 2048, offsets=offsets, config=cfg, dtype=torch.int8)
+            assert int(st.abs().sum()) == 0 and np.array_equal(d8.cpu().numpy(), sym.astype(np.int8)), B.last_kernel()
+    else:
+        dec, st = B.range_decode((buf, nw), model, 2048, offsets=offsets, config=cfg)
+        assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), B.last_kernel()
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05])
+@pytest.mark.parametrize("dtype", ["int32", "int8"])
+def test_small_footprint_decoders_at_the_maximum_rate_on_packed_words(B, O, dtype, frac):
+    P, n = 12, 101
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_streams, n_per = cus * 256 + 512, 256
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + 77)
+    sym = high_rate_symbols(rng, n_streams, n_per, n, frac)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng, max_gap=5)
+    dt = torch.int32 if dtype == "int32" else torch.int8
+    dec, st = B.ans_decode((buf, nw), model, n_per, offsets=offsets, config=(32, 64, P), dtype=dt)
+    assert ALT or B.last_kernel() == ("ans_decode_small_kernel" if dtype == "int32" else "ans_decode_small_n8_kernel")
+    wrong = (dec != dev(sym).to(dt)).any(dim=1).nonzero().flatten()
+    assert int(st.abs().sum()) == 0 and wrong.numel() == 0, f"{wrong.numel()} streams decode wrongly, first {wrong[:4].tolist()}"
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.03, 0.3])
+def test_per_stream_table_decoder_at_the_maximum_rate_on_packed_words(B, O, frac):
+    n, k, P = 320, 2048, 12
+    rng = np.random.default_rng(int(frac * 100) + 9)
+    mu_h, sd_h = rng.uniform(-5, 5, n), rng.uniform(0.4, 0.8, n)
+    model = B.Model.quantized_gaussian_per_stream(-127, 127, dev(mu_h), dev(sd_h), P)
+    tails = rng.choice(np.concatenate([np.arange(-127, -40), np.arange(40, 128)]), (n, k)).astype(np.int32)
+    likely = np.rint(mu_h)[:, None].astype(np.int32) + np.zeros((n, k), np.int32)
+    sym = np.where(rng.random((n, k)) < frac, likely, tails).astype(np.int32)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
+    dec, st = B.ans_decode((buf, nw), model, k, offsets=offsets, config=(32, 64, P))
+    assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), B.last_kernel()
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.02])
+@pytest.mark.parametrize("coder", ["ans", "range"])
+@pytest.mark.parametrize("geo", ["big", "small"])
+def test_per_symbol_gaussian_decoders_at_the_maximum_rate_on_packed_words(B, O, monkeypatch, coder, geo, frac):
+    monkeypatch.setenv("CST_LANE_GEO", geo)
+    rng = np.random.default_rng(int(frac * 1000) + 6)
+    n_streams, n_per, lo, hi = 128, 512, -100, 100
+    sym = rng.integers(60, 101, (n_streams, n_per)).astype(np.int32)
+    likely = rng.random((n_streams, n_per)) < frac
+    mu = np.where(likely, sym.astype(np.float64), -90.0)
+    sd = np.where(likely, 0.3, 0.05)
+    enc_f, dec_f = (B.ans_encode_gaussian, B.ans_decode_gaussian) if coder == "ans" else (B.range_encode_gaussian, B.range_decode_gaussian)
+    enc = enc_f(dev(sym), lo, hi, dev(mu), dev(sd))
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all()
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
+    dec, st = dec_f((buf, nw), lo, hi, dev(mu), dev(sd), offsets=offsets, config=(32, 64, 24))
+    assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), B.last_kernel()
