@@ -251,3 +251,29 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O):
         tail = [int(state[s] & 0xffffffff), int(state[s] >> 32)] if state[s] >> 32 else [int(state[s])]      # into_compressed: the state's words
         got = a[s, : ka[s]].tolist() + b[s, : kb[s]].tolist() + tail
         assert got == want_words[s, : want_n[s]].tolist(), f"stream {s}"
+
+
+@pytest.mark.parametrize("n_streams", [582, 257, 330])
+def test_int8_batches_that_are_not_whole_workgroups(B, O, n_streams):
+    """batches that are not whole workgroups / waves take the conversion path as a whole (a split into a native head and a converted
+    tail was measured and dropped: the two launches run one after the other, and a launch lasts as long as its longest STREAM --
+    65 636 x 4096 int8: 0.63 ms split against 0.54 converted); the words, counts and symbols are the same; also packed + offsets"""
+    P, n_per, lo = 12, 256, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(4000 + n_streams, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    d = _aligned_i8(sym)
+    enc = B.ans_encode(d, model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    out = torch.full((n_streams, n_per), 99, dtype=torch.int8, device="cuda")
+    dec, dstatus = B.ans_decode(enc, model, n_per, out=out)
+    assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
+    packed, offsets = B.compact(enc)
+    out.fill_(98)
+    dec, dstatus = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
+    assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
