@@ -52,8 +52,11 @@ __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeAr
     __syncthreads();
 
     const size_t s0 = ((size_t)blockIdx.x * kBlock + (size_t)wave_in_block * kWave);
-    if (s0 >= a.n_streams) return;                       // (the launcher only takes whole waves)
-    const size_t s = s0 + lane;
+    if (s0 >= a.n_streams) return;
+    // a partial wave: the lanes behind the last stream decode the LAST stream again -- everything a lane does is a function of its
+    // stream alone, so they read what its lane reads and write the same bytes to the same places (symbols, status, state)
+    const uint32_t last_row = (uint32_t)min((size_t)(kWave - 1), a.n_streams - 1 - s0);
+    const size_t s = s0 + min((uint32_t)lane, last_row);
     const size_t N = a.n_per_stream;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     int8_t* out = reinterpret_cast<int8_t*>(a.symbols);   // (the int8 matrix travels in the int32 field of the argument block)
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeAr
     const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
     uint32_t goff[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * N + 16 * (size_t)(lane & 7));
     const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
     uint32_t row_cur = lds_addr(tile_a) + (uint32_t)(lane * kN8RowBytes), row_prev = lds_addr(tile_b) + (uint32_t)(lane * kN8RowBytes);
     uint32_t tr_cur = lds_addr(tile_a) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
@@ -154,8 +157,9 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
     __syncthreads();
 
     const size_t s0 = (size_t)blockIdx.x * kN8SmThreads + (size_t)wave_in_block * kWave;
-    if (s0 >= a.n_streams) return;                       // (the launcher only takes whole waves)
-    const size_t s = s0 + lane;
+    if (s0 >= a.n_streams) return;
+    const uint32_t last_row = (uint32_t)min((size_t)(kWave - 1), a.n_streams - 1 - s0);      // (a partial wave: see ans_decode_n8_kernel)
+    const size_t s = s0 + min((uint32_t)lane, last_row);
     const size_t N = a.n_per_stream;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     int8_t* out = reinterpret_cast<int8_t*>(a.symbols);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
     const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
     uint32_t goff[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * N + 16 * (size_t)(lane & 7));
     const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
     const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * N);
     const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
@@ -190,12 +194,12 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
     }
 }
 
-// Whole waves, rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
+// Rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
 bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (!a.dec_cp || !a.dec_idx) return false;
-    if (a.n_streams == 0 || a.n_streams % kWave != 0) return false;
+    if (a.n_streams == 0) return false;                  // (partial waves are taken: their spare lanes repeat the last stream)
     if (a.n_per_stream % kN8GroupSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if (a.offsets && a.words_capacity == 0) return false;                                          // the lanes' 32-bit word offsets need a known span

@@ -277,3 +277,24 @@ def test_int8_batches_that_are_not_whole_workgroups(B, O, n_streams):
     out.fill_(98)
     dec, dstatus = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
     assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("n_streams", [1, 63, 65, 300, 1000])
+@pytest.mark.parametrize("n_per", [128, 512])
+def test_int8_native_decoder_takes_partial_waves(B, O, n_streams, n_per):
+    """any number of streams: the spare lanes of the last wave decode the last stream again (same reads, same bytes to the same places)"""
+    P, lo = 12, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(6000 + n_streams, 0, n_streams, n_per, lo, cdf, P)
+    enc = B.ans_encode(torch.from_numpy(sym).cuda(), model, (32, 64, P))
+    guard = torch.full((n_streams * n_per + 4096,), 77, dtype=torch.int8, device="cuda")
+    out = guard[: n_streams * n_per].view(n_streams, n_per)
+    dec, st = B.ans_decode(enc, model, n_per, out=out)
+    assert ALT or B.last_kernel() == "ans_decode_n8_kernel"
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym.astype(np.int8))
+    assert (guard[n_streams * n_per:].cpu().numpy() == 77).all(), "symbols were written behind the matrix"
+    packed, offsets = B.compact(enc)
+    out.fill_(55)
+    dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
+    assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym.astype(np.int8))
