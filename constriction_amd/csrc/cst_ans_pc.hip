@@ -74,7 +74,7 @@ __device__ __forceinline__ void ans_encode_pc_loader_loop(const uint32_t (&tile_
 }
 
 __device__ __forceinline__ void ans_encode_pc_storer_loop(uint32_t (&flushed)[2], const uint32_t (&ring_lane_addr)[2], const uint32_t (&publish_addr)[2],
-                                                          uint32_t cap, const uint32_t (&slab_off)[2], const void* words_base, uint32_t n_tiles) {
+                                                          const uint32_t (&cap)[2], const uint32_t (&slab_off)[2], const void* words_base, uint32_t n_tiles) {
 #include "cst_encode_loop_pc_storer.inc"
 }
 
@@ -88,7 +88,7 @@ __device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char*
                                           size_t ring_off, size_t hand_off_) {
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     uint32_t* ring[2]; uint32_t* hand[2];
-    uint32_t ring_addr[2], pub_addr[2], slab_off[2], flushed[2] = {0, 0};
+    uint32_t ring_addr[2], pub_addr[2], slab_off[2], cap[2], flushed[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         ring[c] = reinterpret_cast<uint32_t*>(smem + ring_off + (cw0 + c) * kPcRingWaveBytes);
@@ -96,21 +96,27 @@ __device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char*
         hand[c][lane] = 0;                              // nothing published yet
         ring_addr[c] = lds_addr(ring[c] + lane);
         pub_addr[c] = lds_addr(hand[c] + lane);
+        // a lane behind the last stream (the int8 kernel takes partial workgroups: its coder lane codes the last stream again) has a
+        // slab of capacity 0 where the slab of stream s WOULD lie: nothing of it is ever stored (the quad stores count on slabs a
+        // constant distance apart, so the offset is not clamped)
         slab_off[c] = (uint32_t)((s0 + c * kWave + lane) * a.stride_words * 4);
+        cap[c] = s0 + c * kWave + lane < a.n_streams ? (uint32_t)a.stride_words : 0u;
     }
-    ans_encode_pc_storer_loop(flushed, ring_addr, pub_addr, (uint32_t)a.stride_words, slab_off, a.words, n_t);
+    ans_encode_pc_storer_loop(flushed, ring_addr, pub_addr, cap, slab_off, a.words, n_t);
     pc_barrier();                                       // the coders have published their last write positions and final states
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const size_t s = s0 + c * kWave + lane;
+        const bool mine = s < a.n_streams;               // (a spare lane of a partial workgroup: nothing to finish, nothing to report)
         EncLane<32, 64> L;
-        L.init(a.words + s * a.stride_words, (uint32_t)a.stride_words, ring[c], lane);
+        L.init(a.words + (mine ? s : 0) * a.stride_words, mine ? (uint32_t)a.stride_words : 0u, ring[c], lane);
         L.out.flushed = flushed[c];
         L.out.wr = hand[c][lane];
         L.state = ((uint64_t)hand[c][2 * kWave + lane] << 32) | hand[c][kWave + lane];
         L.bad = hand[c][3 * kWave + lane];
         uint32_t n_words = 0;
         const int32_t status = L.finish(!raw, (uint32_t)a.n_symbols, n_words);
+        if (!mine) continue;
         if (raw) a.state[s] = (uint64_t)L.state;
         a.status[s] = status;
         a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
@@ -244,7 +250,7 @@ __device__ __forceinline__ void ans_encode_pc_n8_coder_loop_ck(uint32_t& lo, uin
 }
 
 __device__ __forceinline__ void ans_encode_pc_n8_loader_loop(const uint32_t (&line_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
-                                                             uint32_t n_tiles, const uint32_t (&goff)[8]) {
+                                                             uint32_t n_tiles, const uint32_t (&goff0)[8], const uint32_t (&goff1)[8]) {
 #include "cst_encode_loop_pc_loader_n8.inc"
 }
 
@@ -275,7 +281,9 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
     if (wave < kPcWaves) {                               // ---- coder ----
         uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
         uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcN8HandOff + cw * kPcHandWaveBytes);
-        const size_t s = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave + lane;
+        // a partial workgroup: the lanes behind the last stream code the LAST stream again (the loader stages its symbols for them);
+        // what they produce is never stored (pc_storer) except the jump points, which they write where its own lane writes them
+        const size_t s = min((size_t)blockIdx.x * kBlock + (size_t)cw * kWave + lane, a.n_streams - 1);
         uint32_t lo = 0, hi = 0;
         int32_t smin = 0, smax = 0;                      // (the statement ORs the first words of the entries it codes into smax: bit 15 = outside the support)
         if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
@@ -295,32 +303,39 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
     const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
     const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
     if (wave < kPcWaves + 2) {                          // ---- loader ----
-        uint32_t goff[8];
+        // rows of the two coder waves, clamped to the last stream (a partial workgroup: see the coder above)
+        const size_t last = a.n_streams - 1;
+        const size_t first0 = min(s0, last), first1 = min(s0 + kWave, last);
+        uint32_t goff0[8], goff1[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)(((size_t)(lane >> 3) + 8 * k) * N + 16 * (size_t)(lane & 7));
-        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + s0 * N + (N - kPcN8LineSyms));
+        for (int k = 0; k < 8; ++k) {
+            const size_t row = (size_t)(lane >> 3) + 8 * k;
+            goff0[k] = (uint32_t)(min(row, last - first0) * N + 16 * (size_t)(lane & 7));
+            goff1[k] = (uint32_t)(min(row, last - first1) * N + 16 * (size_t)(lane & 7));
+        }
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + first0 * N + (N - kPcN8LineSyms));
         const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
         const uint32_t t0 = lds_addr(smem + kPcN8TileOff + (2 * cw0) * kPcN8LineBytes) + (uint32_t)((lane >> 3) * kPcN8RowBytes + 16 * (lane & 7));
         const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcN8LineBytes};
-        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N));
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((first1 - first0) * N));
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
-        ans_encode_pc_n8_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
+        ans_encode_pc_n8_loader_loop(tr_addr, symbols_base, row_block, n_t, goff0, goff1);
         pc_barrier();
         return;
     }
     pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
 }
 
-// Whole workgroups of 256 streams, rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel.
+// Rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel; any number of streams.
 bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
-    if (a.n_streams == 0 || a.n_streams % kBlock != 0) return false;
+    if (a.n_streams == 0) return false;                  // (partial workgroups are taken: their spare lanes repeat the last stream)
     if (a.n_per_stream % kPcN8LineSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
-    if (a.n_streams * a.stride_words * 4 >= 0x100000000ull) return false;                                                  // 32-bit slab offsets
+    if ((a.n_streams + kBlock - 1) / kBlock * kBlock * a.stride_words * 4 >= 0x100000000ull) return false;                  // 32-bit slab offsets
     if (a.n_symbols < 1 || a.n_symbols > 256 || a.min_symbol < -128 || a.min_symbol + a.n_symbols - 1 > 127) return false;
     return true;
 }
@@ -336,7 +351,7 @@ static PcJumpArgs pc_jump_args(const AnsEncodeArgs& a, size_t interval, uint32_t
 }
 
 cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs) {
-    const size_t blocks = a.n_streams / kBlock;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     auto kernel = ans_encode_pc_n8_kernel<false>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});
@@ -349,7 +364,7 @@ bool pc_n8_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_
 }
 
 cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
-    const size_t blocks = a.n_streams / kBlock;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     auto kernel = ans_encode_pc_n8_kernel<true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, pc_jump_args(a, interval, d_ckpt_pos, d_ckpt_state));

@@ -81,7 +81,7 @@ def gen():
     KQ, BH, M1, M2 = "v130", "v143", "v167", "v168"
     ELIG = "s[88:89]"
     clobbers = [f"v{r}" for r in range(120, 176 if EARLY_STORES else (169 if K_PRED else 167))] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87"] + \
-               (["s88", "s89"] if K_PRED or EARLY_ELIG else []) + ["vcc", "memory"]
+               (["s88", "s89"] if K_PRED or EARLY_ELIG else []) + ["vcc", "scc", "memory"]
     SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
 
     a.i("v_mov_b32 v123, 0")

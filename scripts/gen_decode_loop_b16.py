@@ -57,7 +57,7 @@ def gen():
     GOFF = [f"v{180 + k}" for k in range(8)]
     NEW = [f"v{192 + k}" for k in range(4)]                                            # a second-level entry on its way in
     NEW_T = tup(192)
-    clobbers = [f"v{r}" for r in range(120, 196)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "memory"]
+    clobbers = [f"v{r}" for r in range(120, 196)] + [f"s{r}" for r in range(70, 92)] + ["vcc", "scc", "memory"]
     SD, SAVE, V1, V2 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]"
     RET, XSAVE, FLAGGED = "s[70:71]", "s[72:73]", "s[74:75]"
     SBITS, SSH = "s76", "s77"

@@ -55,7 +55,7 @@ def gen():
     WOFFQ = [f"v{205 + p}" for p in range(4)]
     COLQ = [f"v{209 + p}" for p in range(4)]
     C4I, BPA, IDX = "v213", "v214", "v215"
-    clobbers = [f"v{r}" for r in range(120, 216)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "memory"]
+    clobbers = [f"v{r}" for r in range(120, 216)] + ["s80", "s81", "s82", "s84", "s85", "s86", "s87", "vcc", "scc", "memory"]
     SD = "s[84:85]"                  # (s96..s101 hold flat_scratch / xnack_mask on gfx9: never touch them)
 
     # ---- what depends on the lane only ----

@@ -44,7 +44,7 @@ def gen():
     LAND = [f"v{160 + k}" for k in range(K_CHUNKS)]
     WANT, TMP, TADDR, TOFF = "v163", "v164", "v165", "v166"
     PK0, PK1 = "v167", "v168"
-    clobbers = [f"v{r}" for r in range(120, 169)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "vcc", "memory"]
+    clobbers = [f"v{r}" for r in range(120, 169)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "vcc", "scc", "memory"]
     SD = "s[84:85]"
 
     a.i("v_mov_b32 v123, 0")

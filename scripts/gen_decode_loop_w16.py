@@ -54,7 +54,7 @@ def gen():
     LAND = {"A": [f"v{160 + k}" for k in range(K_CHUNKS)], "B": [f"v{188 + k}" for k in range(K_CHUNKS)]}
     WANT, TMP, TADDR, TOFF = "v163", "v164", "v165", "v166"
     GOFF = [f"v{168 + k}" for k in range(8)]
-    clobbers = [f"v{r}" for r in range(120, 192)] + [f"s{r}" for r in range(80, 88)] + ["vcc", "memory"]
+    clobbers = [f"v{r}" for r in range(120, 192)] + [f"s{r}" for r in range(80, 88)] + ["vcc", "scc", "memory"]
     SD, SAVE = "s[84:85]", "s[86:87]"
 
     def window_requests(st):

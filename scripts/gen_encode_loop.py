@@ -100,7 +100,7 @@ XS = ["v247", "v248", "v249", "v254"]
 QFADDR, QFOFF, QLIM = A0, A1, W0
 QBASE = ["%[wbase]", "s[90:91]", "s[92:93]", "s[94:95]"]
 SD, SAVE = "s[84:85]", "s[86:87]"
-CLOBBERS = [f"v{r}" for r in range(100, 256)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 256)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "scc", "memory"]
 ROW = ["%[row0]", "%[row1]"]          # the lane's own row in tile buffer 0 / 1
 TR = ["%[tr0]", "%[tr1]"]             # transposed write address in tile buffer 0 / 1
 

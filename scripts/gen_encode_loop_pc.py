@@ -55,7 +55,7 @@ A0, A1, W0, W1, U0, U1, T0, T1, SM0, SM1, Q0, Q1 = (f"v{r}" for r in range(148, 
 A_T, W_T, U_T, T_T, SM_T, Q_T = (tup(148 + 2 * i, 2) for i in range(6))
 RR, KK, CK, RA, EA0, EA1, WR = (f"v{r}" for r in range(160, 167))
 SD = "s[84:85]"
-CLOBBERS = [f"v{r}" for r in range(100, 170)] + ["s82", "s84", "s85", "vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 170)] + ["s82", "s84", "s85", "vcc", "scc", "memory"]
 ROW = ["%[row0]", "%[row1]"]
 SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD"
 
@@ -279,7 +279,7 @@ HR = {n: [tup(HBASE + 32 * i + 4 * k) for k in range(8)] for i, n in enumerate(S
 HFD = [(tup(234 + 4 * k, 2), tup(236 + 4 * k, 2), tup(234 + 4 * k)) for k in range(4)]
 HWR, HNCH, HLIM, HFADDR, HFOFF = (f"v{r}" for r in range(250, 255))
 HSAVE = "s[86:87]"
-H_CLOBBERS = [f"v{r}" for r in range(HBASE, 255)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "memory"]
+H_CLOBBERS = [f"v{r}" for r in range(HBASE, 255)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "scc", "memory"]
 HTR = ["%[tr0]", "%[tr1]"]
 
 
@@ -430,7 +430,7 @@ LSETS = int(os.environ.get("GEN_LSETS", "2"))           # register sets per code
 LSLEEP = int(os.environ.get("GEN_LSLEEP", "0"))         # experiment: spread a window's 16 requests over the window (64 LSLEEP cycles after each)
 LBASE = 228 - 64 * LSETS
 LR = {(c, i): [tup(LBASE + 32 * (LSETS * c + i) + 4 * k) for k in range(8)] for c in range(2) for i in range(LSETS)}
-L_CLOBBERS = [f"v{r}" for r in range(LBASE, 228)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "memory"]
+L_CLOBBERS = [f"v{r}" for r in range(LBASE, 228)] + [f"s{r}" for r in range(80, 90)] + ["vcc", "scc", "memory"]
 PAIR_TILE_OFF = 2 * 64 * 36 * 4                          # the partner coder's two tile buffers follow this one's
 
 
@@ -505,7 +505,7 @@ SXS = {c: [f"v{236 + 12 * c + k}" for k in range(4)] for c in range(2)}
 SC4I, SBPA = "v252", "v253"
 SSAVE = {0: "s[86:87]", 1: "s[88:89]"}
 SQBASE = ["%[wbase]", "s[90:91]", "s[92:93]", "s[94:95]"]
-S_CLOBBERS = [f"v{r}" for r in range(196, 254)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "memory"]
+S_CLOBBERS = [f"v{r}" for r in range(196, 254)] + [f"s{r}" for r in range(80, 96)] + ["vcc", "scc", "memory"]
 
 
 def s_flush_rows(a):
@@ -527,7 +527,7 @@ def s_flush_rows(a):
         if "storesame" in HABL:
             a.i(f"v_mov_b32 {SFOFF[c]}, %[slaboff{c}]")
     for c in range(2):
-        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap]", "group inside the slab")
+        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap{c}]", "group inside the slab (capacity 0: a lane without a stream of its own)")
         a.i(f"v_cmp_ne_u32 {SSAVE[c]}, 0, {SNCH[c]}")
         a.i(f"s_and_b64 vcc, vcc, {SSAVE[c]}")
         a.wait_lds(f"fl{c}")
@@ -577,7 +577,7 @@ def s_flush_quads(a):
         a.i(f"v_sub_u32 {SNCH[c]}, {SWR[c]}, %[flushed{c}]")
         a.i(f"v_add_u32 {SLIM[c]}, 16, %[flushed{c}]")
         a.i(f"v_lshrrev_b32 {SNCH[c]}, 4, {SNCH[c]}", "whole 16-word groups pending: 0 or 1")
-        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap]", "group inside the slab")
+        a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap{c}]", "group inside the slab (capacity 0: a lane without a stream of its own)")
         a.i(f"v_cndmask_b32_e64 {SLIM[c]}, 0, {SNCH[c]}, vcc")
         a.i(f"v_lshl_or_b32 {SXQ[c]}, {SLIM[c]}, 31, %[flushed{c}]", "flush position | (a group leaves) << 31")
         for k in range(4):
@@ -654,7 +654,7 @@ def main_split():
               "// Storer wave of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_storer_loop in cst_ans_pc.hip."]
     ops = ['    : [flushed0] "+v"(flushed[0]), [flushed1] "+v"(flushed[1])',
            '    : [lanebase0] "v"(ring_lane_addr[0]), [lanebase1] "v"(ring_lane_addr[1]), [pub0] "v"(publish_addr[0]), [pub1] "v"(publish_addr[1]),',
-           '      [cap] "v"(cap), [slaboff0] "v"(slab_off[0]), [slaboff1] "v"(slab_off[1]), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base), [ntiles] "s"(n_tiles)',
+           '      [cap0] "v"(cap[0]), [cap1] "v"(cap[1]), [slaboff0] "v"(slab_off[0]), [slaboff1] "v"(slab_off[1]), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base), [ntiles] "s"(n_tiles)',
            "    : " + ", ".join(f'"{c}"' for c in S_CLOBBERS) + ");"]
     OUT_STORER.write_text(a.render(header, ops))
     print(f"wrote {OUT_STORER} ({a.n_instr()} instructions incl. prologue)")
@@ -679,7 +679,7 @@ N8_LINEBUF = 64 * N8_ROW           # one line buffer of a coder wave: 8448 bytes
 S8 = [f"v{100 + i}" for i in range(4)]
 EA8 = [[f"v{104 + 4 * e + i}" for i in range(4)] for e in range(2)]
 PA, PB = "v112", "v113"
-N8_CLOBBERS = [f"v{r}" for r in range(100, 114)] + [f"v{r}" for r in range(116, 170)] + ["s82", "s83", "s84", "s85", "s86", "s87", "s88", "vcc", "memory"]
+N8_CLOBBERS = [f"v{r}" for r in range(100, 114)] + [f"v{r}" for r in range(116, 170)] + ["s82", "s83", "s84", "s85", "s86", "s87", "s88", "vcc", "scc", "memory"]
 
 
 def n8_read_syms(a, g, ptr, quad):
@@ -785,7 +785,7 @@ def l8_load(a, i):
     for c in range(2):
         base = "s[80:81]" if c == 0 else "s[84:85]"
         for k in range(8):
-            a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
+            a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{c}_{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
     a.i("s_cmp_lg_u32 s83, 0")
     a.i("s_cselect_b32 s88, 0x80, 0")
     a.i("s_cselect_b32 s89, 1, 0")
@@ -882,7 +882,8 @@ def emit_n8_loader():
               "// Loader wave of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_loader_loop in cst_ans_pc.hip."]
     ops = ['    :',
            '    : [tr0] "v"(line_tr_addr[0]), [tr1] "v"(line_tr_addr[1]), [sbase] "s"(symbols_base), [rowblock] "s"(row_block_bytes), [ntiles] "s"(n_tiles),',
-           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           '      ' + ", ".join(f'[goff0_{k}] "v"(goff0[{k}])' for k in range(8)) + ",",
+           '      ' + ", ".join(f'[goff1_{k}] "v"(goff1[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in L_CLOBBERS) + ");"]
     OUT_LOADER_N8.write_text(a.render(header, ops))
     print(f"wrote {OUT_LOADER_N8} ({a.n_instr()} instructions incl. prologue)")

@@ -54,7 +54,7 @@ NCH, LIM, FADDR, FOFF = (f"v{r}" for r in range(BASE + 146, BASE + 150))
 EW = [regs(BASE + 150 + 8 * e, 8) for e in range(2)]         # (c[t], c[t+1]) of the four symbols of two quads
 SD, SAVE = "s[84:85]", "s[86:87]"
 CLOBBERS = [f"v{r}" for r in range(BASE, BASE + 167)] + ["s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89"] + \
-    (["s90"] if CKPT else []) + ["vcc", "memory"]
+    (["s90"] if CKPT else []) + ["vcc", "scc", "memory"]
 # ONE tile buffer per wave (the second one of gen_encode_loop.py costs 36 KiB of LDS the rows need): the next tile is
 # staged between the last read of the current tile (quad 0's symbols, requested in quad 3) and the first read of the
 # next one (its quad 7, requested in quad 2) -- one wave's LDS operations execute in order.

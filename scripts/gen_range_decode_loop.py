@@ -72,7 +72,7 @@ ESET = [[f"v{204 + k}" for k in range(4)], [f"v{216 + k}" for k in range(4)]]   
 ESET_T = [tup(204, 4), tup(216, 4)]
 PAIR_T, PAIR0, PAIR1 = tup(212), "v212", "v213"
 NEW, NEW_T = [f"v{220 + k}" for k in range(4)], tup(220, 4)                             # a second-level entry on its way in
-CLOBBERS = [f"v{r}" for r in range(120, 224)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(120, 224)] + [f"s{r}" for r in range(70, 96)] + ["vcc", "scc", "memory"]
 SD, SAVE, BAD, CHK, HV, REN = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
 RET, XSAVE, FLAGGED, V1, V2 = "s[70:71]", "s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]"    # (s96..s101 are flat_scratch / xnack_mask)
 B16 = False           # True: 12 < P <= 24, the lookup is one 16-byte bucket entry (DecLut::b16) instead of the table of 2^P quantiles

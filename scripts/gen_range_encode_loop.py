@@ -67,7 +67,7 @@ RA, EA = "v228", "v229"
 FD = [(tup(230 + 4 * k, 2), tup(232 + 4 * k, 2), tup(230 + 4 * k)) for k in range(4)]
 NCH, LIM, FADDR, FOFF = "v246", "v247", "v248", "v249"
 CARRY, SAVE, OVF, SLOW, JUNK, MASK = "s[84:85]", "s[86:87]", "s[90:91]", "s[92:93]", "s[94:95]", "s[96:97]"
-CLOBBERS = [f"v{r}" for r in range(100, 250)] + [f"s{r}" for r in range(80, 98)] + (["s78"] if CKPT else []) + ["vcc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 250)] + [f"s{r}" for r in range(80, 98)] + (["s78"] if CKPT else []) + ["vcc", "scc", "memory"]
 ROW = ["%[row0]", "%[row1]"]          # the lane's own row in tile buffer 0 / 1
 TR = ["%[tr0]", "%[tr1]"]             # transposed write address in tile buffer 0 / 1
 

@@ -188,11 +188,11 @@ def test_int8_native_decoder_packed_words_and_raw_state(B, O):
 
 
 def test_int8_shapes_the_native_kernels_do_not_take(B, O):
-    """rows that are not whole 128-symbol lines, partial workgroups, unaligned matrices: the conversion path, same results"""
+    """rows that are not whole 128-symbol lines, unaligned matrices: the conversion path, same results"""
     P, lo = 12, -50
     cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
-    for n_streams, n_per, skew in ((256, 100, 0), (100, 128, 0), (256, 128, 1)):
+    for n_streams, n_per, skew in ((256, 100, 0), (100, 100, 0), (256, 128, 1)):
         sym = O.synth_symbols(70 + n_per, 0, n_streams, n_per, lo, cdf, P)
         want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
         flat = torch.zeros(n_streams * n_per + 256, dtype=torch.int8, device="cuda")
@@ -253,30 +253,54 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O):
         assert got == want_words[s, : want_n[s]].tolist(), f"stream {s}"
 
 
-@pytest.mark.parametrize("n_streams", [582, 257, 330])
-def test_int8_batches_that_are_not_whole_workgroups(B, O, n_streams):
-    """batches that are not whole workgroups / waves take the conversion path as a whole (a split into a native head and a converted
-    tail was measured and dropped: the two launches run one after the other, and a launch lasts as long as its longest STREAM --
-    65 636 x 4096 int8: 0.63 ms split against 0.54 converted); the words, counts and symbols are the same; also packed + offsets"""
+@pytest.mark.parametrize("n_streams", [1, 70, 257, 330, 582])
+@pytest.mark.parametrize("jump", [0, 2])
+def test_int8_native_encoder_takes_partial_workgroups(B, O, n_streams, jump):
+    """any number of streams: the coder lanes behind the last stream code the last stream again and store nothing (their slabs have
+    capacity 0; nothing is written behind the last slab); the jump points they note are the last stream's own.  (A split into a
+    native head and a converted tail was measured first and dropped: two launches run one after the other, and a launch lasts as
+    long as its longest STREAM -- 65 636 x 4096 int8: 0.63 ms split against 0.54 converted.)"""
+    import ctypes as C
+    from constriction_amd import _native as N
     P, n_per, lo = 12, 256, -50
     cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
     sym = O.synth_symbols(4000 + n_streams, 0, n_streams, n_per, lo, cdf, P)
-    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    sym[n_streams // 2, 7] = 51 if n_streams > 1 else sym[0, 7]          # an impossible symbol somewhere in the middle
+    want_words, want_n, want_st = O.ans_encode_batch(sym, lo, cdf, P)
     d = _aligned_i8(sym)
-    enc = B.ans_encode(d, model, (32, 64, P))
+    stride = B.max_words(n_per, (32, 64, P))
+    guard = torch.full((n_streams * stride + 8192,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    n_words = torch.zeros(n_streams + 64, dtype=torch.int32, device="cuda")
+    status = torch.full((n_streams + 64,), -7, dtype=torch.int32, device="cuda")
+    k = max(jump, 1)
+    pos = torch.full((n_streams + 64, k), -3, dtype=torch.int32, device="cuda")
+    state = torch.full((n_streams + 64, k), -3, dtype=torch.int64, device="cuda")
+    lib, cfg = N.lib(), N.CoderConfig(32, 64, P)
+    if jump:
+        N.check(lib.cst_ans_encode_batch_ckpt_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
+                                                  C.c_void_p(n_words.data_ptr()), n_per // jump, C.c_void_p(pos.data_ptr()), C.c_void_p(state.data_ptr()),
+                                                  C.c_void_p(status.data_ptr()), None, None), "ckpt_sym")
+        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel<ckpt>"
+    else:
+        N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
+                                             C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "sym")
+        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
     torch.cuda.synchronize()
-    words, n_words, status = enc.to_numpy()
-    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    st, nw = status.cpu().numpy(), n_words.cpu().numpy()
+    assert st[:n_streams].tolist() == want_st.tolist() and (st[n_streams:] == -7).all() and (nw[n_streams:] == 0).all()
+    words = guard.cpu().numpy().view(np.uint32)
+    assert (words[n_streams * stride:] == 0x5A5A5A5A).all(), "words were written behind the last slab"
+    rows = words[: n_streams * stride].reshape(n_streams, stride)
     for s in range(n_streams):
-        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
-    out = torch.full((n_streams, n_per), 99, dtype=torch.int8, device="cuda")
-    dec, dstatus = B.ans_decode(enc, model, n_per, out=out)
-    assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
-    packed, offsets = B.compact(enc)
-    out.fill_(98)
-    dec, dstatus = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
-    assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
+        if want_st[s] == 0:
+            assert nw[s] == want_n[s] and np.array_equal(rows[s, : want_n[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    if jump:
+        ok = want_st == 0
+        wp, ws = O.ans_jump_table(sym, lo, cdf, P, n_per // jump)
+        assert np.array_equal(pos.cpu().numpy().view(np.uint32)[:n_streams][ok], wp[ok])
+        assert np.array_equal(state.cpu().numpy().view(np.uint64)[:n_streams][ok], ws[ok])
+        assert (pos.cpu().numpy()[n_streams:] == -3).all() and (state.cpu().numpy()[n_streams:] == -3).all(), "jump points were written behind the arrays"
 
 
 @pytest.mark.parametrize("n_streams", [1, 63, 65, 300, 1000])
