@@ -1374,10 +1374,10 @@ cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32
 bool pc_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval);
 cst_status ans_encode_pc_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs);
 cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs);
-bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
-cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs);
+bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes);
+cst_status ans_decode_n8(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs);
 bool n8_decode_small(const AnsDecodeArgs& a, int device_cus);
-cst_status ans_decode_small_n8(const AnsDecodeArgs& a, hipStream_t hs);
+cst_status ans_decode_small_n8(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs);
 // lane-quad word loads for the P <= 12 decoder (cst_ans_dq.hip)
 bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 cst_status ans_decode_dq(const AnsDecodeArgs& a, hipStream_t hs);

@@ -29,16 +29,24 @@ constexpr size_t kN8LdsBytes = kN8DumpOff + kTileDumpBytes;
 static_assert(kN8LdsBytes <= 160 * 1024, "LDS budget");
 static_assert(kN8TileBytes % 4 == 0 && kN8TileOff % 16 == 0, "tile alignment");
 
+template <int BYTES>
 __device__ __forceinline__ void ans_decode_n8_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur,
                                                    uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask,
                                                    uint32_t P, uint32_t ring_mask, const void* words_base, uint64_t store_base, uint32_t n_groups,
                                                    uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
                                                    const uint32_t (&goff)[8]) {
+    if constexpr (BYTES == 1) {
 #include "cst_decode_loop_n8.inc"
+    } else {
+#include "cst_decode_loop_n16.inc"
+    }
 }
 
 // LDS: [word rings: 4 x 8 KiB][cp + sym tables 32 KiB][two byte tiles per wave (all A, then all B)][dump rows]
+// BYTES = 1: int8 matrices; BYTES = 2: int16 (a 128-byte line is 64 symbols: two tiles per pass of the statement)
+template <int BYTES>
 __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeArgs a) {
+    constexpr int kGroupSyms = kN8GroupSyms / BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -59,7 +67,8 @@ __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeAr
     const size_t s = s0 + min((uint32_t)lane, last_row);
     const size_t N = a.n_per_stream;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
-    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);   // (the int8 matrix travels in the int32 field of the argument block)
+    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);   // (the narrow matrix travels in the int32 field of the argument block; BYTE addresses below)
+    const size_t row_bytes = N * BYTES;
 
     DecLane<32, 64, kDecRingSlots, kDecAhead> L;
     const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
@@ -74,26 +83,26 @@ __global__ __launch_bounds__(kBlock) void ans_decode_n8_kernel(const AnsDecodeAr
     const uint32_t qmask = (1u << P) - 1u;
     const uint32_t lut_addr = lds_addr(lut.cp), lane_addr = lds_addr(ring + lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): nothing of the prologue in flight when the statement keeps its own book
-    const uint32_t n_g = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kN8GroupSyms));
+    const uint32_t n_g = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kGroupSyms));
 
     const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
     const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
     uint32_t goff[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * N + 16 * (size_t)(lane & 7));
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * row_bytes + 16 * (size_t)(lane & 7));
     const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
     uint32_t row_cur = lds_addr(tile_a) + (uint32_t)(lane * kN8RowBytes), row_prev = lds_addr(tile_b) + (uint32_t)(lane * kN8RowBytes);
     uint32_t tr_cur = lds_addr(tile_a) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
-    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * N);
+    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * row_bytes);
     const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-    ans_decode_n8_loop(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P, kDecRingMask, words_base,
+    ans_decode_n8_loop<BYTES>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lut_addr, qmask, (uint32_t)P, kDecRingMask, words_base,
                        store_base, n_g, L.in.shift - 1u, lane_addr, lds_addr(dump), w_off, goff);
     // the last group is still in LDS: the statement swapped the buffers behind it, so it is the "previous" one
     wave_lds_fence();
     {
         const unsigned char* last = ((n_g - 1) & 1) ? tile_b : tile_a;
-        int8_t* dst = out + s0 * N + (size_t)(n_g - 1) * kN8GroupSyms;
+        int8_t* dst = out + s0 * row_bytes + (size_t)(n_g - 1) * kN8GroupSyms;      // (a group is 128 BYTES of every row)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(last + ((lane >> 3) + 8 * k) * kN8RowBytes + 16 * (lane & 7));
@@ -128,18 +137,25 @@ constexpr size_t kN8SmDumpOff = kN8SmTileOff + kN8SmWaves * kN8TileBytes;
 constexpr size_t kN8SmLdsBytes = kN8SmDumpOff + 4 * kWave * 4;
 static_assert(kN8SmLdsBytes <= 160 * 1024, "LDS budget");
 
+template <int BYTES>
 __device__ __forceinline__ void decode_groups_loop_small_n8(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t lut_addr,
                                                             uint32_t mask, uint32_t ring_mask, uint32_t P, const void* words_base,
                                                             uint64_t store_base, uint32_t n_tiles, int32_t min_symbol, uint32_t shift_minus_1,
                                                             uint32_t ring_lane_addr, uint32_t dump_addr, uint32_t words_off,
                                                             uint32_t tile_row_addr, uint32_t tile_tr_addr, const uint32_t (&goff)[8]) {
 #define CST_STORE_MOD "nt"
+    if constexpr (BYTES == 1) {
 #include "cst_decode_loop_small_n8.inc"
+    } else {
+#include "cst_decode_loop_small_n16.inc"
+    }
 #undef CST_STORE_MOD
 }
 
 // LDS: [word rings: 8 x 8 KiB][packed table 16 KiB][one byte tile per wave][one landing area for unused chunk slots]
+template <int BYTES>
 __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const AnsDecodeArgs a) {
+    constexpr int kGroupSyms = kN8GroupSyms / BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
     const size_t N = a.n_per_stream;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     int8_t* out = reinterpret_cast<int8_t*>(a.symbols);
+    const size_t row_bytes = N * BYTES;
 
     DecLane<32, 64, kDecRingSlots, kDecAhead> L;
     const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
@@ -177,14 +194,14 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
     const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
     uint32_t goff[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * N + 16 * (size_t)(lane & 7));
+    for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * row_bytes + 16 * (size_t)(lane & 7));
     const uint32_t tr_off = (uint32_t)((lane >> 3) * kN8RowBytes + 16 * (lane & 7));
-    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * N);
+    const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * row_bytes);
     const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the statement keeps its own book from here
-    decode_groups_loop_small_n8(lo, hi, L.in.rd, L.in.lo_issued, lds_addr(lut), (1u << P) - 1u, kDecRingMask, (uint32_t)P, words_base, store_base,
-                                (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kN8GroupSyms)), a.min_symbol, L.in.shift - 1u,
+    decode_groups_loop_small_n8<BYTES>(lo, hi, L.in.rd, L.in.lo_issued, lds_addr(lut), (1u << P) - 1u, kDecRingMask, (uint32_t)P, words_base, store_base,
+                                (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kGroupSyms)), a.min_symbol, L.in.shift - 1u,
                                 lds_addr(ring + lane), lds_addr(dump), w_off, lds_addr(tile) + (uint32_t)(lane * kN8RowBytes), lds_addr(tile) + tr_off,
                                 goff);
     a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
@@ -195,12 +212,13 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
 }
 
 // Rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
-bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
     if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (!a.dec_cp || !a.dec_idx) return false;
     if (a.n_streams == 0) return false;                  // (partial waves are taken: their spare lanes repeat the last stream)
-    if (a.n_per_stream % kN8GroupSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
+    if (symbol_bytes != 1 && symbol_bytes != 2) return false;
+    if (a.n_per_stream % (size_t)(kN8GroupSyms / symbol_bytes) != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if (a.offsets && a.words_capacity == 0) return false;                                          // the lanes' 32-bit word offsets need a known span
     const uint64_t span = a.offsets ? a.words_capacity : (uint64_t)a.n_streams * a.stride_words;
@@ -214,19 +232,21 @@ bool n8_decode_small(const AnsDecodeArgs& a, int device_cus) {
     return a.n_symbols <= 256 && a.n_streams > (size_t)device_cus * kBlock;
 }
 
-cst_status ans_decode_small_n8(const AnsDecodeArgs& a, hipStream_t hs) {
+cst_status ans_decode_small_n8(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kN8SmThreads - 1) / kN8SmThreads;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_small_n8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8SmLdsBytes));
-    hipLaunchKernelGGL(ans_decode_small_n8_kernel, dim3((unsigned)blocks), dim3(kN8SmThreads), kN8SmLdsBytes, hs, a);
+    auto kernel = symbol_bytes == 1 ? ans_decode_small_n8_kernel<1> : ans_decode_small_n8_kernel<2>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8SmLdsBytes));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kN8SmThreads), kN8SmLdsBytes, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
 
-cst_status ans_decode_n8(const AnsDecodeArgs& a, hipStream_t hs) {
+cst_status ans_decode_n8(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_decode_n8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8LdsBytes));
-    hipLaunchKernelGGL(ans_decode_n8_kernel, dim3((unsigned)blocks), dim3(kBlock), kN8LdsBytes, hs, a);
+    auto kernel = symbol_bytes == 1 ? ans_decode_n8_kernel<1> : ans_decode_n8_kernel<2>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kN8LdsBytes));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), kN8LdsBytes, hs, a);
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }

@@ -455,9 +455,9 @@ namespace cst {
 // int8 symbol matrices inside the hand-scheduled loops (cst_ans_n8.hip).  Returns false if the shape is not theirs (the caller
 // then converts next to the int32 kernels: cst_symbols.hip); otherwise *rc is the call's status.
 bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
-                           size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, size_t n_streams, size_t n_per_stream,
-                           cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream,
-                           cst_status* rc) {
+                           size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, int32_t symbol_bytes, size_t n_streams,
+                           size_t n_per_stream, cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags,
+                           void* stream, cst_status* rc) {
     if (!model || !d_n_words || !d_status || !d_symbols8 || n_streams == 0 || model->per_stream || model->d_symbol_of_index) return false;
     if (!config_supported(cfg) || cfg.precision != model->precision || !on_model_device(model)) return false;
     if ((flags & ~(uint32_t)(CST_FLAG_RAW_STATE | CST_FLAG_COLD_WORDS)) != 0 || ((flags & CST_FLAG_RAW_STATE) && !d_state)) return false;
@@ -468,9 +468,10 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
-    if (!n8_decode_usable(a, cfg, layout)) return false;
-    if (n8_decode_small(a, model->cu_count)) *rc = note_kernel("ans_decode_small_n8_kernel", ans_decode_small_n8(a, (hipStream_t)stream));
-    else *rc = note_kernel("ans_decode_n8_kernel", ans_decode_n8(a, (hipStream_t)stream));
+    if (!n8_decode_usable(a, cfg, layout, symbol_bytes)) return false;
+    if (n8_decode_small(a, model->cu_count))
+        *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_small_n8_kernel" : "ans_decode_small_n16_kernel", ans_decode_small_n8(a, symbol_bytes, (hipStream_t)stream));
+    else *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_n8_kernel" : "ans_decode_n16_kernel", ans_decode_n8(a, symbol_bytes, (hipStream_t)stream));
     return true;
 }
 

@@ -148,7 +148,7 @@ bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void*
                        uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags,
                        void* stream, cst_status* rc);
 bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
-                       size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, size_t n_streams, size_t n_per_stream,
+                       size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
                        cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream,
                        cst_status* rc);
 

@@ -155,9 +155,9 @@ cst_status cst_ans_decode_batch_sym(const cst_model* model, cst_coder_config cfg
                                     n_streams, n_per_stream, layout, d_state, d_n_words_out, d_status, flags, stream);
     if (!model || (symbol_bytes != 1 && symbol_bytes != 2)) return CST_ERR_INVALID_ARGUMENT;
     if (!support_fits(model, symbol_bytes)) return CST_ERR_INVALID_ARGUMENT;      // a decoded symbol must be storable
-    if (symbol_bytes == 1) {                   // int8 inside the loops where the shape allows it (cst_ans_n8.hip): no scratch, no second kernel
+    {                                          // int8 / int16 inside the loops where the shape allows it (cst_ans_n8.hip): no scratch, no second kernel
         cst_status rc = CST_OK;
-        if (ans_decode_n8_try(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, n_streams, n_per_stream, layout,
+        if (ans_decode_n8_try(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, d_symbols, symbol_bytes, n_streams, n_per_stream, layout,
                               d_state, d_n_words_out, d_status, flags, stream, &rc))
             return rc;
     }

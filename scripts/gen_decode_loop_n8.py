@@ -24,12 +24,17 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
-OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / "cst_decode_loop_n8.inc"
+# GEN_N16=1: the same statement for INT16 matrices (cst_decode_loop_n16.inc).  A 128-byte line is 64 symbols, so a pass is TWO tiles;
+# a quad is two dwords (one v_perm_b32 per pair of symbols, two ds_write_b32), and the previous group leaves four row blocks per tile.
+N16 = bool(os.environ.get("GEN_N16"))
+OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / \
+    ("cst_decode_loop_n16.inc" if N16 else "cst_decode_loop_n8.inc")
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kDecAhead - 1
 ROW_BYTES = 132       # kN8RowBytes
-SUBTILES = 4          # tiles per group of 128 symbols
+SUBTILES = 2 if N16 else 4          # tiles per group: one 128-byte line of every row
+BLOCK_QUADS = {q: i for i, q in enumerate((1, 3, 5, 7) if N16 else (1, 5))}      # the quads in which a row block of the previous group leaves
 NO_STORE = bool(os.environ.get("GEN_NO_STORE"))      # timing experiment only
 
 
@@ -105,9 +110,9 @@ def gen():
             a.i(f"v_and_or_b32 {RA}, {RA}, %[cmask], %[lanebase]")
             a.ds(f"ds_read_b32 {WD}, {RA}", "w")
             a.ds(f"ds_read_b32 {sym_reg}, {LA} offset:16384", f"sym{nxt}")
-            # the previous group leaves: row blocks 2 sub and 2 sub + 1, in quads 1 and 5 of this tile
-            if pos == 1 and quad in (1, 5):
-                k = 2 * sub + (quad == 5)
+            # the previous group leaves: 8 / SUBTILES row blocks per tile, in the quads of BLOCK_QUADS
+            if pos == 1 and quad in BLOCK_QUADS:
+                k = len(BLOCK_QUADS) * sub + BLOCK_QUADS[quad]
                 for c in range(4):
                     a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{8 * ROW_BYTES * k + 4 * c}", "x",
                          f"previous group, rows (lane>>3)+{8 * k}, bytes 16 (lane&7) .. +15" if c == 0 else None)
@@ -115,14 +120,20 @@ def gen():
             a.i(f"v_min_u32 {R1}, 1, %[rd]")
             a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
             a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
-            if pos == 2 and quad in (1, 5):
-                k = 2 * sub + (quad == 5)
+            if pos == 2 and quad in BLOCK_QUADS:
+                k = len(BLOCK_QUADS) * sub + BLOCK_QUADS[quad]
                 # x was issued in the step before and is covered by this step's lgkmcnt(0)
                 if NO_STORE:
                     a.vm.append(f"store{k}")
                 else:
                     a.vmem(f"global_store_dwordx4 %[goff{k}], {X}, s[80:81] nt", f"store{k}")
-            if pos == 3:
+            if pos == 3 and N16:
+                base = 134 + (quad % 2) * 4
+                a.i(f"v_perm_b32 {PK0}, v{base + 1}, v{base}, %[sel01]", f"symbols {4 * quad}..{4 * quad + 3} as int16")
+                a.i(f"v_perm_b32 {PK1}, v{base + 3}, v{base + 2}, %[sel01]")
+                a.ds(f"ds_write_b32 %[rowcur], {PK0} offset:{64 * sub + 8 * quad}", "tile")
+                a.ds(f"ds_write_b32 %[rowcur], {PK1} offset:{64 * sub + 8 * quad + 4}", "tile")
+            elif pos == 3:
                 base = 134 + (quad % 2) * 4
                 a.i(f"v_perm_b32 {PK0}, v{base + 1}, v{base}, %[sel01]", f"symbols {4 * quad}..{4 * quad + 3} as bytes")
                 a.i(f"v_perm_b32 {PK1}, v{base + 3}, v{base + 2}, %[sel23]")
@@ -153,12 +164,12 @@ def gen():
 def main():
     a, clobbers = gen()
     header = ["// GENERATED by scripts/gen_decode_loop_n8.py -- do not edit by hand (edit the generator and re-run it).",
-              "// Main loop of the hand-scheduled (32,64) ANS decoder for int8 symbol matrices: see ans_decode_n8_loop in cst_ans_n8.hip."]
+              f"// Main loop of the hand-scheduled (32,64) ANS decoder for {'int16' if N16 else 'int8'} symbol matrices: see ans_decode_n8_loop in cst_ans_n8.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued), [rowcur] "+v"(row_cur), [rowprev] "+v"(row_prev),',
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [P] "s"(P), [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base),',
            '      [ngroups] "s"(n_groups), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off),',
-           '      [sel01] "s"(0x0c0c0400u), [sel23] "s"(0x04000c0cu),',
+           ('      [sel01] "s"(0x05040100u),' if N16 else '      [sel01] "s"(0x0c0c0400u), [sel23] "s"(0x04000c0cu),'),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
     OUT.write_text(a.render(header, ops))

@@ -31,9 +31,13 @@ from asmgen import Asm  # noqa: E402
 # register ZERO the other half on this chip (scripts/microbench/ds_d16.hip: SRAM-ECC), and the kernel ran in the same 0.350 ms with
 # the shorter step as with this one: the third LDS read per symbol costs what the two VALU instructions saved.)
 N8 = bool(os.environ.get("GEN_SMALL_N8"))
+# GEN_SMALL_N8=16: INT16 matrices (cst_decode_loop_small_n16.inc) -- a line is 64 symbols: two tiles per pass, a symbol is a HALF of
+# one of the quad's two registers (dst_sel:WORD_n), a quad is two ds_write_b32.
+N16 = os.environ.get("GEN_SMALL_N8") == "16"
 N8_ROW = 132
-SUBTILES = 4 if N8 else 1
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / ("cst_decode_loop_small_n8.inc" if N8 else "cst_decode_loop_small.inc")
+SUBTILES = 2 if N16 else 4 if N8 else 1
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / \
+    ("cst_decode_loop_small_n16.inc" if N16 else "cst_decode_loop_small_n8.inc" if N8 else "cst_decode_loop_small.inc")
 
 K_CHUNKS = 3          # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kPtAhead - 1
@@ -88,7 +92,10 @@ def step(a, j, sub=0):
     a.i(f"v_mad_u64_u32 v[100:101], {SD}, {T0}, {PR}, v[102:103]", "N = (state >> P) * p + (q - c)")
     a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
     a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
-    if N8:
+    if N16:
+        a.i(f"v_add_u32_sdwa {SYM[2 * (quad % 2) + (pos >> 1)]}, %[minsym], {CP} dst_sel:WORD_{pos & 1} dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3",
+            "decoded symbol -> half of one of the quad's two registers (also: one instruction between vcc's writer and reader)")
+    elif N8:
         a.i(f"v_add_u32_sdwa {SYM[quad % 2]}, %[minsym], {CP} dst_sel:BYTE_{pos} dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3",
             "decoded symbol -> byte of the quad's register (also: one instruction between vcc's writer and reader)")
     else:
@@ -99,7 +106,10 @@ def step(a, j, sub=0):
     a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
     a.ds(f"ds_read_b32 {CP}, {LA}", "cp", "next entry  <- end of the serial chain")
     tail(a, sym_reg, last=(j == 31))
-    if pos == 3 and N8:
+    if pos == 3 and N16:
+        a.ds(f"ds_write_b32 %[rowcur], {SYM[2 * (quad % 2)]} offset:{64 * sub + 8 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3} of tile {sub}")
+        a.ds(f"ds_write_b32 %[rowcur], {SYM[2 * (quad % 2) + 1]} offset:{64 * sub + 8 * quad + 4}", "tile")
+    elif pos == 3 and N8:
         a.ds(f"ds_write_b32 %[rowcur], {SYM[quad % 2]} offset:{32 * sub + 4 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3} of tile {sub}")
     elif pos == 3:
         base = (quad % 2) * 4
@@ -184,7 +194,8 @@ def main():
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_decode_loop_small.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (32,64) ANS decoder, small LDS footprint" +
-              (", int8 symbol matrices: see decode_groups_loop_small_n8 in cst_ans_n8.hip." if N8 else ": see decode_tiles_loop_small in cst_ans_small.hip.")]
+              (", int16 symbol matrices: see decode_groups_loop_small_n8 in cst_ans_n8.hip." if N16 else
+               ", int8 symbol matrices: see decode_groups_loop_small_n8 in cst_ans_n8.hip." if N8 else ": see decode_tiles_loop_small in cst_ans_small.hip.")]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued)',
            '    : [lut] "s"(lut_addr), [mask] "s"(mask), [cmask] "s"(ring_mask), [P] "s"(P), [wbase] "s"(words_base), [gbase] "s"(store_base),',
            '      [ntiles] "s"(n_tiles), [minsym] "v"(min_symbol), [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr),',

@@ -314,3 +314,27 @@ def test_per_symbol_gaussian_decoders_at_the_maximum_rate_on_packed_words(B, O, 
     buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
     dec, st = dec_f((buf, nw), lo, hi, dev(mu), dev(sd), offsets=offsets, config=(32, 64, 24))
     assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), B.last_kernel()
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.2])
+@pytest.mark.parametrize("n_streams", [256, "small"])
+def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
+    """the decoders that write int16 matrices themselves (two tiles per pass), one and two waves per SIMD, slabs and packed words"""
+    P, n = 12, 101
+    if n_streams == "small":
+        n_streams, n_per = torch.cuda.get_device_properties(0).multi_processor_count * 256 + 320, 256
+    else:
+        n_per = 2048
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 1000, P)                 # symbols 1000 .. 1100: int16, not int8
+    rng = np.random.default_rng(int(frac * 1000) + 17)
+    sym = high_rate_symbols(rng, n_streams, n_per, n, frac) + 1000
+    d = dev(sym.astype(np.int16))
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    dec, st = B.ans_decode(enc, model, n_per, dtype=torch.int16)
+    assert ALT or B.last_kernel() == ("ans_decode_small_n16_kernel" if n_streams > 65536 else "ans_decode_n16_kernel")
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    words, n_words, _ = enc.to_numpy()
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng, max_gap=5)
+    dec, st = B.ans_decode((buf, nw), model, n_per, offsets=offsets, config=(32, 64, P), dtype=torch.int16)
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)

@@ -322,3 +322,35 @@ def test_int8_native_decoder_takes_partial_waves(B, O, n_streams, n_per):
     out.fill_(55)
     dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
     assert (st.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym.astype(np.int8))
+
+
+# ---- int16 matrices inside the decoder loops (a 128-byte line is 64 symbols: two tiles per pass) ----
+
+@pytest.mark.parametrize("P", [10, 12])
+@pytest.mark.parametrize("support", [(-300, 300), (-100, 100), (1000, 1200), (-32768, -32700), (32000, 32767)], ids=lambda s: "%d..%d" % s)
+@pytest.mark.parametrize("n_streams,n_per", [(1, 64), (70, 128), (256, 192), (300, 4096), (768, 1152)])
+def test_int16_native_decoders_decode_like_the_oracle(B, O, P, support, n_streams, n_per):
+    lo, hi = support
+    if hi - lo + 1 > (1 << P) // 2:
+        pytest.skip("alphabet too large for the precision")
+    cdf = O.GaussianModel(lo, hi, 0.4 * lo + 0.6 * hi, 30.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(2000 + P, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    d = torch.from_numpy(sym).to(torch.int16).cuda()
+    enc = B.ans_encode(d, model, (32, 64, P))
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(0, n_streams, max(1, n_streams // 40)):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    guard = torch.full((n_streams * n_per + 4096,), 77, dtype=torch.int16, device="cuda")
+    out = guard[: n_streams * n_per].view(n_streams, n_per)
+    dec, st = B.ans_decode(enc, model, n_per, out=out)
+    assert ALT or B.last_kernel() == "ans_decode_n16_kernel"
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+    assert (guard[n_streams * n_per:].cpu().numpy() == 77).all(), "symbols were written behind the matrix"
+    packed, offsets = B.compact(enc)
+    out.fill_(55)
+    dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
