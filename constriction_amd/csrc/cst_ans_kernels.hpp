@@ -1369,6 +1369,9 @@ bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout l
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs);
 // int8 symbol matrices inside the loops (cst_ans_n8.hip)
 bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);
+bool pc_n16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);
+bool pc_n16_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval);
+cst_status ans_encode_pc_n16(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs);   // interval 0: no jump points
 bool pc_n8_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval);
 cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs);
 bool pc_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval);

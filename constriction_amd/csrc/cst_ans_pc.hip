@@ -327,6 +327,124 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
     pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// INT16 symbol matrices (scripts/gen_encode_loop_pc.py, "INT16 symbol matrices"): the int8 workgroup with lines of 64 symbols (two tiles).
+// The table is the int32 kernel's (at most 1024 entries, at LDS address 0 .. 16 KiB); the coder forms  table + 16 (symbol - min)
+// with one v_mad_i32_i16 per symbol (op_sel picks the half of the dword) and folds those addresses for the range check.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ans_encode_pc_n16_coder_loop(uint32_t& lo, uint32_t& hi, uint32_t& smin, uint32_t& smax, uint32_t line_row_addr,
+                                                             uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_n16.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_n16_coder_loop_ck(uint32_t& lo, uint32_t& hi, uint32_t& smin, uint32_t& smax, uint32_t line_row_addr,
+                                                                uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P,
+                                                                uint32_t n_tiles, const uint32_t* ckpt_pos, const uint64_t* ckpt_state, uint32_t ckpt_tiles,
+                                                                uint32_t ckpt_pos_off, uint32_t ckpt_state_off) {
+#include "cst_encode_loop_pc_n16_ck.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_n16_loader_loop(const uint32_t (&line_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
+                                                              uint32_t n_tiles, const uint32_t (&goff0)[8], const uint32_t (&goff1)[8]) {
+#include "cst_encode_loop_pc_loader_n16.inc"
+}
+
+template <bool JUMP>
+__global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const AnsEncodeArgs a, const PcJumpArgs jp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int cw = wave & (kPcWaves - 1);
+    const int P = a.precision;
+    const size_t N = a.n_per_stream;
+    const uint32_t n_t = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms));
+    const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
+    const int8_t* symbols = reinterpret_cast<const int8_t*>(a.symbols);      // (BYTE addresses of the int16 matrix below)
+    const size_t row_bytes = N * 2;
+
+    EncEntry* table = reinterpret_cast<EncEntry*>(smem);
+    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = pack_entry(a.enc[i], P);
+
+    if (wave < kPcWaves) {                               // ---- coder ----
+        uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
+        uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcN8HandOff + cw * kPcHandWaveBytes);
+        const size_t s = min((size_t)blockIdx.x * kBlock + (size_t)cw * kWave + lane, a.n_streams - 1);      // (partial workgroups: as for int8)
+        uint32_t lo = 0, hi = 0;
+        const uint32_t table_addr = lds_addr(table);
+        uint32_t smin = table_addr, smax = table_addr;    // (the statement folds the table ADDRESSES it reads: unsigned min / max)
+        if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
+        const uint32_t row_addr = lds_addr(smem + kPcN8TileOff + (2 * cw) * kPcN8LineBytes) + (uint32_t)(lane * kPcN8RowBytes);
+        const uint32_t bias = table_addr - 16u * (uint32_t)a.min_symbol;
+        pc_barrier();                                   // table and the first line are in LDS
+        if constexpr (JUMP)
+            ans_encode_pc_n16_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t, jp.pos,
+                                            jp.state, jp.tiles, (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4),
+                                            (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8));
+        else
+            ans_encode_pc_n16_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t);
+        hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
+        // largest raw table index seen: an address below the table wraps to a huge one
+        hand[3 * kWave + lane] = max((smax - table_addr) >> 4, (smin - table_addr) >> 4);
+        pc_barrier();                                   // the last window and the final state are published
+        return;
+    }
+    const int pair = wave & 1, cw0 = 2 * pair;
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
+    if (wave < kPcWaves + 2) {                          // ---- loader ----
+        const size_t last = a.n_streams - 1;
+        const size_t first0 = min(s0, last), first1 = min(s0 + kWave, last);
+        uint32_t goff0[8], goff1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t row = (size_t)(lane >> 3) + 8 * k;
+            goff0[k] = (uint32_t)(min(row, last - first0) * row_bytes + 16 * (size_t)(lane & 7));
+            goff1[k] = (uint32_t)(min(row, last - first1) * row_bytes + 16 * (size_t)(lane & 7));
+        }
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + first0 * row_bytes + (row_bytes - 128));
+        const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const uint32_t t0 = lds_addr(smem + kPcN8TileOff + (2 * cw0) * kPcN8LineBytes) + (uint32_t)((lane >> 3) * kPcN8RowBytes + 16 * (lane & 7));
+        const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcN8LineBytes};
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((first1 - first0) * row_bytes));
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
+        ans_encode_pc_n16_loader_loop(tr_addr, symbols_base, row_block, n_t, goff0, goff1);
+        pc_barrier();
+        return;
+    }
+    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
+}
+
+// Rows that are whole 128-byte aligned lines of 64 int16 symbols, a table of at most 1024 entries, slabs as for the int32 kernel.
+bool pc_n16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
+    if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
+    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (a.n_streams == 0) return false;
+    if (a.n_per_stream % 64 != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 23)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
+    if ((a.n_streams + kBlock - 1) / kBlock * kBlock * a.stride_words * 4 >= 0x100000000ull) return false;                  // 32-bit slab offsets
+    if (a.n_symbols < 1 || (size_t)a.n_symbols * sizeof(EncEntry) > kPcTableBytes) return false;
+    return a.min_symbol >= -32768 && a.min_symbol + a.n_symbols - 1 <= 32767;
+}
+
+cst_status ans_encode_pc_n16(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (interval) {
+        auto kernel = ans_encode_pc_n16_kernel<true>;
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a,
+                           PcJumpArgs{d_ckpt_pos, d_ckpt_state, (uint32_t)(interval / kTileSyms), (uint32_t)(a.n_per_stream / interval)});
+    } else {
+        auto kernel = ans_encode_pc_n16_kernel<false>;
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});
+    }
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+bool pc_n16_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval);
+
 // Rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel; any number of streams.
 bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
@@ -344,6 +462,10 @@ bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layou
 static bool pc_jump_ok(const AnsEncodeArgs& a, size_t interval) {
     if (interval == 0 || interval % kTileSyms != 0 || a.n_per_stream % interval != 0) return false;
     return a.n_streams * (a.n_per_stream / interval) * 8 < 0x100000000ull;
+}
+
+bool pc_n16_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, size_t interval) {
+    return pc_n16_encode_usable(a, cfg, layout) && pc_jump_ok(a, interval);
 }
 
 static PcJumpArgs pc_jump_args(const AnsEncodeArgs& a, size_t interval, uint32_t* pos, uint64_t* state) {

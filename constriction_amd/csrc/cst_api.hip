@@ -475,9 +475,9 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
     return true;
 }
 
-bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void* d_symbols8, size_t n_streams, size_t n_per_stream, cst_layout layout,
-                       uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags,
-                       void* stream, cst_status* rc) {
+bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void* d_symbols8, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
+                       cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status,
+                       uint32_t flags, void* stream, cst_status* rc) {
     if (!model || !d_words || !d_n_words || !d_status || !d_symbols8 || n_streams == 0 || model->per_stream || model->d_symbol_of_index) return false;
     if (!config_supported(cfg) || cfg.precision != model->precision || !on_model_device(model)) return false;
     if ((flags & ~(uint32_t)CST_FLAG_RAW_STATE) != 0 || ((flags & CST_FLAG_RAW_STATE) && !d_state)) return false;
@@ -486,7 +486,12 @@ bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void*
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.state = d_state; a.status = d_status;
     a.flags = flags;
-    if (!pc_n8_encode_usable(a, cfg, layout)) return false;
+    if (symbol_bytes == 2) {
+        if (!pc_n16_encode_usable(a, cfg, layout)) return false;
+        *rc = note_kernel("ans_encode_pc_n16_kernel", ans_encode_pc_n16(a, 0, nullptr, nullptr, (hipStream_t)stream));
+        return true;
+    }
+    if (symbol_bytes != 1 || !pc_n8_encode_usable(a, cfg, layout)) return false;
     *rc = note_kernel("ans_encode_pc_n8_kernel", ans_encode_pc_n8(a, (hipStream_t)stream));
     return true;
 }

@@ -144,9 +144,9 @@ void set_hip_error(hipError_t e, const char* what);
 // thread-local record of which kernel family the last coder call of this thread launched (cst_last_kernel_name); returns rc
 cst_status note_kernel(const char* name, cst_status rc);
 // int8 matrices inside the loops (cst_api.hip / cst_ans_n8.hip): false = not their shape, the caller converts instead
-bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void* d_symbols8, size_t n_streams, size_t n_per_stream, cst_layout layout,
-                       uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status, uint32_t flags,
-                       void* stream, cst_status* rc);
+bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void* d_symbols8, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
+                       cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state, int32_t* d_status,
+                       uint32_t flags, void* stream, cst_status* rc);
 bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
                        size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
                        cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream,

@@ -134,9 +134,10 @@ cst_status cst_ans_encode_batch_sym(const cst_model* model, cst_coder_config cfg
         return cst_ans_encode_batch(model, cfg, reinterpret_cast<const int32_t*>(d_symbols), n_streams, n_per_stream, layout, d_words, stride_words,
                                     d_n_words, d_state, d_status, flags, stream);
     if (!model || (symbol_bytes != 1 && symbol_bytes != 2)) return CST_ERR_INVALID_ARGUMENT;
-    if (symbol_bytes == 1) {                   // int8 inside the hand-scheduled loops where the shape allows it (cst_ans_pc.hip): no scratch, no second kernel
+    {                                          // int8 / int16 inside the hand-scheduled loops where the shape allows it (cst_ans_pc.hip): no scratch, no second kernel
         cst_status rc8 = CST_OK;
-        if (ans_encode_n8_try(model, cfg, d_symbols, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status, flags, stream, &rc8))
+        if (ans_encode_n8_try(model, cfg, d_symbols, symbol_bytes, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status, flags,
+                              stream, &rc8))
             return rc8;
     }
     if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;

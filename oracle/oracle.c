@@ -924,6 +924,7 @@ API void cst_oracle_ans_jump_table(int W, int S, int P, const int32_t *symbols, 
         uint64_t st = 0;
         for (size_t t = n_per_stream; t-- > 0;) {           /* encode_symbol, stack.rs:1014-1048 (symbols last to first) */
             const int64_t i = (int64_t)x[t] - lo;
+            if (i < 0 || i >= n_sym) break;                  /* an impossible symbol: the stream's remaining jump points stay as they are */
             const uint32_t c = row[i], p = row[i + 1] - c;
             if ((st >> (S - P)) >= p) { len++; st >>= W; }
             st = ((st / p) << P) | (c + st % p);

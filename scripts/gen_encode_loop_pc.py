@@ -891,11 +891,182 @@ def emit_n8_loader():
         print("  note:", n)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# INT16 symbol matrices (cst_encode_loop_pc_n16{,_ck}.inc / cst_encode_loop_pc_loader_n16.inc, ans_encode_pc_n16_kernel).  A 128-byte
+# line is 64 symbols: TWO tiles.  The coder reads a quad as two dwords (one ds_read2_b32) and forms a table address per symbol with
+#     v_mad_i32_i16 ea, quad_half, 16, table - 16 min_symbol  op_sel:[k,0,0,0]        (k: the high or the low half of the dword)
+# -- one instruction again, against the int32 form's table of at most 1024 entries at its ordinary place; the range check folds the
+# ADDRESSES with unsigned min3 / max3 (an address below the table wraps to a huge one).  The tile pointers leapfrog as for int8; with
+# two tiles per line EVERY second step jumps to the other line buffer (J, then 128 - J).  The loader stages a line in two windows.
+# ---------------------------------------------------------------------------------------------------------------------
+OUT_N16 = CSRC / "cst_encode_loop_pc_n16.inc"
+OUT_N16_CK = CSRC / "cst_encode_loop_pc_n16_ck.inc"
+OUT_LOADER_N16 = CSRC / "cst_encode_loop_pc_loader_n16.inc"
+S16 = [(f"v{100 + 2 * i}", f"v{101 + 2 * i}", tup(100 + 2 * i, 2)) for i in range(4)]        # a quad: two dwords
+N16_CLOBBERS = [f"v{r}" for r in range(100, 170)] + ["s82", "s83", "s84", "s85", "s87", "s88", "vcc", "scc", "memory"]
+EA16 = [[f"v{108 + 4 * e + i}" for i in range(4)] for e in range(2)]                          # v108 .. v115 (PA, PB move to v170 / v171 ... see below)
+PA16, PB16 = "v172", "v173"
+
+
+def n16_read_syms(a, g, ptr, quad):
+    a.ds(f"ds_read2_b32 {S16[g % 4][2]}, {ptr} offset0:{2 * quad} offset1:{2 * quad + 1}", f"S{g}")
+
+
+def n16_fetch_entries(a, g):
+    lo_reg, hi_reg, _ = S16[g % 4]
+    for i, (reg, half) in enumerate(((hi_reg, 1), (hi_reg, 0), (lo_reg, 1), (lo_reg, 0))):      # consumption order: the quad's last symbol first
+        a.i(f"v_mad_i32_i16 {EA16[g % 2][i]}, {reg}, 16, %[tbl] op_sel:[{half},0,0,0]", "table + 16 (symbol - min_symbol)")
+        a.ds(f"ds_read_b128 {E_T[g % 2][i]}, {EA16[g % 2][i]}", f"E{g}")
+
+
+def n16_fold_minmax(a, g):
+    x, y, z, w = EA16[g % 2]
+    a.i(f"v_max3_u32 %[smax], %[smax], {x}, {y}", "the range check, on the table addresses of the quad being coded")
+    a.i(f"v_max3_u32 %[smax], %[smax], {z}, {w}")
+    a.i(f"v_min3_u32 %[smin], %[smin], {x}, {y}")
+    a.i(f"v_min3_u32 %[smin], %[smin], {z}, {w}")
+
+
+def n16_half(a, cur, nxt, g0, delta, site=0):
+    a.i(f"; ---- tile at {cur}")
+    for j in range(8):
+        g, quad = g0 + j, 7 - j
+        if quad == 1:
+            hand_off(a)
+        if f"S{g + 1}" in a.lds:
+            a.wait_lds(f"S{g + 1}", f"quad {quad}: symbols of the next quad are back", cap=True)
+        far = quad - 2
+        n16_read_syms(a, g + 2, cur if far >= 0 else nxt, far if far >= 0 else far + 8)
+        n16_fetch_entries(a, g + 1)
+        if f"E{g}" in a.lds:
+            a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
+        n16_fold_minmax(a, g)
+        for c, p, m0, m1 in E[g % 2]:
+            step(a, c, p, m0, m1)
+    a.i(f"v_add_u32 {cur}, {delta}, {nxt}", "leapfrog: the tile after the next")
+    ck_hook(a, site)
+
+
+def gen_n16():
+    a = Asm()
+    a.i(f"v_mov_b32 {W1}, 0")
+    a.i(f"v_mov_b32 {LO}, %[lo]")
+    a.i(f"v_mov_b32 {HI}, %[hi]")
+    if PRIO:
+        a.i(f"s_setprio {PRIO}", "the coder chain's wave goes first on its SIMD; the helpers fill the gaps")
+    a.i(f"v_mov_b32 {WR}, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
+    a.i(f"v_add_u32 {PA16}, 64, %[row0]", "tile 0: the last 32 symbols (64 bytes) of the line in buffer 0")
+    a.i(f"v_mov_b32 {PB16}, %[row0]")
+    a.i(f"s_mov_b32 s87, {N8_LINEBUF + 64}", "J: from the first tile of a line in buffer 0 to the last tile of the line in buffer 1 (128 - J: back)")
+    ck_prologue(a)
+    n16_read_syms(a, 0, PA16, 7)
+    n16_read_syms(a, 1, PA16, 6)
+    a.wait_lds("S0")
+    n16_fetch_entries(a, 0)
+    a.i("1:")
+    first = len(a.events)
+    # tile A (even index i) is the last tile of its line, tile B the first: P(i + 2) = P(i + 1) + jump, P(i + 3) = P(i + 2) - 64
+    n16_half(a, PA16, PB16, 0, "s87", site=0)
+    a.i("s_sub_u32 s87, 128, s87", "the next jump goes the other way")
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_eq_u32 s82, 0")
+    a.i("s_cbranch_scc1 2f")
+    n16_half(a, PB16, PA16, 8, "-64", site=1)
+    a.i("s_sub_u32 s82, s82, 1")
+    a.i("s_cmp_lg_u32 s82, 0")
+    a.i("s_cbranch_scc1 1b")
+    ren = {"S16": "S0", "S17": "S1", "E16": "E0"}
+    lds_back = [ren.get(t, t) for t in a.lds]
+    lds_end, vm_end, notes = a.verify_loop(first, lds_back, a.vm, passes=1)
+    lds_end = [ren.get(t, t) for t in lds_end]
+    assert lds_end == lds_back and vm_end == a.vm, (lds_end, lds_back)
+    a.i("2:")
+    a.ds(f"ds_write_b32 %[pub], {WR}", "cnt", "all words of the main loop")
+    a.i(f"v_mov_b32 %[lo], {LO}")
+    a.i(f"v_mov_b32 %[hi], {HI}")
+    a.wait_lds_all()
+    ck_blocks(a, (0, 1))
+    return a, notes
+
+
+def gen_loader_n16():
+    assert LSETS == 2
+    a = Asm()
+    a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST line of the pair's first stream: line 0")
+    a.i("s_add_u32 s84, s80, %[rowblock]", "... and of the second coder wave's first stream")
+    a.i("s_addc_u32 s85, s81, 0")
+    a.i("s_mov_b32 s82, %[ntiles]", "windows left")
+    a.i("s_lshr_b32 s83, %[ntiles], 1")
+    a.i("s_sub_u32 s83, s83, 1", "lines left to request")
+    l8_load(a, 0)
+    l8_load(a, 1)
+    for c in range(2):
+        a.wait_vm(f"ld{c}0", f"coder {c}: line 0 has arrived")
+    l8_stage(a, 0, 0, range(8))
+    l8_load(a, 0)
+    a.wait_lds_all("line 0 is staged (and the table, by everybody)")
+    a.i("s_barrier")
+    a.i("1:")
+    first = len(a.events)
+    for w in range(4):
+        line, v = w // 2 + 1, w % 2
+        i = buf = line & 1
+        a.i(f"; ---- window {w}: set {i}, row blocks {4 * v} .. {4 * v + 3} -> line buffers {buf}")
+        if v == 0:
+            for c in range(2):
+                a.wait_vm(f"ld{c}{i}", f"coder {c}: the line in set {i} has arrived")
+        l8_stage(a, i, buf, range(4 * v, 4 * v + 4))
+        if v == 1:
+            l8_load(a, i)
+        a.wait_lds_all("the row blocks are staged")
+        a.i("s_barrier")
+        a.i("s_sub_u32 s82, s82, 1")
+        if w < 3:
+            a.i("s_cmp_eq_u32 s82, 0")
+            a.i("s_cbranch_scc1 2f")
+        else:
+            a.i("s_cmp_lg_u32 s82, 0")
+            a.i("s_cbranch_scc1 1b")
+    lds_end, vm_end, notes = a.verify_loop(first, a.lds, a.vm, passes=1)
+    assert lds_end == a.lds and vm_end == a.vm, (vm_end, a.vm)
+    a.i("2:")
+    a.wait_vm_all("nothing may land in the scratch registers after the statement")
+    a.wait_lds_all()
+    return a, notes
+
+
+def main_n16():
+    global JUMP
+    for JUMP, out in ((False, OUT_N16), (True, OUT_N16_CK)):
+        a, notes = gen_n16()
+        header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+                  "// Coder half of the producer / consumer (32,64) ANS encoder for int16 symbol matrices: see ans_encode_pc_n16_coder_loop in cst_ans_pc.hip."]
+        ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
+               '    : [row0] "v"(line_row_addr), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
+               '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+               "    : " + ", ".join(f'"{c}"' for c in N16_CLOBBERS + [PA16, PB16] + ck_clobbers()) + ");"]
+        out.write_text(a.render(header, ops))
+        print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
+    JUMP = False
+    a, notes = gen_loader_n16()
+    header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
+              "// Loader wave of the producer / consumer (32,64) ANS encoder for int16 symbol matrices: see ans_encode_pc_n16_loader_loop in cst_ans_pc.hip."]
+    ops = ['    :',
+           '    : [tr0] "v"(line_tr_addr[0]), [tr1] "v"(line_tr_addr[1]), [sbase] "s"(symbols_base), [rowblock] "s"(row_block_bytes), [ntiles] "s"(n_tiles),',
+           '      ' + ", ".join(f'[goff0_{k}] "v"(goff0[{k}])' for k in range(8)) + ",",
+           '      ' + ", ".join(f'[goff1_{k}] "v"(goff1[{k}])' for k in range(8)),
+           "    : " + ", ".join(f'"{c}"' for c in L_CLOBBERS) + ");"]
+    OUT_LOADER_N16.write_text(a.render(header, ops))
+    print(f"wrote {OUT_LOADER_N16} ({a.n_instr()} instructions incl. prologue)")
+
+
 def main_all():
     main()
     main_helper()
     main_split()
     main_n8()
+    main_n16()
 
 
 if __name__ == "__main__":

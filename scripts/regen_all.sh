@@ -10,5 +10,7 @@ GEN_RANGE_CK=1 python scripts/gen_range_encode_loop.py > /dev/null
 GEN_RANGE_SUB=1 python scripts/gen_range_decode_loop.py > /dev/null
 GEN_W16_PACKED=1 python scripts/gen_encode_loop_w16.py > /dev/null
 GEN_SMALL_N8=1 python scripts/gen_decode_loop_small.py > /dev/null
+GEN_SMALL_N8=16 python scripts/gen_decode_loop_small.py > /dev/null
+GEN_N16=1 python scripts/gen_decode_loop_n8.py > /dev/null
 GEN_W16_PACKED=1 python scripts/gen_decode_loop_w16.py > /dev/null
 git status --short constriction_amd/csrc | grep '\.inc' | wc -l

@@ -57,6 +57,9 @@ def test_small_footprint_loops_are_in_sync(tmp_path, monkeypatch):
     monkeypatch.setenv("GEN_SMALL_N8", "1")                   # round 5: the same loop over byte tiles (int8 matrices)
     text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small_n8.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small_n8.inc").read_text()
+    monkeypatch.setenv("GEN_SMALL_N8", "16")                  # ... and int16
+    text = _regenerate(_load("gen_decode_loop_small"), tmp_path, "cst_decode_loop_small_n16.inc")
+    assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_small_n16.inc").read_text()
 
 
 def test_pt_loops_are_in_sync(tmp_path, monkeypatch):
@@ -141,8 +144,9 @@ def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
     mod.OUT_LOADER, mod.OUT_STORER = tmp_path / "loader.inc", tmp_path / "storer.inc"
     mod.OUT_N8, mod.OUT_LOADER_N8 = tmp_path / "n8.inc", tmp_path / "loader_n8.inc"      # round 5: the int8 forms of coder and loader
     mod.OUT_CK, mod.OUT_N8_CK = tmp_path / "ck.inc", tmp_path / "n8_ck.inc"              # ... and the coders that note jump points
+    mod.OUT_N16, mod.OUT_N16_CK, mod.OUT_LOADER_N16 = tmp_path / "n16.inc", tmp_path / "n16_ck.inc", tmp_path / "loader_n16.inc"      # int16
     mod.main_all()
-    for name in ("loader", "storer", "n8", "loader_n8", "ck", "n8_ck"):
+    for name in ("loader", "storer", "n8", "loader_n8", "ck", "n8_ck", "n16", "n16_ck", "loader_n16"):
         assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()
@@ -165,6 +169,11 @@ def test_int8_decoder_loop_is_in_sync(tmp_path, monkeypatch):
     mod.OUT = tmp_path / "n8.inc"
     mod.main()
     assert (tmp_path / "n8.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_n8.inc").read_text()
+    monkeypatch.setenv("GEN_N16", "1")                        # ... and int16 matrices (two tiles per pass)
+    mod = _load("gen_decode_loop_n8")
+    mod.OUT = tmp_path / "n16.inc"
+    mod.main()
+    assert (tmp_path / "n16.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_n16.inc").read_text()
 
 
 def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):

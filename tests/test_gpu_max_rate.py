@@ -330,7 +330,12 @@ def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
     rng = np.random.default_rng(int(frac * 1000) + 17)
     sym = high_rate_symbols(rng, n_streams, n_per, n, frac) + 1000
     d = dev(sym.astype(np.int16))
-    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    enc = B.ans_encode(d, model, (32, 64, P))
+    assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel"
+    plain = B.ans_encode(dev(sym), model, (32, 64, P))
+    assert torch.equal(enc.n_words, plain.n_words) and int(enc.status.abs().sum()) == 0
+    used = torch.arange(plain.words.shape[1], device="cuda")[None, :] < plain.n_words[:, None]
+    assert bool(((enc.words == plain.words) | ~used).all()), "the int16 encoder's words differ from the int32 encoder's"
     dec, st = B.ans_decode(enc, model, n_per, dtype=torch.int16)
     assert ALT or B.last_kernel() == ("ans_decode_small_n16_kernel" if n_streams > 65536 else "ans_decode_n16_kernel")
     assert int(st.abs().sum()) == 0 and torch.equal(dec, d)

@@ -354,3 +354,50 @@ def test_int16_native_decoders_decode_like_the_oracle(B, O, P, support, n_stream
     out.fill_(55)
     dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("P", [10, 12])
+@pytest.mark.parametrize("support", [(-300, 300), (-100, 100), (1000, 1200), (-32768, -32700), (32000, 32767), (-2000, -1000)], ids=lambda s: "%d..%d" % s)
+@pytest.mark.parametrize("n_streams,n_per,jump", [(1, 64, 0), (70, 128, 2), (256, 192, 3), (300, 4096, 4), (768, 1152, 0), (512, 64, 1)])
+def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams, n_per, jump):
+    """ans_encode_pc_n16_kernel (lines of 64 symbols, table addresses by v_mad_i32_i16): every stream's words, counts and status against
+    the CPU oracle on the widened values; impossible symbols below and above the support; partial workgroups; jump points"""
+    lo, hi = support
+    if hi - lo + 1 > (1 << P) // 2:
+        pytest.skip("alphabet too large for the precision")
+    cdf = O.GaussianModel(lo, hi, 0.4 * lo + 0.6 * hi, 30.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(3000 + P, 0, n_streams, n_per, lo, cdf, P)
+    bad = []
+    if n_streams >= 70:
+        for r, v in ((3, lo - 1), (n_streams - 2, hi + 1), (n_streams // 2, -32768), (n_streams // 3, 32767)):
+            if -32768 <= v <= 32767 and not lo <= v <= hi:
+                sym[r, (7 * r) % n_per] = v
+                bad.append(r)
+    want_words, want_n, want_st = O.ans_encode_batch(sym, lo, cdf, P)
+    assert all(want_st[r] == 1 for r in bad)
+    d = torch.from_numpy(sym).to(torch.int16).cuda()
+    assert d.data_ptr() % 128 == 0
+    if jump:
+        enc, ck = B.ans_encode_checkpointed(d, model, n_per // jump, (32, 64, P))
+        assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel<ckpt>"
+    else:
+        enc = B.ans_encode(d, model, (32, 64, P))
+        assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel"
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert status.tolist() == want_st.tolist()
+    for s in range(n_streams):
+        if want_st[s] == 0:
+            assert n_words[s] == want_n[s] and np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    ok = want_st == 0
+    if jump:
+        wp, ws = O.ans_jump_table(sym, lo, cdf, P, n_per // jump)
+        assert np.array_equal(ck.pos.cpu().numpy().view(np.uint32)[ok], wp[ok]) and np.array_equal(ck.state.cpu().numpy().view(np.uint64)[ok], ws[ok])
+    if ok.all():
+        dec, st = B.ans_decode(enc, model, n_per, dtype=torch.int16)
+        assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+        if jump and (n_per // jump) % 64 == 0:
+            dec, st = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=torch.int16)
+            assert ALT or B.last_kernel() in ("ans_decode_n16_kernel", "ans_decode_small_n16_kernel")
+            assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
