@@ -366,8 +366,8 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
 
 def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
     """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8).
-    int8 (round 5): the hand-scheduled loops read / write the int8 matrix themselves (ans_encode_pc_n8_kernel / ans_decode_n8_kernel:
-    cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 B per symbol + 4 B per word each way, and that is the traffic; the
+    int8 / int16 (round 5): the hand-scheduled loops read / write the narrow matrix themselves (ans_encode_pc_n8_kernel / ans_decode_n8_kernel
+    and their n16 forms: cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 or 2 B per symbol + 4 B per word each way, and that is the traffic; the
     kernels are bound by instruction issue, not by HBM (one wave per SIMD: DESIGN.md 4.13), so their HBM fractions are low by
     construction.  `conversion_path`: the same call with CST_NO_N8=1 -- widened / narrowed by a streaming kernel next to the int32
     coder kernels (what int16 matrices and the shapes the native kernels do not take still use)."""
@@ -385,7 +385,7 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
     dec_ms = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
     total_words = enc.total_words()
     byts = nb * n_streams * n_per + 4 * total_words
-    native = enc_kernel.endswith("n8_kernel")
+    native = enc_kernel.endswith("n8_kernel") or enc_kernel.endswith("n16_kernel")
     entry = {"workload": f"C2 with {str(dtype).replace('torch.', '')} symbol matrices " +
                          ("(read / written by the coder loops themselves)" if native else "(widened / narrowed on the device next to the coder call)"),
              "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
@@ -705,10 +705,12 @@ def other_configs(B, rank, world, dist, args, reps=5):
         add("C2 with 16-bit words (SmallAnsCoder preset)", "ans", (16, 32, 12), m12, sym12, reps, check, cdf12)
         add("C2 with 16-bit words, PACKED two per slot as the reference's Vec<u16> (CST_FLAG_PACKED_W16)", "ans", (16, 32, 12), m12, sym12, reps, check,
             cdf12, packed16=True)
-        try:
-            out.append(narrow_config(B, m12, sym12, reps, check))
-        except Exception as exc:      # noqa: BLE001
-            out.append({"workload": "C2 with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
+        for narrow_dtype in (torch.int8, torch.int16):
+            try:
+                out.append(narrow_config(B, m12, sym12, reps, check, dtype=narrow_dtype))
+            except Exception as exc:      # noqa: BLE001
+                out.append({"workload": f"C2 with {str(narrow_dtype).replace('torch.', '')} symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200],
+                            "bit_exact": False})
         m24, cdf24 = gaussian(24)
         sym24 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, torch.from_numpy(cdf24.astype(np.int64)).cuda(), 24)
         add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity stress of the kernels that read / write INT8 symbol matrices themselves (round 5: ans_encode_pc_n8_kernel with and
 without jump points, ans_decode_n8_kernel, ans_decode_small_n8_kernel) against the CPU oracle (not part of the test suite: minutes of
-GPU time).  Only shapes those kernels take: whole workgroups of 256 streams, rows of whole 128-symbol lines, (32,64), 8 <= P <= 12,
-supports inside int8; random tables (model-distributed, uniform and all-tail data: up to P bits per symbol), slab strides (some too
+GPU time).  Only shapes those kernels take: any number of streams, rows of whole 128-byte lines (int8 and, since later in the round, int16), (32,64),
+8 <= P <= 12, supports inside the type; random tables (model-distributed, uniform and all-tail data: up to P bits per symbol), slab strides (some too
 small: CST_STREAM_CAPACITY), impossible symbols, jump points of every interval that divides the rows, and batches of more than 256
 streams per CU (the two-waves-per-SIMD decoder).
 usage: python tests/stress/stress_n8.py [seconds] [seed]"""
@@ -21,9 +21,13 @@ lib = N.lib()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 while time.time() < t_end:
     P = int(rng.integers(8, 13))
-    n = int(rng.choice([2, 3, 17, 101, 128, 255, 256]))
+    nb = int(rng.choice([1, 1, 2]))                     # int8 or int16 matrices
+    n = int(rng.choice([2, 3, 17, 101, 128, 255, 256] if nb == 1 else [2, 17, 101, 256, 300, 601, 1024]))
     n = min(n, (1 << P) // 2)
-    lo = int(rng.integers(-128, 128 - n + 1))
+    lo = int(rng.integers(-128, 128 - n + 1)) if nb == 1 else int(rng.choice([-32768, 32768 - n, -n // 2, int(rng.integers(-32768, 32768 - n + 1))]))
+    tmin, tmax, np_t, t_t, line = (-128, 127, np.int8, torch.int8, 128) if nb == 1 else (-32768, 32767, np.int16, torch.int16, 64)
+    names = {"enc": "ans_encode_pc_n8_kernel" if nb == 1 else "ans_encode_pc_n16_kernel", "dec": "ans_decode_n8_kernel" if nb == 1 else "ans_decode_n16_kernel",
+             "small": "ans_decode_small_n8_kernel" if nb == 1 else "ans_decode_small_n16_kernel"}
     w = rng.gamma(0.3, 1.0, n) + 1e-9
     p = np.maximum(1, np.floor(w / w.sum() * ((1 << P) - n)).astype(np.int64))
     p[int(np.argmax(p))] += (1 << P) - int(p.sum())
@@ -31,7 +35,9 @@ while time.time() < t_end:
     model = B.Model.from_cdf(cdf, lo, P)
     big = rng.random() < 0.15                           # more than 256 streams per CU: the small-footprint decoder
     n_streams = cus * 256 + 256 * int(rng.integers(1, 4)) if big else 256 * int(rng.choice([1, 2, 3, 8]))
-    n_per = 128 * int(rng.choice([1, 2]) if big else rng.choice([1, 2, 3, 4, 5, 8, 32]))
+    n_per = line * int(rng.choice([1, 2]) if big else rng.choice([1, 2, 3, 4, 5, 8, 32]))
+    if rng.random() < 0.3 and not big:
+        n_streams = int(rng.integers(1, 700))           # partial workgroups / waves
     kind = rng.random()
     if kind < 0.4:
         idx = rng.choice(n, size=(n_streams, n_per), p=p / float(1 << P))
@@ -40,11 +46,11 @@ while time.time() < t_end:
     else:                                               # the rarest symbols only: the maximum rate of the word windows
         rare = np.flatnonzero(p == p.min())
         idx = rng.choice(rare, size=(n_streams, n_per))
-    sym = (idx + lo).astype(np.int8)
+    sym = (idx + lo).astype(np_t)
     bad_rows = []
     if not big:
         for _ in range(int(rng.choice([0, 0, 1, 5]))):      # impossible symbols (where the type has room for them)
-            cand = [v for v in (lo - 1, lo + n, -128, 127) if -128 <= v <= 127 and not (lo <= v < lo + n)]
+            cand = [v for v in (lo - 1, lo + n, tmin, tmax) if tmin <= v <= tmax and not (lo <= v < lo + n)]
             if cand:
                 r = int(rng.integers(n_streams))
                 sym[r, rng.integers(n_per)] = int(rng.choice(cand))
@@ -61,21 +67,21 @@ while time.time() < t_end:
     status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     divisors = [k for k in (1, 2, 3, 4, 8) if n_per % k == 0 and (n_per // k) % 32 == 0]
     k = int(rng.choice(divisors)) if rng.random() < 0.5 else 0
-    tag = f"P={P} n={n} lo={lo} streams={n_streams} n_per={n_per} stride={stride} k={k} kind={kind:.2f}"
+    tag = f"bytes={nb} P={P} n={n} lo={lo} streams={n_streams} n_per={n_per} stride={stride} k={k} kind={kind:.2f}"
     if k:
         interval = n_per // k
         pos = torch.zeros((n_streams, k), dtype=torch.int32, device="cuda")
         state = torch.zeros((n_streams, k), dtype=torch.int64, device="cuda")
-        N.check(lib.cst_ans_encode_batch_ckpt_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0,
+        N.check(lib.cst_ans_encode_batch_ckpt_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(d.data_ptr()), nb, n_streams, n_per, 0,
                                                   C.c_void_p(guard.data_ptr()), stride, C.c_void_p(n_words.data_ptr()), interval,
                                                   C.c_void_p(pos.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(status.data_ptr()), None,
                                                   None), "cst_ans_encode_batch_ckpt_sym")
-        assert B.last_kernel() == "ans_encode_pc_n8_kernel<ckpt>", (tag, B.last_kernel())
+        assert B.last_kernel() == names["enc"] + "<ckpt>", (tag, B.last_kernel())
     else:
-        N.check(lib.cst_ans_encode_batch_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0,
+        N.check(lib.cst_ans_encode_batch_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(d.data_ptr()), nb, n_streams, n_per, 0,
                                              C.c_void_p(guard.data_ptr()), stride, C.c_void_p(n_words.data_ptr()), None,
                                              C.c_void_p(status.data_ptr()), 0, None, None), "cst_ans_encode_batch_sym")
-        assert B.last_kernel() == "ans_encode_pc_n8_kernel", (tag, B.last_kernel())
+        assert B.last_kernel() == names["enc"], (tag, B.last_kernel())
     torch.cuda.synchronize()
     got_st, got_n = status.cpu().numpy(), n_words.cpu().numpy()
     assert got_st[check].tolist() == want_st.tolist(), tag
@@ -94,15 +100,15 @@ while time.time() < t_end:
     # decode: whole streams, and chunk by chunk where jump points were noted
     if good.all():
         enc = B.EncodedBatch(guard[: n_streams * stride].view(n_streams, stride), n_words, status, (32, 64, P))
-        out = torch.full((n_streams, n_per), 99, dtype=torch.int8, device="cuda")
+        out = torch.full((n_streams, n_per), 99, dtype=t_t, device="cuda")
         dec, dst = B.ans_decode(enc, model, n_per, out=out, cold=bool(rng.random() < 0.5))
-        assert B.last_kernel() == ("ans_decode_small_n8_kernel" if big else "ans_decode_n8_kernel"), (tag, B.last_kernel())
+        assert B.last_kernel() == (names["small"] if big and n <= 256 else names["dec"]), (tag, B.last_kernel())
         assert int(dst.abs().sum().item()) == 0 and torch.equal(dec, d), tag
         n_small += int(big)
-        if k and interval % 128 == 0:
+        if k and interval % line == 0:
             out.fill_(98)
             dec, dst = B.ans_decode_checkpointed(enc, B.Checkpoints(interval, pos, state), model, n_per, out=out)
-            assert B.last_kernel() in ("ans_decode_n8_kernel", "ans_decode_small_n8_kernel"), (tag, B.last_kernel())
+            assert B.last_kernel() in (names["dec"], names["small"]), (tag, B.last_kernel())
             assert int(dst.abs().sum().item()) == 0 and torch.equal(dec, d), tag
             n_jump += 1
     n_cases += 1
