@@ -357,8 +357,9 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         stride = tuned_stride(symbols, model, config, layout) if out is None else None
     narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
     if narrow != 4:
-        # int8 / int16 symbol matrices (the reference's Symbol is generic, quantize.rs:229-255): widened on the device next to the
-        # coder call -- what they save is the link to the host (cst_ans_encode_batch_sym)
+        # int8 / int16 symbol matrices (the reference's Symbol is generic, quantize.rs:229-255; cst_ans_encode_batch_sym): rows of whole
+        # 128-byte lines at (32, 64, P <= 12) are read by the encoder loops themselves (round 5: a quarter / half of the symbol bytes in
+        # HBM and on the link); every other shape is widened on the device next to the int32 call
         if model.noncontiguous:
             raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
         symbols = _require_cuda(symbols, symbols.dtype, "symbols")
@@ -418,8 +419,9 @@ def ans_roundtrip_launcher(symbols: torch.Tensor, model: Model, encoded: Encoded
 def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, config=None, cold: Optional[bool] = None, dtype=torch.int32):
     """One AnsCoder per stream: from_compressed + decode_iid_symbols (stack.rs:299-318, mod.rs:1016-1031).
-    dtype (or the dtype of `out`): torch.int32, or int16 / int8 for a narrow symbol matrix (narrowed on the device next to the
-    decoder call: cst_ans_decode_batch_sym; the model's support must fit the type).
+    dtype (or the dtype of `out`): torch.int32, or int16 / int8 for a narrow symbol matrix (cst_ans_decode_batch_sym: written by the
+    decoder loops themselves where the rows are whole 128-byte lines at (32, 64, P <= 12), narrowed on the device next to the int32
+    call otherwise; the model's support must fit the type).
 
     `encoded` is an EncodedBatch, or (words, n_words) with `offsets` for the packed layout.  `cold` (CST_FLAG_COLD_WORDS, a hint
     that never changes results): are the words NOT expected in the GPU's caches?  Default None = decided by provenance: hot only
