@@ -69,7 +69,7 @@ __device__ __forceinline__ void ans_encode_pc_helper_loop(uint32_t& flushed, con
 }
 
 __device__ __forceinline__ void ans_encode_pc_loader_loop(const uint32_t (&tile_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
-                                                          uint32_t n_tiles, const uint32_t (&goff)[8]) {
+                                                          uint32_t n_tiles, const uint32_t (&goff0)[8], const uint32_t (&goff1)[8]) {
 #include "cst_encode_loop_pc_loader.inc"
 }
 
@@ -130,18 +130,26 @@ __device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned
     const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
     const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw0 * kWave;
     if (wave < kPcWaves + 2) {                          // ---- loader ----
-        uint32_t goff[8];
+        // rows of the two coder waves, clamped to the last stream: a partial workgroup's spare coder lanes code the last stream again
+        // (round 5, as in the int8 kernel below; pc_storer stores nothing of theirs)
+        const size_t last = a.n_streams - 1;
+        const size_t first0 = min(s0, last), first1 = min(s0 + kWave, last);
+        uint32_t goff0[8], goff1[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
-        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + (size_t)(n_t - 1) * kTileSyms);
+        for (int k = 0; k < 8; ++k) {
+            const size_t row = (size_t)(lane >> 3) + 8 * k;
+            goff0[k] = (uint32_t)((min(row, last - first0) * N + 4 * (size_t)(lane & 7)) * 4);
+            goff1[k] = (uint32_t)((min(row, last - first1) * N + 4 * (size_t)(lane & 7)) * 4);
+        }
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + first0 * N + (size_t)(n_t - 1) * kTileSyms);
         const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
         const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
         const uint32_t t0 = lds_addr(smem + kPcTileOff + (2 * cw0) * kPcTileBytes) + tr_off;
         const uint32_t tr_addr[2] = {t0, t0 + (uint32_t)kPcTileBytes};
-        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(kWave * N * 4));
+        const uint32_t row_block = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((first1 - first0) * N * 4));
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the statement keeps its own book from here
-        ans_encode_pc_loader_loop(tr_addr, symbols_base, row_block, n_t, goff);
+        ans_encode_pc_loader_loop(tr_addr, symbols_base, row_block, n_t, goff0, goff1);
         pc_barrier();
         return;
     }
@@ -168,8 +176,10 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
                         reinterpret_cast<int32_t*>(smem + kPcTileOff + (2 * cw + 1) * kPcTileBytes)};
     uint32_t* hand = reinterpret_cast<uint32_t*>(smem + kPcHandOff + cw * kPcHandWaveBytes);
 
-    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave;      // (the launcher only takes whole workgroups)
-    const size_t s = s0 + lane;
+    const size_t s0 = (size_t)blockIdx.x * kBlock + (size_t)cw * kWave;
+    // a partial workgroup (split helpers only): the coder lanes behind the last stream code the LAST stream again -- the loader stages
+    // its symbols for them, pc_storer stores nothing of theirs, the jump points they note are its own
+    const size_t s = min(s0 + lane, a.n_streams - 1);
 
     if (!helper) {
         uint32_t lo = 0, hi = 0;
@@ -494,22 +504,23 @@ cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32
     return CST_OK;
 }
 
-// Whole workgroups of 256 streams, at most one per CU (more streams than that: the two-waves-per-SIMD kernels of
+// Any number of streams (partial workgroups since round 5), at most one workgroup per CU (more streams than that: the two-waves-per-SIMD kernels of
 // cst_ans_small.hip), rows that are whole 128-byte aligned tiles, 64-byte aligned slabs of whole 64-byte groups.
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
     if (getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs)
     if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     (void)device_cus;     // (more than one workgroup per CU: they run one after another, cst_api.hip asks the small-footprint kernels first)
-    if (a.n_streams == 0 || a.n_streams % kBlock != 0) return false;
+    if (a.n_streams == 0) return false;
+    if (a.n_streams % kBlock != 0 && getenv("CST_PC_COMBINED")) return false;                      // (partial workgroups: the split helpers only)
     if (a.n_per_stream % kTileSyms != 0 || a.n_per_stream < 2 * kTileSyms || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
-    if (a.n_streams * a.stride_words * 4 >= 0x100000000ull || 64 * a.n_per_stream * 4 >= 0x100000000ull) return false;   // 32-bit offsets
+    if ((a.n_streams + kBlock - 1) / kBlock * kBlock * a.stride_words * 4 >= 0x100000000ull || 64 * a.n_per_stream * 4 >= 0x100000000ull) return false;   // 32-bit offsets
     return (size_t)a.n_symbols * sizeof(EncEntry) <= kPcTableBytes;
 }
 
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs) {
-    const size_t blocks = a.n_streams / kBlock;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     static const bool combined = getenv("CST_PC_COMBINED") != nullptr;      // (A/B runs: every helper wave loads AND stores)
     auto kernel = combined ? ans_encode_pc_kernel<false> : ans_encode_pc_kernel<true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
@@ -525,7 +536,7 @@ bool pc_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_lay
 }
 
 cst_status ans_encode_pc_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
-    const size_t blocks = a.n_streams / kBlock;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     auto kernel = ans_encode_pc_kernel<true, true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a, pc_jump_args(a, interval, d_ckpt_pos, d_ckpt_state));

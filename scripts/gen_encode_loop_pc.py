@@ -439,7 +439,7 @@ def l_load(a, i):
         base = "s[80:81]" if c == 0 else "s[84:85]"
         for k in range(8):
             if "noloads" not in HABL:
-                a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
+                a.vmem(f"global_load_dwordx4 {LR[(c, i)][k]}, %[goff{c}_{k}], {base} {HLOAD_MOD}".rstrip(), f"ld{c}{i}")
                 if LSLEEP:
                     a.i(f"s_sleep {LSLEEP}")
     a.i("s_cmp_lg_u32 s83, 0")
@@ -643,7 +643,8 @@ def main_split():
               "// Loader wave of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_loader_loop in cst_ans_pc.hip."]
     ops = ['    :',
            '    : [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]), [sbase] "s"(symbols_base), [rowblock] "s"(row_block_bytes), [ntiles] "s"(n_tiles),',
-           '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
+           '      ' + ", ".join(f'[goff0_{k}] "v"(goff0[{k}])' for k in range(8)) + ",",
+           '      ' + ", ".join(f'[goff1_{k}] "v"(goff1[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in L_CLOBBERS) + ");"]
     OUT_LOADER.write_text(a.render(header, ops))
     print(f"wrote {OUT_LOADER} ({a.n_instr()} instructions incl. prologue)")
