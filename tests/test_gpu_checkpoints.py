@@ -190,7 +190,7 @@ def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, monke
 @pytest.mark.parametrize("dtype", ["int32", "int8"])
 @pytest.mark.parametrize("P", [12, 9])
 @pytest.mark.parametrize("n_streams,n_per,interval", [(256, 256, 128), (256, 1024, 256), (512, 768, 384), (256, 4096, 512), (256, 512, 512),
-                                                      (256, 256, 32), (256, 384, 96)])
+                                                      (256, 256, 32), (256, 384, 96), (70, 256, 128), (1, 128, 64), (321, 512, 128)])
 def test_producer_consumer_encoders_note_jump_points(B, O, dtype, P, n_streams, n_per, interval):
     """cst_ans_encode_batch_ckpt / _ckpt_sym on shapes the producer / consumer encoders take: the words of the plain encoder, the
     jump table of the CPU oracle (AnsCoder::pos() in front of every chunk: stack.rs:1107-1139) for EVERY stream, and the chunks
