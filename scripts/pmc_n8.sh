@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): scripts/pmc_n8.sh <tag> -- the kernels that read / write INT8 symbol matrices themselves (round 5:
-# ans_encode_pc_n8_kernel, ans_decode_n8_kernel, ans_decode_small_n8_kernel) next to the int32 kernels of the same batch:
+# ans_encode_pc_n8_kernel, ans_decode_n8_kernel, ans_decode_small_n8_kernel and their int16 forms) next to the int32 kernels of the same batch:
 # SQ counters (two rocprofv3 --pmc passes), HBM traffic (FETCH_SIZE / WRITE_SIZE, one pass each; counters never share a run with a
 # trace) and one --kernel-trace --stats pass.  65 536 x 4096 whole, with two jump points per stream, and 131 072 x 4096.
 # Output: gpurun_out/<tag>_n8_counters.md (copy to profiles/).
@@ -18,8 +18,8 @@ m = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
 cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
 for n in (65536, 131072):
     sym32 = bench.synth_symbols_device(0xC0FFEE, 0, n, k, -50, cdf, P)
-    sym8 = sym32.to(torch.int8)
-    for sym in (sym32, sym8):
+    sym8, sym16 = sym32.to(torch.int8), sym32.to(torch.int16)
+    for sym in (sym32, sym8, sym16):
         enc = B.ans_encode(sym, m, (32, 64, P))
         dec = torch.empty_like(sym)
         for _ in range(4):
@@ -34,7 +34,7 @@ for n in (65536, 131072):
             assert torch.equal(dec, sym)
             del pair
         del enc, dec
-    del sym32, sym8
+    del sym32, sym8, sym16
 torch.cuda.synchronize()
 PY
 for pass in "a SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" \
@@ -50,8 +50,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$d -o st 
 find $d -mindepth 2 -name "*.csv" -exec mv {} $d/ \;
 python - <<PY > gpurun_out/${tag}_n8_counters.md
 import csv, glob, collections, statistics
-want = ("ans_encode_pc_kernel", "ans_encode_pc_n8_kernel", "ans_decode_kernel<32, 64, 0, true, 1, true, 8, true>", "ans_decode_n8_kernel",
-        "ans_decode_small_kernel", "ans_decode_small_n8_kernel", "ans_encode_small_kernel")
+want = ("ans_encode_pc_kernel", "ans_encode_pc_n8_kernel", "ans_encode_pc_n16_kernel", "ans_decode_kernel<32, 64, 0, true, 1, true, 8, true>",
+        "ans_decode_n8_kernel", "ans_decode_small_kernel", "ans_decode_small_n8_kernel", "ans_encode_small_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/${tag}_n8_[abfw]/*counter_collection.csv"):
     per_dispatch = collections.defaultdict(float)
@@ -70,7 +70,8 @@ print("# ${tag}: the kernels that read / write int8 symbol matrices themselves, 
 print("scripts/pmc_n8.sh: rocprofv3 --pmc (two SQ passes, FETCH_SIZE and WRITE_SIZE in a pass each), medians over the launches of a kernel at one grid")
 print("size; per symbol and wave = counter / (streams / 64 x 4096) wave-symbols (cycle counters x 4: they count in units of four cycles; the")
 print("producer / consumer encoders' counters are sums over coder AND helper waves, normalised by the coder waves).  FETCH x 2 as the guide")
-print("prescribes for wide streaming reads on gfx950; traffic in bytes per symbol (algorithmic: 4 or 1 B per symbol + 4 B per word, 0.677 B).\n")
+print("prescribes for wide streaming reads on gfx950; traffic in bytes per symbol (algorithmic: 4, 2 or 1 B per symbol + 4 B per word, 0.677 B).")
+print("Template arguments: ans_decode_n8_kernel<1> / <2> = int8 / int16; ans_encode_pc_n8_kernel<false> / <true>, ..._n16_kernel<...> = without / with jump points.\n")
 cols = ["SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES"]
 cyc = {"SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"}
 print("| kernel | streams | " + " | ".join(c.replace("SQ_", "") for c in cols) + " | FETCH x 2 B/sym | WRITE B/sym |")

@@ -227,3 +227,15 @@ def test_every_loop_head_is_pinned_to_a_cache_line():
         heads = [i for i, ln in enumerate(lines) if ln == '"1:\\n"']
         assert len(heads) == 1, p.name
         assert lines[heads[0] - 1] == '".p2align 6\\n\\t"', p.name
+
+
+def test_every_statement_declares_scc_clobbered():
+    """the generated statements count tiles and compare on the scalar side (s_sub_u32 / s_cmp_* / s_add_u32 ...: all write SCC).  Until
+    round 5 none declared it, and one harmless edit made the compiler keep a flag in SCC ACROSS a statement"""
+    incs = sorted((ROOT / "constriction_amd" / "csrc").glob("*.inc"))
+    statements = [p for p in incs if "asm volatile(" in p.read_text()]
+    assert len(statements) >= 40
+    for p in statements:
+        text = p.read_text()
+        clobbers = text[text.rindex("    : "):]
+        assert '"scc"' in clobbers and '"vcc"' in clobbers and '"memory"' in clobbers, p.name
