@@ -35,3 +35,12 @@ def test_c_example_runs(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 mismatches" in res.stdout and "words against the int32 call" in res.stdout and " 0 mismatches (symbols" in res.stdout
     assert "ans_encode_pc_n8_kernel<ckpt>" in res.stdout          # the int8 matrix was read by the encoder loops themselves
+
+
+@pytest.mark.gpu
+def test_python_int8_example_runs():
+    """examples/batched_int8_latents.py: int8 latents through the batched coder, packed words, jump points"""
+    import sys
+    res = subprocess.run([sys.executable, str(ROOT / "examples" / "batched_int8_latents.py"), "1024", "512"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ans_encode_pc_n8_kernel" in res.stdout and "ans_decode_n8_kernel" in res.stdout and res.stdout.strip().endswith("the int32 call's")
