@@ -761,12 +761,13 @@ def other_configs(B, rank, world, dist, args, reps=5):
     packed, offsets = B.compact(enc5)
     e["compact_ms"] = round(event_ms(lambda: B.compact(enc5, out=(packed, offsets)), reps), 4)
     if world == 1:
-        try:      # the shard as an int8 matrix: a quarter of the symbol bytes of a batch that never fits the caches
-            e8 = narrow_config(B, m12, sym5, reps, check)
-            e["int8_symbols"] = {k: e8[k] for k in ("encode_ms", "decode_ms", "Msymbols_per_s", "encode_kernel", "decode_kernel", "bit_exact",
-                                                    "conversion_path") if k in e8}
-        except Exception as exc:      # noqa: BLE001
-            e["int8_symbols"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        for key, narrow_dtype in (("int8_symbols", torch.int8), ("int16_symbols", torch.int16)):
+            try:      # the shard as a narrow matrix: a quarter / half of the symbol bytes of a batch that never fits the caches
+                e8 = narrow_config(B, m12, sym5, reps, check, dtype=narrow_dtype)
+                e[key] = {k: e8[k] for k in ("encode_ms", "decode_ms", "Msymbols_per_s", "encode_kernel", "decode_kernel", "bit_exact",
+                                             "conversion_path") if k in e8}
+            except Exception as exc:      # noqa: BLE001
+                e[key] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if dist is not None and not args.no_gather:
         from constriction_amd import dist as D
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()

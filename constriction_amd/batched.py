@@ -346,8 +346,11 @@ def _layout_shape(symbols: torch.Tensor, layout: str):
 
 
 def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-               stride=None, out: Optional[EncodedBatch] = None, packed16: bool = False) -> EncodedBatch:
+               stride=None, out: Optional[EncodedBatch] = None, packed16: bool = False, jump_points: int = 0) -> EncodedBatch:
     """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895).
+    jump_points = k > 0 (k divides the rows): the encoder also notes `AnsCoder.pos()` in front of every k-th part of a stream
+    (ans_encode_checkpointed; the words are unchanged) and the batch carries them as `.jump` -- ans_decode then decodes every part on a
+    lane of its own (two or more waves per SIMD where a 65 536-stream batch has one: int8 / int16 matrices, tables per stream).
     stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride).
     packed16 (the (16,32) preset only): the words two per 32-bit slot, as the reference's Vec<u16> (CST_FLAG_PACKED_W16) -- the
     batch's `words` is then an int16 tensor; ans_decode and compact recognise it."""
@@ -355,6 +358,15 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout) if out is None else None
+    if jump_points:
+        n_per = symbols.shape[1] if layout == "stream_major" else symbols.shape[0]
+        if packed16 or jump_points < 0 or n_per % jump_points != 0:
+            raise ValueError("jump_points must divide the number of symbols per stream (and needs unpacked words)")
+        prev = (out, out.jump) if out is not None and getattr(out, "jump", None) is not None else None
+        enc, ck = ans_encode_checkpointed(symbols, model, n_per // jump_points, config, layout, stride, out=prev)
+        enc.jump = ck
+        _stamp_fresh(enc)
+        return enc
     narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
     if narrow != 4:
         # int8 / int16 symbol matrices (the reference's Symbol is generic, quantize.rs:229-255; cst_ans_encode_batch_sym): rows of whole
@@ -427,6 +439,11 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     that never changes results): are the words NOT expected in the GPU's caches?  Default None = decided by provenance: hot only
     if `encoded` is the EncodedBatch that the last ans_encode on this HIP stream filled (and small enough to have stayed in the
     caches); words that came from the host, a peer or a file -- plain tensors, packed + offsets -- are cold."""
+    jump = getattr(encoded, "jump", None) if isinstance(encoded, EncodedBatch) else None
+    if jump is not None and offsets is None and layout == "stream_major" and n_per_stream % jump.interval == 0:
+        # the batch carries jump points (ans_encode(..., jump_points=k)): every part of a stream on a lane of its own
+        dec, part_status = ans_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype if out is None else out.dtype)
+        return dec, part_status.amax(dim=1)
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
         stride = words.shape[1]

@@ -401,3 +401,27 @@ def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams,
             dec, st = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=torch.int16)
             assert ALT or B.last_kernel() in ("ans_decode_n16_kernel", "ans_decode_small_n16_kernel")
             assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("dtype", [torch.int8, torch.int16, torch.int32], ids=["int8", "int16", "int32"])
+def test_jump_points_travel_with_the_batch(B, O, dtype):
+    """ans_encode(..., jump_points=k) notes AnsCoder.pos() on its way and hangs the table on the batch; ans_decode finds it there and
+    decodes every part on a lane of its own -- the words are the plain encoder's, the symbols the input"""
+    P, n_streams, n_per, lo = 12, 512, 1024, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(99, 0, n_streams, n_per, lo, cdf, P)
+    d = torch.from_numpy(sym).to(dtype).cuda()
+    plain = B.ans_encode(d, model, (32, 64, P))
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=4)
+    assert enc.jump.pos.shape == (n_streams, 4) and torch.equal(enc.n_words, plain.n_words)
+    used = torch.arange(plain.words.shape[1], device="cuda")[None, :] < plain.n_words[:, None]
+    assert bool(((enc.words == plain.words) | ~used).all())
+    wp, ws = O.ans_jump_table(sym, lo, cdf, P, n_per // 4)
+    assert np.array_equal(enc.jump.pos.cpu().numpy().view(np.uint32), wp) and np.array_equal(enc.jump.state.cpu().numpy().view(np.uint64), ws)
+    dec, st = B.ans_decode(enc, model, n_per, dtype=dtype)
+    assert st.shape == (n_streams,) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    again = B.ans_encode(d, model, (32, 64, P), jump_points=4, out=enc)          # into the same buffers
+    assert again is enc and torch.equal(B.ans_decode(enc, model, n_per, dtype=dtype)[0], d)
+    with pytest.raises(ValueError):
+        B.ans_encode(d, model, (32, 64, P), jump_points=3)
