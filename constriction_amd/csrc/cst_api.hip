@@ -468,6 +468,10 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
+    if (b16_narrow_decode_usable(a, cfg, layout, symbol_bytes)) {      // 12 < P <= 24
+        *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_b16_n8_kernel" : "ans_decode_b16_n16_kernel", ans_decode_b16_narrow(a, symbol_bytes, (hipStream_t)stream));
+        return true;
+    }
     if (!n8_decode_usable(a, cfg, layout, symbol_bytes)) return false;
     if (n8_decode_small(a, model->cu_count))
         *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_small_n8_kernel" : "ans_decode_small_n16_kernel", ans_decode_small_n8(a, symbol_bytes, (hipStream_t)stream));

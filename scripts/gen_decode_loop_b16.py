@@ -25,6 +25,18 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from asmgen import Asm  # noqa: E402
 
 OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc"
+# GEN_B16_NARROW=1 / 2 (round 5: cst_decode_loop_b16_n8.inc / _n16.inc, ans_decode_b16_narrow_kernel): int8 / int16 symbol matrices.  A
+# decoded quad is packed (two v_perm_b32 + v_or for int8, two v_perm_b32 for int16) into the lane's row of ONE byte tile -- rows of 128
+# bytes + 4: a line of the matrix -- and the group of 128 / 64 symbols leaves when its last tile is done, in a block of eight row
+# blocks (four ds_read_b32 + one 16-byte store each) that a scalar branch skips on the other tiles.  Nobody covers that block's ~300
+# cycles (one wave per SIMD), but they come once per 128 / 64 symbols of ~214 cycles each; in exchange the statement's body stays ONE
+# tile.  The block's memory operations are not in the wait-count book: operations the book does not know can only make a wait
+# LONGER (they are younger than what it waits for, or older and retired with it), never shorter.
+NARROW = int(os.environ.get("GEN_B16_NARROW", "0"))
+N8_ROW = 132
+TILES_PER_GROUP = {0: 1, 1: 4, 2: 2}[NARROW]
+if NARROW:
+    OUT = OUT.with_name("cst_decode_loop_b16_n8.inc" if NARROW == 1 else "cst_decode_loop_b16_n16.inc")
 
 K_CHUNKS = 3          # window chunks requested per HALF tile (16 symbols * 24 bits = 12 words = 3 chunks)
 AHEAD_M1 = 23         # kDecAhead - 1
@@ -105,8 +117,13 @@ def gen():
     # here before the first step writes symbols over them): rows of any length take per-row offsets (row_skew,
     # cst_ans_kernels.hpp), partial waves repeat their last row, symbol-major batches have their own mapping -- all the
     # kernel's business, and an asm statement has room for 30 operands
-    a.ds(f"ds_read_b128 {tup(180)}, %[rowcur]", "goff")
-    a.ds(f"ds_read_b128 {tup(184)}, %[rowcur] offset:16", "goff")
+    if NARROW:
+        for k in range(8):
+            a.ds(f"ds_read_b32 {GOFF[k]}, %[rowcur] offset:{4 * k}", "goff")      # (rows of 33 words: not 16-byte aligned)
+        a.i("s_mov_b32 s83, 0", "tiles of the current group done")
+    else:
+        a.ds(f"ds_read_b128 {tup(180)}, %[rowcur]", "goff")
+        a.ds(f"ds_read_b128 {tup(184)}, %[rowcur] offset:16", "goff")
     a.wait_lds_all("the store offsets")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the PREVIOUS tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
@@ -152,7 +169,9 @@ def gen():
         a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
         a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
         a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
-        if pos == 1 and SYMBOL_MAJOR:
+        if NARROW:
+            pass                          # (the group leaves in a block of its own behind its last tile)
+        elif pos == 1 and SYMBOL_MAJOR:
             for c in range(4):
                 a.ds(f"ds_read_b32 v{144 + c}, %[trprev] offset:{(32 * (quad & 1) + c) * 144 + 32 * (quad >> 1)}", "x")
         elif pos == 1:
@@ -162,9 +181,21 @@ def gen():
             a.i(f"v_min_u32 {R1}, 1, %[rd]")
             a.i(f"v_alignbit_b32 {T0}, %[hi], %[lo], %[P]")
             a.i(f"v_lshrrev_b32 {T1}, %[P], %[hi]")
-        if pos == 2:
+        if pos == 2 and not NARROW:
             a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {X}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
-        if pos == 3:
+        if pos == 3 and NARROW == 1:
+            base = 134 + (quad % 2) * 4
+            a.i(f"v_perm_b32 v144, v{base + 1}, v{base}, %[sel01]", f"symbols {4 * quad}..{4 * quad + 3} as bytes")
+            a.i(f"v_perm_b32 v145, v{base + 3}, v{base + 2}, %[sel23]")
+            a.i("v_or_b32 v144, v144, v145")
+            a.ds(f"ds_write_b32 %[rowcur], v144 offset:{4 * quad}", "tile")
+        elif pos == 3 and NARROW == 2:
+            base = 134 + (quad % 2) * 4
+            a.i(f"v_perm_b32 v144, v{base + 1}, v{base}, %[sel01]", f"symbols {4 * quad}..{4 * quad + 3} as int16")
+            a.i(f"v_perm_b32 v145, v{base + 3}, v{base + 2}, %[sel01]")
+            a.ds(f"ds_write_b32 %[rowcur], v144 offset:{8 * quad}", "tile")
+            a.ds(f"ds_write_b32 %[rowcur], v145 offset:{8 * quad + 4}", "tile")
+        elif pos == 3:
             base = 134 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
         if j == 15:
@@ -172,10 +203,28 @@ def gen():
             a.wait_lds_all("landed chunks visible")
 
     window_landing("---- end of tile")
-    a.i("v_swap_b32 %[rowcur], %[rowprev]")
-    a.i("v_swap_b32 %[trcur], %[trprev]")
-    a.i("s_add_u32 s80, s80, %[tilestep]" if SYMBOL_MAJOR else "s_add_u32 s80, s80, 0x80")
-    a.i("s_addc_u32 s81, s81, 0")
+    if NARROW:
+        a.wait_lds_all("landed chunks (and the tile's last quad) are in LDS")
+        a.i(f"v_add_u32 %[rowcur], {128 // TILES_PER_GROUP}, %[rowcur]", "the next tile's bytes of the row")
+        a.i("s_add_u32 s83, s83, 1")
+        a.i(f"s_cmp_lg_u32 s83, {TILES_PER_GROUP}")
+        a.i("s_cbranch_scc1 50f", "the group is not complete: nothing leaves")
+        # ---- the group leaves: eight row blocks of whole 128-byte lines (not in the book: see the top of the file) ----
+        for k in range(8):
+            for c in range(4):
+                a.i(f"ds_read_b32 v{144 + c}, %[trcur] offset:{8 * N8_ROW * k + 4 * c}")
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"global_store_dwordx4 {GOFF[k]}, v[144:147], s[80:81] nt")
+        a.i("v_subrev_u32 %[rowcur], 128, %[rowcur]")
+        a.i("s_mov_b32 s83, 0")
+        a.i("s_add_u32 s80, s80, 0x80")
+        a.i("s_addc_u32 s81, s81, 0")
+        a.i("50:", None)
+    else:
+        a.i("v_swap_b32 %[rowcur], %[rowprev]")
+        a.i("v_swap_b32 %[trcur], %[trprev]")
+        a.i("s_add_u32 s80, s80, %[tilestep]" if SYMBOL_MAJOR else "s_add_u32 s80, s80, 0x80")
+        a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.wait_lds_all("landed chunks visible to the next tile")
@@ -255,7 +304,7 @@ def gen():
 
 def main():
     global SYMBOL_MAJOR
-    for SYMBOL_MAJOR, out in ((False, OUT), (True, OUT_SM)):
+    for SYMBOL_MAJOR, out in (((False, OUT),) if NARROW else ((False, OUT), (True, OUT_SM))):
         emit(out)
     SYMBOL_MAJOR = False
 
@@ -268,7 +317,8 @@ def emit(out):
            '      [trcur] "+v"(tr_cur), [trprev] "+v"(tr_prev)',
            '    : [lut] "s"(lut_addr), [cdf] "s"(cdf_addr), [mask] "s"(mask), [P] "s"(P), [bsh] "s"(bucket_shift), [minsym] "v"(min_symbol), [cfield] "s"(c_field_mask), [ishift] "s"(index_shift),',
            '      [cmask] "s"(ring_mask), [wbase] "s"(words_base), [gbase] "s"(store_base), [ntiles] "s"(n_tiles),',
-           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else ''),
+           '      [shm1] "v"(shift_minus_1), [lanebase] "v"(ring_lane_addr), [dump] "v"(dump_addr), [woff] "v"(words_off)' + (', [tilestep] "s"(tile_step_bytes)' if SYMBOL_MAJOR else '') +
+           (', [sel01] "s"(0x0c0c0400u), [sel23] "s"(0x04000c0cu)' if NARROW == 1 else ', [sel01] "s"(0x05040100u)' if NARROW == 2 else ''),
            "    : " + ", ".join(f'"{c}"' for c in clobbers) + ");"]
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions per iteration incl. loop control)")

@@ -343,3 +343,26 @@ def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
     buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng, max_gap=5)
     dec, st = B.ans_decode((buf, nw), model, n_per, offsets=offsets, config=(32, 64, P), dtype=torch.int16)
     assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("P", [24, 16])
+@pytest.mark.parametrize("dtype", ["int8", "int16"])
+def test_narrow_high_precision_decoders_at_the_maximum_rate(B, O, dtype, P, frac):
+    """ans_decode_b16_narrow_kernel at 24 words per 32-symbol tile (P = 24: every symbol of probability 2^-24), slabs and packed words;
+    the tails also take the statement's out-of-line walk over the cdf table on nearly every step"""
+    n = 101
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + P + 3)
+    sym = high_rate_symbols(rng, 200, 2048, n, frac)
+    dt = torch.int8 if dtype == "int8" else torch.int16
+    d = dev(sym).to(dt)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    dec, st = B.ans_decode(enc, model, 2048, dtype=dt)
+    assert ALT or B.last_kernel() == ("ans_decode_b16_n8_kernel" if dtype == "int8" else "ans_decode_b16_n16_kernel")
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    words, n_words, _ = enc.to_numpy()
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
+    dec, st = B.ans_decode((buf, nw), model, 2048, offsets=offsets, config=(32, 64, P), dtype=dt)
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)

@@ -425,3 +425,33 @@ def test_jump_points_travel_with_the_batch(B, O, dtype):
     assert again is enc and torch.equal(B.ans_decode(enc, model, n_per, dtype=dtype)[0], d)
     with pytest.raises(ValueError):
         B.ans_encode(d, model, (32, 64, P), jump_points=3)
+
+
+# ---- narrow matrices at 12 < P <= 24 (the reference's default precision): the bucket-entry decoder writes them itself ----
+
+@pytest.mark.parametrize("dtype", [torch.int8, torch.int16], ids=["int8", "int16"])
+@pytest.mark.parametrize("P", [13, 16, 24])
+@pytest.mark.parametrize("n_streams,n_per", [(1, 128), (70, 256), (256, 384), (300, 4096), (512, 128)])
+def test_narrow_decoders_at_high_precision(B, O, dtype, P, n_streams, n_per):
+    lo, hi = (-100, 100) if dtype == torch.int8 else (900, 1150)
+    cdf = O.GaussianModel(lo, hi, 0.5 * (lo + hi) + 7.3, 11.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(7000 + P, 0, n_streams, n_per, lo, cdf, P)
+    d = torch.from_numpy(sym).to(dtype).cuda()
+    enc = B.ans_encode(d, model, (32, 64, P))
+    torch.cuda.synchronize()
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(0, n_streams, max(1, n_streams // 30)):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    guard = torch.full((n_streams * n_per + 4096,), 77, dtype=dtype, device="cuda")
+    out = guard[: n_streams * n_per].view(n_streams, n_per)
+    dec, st = B.ans_decode(enc, model, n_per, out=out)
+    assert ALT or B.last_kernel() == ("ans_decode_b16_n8_kernel" if dtype == torch.int8 else "ans_decode_b16_n16_kernel")
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+    assert (guard[n_streams * n_per:].cpu().numpy() == 77).all(), "symbols were written behind the matrix"
+    packed, offsets = B.compact(enc)
+    out.fill_(55)
+    dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
+    assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
