@@ -223,9 +223,9 @@ cst_status cst_ans_encode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
         e.n_symbols = model->n_symbols; e.min_symbol = model->min_symbol; e.precision = model->precision; e.words = d_words;
         e.stride_words = stride_words; e.n_words = d_n_words; e.state = nullptr; e.status = d_status; e.flags = 0;
         if (symbol_bytes == 1 && pc_n8_encode_ckpt_usable(e, cfg, layout, ckpt_interval))      // the int8 matrix inside the loops, jump points on the way
-            return note_kernel("ans_encode_pc_n8_kernel<ckpt>", ans_encode_pc_n8_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+            return note_kernel(e.precision > 12 ? "ans_encode_pc_n8_kernel<wide, ckpt>" : "ans_encode_pc_n8_kernel<ckpt>", ans_encode_pc_n8_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
         if (symbol_bytes == 2 && pc_n16_encode_ckpt_usable(e, cfg, layout, ckpt_interval))
-            return note_kernel("ans_encode_pc_n16_kernel<ckpt>", ans_encode_pc_n16(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+            return note_kernel(e.precision > 12 ? "ans_encode_pc_n16_kernel<wide, ckpt>" : "ans_encode_pc_n16_kernel<ckpt>", ans_encode_pc_n16(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
     }
     if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
     int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);

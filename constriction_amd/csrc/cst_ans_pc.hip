@@ -78,12 +78,19 @@ __device__ __forceinline__ void ans_encode_pc_storer_loop(uint32_t (&flushed)[2]
 #include "cst_encode_loop_pc_storer.inc"
 }
 
+// ... two 64-byte groups per tile and coder wave (the coders at 12 < P <= 24: 32 symbols can emit 24 words)
+__device__ __forceinline__ void ans_encode_pc_storer2_loop(uint32_t (&flushed)[2], const uint32_t (&ring_lane_addr)[2], const uint32_t (&publish_addr)[2],
+                                                           const uint32_t (&cap)[2], const uint32_t (&slab_off)[2], const void* words_base, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_storer2.inc"
+}
+
 // LDS hand-off between the two halves of a workgroup: this wave's LDS operations have completed, then the barrier.  (Not
 // __syncthreads(): its fence would also wait for the helper's symbol loads, which are requested tiles ahead on purpose.)
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // the storer waves (6, 7; each for the coder waves cw0, cw0 + 1): complete 64-byte groups ring -> slab while the coders run, then
 // the ends of the streams.  Shared by the int32 and the int8 kernel (their rings and hand-off areas look alike).
+template <bool TWO_GROUPS = false>
 __device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char* smem, int lane, int cw0, size_t s0, uint32_t n_t,
                                           size_t ring_off, size_t hand_off_) {
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
@@ -102,7 +109,8 @@ __device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char*
         slab_off[c] = (uint32_t)((s0 + c * kWave + lane) * a.stride_words * 4);
         cap[c] = s0 + c * kWave + lane < a.n_streams ? (uint32_t)a.stride_words : 0u;
     }
-    ans_encode_pc_storer_loop(flushed, ring_addr, pub_addr, cap, slab_off, a.words, n_t);
+    if constexpr (TWO_GROUPS) ans_encode_pc_storer2_loop(flushed, ring_addr, pub_addr, cap, slab_off, a.words, n_t);
+    else ans_encode_pc_storer_loop(flushed, ring_addr, pub_addr, cap, slab_off, a.words, n_t);
     pc_barrier();                                       // the coders have published their last write positions and final states
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -259,12 +267,25 @@ __device__ __forceinline__ void ans_encode_pc_n8_coder_loop_ck(uint32_t& lo, uin
 #include "cst_encode_loop_pc_n8_ck.inc"
 }
 
+// ... at 12 < P <= 24: unpacked entries {c, p, floor(2^64 / p)} and the step of cst_encode_loop_wide.inc (round 5)
+__device__ __forceinline__ void ans_encode_pc_n8w_coder_loop(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, uint32_t line_row_addr,
+                                                             uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_n8w.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_n8w_coder_loop_ck(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, uint32_t line_row_addr,
+                                                                uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t P, uint32_t n_tiles,
+                                                                const uint32_t* ckpt_pos, const uint64_t* ckpt_state, uint32_t ckpt_tiles,
+                                                                uint32_t ckpt_pos_off, uint32_t ckpt_state_off) {
+#include "cst_encode_loop_pc_n8w_ck.inc"
+}
+
 __device__ __forceinline__ void ans_encode_pc_n8_loader_loop(const uint32_t (&line_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
                                                              uint32_t n_tiles, const uint32_t (&goff0)[8], const uint32_t (&goff1)[8]) {
 #include "cst_encode_loop_pc_loader_n8.inc"
 }
 
-template <bool JUMP>
+template <bool JUMP, bool WIDE = false>
 __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsEncodeArgs a, const PcJumpArgs jp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -283,8 +304,11 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
     for (int u = threadIdx.x; u < 256; u += kPcThreads) {
         const int idx = (u - 128) - a.min_symbol;
         const bool in_support = idx >= 0 && idx < a.n_symbols;
-        EncEntry e = pack_entry(a.enc[in_support ? idx : 0], P);
-        if (!in_support) e.c |= 0x8000u;                 // the range check's flag (c < 2^12 in a real entry): n8_fold_minmax of the generator
+        EncEntry e = a.enc[in_support ? idx : 0];
+        if constexpr (!WIDE) e = pack_entry(e, P);
+        // the range check's flag (n8_fold_minmax of the generator): a bit no real entry has in its first word (c < 2^12 packed with
+        // c + 2^P - p < 2^13 above it; c < 2^24 unpacked)
+        if (!in_support) e.c |= WIDE ? 0x80000000u : 0x8000u;
         table[u] = e;
     }
 
@@ -299,14 +323,20 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
         if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
         const uint32_t row_addr = lds_addr(smem + kPcN8TileOff + (2 * cw) * kPcN8LineBytes) + (uint32_t)(lane * kPcN8RowBytes);
         pc_barrier();                                   // table and the first line are in LDS
-        if constexpr (JUMP)
+        const uint32_t jpos = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4), jstate = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8);
+        if constexpr (JUMP && WIDE)
+            ans_encode_pc_n8w_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t, jp.pos, jp.state,
+                                            jp.tiles, jpos, jstate);
+        else if constexpr (JUMP)
             ans_encode_pc_n8_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t, jp.pos, jp.state,
-                                           jp.tiles, (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4), (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8));
+                                           jp.tiles, jpos, jstate);
+        else if constexpr (WIDE)
+            ans_encode_pc_n8w_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t);
         else
             ans_encode_pc_n8_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), (uint32_t)P, n_t);
         hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
         (void)smin;
-        hand[3 * kWave + lane] = (smax & 0x8000) ? 0xffffffffu : 0u;        // "largest table index seen": beyond every alphabet, or inside
+        hand[3 * kWave + lane] = ((uint32_t)smax & (WIDE ? 0x80000000u : 0x8000u)) ? 0xffffffffu : 0u;   // "largest table index seen": beyond every alphabet, or inside
         pc_barrier();                                   // the last window and the final state are published
         return;
     }
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n8_kernel(const AnsE
         pc_barrier();
         return;
     }
-    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
+    pc_storer<WIDE>(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -354,12 +384,24 @@ __device__ __forceinline__ void ans_encode_pc_n16_coder_loop_ck(uint32_t& lo, ui
 #include "cst_encode_loop_pc_n16_ck.inc"
 }
 
+__device__ __forceinline__ void ans_encode_pc_n16w_coder_loop(uint32_t& lo, uint32_t& hi, uint32_t& smin, uint32_t& smax, uint32_t line_row_addr,
+                                                              uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_n16w.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_n16w_coder_loop_ck(uint32_t& lo, uint32_t& hi, uint32_t& smin, uint32_t& smax, uint32_t line_row_addr,
+                                                                 uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P,
+                                                                 uint32_t n_tiles, const uint32_t* ckpt_pos, const uint64_t* ckpt_state, uint32_t ckpt_tiles,
+                                                                 uint32_t ckpt_pos_off, uint32_t ckpt_state_off) {
+#include "cst_encode_loop_pc_n16w_ck.inc"
+}
+
 __device__ __forceinline__ void ans_encode_pc_n16_loader_loop(const uint32_t (&line_tr_addr)[2], uint64_t symbols_base, uint32_t row_block_bytes,
                                                               uint32_t n_tiles, const uint32_t (&goff0)[8], const uint32_t (&goff1)[8]) {
 #include "cst_encode_loop_pc_loader_n16.inc"
 }
 
-template <bool JUMP>
+template <bool JUMP, bool WIDE = false>
 __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const AnsEncodeArgs a, const PcJumpArgs jp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const Ans
     const size_t row_bytes = N * 2;
 
     EncEntry* table = reinterpret_cast<EncEntry*>(smem);
-    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = pack_entry(a.enc[i], P);
+    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = WIDE ? a.enc[i] : pack_entry(a.enc[i], P);
 
     if (wave < kPcWaves) {                               // ---- coder ----
         uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
@@ -386,10 +428,15 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const Ans
         const uint32_t row_addr = lds_addr(smem + kPcN8TileOff + (2 * cw) * kPcN8LineBytes) + (uint32_t)(lane * kPcN8RowBytes);
         const uint32_t bias = table_addr - 16u * (uint32_t)a.min_symbol;
         pc_barrier();                                   // table and the first line are in LDS
-        if constexpr (JUMP)
+        const uint32_t jpos = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4), jstate = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8);
+        if constexpr (JUMP && WIDE)
+            ans_encode_pc_n16w_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t, jp.pos,
+                                             jp.state, jp.tiles, jpos, jstate);
+        else if constexpr (JUMP)
             ans_encode_pc_n16_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t, jp.pos,
-                                            jp.state, jp.tiles, (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4),
-                                            (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8));
+                                            jp.state, jp.tiles, jpos, jstate);
+        else if constexpr (WIDE)
+            ans_encode_pc_n16w_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t);
         else
             ans_encode_pc_n16_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t);
         hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
@@ -421,13 +468,13 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const Ans
         pc_barrier();
         return;
     }
-    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
+    pc_storer<WIDE>(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcN8HandOff);
 }
 
 // Rows that are whole 128-byte aligned lines of 64 int16 symbols, a table of at most 1024 entries, slabs as for the int32 kernel.
 bool pc_n16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
-    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
     if (a.n_streams == 0) return false;
     if (a.n_per_stream % 64 != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 23)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
@@ -439,13 +486,14 @@ bool pc_n16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layo
 
 cst_status ans_encode_pc_n16(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    const bool wide = a.precision > 12;
     if (interval) {
-        auto kernel = ans_encode_pc_n16_kernel<true>;
+        auto kernel = wide ? ans_encode_pc_n16_kernel<true, true> : ans_encode_pc_n16_kernel<true>;
         CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a,
                            PcJumpArgs{d_ckpt_pos, d_ckpt_state, (uint32_t)(interval / kTileSyms), (uint32_t)(a.n_per_stream / interval)});
     } else {
-        auto kernel = ans_encode_pc_n16_kernel<false>;
+        auto kernel = wide ? ans_encode_pc_n16_kernel<false, true> : ans_encode_pc_n16_kernel<false>;
         CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});
     }
@@ -458,7 +506,7 @@ bool pc_n16_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst
 // Rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel; any number of streams.
 bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
     if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
-    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
     if (a.n_streams == 0) return false;                  // (partial workgroups are taken: their spare lanes repeat the last stream)
     if (a.n_per_stream % kPcN8LineSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
@@ -484,7 +532,7 @@ static PcJumpArgs pc_jump_args(const AnsEncodeArgs& a, size_t interval, uint32_t
 
 cst_status ans_encode_pc_n8(const AnsEncodeArgs& a, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    auto kernel = ans_encode_pc_n8_kernel<false>;
+    auto kernel = a.precision > 12 ? ans_encode_pc_n8_kernel<false, true> : ans_encode_pc_n8_kernel<false>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});
     CST_HIP_TRY(hipGetLastError());
@@ -497,7 +545,7 @@ bool pc_n8_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_
 
 cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    auto kernel = ans_encode_pc_n8_kernel<true>;
+    auto kernel = a.precision > 12 ? ans_encode_pc_n8_kernel<true, true> : ans_encode_pc_n8_kernel<true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcN8LdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcN8LdsBytes, hs, a, pc_jump_args(a, interval, d_ckpt_pos, d_ckpt_state));
     CST_HIP_TRY(hipGetLastError());

@@ -492,11 +492,11 @@ bool ans_encode_n8_try(const cst_model* model, cst_coder_config cfg, const void*
     a.flags = flags;
     if (symbol_bytes == 2) {
         if (!pc_n16_encode_usable(a, cfg, layout)) return false;
-        *rc = note_kernel("ans_encode_pc_n16_kernel", ans_encode_pc_n16(a, 0, nullptr, nullptr, (hipStream_t)stream));
+        *rc = note_kernel(a.precision > 12 ? "ans_encode_pc_n16_kernel<wide>" : "ans_encode_pc_n16_kernel", ans_encode_pc_n16(a, 0, nullptr, nullptr, (hipStream_t)stream));
         return true;
     }
     if (symbol_bytes != 1 || !pc_n8_encode_usable(a, cfg, layout)) return false;
-    *rc = note_kernel("ans_encode_pc_n8_kernel", ans_encode_pc_n8(a, (hipStream_t)stream));
+    *rc = note_kernel(a.precision > 12 ? "ans_encode_pc_n8_kernel<wide>" : "ans_encode_pc_n8_kernel", ans_encode_pc_n8(a, (hipStream_t)stream));
     return true;
 }
 

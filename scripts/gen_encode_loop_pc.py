@@ -102,6 +102,42 @@ def step(a, e0, e1, m0, m1):
     a.i(f"v_mad_u64_u32 {ST_T}, {SD}, {Q0}, %[twoP], {A_T}", "state = q_est 2^P + r_est + c'")
 
 
+# 12 < P <= 24 (round 5: the int8 / int16 coders at the reference's default precision): gen_encode_loop_wide.py's step on UNPACKED
+# entries {c, p, floor(2^64 / p)} with this generator's registers -- 24 VALU instructions + the ring write.
+WIDE = False
+PSHL = KK
+
+
+def step_wide(a, c, p, m0, m1):
+    a.i(f"v_lshlrev_b32 {PSHL}, %[sh], {p}", "p << (32 - P)")
+    a.i(f"v_cmp_ge_u32 vcc, {HI}, {PSHL}", "emit <=> (state >> (64 - P)) >= p")
+    a.i(f"v_lshlrev_b32 {RA}, 8, {WR}")
+    a.i(f"v_and_or_b32 {RA}, {RA}, %[c3f00], %[lanebase]")
+    a.i(f"v_cndmask_b32_e64 {A0}, {LO}, {HI}, vcc")
+    a.i(f"v_cndmask_b32_e64 {A1}, {HI}, 0, vcc")
+    a.ds(f"ds_write_b32 {RA}, {LO}", "W", "candidate word, always written")
+    a.i(f"v_addc_co_u32 {WR}, vcc, 0, {WR}, vcc")
+    a.i(f"v_mul_hi_u32 {W0}, {A0}, {m0}")
+    a.i(f"v_mad_u64_u32 {U_T}, vcc, {A1}, {m0}, {W_T}", "U = a1*m0 + hi32(a0*m0)   (< 2^64)")
+    a.i(f"v_mad_u64_u32 {T_T}, vcc, {A0}, {m1}, {U_T}", "T = a0*m1 + U, carry -> vcc")
+    a.i(f"v_mov_b32 {SM0}, {T1}")
+    a.i(f"v_addc_co_u32 {SM1}, vcc, 0, {W1}, vcc", "[T_hi, carry]")
+    a.i(f"v_mad_u64_u32 {Q_T}, vcc, {A1}, {m1}, {SM_T}", "q_est in {q - 1, q}")
+    a.i(f"v_mul_lo_u32 {RR}, {Q0}, {p}")
+    a.i(f"v_sub_u32 {RR}, {A0}, {RR}", "r_est (< 2p: its low 32 bits)")
+    a.i(f"v_sub_u32 {CK}, {RR}, {p}", "r_est - p   (wraps if r_est < p)")
+    a.i(f"v_cmp_ge_u32 vcc, {RR}, {p}", "fix <=> q = q_est + 1")
+    a.i(f"v_min_u32 {RR}, {RR}, {CK}", "r")
+    a.i(f"v_cndmask_b32 {CK}, 0, %[twoP], vcc", "fix 2^P")
+    a.i(f"v_lshlrev_b32 {A1}, %[P], {Q1}", "q_est_hi << P   (q < 2^(64 - P))")
+    a.i(f"v_add3_u32 {A0}, {RR}, {c}, {CK}", "r + c + fix 2^P   (< 2^26)")
+    a.i(f"v_mad_u64_u32 {ST_T}, {SD}, {Q0}, %[twoP], {A_T}", "state = q_est 2^P + r + c + fix 2^P")
+
+
+def coder_step(a, c, p, m0, m1):
+    (step_wide if WIDE else step)(a, c, p, m0, m1)
+
+
 def read_syms(a, g, buf, quad):
     a.ds(f"ds_read_b128 {S_T[g % 4]}, {ROW[buf]} offset:{16 * quad}", f"S{g}")
 
@@ -577,6 +613,8 @@ def s_flush_quads(a):
         a.i(f"v_sub_u32 {SNCH[c]}, {SWR[c]}, %[flushed{c}]")
         a.i(f"v_add_u32 {SLIM[c]}, 16, %[flushed{c}]")
         a.i(f"v_lshrrev_b32 {SNCH[c]}, 4, {SNCH[c]}", "whole 16-word groups pending: 0 or 1")
+        if STORER_GROUPS > 1:
+            a.i(f"v_min_u32 {SNCH[c]}, 1, {SNCH[c]}", "(12 < P <= 24: up to 39 words wait, ONE group leaves per pass)")
         a.i(f"v_cmp_le_u32 vcc, {SLIM[c]}, %[cap{c}]", "group inside the slab (capacity 0: a lane without a stream of its own)")
         a.i(f"v_cndmask_b32_e64 {SLIM[c]}, 0, {SNCH[c]}, vcc")
         a.i(f"v_lshl_or_b32 {SXQ[c]}, {SLIM[c]}, 31, %[flushed{c}]", "flush position | (a group leaves) << 31")
@@ -603,6 +641,9 @@ def s_flush_quads(a):
             a.i(f"s_mov_b64 exec, {SSAVE[c]}")
 
 
+STORER_GROUPS = 1        # 64-byte groups a storer moves per tile and coder wave (2: the coders at 12 < P <= 24)
+
+
 def gen_storer():
     a = Asm()
     a.i("s_mov_b32 s82, %[ntiles]", "windows left")
@@ -627,7 +668,8 @@ def gen_storer():
         a.i("s_cbranch_scc1 1b")
         a.i("2:")
     else:
-        (s_flush_quads if SQUAD else s_flush_rows)(a)
+        for _ in range(STORER_GROUPS):
+            (s_flush_quads if SQUAD else s_flush_rows)(a)
         a.wait_lds_all()
         a.i("s_barrier")
         a.i("s_sub_u32 s82, s82, 1")
@@ -650,6 +692,13 @@ def main_split():
     print(f"wrote {OUT_LOADER} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:
         print("  note:", n)
+    global STORER_GROUPS
+    for STORER_GROUPS, out_storer in ((1, OUT_STORER), (2, OUT_STORER2)):
+        emit_storer(out_storer)
+    STORER_GROUPS = 1
+
+
+def emit_storer(out_storer):
     a, notes = gen_storer()
     header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
               "// Storer wave of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_storer_loop in cst_ans_pc.hip."]
@@ -657,8 +706,8 @@ def main_split():
            '    : [lanebase0] "v"(ring_lane_addr[0]), [lanebase1] "v"(ring_lane_addr[1]), [pub0] "v"(publish_addr[0]), [pub1] "v"(publish_addr[1]),',
            '      [cap0] "v"(cap[0]), [cap1] "v"(cap[1]), [slaboff0] "v"(slab_off[0]), [slaboff1] "v"(slab_off[1]), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base), [ntiles] "s"(n_tiles)',
            "    : " + ", ".join(f'"{c}"' for c in S_CLOBBERS) + ");"]
-    OUT_STORER.write_text(a.render(header, ops))
-    print(f"wrote {OUT_STORER} ({a.n_instr()} instructions incl. prologue)")
+    out_storer.write_text(a.render(header, ops))
+    print(f"wrote {out_storer} ({a.n_instr()} instructions incl. prologue)")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -727,7 +776,7 @@ def n8_half(a, cur, nxt, g0, delta, site=0):
             a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
         n8_fold_minmax(a, g)
         for c, p, m0, m1 in E[g % 2]:
-            step(a, c, p, m0, m1)
+            coder_step(a, c, p, m0, m1)
     a.i(f"v_add_u32 {cur}, {delta}, {nxt}", "leapfrog: the tile after the next")
     ck_hook(a, site)
 
@@ -853,13 +902,21 @@ def gen_loader_n8():
 
 
 OUT_N8_CK = CSRC / "cst_encode_loop_pc_n8_ck.inc"
+OUT_N8W = CSRC / "cst_encode_loop_pc_n8w.inc"             # the same coders at 12 < P <= 24 (step_wide)
+OUT_N8W_CK = CSRC / "cst_encode_loop_pc_n8w_ck.inc"
+OUT_N16W = CSRC / "cst_encode_loop_pc_n16w.inc"
+OUT_N16W_CK = CSRC / "cst_encode_loop_pc_n16w_ck.inc"
+OUT_STORER2 = CSRC / "cst_encode_loop_pc_storer2.inc"     # ... and their storer: two 64-byte groups per tile (32 symbols can emit 24 words)
 
 
 def main_n8():
-    global JUMP
+    global JUMP, WIDE
     for JUMP, out in ((False, OUT_N8), (True, OUT_N8_CK)):
         emit_n8_coder(out)
-    JUMP = False
+    WIDE = True                                             # 12 < P <= 24
+    for JUMP, out in ((False, OUT_N8W), (True, OUT_N8W_CK)):
+        emit_n8_coder(out)
+    JUMP = WIDE = False
     emit_n8_loader()
 
 
@@ -869,7 +926,7 @@ def emit_n8_coder(out):
               "// Coder half of the producer / consumer (32,64) ANS encoder for int8 symbol matrices: see ans_encode_pc_n8_coder_loop in cst_ans_pc.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(line_row_addr), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [four] "v"(4u),',
-           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + (', [sh] "s"(32u - P)' if WIDE else '') + ck_operands(),
            "    : " + ", ".join(f'"{c}"' for c in N8_CLOBBERS + ck_clobbers()) + ");"]
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
@@ -943,7 +1000,7 @@ def n16_half(a, cur, nxt, g0, delta, site=0):
             a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
         n16_fold_minmax(a, g)
         for c, p, m0, m1 in E[g % 2]:
-            step(a, c, p, m0, m1)
+            coder_step(a, c, p, m0, m1)
     a.i(f"v_add_u32 {cur}, {delta}, {nxt}", "leapfrog: the tile after the next")
     ck_hook(a, site)
 
@@ -1038,18 +1095,18 @@ def gen_loader_n16():
 
 
 def main_n16():
-    global JUMP
-    for JUMP, out in ((False, OUT_N16), (True, OUT_N16_CK)):
+    global JUMP, WIDE
+    for WIDE, JUMP, out in ((False, False, OUT_N16), (False, True, OUT_N16_CK), (True, False, OUT_N16W), (True, True, OUT_N16W_CK)):
         a, notes = gen_n16()
         header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
                   "// Coder half of the producer / consumer (32,64) ANS encoder for int16 symbol matrices: see ans_encode_pc_n16_coder_loop in cst_ans_pc.hip."]
         ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
                '    : [row0] "v"(line_row_addr), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
-               '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+               '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + (', [sh] "s"(32u - P)' if WIDE else '') + ck_operands(),
                "    : " + ", ".join(f'"{c}"' for c in N16_CLOBBERS + [PA16, PB16] + ck_clobbers()) + ");"]
         out.write_text(a.render(header, ops))
         print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
-    JUMP = False
+    JUMP = WIDE = False
     a, notes = gen_loader_n16()
     header = ["// GENERATED by scripts/gen_encode_loop_pc.py -- do not edit by hand (edit the generator and re-run it).",
               "// Loader wave of the producer / consumer (32,64) ANS encoder for int16 symbol matrices: see ans_encode_pc_n16_loader_loop in cst_ans_pc.hip."]

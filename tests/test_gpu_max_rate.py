@@ -348,7 +348,7 @@ def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
 @pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
 @pytest.mark.parametrize("P", [24, 16])
 @pytest.mark.parametrize("dtype", ["int8", "int16"])
-def test_narrow_high_precision_decoders_at_the_maximum_rate(B, O, dtype, P, frac):
+def test_narrow_high_precision_kernels_at_the_maximum_rate(B, O, dtype, P, frac):
     """ans_decode_b16_narrow_kernel at 24 words per 32-symbol tile (P = 24: every symbol of probability 2^-24), slabs and packed words;
     the tails also take the statement's out-of-line walk over the cdf table on nearly every step"""
     n = 101
@@ -359,6 +359,12 @@ def test_narrow_high_precision_decoders_at_the_maximum_rate(B, O, dtype, P, frac
     dt = torch.int8 if dtype == "int8" else torch.int16
     d = dev(sym).to(dt)
     enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    narrow = B.ans_encode(d, model, (32, 64, P))            # ... and the narrow encoder (its storer moves two word groups per tile)
+    assert ALT or B.last_kernel() == "ans_encode_pc_n%d_kernel<wide>" % (8 * d.element_size())
+    assert torch.equal(narrow.n_words, enc.n_words) and int(narrow.status.abs().sum()) == 0
+    wa, na, _ = enc.to_numpy()
+    wb, _, _ = narrow.to_numpy()
+    assert all(np.array_equal(wa[s, : na[s]], wb[s, : na[s]]) for s in range(wa.shape[0]))
     dec, st = B.ans_decode(enc, model, 2048, dtype=dt)
     assert ALT or B.last_kernel() == ("ans_decode_b16_n8_kernel" if dtype == "int8" else "ans_decode_b16_n16_kernel")
     assert int(st.abs().sum()) == 0 and torch.equal(dec, d)

@@ -208,13 +208,20 @@ def test_int8_shapes_the_native_kernels_do_not_take(B, O):
         assert torch.equal(dec, d)
 
 
-def test_int8_native_encoder_capacity_and_raw_state(B, O):
+def _pc_name(bytes_, P, jump=False):
+    """the encoder kernel's name as cst_last_kernel reports it (12 < P <= 24: the wide step, two word groups per tile)"""
+    tags = (["wide"] if P > 12 else []) + (["ckpt"] if jump else [])
+    return "ans_encode_pc_n%d_kernel" % (8 * bytes_) + ("<%s>" % ", ".join(tags) if tags else "")
+
+
+@pytest.mark.parametrize("P", [12, 16, 24])
+def test_int8_native_encoder_capacity_and_raw_state(B, O, P):
     """the int8 encoder on slabs that are too small (CST_STREAM_CAPACITY, nothing written behind the slabs) and continuing from a given
     state (CST_FLAG_RAW_STATE: AnsCoder::encode_symbols_reverse on a non-empty coder, stack.rs:784-849): the two halves of every row
     coded by two calls are the row coded by one"""
     import ctypes as C
     from constriction_amd import _native as N
-    P, n_streams, n_per, lo = 12, 512, 512, -50
+    n_streams, n_per, lo = 512, 512, -50
     cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
     sym = O.synth_symbols(78, 0, n_streams, n_per, lo, cdf, P)
@@ -227,7 +234,7 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O):
     status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
                                          C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "capacity")
-    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     assert (want_n > stride).all() and (status.cpu().numpy() == 2).all() and (n_words.cpu().numpy() == 0).all()
     assert (guard[n_streams * stride:].cpu().numpy() == 0x5A5A5A5A).all(), "words were written behind the last slab"
@@ -243,7 +250,7 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O):
     for part, w, n in ((second, wa, na), (first, wb, nb)):
         N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(part.data_ptr()), 1, n_streams, half, 0, C.c_void_p(w.data_ptr()), full,
                                              C.c_void_p(n.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(status.data_ptr()), 1, None, None), "raw")
-        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+        assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     a, b = wa.cpu().numpy().view(np.uint32), wb.cpu().numpy().view(np.uint32)
     ka, kb, state = na.cpu().numpy(), nb.cpu().numpy(), st.cpu().numpy().view(np.uint64)
@@ -255,14 +262,15 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O):
 
 @pytest.mark.parametrize("n_streams", [1, 70, 257, 330, 582])
 @pytest.mark.parametrize("jump", [0, 2])
-def test_int8_native_encoder_takes_partial_workgroups(B, O, n_streams, jump):
+@pytest.mark.parametrize("P", [12, 24])
+def test_int8_native_encoder_takes_partial_workgroups(B, O, n_streams, jump, P):
     """any number of streams: the coder lanes behind the last stream code the last stream again and store nothing (their slabs have
     capacity 0; nothing is written behind the last slab); the jump points they note are the last stream's own.  (A split into a
     native head and a converted tail was measured first and dropped: two launches run one after the other, and a launch lasts as
     long as its longest STREAM -- 65 636 x 4096 int8: 0.63 ms split against 0.54 converted.)"""
     import ctypes as C
     from constriction_amd import _native as N
-    P, n_per, lo = 12, 256, -50
+    n_per, lo = 256, -50
     cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
     sym = O.synth_symbols(4000 + n_streams, 0, n_streams, n_per, lo, cdf, P)
@@ -281,11 +289,11 @@ def test_int8_native_encoder_takes_partial_workgroups(B, O, n_streams, jump):
         N.check(lib.cst_ans_encode_batch_ckpt_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
                                                   C.c_void_p(n_words.data_ptr()), n_per // jump, C.c_void_p(pos.data_ptr()), C.c_void_p(state.data_ptr()),
                                                   C.c_void_p(status.data_ptr()), None, None), "ckpt_sym")
-        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel<ckpt>"
+        assert ALT or B.last_kernel() == _pc_name(1, P, True)
     else:
         N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
                                              C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "sym")
-        assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+        assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     st, nw = status.cpu().numpy(), n_words.cpu().numpy()
     assert st[:n_streams].tolist() == want_st.tolist() and (st[n_streams:] == -7).all() and (nw[n_streams:] == 0).all()
@@ -356,7 +364,7 @@ def test_int16_native_decoders_decode_like_the_oracle(B, O, P, support, n_stream
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
 
 
-@pytest.mark.parametrize("P", [10, 12])
+@pytest.mark.parametrize("P", [10, 12, 16, 24])
 @pytest.mark.parametrize("support", [(-300, 300), (-100, 100), (1000, 1200), (-32768, -32700), (32000, 32767), (-2000, -1000)], ids=lambda s: "%d..%d" % s)
 @pytest.mark.parametrize("n_streams,n_per,jump", [(1, 64, 0), (70, 128, 2), (256, 192, 3), (300, 4096, 4), (768, 1152, 0), (512, 64, 1)])
 def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams, n_per, jump):
@@ -380,10 +388,10 @@ def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams,
     assert d.data_ptr() % 128 == 0
     if jump:
         enc, ck = B.ans_encode_checkpointed(d, model, n_per // jump, (32, 64, P))
-        assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel<ckpt>"
+        assert ALT or B.last_kernel() == _pc_name(2, P, True)
     else:
         enc = B.ans_encode(d, model, (32, 64, P))
-        assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel"
+        assert ALT or B.last_kernel() == _pc_name(2, P)
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert status.tolist() == want_st.tolist()
@@ -399,7 +407,7 @@ def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams,
         assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
         if jump and (n_per // jump) % 64 == 0:
             dec, st = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=torch.int16)
-            assert ALT or B.last_kernel() in ("ans_decode_n16_kernel", "ans_decode_small_n16_kernel")
+            assert ALT or P > 12 or B.last_kernel() in ("ans_decode_n16_kernel", "ans_decode_small_n16_kernel")
             assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
 
 
@@ -432,13 +440,15 @@ def test_jump_points_travel_with_the_batch(B, O, dtype):
 @pytest.mark.parametrize("dtype", [torch.int8, torch.int16], ids=["int8", "int16"])
 @pytest.mark.parametrize("P", [13, 16, 24])
 @pytest.mark.parametrize("n_streams,n_per", [(1, 128), (70, 256), (256, 384), (300, 4096), (512, 128)])
-def test_narrow_decoders_at_high_precision(B, O, dtype, P, n_streams, n_per):
+def test_narrow_kernels_at_high_precision(B, O, dtype, P, n_streams, n_per):
     lo, hi = (-100, 100) if dtype == torch.int8 else (900, 1150)
     cdf = O.GaussianModel(lo, hi, 0.5 * (lo + hi) + 7.3, 11.0, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
     sym = O.synth_symbols(7000 + P, 0, n_streams, n_per, lo, cdf, P)
     d = torch.from_numpy(sym).to(dtype).cuda()
     enc = B.ans_encode(d, model, (32, 64, P))
+    if d.data_ptr() % 128 == 0 and n_per % (128 // d.element_size()) == 0:
+        assert ALT or B.last_kernel() == _pc_name(d.element_size(), P)
     torch.cuda.synchronize()
     want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
     words, n_words, status = enc.to_numpy()
