@@ -132,7 +132,7 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cf
         e.min_symbol = model->min_symbol; e.precision = model->precision; e.words = d_words; e.stride_words = stride_words;
         e.n_words = d_n_words; e.state = nullptr; e.status = d_status; e.flags = 0;
         if (pc_encode_ckpt_usable(e, cfg, layout, ckpt_interval))
-            return note_kernel("ans_encode_pc_kernel<ckpt>", ans_encode_pc_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+            return note_kernel(e.precision > 12 ? "ans_encode_pc_kernel<wide, ckpt>" : "ans_encode_pc_kernel<ckpt>", ans_encode_pc_ckpt(e, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
     }
     CkptEncodeArgs a{};
     a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.layout = layout; a.enc = model->d_enc;

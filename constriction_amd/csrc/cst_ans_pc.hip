@@ -62,6 +62,19 @@ __device__ __forceinline__ void ans_encode_pc_coder_loop_ck(uint32_t& lo, uint32
 #include "cst_encode_loop_pc_ck.inc"
 }
 
+// ... at 12 < P <= 24 (round 5): unpacked entries {c, p, floor(2^64 / p)}, the step of cst_encode_loop_wide.inc
+__device__ __forceinline__ void ans_encode_pc_w_coder_loop(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, const uint32_t (&tile_row_addr)[2],
+                                                           uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P, uint32_t n_tiles) {
+#include "cst_encode_loop_pc_w.inc"
+}
+
+__device__ __forceinline__ void ans_encode_pc_w_coder_loop_ck(uint32_t& lo, uint32_t& hi, int32_t& smin, int32_t& smax, const uint32_t (&tile_row_addr)[2],
+                                                              uint32_t ring_lane_addr, uint32_t publish_addr, uint32_t table_bias, uint32_t P, uint32_t n_tiles,
+                                                              const uint32_t* ckpt_pos, const uint64_t* ckpt_state, uint32_t ckpt_tiles,
+                                                              uint32_t ckpt_pos_off, uint32_t ckpt_state_off) {
+#include "cst_encode_loop_pc_w_ck.inc"
+}
+
 __device__ __forceinline__ void ans_encode_pc_helper_loop(uint32_t& flushed, const uint32_t (&tile_tr_addr)[2], uint32_t ring_lane_addr,
                                                           uint32_t publish_addr, uint32_t cap, uint32_t slab_off, const void* words_base,
                                                           uint64_t symbols_base, uint32_t n_tiles, const uint32_t (&goff)[8]) {
@@ -133,6 +146,7 @@ __device__ __forceinline__ void pc_storer(const AnsEncodeArgs& a, unsigned char*
 
 // the helper waves of a workgroup split by role: waves 4, 5 load and stage the tiles of coder waves (0, 1), (2, 3); waves 6, 7
 // flush their rings and finish their streams
+template <bool TWO_GROUPS = false>
 __device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned char* smem, int wave, int lane, uint32_t n_t) {
     const size_t N = a.n_per_stream;
     const int pair = wave & 1, cw0 = 2 * pair;          // the pair's first coder wave
@@ -161,11 +175,12 @@ __device__ __forceinline__ void pc_split_helper(const AnsEncodeArgs& a, unsigned
         pc_barrier();
         return;
     }
-    pc_storer(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcHandOff);
+    pc_storer<TWO_GROUPS>(a, smem, lane, cw0, s0, n_t, kPcRingOff, kPcHandOff);
 }
 
-template <bool SPLIT, bool JUMP = false>
+template <bool SPLIT, bool JUMP = false, bool WIDE = false>
 __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEncodeArgs a, const PcJumpArgs jp) {
+    static_assert(SPLIT || !WIDE, "12 < P <= 24: the split helpers only (a storer that moves two word groups per tile)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
 
     EncEntry* table = reinterpret_cast<EncEntry*>(smem);
-    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = pack_entry(a.enc[i], P);
+    for (int i = threadIdx.x; i < a.n_symbols; i += kPcThreads) table[i] = WIDE ? a.enc[i] : pack_entry(a.enc[i], P);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + kPcRingOff + cw * kPcRingWaveBytes);
     int32_t* tile[2] = {reinterpret_cast<int32_t*>(smem + kPcTileOff + (2 * cw) * kPcTileBytes),
                         reinterpret_cast<int32_t*>(smem + kPcTileOff + (2 * cw + 1) * kPcTileBytes)};
@@ -195,13 +210,18 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
         if (raw) { const uint64_t st = a.state[s]; lo = (uint32_t)st; hi = (uint32_t)(st >> 32); }
         const uint32_t row_addr[2] = {lds_addr(tile[0] + lane * kTileStride), lds_addr(tile[1] + lane * kTileStride)};
         pc_barrier();                                   // table and the first tile are in LDS
-        if constexpr (JUMP)
-            ans_encode_pc_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane),
-                                        lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, n_t, jp.pos, jp.state, jp.tiles,
-                                        (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4), (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8));
+        const uint32_t bias = lds_addr(table) - 16u * (uint32_t)a.min_symbol;
+        const uint32_t jpos = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 4), jstate = (uint32_t)((s * jp.n_chunks + jp.n_chunks - 1) * 8);
+        if constexpr (JUMP && WIDE)
+            ans_encode_pc_w_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t, jp.pos, jp.state,
+                                          jp.tiles, jpos, jstate);
+        else if constexpr (JUMP)
+            ans_encode_pc_coder_loop_ck(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t, jp.pos, jp.state,
+                                        jp.tiles, jpos, jstate);
+        else if constexpr (WIDE)
+            ans_encode_pc_w_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t);
         else
-            ans_encode_pc_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane),
-                                     lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, n_t);
+            ans_encode_pc_coder_loop(lo, hi, smin, smax, row_addr, lds_addr(ring + lane), lds_addr(hand + lane), bias, (uint32_t)P, n_t);
         // largest raw table index seen: a symbol below min_symbol wraps to a huge one
         hand[kWave + lane] = lo; hand[2 * kWave + lane] = hi;
         hand[3 * kWave + lane] = max((uint32_t)smax - (uint32_t)a.min_symbol, (uint32_t)smin - (uint32_t)a.min_symbol);
@@ -209,7 +229,8 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
         return;
     }
 
-    if (SPLIT) { pc_split_helper(a, smem, wave, lane, n_t); return; }
+    if constexpr (SPLIT) { pc_split_helper<WIDE>(a, smem, wave, lane, n_t); return; }
+    else {
 
     // ---- helper (combined: loads, staging and flush of its own coder wave) ----
     EncLane<32, 64> L;
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_kernel(const AnsEnco
     if (raw) a.state[s] = (uint64_t)L.state;
     a.status[s] = status;
     a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -556,7 +578,9 @@ cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32
 // cst_ans_small.hip), rows that are whole 128-byte aligned tiles, 64-byte aligned slabs of whole 64-byte groups.
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
     if (getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs)
-    if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
+    if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
+    // 12 < P <= 24 (round 5: the wide step in the coder waves, two word groups per tile in the storers; ans_encode_wide_kernel before)
+    if (a.precision > 12 && (getenv("CST_NO_PC_WIDE") || getenv("CST_PC_COMBINED"))) return false;
     (void)device_cus;     // (more than one workgroup per CU: they run one after another, cst_api.hip asks the small-footprint kernels first)
     if (a.n_streams == 0) return false;
     if (a.n_streams % kBlock != 0 && getenv("CST_PC_COMBINED")) return false;                      // (partial workgroups: the split helpers only)
@@ -570,7 +594,7 @@ bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout l
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     static const bool combined = getenv("CST_PC_COMBINED") != nullptr;      // (A/B runs: every helper wave loads AND stores)
-    auto kernel = combined ? ans_encode_pc_kernel<false> : ans_encode_pc_kernel<true>;
+    auto kernel = a.precision > 12 ? ans_encode_pc_kernel<true, false, true> : combined ? ans_encode_pc_kernel<false> : ans_encode_pc_kernel<true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});
     CST_HIP_TRY(hipGetLastError());
@@ -585,7 +609,7 @@ bool pc_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_lay
 
 cst_status ans_encode_pc_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    auto kernel = ans_encode_pc_kernel<true, true>;
+    auto kernel = a.precision > 12 ? ans_encode_pc_kernel<true, true, true> : ans_encode_pc_kernel<true, true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a, pc_jump_args(a, interval, d_ckpt_pos, d_ckpt_state));
     CST_HIP_TRY(hipGetLastError());

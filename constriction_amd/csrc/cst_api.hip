@@ -303,7 +303,7 @@ cst_status cst_ans_encode_batch(const cst_model* model, cst_coder_config cfg, co
         return note_kernel("ans_encode_w16pk_kernel", ans_encode_w16pk(a, hs));
     }
     if (small_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_small_kernel", ans_encode_small(a, hs));   // more than one wave per SIMD
-    if (pc_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_encode_pc_kernel", ans_encode_pc(a, hs));           // one wave per SIMD: coder + helper waves
+    if (pc_encode_usable(a, cfg, layout, model->cu_count)) return note_kernel(a.precision > 12 ? "ans_encode_pc_kernel<wide>" : "ans_encode_pc_kernel", ans_encode_pc(a, hs));           // one wave per SIMD: coder + helper waves
     if (w16_encode_usable(a, cfg, layout)) return note_kernel("ans_encode_w16_kernel", ans_encode_w16(a, layout, hs));               // SmallAnsCoder preset
     if (wide_encode_usable(a, cfg, layout)) return note_kernel("ans_encode_wide_kernel", ans_encode_wide(a, layout, hs));            // 12 < P <= 24
     if (cfg.word_bits == 32) return note_kernel("ans_encode_kernel", encode_dispatch<32, 64>(a, layout, hs));

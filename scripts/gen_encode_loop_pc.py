@@ -232,7 +232,7 @@ def half(a, h, g0, site=0):
             a.wait_lds(f"E{g}", f"entries of quad {quad} are back", cap=True)
         fold_minmax(a, g)
         for c, p, m0, m1 in E[g % 2]:
-            step(a, c, p, m0, m1)
+            coder_step(a, c, p, m0, m1)
     ck_hook(a, site)
 
 
@@ -275,10 +275,10 @@ def gen():
 
 
 def main():
-    global JUMP
-    for JUMP, out in ((False, OUT), (True, OUT_CK)):
+    global JUMP, WIDE
+    for WIDE, JUMP, out in ((False, False, OUT), (False, True, OUT_CK), (True, False, OUT_W), (True, True, OUT_W_CK)):
         emit_coder(out)
-    JUMP = False
+    JUMP = WIDE = False
 
 
 def emit_coder(out):
@@ -287,7 +287,7 @@ def emit_coder(out):
               "// Coder half of the producer / consumer (32,64) ANS encoder: see ans_encode_pc_coder_loop in cst_ans_pc.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [smin] "+v"(smin), [smax] "+v"(smax)',
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [lanebase] "v"(ring_lane_addr), [pub] "v"(publish_addr), [tbl] "s"(table_bias),',
-           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + ck_operands(),
+           '      [twoP] "v"(1u << P), [P] "s"(P), [c3f00] "s"(0x3f00u), [ntiles] "s"(n_tiles)' + (', [sh] "s"(32u - P)' if WIDE else '') + ck_operands(),
            "    : " + ", ".join(f'"{c}"' for c in CLOBBERS + ck_clobbers()) + ");"]
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
@@ -902,6 +902,8 @@ def gen_loader_n8():
 
 
 OUT_N8_CK = CSRC / "cst_encode_loop_pc_n8_ck.inc"
+OUT_W = CSRC / "cst_encode_loop_pc_w.inc"                 # the int32 coders at 12 < P <= 24
+OUT_W_CK = CSRC / "cst_encode_loop_pc_w_ck.inc"
 OUT_N8W = CSRC / "cst_encode_loop_pc_n8w.inc"             # the same coders at 12 < P <= 24 (step_wide)
 OUT_N8W_CK = CSRC / "cst_encode_loop_pc_n8w_ck.inc"
 OUT_N16W = CSRC / "cst_encode_loop_pc_n16w.inc"

@@ -104,6 +104,10 @@ def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
     text = _regenerate(_load("gen_decode_loop_b16"), tmp_path, "cst_decode_loop_b16.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16.inc").read_text()
     assert (tmp_path / "sm_cst_decode_loop_b16.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_decode_loop_b16_sm.inc").read_text()
+    for mode, name in (("1", "cst_decode_loop_b16_n8.inc"), ("2", "cst_decode_loop_b16_n16.inc")):      # round 5: int8 / int16 matrices
+        monkeypatch.setenv("GEN_B16_NARROW", mode)
+        assert _regenerate(_load("gen_decode_loop_b16"), tmp_path, name) == (ROOT / "constriction_amd" / "csrc" / name).read_text()
+    monkeypatch.delenv("GEN_B16_NARROW")
     text = _regenerate(_load("gen_encode_loop_wide"), tmp_path, "cst_encode_loop_wide.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide.inc").read_text()
     assert (tmp_path / "sm_cst_encode_loop_wide.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide_sm.inc").read_text()
@@ -145,8 +149,10 @@ def test_producer_consumer_loops_are_in_sync(tmp_path, monkeypatch):
     mod.OUT_N8, mod.OUT_LOADER_N8 = tmp_path / "n8.inc", tmp_path / "loader_n8.inc"      # round 5: the int8 forms of coder and loader
     mod.OUT_CK, mod.OUT_N8_CK = tmp_path / "ck.inc", tmp_path / "n8_ck.inc"              # ... and the coders that note jump points
     mod.OUT_N16, mod.OUT_N16_CK, mod.OUT_LOADER_N16 = tmp_path / "n16.inc", tmp_path / "n16_ck.inc", tmp_path / "loader_n16.inc"      # int16
+    mod.OUT_N8W, mod.OUT_N8W_CK, mod.OUT_N16W, mod.OUT_N16W_CK = (tmp_path / f"{n}.inc" for n in ("n8w", "n8w_ck", "n16w", "n16w_ck"))    # 12 < P <= 24
+    mod.OUT_STORER2 = tmp_path / "storer2.inc"
     mod.main_all()
-    for name in ("loader", "storer", "n8", "loader_n8", "ck", "n8_ck", "n16", "n16_ck", "loader_n16"):
+    for name in ("loader", "storer", "storer2", "n8", "loader_n8", "ck", "n8_ck", "n16", "n16_ck", "loader_n16", "n8w", "n8w_ck", "n16w", "n16w_ck"):
         assert (tmp_path / f"{name}.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / f"cst_encode_loop_pc_{name}.inc").read_text()
     assert (tmp_path / "coder.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc.inc").read_text()
     assert (tmp_path / "helper.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_pc_helper.inc").read_text()

@@ -9,6 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
+ALT = any(os.environ.get(k) for k in ("CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED", "CST_NO_PC_WIDE"))    # (A/B runs: scripts/alt_paths.sh)
 
 
 @pytest.fixture(scope="module")
@@ -44,8 +45,8 @@ def _aligned_symbols(sym):
     return d
 
 
-@pytest.mark.parametrize("P", [8, 11, 12])
-@pytest.mark.parametrize("n_streams,n_per", [(256, 64), (256, 96), (512, 160), (1024, 992), (768, 4096)])
+@pytest.mark.parametrize("P", [8, 11, 12, 13, 16, 24])          # (12 < P <= 24, round 5: the wide step in the coder waves, two word groups per tile)
+@pytest.mark.parametrize("n_streams,n_per", [(256, 64), (256, 96), (512, 160), (1024, 992), (768, 4096), (300, 128)])
 def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per):
     lo, hi = -60, 60
     cdf = O.GaussianModel(lo, hi, 2.5, 7.0 if P > 8 else 9.0, P, 32).cdf_table()
@@ -57,6 +58,7 @@ def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per):
     sym[255, n_per // 2] = -2 ** 31
     want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdf, P)
     enc = B.ans_encode(_aligned_symbols(sym), model, (32, 64, P))
+    assert ALT or B.last_kernel() == ("ans_encode_pc_kernel<wide>" if P > 12 else "ans_encode_pc_kernel")
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert status.tolist() == want_status.tolist() and sorted(np.flatnonzero(status).tolist()) == [3, 70, 200, 255]
@@ -78,10 +80,11 @@ def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per):
     assert (dstatus.cpu().numpy()[good] == 0).all() and np.array_equal(dec.cpu().numpy()[good], sym[good])
 
 
-def test_pc_encoder_capacity_and_raw_state(B, O):
+@pytest.mark.parametrize("P", [12, 24])
+def test_pc_encoder_capacity_and_raw_state(B, O, P):
     """slabs that are too small (CST_STREAM_CAPACITY, nothing written behind the slab) and coders that continue from a given
     state (CST_FLAG_RAW_STATE: AnsCoder::encode_symbols_reverse on a non-empty coder, stack.rs:784-849)"""
-    P, n_streams, n_per, lo = 12, 512, 256, -50
+    n_streams, n_per, lo = 512, 256, -50
     cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
     sym = O.synth_symbols(77, 0, n_streams, n_per, lo, cdf, P)
