@@ -364,7 +364,7 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
     return entry
 
 
-def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
+def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, name="C2"):
     """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8).
     int8 / int16 (round 5): the hand-scheduled loops read / write the narrow matrix themselves (ans_encode_pc_n8_kernel / ans_decode_n8_kernel
     and their n16 forms: cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 or 2 B per symbol + 4 B per word each way, and that is the traffic; the
@@ -373,7 +373,7 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
     coder kernels (what int16 matrices and the shapes the native kernels do not take still use)."""
     import os
     n_streams, n_per = symbols.shape
-    cfg = (W, S, P)
+    cfg = cfg or (W, S, P)
     narrow = symbols.to(dtype)
     nb = narrow.element_size()
     enc = B.ans_encode(narrow, model, cfg)
@@ -385,8 +385,8 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8):
     dec_ms = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
     total_words = enc.total_words()
     byts = nb * n_streams * n_per + 4 * total_words
-    native = enc_kernel.endswith("n8_kernel") or enc_kernel.endswith("n16_kernel")
-    entry = {"workload": f"C2 with {str(dtype).replace('torch.', '')} symbol matrices " +
+    native = "n8_kernel" in enc_kernel or "n16_kernel" in enc_kernel
+    entry = {"workload": f"{name} with {str(dtype).replace('torch.', '')} symbol matrices " +
                          ("(read / written by the coder loops themselves)" if native else "(widened / narrowed on the device next to the coder call)"),
              "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
              "encode_kernel": enc_kernel, "decode_kernel": dec_kernel,
@@ -714,6 +714,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
         m24, cdf24 = gaussian(24)
         sym24 = synth_symbols_device(SEED, rank * N_STREAMS, N_STREAMS, N_PER, LO, torch.from_numpy(cdf24.astype(np.int64)).cuda(), 24)
         add("C2 at P = 24 (DefaultAnsCoder preset)", "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        try:
+            out.append(narrow_config(B, m24, sym24, reps, check, dtype=torch.int8, cfg=(32, 64, 24), name="C2 at P = 24 (DefaultAnsCoder preset)"))
+        except Exception as exc:      # noqa: BLE001
+            out.append({"workload": "C2 at P = 24 with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         add("C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         add("C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         jump("C2 decode with k jump points per stream (small-footprint decoder on 65 536 k virtual streams; the producer / consumer encoder "
