@@ -2,7 +2,7 @@
 """Randomised parity stress of the kernels that read / write INT8 symbol matrices themselves (round 5: ans_encode_pc_n8_kernel with and
 without jump points, ans_decode_n8_kernel, ans_decode_small_n8_kernel) against the CPU oracle (not part of the test suite: minutes of
 GPU time).  Only shapes those kernels take: any number of streams, rows of whole 128-byte lines (int8 and, since later in the round, int16), (32,64),
-8 <= P <= 12, supports inside the type; random tables (model-distributed, uniform and all-tail data: up to P bits per symbol), slab strides (some too
+8 <= P <= 24 (12 < P: the wide coders and bucket-entry decoders, int32 matrices too), supports inside the type; random tables (model-distributed, uniform and all-tail data: up to P bits per symbol), slab strides (some too
 small: CST_STREAM_CAPACITY), impossible symbols, jump points of every interval that divides the rows, and batches of more than 256
 streams per CU (the two-waves-per-SIMD decoder).
 usage: python tests/stress/stress_n8.py [seconds] [seed]"""
@@ -20,14 +20,22 @@ n_cases = n_streams_total = n_jump = n_small = 0
 lib = N.lib()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 while time.time() < t_end:
-    P = int(rng.integers(8, 13))
-    nb = int(rng.choice([1, 1, 2]))                     # int8 or int16 matrices
+    P = int(rng.integers(8, 13)) if rng.random() < 0.5 else int(rng.integers(13, 25))      # 12 < P <= 24: the wide step, bucket-entry decoders
+    nb = int(rng.choice([1, 1, 2] + ([4] if P > 12 else [])))      # int8 or int16 matrices (12 < P: also the int32 form of the same coder waves)
     n = int(rng.choice([2, 3, 17, 101, 128, 255, 256] if nb == 1 else [2, 17, 101, 256, 300, 601, 1024]))
     n = min(n, (1 << P) // 2)
     lo = int(rng.integers(-128, 128 - n + 1)) if nb == 1 else int(rng.choice([-32768, 32768 - n, -n // 2, int(rng.integers(-32768, 32768 - n + 1))]))
-    tmin, tmax, np_t, t_t, line = (-128, 127, np.int8, torch.int8, 128) if nb == 1 else (-32768, 32767, np.int16, torch.int16, 64)
-    names = {"enc": "ans_encode_pc_n8_kernel" if nb == 1 else "ans_encode_pc_n16_kernel", "dec": "ans_decode_n8_kernel" if nb == 1 else "ans_decode_n16_kernel",
-             "small": "ans_decode_small_n8_kernel" if nb == 1 else "ans_decode_small_n16_kernel"}
+    if nb == 4 and rng.random() < 0.5:
+        lo = int(rng.choice([-2 ** 31, 2 ** 31 - n, 10 ** 6]))
+    tmin, tmax, np_t, t_t, line = {1: (-128, 127, np.int8, torch.int8, 128), 2: (-32768, 32767, np.int16, torch.int16, 64),
+                                   4: (-2 ** 31, 2 ** 31 - 1, np.int32, torch.int32, 32)}[nb]
+    bits = {1: "_n8", 2: "_n16", 4: ""}[nb]
+    if P <= 12:
+        names = {"enc": f"ans_encode_pc{bits}_kernel", "ck": f"ans_encode_pc{bits}_kernel<ckpt>", "dec": f"ans_decode{bits}_kernel",
+                 "small": f"ans_decode_small{bits}_kernel"}
+    else:
+        names = {"enc": f"ans_encode_pc{bits}_kernel<wide>", "ck": f"ans_encode_pc{bits}_kernel<wide, ckpt>", "dec": f"ans_decode_b16{bits}_kernel",
+                 "small": f"ans_decode_b16{bits}_kernel"}
     w = rng.gamma(0.3, 1.0, n) + 1e-9
     p = np.maximum(1, np.floor(w / w.sum() * ((1 << P) - n)).astype(np.int64))
     p[int(np.argmax(p))] += (1 << P) - int(p.sum())
@@ -36,6 +44,8 @@ while time.time() < t_end:
     big = rng.random() < 0.15                           # more than 256 streams per CU: the small-footprint decoder
     n_streams = cus * 256 + 256 * int(rng.integers(1, 4)) if big else 256 * int(rng.choice([1, 2, 3, 8]))
     n_per = line * int(rng.choice([1, 2]) if big else rng.choice([1, 2, 3, 4, 5, 8, 32]))
+    if nb == 4:
+        n_per = 32 * int(rng.choice([2, 4]) if big else rng.choice([2, 3, 4, 5, 8, 16, 64]))     # (the int32 coder's read-ahead wants two tiles)
     if rng.random() < 0.3 and not big:
         n_streams = int(rng.integers(1, 700))           # partial workgroups / waves
     kind = rng.random()
@@ -76,7 +86,7 @@ while time.time() < t_end:
                                                   C.c_void_p(guard.data_ptr()), stride, C.c_void_p(n_words.data_ptr()), interval,
                                                   C.c_void_p(pos.data_ptr()), C.c_void_p(state.data_ptr()), C.c_void_p(status.data_ptr()), None,
                                                   None), "cst_ans_encode_batch_ckpt_sym")
-        assert B.last_kernel() == names["enc"] + "<ckpt>", (tag, B.last_kernel())
+        assert B.last_kernel() == names["ck"], (tag, B.last_kernel())
     else:
         N.check(lib.cst_ans_encode_batch_sym(model._h, N.CoderConfig(32, 64, P), C.c_void_p(d.data_ptr()), nb, n_streams, n_per, 0,
                                              C.c_void_p(guard.data_ptr()), stride, C.c_void_p(n_words.data_ptr()), None,
@@ -102,13 +112,14 @@ while time.time() < t_end:
         enc = B.EncodedBatch(guard[: n_streams * stride].view(n_streams, stride), n_words, status, (32, 64, P))
         out = torch.full((n_streams, n_per), 99, dtype=t_t, device="cuda")
         dec, dst = B.ans_decode(enc, model, n_per, out=out, cold=bool(rng.random() < 0.5))
-        assert B.last_kernel() == (names["small"] if big and n <= 256 else names["dec"]), (tag, B.last_kernel())
+        bucket_entries = n <= 256 or (n <= 1024 and P <= 22)     # (cst_common.hpp bucket16_usable: what the 12 < P decoders' entries can hold)
+        assert B.last_kernel() == (names["small"] if big and n <= 256 else names["dec"]) or nb == 4 or (P > 12 and not bucket_entries), (tag, B.last_kernel())
         assert int(dst.abs().sum().item()) == 0 and torch.equal(dec, d), tag
         n_small += int(big)
         if k and interval % line == 0:
             out.fill_(98)
             dec, dst = B.ans_decode_checkpointed(enc, B.Checkpoints(interval, pos, state), model, n_per, out=out)
-            assert B.last_kernel() in (names["dec"], names["small"]), (tag, B.last_kernel())
+            assert P > 12 or B.last_kernel() in (names["dec"], names["small"]), (tag, B.last_kernel())
             assert int(dst.abs().sum().item()) == 0 and torch.equal(dec, d), tag
             n_jump += 1
     n_cases += 1
