@@ -314,12 +314,13 @@ extern "C" {
     /// those of the int32 calls on the widened values; an encoder symbol outside the model's support is an impossible symbol as ever,
     /// a decoder whose model's support does not fit the type returns CST_ERR_INVALID_ARGUMENT.  The two conversions are exported on
     /// their own for the other coders (range, per-symbol, checkpointed calls take int32).
-    /// NARROW MATRICES INSIDE THE LOOPS (round 5): symbol_bytes = 1 or 2 with the default preset (32,64), 8 <= P <= 12, a shared table,
+    /// NARROW MATRICES INSIDE THE LOOPS (round 5): symbol_bytes = 1 or 2 with the default preset (32,64), 8 <= P <= 24, a shared table,
     /// stream-major rows that are whole 128-BYTE lines (128 int8 / 64 int16 symbols) of a 128-byte aligned matrix, any number of streams
     /// (encode: 64-byte aligned slabs with stride_words % 16 == 0, at most 256 (int8) / 1024 (int16) symbols; decode: a known span of
     /// the words) are coded by kernels that read / write the narrow matrix themselves -- no conversion, d_scratch is not touched and
     /// may be NULL; the same words, counts, status (cst_last_kernel_name: "ans_encode_pc_n8_kernel" / "ans_decode_n8_kernel" /
-    /// "ans_decode_small_n8_kernel" and their n16 forms).  Every other shape takes the conversion.
+    /// "ans_decode_small_n8_kernel" and their n16 forms; 12 < P <= 24: "ans_encode_pc_n8_kernel<wide>" / "ans_decode_b16_n8_kernel").
+    /// Every other shape takes the conversion.
     pub fn cst_symbols_widen(
         d_in: *const c_void,
         symbol_bytes: i32,
