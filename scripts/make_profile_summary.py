@@ -73,7 +73,7 @@ traffic = {}
 lines = [f"# {tag}: rocprofv3 summary of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (headline C2 + the `configs` block, 1 MI355X)", "",
          "Kernels by configuration: `ans_encode_pc_kernel` (coder + helper waves) and `ans_decode_kernel<32, 64, 0, true, ...8, true>` = C2 headline",
          "(`ans_encode_kernel<32, 64, 0, true, 8, ...>` = the one-wave encoder: batches the producer / consumer kernel does not take, here the tuner's odd strides); `ans_*_w16_kernel` = 16-bit words;",
-         "`ans_encode_kernel<32, 64, 0, true, 4, ...>` / `ans_decode_b16_kernel` = P = 24; `range_*_fast_kernel<...>` = C4 (`<1>`/`<false>`: P = 12, `<2>`/`<true>`: P = 24);",
+         "`ans_encode_pc_kernel<true, false, true>` (the wide step) / `ans_decode_b16_kernel` = P = 24; `range_*_fast_kernel<...>` = C4 (`<1>`/`<false>`: P = 12, `<2>`/`<true>`: P = 24);",
          "`ans_*_pt_kernel` = C3 (per-stream tables); `ans_*_small_kernel` = C5 shard (131072 streams); `compact_kernel` = packing.", "",
          f"bench line: value = {bench['value']} Msym/s, encode {bench['encode_ms']} ms, decode {bench['decode_ms']} ms, "
          f"algorithmic bytes/launch = {bench['roofline']['algorithmic_bytes_per_launch']}", "",
@@ -91,8 +91,10 @@ for r in ours:
         continue
     hbm = (2 * fk + wk) * 1024
     # the headline kernels (C2: (32,64), P = 12, stream-major, hand-scheduled) keep their short keys for bench.py's `traffic`
-    headline = ("ans_encode_pc_kernel" in k) or ("ans_decode_kernel<32, 64, 0, true, 1, true, 8, true" in k)
-    key = ("ans_encode_pc_kernel" if "ans_encode_pc_kernel" in k else "ans_decode_kernel") if headline else short
+    # (the plain instantiation only: <SPLIT = true, JUMP = false, WIDE = false>; the jump-point and 12 < P <= 24 forms keep their own rows)
+    pc_headline = "ans_encode_pc_kernel<true, false, false>" in k or "ans_encode_pc_kernel<true, false>" in k
+    headline = pc_headline or ("ans_decode_kernel<32, 64, 0, true, 1, true, 8, true" in k)
+    key = ("ans_encode_pc_kernel" if pc_headline else "ans_decode_kernel") if headline else short
     traffic[key] = {"hbm_bytes_per_launch": int(hbm), "fetch_kib_raw": fk, "write_kib": wk,
                     "l2_hit_rate": None if not h else round(h / (h + m), 4)}
     alg = bench["roofline"]["algorithmic_bytes_per_launch"] if headline else ""
