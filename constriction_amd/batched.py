@@ -686,6 +686,8 @@ def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layou
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout, coder="range") if out is None else None
+    if symbols.dtype in (torch.int8, torch.int16):
+        symbols = _widened(symbols, model)                 # (the range coder's kernels take int32: cst_symbols_widen in front of them)
     symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
@@ -700,9 +702,33 @@ def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layou
     return out
 
 
+def _widened(symbols: torch.Tensor, model: Model) -> torch.Tensor:
+    """an int8 / int16 symbol matrix as int32, on the current stream (cst_symbols_widen; the reference's Symbol is generic,
+    quantize.rs:229-255 -- the ANS calls read such matrices themselves, the other coders' kernels take int32)"""
+    if model.noncontiguous:
+        raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
+    symbols = _require_cuda(symbols, symbols.dtype, "symbols")
+    wide = torch.empty(symbols.shape, dtype=torch.int32, device=symbols.device)
+    N.check(N.lib().cst_symbols_widen(_ptr(symbols), _SYMBOL_BYTES[symbols.dtype], symbols.numel(), _ptr(wide), _stream_ptr()), "cst_symbols_widen")
+    return wide
+
+
+def _narrowed(wide: torch.Tensor, model: Model, out: Optional[torch.Tensor], dtype) -> torch.Tensor:
+    """decoded int32 symbols as int8 / int16 (cst_symbols_narrow); the model's support must fit the type, as for cst_ans_decode_batch_sym"""
+    if model.noncontiguous:
+        raise ValueError("narrow symbol matrices: contiguous alphabets only")
+    info = torch.iinfo(dtype)
+    if model.min_symbol < info.min or model.min_symbol + model.n_symbols - 1 > info.max:
+        raise ValueError(f"the model's support does not fit {dtype}")
+    out = torch.empty(wide.shape, dtype=dtype, device=wide.device) if out is None else out
+    N.check(N.lib().cst_symbols_narrow(_ptr(wide), wide.numel(), _ptr(out), _SYMBOL_BYTES[dtype], _stream_ptr()), "cst_symbols_narrow")
+    return out
+
+
 def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", offsets: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None, config=None):
-    """One RangeDecoder per stream: from_compressed + decode_iid_symbols (queue.rs:847-868, 968-1033)."""
+                 out: Optional[torch.Tensor] = None, config=None, dtype=torch.int32):
+    """One RangeDecoder per stream: from_compressed + decode_iid_symbols (queue.rs:847-868, 968-1033).
+    dtype (or the dtype of `out`): int32, or int16 / int8 -- narrowed on the device behind the decoder (cst_symbols_narrow)."""
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
         stride = words.shape[1]
@@ -712,6 +738,12 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
         config = config or (32, 64, 12)
     n_streams = n_words.numel()
     dev = words.device
+    dtype = out.dtype if out is not None else dtype
+    if dtype not in _SYMBOL_BYTES:
+        raise TypeError("decoded symbols are int32, int16 or int8")
+    narrow_out = None
+    if dtype != torch.int32:
+        narrow_out, out = out, None
     if out is None:
         shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
         out = torch.empty(shape, dtype=torch.int32, device=dev)
@@ -720,6 +752,8 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
     N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                            _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
                                            _stream_ptr()), "cst_range_decode_batch")
+    if dtype != torch.int32:
+        return _narrowed(out, model, narrow_out, dtype), status
     return _to_symbols(model, out), status
 
 

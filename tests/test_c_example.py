@@ -1,5 +1,6 @@
 """The drop-in boundary is a plain C ABI: examples/c_abi_roundtrip.c (C99, no Python, no torch) compiles and links against
 include/constriction_amd.h + the in-tree library with gcc (CPU check), and on an MI355X it runs: encode, decode, compare."""
+import os
 import shutil
 import subprocess
 from pathlib import Path
@@ -7,6 +8,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS"))      # (A/B runs, scripts/alt_paths.sh: other kernels, same results)
 LIB = ROOT / "constriction_amd" / "lib"
 
 
@@ -34,7 +36,7 @@ def test_c_example_runs(tmp_path):
     res = subprocess.run([str(build(tmp_path))], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 mismatches" in res.stdout and "words against the int32 call" in res.stdout and " 0 mismatches (symbols" in res.stdout
-    assert "ans_encode_pc_n8_kernel<ckpt>" in res.stdout          # the int8 matrix was read by the encoder loops themselves
+    assert ALT or "ans_encode_pc_n8_kernel<ckpt>" in res.stdout          # the int8 matrix was read by the encoder loops themselves
 
 
 @pytest.mark.gpu
@@ -43,4 +45,5 @@ def test_python_int8_example_runs():
     import sys
     res = subprocess.run([sys.executable, str(ROOT / "examples" / "batched_int8_latents.py"), "1024", "512"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ans_encode_pc_n8_kernel" in res.stdout and "ans_decode_n8_kernel" in res.stdout and res.stdout.strip().endswith("the int32 call's")
+    assert ALT or ("ans_encode_pc_n8_kernel" in res.stdout and "ans_decode_n8_kernel" in res.stdout)
+    assert res.stdout.strip().endswith("the int32 call's")

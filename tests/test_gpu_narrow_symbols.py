@@ -208,6 +208,14 @@ def test_int8_shapes_the_native_kernels_do_not_take(B, O):
         assert torch.equal(dec, d)
 
 
+def _conv_scratch(n_streams, n_per, symbol_bytes=1, interval=0):
+    """the scratch of the conversion path (the A/B runs of scripts/alt_paths.sh switch the native kernels off: the same calls then convert)"""
+    from constriction_amd import _native as N
+    lib = N.lib()
+    nbytes = lib.cst_ckpt_sym_scratch_bytes(n_streams, n_per, interval, symbol_bytes) if interval else lib.cst_symbols_scratch_bytes(n_streams, n_per, symbol_bytes)
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device="cuda")
+
+
 def _pc_name(bytes_, P, jump=False):
     """the encoder kernel's name as cst_last_kernel reports it (12 < P <= 24: the wide step, two word groups per tile)"""
     tags = (["wide"] if P > 12 else []) + (["ckpt"] if jump else [])
@@ -233,7 +241,8 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O, P):
     n_words = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     status = torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
-                                         C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "capacity")
+                                         C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0,
+                                         C.c_void_p(_conv_scratch(n_streams, n_per).data_ptr()), None), "capacity")
     assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     assert (want_n > stride).all() and (status.cpu().numpy() == 2).all() and (n_words.cpu().numpy() == 0).all()
@@ -249,7 +258,8 @@ def test_int8_native_encoder_capacity_and_raw_state(B, O, P):
     na, nb = torch.zeros(n_streams, dtype=torch.int32, device="cuda"), torch.zeros(n_streams, dtype=torch.int32, device="cuda")
     for part, w, n in ((second, wa, na), (first, wb, nb)):
         N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(part.data_ptr()), 1, n_streams, half, 0, C.c_void_p(w.data_ptr()), full,
-                                             C.c_void_p(n.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(status.data_ptr()), 1, None, None), "raw")
+                                             C.c_void_p(n.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(status.data_ptr()), 1,
+                                             C.c_void_p(_conv_scratch(n_streams, half).data_ptr()), None), "raw")
         assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     a, b = wa.cpu().numpy().view(np.uint32), wb.cpu().numpy().view(np.uint32)
@@ -288,11 +298,13 @@ def test_int8_native_encoder_takes_partial_workgroups(B, O, n_streams, jump, P):
     if jump:
         N.check(lib.cst_ans_encode_batch_ckpt_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
                                                   C.c_void_p(n_words.data_ptr()), n_per // jump, C.c_void_p(pos.data_ptr()), C.c_void_p(state.data_ptr()),
-                                                  C.c_void_p(status.data_ptr()), None, None), "ckpt_sym")
+                                                  C.c_void_p(status.data_ptr()), C.c_void_p(_conv_scratch(n_streams, n_per, 1, n_per // jump).data_ptr()), None),
+                "ckpt_sym")
         assert ALT or B.last_kernel() == _pc_name(1, P, True)
     else:
         N.check(lib.cst_ans_encode_batch_sym(model._h, cfg, C.c_void_p(d.data_ptr()), 1, n_streams, n_per, 0, C.c_void_p(guard.data_ptr()), stride,
-                                             C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0, None, None), "sym")
+                                             C.c_void_p(n_words.data_ptr()), None, C.c_void_p(status.data_ptr()), 0,
+                                             C.c_void_p(_conv_scratch(n_streams, n_per).data_ptr()), None), "sym")
         assert ALT or B.last_kernel() == _pc_name(1, P)
     torch.cuda.synchronize()
     st, nw = status.cpu().numpy(), n_words.cpu().numpy()
@@ -465,3 +477,34 @@ def test_narrow_kernels_at_high_precision(B, O, dtype, P, n_streams, n_per):
     out.fill_(55)
     dec, st = B.ans_decode((packed, enc.n_words), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
     assert (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+# ---- the range coder takes narrow tensors through the exported conversions (its kernels code int32) ----
+
+@pytest.mark.parametrize("dtype", [torch.int8, torch.int16], ids=["int8", "int16"])
+@pytest.mark.parametrize("cfg", [(32, 64, 12), (32, 64, 24), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+@pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
+def test_range_coder_takes_narrow_tensors(B, O, dtype, cfg, layout):
+    W, S, P = cfg
+    lo, hi = (-100, 100) if dtype == torch.int8 else (-300, 300)
+    cdf = O.GaussianModel(lo, hi, 2.5, 30.0, P, W).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    n_streams, n_per = 256, 101
+    sym = O.synth_symbols(11 + P, 0, n_streams, n_per, lo, cdf, P)
+    want_words, want_n, _ = O.rc_encode_batch(sym, lo, cdf, P, W, S)
+    d = torch.from_numpy(sym if layout == "stream_major" else np.ascontiguousarray(sym.T)).to(dtype).cuda()
+    enc = B.range_encode(d, model, cfg, layout=layout)
+    torch.cuda.synchronize()
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+    dec, st = B.range_decode(enc, model, n_per, layout=layout, dtype=dtype)
+    assert dec.dtype == dtype and (st.cpu().numpy() == 0).all() and torch.equal(dec, d)
+    out = torch.empty_like(d)
+    dec, st = B.range_decode(enc, model, n_per, layout=layout, out=out)
+    assert dec.data_ptr() == out.data_ptr() and torch.equal(out, d)
+    # a support that does not fit the type is refused, as by cst_ans_decode_batch_sym
+    wide_model = B.Model.from_cdf(np.array([0, 1 << (P - 1), 1 << P], dtype=np.uint32), 40000, P)
+    with pytest.raises(ValueError):
+        B.range_decode(enc, wide_model, n_per, layout=layout, dtype=dtype)
