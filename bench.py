@@ -370,7 +370,7 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
     and their n16 forms: cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 or 2 B per symbol + 4 B per word each way, and that is the traffic; the
     kernels are bound by instruction issue, not by HBM (one wave per SIMD: DESIGN.md 4.13), so their HBM fractions are low by
     construction.  `conversion_path`: the same call with CST_NO_N8=1 -- widened / narrowed by a streaming kernel next to the int32
-    coder kernels (what int16 matrices and the shapes the native kernels do not take still use)."""
+    coder kernels (what the shapes the native kernels do not take -- symbol-major, other presets, rows that are not whole lines -- still use)."""
     import os
     n_streams, n_per = symbols.shape
     cfg = cfg or (W, S, P)
