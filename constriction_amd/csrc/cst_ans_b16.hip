@@ -444,30 +444,53 @@ cst_status ans_encode_wide(const AnsEncodeArgs& a, cst_layout layout, hipStream_
 // symbols leaves behind its last tile in a block of eight row blocks.  Whole rows of lines, any number of streams (the spare lanes of
 // a partial wave repeat the last stream), the words' span known; everything else converts next to ans_decode_b16_kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int kB16NarrowRowBytes = 132;
-constexpr size_t kB16NarrowTileBytes = (size_t)kWave * kB16NarrowRowBytes;
+// SMALL (GEN_B16_SMALL): the small-footprint form for two waves per SIMD -- workgroups of 512 threads, word rings of 16 slots with a window every
+// quarter tile, and the one tile per wave for int32 matrices too (BYTES = 4: rows of 36 words): more than 256 streams per CU (a C5-sized shard,
+// the virtual streams of a batch decoded through jump points).
+template <int BYTES, bool SMALL>
+struct B16NarrowGeo {
+    static constexpr int kThreads = SMALL ? 512 : kBlock;
+    static constexpr int kSlots = SMALL ? 16 : kDecRingSlots;
+    static constexpr int kAheadWords = SMALL ? 12 : kDecAhead;              // SMALL: two quarter tiles of at most 6 words each
+    static constexpr uint32_t kRingMask = (uint32_t)(kSlots - 1) * kWave * 4;
+    static constexpr size_t kRingBytes = (size_t)(kThreads / kWave) * kSlots * kWave * 4;
+    static constexpr int kRowBytes = BYTES == 4 ? 144 : 132;               // a 128-byte line of the matrix + padding (int32: 16-byte aligned rows)
+    static constexpr size_t kTileBytes = (size_t)kWave * kRowBytes;
+    static_assert(BYTES != 4 || SMALL, "int32 matrices at one wave per SIMD: ans_decode_b16_kernel");
+};
 
-template <int BYTES>
+template <int BYTES, bool SMALL>
 __device__ __forceinline__ void ans_decode_b16_narrow_loop(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur,
                                                            uint32_t& row_prev, uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr,
                                                            uint32_t cdf_addr, uint32_t mask, uint32_t P, uint32_t bucket_shift,
                                                            int32_t min_symbol, uint32_t ring_mask, const void* words_base, uint64_t store_base,
                                                            uint32_t n_tiles, uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
                                                            uint32_t words_off, uint32_t c_field_mask, uint32_t index_shift) {
-    if constexpr (BYTES == 1) {
+    if constexpr (SMALL && BYTES == 1) {
+#include "cst_decode_loop_b16_s8.inc"
+    } else if constexpr (SMALL && BYTES == 2) {
+#include "cst_decode_loop_b16_s16.inc"
+    } else if constexpr (SMALL) {
+#include "cst_decode_loop_b16_s32.inc"
+    } else if constexpr (BYTES == 1) {
 #include "cst_decode_loop_b16_n8.inc"
     } else {
 #include "cst_decode_loop_b16_n16.inc"
     }
 }
 
+template <int BYTES, bool SMALL>
 static size_t b16_narrow_lds_bytes(int n_symbols, int bucket_bits) {
-    return kB16RingBytes + b16_table_bytes(n_symbols, bucket_bits) + (size_t)(kBlock / kWave) * kB16NarrowTileBytes + kTileDumpBytes;
+    using G = B16NarrowGeo<BYTES, SMALL>;
+    return G::kRingBytes + ((b16_table_bytes(n_symbols, bucket_bits) + 15) & ~(size_t)15) + (size_t)(G::kThreads / kWave) * G::kTileBytes +
+           (size_t)(G::kThreads / kWave) * 4 * kWave * 4;
 }
 
-// LDS layout: [word rings, 8 KiB per wave][cdf][bucket entries][second-level tables][one byte tile per wave][dump rows]
-template <int BYTES>
-__global__ __launch_bounds__(kBlock) void ans_decode_b16_narrow_kernel(const AnsDecodeArgs a) {
+// LDS layout: [word rings][cdf][bucket entries][second-level tables][one tile per wave][dump rows]
+template <int BYTES, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 512 : kBlock) void ans_decode_b16_narrow_kernel(const AnsDecodeArgs a) {
+    using G = B16NarrowGeo<BYTES, SMALL>;
+    constexpr int kWaves = G::kThreads / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -475,25 +498,25 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_narrow_kernel(const Ans
     DecLut lut{};
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
-    const size_t lds_off = stage_decoder_tables<kDecBucket, true, true>(smem + kB16RingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
+    const size_t lds_off = stage_decoder_tables<kDecBucket, true, true>(smem + G::kRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
                                                                   a.n_symbols, lut, cdf, bucket);
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (kDecRingSlots * kWave);
-    unsigned char* tile = smem + kB16RingBytes + ((lds_off + 15) & ~(size_t)15) + wave_in_block * kB16NarrowTileBytes;
-    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + kB16RingBytes + ((lds_off + 15) & ~(size_t)15) + (size_t)(kBlock / kWave) * kB16NarrowTileBytes) +
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (G::kSlots * kWave);
+    unsigned char* tile = smem + G::kRingBytes + ((lds_off + 15) & ~(size_t)15) + wave_in_block * G::kTileBytes;
+    uint32_t* dump = reinterpret_cast<uint32_t*>(smem + G::kRingBytes + ((lds_off + 15) & ~(size_t)15) + (size_t)kWaves * G::kTileBytes) +
                      wave_in_block * (4 * kWave) + lane;
-    if ((lds_addr(ring) & (uint32_t)(kDecRingSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
+    if ((lds_addr(ring) & (uint32_t)(G::kSlots * kWave * 4 - 1)) != 0) __builtin_trap();   // the ring address is formed with v_and_or
     __syncthreads();
 
-    const size_t s0 = ((size_t)blockIdx.x * kBlock + (size_t)wave_in_block * kWave);
+    const size_t s0 = ((size_t)blockIdx.x * G::kThreads + (size_t)wave_in_block * kWave);
     if (s0 >= a.n_streams) return;
     const uint32_t last_row = (uint32_t)min((size_t)(kWave - 1), a.n_streams - 1 - s0);      // (a partial wave: the spare lanes repeat the last stream)
     const size_t s = s0 + min((uint32_t)lane, last_row);
     const size_t N = a.n_per_stream, row_bytes = N * BYTES;
     const int bucket_shift = P - a.bucket_bits;
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
-    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);      // (BYTE addresses of the narrow matrix)
+    int8_t* out = reinterpret_cast<int8_t*>(a.symbols);      // (BYTE addresses of the matrix)
 
-    DecLane<32, 64, kDecRingSlots, kDecAhead> L;
+    DecLane<32, 64, G::kSlots, G::kAheadWords> L;
     const WordSlice ws = word_slice(a.offsets, a.stride_words, a.n_words, s, a.words_capacity);
     L.init(a.words + ws.off, ws.n, ring, lane);
     if (raw) L.state = a.state[s];
@@ -504,21 +527,21 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_narrow_kernel(const Ans
     const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
     const uint32_t w_off = (uint32_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
     // the statement reads its eight store offsets from the head of the lane's row (before the first symbols land there)
-    uint32_t* my = reinterpret_cast<uint32_t*>(tile + lane * kB16NarrowRowBytes);
+    uint32_t* my = reinterpret_cast<uint32_t*>(tile + lane * G::kRowBytes);
 #pragma unroll
     for (int k = 0; k < 8; ++k) my[k] = (uint32_t)((size_t)min((uint32_t)((lane >> 3) + 8 * k), last_row) * row_bytes + 16 * (size_t)(lane & 7));
     wave_lds_fence();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
     uint32_t lo = (uint32_t)L.state, hi = (uint32_t)(L.state >> 32);
     uint32_t row_cur = lds_addr(my), row_prev = row_cur;
-    uint32_t tr_cur = lds_addr(tile) + (uint32_t)((lane >> 3) * kB16NarrowRowBytes + 16 * (lane & 7)), tr_prev = tr_cur;
+    uint32_t tr_cur = lds_addr(tile) + (uint32_t)((lane >> 3) * G::kRowBytes + 16 * (lane & 7)), tr_prev = tr_cur;
     const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(out + s0 * row_bytes);
     const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
-    ans_decode_b16_narrow_loop<BYTES>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
-                                      (1u << P) - 1u, (uint32_t)P, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), a.min_symbol, kDecRingMask,
-                                      words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms)), L.in.shift - 1u,
-                                      lds_addr(ring + lane), lds_addr(dump), w_off, (1u << lut.idx_shift) - 1u, (uint32_t)lut.idx_shift);
+    ans_decode_b16_narrow_loop<BYTES, SMALL>(lo, hi, L.in.rd, L.in.lo_issued, row_cur, row_prev, tr_cur, tr_prev, lds_addr(lut.b16), lds_addr(cdf),
+                                             (1u << P) - 1u, (uint32_t)P, (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), a.min_symbol, G::kRingMask,
+                                             words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms)), L.in.shift - 1u,
+                                             lds_addr(ring + lane), lds_addr(dump), w_off, (1u << lut.idx_shift) - 1u, (uint32_t)lut.idx_shift);
     a.status[s] = ws.bad ? (int32_t)CST_STREAM_INVALID_DATA : L.status;
     if (raw) {
         a.state[s] = ((uint64_t)hi << 32) | lo;
@@ -526,27 +549,56 @@ __global__ __launch_bounds__(kBlock) void ans_decode_b16_narrow_kernel(const Ans
     }
 }
 
-bool b16_narrow_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
-    if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
-    if (symbol_bytes != 1 && symbol_bytes != 2) return false;
+static bool b16_narrow_shape_ok(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision <= 12 || a.precision > 24) return false;
     if (!bucket16_usable(a.n_symbols, a.precision) || !a.bucket || !a.cdf || a.n_streams == 0) return false;
     if (a.n_per_stream % (size_t)(128 / symbol_bytes) != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 23)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if (a.offsets && a.words_capacity == 0) return false;                                          // the lanes' 32-bit word offsets need a known span
+    if ((a.flags & CST_FLAG_RAW_STATE) && !a.state) return false;
     const uint64_t span = a.offsets ? a.words_capacity : (uint64_t)a.n_streams * a.stride_words;
-    return span * 4 + 256 < 0x80000000ull && b16_narrow_lds_bytes(a.n_symbols, a.bucket_bits) <= 160 * 1024;
+    return span * 4 + 256 < 0x80000000ull;
+}
+
+bool b16_narrow_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
+    if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
+    if (symbol_bytes != 1 && symbol_bytes != 2) return false;
+    if (!b16_narrow_shape_ok(a, cfg, layout, symbol_bytes)) return false;
+    return (symbol_bytes == 1 ? b16_narrow_lds_bytes<1, false>(a.n_symbols, a.bucket_bits) : b16_narrow_lds_bytes<2, false>(a.n_symbols, a.bucket_bits)) <= 160 * 1024;
+}
+
+// ... on the small-footprint form: more streams than one wave per SIMD of this device (symbol_bytes = 1, 2 or 4)
+bool b16_small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes, int device_cus) {
+    const char* e = getenv("CST_SMALL_KERNELS");         // (A/B runs, as for cst_ans_small.hip: 0 / enc = never the small decoders)
+    if (e && (e[0] == '0' || e[0] == 'e')) return false;
+    if (symbol_bytes != 1 && symbol_bytes != 2 && symbol_bytes != 4) return false;
+    if (symbol_bytes != 4 && getenv("CST_NO_N8")) return false;
+    if (a.n_streams <= (size_t)device_cus * kBlock) return false;
+    if (!b16_narrow_shape_ok(a, cfg, layout, symbol_bytes)) return false;
+    const size_t lds = symbol_bytes == 1 ? b16_narrow_lds_bytes<1, true>(a.n_symbols, a.bucket_bits)
+                     : symbol_bytes == 2 ? b16_narrow_lds_bytes<2, true>(a.n_symbols, a.bucket_bits) : b16_narrow_lds_bytes<4, true>(a.n_symbols, a.bucket_bits);
+    return lds <= 160 * 1024;
+}
+
+template <int BYTES, bool SMALL>
+static cst_status launch_b16_narrow(const AnsDecodeArgs& a, hipStream_t hs) {
+    using G = B16NarrowGeo<BYTES, SMALL>;
+    const size_t lds = b16_narrow_lds_bytes<BYTES, SMALL>(a.n_symbols, a.bucket_bits);
+    const size_t blocks = (a.n_streams + G::kThreads - 1) / G::kThreads;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    auto kernel = ans_decode_b16_narrow_kernel<BYTES, SMALL>;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(G::kThreads), lds, hs, a);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 cst_status ans_decode_b16_narrow(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs) {
-    const size_t lds = b16_narrow_lds_bytes(a.n_symbols, a.bucket_bits);
-    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    auto kernel = symbol_bytes == 1 ? ans_decode_b16_narrow_kernel<1> : ans_decode_b16_narrow_kernel<2>;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
-    CST_HIP_TRY(hipGetLastError());
-    return CST_OK;
+    return symbol_bytes == 1 ? launch_b16_narrow<1, false>(a, hs) : launch_b16_narrow<2, false>(a, hs);
+}
+
+cst_status ans_decode_b16_small(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs) {
+    return symbol_bytes == 1 ? launch_b16_narrow<1, true>(a, hs) : symbol_bytes == 2 ? launch_b16_narrow<2, true>(a, hs) : launch_b16_narrow<4, true>(a, hs);
 }
 
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout) {

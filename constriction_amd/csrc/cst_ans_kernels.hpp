@@ -1394,6 +1394,8 @@ cst_status ans_encode_wide(const AnsEncodeArgs& a, cst_layout layout, hipStream_
 bool b16_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout);
 bool b16_narrow_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes);      // int8 / int16 matrices at 12 < P <= 24
 cst_status ans_decode_b16_narrow(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs);
+bool b16_small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes, int device_cus);   // ... two waves per SIMD (int32 too)
+cst_status ans_decode_b16_small(const AnsDecodeArgs& a, int symbol_bytes, hipStream_t hs);
 cst_status ans_decode_b16(const AnsDecodeArgs& a, cst_layout layout, hipStream_t hs);
 // the hand-scheduled decoder of the (16,32) preset (cst_ans_w16.hip)
 bool w16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout);

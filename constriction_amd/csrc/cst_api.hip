@@ -343,6 +343,7 @@ cst_status cst_ans_decode_batch(const cst_model* model, cst_coder_config cfg, co
         return note_kernel("ans_decode_w16pk_kernel", ans_decode_w16pk(a, hs));
     }
     if (small_decode_usable(a, cfg, layout, model->cu_count)) return note_kernel("ans_decode_small_kernel", ans_decode_small(a, hs));   // more than one wave per SIMD
+    if (b16_small_decode_usable(a, cfg, layout, 4, model->cu_count)) return note_kernel("ans_decode_b16_small_kernel", ans_decode_b16_small(a, 4, hs));   // 12 < P <= 24, two waves per SIMD
     if (b16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_b16_kernel", ans_decode_b16(a, layout, hs));               // 12 < P <= 24
     if (w16_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_w16_kernel", ans_decode_w16(a, layout, hs));               // SmallAnsCoder preset
     if (dq_decode_usable(a, cfg, layout)) return note_kernel("ans_decode_dq_kernel", ans_decode_dq(a, hs));                          // P <= 12, whole aligned tiles: lane-quad word loads
@@ -468,6 +469,10 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
     a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
     a.min_symbol = model->min_symbol; a.precision = model->precision; a.state = d_state; a.n_words_out = d_n_words_out;
     a.status = d_status; a.flags = flags; a.words_capacity = words_capacity;
+    if (b16_small_decode_usable(a, cfg, layout, symbol_bytes, model->cu_count)) {      // 12 < P <= 24, more than one wave per SIMD
+        *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_b16_small_n8_kernel" : "ans_decode_b16_small_n16_kernel", ans_decode_b16_small(a, symbol_bytes, (hipStream_t)stream));
+        return true;
+    }
     if (b16_narrow_decode_usable(a, cfg, layout, symbol_bytes)) {      // 12 < P <= 24
         *rc = note_kernel(symbol_bytes == 1 ? "ans_decode_b16_n8_kernel" : "ans_decode_b16_n16_kernel", ans_decode_b16_narrow(a, symbol_bytes, (hipStream_t)stream));
         return true;

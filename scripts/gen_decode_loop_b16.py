@@ -33,13 +33,23 @@ OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / "cs
 # tile.  The block's memory operations are not in the wait-count book: operations the book does not know can only make a wait
 # LONGER (they are younger than what it waits for, or older and retired with it), never shorter.
 NARROW = int(os.environ.get("GEN_B16_NARROW", "0"))
-N8_ROW = 132
-TILES_PER_GROUP = {0: 1, 1: 4, 2: 2}[NARROW]
-if NARROW:
+# GEN_B16_SMALL=1 with GEN_B16_NARROW=1 / 2 / 4 (cst_decode_loop_b16_s8.inc / _s16.inc / _s32.inc, ans_decode_b16_narrow_kernel<BYTES, true>): the
+# SMALL-FOOTPRINT form for two waves per SIMD (more than 256 streams per CU: a C5-sized shard, or the virtual streams of a batch decoded through
+# jump points).  Rings of 16 slots -- a window every QUARTER tile: 8 symbols take at most 6 words, two chunks -- and the one tile per wave of the
+# narrow form, for int32 too (GEN_B16_NARROW=4: rows of 36 words, the tile leaves in the block behind its landing): eight waves in 140 KiB.
+SMALL = int(os.environ.get("GEN_B16_SMALL", "0"))
+assert not SMALL or NARROW in (1, 2, 4), "the small-footprint form: int8, int16 or int32 through the one-tile block"
+assert NARROW != 4 or SMALL
+N8_ROW = 144 if NARROW == 4 else 132
+TILES_PER_GROUP = {0: 1, 1: 4, 2: 2, 4: 1}[NARROW]
+if SMALL:
+    OUT = OUT.with_name({1: "cst_decode_loop_b16_s8.inc", 2: "cst_decode_loop_b16_s16.inc", 4: "cst_decode_loop_b16_s32.inc"}[NARROW])
+elif NARROW:
     OUT = OUT.with_name("cst_decode_loop_b16_n8.inc" if NARROW == 1 else "cst_decode_loop_b16_n16.inc")
 
-K_CHUNKS = 3          # window chunks requested per HALF tile (16 symbols * 24 bits = 12 words = 3 chunks)
-AHEAD_M1 = 23         # kDecAhead - 1
+WINDOWS = (0, 8, 16, 24) if SMALL else (0, 16)     # steps in front of which the next part of the tile's words is requested
+K_CHUNKS = 2 if SMALL else 3     # window chunks requested per part (16 symbols * 24 bits = 12 words = 3 chunks; 8 symbols: 6 words = 2 chunks)
+AHEAD_M1 = 11 if SMALL else 23   # kDecAhead - 1
 
 
 def tup(base, n=4):
@@ -117,7 +127,7 @@ def gen():
     # here before the first step writes symbols over them): rows of any length take per-row offsets (row_skew,
     # cst_ans_kernels.hpp), partial waves repeat their last row, symbol-major batches have their own mapping -- all the
     # kernel's business, and an asm statement has room for 30 operands
-    if NARROW:
+    if NARROW in (1, 2):
         for k in range(8):
             a.ds(f"ds_read_b32 {GOFF[k]}, %[rowcur] offset:{4 * k}", "goff")      # (rows of 33 words: not 16-byte aligned)
         a.i("s_mov_b32 s83, 0", "tiles of the current group done")
@@ -131,7 +141,7 @@ def gen():
 
     for j in range(32):
         quad, pos = divmod(j, 4)
-        if j in (0, 16):
+        if j in WINDOWS:
             # ---- window: request the chunks the next half tile may need, then this half tile's first lookup ----
             window_requests()
             lookup(j)
@@ -160,7 +170,7 @@ def gen():
         a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
         a.wait_lds_all("candidate word (and everything older) is back")
         a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
-        last_of_half = j in (15, 31)
+        last_of_half = (j + 1) in WINDOWS or j == 31
         if not last_of_half:
             lookup(j + 1)
         a.i(f"v_subbrev_co_u32 %[rd], {SD}, 0, %[rd], vcc")
@@ -198,12 +208,21 @@ def gen():
         elif pos == 3:
             base = 134 + (quad % 2) * 4
             a.ds(f"ds_write_b128 %[rowcur], v[{base}:{base + 3}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
-        if j == 15:
-            window_landing("---- middle of the tile: the first half's chunks land")
+        if (j + 1) in WINDOWS:
+            window_landing("---- inside the tile: the chunks of the part just decoded land")
             a.wait_lds_all("landed chunks visible")
 
     window_landing("---- end of tile")
-    if NARROW:
+    if NARROW == 4:
+        a.wait_lds_all("landed chunks (and the tile's last quad) are in LDS")
+        # ---- the tile leaves: eight row blocks of whole 128-byte lines (not in the book: see the top of the file) ----
+        for k in range(8):
+            a.i(f"ds_read_b128 v[144:147], %[trcur] offset:{8 * N8_ROW * k}")
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i(f"global_store_dwordx4 {GOFF[k]}, v[144:147], s[80:81] nt")
+        a.i("s_add_u32 s80, s80, 0x80")
+        a.i("s_addc_u32 s81, s81, 0")
+    elif NARROW:
         a.wait_lds_all("landed chunks (and the tile's last quad) are in LDS")
         a.i(f"v_add_u32 %[rowcur], {128 // TILES_PER_GROUP}, %[rowcur]", "the next tile's bytes of the row")
         a.i("s_add_u32 s83, s83, 1")

@@ -14,5 +14,6 @@ GEN_SMALL_N8=16 python scripts/gen_decode_loop_small.py > /dev/null
 GEN_N16=1 python scripts/gen_decode_loop_n8.py > /dev/null
 GEN_B16_NARROW=1 python scripts/gen_decode_loop_b16.py > /dev/null
 GEN_B16_NARROW=2 python scripts/gen_decode_loop_b16.py > /dev/null
+for n in 1 2 4; do GEN_B16_SMALL=1 GEN_B16_NARROW=$n python scripts/gen_decode_loop_b16.py > /dev/null; done
 GEN_W16_PACKED=1 python scripts/gen_decode_loop_w16.py > /dev/null
 git status --short constriction_amd/csrc | grep '\.inc' | wc -l

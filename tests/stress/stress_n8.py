@@ -35,7 +35,7 @@ while time.time() < t_end:
                  "small": f"ans_decode_small{bits}_kernel"}
     else:
         names = {"enc": f"ans_encode_pc{bits}_kernel<wide>", "ck": f"ans_encode_pc{bits}_kernel<wide, ckpt>", "dec": f"ans_decode_b16{bits}_kernel",
-                 "small": f"ans_decode_b16{bits}_kernel"}
+                 "small": f"ans_decode_b16_small{bits}_kernel"}
     w = rng.gamma(0.3, 1.0, n) + 1e-9
     p = np.maximum(1, np.floor(w / w.sum() * ((1 << P) - n)).astype(np.int64))
     p[int(np.argmax(p))] += (1 << P) - int(p.sum())
@@ -113,7 +113,8 @@ while time.time() < t_end:
         out = torch.full((n_streams, n_per), 99, dtype=t_t, device="cuda")
         dec, dst = B.ans_decode(enc, model, n_per, out=out, cold=bool(rng.random() < 0.5))
         bucket_entries = n <= 256 or (n <= 1024 and P <= 22)     # (cst_common.hpp bucket16_usable: what the 12 < P decoders' entries can hold)
-        assert B.last_kernel() == (names["small"] if big and n <= 256 else names["dec"]) or nb == 4 or (P > 12 and not bucket_entries), (tag, B.last_kernel())
+        want_kernel = names["small"] if big and (n <= 256 or P > 12) else names["dec"]
+        assert B.last_kernel() == want_kernel or (nb == 4 and not big) or (P > 12 and not bucket_entries), (tag, B.last_kernel())
         assert int(dst.abs().sum().item()) == 0 and torch.equal(dec, d), tag
         n_small += int(big)
         if k and interval % line == 0:

@@ -107,7 +107,12 @@ def test_wide_precision_loops_are_in_sync(tmp_path, monkeypatch):
     for mode, name in (("1", "cst_decode_loop_b16_n8.inc"), ("2", "cst_decode_loop_b16_n16.inc")):      # round 5: int8 / int16 matrices
         monkeypatch.setenv("GEN_B16_NARROW", mode)
         assert _regenerate(_load("gen_decode_loop_b16"), tmp_path, name) == (ROOT / "constriction_amd" / "csrc" / name).read_text()
+    monkeypatch.setenv("GEN_B16_SMALL", "1")                  # ... and the small-footprint forms (two waves per SIMD), int32 too
+    for mode, name in (("1", "cst_decode_loop_b16_s8.inc"), ("2", "cst_decode_loop_b16_s16.inc"), ("4", "cst_decode_loop_b16_s32.inc")):
+        monkeypatch.setenv("GEN_B16_NARROW", mode)
+        assert _regenerate(_load("gen_decode_loop_b16"), tmp_path, name) == (ROOT / "constriction_amd" / "csrc" / name).read_text()
     monkeypatch.delenv("GEN_B16_NARROW")
+    monkeypatch.delenv("GEN_B16_SMALL")
     text = _regenerate(_load("gen_encode_loop_wide"), tmp_path, "cst_encode_loop_wide.inc")
     assert text == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide.inc").read_text()
     assert (tmp_path / "sm_cst_encode_loop_wide.inc").read_text() == (ROOT / "constriction_amd" / "csrc" / "cst_encode_loop_wide_sm.inc").read_text()

@@ -373,3 +373,74 @@ def test_narrow_high_precision_kernels_at_the_maximum_rate(B, O, dtype, P, frac)
     buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng)
     dec, st = B.ans_decode((buf, nw), model, 2048, offsets=offsets, config=(32, 64, P), dtype=dt)
     assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+
+
+_B16_SMALL = {"int32": "ans_decode_b16_small_kernel", "int16": "ans_decode_b16_small_n16_kernel", "int8": "ans_decode_b16_small_n8_kernel"}
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
+@pytest.mark.parametrize("P", [24, 16])
+@pytest.mark.parametrize("dtype", ["int32", "int16", "int8"])
+def test_small_footprint_high_precision_decoders_at_the_maximum_rate(B, O, dtype, P, frac):
+    """ans_decode_b16_narrow_kernel<BYTES, SMALL> (12 < P <= 24 at more than 256 streams per CU: two waves per SIMD, 16-slot word rings
+    with a window every quarter tile -- 8 symbols of probability 2^-24 take the 6 words a window supplies), slabs and packed words"""
+    n = 101
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_streams, n_per = cus * 256 + 300, 256
+    cdf = spiky_cdf(n, P)
+    model = B.Model.from_cdf(cdf, 0, P)
+    rng = np.random.default_rng(int(frac * 1000) + P + 5)
+    sym = high_rate_symbols(rng, n_streams, n_per, n, frac)
+    dt = {"int32": torch.int32, "int16": torch.int16, "int8": torch.int8}[dtype]
+    d = dev(sym).to(dt)
+    enc = B.ans_encode(dev(sym), model, (32, 64, P))
+    assert int(enc.status.abs().sum()) == 0
+    words, n_words, _ = enc.to_numpy()
+    for s in (0, 4097, n_streams - 1):
+        w, nw, _ = O.ans_encode_batch(sym[s: s + 1], 0, cdf, P, 32, 64)
+        assert np.array_equal(words[s, : n_words[s]], w[0, : nw[0]]), f"stream {s}"
+    guard = torch.full((n_streams * n_per + 4096,), 77, dtype=dt, device="cuda")
+    out = guard[: n_streams * n_per].view(n_streams, n_per)
+    dec, st = B.ans_decode(enc, model, n_per, out=out)
+    assert ALT or B.last_kernel() == _B16_SMALL[dtype]
+    wrong = (dec != d).any(dim=1).nonzero().flatten()
+    assert int(st.abs().sum()) == 0 and wrong.numel() == 0, f"{wrong.numel()} streams decode wrongly, first {wrong[:4].tolist()}"
+    assert (guard[n_streams * n_per:] == 77).all(), "symbols were written behind the matrix"
+    buf, offsets, nw = gapped(words.view(np.uint32), n_words, rng, max_gap=5)
+    out.fill_(55)
+    dec, st = B.ans_decode((buf, nw), model, n_per, offsets=offsets, config=(32, 64, P), out=out)
+    assert ALT or B.last_kernel() == _B16_SMALL[dtype]
+    wrong = (dec != d).any(dim=1).nonzero().flatten()
+    assert int(st.abs().sum()) == 0 and wrong.numel() == 0, f"packed words: {wrong.numel()} streams decode wrongly, first {wrong[:4].tolist()}"
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int8"])
+@pytest.mark.parametrize("P", [24, 13])
+def test_small_footprint_high_precision_decoders_on_model_data_and_jump_points(B, O, dtype, P):
+    """... on Gaussian data (the tails walk the cdf table out of line), and as the decoder of a batch with jump points (the virtual streams
+    of 65 536 x k chunks are what brings a batch of one wave per SIMD above 256 streams per CU)"""
+    lo, hi = -100, 100
+    cdf = O.GaussianModel(lo, hi, 7.3, 11.0, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_streams, n_per, k = cus * 128 + 64, 512, 4
+    dt = torch.int32 if dtype == "int32" else torch.int8
+    cdf_dev = torch.from_numpy(cdf.astype(np.int64)).cuda()
+    import bench
+    sym = bench.synth_symbols_device(77 + P, 0, n_streams, n_per, lo, cdf_dev, P)
+    d = sym.to(dt)
+    enc, ck = B.ans_encode_checkpointed(d, model, n_per // k, (32, 64, P))
+    plain = B.ans_encode(sym, model, (32, 64, P))
+    assert torch.equal(enc.n_words, plain.n_words) and int(enc.status.abs().sum()) == 0
+    host = sym[:3].cpu().numpy()
+    want_words, want_n, _ = O.ans_encode_batch(host, lo, cdf, P)
+    for s in range(3):
+        assert enc.stream(s).tolist() == want_words[s, : want_n[s]].tolist()
+    dec, st = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=dt)
+    assert ALT or B.last_kernel() == _B16_SMALL[dtype]
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    big = torch.cat([d, d, d])[: cus * 256 + 70]                 # ... and whole streams, a partial last wave
+    enc2 = B.ans_encode(big, model, (32, 64, P))
+    dec, st = B.ans_decode(enc2, model, n_per, dtype=dt)
+    assert ALT or B.last_kernel() == _B16_SMALL[dtype]
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, big)
