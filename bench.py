@@ -727,6 +727,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
              "notes the jump points on its way)", "ans", (32, 64, 12), m12, sym12, reps, check, cdf12)
         jump("C2 with int8 symbol matrices: decode with k jump points per stream (the loops read / write int8 themselves; 65 536 k virtual "
              "streams on the small-footprint int8 decoder, two waves per SIMD)", "ans", (32, 64, 12), m12, sym12.to(torch.int8), reps, check, cdf12)
+        jump("C2 at P = 24 (DefaultAnsCoder preset): decode with k jump points per stream (small-footprint bucket-entry decoder, two waves per SIMD)",
+             "ans", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        jump("C2 at P = 24 with int8 symbol matrices: decode with k jump points per stream (small-footprint bucket-entry decoder that writes int8)",
+             "ans", (32, 64, 24), m24, sym24.to(torch.int8), reps, check, cdf24)
         jump("C4 range coder, P = 12: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         jump("C4 range coder, P = 24: decode with k jump points per stream (sub-lane decoder)", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
         del sym24, m24
