@@ -493,6 +493,11 @@ def l_stage(a, i, buf):
         if "noloads" not in HABL:
             a.wait_vm(f"ld{c}{i}", f"coder {c}: symbols in set {i} have arrived")
         for k in range(8):
+            if "nostage" in HABL:                 # (timing experiments, results wrong: the loads are still waited for)
+                continue
+            if "stage32" in HABL:                 # a quarter of the register-file reads and LDS writes of the staging
+                a.ds(f"ds_write_b32 {HTR[buf]}, v{LBASE + 32 * (LSETS * c + i) + 4 * k} offset:{PAIR_TILE_OFF * c + 1152 * k}", "tl")
+                continue
             a.ds(f"ds_write_b128 {HTR[buf]}, {LR[(c, i)][k]} offset:{PAIR_TILE_OFF * c + 1152 * k}", "tl")
 
 
