@@ -6,6 +6,10 @@
 # Output: gpurun_out/<tag>_n8_counters.md (copy to profiles/).
 set -u
 tag=${1:-r05}
+# PMC_P=24 scripts/pmc_n8.sh <tag>: the same at 12 < P <= 24 (wide producer / consumer encoders, bucket-entry decoders and their small-footprint
+# forms; whole streams only) -> gpurun_out/<tag>_hp_counters.md
+PMC_P=${PMC_P:-12}
+name_out=n8; [ "$PMC_P" != 12 ] && name_out=hp
 export TMPDIR=/tmp
 R=$PWD
 cat > /tmp/n8_run.py <<PY
@@ -13,7 +17,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, "$R")
 import bench
 from constriction_amd import batched as B
-k, P = 4096, 12
+k, P = 4096, $PMC_P
 m = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
 cdf = torch.from_numpy(m.cdf().astype(np.int64)).cuda()
 for n in (65536, 131072):
@@ -26,7 +30,7 @@ for n in (65536, 131072):
             B.ans_encode(sym, m, (32, 64, P), out=enc)
             B.ans_decode(enc, m, k, out=dec)
         assert torch.equal(dec, sym)
-        if n == 65536:
+        if n == 65536 and P == 12:
             pair = B.ans_encode_checkpointed(sym, m, k // 2, (32, 64, P))
             for _ in range(4):
                 B.ans_encode_checkpointed(sym, m, k // 2, (32, 64, P), out=pair)
@@ -48,10 +52,11 @@ done
 d=gpurun_out/${tag}_n8_stats; mkdir -p $d
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$d -o st -- python /tmp/n8_run.py > /dev/null 2> $d/err.log
 find $d -mindepth 2 -name "*.csv" -exec mv {} $d/ \;
-python - <<PY > gpurun_out/${tag}_n8_counters.md
+python - <<PY > gpurun_out/${tag}_${name_out}_counters.md
 import csv, glob, collections, statistics
 want = ("ans_encode_pc_kernel", "ans_encode_pc_n8_kernel", "ans_encode_pc_n16_kernel", "ans_decode_kernel<32, 64, 0, true, 1, true, 8, true>",
-        "ans_decode_n8_kernel", "ans_decode_small_kernel", "ans_decode_small_n8_kernel", "ans_encode_small_kernel")
+        "ans_decode_n8_kernel", "ans_decode_small_kernel", "ans_decode_small_n8_kernel", "ans_encode_small_kernel", "ans_decode_b16_kernel",
+        "ans_decode_b16_narrow_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/${tag}_n8_[abfw]/*counter_collection.csv"):
     per_dispatch = collections.defaultdict(float)
@@ -66,7 +71,7 @@ for f in glob.glob("gpurun_out/${tag}_n8_[abfw]/*counter_collection.csv"):
 # wave-symbols of a launch: grid threads / 64 coder lanes ... x 4096 symbols (the encoders' grids hold as many helper as coder waves)
 def streams(k, g):
     return g // 2 if "ans_encode_pc" in k else g
-print("# ${tag}: the kernels that read / write int8 symbol matrices themselves, next to the int32 kernels of the same batch\n")
+print("# ${tag}: the kernels that read / write int8 symbol matrices themselves, next to the int32 kernels of the same batch" + ("" if $PMC_P == 12 else " -- at P = $PMC_P (ans_decode_b16_narrow_kernel<BYTES, SMALL>: <1 | 2, false> one wave per SIMD, <1 | 2 | 4, true> the small-footprint form; ans_encode_pc_*_kernel<JUMP, true> the wide step)") + "\n")
 print("scripts/pmc_n8.sh: rocprofv3 --pmc (two SQ passes, FETCH_SIZE and WRITE_SIZE in a pass each), medians over the launches of a kernel at one grid")
 print("size; per symbol and wave = counter / (streams / 64 x 4096) wave-symbols (cycle counters x 4: they count in units of four cycles; the")
 print("producer / consumer encoders' counters are sums over coder AND helper waves, normalised by the coder waves).  FETCH x 2 as the guide")
@@ -97,5 +102,5 @@ for fpath in glob.glob("gpurun_out/${tag}_n8_stats/*kernel_stats.csv"):
         if any(w in r["Name"] for w in want):
             print(f"| \`{r['Name'].replace('void cst::', '').replace('cst::', '').split('(')[0][:64]}\` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} |")
 PY
-cat gpurun_out/${tag}_n8_counters.md
+cat gpurun_out/${tag}_${name_out}_counters.md
 rm -rf gpurun_out/${tag}_n8_a gpurun_out/${tag}_n8_b gpurun_out/${tag}_n8_f gpurun_out/${tag}_n8_w gpurun_out/${tag}_n8_stats
