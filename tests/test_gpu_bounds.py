@@ -153,3 +153,58 @@ def test_corrupt_checkpoints(B):
     d = dec.cpu().numpy().reshape(n_streams, n_per // interval, interval)
     s = sym.reshape(n_streams, n_per // interval, interval)
     assert np.array_equal(d[want == 0], s[want == 0])
+
+
+@pytest.mark.parametrize("dtype", ["int8", "int16", "int32"])
+@pytest.mark.parametrize("P", [12, 24])
+@pytest.mark.parametrize("shape", ["one wave per SIMD", "small footprint"])
+def test_corrupt_metadata_narrow_and_small_footprint_decoders(B, dtype, P, shape):
+    """the decoders that write int8 / int16 matrices themselves (cst_ans_n8.hip, ans_decode_b16_narrow_kernel) and the small-footprint
+    forms of every type (more than 256 streams per CU): corrupt counts in slabs and corrupt offsets / counts in a packed buffer flag
+    exactly their streams, everybody else decodes, nothing is written behind the matrix"""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n_streams, n_per = (300, 512) if shape == "one wave per SIMD" else (cus * 256 + 100, 128)
+    rng = np.random.default_rng(P + n_streams)
+    sym = _symbols(rng, n_streams, n_per)
+    dt = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32}[dtype]
+    d = dev(sym).to(dt)
+    model = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, P)
+    config = (32, 64, P)
+    enc = B.ans_encode(d, model, config)
+    n = enc.n_words.cpu().numpy().astype(np.int64)
+    bad = [0, 5, 63, 64, n_streams - 1]
+    n_bad = n.copy()
+    n_bad[bad] = [enc.stride + 1, 0x7FFFFFF0, 0xFFFFFFFF, 1 << 20, 0xFFFFFFF0]
+    ok = np.ones(n_streams, bool)
+    ok[bad] = False
+    guard = torch.full((n_streams * n_per + 4096,), 77, dtype=dt, device="cuda")
+    out = guard[: n_streams * n_per].view(n_streams, n_per)
+    good_counts = enc.n_words
+    enc.n_words = dev(n_bad.astype(np.uint32).view(np.int32))
+    dec, status = B.ans_decode(enc, model, n_per, out=out)
+    kernel = B.last_kernel()
+    st = status.cpu().numpy()
+    assert (st[~ok] == INVALID).all() and (st[ok] == 0).all(), kernel
+    assert torch.equal(dec[torch.from_numpy(ok).cuda()], d[torch.from_numpy(ok).cuda()]), kernel
+    assert (guard[n_streams * n_per:] == 77).all(), kernel
+    enc.n_words = good_counts
+    packed, offsets = B.compact(enc)
+    total = int(offsets[-1].item())
+    packed = packed[:total].clone()
+    off = offsets.cpu().numpy().astype(np.int64)
+    m = n.copy()
+    off[3] = total + 1
+    off[64] = 1 << 40
+    off[65] = -8
+    m[100] = total
+    m[n_streams - 1] += 1
+    bad = [3, 64, 65, 100, n_streams - 1]
+    ok[:] = True
+    ok[bad] = False
+    out.fill_(55)
+    dec, status = B.ans_decode((packed, dev(m.astype(np.uint32).view(np.int32))), model, n_per, offsets=dev(off), config=config, out=out)
+    kernel = B.last_kernel()
+    st = status.cpu().numpy()
+    assert (st[~ok] == INVALID).all() and (st[ok] == 0).all(), kernel
+    assert torch.equal(dec[torch.from_numpy(ok).cuda()], d[torch.from_numpy(ok).cuda()]), kernel
+    assert (guard[n_streams * n_per:] == 77).all(), kernel
