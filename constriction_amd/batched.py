@@ -963,12 +963,20 @@ def _ckpt_scratch(kind, dev, nbytes):
     return buf
 
 
-def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None,
-                            dtype=torch.int32):
+def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None,
+                            dtype=torch.int32, offsets: Optional[torch.Tensor] = None, config=None):
     """Decodes every chunk on its own lane (AnsCoder.seek(pos, state) + `interval` symbols per chunk).
     Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks]).  dtype (or the dtype of `out`): int32, or int16 / int8 for
-    a narrow symbol matrix (cst_ans_decode_batch_ckpt_sym: int8 chunks of whole 128-symbol lines are written by the decoder loops)."""
-    n_streams = encoded.n_words.numel()
+    a narrow symbol matrix (cst_ans_decode_batch_ckpt_sym: int8 chunks of whole 128-symbol lines are written by the decoder loops).
+    `encoded`: an EncodedBatch (slabs), or the PACKED words of compact() / container.load() / a gather with `offsets` (int64
+    [n_streams + 1]) and `config` -- jump points count words from the start of their stream, wherever the stream lies."""
+    if not isinstance(encoded, EncodedBatch):
+        if offsets is None:
+            raise ValueError("packed words need their offsets")
+        words = encoded[0] if isinstance(encoded, (tuple, list)) else encoded
+        encoded = EncodedBatch(words.view(1, -1), checkpoints.pos[:, 0], checkpoints.pos[:, 0], tuple(config or (32, 64, 12)))
+    n_streams = checkpoints.pos.shape[0]
+    stride_arg = 0 if offsets is not None else encoded.words.shape[1]
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
     if out is None:
@@ -984,13 +992,13 @@ def ans_decode_checkpointed(encoded: EncodedBatch, checkpoints: Checkpoints, mod
             raise ValueError("narrow symbol matrices: contiguous alphabets only")
         scratch = _ckpt_scratch(("ans_ckpt_sym", torch.cuda.current_stream().cuda_stream), dev,
                                 L.cst_ckpt_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, narrow))
-        N.check(L.cst_ans_decode_batch_ckpt_sym(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
+        N.check(L.cst_ans_decode_batch_ckpt_sym(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets), stride_arg,
                                                 encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out),
                                                 narrow, n_streams, n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()),
                 "cst_ans_decode_batch_ckpt_sym")
         return out, status
     scratch = _ckpt_scratch("ans_ckpt", dev, L.cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
-    N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
+    N.check(L.cst_ans_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets), stride_arg,
                                         encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out), n_streams,
                                         n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()), "cst_ans_decode_batch_ckpt")
     return _to_symbols(model, out), status

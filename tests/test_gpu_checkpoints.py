@@ -234,3 +234,50 @@ def test_int8_jump_points_on_shapes_that_convert(B, O):
         assert np.array_equal(ck.state.cpu().numpy().view(np.uint64), want_state)
         dec, dstatus = B.ans_decode_checkpointed(enc, ck, model, n_per, dtype=dtype)
         assert (dstatus.cpu().numpy() == 0).all() and torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int8"])
+@pytest.mark.parametrize("P", [12, 24])
+def test_jump_points_on_packed_words(B, O, dtype, P):
+    """the words of compact() (what container.load or a gather hands over) decoded through the jump table of the batch: a jump point counts
+    words from the start of ITS stream, wherever the stream lies (cst_ans_decode_batch_ckpt[_sym] with d_offsets)"""
+    lo, n_streams, n_per, k = -50, 300, 512, 4
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(900 + P, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(sym if dtype == "int32" else sym.astype(np.int8))
+    enc, ck = B.ans_encode_checkpointed(d, model, n_per // k, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    total = int(offsets[-1].item())
+    packed = packed[:total].clone()
+    dec, st = B.ans_decode_checkpointed(packed, ck, model, n_per, dtype=d.dtype, offsets=offsets, config=(32, 64, P))
+    assert dec.dtype == d.dtype and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    with pytest.raises(ValueError):
+        B.ans_decode_checkpointed(packed, ck, model, n_per, dtype=d.dtype)
+    # a jump point beyond its stream's words: that chunk alone is flagged
+    bad = B.Checkpoints(ck.interval, ck.pos.clone(), ck.state)
+    bad.pos[7, 2] = 0x7FFFFFF0
+    dec, st = B.ans_decode_checkpointed(packed, bad, model, n_per, dtype=d.dtype, offsets=offsets, config=(32, 64, P))
+    st = st.cpu().numpy()
+    assert st[7, 2] == 3 and (np.delete(st.reshape(-1), 7 * k + 2) == 0).all()
+
+
+def test_jump_points_travel_in_the_container(B, O, tmp_path):
+    """encode with jump points -> compact -> container file -> load -> decode k lanes per stream from the packed words"""
+    from constriction_amd import container
+    P, lo, n_streams, n_per, k = 24, -50, 200, 256, 2
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(31, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(sym.astype(np.int8))
+    enc, ck = B.ans_encode_checkpointed(d, model, n_per // k, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    path = tmp_path / "batch.cst"
+    container.save(path, packed, offsets, (32, 64, P), jump_points=ck)
+    words, off, cfg, (interval, pos, state) = container.load_with_jump_points(path)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
+    for s in (0, 77, n_streams - 1):
+        assert words[int(off[s]): int(off[s + 1])].tolist() == want_words[s, : want_n[s]].tolist()
+    jump = B.Checkpoints(interval, dev(pos.view(np.int32)), dev(state.view(np.int64)))
+    dec, st = B.ans_decode_checkpointed(dev(words.view(np.int32)), jump, model, n_per, dtype=torch.int8, offsets=dev(off.astype(np.int64)), config=cfg)
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)

@@ -140,3 +140,42 @@ def test_packed_batch_container_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         container.load(tmp_path / "preset.cst")
 
+
+
+def test_packed_batch_container_with_a_jump_table(tmp_path):
+    """round 5: the batch's jump table (Pos / Seek side information) behind the words -- a reader that ignores it gets the plain batch,
+    the old format (field 36..39 = 0) reads as a batch without one, truncated and hostile tables are rejected from the file size"""
+    import struct
+    from types import SimpleNamespace
+    import numpy as np
+    import pytest
+    from constriction_amd import container
+    rng = np.random.default_rng(5)
+    n_streams, k = 11, 3
+    lens = rng.integers(1, 9, n_streams)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    words = rng.integers(0, 2 ** 32, int(offsets[-1]), dtype=np.uint64).astype(np.uint32)
+    jump = SimpleNamespace(interval=64, pos=rng.integers(0, 9, (n_streams, k)).astype(np.int32),
+                           state=rng.integers(0, 2 ** 63, (n_streams, k), dtype=np.int64))
+    path = tmp_path / "jump.cst"
+    container.save(path, words, offsets, (32, 64, 12), jump_points=jump)
+    w, o, cfg = container.load(path)                                   # the table is skipped
+    assert cfg == (32, 64, 12) and w.tolist() == words.tolist() and o.tolist() == offsets.tolist()
+    w, o, cfg, got = container.load_with_jump_points(path)
+    assert got[0] == 64 and got[1].dtype == np.uint32 and got[2].dtype == np.uint64
+    assert got[1].tolist() == jump.pos.tolist() and got[2].tolist() == jump.state.view(np.uint64).tolist()
+    plain = tmp_path / "plain.cst"
+    container.save(plain, words, offsets, (32, 64, 12))
+    assert container.load_with_jump_points(plain)[3] is None
+    raw = path.read_bytes()
+    assert len(raw) == len(plain.read_bytes()) + 8 + 12 * n_streams * k
+    (tmp_path / "cut.cst").write_bytes(raw[:-8])
+    with pytest.raises(ValueError):
+        container.load(tmp_path / "cut.cst")
+    body = bytearray(raw)
+    body[36:40] = struct.pack("<I", 1 << 30)                           # a hostile n_chunks: the size check, nothing allocated
+    (tmp_path / "huge.cst").write_bytes(bytes(body))
+    with pytest.raises(ValueError):
+        container.load_with_jump_points(tmp_path / "huge.cst")
+    with pytest.raises(ValueError):
+        container.save(tmp_path / "bad.cst", words, offsets, (32, 64, 12), jump_points=SimpleNamespace(interval=64, pos=jump.pos[:-1], state=jump.state[:-1]))
