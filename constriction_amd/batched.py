@@ -1039,9 +1039,18 @@ def range_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int
     return out, ck
 
 
-def range_decode_checkpointed(encoded: EncodedBatch, checkpoints: RangeCheckpoints, model: Model, n_per_stream: int, out=None, status=None):
+def range_decode_checkpointed(encoded, checkpoints: RangeCheckpoints, model: Model, n_per_stream: int, out=None, status=None,
+                              offsets: Optional[torch.Tensor] = None, config=None):
     """Every chunk on its own lane: RangeDecoder.seek(pos, (lower, range)) + `interval` symbols per chunk.
-    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks])."""
+    Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks]).  `encoded`: an EncodedBatch, or (packed words, n_words)
+    with `offsets` (int64 [n_streams + 1]) and `config` for the words of compact() / container.load() / a gather."""
+    stride_arg = None
+    if not isinstance(encoded, EncodedBatch):
+        if offsets is None:
+            raise ValueError("packed words need their offsets")
+        words, n_words = encoded
+        encoded = EncodedBatch(words.view(1, -1), n_words, n_words, tuple(config or (32, 64, 12)))
+        stride_arg = 0
     n_streams = encoded.n_words.numel()
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
@@ -1051,8 +1060,8 @@ def range_decode_checkpointed(encoded: EncodedBatch, checkpoints: RangeCheckpoin
         status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
     L = N.lib()
     scratch = _ckpt_scratch("range_ckpt", dev, L.cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
-    N.check(L.cst_range_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), None, encoded.words.shape[1],
-                                          encoded.words.numel(), _ptr(encoded.n_words), checkpoints.interval, _ptr(checkpoints.pos),
+    N.check(L.cst_range_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets),
+                                          encoded.words.shape[1] if stride_arg is None else stride_arg, encoded.words.numel(), _ptr(encoded.n_words), checkpoints.interval, _ptr(checkpoints.pos),
                                           _ptr(checkpoints.lower), _ptr(checkpoints.range), _ptr(out), n_streams, n_per_stream,
                                           _ptr(scratch), _ptr(status), _stream_ptr()), "cst_range_decode_batch_ckpt")
     return _to_symbols(model, out), status

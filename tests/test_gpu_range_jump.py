@@ -136,3 +136,21 @@ def test_range_jump_points_full_size_k2(B, O):
     assert np.array_equal(ck.pos[rows].cpu().numpy().view(np.uint32), want_pos)
     assert np.array_equal(ck.lower[rows].cpu().numpy().view(np.uint64), want_lower)
     assert np.array_equal(ck.range[rows].cpu().numpy().view(np.uint64), want_range)
+
+
+@pytest.mark.parametrize("P", [12, 24])
+def test_range_jump_points_on_packed_words(B, O, P):
+    """the words of compact() decoded through the batch's jump table (cst_range_decode_batch_ckpt with d_offsets)"""
+    lo, n_streams, n_per, k = -50, 300, 512, 4
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(70 + P, 0, n_streams, n_per, lo, cdf, P)
+    d = torch.from_numpy(sym).cuda()
+    enc, ck = B.range_encode_checkpointed(d, model, n_per // k, (32, 64, P))
+    packed, offsets = B.compact(enc)
+    total = int(offsets[-1].item())
+    packed = packed[:total].clone()
+    dec, st = B.range_decode_checkpointed((packed, enc.n_words), ck, model, n_per, offsets=offsets, config=(32, 64, P))
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    with pytest.raises(ValueError):
+        B.range_decode_checkpointed((packed, enc.n_words), ck, model, n_per)
