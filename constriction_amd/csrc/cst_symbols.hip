@@ -8,7 +8,10 @@
 // call: one streaming kernel (16 symbols per lane and access, non-temporal) widens intN -> int32 into a scratch matrix in front
 // of an encode, or narrows the decoder's int32 output behind it.  The coder kernels, their words and their status are untouched;
 // the extra HBM traffic is 5 bytes per int8 symbol (0.27 ms for the 268 M symbols of config C2, against the 5 ms their bytes
-// spend on the link).  Native narrow loads / stores inside the hand-scheduled loops are the next step.
+// spend on the link).  Since the second half of round 5 the (32,64) ANS loops read and write int8 / int16 matrices THEMSELVES where the
+// shape allows it (cst_ans_pc.hip, cst_ans_n8.hip, ans_decode_b16_narrow_kernel: DESIGN.md 4.13) -- cst_ans_*_batch_sym try them
+// first; this file is the path of every other shape (symbol-major, other presets, rows that are not whole 128-byte lines, per-stream
+// tables) and, through the two exported conversions, of the other coders.
 #include "cst_common.hpp"
 
 namespace cst {
