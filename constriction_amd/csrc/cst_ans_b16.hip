@@ -456,6 +456,9 @@ struct B16NarrowGeo {
     static constexpr size_t kRingBytes = (size_t)(kThreads / kWave) * kSlots * kWave * 4;
     static constexpr int kRowBytes = BYTES == 4 ? 144 : 132;               // a 128-byte line of the matrix + padding (int32: 16-byte aligned rows)
     static constexpr size_t kTileBytes = (size_t)kWave * kRowBytes;
+    // bucket entries: the one-wave form has LDS to spare and tabulates 2^12 buckets (half as many quantiles beyond their entry's third
+    // symbol: the out-of-line excursions cost the 2^11 form 11 % at P = 24 on C2's Gaussian); the eight-wave form keeps the model's 2^11
+    static constexpr int kTableBits = SMALL ? 0 : 12;
     static_assert(BYTES != 4 || SMALL, "int32 matrices at one wave per SIMD: ans_decode_b16_kernel");
 };
 
@@ -482,6 +485,7 @@ __device__ __forceinline__ void ans_decode_b16_narrow_loop(uint32_t& lo, uint32_
 template <int BYTES, bool SMALL>
 static size_t b16_narrow_lds_bytes(int n_symbols, int bucket_bits) {
     using G = B16NarrowGeo<BYTES, SMALL>;
+    if (G::kTableBits) bucket_bits = G::kTableBits;
     return G::kRingBytes + ((b16_table_bytes(n_symbols, bucket_bits) + 15) & ~(size_t)15) + (size_t)(G::kThreads / kWave) * G::kTileBytes +
            (size_t)(G::kThreads / kWave) * 4 * kWave * 4;
 }
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(SMALL ? 512 : kBlock) void ans_decode_b16_narrow_ke
     const uint32_t* cdf = a.cdf;
     const uint16_t* bucket = a.bucket;
     const size_t lds_off = stage_decoder_tables<kDecBucket, true, true>(smem + G::kRingBytes, P, a.dec_cp, a.dec_idx, a.cdf, a.bucket, a.bucket_bits,
-                                                                  a.n_symbols, lut, cdf, bucket);
+                                                                  a.n_symbols, lut, cdf, bucket, G::kTableBits);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + wave_in_block * (G::kSlots * kWave);
     unsigned char* tile = smem + G::kRingBytes + ((lds_off + 15) & ~(size_t)15) + wave_in_block * G::kTileBytes;
     uint32_t* dump = reinterpret_cast<uint32_t*>(smem + G::kRingBytes + ((lds_off + 15) & ~(size_t)15) + (size_t)kWaves * G::kTileBytes) +
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(SMALL ? 512 : kBlock) void ans_decode_b16_narrow_ke
     const uint32_t last_row = (uint32_t)min((size_t)(kWave - 1), a.n_streams - 1 - s0);      // (a partial wave: the spare lanes repeat the last stream)
     const size_t s = s0 + min((uint32_t)lane, last_row);
     const size_t N = a.n_per_stream, row_bytes = N * BYTES;
-    const int bucket_shift = P - a.bucket_bits;
+    const int bucket_shift = P - (G::kTableBits ? G::kTableBits : a.bucket_bits);
     const bool raw = (a.flags & CST_FLAG_RAW_STATE) != 0;
     int8_t* out = reinterpret_cast<int8_t*>(a.symbols);      // (BYTE addresses of the matrix)
 

@@ -1001,11 +1001,14 @@ __device__ __forceinline__ uint32_t ans_decode_step(LANE& L, const DecLut lut, c
 
 // Copies the decoder tables selected by MODE into LDS (if LUT_IN_LDS) and returns the bytes used.
 // SUB: with second-level tables behind the bucket entries (kSubAreaBytes more; every thread of the workgroup must call)
+// table_bits (bucket entries only): 0 = the model's bucket array as it is; otherwise 2^table_bits entries whose first symbols are found by a
+// binary search of the cdf copy (the model tabulates 2^11 buckets; a kernel with LDS to spare halves their width: fewer quantiles lie beyond
+// their entry's third symbol)
 template <int MODE, bool LUT_IN_LDS, bool SUB = false>
 __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int P, const uint32_t* dec_cp, const uint16_t* dec_idx,
                                                        const uint32_t* g_cdf, const uint16_t* g_bucket, int bucket_bits,
                                                        int n_symbols, DecLut& lut, const uint32_t*& cdf,
-                                                       const uint16_t*& bucket) {
+                                                       const uint16_t*& bucket, int table_bits = 0) {
     size_t lds_off = 0;
     lut.cp = dec_cp; lut.idx = dec_idx;
     if constexpr (MODE == kDecLutCP) {
@@ -1022,6 +1025,9 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
             uint32_t* c = reinterpret_cast<uint32_t*>(smem);
             for (int i = threadIdx.x; i <= n_symbols; i += blockDim.x) c[i] = g_cdf[i];
             lds_off = (((size_t)n_symbols + 1) * 4 + 15) & ~(size_t)15;
+            const bool searched = table_bits != 0 && table_bits != bucket_bits;
+            const int model_bits = bucket_bits;
+            if (searched) { bucket_bits = table_bits; __syncthreads(); }        // (the searches read the cdf copy)
             const int nb = (1 << bucket_bits);
             if (bucket16_usable(n_symbols, P)) {
                 uint4* b = reinterpret_cast<uint4*>(smem + lds_off);
@@ -1038,7 +1044,18 @@ __device__ __forceinline__ size_t stage_decoder_tables(unsigned char* smem, int 
                     __syncthreads();
                 }
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-                    const uint4 e = entry_at(g_bucket[i]);
+                    uint32_t first = 0;
+                    if (searched) {                                                // the symbol that holds the bucket's first quantile
+                        const uint32_t q0 = (uint32_t)i << shift;
+                        uint32_t hi = n;                                           // c[0] = 0 <= q0 < 2^P = c[n]
+                        if (bucket_bits > model_bits) {                            // ... lies between the first symbols of the model's bucket and of its successor
+                            const int d = bucket_bits - model_bits;
+                            first = g_bucket[i >> d];
+                            if (((i >> d) + 1) < (1 << model_bits)) hi = min(n, (uint32_t)g_bucket[(i >> d) + 1] + 1u);
+                        }
+                        while (hi - first > 1) { const uint32_t mid = (first + hi) >> 1; if (c[mid] <= q0) first = mid; else hi = mid; }
+                    } else first = g_bucket[i];
+                    const uint4 e = entry_at(first);
                     if constexpr (SUB) {
                         // more than three symbols begin in this bucket <=> a quantile of it lies at or above the fourth cumulative:
                         // the bucket claims slot (i mod kSubTables) for a second-level table (the lowest claimant keeps it; the

@@ -47,6 +47,8 @@ if SMALL:
 elif NARROW:
     OUT = OUT.with_name("cst_decode_loop_b16_n8.inc" if NARROW == 1 else "cst_decode_loop_b16_n16.inc")
 
+# bucket entries: 2^11 as the model tabulates them, 2^12 in the one-wave narrow kernels (LDS to spare: B16NarrowGeo::kTableBits)
+BUCKET_BITS = 12 if (NARROW in (1, 2) and not SMALL) else 11
 WINDOWS = (0, 8, 16, 24) if SMALL else (0, 16)     # steps in front of which the next part of the tile's words is requested
 K_CHUNKS = 2 if SMALL else 3     # window chunks requested per part (16 symbols * 24 bits = 12 words = 3 chunks; 8 symbols: 6 words = 2 chunks)
 AHEAD_M1 = 11 if SMALL else 23   # kDecAhead - 1
@@ -108,7 +110,7 @@ def gen():
             a.ds(f"ds_write2st64_b32 {LAND[k]}, {r[2]}, {r[3]} offset0:2 offset1:3", "land")
 
     def lookup(step):
-        a.i(f"v_bfe_u32 {LA}, %[lo], %[bsh], 11", "bucket = bits [P - 11, P) of the state")
+        a.i(f"v_bfe_u32 {LA}, %[lo], %[bsh], {BUCKET_BITS}", f"bucket = bits [P - {BUCKET_BITS}, P) of the state")
         a.i(f"v_lshl_add_u32 {LA}, {LA}, 4, %[lut]")
         a.ds(f"ds_read_b128 {ESET_T[step % 2]}, {LA}", "e", "bucket entry  <- end of the serial chain")
         a.i(f"v_and_b32 {Q}, %[mask], %[lo]", "quantile")
@@ -160,7 +162,9 @@ def gen():
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E1}, {V1}")
         a.i(f"v_cndmask_b32_e64 {NXT}, {NXT}, {E3}, {V2}")
         a.i(f"v_cndmask_b32_e64 {C}, {C}, {E2}, {V2}")
-        if not os.environ.get("GEN_NO_WALK"):       # timing experiment only: results are wrong
+        if os.environ.get("GEN_NO_WALK") == "2":    # timing experiment only (results wrong): a branch that never waits for the VALU's vcc
+            a.i(f"s_cbranch_execz 1{j:02d}f")
+        elif not os.environ.get("GEN_NO_WALK"):     # (GEN_NO_WALK=1: timing experiment only, results wrong)
             a.i(f"s_cbranch_vccnz 1{j:02d}f", "-> walk the cdf table for those lanes (rare; it also leaves index - 2 in the entry)")
         a.i(f"2{j:02d}:", None)
         a.i(f"v_sub_u32 {PR}, {NXT}, {C}", "p")
@@ -278,7 +282,11 @@ def gen():
         a.i(f"v_lshrrev_b32 {TMPA}, {SSH}, {Q}", "slot | part of the bucket")
         a.i(f"v_and_b32 {TMPA}, {SBITS}, {TMPA}")
         a.i(f"v_lshl_add_u32 {TMPA}, {TMPA}, 4, %[lut]")
-        a.i(f"ds_read_b128 {NEW_T}, {TMPA} offset:32768", "(behind the 2048 bucket entries)")
+        if BUCKET_BITS == 11:
+            a.i(f"ds_read_b128 {NEW_T}, {TMPA} offset:32768", "(behind the 2048 bucket entries)")
+        else:
+            a.i(f"v_add_u32 {TMPA}, {16 << BUCKET_BITS}, {TMPA}", "(behind the 4096 bucket entries: beyond the 16-bit offset field)")
+            a.i(f"ds_read_b128 {NEW_T}, {TMPA}")
         a.i("s_waitcnt lgkmcnt(0)")
         a.i(f"v_and_b32 {TMPA}, %[cfield], {NEW[0]}")
         a.i(f"v_cmp_le_u32 vcc, {TMPA}, {Q}")
