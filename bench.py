@@ -10,7 +10,9 @@ QuantizedGaussian(-50, 50, 3.2, 9.6) table into per-stream slabs, then ANS-decod
 65 536 streams (weak scaling, no data-path collective).  `python bench.py --gpus N` starts its own ranks
 (re-executes itself under torch.distributed.run on 127.0.0.1) unless a launcher already did.
 
-Rank 0 prints ONE JSON line.  `value` = symbols all ranks processed / max-over-ranks time of the K
+Rank 0's LAST stdout line is the bench line: the contract's keys only, under 4 KB (contract_line below).  Everything
+else -- `configs`, `after_cache_flush`, `end_to_end`, `rate` -- is the detail record: bench_detail.json next to this script
+and the stdout line before the last one.  `value` = symbols all ranks processed / max-over-ranks time of the K
 timed steps (barrier + synchronize on both sides).  `roofline` is measured live with HIP events on
 the launch stream around the dominant kernel; `cpu_baseline` times the CPU oracle ("port": the
 repo's C restatement of the reference arithmetic, the Rust crate cannot be built here) on the
@@ -212,10 +214,10 @@ def cpu_baseline(cdf, symbols_host, repeats=3):
     enc_rate, dec_rate, enc1, dec1 = n / te / 1e6, n / td / 1e6, n1 / te1 / 1e6, n1 / td1 / 1e6
     return {
         "value": round(n / (te + td) / 1e6, 2), "unit": "Msymbols/s", "cores": cores, "kind": "port",
-        "sample": f"{len(symbols_host)} of {N_STREAMS} streams x {N_PER} symbols (the GPU's own input), {cores} pinned threads, buffers allocated "
-                  f"and first touched outside the timed region, best of {repeats} (encode {enc_rate:.0f} + decode {dec_rate:.0f} Msym/s); "
-                  f"1 thread: {n1 / (te1 + td1) / 1e6:.1f} Msym/s "
-                  f"({te1 / n1 * 1e9:.1f} ns/sym encode, {td1 / n1 * 1e9:.1f} ns/sym decode)",
+        "sample": f"{len(symbols_host)} of {N_STREAMS} streams x {N_PER} symbols (the GPU's own input), {cores} pinned threads, best of {repeats}",
+        "sample_detail": f"buffers allocated and first touched outside the timed region (encode {enc_rate:.0f} + decode {dec_rate:.0f} Msym/s); "
+                         f"1 thread: {n1 / (te1 + td1) / 1e6:.1f} Msym/s "
+                         f"({te1 / n1 * 1e9:.1f} ns/sym encode, {td1 / n1 * 1e9:.1f} ns/sym decode)",
         "single_thread_value": round(n1 / (te1 + td1) / 1e6, 2),
         "encode_Msymbols_per_s": round(enc_rate, 1), "decode_Msymbols_per_s": round(dec_rate, 1),
         "scaling_efficiency": {"encode": round(enc_rate / (cores * enc1), 3), "decode": round(dec_rate / (cores * dec1), 3),
@@ -807,6 +809,53 @@ def other_configs(B, rank, world, dist, args, reps=5):
     return out
 
 
+# ---- the output contract: ONE small last line, everything else beside it ----
+LINE_LIMIT = 4096          # bytes; round 5's 21-KB line was not parsed by the driver (BENCH_r05.json: parsed null)
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "bit_exact", "encode_ms", "decode_ms", "compact_ms", "roofline", "cpu_baseline",
+                 "per_rank", "rccl_ranks_seen", "configs_error")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_cold", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample", "single_thread_value", "logical_cpus", "cgroup_cpu_quota")
+
+
+def contract_line(full):
+    """The LAST stdout line: the contract's keys only, prose cut short, <= LINE_LIMIT bytes whatever the run added to `full`.
+    The reports (`configs`, `after_cache_flush`, `end_to_end`, `rate`, notes) travel in the detail record instead."""
+    short = {k: full[k] for k in CONTRACT_KEYS if k in full}
+    if "roofline" in short:
+        short["roofline"] = {k: full["roofline"][k] for k in ROOFLINE_KEYS if k in full["roofline"]}
+    if "cpu_baseline" in short:
+        cb = {k: full["cpu_baseline"][k] for k in CPU_BASELINE_KEYS if k in full["cpu_baseline"]}
+        if isinstance(cb.get("sample"), str):
+            cb["sample"] = cb["sample"][:160]
+        short["cpu_baseline"] = cb
+    if "configs" in full:
+        cfgs = full["configs"]
+        short["configs_reported"] = len(cfgs)
+        short["configs_bit_exact"] = all(c.get("bit_exact", True) for c in cfgs)
+    short["detail"] = "bench_detail.json (also the previous stdout line)"
+    # whatever else grows: the line must stay parseable
+    for victim in ("per_rank", "configs_error", "detail"):
+        if len(json.dumps(short)) < LINE_LIMIT:
+            break
+        short.pop(victim, None)
+    if len(json.dumps(short)) >= LINE_LIMIT and isinstance(short.get("config"), dict):
+        short["config"] = {k: (v[:120] if isinstance(v, str) else v) for k, v in short["config"].items()}
+    assert len(json.dumps(short)) < LINE_LIMIT, "bench line outgrew its reader"
+    return short
+
+
+def emit(full, detail_path=None):
+    """detail record -> bench_detail.json next to this script AND an earlier stdout line; then the contract line, LAST"""
+    detail = json.dumps({"bench_detail": full})
+    try:
+        Path(detail_path or (ROOT / "bench_detail.json")).write_text(detail + "\n")
+    except OSError as exc:
+        print(json.dumps({"bench_detail_write_error": str(exc)[:200]}), flush=True)
+    print(detail, flush=True)
+    print(json.dumps(contract_line(full)), flush=True)
+
+
 def plumbing(args, rank, world, dist):
     """The multi-rank skeleton of this script on host tensors (see --plumbing): every rank owns streams
     [rank * n, (rank + 1) * n) whose "compressed words" are a function of the global stream id, packs them, gathers them
@@ -866,6 +915,7 @@ def main():
                          "'default' (max_words), or a number")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of the C5 shard's packed words")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--detail-out", default=None, help="where the detail record goes (default: bench_detail.json next to this script)")
     ap.add_argument("--plumbing", action="store_true",
                     help="no GPU work: run only the multi-rank plumbing of this script (self-launch, rendezvous, stream sharding, "
                          "variable-length gather of per-stream words to rank 0, max-over-ranks timing) on host tensors -- "
@@ -1108,7 +1158,7 @@ def main():
             line["configs_error"] = configs_error
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cdf, symbols.cpu().numpy())
-        print(json.dumps(line), flush=True)
+        emit(line, args.detail_out)
     if dist is not None:
         try:
             dist.barrier()
