@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code, clippy::too_many_arguments)]
 use core::ffi::{c_char, c_void};
 
-pub const CST_ABI_VERSION: i32 = 4;
+pub const CST_ABI_VERSION: i32 = 5;
 
 /// `cst_status`
 pub type CstStatus = i32;
@@ -39,6 +39,8 @@ pub const CST_FLAG_NONE: u32 = 0;
 pub const CST_FLAG_RAW_STATE: u32 = 1;
 pub const CST_FLAG_COLD_WORDS: u32 = 2;
 pub const CST_FLAG_PACKED_W16: u32 = 4;
+pub const CST_CODER_ANS: i32 = 0;
+pub const CST_CODER_RANGE: i32 = 1;
 
 /// `cst_model`: opaque, device-resident model image
 #[repr(C)]
@@ -698,6 +700,42 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    pub fn cst_jump_points_auto(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        coder: i32,
+        symbol_bytes: i32,
+        d_symbols: *const c_void,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *const c_void,
+        stride_words: usize,
+    ) -> usize;
+
+    pub fn cst_jump_points_auto_gaussian(
+        cfg: CstCoderConfig,
+        coder: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+    ) -> usize;
+
+    /// Debug switches (ABI 5).  The dispatcher's A/B switches are environment variables read ONCE, when the library is loaded --
+    /// no coder call reads the environment.  Each selects among kernels that produce the same words and symbols (the parity suite
+    /// runs under every one of them, scripts/alt_paths.sh):
+    ///   CST_NO_PC_ENCODER=1      never the producer / consumer encoders          CST_NO_PC_WIDE=1   12 < P <= 24 on ans_encode_wide_kernel
+    ///   CST_PC_COMBINED=1        their helper waves load AND store                CST_NO_N8=1        narrow matrices through the conversion kernels
+    ///   CST_SMALL_KERNELS=0|enc|dec   never / only the encoder / only the decoder of the small-footprint kernels
+    ///   CST_DQ_DECODER=1         the lane-quad decoder without CST_FLAG_COLD_WORDS CST_PT_SUB_WAVES=8 sub-lane decoder: never sixteen waves
+    ///   CST_SUB_ORDER=0          range sub-lane decoder: chunks side by side      CST_LANE_GEO=big|small   per-symbol lane decoder geometry
+    ///   CST_FUSED_MIN_STREAMS=n  from how many streams the fused per-symbol encoder runs
+    ///   CST_AUTO_JUMP=0          cst_jump_points_auto* answer 0
+    /// (CST_RCCL_LIB=<path>, read at the first collective call, names the RCCL library to open.)
+    /// cst_debug_reload_knobs re-reads them: for tests that drive several paths inside one process; not thread-safe against
+    /// concurrent coder calls.
+    pub fn cst_debug_reload_knobs();
+
     /// Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
     /// concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled
     /// look-back, fused with the copy), fully asynchronous on `stream`: no host synchronisation, no allocation.
@@ -742,8 +780,11 @@ extern "C" {
     /// (src/backends.rs:1424-1448; docs :774-803) are its coders over words stored last-written-first, the order in which a decoder
     /// consumes them -- what a file or socket that is decoded while it arrives holds.  This entry point converts a batch between the
     /// two orders (it is its own inverse); the decoders of this library take the reference's default order.
-    ///   d_offsets_in / d_offsets_out   packed layouts (offsets[s] = first word of stream s), or NULL for slabs `stride` words apart
-    /// In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream.
+    ///   d_offsets_in / d_offsets_out   packed layouts (the n_streams + 1 offsets of cst_compact_words: offsets[s] = first word of
+    ///                                  stream s), or NULL for slabs `stride` words apart
+    /// In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream.  A stream whose
+    /// count exceeds its slab (stride) or its slice of a packed buffer (offsets[s + 1] - offsets[s]) is left untouched -- counts and
+    /// offsets are caller data, and the decoders would report such a stream as CST_STREAM_INVALID_DATA.
     pub fn cst_words_reverse(
         d_words_in: *const u32,
         d_offsets_in: *const u64,

@@ -496,6 +496,32 @@ impl BatchedAnsCoder {
         unsafe { ffi::cst_ans_max_words(n_symbols, self.config) }
     }
 
+    /// The library's own choice of jump points for a batch about to be encoded with `encode_iid_symbols_reverse*` (ABI 5,
+    /// `cst_jump_points_auto`): the `interval` to hand to `encode_iid_symbols_reverse_with_checkpoints[_narrow]` and to the matching
+    /// `decode_iid_symbols_from_checkpoints*`, or 0 = the plain calls are as fast.  Jump points (`Pos` / `Seek`,
+    /// src/stream/stack.rs:1107-1139) never change the words.  `symbol_bytes` = 4 for `i32` matrices, 1 / 2 for `i8` / `i16`.
+    pub fn auto_jump_interval(&self, symbol_bytes: usize, n_streams: usize, n_per_stream: usize, model: &DeviceModel) -> usize {
+        unsafe {
+            ffi::cst_jump_points_auto(
+                model.as_raw(),
+                self.config,
+                ffi::CST_CODER_ANS,
+                symbol_bytes as i32,
+                core::ptr::null(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                core::ptr::null(),
+                self.max_words(n_per_stream),
+            )
+        }
+    }
+
+    /// ... for `encode_symbols_reverse_with_checkpoints` (every symbol its own mean and std; `cst_jump_points_auto_gaussian`).
+    pub fn auto_jump_interval_gaussian(&self, n_streams: usize, n_per_stream: usize) -> usize {
+        unsafe { ffi::cst_jump_points_auto_gaussian(self.config, ffi::CST_CODER_ANS, n_streams, n_per_stream, self.layout.raw()) }
+    }
+
     /// Per stream: `AnsCoder::new()`, `encode_iid_symbols_reverse(symbols[s], &model)?`, `into_compressed()`
     /// (src/stream/stack.rs:249, 835-849, 891-895).
     pub fn encode_iid_symbols_reverse(
@@ -780,10 +806,11 @@ impl BatchedAnsCoder {
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
         let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
-        if checkpoints.interval == 0 || means.len() < count || stds.len() < count {
+        let n_chunks = checkpoints.chunks_for(n_streams, n_per_stream)?;
+        if means.len() < count || stds.len() < count {
             return Err(Error::InvalidArgument);
         }
-        let n_points = n_streams.checked_mul((n_per_stream + checkpoints.interval - 1) / checkpoints.interval).ok_or(Error::InvalidArgument)?;
+        let n_points = n_streams * n_chunks;
         let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_points)? };
         let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
         check(unsafe {
@@ -1096,7 +1123,7 @@ impl BatchedAnsCoder {
         stream: &Stream,
     ) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
-        let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
+        let n_chunks = checkpoints.chunks_for(n_streams, n_per_stream)?;
         let mut out = DecodedBatch { symbols: DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?, status: DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)? };
         let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
         check(unsafe {
@@ -1176,10 +1203,7 @@ impl BatchedAnsCoder {
         stream: &Stream,
     ) -> Result<(DeviceBuffer<T>, DeviceBuffer<i32>)> {
         let n_streams = encoded.n_streams;
-        if checkpoints.interval == 0 {
-            return Err(Error::InvalidArgument);
-        }
-        let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
+        let n_chunks = checkpoints.chunks_for(n_streams, n_per_stream)?;
         let mut symbols: DeviceBuffer<T> = DeviceBuffer::new(n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?)?;
         let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?)?;
         let mut scratch: DeviceBuffer<u8> =
@@ -1216,6 +1240,22 @@ pub struct Checkpoints {
     pub interval: usize,
 }
 
+impl Checkpoints {
+    /// Jump points per stream if this table describes `n_streams` streams of `n_per_stream` symbols -- whole chunks, one entry per
+    /// (stream, chunk) in both arrays -- else `InvalidArgument`: the C calls index `[n_streams][n_per_stream / interval]` and trust it.
+    pub fn chunks_for(&self, n_streams: usize, n_per_stream: usize) -> Result<usize> {
+        if self.interval == 0 || n_per_stream % self.interval != 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = n_per_stream / self.interval;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        if self.pos.len() < n_points || self.state.len() < n_points {
+            return Err(Error::InvalidArgument);
+        }
+        Ok(n_chunks)
+    }
+}
+
 /// `RangeEncoder::pos()` of every stream in front of every chunk (src/stream/queue.rs:172-196).
 pub struct RangeCheckpoints {
     pub pos: DeviceBuffer<u32>,
@@ -1242,6 +1282,25 @@ impl BatchedRangeEncoder {
 
     pub fn max_words(&self, n_symbols: usize) -> usize {
         unsafe { ffi::cst_range_max_words(n_symbols, self.config) }
+    }
+
+    /// The library's own choice of jump points (`RangeEncoder::pos`, src/stream/queue.rs:172-196) for a batch about to be encoded:
+    /// the `interval` for `encode_iid_symbols_with_checkpoints` / `BatchedRangeDecoder::decode_iid_symbols_from_checkpoints`, or 0.
+    pub fn auto_jump_interval(&self, n_streams: usize, n_per_stream: usize, model: &DeviceModel) -> usize {
+        unsafe {
+            ffi::cst_jump_points_auto(
+                model.as_raw(),
+                self.config,
+                ffi::CST_CODER_RANGE,
+                4,
+                core::ptr::null(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                core::ptr::null(),
+                self.max_words(n_per_stream),
+            )
+        }
     }
 
     /// Per stream: `RangeEncoder::new()`, `encode_iid_symbols(symbols[s], &model)?`, `into_compressed()`
@@ -1453,7 +1512,10 @@ impl BatchedRangeDecoder {
         if checkpoints.interval == 0 {
             return Err(Error::InvalidArgument);
         }
-        let n_chunks = (n_per_stream + checkpoints.interval - 1) / checkpoints.interval;
+        if n_per_stream % checkpoints.interval != 0 {
+            return Err(Error::InvalidArgument); // whole chunks only: the C call indexes [n_streams][n_per_stream / interval]
+        }
+        let n_chunks = n_per_stream / checkpoints.interval;
         let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
         let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
         if checkpoints.pos.len() < n_points || checkpoints.lower.len() < n_points || checkpoints.range.len() < n_points {

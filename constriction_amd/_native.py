@@ -33,6 +33,8 @@ FLAG_RAW_STATE = 1
 FLAG_COLD_WORDS = 2
 FLAG_PACKED_W16 = 4
 
+CODER_ANS, CODER_RANGE = 0, 1
+
 
 class BackendUnavailable(RuntimeError):
     """The HIP extension (or a GPU) is missing.  The product path never falls back to the CPU."""
@@ -93,6 +95,9 @@ SIGNATURES = {
     "cst_ans_decode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_range_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_range_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
+    "cst_jump_points_auto": (_z, [_vp, CoderConfig, _i32, _i32, _vp, _z, _z, _i32, _vp, _z]),
+    "cst_jump_points_auto_gaussian": (_z, [CoderConfig, _i32, _z, _z, _i32]),
+    "cst_debug_reload_knobs": (None, []),
     "cst_range_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_ans_encode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _z, _vp, _vp, _vp]),
     "cst_ans_decode_ragged": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _vp, _vp]),
@@ -158,7 +163,7 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError here means the ABI and the binding disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.cst_abi_version() != 4:
+    if lib.cst_abi_version() != 5:
         raise BackendUnavailable("ABI version mismatch between _native.py and libconstriction_amd.so")
     _lib = lib
     return lib
@@ -171,6 +176,12 @@ def lib():
     if n < 1:
         raise BackendUnavailable("no MI355X (gfx950) device visible; constriction_amd has no CPU fallback")
     return l
+
+
+def reload_knobs():
+    """cst_debug_reload_knobs: the library re-reads its CST_* debug switches from the environment (it reads them once, when it
+    is loaded); for tests that set one inside the process"""
+    load_library().cst_debug_reload_knobs()
 
 
 def check(status: int, what: str = ""):

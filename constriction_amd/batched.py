@@ -190,11 +190,22 @@ def _to_symbols(model: "Model", decoded: torch.Tensor) -> torch.Tensor:
 
 @dataclass
 class EncodedBatch:
-    """Per-stream compressed words in fixed-stride slabs (stream s: words[s, :n_words[s]])."""
+    """Per-stream compressed words in fixed-stride slabs (stream s: words[s, :n_words[s]]).
+
+    jump: the jump points the encode call noted for its own words (Checkpoints / RangeCheckpoints, `jump_points=` of the encode
+    calls; None = none) -- side information the matching decode call uses to decode every stream on several lanes.  They describe
+    the words the encoder wrote: replacing `words` or `n_words` drops them, and whoever edits those tensors IN PLACE sets
+    `jump = None` (the plain decoders read the words alone)."""
     words: torch.Tensor      # uint32 as int32 storage? -> torch.int32 view of uint32 words [n_streams, stride]
     n_words: torch.Tensor    # int32 [n_streams] (values are counts)
     status: torch.Tensor     # int32 [n_streams]
     config: tuple
+    jump: Optional[object] = None
+
+    def __setattr__(self, name, value):
+        if name in ("words", "n_words") and "jump" in self.__dict__:
+            object.__setattr__(self, "jump", None)
+        object.__setattr__(self, name, value)
 
     @property
     def stride(self):
@@ -345,28 +356,59 @@ def _layout_shape(symbols: torch.Tensor, layout: str):
     raise ValueError("layout must be 'stream_major' or 'symbol_major'")
 
 
+def _new_batch(n_streams, stride, dev, config, packed16=False) -> EncodedBatch:
+    return EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int16 if packed16 else torch.int32, device=dev),
+                        torch.empty(n_streams, dtype=torch.int32, device=dev),
+                        torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+
+
+def _jump_interval(jump_points, n_per: int, auto) -> int:
+    """`jump_points` of an encode call -> symbols between jump points (0 = none).  "auto": the library's own choice for this batch
+    (`auto()` asks cst_jump_points_auto); an integer k: k jump points per stream (must divide the row length)."""
+    if isinstance(jump_points, str):
+        if jump_points != "auto":
+            raise ValueError("jump_points must be 'auto' or a number of jump points per stream")
+        return int(auto())
+    k = int(jump_points or 0)
+    if k == 0:
+        return 0
+    if k < 0 or n_per % k != 0:
+        raise ValueError("jump_points must divide the number of symbols per stream")
+    return n_per // k
+
+
+def _jump_table(out: EncodedBatch, kind, interval: int, n_streams: int, n_per: int, dev):
+    """the jump table of `out` for this shape: the batch's own one if it has the right form (coding again into the same buffers
+    allocates nothing), else a new one"""
+    n_chunks = (n_per + interval - 1) // interval
+    ck = out.jump
+    if isinstance(ck, kind) and ck.interval == interval and tuple(ck.pos.shape) == (n_streams, n_chunks) and ck.pos.device == dev:
+        return ck
+    if kind is Checkpoints:
+        return Checkpoints(interval, torch.zeros((n_streams, n_chunks), dtype=torch.int32, device=dev),
+                           torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
+    return RangeCheckpoints(interval, *(torch.zeros((n_streams, n_chunks), dtype=dt, device=dev) for dt in (torch.int32, torch.int64, torch.int64)))
+
+
 def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-               stride=None, out: Optional[EncodedBatch] = None, packed16: bool = False, jump_points: int = 0) -> EncodedBatch:
+               stride=None, out: Optional[EncodedBatch] = None, packed16: bool = False, jump_points="auto") -> EncodedBatch:
     """One AnsCoder per stream: encode_iid_symbols_reverse + into_compressed (stack.rs:835-849, 891-895).
-    jump_points = k > 0 (k divides the rows): the encoder also notes `AnsCoder.pos()` in front of every k-th part of a stream
-    (ans_encode_checkpointed; the words are unchanged) and the batch carries them as `.jump` -- ans_decode then decodes every part on a
-    lane of its own (two or more waves per SIMD where a 65 536-stream batch has one: int8 / int16 matrices, tables per stream).
+    jump_points: the encoder can also note `AnsCoder.pos()` (stack.rs:1107-1139) in front of every k-th part of a stream -- the
+    words are unchanged, the batch carries the points as `.jump`, and ans_decode then decodes every part on a lane of its own (two
+    or more waves per SIMD where a 65 536-stream batch has one).  "auto" (default): where that pays and costs the encoder nothing
+    (cst_jump_points_auto: int8 / int16 matrices, tables per stream, P > 12, fewer streams than the chip has lanes; none for
+    int32 symbols with one table of P <= 12 at 65 536 streams or more); an integer k: k points per stream (k divides the rows);
+    0: none.
     stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride).
     packed16 (the (16,32) preset only): the words two per 32-bit slot, as the reference's Vec<u16> (CST_FLAG_PACKED_W16) -- the
-    batch's `words` is then an int16 tensor; ans_decode and compact recognise it."""
+    batch's `words` is then an int16 tensor; ans_decode and compact recognise it.
+    out: an EncodedBatch of an earlier call with the same shapes, to code into the same buffers (its jump table is reused,
+    replaced or dropped as this call's jump_points say)."""
     if isinstance(stride, str):
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout) if out is None else None
-    if jump_points:
-        n_per = symbols.shape[1] if layout == "stream_major" else symbols.shape[0]
-        if packed16 or jump_points < 0 or n_per % jump_points != 0:
-            raise ValueError("jump_points must divide the number of symbols per stream (and needs unpacked words)")
-        prev = (out, out.jump) if out is not None and getattr(out, "jump", None) is not None else None
-        enc, ck = ans_encode_checkpointed(symbols, model, n_per // jump_points, config, layout, stride, out=prev)
-        enc.jump = ck
-        _stamp_fresh(enc)
-        return enc
+    given = symbols
     narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
     if narrow != 4:
         # int8 / int16 symbol matrices (the reference's Symbol is generic, quantize.rs:229-255; cst_ans_encode_batch_sym): rows of whole
@@ -379,22 +421,29 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
-        stride = stride or max_words(n_per, config)
-        dev = symbols.device
-        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int16 if packed16 else torch.int32, device=dev),
-                           torch.empty(n_streams, dtype=torch.int32, device=dev),
-                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
+        out = _new_batch(n_streams, stride or max_words(n_per, config), symbols.device, config, packed16)
+    if out.packed16 and not (isinstance(jump_points, str) or not jump_points):
+        raise ValueError("jump_points: unpacked words only")
+    L = N.lib()
+    interval = 0 if out.packed16 else _jump_interval(jump_points, n_per, lambda: L.cst_jump_points_auto(
+        model._h, _cfg(*config), N.CODER_ANS, narrow, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
+    if interval:
+        ck = _jump_table(out, Checkpoints, interval, n_streams, n_per, symbols.device)
+        ans_encode_checkpointed(given, model, interval, config, layout, out=(out, ck))
+        out.jump = ck
+        _stamp_fresh(out)
+        return out
+    out.jump = None              # (an earlier call's jump points describe an earlier call's words)
     flags = N.FLAG_PACKED_W16 if out.packed16 else N.FLAG_NONE
     if narrow != 4:
-        L = N.lib()
-        scratch = _ckpt_scratch(("widen", torch.cuda.current_stream().cuda_stream), symbols.device, L.cst_symbols_scratch_bytes(n_streams, n_per, narrow))
+        scratch = _ckpt_scratch("widen", symbols.device, L.cst_symbols_scratch_bytes(n_streams, n_per, narrow))
         N.check(L.cst_ans_encode_batch_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words),
                                            out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags, _ptr(scratch),
                                            _stream_ptr()), "cst_ans_encode_batch_sym")
     else:
-        N.check(N.lib().cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
-                                             out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags,
-                                             _stream_ptr()), "cst_ans_encode_batch")
+        N.check(L.cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
+                                       out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags,
+                                       _stream_ptr()), "cst_ans_encode_batch")
     _stamp_fresh(out)
     return out
 
@@ -439,9 +488,11 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     that never changes results): are the words NOT expected in the GPU's caches?  Default None = decided by provenance: hot only
     if `encoded` is the EncodedBatch that the last ans_encode on this HIP stream filled (and small enough to have stayed in the
     caches); words that came from the host, a peer or a file -- plain tensors, packed + offsets -- are cold."""
-    jump = getattr(encoded, "jump", None) if isinstance(encoded, EncodedBatch) else None
-    if jump is not None and offsets is None and layout == "stream_major" and n_per_stream % jump.interval == 0:
-        # the batch carries jump points (ans_encode(..., jump_points=k)): every part of a stream on a lane of its own
+    jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
+    if isinstance(jump, Checkpoints) and offsets is None and layout == "stream_major" and not encoded.packed16 and \
+            n_per_stream == jump.interval * jump.pos.shape[1] and jump.pos.shape[0] == encoded.n_words.numel():
+        # the batch carries jump points for exactly this decode (ans_encode, jump_points): every part of a stream on a lane of its
+        # own.  (A prefix of the streams, n_per_stream < what was encoded, is a plain decode: the table's rows have another stride.)
         dec, part_status = ans_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype if out is None else out.dtype)
         return dec, part_status.amax(dim=1)
     if isinstance(encoded, EncodedBatch):
@@ -468,7 +519,7 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
         if model.noncontiguous:
             raise ValueError("narrow symbol matrices: contiguous alphabets only")
         L = N.lib()
-        scratch = _ckpt_scratch(("narrow", torch.cuda.current_stream().cuda_stream), dev, L.cst_symbols_scratch_bytes(n_streams, n_per_stream, narrow))
+        scratch = _ckpt_scratch("narrow", dev, L.cst_symbols_scratch_bytes(n_streams, n_per_stream, narrow))
         N.check(L.cst_ans_decode_batch_sym(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
                                            _ptr(out), narrow, n_streams, n_per_stream, lay, None, None, _ptr(status),
                                            flags, _ptr(scratch), _stream_ptr()), "cst_ans_decode_batch_sym")
@@ -679,26 +730,35 @@ def range_max_words(n_per_stream: int, config=(32, 64, 12)) -> int:
 
 
 def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout="stream_major",
-                 stride=None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+                 stride=None, out: Optional[EncodedBatch] = None, jump_points="auto") -> EncodedBatch:
     """One RangeEncoder per stream: encode_iid_symbols + get_compressed (queue.rs:612-705, 458-523).
-    stride: words per slab (default range_max_words), or "tuned" (tuned_stride(..., coder="range"))."""
+    stride: words per slab (default range_max_words), or "tuned" (tuned_stride(..., coder="range")).
+    jump_points: as for ans_encode -- `RangeEncoder.pos()` (queue.rs:172-196) in front of every k-th part of a stream, carried as
+    `.jump` for range_decode; "auto" (default) = cst_jump_points_auto (the range decoder's division chain is latency-bound at one
+    wave per SIMD: two lanes per stream at 65 536 streams), an integer k, or 0."""
     if isinstance(stride, str):
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout, coder="range") if out is None else None
     if symbols.dtype in (torch.int8, torch.int16):
         symbols = _widened(symbols, model)                 # (the range coder's kernels take int32: cst_symbols_widen in front of them)
-    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    given = _require_cuda(symbols, torch.int32, "symbols")
+    symbols = _to_indices(model, given)
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
-        stride = stride or range_max_words(n_per, config)
-        dev = symbols.device
-        out = EncodedBatch(torch.empty((n_streams, stride), dtype=torch.int32, device=dev),
-                           torch.empty(n_streams, dtype=torch.int32, device=dev),
-                           torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
-    N.check(N.lib().cst_range_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
-                                           out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
-                                           _stream_ptr()), "cst_range_encode_batch")
+        out = _new_batch(n_streams, stride or range_max_words(n_per, config), symbols.device, config)
+    L = N.lib()
+    interval = 0 if model.n_tables != 1 else _jump_interval(jump_points, n_per, lambda: L.cst_jump_points_auto(
+        model._h, _cfg(*config), N.CODER_RANGE, 4, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
+    if interval:
+        ck = _jump_table(out, RangeCheckpoints, interval, n_streams, n_per, symbols.device)
+        range_encode_checkpointed(given, model, interval, config, layout, out=(out, ck))
+        out.jump = ck
+        return out
+    out.jump = None
+    N.check(L.cst_range_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
+                                     out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
+                                     _stream_ptr()), "cst_range_encode_batch")
     return out
 
 
@@ -744,6 +804,13 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
     narrow_out = None
     if dtype != torch.int32:
         narrow_out, out = out, None
+    jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
+    if isinstance(jump, RangeCheckpoints) and offsets is None and layout == "stream_major" and \
+            n_per_stream == jump.interval * jump.pos.shape[1] and jump.pos.shape[0] == n_streams:
+        # the batch carries jump points for exactly this decode: every part of a stream on a lane of its own
+        wide, part_status = range_decode_checkpointed(encoded, jump, model, n_per_stream, out=out)
+        status = part_status.amax(dim=1)
+        return (_narrowed(wide, model, narrow_out, dtype), status) if dtype != torch.int32 else (wide, status)
     if out is None:
         shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
         out = torch.empty(shape, dtype=torch.int32, device=dev)
@@ -795,18 +862,35 @@ def _encode_gaussian(fn_name, max_words_fn, symbols, min_symbol, max_symbol, mea
 
 
 def ans_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32, 64, 24), layout="stream_major",
-                        stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
-    """One AnsCoder per stream: encode_reverse(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed."""
-    return _encode_gaussian("cst_ans_encode_gaussian_batch", max_words, symbols, min_symbol, max_symbol, means, stds, config,
-                            layout, stride, out)
+                        stride: Optional[int] = None, out: Optional[EncodedBatch] = None, jump_points="auto") -> EncodedBatch:
+    """One AnsCoder per stream: encode_reverse(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed.
+    jump_points: as for ans_encode ("auto" = cst_jump_points_auto_gaussian: batches the fused encoder takes, of at most one wave of
+    streams per SIMD, get the points that give ans_decode_gaussian two; an integer k; 0)."""
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    interval = _jump_interval(jump_points, n_per, lambda: N.lib().cst_jump_points_auto_gaussian(_cfg(*config), N.CODER_ANS, n_streams, n_per, lay))
+    if interval:
+        if layout != "stream_major":
+            raise ValueError("jump_points: stream-major batches only")
+        if out is None:
+            out = _new_batch(n_streams, stride or max_words(n_per, config), symbols.device, config)
+        ck = _jump_table(out, Checkpoints, interval, n_streams, n_per, symbols.device)
+        ans_encode_gaussian_checkpointed(symbols, min_symbol, max_symbol, means, stds, interval, config, out=(out, ck))
+        out.jump = ck
+        return out
+    out = _encode_gaussian("cst_ans_encode_gaussian_batch", max_words, symbols, min_symbol, max_symbol, means, stds, config,
+                           layout, stride, out)
+    out.jump = None
+    return out
 
 
 def range_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32, 64, 24), layout="stream_major",
                           stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
     """One RangeEncoder per stream: encode(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed
     (src/pybindings/stream/queue.rs:343-410)."""
-    return _encode_gaussian("cst_range_encode_gaussian_batch", range_max_words, symbols, min_symbol, max_symbol, means, stds,
-                            config, layout, stride, out)
+    out = _encode_gaussian("cst_range_encode_gaussian_batch", range_max_words, symbols, min_symbol, max_symbol, means, stds,
+                           config, layout, stride, out)
+    out.jump = None
+    return out
 
 
 def _decode_gaussian(fn_name, ans, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config):
@@ -893,7 +977,13 @@ def release_scratch():
 
 
 def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
-    """One AnsCoder per stream: AnsCoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
+    """One AnsCoder per stream: AnsCoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s]).  A batch that carries
+    jump points for exactly this shape (ans_encode_gaussian, jump_points) decodes every part of a stream on a lane of its own."""
+    jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
+    if isinstance(jump, Checkpoints) and offsets is None and layout == "stream_major" and means.dim() == 2 and \
+            tuple(means.shape) == (jump.pos.shape[0], jump.interval * jump.pos.shape[1]) and jump.pos.shape[0] == encoded.n_words.numel():
+        dec, part_status = ans_decode_gaussian_checkpointed(encoded, jump, min_symbol, max_symbol, means, stds, out=out)
+        return dec, part_status.amax(dim=1)
     return _decode_gaussian("cst_ans_decode_gaussian_batch", True, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)
 
 
@@ -943,7 +1033,7 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
                          torch.zeros((n_streams, n_chunks), dtype=torch.int64, device=dev))
     if narrow != 4:
         L = N.lib()
-        scratch = _ckpt_scratch(("ckpt_widen", torch.cuda.current_stream().cuda_stream), dev, L.cst_ckpt_sym_scratch_bytes(n_streams, n_per, int(interval), narrow))
+        scratch = _ckpt_scratch("ckpt_widen", dev, L.cst_ckpt_sym_scratch_bytes(n_streams, n_per, int(interval), narrow))
         N.check(L.cst_ans_encode_batch_ckpt_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words), stride,
                                                 _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.state), _ptr(out.status), _ptr(scratch),
                                                 _stream_ptr()), "cst_ans_encode_batch_ckpt_sym")
@@ -955,12 +1045,25 @@ def ans_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int, 
 
 
 def _ckpt_scratch(kind, dev, nbytes):
-    """a scratch buffer per purpose and device (per HIP stream where calls on several streams may overlap), grown on demand"""
-    key = (kind, dev.index)
+    """a scratch buffer per purpose, device AND HIP stream (two calls on different streams must not share one: the kernels of
+    both may be in flight), grown on demand.  A buffer is only ever used on the stream it was allocated on -- the stream in its
+    key -- so the caching allocator's stream-ordered reuse holds when a larger one replaces it."""
+    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return buf
+
+
+def _check_jump_shape(checkpoints, n_per_stream: int) -> None:
+    """The C calls index the jump tables as [n_streams][n_per_stream / interval]: a table with another number of points per stream
+    (a prefix decode of a batch encoded with more) would be read with the wrong row stride -- refuse it."""
+    if tuple(checkpoints.pos.shape[1:]) != (n_per_stream // checkpoints.interval,) or n_per_stream % checkpoints.interval != 0:
+        raise ValueError(f"jump points every {checkpoints.interval} symbols, {checkpoints.pos.shape[1]} per stream, do not describe streams of "
+                         f"{n_per_stream} symbols (decode them whole, or without the jump points)")
+    for t in vars(checkpoints).values():
+        if isinstance(t, torch.Tensor) and tuple(t.shape) != tuple(checkpoints.pos.shape):
+            raise ValueError("jump points: tensors of different shapes")
 
 
 def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None,
@@ -979,6 +1082,7 @@ def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_p
     stride_arg = 0 if offsets is not None else encoded.words.shape[1]
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
+    _check_jump_shape(checkpoints, n_per_stream)
     if out is None:
         out = torch.empty((n_streams, n_per_stream), dtype=dtype, device=dev)
     if status is None:
@@ -990,7 +1094,7 @@ def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_p
     if narrow != 4:
         if model.noncontiguous:
             raise ValueError("narrow symbol matrices: contiguous alphabets only")
-        scratch = _ckpt_scratch(("ans_ckpt_sym", torch.cuda.current_stream().cuda_stream), dev,
+        scratch = _ckpt_scratch("ans_ckpt_sym", dev,
                                 L.cst_ckpt_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, narrow))
         N.check(L.cst_ans_decode_batch_ckpt_sym(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets), stride_arg,
                                                 encoded.words.numel(), checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.state), _ptr(out),
@@ -1054,6 +1158,9 @@ def range_decode_checkpointed(encoded, checkpoints: RangeCheckpoints, model: Mod
     n_streams = encoded.n_words.numel()
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
+    _check_jump_shape(checkpoints, n_per_stream)
+    if checkpoints.pos.shape[0] != n_streams:
+        raise ValueError("jump points of another batch: one row per stream")
     if out is None:
         out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
     if status is None:
@@ -1101,6 +1208,9 @@ def ans_decode_gaussian_checkpointed(encoded: EncodedBatch, checkpoints: Checkpo
     means, stds = _gaussian_args(means.shape, means, stds)
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
+    _check_jump_shape(checkpoints, n_per)
+    if checkpoints.pos.shape[0] != n_streams:
+        raise ValueError("jump points of another batch: one row per stream")
     if out is None:
         out = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
     if status is None:

@@ -100,7 +100,10 @@ def load_with_jump_points(path):
     if (len(offsets) != n_streams + 1 or len(words) != total or int(offsets[0]) != 0 or int(offsets[-1]) != total
             or np.any(offsets[1:] < offsets[:-1])):
         raise ValueError("truncated or inconsistent packed-batch container")
-    # (a jump point beyond its stream's words is caught by the decoder: CST_STREAM_INVALID_DATA for that chunk)
+    # a jump point counts words from the start of ITS stream: one beyond the stream's words would make the packed decoders read the
+    # neighbour's (they check a point against the whole buffer and against the stream's first point, not against the stream's end)
+    if jump is not None and np.any(jump[1].astype(np.uint64) > np.diff(offsets.astype(np.uint64))[:, None]):
+        raise ValueError("inconsistent packed-batch container (a jump point beyond its stream's words)")
     return words.astype(np.uint32), offsets.astype(np.uint64), (int(w), int(s), int(p)), jump
 
 

@@ -565,7 +565,7 @@ static bool b16_narrow_shape_ok(const AnsDecodeArgs& a, cst_coder_config cfg, cs
 }
 
 bool b16_narrow_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
-    if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
+    if (knobs().no_n8) return false;                     // (A/B runs: the conversion path)
     if (symbol_bytes != 1 && symbol_bytes != 2) return false;
     if (!b16_narrow_shape_ok(a, cfg, layout, symbol_bytes)) return false;
     return (symbol_bytes == 1 ? b16_narrow_lds_bytes<1, false>(a.n_symbols, a.bucket_bits) : b16_narrow_lds_bytes<2, false>(a.n_symbols, a.bucket_bits)) <= 160 * 1024;
@@ -573,10 +573,9 @@ bool b16_narrow_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_
 
 // ... on the small-footprint form: more streams than one wave per SIMD of this device (symbol_bytes = 1, 2 or 4)
 bool b16_small_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes, int device_cus) {
-    const char* e = getenv("CST_SMALL_KERNELS");         // (A/B runs, as for cst_ans_small.hip: 0 / enc = never the small decoders)
-    if (e && (e[0] == '0' || e[0] == 'e')) return false;
+    if (!knobs().small_decoders) return false;           // (A/B runs, as for cst_ans_small.hip)
     if (symbol_bytes != 1 && symbol_bytes != 2 && symbol_bytes != 4) return false;
-    if (symbol_bytes != 4 && getenv("CST_NO_N8")) return false;
+    if (symbol_bytes != 4 && knobs().no_n8) return false;
     if (a.n_streams <= (size_t)device_cus * kBlock) return false;
     if (!b16_narrow_shape_ok(a, cfg, layout, symbol_bytes)) return false;
     const size_t lds = symbol_bytes == 1 ? b16_narrow_lds_bytes<1, true>(a.n_symbols, a.bucket_bits)

@@ -101,6 +101,21 @@ __global__ void ckpt_spread_status_kernel(const int32_t* __restrict__ per_stream
     if (v < n_streams * n_chunks) out[v] = per_stream[v / n_chunks];
 }
 
+__global__ void ans_ckpt_flag_kernel(const uint32_t* __restrict__ pos, size_t n_streams, size_t n_chunks, size_t stride, int32_t* __restrict__ status) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    const uint32_t whole = pos[v / n_chunks * n_chunks];
+    if (pos[v] > whole || (stride != 0 && whole > stride)) status[v] = CST_STREAM_INVALID_DATA;
+}
+
+cst_status flag_bad_jump_points(const uint32_t* d_ckpt_pos, size_t n_streams, size_t n_chunks, size_t stride_words, int32_t* d_status, hipStream_t hs) {
+    const size_t n = n_streams * n_chunks;
+    if (n == 0) return CST_OK;
+    hipLaunchKernelGGL(ans_ckpt_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, d_ckpt_pos, n_streams, n_chunks, stride_words, d_status);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 } // namespace cst
 
 using namespace cst;
@@ -199,8 +214,10 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
     CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));   // (the raw decode updates its state array)
     // every virtual stream's slice [off(s), off(s) + pos) is checked against the buffer (slab form: against all slabs)
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
-    return cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR,
-                                v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+    const cst_status rc = cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval,
+                                               CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+    if (rc != CST_OK) return rc;
+    return flag_bad_jump_points(d_ckpt_pos, n_streams, n_chunks, d_offsets ? 0 : stride_words, d_status, hs);
 }
 
 // ---- narrow symbol matrices through jump points (round 5) ----
@@ -270,8 +287,10 @@ cst_status cst_ans_decode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
     CST_HIP_TRY(hipGetLastError());
     CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
-    return cst_ans_decode_batch_sym(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, symbol_bytes, n_virtual, ckpt_interval,
-                                    CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, conv_scratch, stream);
+    const cst_status rc = cst_ans_decode_batch_sym(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, symbol_bytes, n_virtual, ckpt_interval,
+                                                   CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, conv_scratch, stream);
+    if (rc != CST_OK) return rc;
+    return flag_bad_jump_points(d_ckpt_pos, n_streams, n_chunks, d_offsets ? 0 : stride_words, d_status, hs);
 }
 
 } // extern "C"

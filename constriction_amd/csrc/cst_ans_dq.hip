@@ -138,7 +138,7 @@ bool dq_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout l
     // 0.274 against 0.296 / 0.368 / 0.255 -- whole 64-byte segments are what single reads among 4 TB/s of writes should look
     // like (scripts/microbench/rw_mix.hip shows the same without any decoder), the tile's read-back burst and the position
     // exchange are what it costs where the words sit in the caches at a well-chosen stride.
-    if (!(a.flags & CST_FLAG_COLD_WORDS) && !getenv("CST_DQ_DECODER")) return false;
+    if (!(a.flags & CST_FLAG_COLD_WORDS) && !knobs().dq_decoder) return false;
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (!a.dec_cp || !a.dec_idx) return false;
     if (a.n_streams == 0 || a.n_streams % kWave != 0) return false;

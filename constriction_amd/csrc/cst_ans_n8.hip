@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kN8SmThreads) void ans_decode_small_n8_kernel(const
 
 // Rows that are whole 128-byte aligned groups (at least one), every stream's words within 2 GiB of the buffer.
 bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout layout, int symbol_bytes) {
-    if (getenv("CST_NO_N8")) return false;               // (A/B runs: the conversion path)
+    if (knobs().no_n8) return false;                     // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 12) return false;
     if (!a.dec_cp || !a.dec_idx) return false;
     if (a.n_streams == 0) return false;                  // (partial waves are taken: their spare lanes repeat the last stream)
@@ -227,8 +227,7 @@ bool n8_decode_usable(const AnsDecodeArgs& a, cst_coder_config cfg, cst_layout l
 
 // more streams than one wave per SIMD of this device (and a table the packed form holds): the small-footprint form
 bool n8_decode_small(const AnsDecodeArgs& a, int device_cus) {
-    const char* e = getenv("CST_SMALL_KERNELS");         // (A/B runs, as for cst_ans_small.hip: 0 / enc = never the small decoder)
-    if (e && (e[0] == '0' || e[0] == 'e')) return false;
+    if (!knobs().small_decoders) return false;           // (A/B runs, as for cst_ans_small.hip)
     return a.n_symbols <= 256 && a.n_streams > (size_t)device_cus * kBlock;
 }
 

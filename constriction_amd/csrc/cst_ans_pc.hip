@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kPcThreads) void ans_encode_pc_n16_kernel(const Ans
 
 // Rows that are whole 128-byte aligned lines of 64 int16 symbols, a table of at most 1024 entries, slabs as for the int32 kernel.
 bool pc_n16_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
+    if (knobs().no_n8 || knobs().no_pc_encoder) return false;      // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
     if (a.n_streams == 0) return false;
     if (a.n_per_stream % 64 != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 23)) return false;
@@ -527,7 +527,7 @@ bool pc_n16_encode_ckpt_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst
 
 // Rows that are whole 128-byte aligned lines, a support inside int8, slabs as for the int32 kernel; any number of streams.
 bool pc_n8_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout) {
-    if (getenv("CST_NO_N8") || getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs: the conversion path)
+    if (knobs().no_n8 || knobs().no_pc_encoder) return false;      // (A/B runs: the conversion path)
     if (cfg.word_bits != 32 || cfg.state_bits != 64 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
     if (a.n_streams == 0) return false;                  // (partial workgroups are taken: their spare lanes repeat the last stream)
     if (a.n_per_stream % kPcN8LineSyms != 0 || a.n_per_stream == 0 || a.n_per_stream >= (1u << 24)) return false;
@@ -577,13 +577,13 @@ cst_status ans_encode_pc_n8_ckpt(const AnsEncodeArgs& a, size_t interval, uint32
 // Any number of streams (partial workgroups since round 5), at most one workgroup per CU (more streams than that: the two-waves-per-SIMD kernels of
 // cst_ans_small.hip), rows that are whole 128-byte aligned tiles, 64-byte aligned slabs of whole 64-byte groups.
 bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {
-    if (getenv("CST_NO_PC_ENCODER")) return false;      // (A/B runs)
+    if (knobs().no_pc_encoder) return false;      // (A/B runs)
     if (cfg.word_bits != 32 || layout != CST_LAYOUT_STREAM_MAJOR || a.precision < 8 || a.precision > 24) return false;
     // 12 < P <= 24 (round 5: the wide step in the coder waves, two word groups per tile in the storers; ans_encode_wide_kernel before)
-    if (a.precision > 12 && (getenv("CST_NO_PC_WIDE") || getenv("CST_PC_COMBINED"))) return false;
+    if (a.precision > 12 && (knobs().no_pc_wide || knobs().pc_combined)) return false;
     (void)device_cus;     // (more than one workgroup per CU: they run one after another, cst_api.hip asks the small-footprint kernels first)
     if (a.n_streams == 0) return false;
-    if (a.n_streams % kBlock != 0 && getenv("CST_PC_COMBINED")) return false;                      // (partial workgroups: the split helpers only)
+    if (a.n_streams % kBlock != 0 && knobs().pc_combined) return false;                      // (partial workgroups: the split helpers only)
     if (a.n_per_stream % kTileSyms != 0 || a.n_per_stream < 2 * kTileSyms || a.n_per_stream >= (1u << 24)) return false;
     if ((reinterpret_cast<uintptr_t>(a.symbols) & 127) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.words) & 63) != 0 || a.stride_words % 16 != 0 || a.stride_words == 0) return false;
@@ -593,7 +593,7 @@ bool pc_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout l
 
 cst_status ans_encode_pc(const AnsEncodeArgs& a, hipStream_t hs) {
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
-    static const bool combined = getenv("CST_PC_COMBINED") != nullptr;      // (A/B runs: every helper wave loads AND stores)
+    const bool combined = knobs().pc_combined;      // (A/B runs: every helper wave loads AND stores)
     auto kernel = a.precision > 12 ? ans_encode_pc_kernel<true, false, true> : combined ? ans_encode_pc_kernel<false> : ans_encode_pc_kernel<true>;
     CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPcLdsBytes));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kPcThreads), kPcLdsBytes, hs, a, PcJumpArgs{nullptr, nullptr, 0u, 0u});

@@ -688,9 +688,8 @@ static int pt_sub_shift(size_t k) {
 // fits.  (CST_PT_SUB_WAVES=8 never takes sixteen: A/B runs.)  The 16-slot statement is for P = 12.
 struct PtSubGeo { int waves; bool ring16; };
 static PtSubGeo pt_sub_geometry(const cst_model* m, int ks) {
-    const char* e = getenv("CST_PT_SUB_WAVES");
     const bool p12 = m->precision == 12;
-    if (!(e && e[0] == '8') && ks >= 3 && p12 && pt_sub_lds_bytes(m, 16, true, ks) <= 160 * 1024) return {16, true};
+    if (!knobs().pt_sub_8_waves && ks >= 3 && p12 && pt_sub_lds_bytes(m, 16, true, ks) <= 160 * 1024) return {16, true};
     if (pt_sub_lds_bytes(m, 8, false, ks) <= 160 * 1024) return {8, false};
     if (p12 && pt_sub_lds_bytes(m, 8, true, ks) <= 160 * 1024) return {8, true};
     return {0, false};

@@ -253,12 +253,7 @@ static size_t small_encode_lds(const AnsEncodeArgs& a) {
 // More streams than one wave per SIMD of this device, and a shape the small-footprint kernels take?
 // CST_SMALL_KERNELS=0 / =enc / =dec (A/B runs): never take the small-footprint kernels / only the encoder / only the decoder
 static bool small_allowed(bool encode) {
-    const char* e = getenv("CST_SMALL_KERNELS");
-    if (!e) return true;
-    if (e[0] == '0') return false;
-    if (e[0] == 'e') return encode;
-    if (e[0] == 'd') return !encode;
-    return true;
+    return encode ? knobs().small_encoders : knobs().small_decoders;
 }
 
 bool small_encode_usable(const AnsEncodeArgs& a, cst_coder_config cfg, cst_layout layout, int device_cus) {

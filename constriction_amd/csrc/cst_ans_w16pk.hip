@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void gather_words16_kernel(const uint16_t* __r
     if (n > stride || off + n > capacity) return;            // (a stream that would end beyond the buffer is not copied)
     const uint16_t* in = src + s * stride;
     uint16_t* out = dst + off;
-    const uint32_t head = min(n, (uint32_t)((8 - (off & 7)) & 7));          // halfwords up to the first 16-byte boundary of dst
+    // halfwords up to the first 16-byte boundary of the DESTINATION ADDRESS (d_packed16 itself need not be 16-byte aligned)
+    const uint32_t head = min(n, (uint32_t)(((16 - (reinterpret_cast<uintptr_t>(out) & 15)) & 15) >> 1));
     if ((uint32_t)lane < head) out[lane] = in[lane];
     const uint32_t n8 = (n - head) >> 3;
     for (uint32_t i = lane; i < n8; i += 64) {

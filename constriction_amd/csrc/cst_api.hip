@@ -232,6 +232,11 @@ __global__ __launch_bounds__(kBlock) void words_reverse_kernel(const uint32_t* i
     if (s >= n_streams) return;
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t n = n_words[s];
+    // counts and offsets are caller data, as for the decoders (word_slice): a stream whose count leaves its slab, or its slice of a
+    // packed buffer (offsets[s + 1] - offsets[s]), is left untouched instead of read / written out of bounds
+    if ((!off_in && stride_in != 0 && n > stride_in) || (!off_out && stride_out != 0 && n > stride_out)) return;
+    if ((off_in && (off_in[s + 1] < off_in[s] || n > off_in[s + 1] - off_in[s])) ||
+        (off_out && (off_out[s + 1] < off_out[s] || n > off_out[s + 1] - off_out[s]))) return;
     const uint32_t* src = in + (off_in ? (size_t)off_in[s] : s * stride_in);
     uint32_t* dst = out + (off_out ? (size_t)off_out[s] : s * stride_out);
     for (uint32_t i = (uint32_t)lane; i < (n + 1) / 2; i += kWave) {

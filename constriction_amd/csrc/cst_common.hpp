@@ -139,6 +139,25 @@ struct cst_model {
 
 namespace cst {
 
+// The dispatcher's A/B switches (include/constriction_amd.h, "Debug switches"): CST_* environment variables, read ONCE when the
+// library is loaded into this struct -- no coder call reads the environment.  cst_debug_reload_knobs() re-reads them (the parity
+// tests that drive an alternate kernel path inside one process).  They select among kernels that produce the SAME words and symbols.
+struct Knobs {
+    bool no_pc_encoder = false;       // CST_NO_PC_ENCODER: never the producer / consumer encoders (cst_ans_pc.hip)
+    bool no_n8 = false;               // CST_NO_N8: int8 / int16 matrices always through the conversion kernels
+    bool no_pc_wide = false;          // CST_NO_PC_WIDE: 12 < P <= 24 on ans_encode_wide_kernel
+    bool pc_combined = false;         // CST_PC_COMBINED: every helper wave of the pc encoder loads AND stores
+    bool dq_decoder = false;          // CST_DQ_DECODER: the lane-quad decoder without CST_FLAG_COLD_WORDS
+    bool small_encoders = true;       // CST_SMALL_KERNELS=0|enc|dec: never / only the encoder / only the decoder of the small-footprint kernels
+    bool small_decoders = true;
+    bool pt_sub_8_waves = false;      // CST_PT_SUB_WAVES=8: the per-stream-table sub-lane decoder never takes sixteen waves
+    bool sub_order_flat = false;      // CST_SUB_ORDER=0: range sub-lane decoder, the chunks of a group side by side
+    int lane_geo = 0;                 // CST_LANE_GEO=big|small: 1 / 2 forces a geometry of the per-symbol lane decoder (0: by shape)
+    size_t fused_min_streams = 16384; // CST_FUSED_MIN_STREAMS: from how many streams the fused per-symbol encoder runs
+    int auto_jump = 1;                // CST_AUTO_JUMP=0: cst_jump_points_auto answers 0 (the plain decoders everywhere)
+};
+const Knobs& knobs();
+
 // thread-local record of the last HIP failure (cst_last_hip_error)
 void set_hip_error(hipError_t e, const char* what);
 // thread-local record of which kernel family the last coder call of this thread launched (cst_last_kernel_name); returns rc
@@ -151,6 +170,10 @@ bool ans_decode_n8_try(const cst_model* model, cst_coder_config cfg, const uint3
                        size_t words_capacity, const uint32_t* d_n_words, void* d_symbols8, int32_t symbol_bytes, size_t n_streams, size_t n_per_stream,
                        cst_layout layout, uint64_t* d_state, uint32_t* d_n_words_out, int32_t* d_status, uint32_t flags, void* stream,
                        cst_status* rc);
+
+// jump tables are caller data: a point that claims more words than its stream's first point (the whole bulk), or than a slab
+// holds (stride_words != 0), flags its chunk CST_STREAM_INVALID_DATA behind the decode (cst_ans_ckpt.hip)
+cst_status flag_bad_jump_points(const uint32_t* d_ckpt_pos, size_t n_streams, size_t n_chunks, size_t stride_words, int32_t* d_status, hipStream_t hs);
 
 #define CST_HIP_TRY(expr)                                      \
     do {                                                       \

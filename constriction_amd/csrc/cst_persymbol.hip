@@ -1528,9 +1528,7 @@ static cst_status encode_two_pass(cst_coder_config cfg, size_t n_streams, size_t
 // for every SIMD pair) the fused kernel is the faster one; below, and for the one long stream of the drop-in API, two passes.
 // (CST_FUSED_MIN_STREAMS in the environment moves the threshold: the parity tests run the fused kernel on small batches.)
 static bool fused_encode_usable(size_t n_streams, size_t n_per_stream) {
-    size_t min_streams = 16384;
-    if (const char* env = getenv("CST_FUSED_MIN_STREAMS")) min_streams = (size_t)strtoull(env, nullptr, 10);
-    return n_streams >= min_streams && n_per_stream >= 1;
+    return n_streams >= knobs().fused_min_streams && n_per_stream >= 1;
 }
 
 template <int KIND>
@@ -1629,8 +1627,8 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
         // more streams than one wave per SIMD: the small geometry, eight waves per CU (CST_LANE_GEO=big|small forces one: A/B runs)
         int cus = 256;
         { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-        const char* geo = getenv("CST_LANE_GEO");
-        const bool small = KIND != kChain && (geo ? geo[0] == 's' : a.n_streams > (size_t)cus * kBlock);
+        const int geo = knobs().lane_geo;
+        const bool small = KIND != kChain && (geo ? geo == 2 : a.n_streams > (size_t)cus * kBlock);
         auto go = [&](auto kernel, int threads, size_t lds) -> cst_status {
             const size_t lane_blocks = (a.n_streams + threads - 1) / threads;
             CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1648,7 +1646,10 @@ static cst_status decode_per_symbol(cst_coder_config cfg, const PerSymbolDecodeA
                                      : go(decode_gaussian_lane_kernel<16, 32, KIND, false>, LaneGeo<false>::kThreads, LaneGeo<false>::kLdsBytes);
         }
         if (rc != CST_OK) return rc;
+        note_kernel(KIND == kChain ? "chain_decode_gaussian_lane_kernel" : KIND == kRange ? (small ? "range_decode_gaussian_lane_kernel<small>" : "range_decode_gaussian_lane_kernel")
+                                   : (small ? "ans_decode_gaussian_lane_kernel<small>" : "ans_decode_gaussian_lane_kernel"), CST_OK);
     } else if (KIND != kChain && gaussian && a.n_symbols < kRowEntries && a.n_per_stream >= 32) {
+        note_kernel("decode_gaussian_by_rows", CST_OK);
         if constexpr (KIND != kChain) return decode_gaussian_by_rows<KIND>(cfg, a, hs);
     } else if (gaussian) {
         if (cfg.word_bits == 32) hipLaunchKernelGGL((decode_wave_kernel<32, 64, KIND, GaussianLeft>), dim3((unsigned)blocks), dim3(kBlock), 0, hs, a);
@@ -1759,8 +1760,9 @@ cst_status cst_ans_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbo
     if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
     hipStream_t hs = (hipStream_t)stream;
     if (fused_encode_usable(n_streams, n_per_stream))
-        return encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words,
-                                           stride_words, d_n_words, d_state, nullptr, d_status, flags, hs);
+        return note_kernel("ans_encode_gaussian_fused_kernel", encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words,
+                                           stride_words, d_n_words, d_state, nullptr, d_status, flags, hs));
+    note_kernel("ans_encode_gaussian_two_pass", CST_OK);
     return encode_two_pass<kAns>(cfg, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, nullptr,
                                  d_status, flags, hs, [&](EncEntry* out, size_t n) {
         hipLaunchKernelGGL(gaussian_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hs, cfg.precision, min_symbol,
@@ -1782,8 +1784,8 @@ cst_status cst_ans_encode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_
     if (!d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0 || ckpt_interval % kFuTile != 0 || n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;
     if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
     if (n_streams == 0) return CST_OK;
-    return encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words, stride_words,
-                                       d_n_words, nullptr, nullptr, d_status, CST_FLAG_NONE, (hipStream_t)stream, ckpt_interval, d_ckpt_pos, d_ckpt_state);
+    return note_kernel("ans_encode_gaussian_fused_kernel<ckpt>", encode_gaussian_fused<kAns>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words, stride_words,
+                                       d_n_words, nullptr, nullptr, d_status, CST_FLAG_NONE, (hipStream_t)stream, ckpt_interval, d_ckpt_pos, d_ckpt_state));
 }
 
 __global__ void gaussian_ckpt_offsets_kernel(const uint64_t* __restrict__ offsets, size_t stride_words, size_t n_streams, size_t n_chunks,
@@ -1808,8 +1810,10 @@ cst_status cst_ans_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_
                        n_streams, n_chunks, d_ckpt_state, v_offsets, v_state);
     CST_HIP_TRY(hipGetLastError());
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
-    return cst_ans_decode_gaussian_batch(cfg, min_symbol, max_symbol, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_means, d_stds, d_symbols, n_virtual,
-                                         ckpt_interval, CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+    const cst_status rc = cst_ans_decode_gaussian_batch(cfg, min_symbol, max_symbol, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_means, d_stds, d_symbols,
+                                                        n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
+    if (rc != CST_OK) return rc;
+    return flag_bad_jump_points(d_ckpt_pos, n_streams, n_chunks, d_offsets ? 0 : stride_words, d_status, (hipStream_t)stream);
 }
 
 cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,

@@ -1035,8 +1035,7 @@ cst_status range_decode_sub(const RangeDecodeArgs& a, hipStream_t hs) {
     const size_t lds = range_decode_sub_lds(a);
     const size_t blocks = ((a.n_streams + kWave - 1) / kWave * a.n_chunks + kRsWaves - 1) / kRsWaves;      // a wave = 64 streams x one chunk
     RangeDecodeArgs b = a;
-    const char* order = getenv("CST_SUB_ORDER");
-    if (order && order[0] == '0') b.flags |= 0x100u;            // (A/B runs: the chunks of a group side by side)
+    if (knobs().sub_order_flat) b.flags |= 0x100u;            // (A/B runs: the chunks of a group side by side)
     auto go = [&](auto kernel) -> cst_status {
         CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kRsThreads), lds, hs, b);

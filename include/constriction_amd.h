@@ -11,7 +11,8 @@
  *    (NULL = the default stream).  All `d_*` pointers are DEVICE pointers (HBM), all `h_*`
  *    pointers are host pointers.  The library never frees caller memory.
  *  - all batched calls are asynchronous on `stream`; results are valid after the caller
- *    synchronises that stream.  Functions are re-entrant; no global mutable state.
+ *    synchronises that stream.  Functions are re-entrant; no coder call writes global state (the only process-wide data are
+ *    the debug switches below: read once when the library is loaded).
  *  - every function returns a cst_status (0 = ok, negative = call-level error).  Per-stream
  *    outcomes go to the caller's `d_status` array (cst_stream_status), mirroring the
  *    reference's per-coder Result values (src/lib.rs:313-316, 376-385).
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CST_ABI_VERSION 4
+#define CST_ABI_VERSION 5
 
 typedef enum cst_status {
     CST_OK = 0,
@@ -431,6 +432,40 @@ cst_status cst_range_decode_batch_ckpt(const cst_model *model, cst_coder_config 
                                        size_t n_streams, size_t n_per_stream, void *d_scratch, int32_t *d_status,
                                        void *stream);
 
+/* ABI 5: which jump points should a batch carry?  Jump points never change a stream's words; what they buy is lanes -- k jump
+ * points per stream let the same words decode on k lanes, and every decoder of this library except the int32 shared-table one
+ * (P <= 12) is latency-bound at one wave of streams per SIMD.  The library's own answer for a batch about to be
+ * ENCODED with the given arguments (the same meaning as in cst_ans_encode_batch_sym / cst_range_encode_batch; symbol_bytes = 1, 2
+ * or 4; d_symbols / d_words / stride_words are looked at for alignment only):
+ *   returns the ckpt_interval to pass to cst_ans_encode_batch_ckpt[_sym] / cst_range_encode_batch_ckpt and to the matching
+ *   *_decode_batch_ckpt call, or 0 = carry none (the plain decoder is as fast, or the shape is not one the checkpointing encoders
+ *   take at the plain encoders' speed).
+ * coder: CST_CODER_ANS or CST_CODER_RANGE.  cst_jump_points_auto_gaussian: the same for cst_ans_encode_gaussian_batch_ckpt (every
+ * symbol its own mean and std).  The Python layer (constriction_amd.batched, jump_points="auto", the default) and the Rust
+ * wrappers ask here; CST_AUTO_JUMP=0 in the environment makes both answer 0. */
+#define CST_CODER_ANS 0
+#define CST_CODER_RANGE 1
+size_t cst_jump_points_auto(const cst_model *model, cst_coder_config cfg, int32_t coder, int32_t symbol_bytes,
+                            const void *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
+                            const void *d_words, size_t stride_words);
+size_t cst_jump_points_auto_gaussian(cst_coder_config cfg, int32_t coder, size_t n_streams, size_t n_per_stream,
+                                     cst_layout layout);
+
+/* Debug switches (ABI 5).  The dispatcher's A/B switches are environment variables read ONCE, when the library is loaded --
+ * no coder call reads the environment.  Each selects among kernels that produce the same words and symbols (the parity suite
+ * runs under every one of them, scripts/alt_paths.sh):
+ *   CST_NO_PC_ENCODER=1      never the producer / consumer encoders          CST_NO_PC_WIDE=1   12 < P <= 24 on ans_encode_wide_kernel
+ *   CST_PC_COMBINED=1        their helper waves load AND store                CST_NO_N8=1        narrow matrices through the conversion kernels
+ *   CST_SMALL_KERNELS=0|enc|dec   never / only the encoder / only the decoder of the small-footprint kernels
+ *   CST_DQ_DECODER=1         the lane-quad decoder without CST_FLAG_COLD_WORDS CST_PT_SUB_WAVES=8 sub-lane decoder: never sixteen waves
+ *   CST_SUB_ORDER=0          range sub-lane decoder: chunks side by side      CST_LANE_GEO=big|small   per-symbol lane decoder geometry
+ *   CST_FUSED_MIN_STREAMS=n  from how many streams the fused per-symbol encoder runs
+ *   CST_AUTO_JUMP=0          cst_jump_points_auto* answer 0
+ * (CST_RCCL_LIB=<path>, read at the first collective call, names the RCCL library to open.)
+ * cst_debug_reload_knobs re-reads them: for tests that drive several paths inside one process; not thread-safe against
+ * concurrent coder calls. */
+void cst_debug_reload_knobs(void);
+
 /* Exclusive prefix sum of d_n_words into d_offsets[n_streams+1] and gather of the slabs into one packed buffer (the
  * concatenation of every stream's `into_compressed()` result) -- ONE kernel (single-pass scan with decoupled
  * look-back, fused with the copy), fully asynchronous on `stream`: no host synchronisation, no allocation.
@@ -457,8 +492,11 @@ cst_status cst_compact_words16(const uint16_t *d_words16, size_t stride_words, c
  * (src/backends.rs:1424-1448; docs :774-803) are its coders over words stored last-written-first, the order in which a decoder
  * consumes them -- what a file or socket that is decoded while it arrives holds.  This entry point converts a batch between the
  * two orders (it is its own inverse); the decoders of this library take the reference's default order.
- *   d_offsets_in / d_offsets_out   packed layouts (offsets[s] = first word of stream s), or NULL for slabs `stride` words apart
- * In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream. */
+ *   d_offsets_in / d_offsets_out   packed layouts (the n_streams + 1 offsets of cst_compact_words: offsets[s] = first word of
+ *                                  stream s), or NULL for slabs `stride` words apart
+ * In place (same buffer, same layout on both sides) is allowed.  One asynchronous kernel, a wave per stream.  A stream whose
+ * count exceeds its slab (stride) or its slice of a packed buffer (offsets[s + 1] - offsets[s]) is left untouched -- counts and
+ * offsets are caller data, and the decoders would report such a stream as CST_STREAM_INVALID_DATA. */
 cst_status cst_words_reverse(const uint32_t *d_words_in, const uint64_t *d_offsets_in, size_t stride_in,
                              const uint32_t *d_n_words, size_t n_streams, uint32_t *d_words_out,
                              const uint64_t *d_offsets_out, size_t stride_out, void *stream);

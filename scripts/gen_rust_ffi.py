@@ -102,6 +102,8 @@ def generate() -> str:
         o.append("")
     for k, v in re.findall(r"#define (CST_FLAG_\w+) (\d+)u", text):
         o.append(f"pub const {k}: u32 = {v};")
+    for k, v in re.findall(r"#define (CST_CODER_\w+) (\d+)\b", text):
+        o.append(f"pub const {k}: i32 = {v};")
     o.append("")
     o += ["/// `cst_model`: opaque, device-resident model image", "#[repr(C)]", "pub struct CstModel {", "    _private: [u8; 0],", "}", ""]
     for name, fields in parse_structs(text):

@@ -43,7 +43,8 @@ with open(out / f"{tag}_kernel_stats.csv", "w", newline="") as f:
     w.writeheader()
     for r in ours:
         w.writerow(r)
-bench = json.loads((g / f"{tag}_stats" / "bench.json").read_text())
+_lines = [json.loads(l) for l in (g / f"{tag}_stats" / "bench.json").read_text().splitlines() if l.startswith("{")]
+bench = next((l["bench_detail"] for l in _lines if "bench_detail" in l), _lines[-1])      # the detail record holds the contract line's keys too
 
 # per-dispatch durations from the kernel trace: the median is what the bench's timed steps see (the --stats average also
 # holds the first launches and bench.py's three `after_cache_flush` launches per headline kernel)

@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_bounds(lib):
     from constriction_amd._native import CoderConfig
-    assert lib.cst_abi_version() == 4
+    assert lib.cst_abi_version() == 5
     # config C2: ceil(4096*12/32) + 2 = 1538
     assert lib.cst_ans_max_words(4096, CoderConfig(32, 64, 12)) == 1552     # 1538 rounded up to 64 bytes
     assert lib.cst_ans_max_words(5, CoderConfig(32, 64, 24)) == 16        # 4 + 2 rounded up

@@ -1,0 +1,265 @@
+"""Jump points by default (ABI 5: cst_jump_points_auto; batched.*_encode(..., jump_points="auto")).
+
+The reference's Pos / Seek (src/stream/stack.rs:1107-1139, src/stream/queue.rs:172-196, 900-926) are side information: with or without
+them a stream's words are the same.  These tests pin exactly that for the library's own choice -- `auto` never changes words, counts,
+status or decoded symbols, against the plain call AND against the CPU oracle -- and the three ways a jump table used to go stale
+(round-5 advisor findings: buffer reuse, a prefix decode, scratch shared between HIP streams)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _same_batch(a, b):
+    assert torch.equal(a.n_words, b.n_words) and torch.equal(a.status, b.status)
+    used = torch.arange(a.words.shape[1], device="cuda")[None, :] < a.n_words[:, None]
+    assert bool(((a.words == b.words) | ~used).all())
+
+
+def _oracle_words(O, coder, sym, lo, cdf, P, enc, every):
+    want_words, want_n, _ = (O.ans_encode_batch if coder == "ans" else O.rc_encode_batch)(sym, lo, cdf, P)
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(0, len(sym), every):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]]), f"stream {s}"
+
+
+SHAPES = [(256, 1024), (300, 4096), (1024, 2048), (4096, 512), (520, 1536)]
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int8, torch.int16], ids=["int32", "int8", "int16"])
+@pytest.mark.parametrize("P", [12, 24])
+@pytest.mark.parametrize("n_streams,n_per", SHAPES)
+def test_auto_jump_points_never_change_results_ans(B, O, dtype, P, n_streams, n_per):
+    lo, hi = -50, 50
+    cdf = O.GaussianModel(lo, hi, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(4242 + P, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(sym).to(dtype)
+    plain = B.ans_encode(d, model, (32, 64, P), jump_points=0)
+    assert plain.jump is None
+    auto = B.ans_encode(d, model, (32, 64, P))                      # the default call
+    # fewer streams than the chip has lanes: the library takes jump points for every kind of batch here
+    assert auto.jump is not None and auto.jump.interval >= 256 and n_per % auto.jump.interval == 0, "auto took no jump points"
+    _same_batch(plain, auto)
+    _oracle_words(O, "ans", sym, lo, cdf, P, auto, max(1, n_streams // 40))
+    wp, ws = O.ans_jump_table(sym, lo, cdf, P, auto.jump.interval)
+    assert np.array_equal(auto.jump.pos.cpu().numpy().view(np.uint32), wp) and np.array_equal(auto.jump.state.cpu().numpy().view(np.uint64), ws)
+    dec_p, st_p = B.ans_decode(plain, model, n_per, dtype=dtype)
+    dec_a, st_a = B.ans_decode(auto, model, n_per, dtype=dtype)
+    assert st_a.shape == st_p.shape and torch.equal(st_a, st_p) and int(st_a.abs().sum()) == 0
+    assert torch.equal(dec_a, dec_p) and torch.equal(dec_a, d)
+
+
+@pytest.mark.parametrize("P", [12, 24])
+@pytest.mark.parametrize("n_streams,n_per", SHAPES)
+def test_auto_jump_points_never_change_results_range(B, O, P, n_streams, n_per):
+    lo, hi = -50, 50
+    cdf = O.GaussianModel(lo, hi, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    sym = O.synth_symbols(777 + P, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(sym)
+    plain = B.range_encode(d, model, (32, 64, P), jump_points=0)
+    auto = B.range_encode(d, model, (32, 64, P))
+    assert plain.jump is None and auto.jump is not None and n_per % auto.jump.interval == 0
+    _same_batch(plain, auto)
+    _oracle_words(O, "range", sym, lo, cdf, P, auto, max(1, n_streams // 40))
+    dec_p, st_p = B.range_decode(plain, model, n_per)
+    dec_a, st_a = B.range_decode(auto, model, n_per)
+    assert torch.equal(st_a, st_p) and int(st_a.abs().sum()) == 0 and torch.equal(dec_a, dec_p) and torch.equal(dec_a, d)
+    d8, s8 = B.range_decode(auto, model, n_per, dtype=torch.int8)
+    assert d8.dtype == torch.int8 and torch.equal(d8.to(torch.int32), d) and int(s8.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n_streams,n_per", [(256, 1024), (512, 4096), (1100, 2048)])
+def test_auto_jump_points_never_change_results_per_stream_tables(B, O, n_streams, n_per):
+    """config C3's shape: one quantized Gaussian per stream, support -127..127"""
+    P, lo, hi = 12, -127, 127
+    rng = np.random.default_rng(n_streams)
+    mu, sd = rng.uniform(-10, 10, n_streams), np.exp(rng.uniform(np.log(0.5), np.log(16.0), n_streams))
+    model = B.Model.quantized_gaussian_per_stream(lo, hi, dev(mu), dev(sd), P)
+    cdfs = np.stack([O.GaussianModel(lo, hi, float(m), float(s), P, 32).cdf_table() for m, s in zip(mu, sd)])
+    sym = np.stack([O.synth_symbols(9, s, 1, n_per, lo, cdfs[s], P)[0] for s in range(n_streams)])
+    d = dev(sym)
+    plain = B.ans_encode(d, model, (32, 64, P), jump_points=0)
+    auto = B.ans_encode(d, model, (32, 64, P))
+    assert auto.jump is not None and auto.jump.pos.shape[1] in (2, 4, 8, 16)
+    _same_batch(plain, auto)
+    want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdfs, P)
+    words, n_words, status = auto.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(0, n_streams, max(1, n_streams // 40)):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]])
+    dec_p, st_p = B.ans_decode(plain, model, n_per)
+    dec_a, st_a = B.ans_decode(auto, model, n_per)
+    assert B.last_kernel() == "ans_decode_pt_sub_kernel"
+    assert torch.equal(st_a, st_p) and int(st_a.abs().sum()) == 0 and torch.equal(dec_a, dec_p) and torch.equal(dec_a, d)
+
+
+def test_auto_jump_points_never_change_results_per_symbol_gaussians(B, O, knob):
+    """f1: every symbol its own (mean, std).  The fused encoder notes the points; CST_FUSED_MIN_STREAMS lets a small batch take it"""
+    n_streams, n_per, lo, hi = 16384, 512, -100, 100
+    rng = np.random.default_rng(3)
+    mu = rng.uniform(-30, 30, (n_streams, n_per)); sd = np.exp(rng.uniform(-1, 3, (n_streams, n_per)))
+    sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), lo, hi).astype(np.int32)
+    plain = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu), dev(sd), jump_points=0)
+    auto = B.ans_encode_gaussian(dev(sym), lo, hi, dev(mu), dev(sd))
+    assert plain.jump is None and auto.jump is not None and auto.jump.interval * auto.jump.pos.shape[1] == n_per
+    assert B.last_kernel() == "ans_encode_gaussian_fused_kernel<ckpt>"
+    _same_batch(plain, auto)
+    for s in (0, 77, n_streams - 1):
+        c = O.AnsCoder()
+        c.encode_gaussian_reverse(sym[s], lo, hi, mu[s], sd[s], 24, 32)
+        assert auto.stream(s).tolist() == c.get_compressed().tolist()
+    dec_p, st_p = B.ans_decode_gaussian(plain, lo, hi, dev(mu), dev(sd))
+    dec_a, st_a = B.ans_decode_gaussian(auto, lo, hi, dev(mu), dev(sd))
+    assert torch.equal(st_a, st_p) and int(st_a.abs().sum()) == 0 and torch.equal(dec_a, dec_p) and np.array_equal(dec_a.cpu().numpy(), sym)
+
+
+def test_what_auto_answers_for_the_baseline_shapes(B, O):
+    """the policy itself (no coding): BASELINE.json's shapes at 65 536 x 4096 and the shapes that must NOT get jump points"""
+    from constriction_amd import _native as N
+    L = N.lib()
+    slots = torch.cuda.get_device_properties(0).multi_processor_count * 256
+    n, n_per, stride = slots, 4096, 2016
+
+    def ask(model, P, coder=N.CODER_ANS, nbytes=4, n_streams=n, per=n_per, layout=N.LAYOUT_STREAM_MAJOR):
+        return L.cst_jump_points_auto(model._h, N.CoderConfig(32, 64, P), coder, nbytes, None, n_streams, per, layout, None, 4096)
+
+    m12 = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, 12)
+    m24 = B.Model.quantized_gaussian(-50, 50, 3.2, 9.6, 24)
+    assert ask(m12, 12) == 0                                     # C2, int32: the plain decoder is at its floor (the headline is untouched)
+    assert ask(m12, 12, nbytes=1) == n_per // 2                  # C2 int8: two lanes per stream
+    assert ask(m12, 12, nbytes=2) == n_per // 2
+    assert ask(m24, 24) == n_per // 2 and ask(m24, 24, nbytes=1) == n_per // 2
+    assert ask(m12, 12, coder=N.CODER_RANGE) == n_per // 2 and ask(m24, 24, coder=N.CODER_RANGE) == n_per // 2      # C4
+    assert ask(m12, 12, n_streams=2 * n) == 0 and ask(m12, 12, nbytes=1, n_streams=2 * n) == 0                    # the C5 shard: two waves per SIMD already
+    assert ask(m12, 12, n_streams=n // 2) == n_per // 2          # half a chip of int32 streams: filled
+    assert ask(m12, 12, n_streams=n // 2, nbytes=1) == n_per // 4
+    assert ask(m12, 12, layout=N.LAYOUT_SYMBOL_MAJOR) == 0 and ask(m12, 12, nbytes=1, per=100) == 0 and ask(m12, 12, nbytes=1, per=384) == 0
+    assert L.cst_jump_points_auto(m12._h, N.CoderConfig(16, 32, 12), N.CODER_ANS, 1, None, n, n_per, 0, None, 4096) == 0       # other presets
+    assert L.cst_jump_points_auto_gaussian(N.CoderConfig(32, 64, 24), N.CODER_ANS, n, n_per, 0) == n_per // 2     # f1
+    assert L.cst_jump_points_auto_gaussian(N.CoderConfig(32, 64, 24), N.CODER_ANS, 100, n_per, 0) == 0            # (two-pass encoder: no points)
+    assert L.cst_jump_points_auto_gaussian(N.CoderConfig(32, 64, 24), N.CODER_ANS, 2 * n, n_per, 0) == 0
+    rng = np.random.default_rng(1)
+    mu, sd = rng.uniform(-10, 10, 2048), np.exp(rng.uniform(np.log(0.5), np.log(16.0), 2048))
+    pt = B.Model.quantized_gaussian_per_stream(-127, 127, dev(mu), dev(sd), 12)
+    assert ask(pt, 12, n_streams=2048) in (n_per // 8, n_per // 16)                                                # C3: eight lanes per stream or more
+
+
+def test_switching_auto_off(B, O, knob):
+    P, lo = 12, -50
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    d = dev(O.synth_symbols(1, 0, 256, 1024, lo, cdf, P))
+    assert B.ans_encode(d, model, (32, 64, P)).jump is not None
+    knob(CST_AUTO_JUMP="0")
+    assert B.ans_encode(d, model, (32, 64, P)).jump is None and B.range_encode(d, model, (32, 64, P)).jump is None
+
+
+# ---- the ways a jump table went stale (advisor, round 5) ----
+
+def test_a_jump_table_does_not_survive_buffer_reuse(B, O):
+    P, lo, n_streams, n_per = 12, -50, 512, 1024
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    a, b = dev(O.synth_symbols(10, 0, n_streams, n_per, lo, cdf, P)), dev(O.synth_symbols(11, 0, n_streams, n_per, lo, cdf, P))
+    enc = B.ans_encode(a, model, (32, 64, P), jump_points=4)
+    table = enc.jump
+    assert table is not None
+    again = B.ans_encode(b, model, (32, 64, P), jump_points=0, out=enc)            # other symbols, no jump points, the same buffers
+    assert again is enc and enc.jump is None
+    dec, st = B.ans_decode(enc, model, n_per)
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, b)
+    # ... and jump points asked for on a batch that has none: coded into THAT batch (only the table is allocated)
+    words_ptr = enc.words.data_ptr()
+    third = B.ans_encode(a, model, (32, 64, P), jump_points=2, out=enc)
+    assert third is enc and enc.words.data_ptr() == words_ptr and enc.jump.pos.shape == (n_streams, 2)
+    assert torch.equal(B.ans_decode(enc, model, n_per)[0], a)
+    fourth = B.ans_encode(b, model, (32, 64, P), jump_points=2, out=enc)           # the same form again: the table itself is reused
+    assert fourth.jump is third.jump or fourth.jump.pos.data_ptr() == third.jump.pos.data_ptr()
+    assert torch.equal(B.ans_decode(enc, model, n_per)[0], b)
+    # replacing the words or the counts drops the table (it describes the words the encoder wrote)
+    enc.n_words = enc.n_words.clone()
+    assert enc.jump is None
+    # the range coder's calls keep the same rules
+    r = B.range_encode(a, model, (32, 64, P), jump_points=4)
+    assert r.jump is not None and B.range_encode(b, model, (32, 64, P), jump_points=0, out=r).jump is None
+    assert torch.equal(B.range_decode(r, model, n_per)[0], b)
+
+
+def test_a_prefix_decode_does_not_take_the_jump_points(B, O):
+    """decoding FEWER symbols than were encoded is legal for the plain ANS decoder (the first symbols of every stream); a table with
+    four points per stream must not be read as one with two"""
+    P, lo, n_streams, n_per = 12, -50, 384, 2048
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    d = dev(O.synth_symbols(12, 0, n_streams, n_per, lo, cdf, P))
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=4)
+    half, st = B.ans_decode(enc, model, n_per // 2)
+    assert int(st.abs().sum()) == 0 and torch.equal(half, d[:, : n_per // 2])
+    with pytest.raises(ValueError):
+        B.ans_decode_checkpointed(enc, enc.jump, model, n_per // 2)
+    r = B.range_encode(d, model, (32, 64, P), jump_points=4)
+    with pytest.raises(ValueError):
+        B.range_decode_checkpointed(r, r.jump, model, n_per // 2)
+    assert torch.equal(B.range_decode(r, model, n_per // 2)[0], d[:, : n_per // 2])
+
+
+def test_jump_decodes_on_two_hip_streams_do_not_share_scratch(B, O):
+    P, lo, n_streams, n_per = 12, -50, 2048, 2048
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    syms = [dev(O.synth_symbols(20 + i, 0, n_streams, n_per, lo, cdf, P)) for i in range(2)]
+    encs = [B.ans_encode(s, model, (32, 64, P), jump_points=8) for s in syms]
+    rencs = [B.range_encode(s, model, (32, 64, P), jump_points=8) for s in syms]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [[], []]
+    for _ in range(6):
+        for i, hs in enumerate(streams):
+            with torch.cuda.stream(hs):
+                outs[i].append(B.ans_decode(encs[i], model, n_per)[0])
+                outs[i].append(B.range_decode(rencs[i], model, n_per)[0])
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert all(torch.equal(o, syms[i]) for o in outs[i])
+    keys = [k for k in B._scratch if isinstance(k, tuple) and k[0] in ("ans_ckpt", "range_ckpt")]
+    assert len({k[-1] for k in keys}) >= 2          # one buffer per HIP stream
+
+
+def test_corrupt_jump_points_are_flagged(B, O):
+    """a point that claims more words than its stream's first point (the whole bulk), or than the slab holds, flags its chunk"""
+    P, lo, n_streams, n_per = 12, -50, 256, 1024
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    d = dev(O.synth_symbols(31, 0, n_streams, n_per, lo, cdf, P))
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=4)
+    enc.jump.pos[5, 2] = enc.jump.pos[5, 0] + 1
+    enc.jump.pos[9, 0] = enc.words.shape[1] + 1
+    dec, st = B.ans_decode_checkpointed(enc, enc.jump, model, n_per)
+    st = st.cpu().numpy()
+    assert st[5, 2] == 3 and (st[9] == 3).all()
+    st[5, 2] = 0; st[9] = 0
+    assert (st == 0).all()
+    ok = np.ones(n_streams, bool); ok[[5, 9]] = False
+    assert torch.equal(dec[torch.from_numpy(ok).cuda()], d[torch.from_numpy(ok).cuda()])

@@ -24,8 +24,11 @@ def test_bench_with_two_ranks_on_one_gpu():
                          capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints ONE line
-    line = json.loads(lines[0])
+    assert len(lines) == 2, res.stdout[-2000:]                      # rank 0 prints the detail record, then THE line
+    assert "bench_detail" in json.loads(lines[0])
+    assert len(lines[-1]) < 4096
+    line = json.loads(lines[-1])
+    assert "roofline" in line and "configs" not in line and "after_cache_flush" not in line
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["rccl_ranks_seen"] == 2
     assert sorted(r["rank"] for r in line["per_rank"]) == [0, 1]

@@ -162,8 +162,8 @@ def test_per_stream_jump_points_corrupt_positions(B, O):
 # ---------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n_streams,n_per,interval", [(64, 64, 16), (130, 96, 32), (70, 128, 64), (256, 48, 48)], ids=lambda v: str(v))
-def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, monkeypatch):
-    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")          # the fused encoder on small batches (it is the one that notes jump points)
+def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, knob):
+    knob(CST_FUSED_MIN_STREAMS="1")          # the fused encoder on small batches (it is the one that notes jump points)
     rng = np.random.default_rng(n_streams + n_per)
     mu = rng.uniform(-30, 30, (n_streams, n_per)); sd = np.exp(rng.uniform(-1, 3, (n_streams, n_per)))
     sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), -100, 100).astype(np.int32)

@@ -31,11 +31,14 @@ def dev(a):
 
 
 def _dq(fn):
+    from constriction_amd import _native
     os.environ["CST_DQ_DECODER"] = "1"
+    _native.reload_knobs()            # (the library reads its switches once, at load)
     try:
         return fn()
     finally:
         del os.environ["CST_DQ_DECODER"]
+        _native.reload_knobs()
 
 
 @pytest.mark.parametrize("P", [8, 11, 12])

@@ -171,11 +171,11 @@ def test_small_footprint_kernels_at_the_maximum_rate(B, O, dtype, frac):
 @pytest.mark.parametrize("frac", [0.0, 0.02, 0.2])
 @pytest.mark.parametrize("coder", ["ans", "range"])
 @pytest.mark.parametrize("geo", ["big", "small"])
-def test_per_symbol_gaussian_decoders_at_the_maximum_rate(B, O, monkeypatch, coder, geo, frac):
+def test_per_symbol_gaussian_decoders_at_the_maximum_rate(B, O, knob, coder, geo, frac):
     """f1 (every symbol its own mean and std) at 24 bits per symbol: needle-thin models far from their symbol -- the leaky
     quantizer's floor of 2^-24 -- with a likely symbol here and there; both geometries of the lane decoder (CST_LANE_GEO), both
     coders, and the jump-point form of the ANS coder"""
-    monkeypatch.setenv("CST_LANE_GEO", geo)
+    knob(CST_LANE_GEO=geo)
     rng = np.random.default_rng(int(frac * 1000) + 5)
     n_streams, n_per, lo, hi = 128, 512, -100, 100
     sym = rng.integers(60, 101, (n_streams, n_per)).astype(np.int32)
@@ -300,8 +300,8 @@ def test_per_stream_table_decoder_at_the_maximum_rate_on_packed_words(B, O, frac
 @pytest.mark.parametrize("frac", [0.0, 0.02])
 @pytest.mark.parametrize("coder", ["ans", "range"])
 @pytest.mark.parametrize("geo", ["big", "small"])
-def test_per_symbol_gaussian_decoders_at_the_maximum_rate_on_packed_words(B, O, monkeypatch, coder, geo, frac):
-    monkeypatch.setenv("CST_LANE_GEO", geo)
+def test_per_symbol_gaussian_decoders_at_the_maximum_rate_on_packed_words(B, O, knob, coder, geo, frac):
+    knob(CST_LANE_GEO=geo)
     rng = np.random.default_rng(int(frac * 1000) + 6)
     n_streams, n_per, lo, hi = 128, 512, -100, 100
     sym = rng.integers(60, 101, (n_streams, n_per)).astype(np.int32)

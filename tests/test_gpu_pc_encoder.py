@@ -31,11 +31,14 @@ def dev(a):
 
 
 def _one_wave(fn):
+    from constriction_amd import _native
     os.environ["CST_NO_PC_ENCODER"] = "1"
+    _native.reload_knobs()            # (the library reads its switches once, at load)
     try:
         return fn()
     finally:
         del os.environ["CST_NO_PC_ENCODER"]
+        _native.reload_knobs()
 
 
 def _aligned_symbols(sym):

@@ -41,10 +41,10 @@ def workload(n_streams, n_per, lo, hi, seed):
 @pytest.mark.parametrize("n_streams,n_per", [(1, 300), (65, 40), (1000, 21)])
 @pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
 @pytest.mark.parametrize("encoder", ["two_pass", "fused"])
-def test_gaussian_per_symbol_batch_parity(B, O, coder, cfg, n_streams, n_per, layout, encoder, monkeypatch):
+def test_gaussian_per_symbol_batch_parity(B, O, coder, cfg, n_streams, n_per, layout, encoder, knob):
     # batches of >= 16 384 streams take the fused encoder kernel (entries computed and coded in one kernel, nothing but inputs
     # and words in HBM); CST_FUSED_MIN_STREAMS moves that threshold so that the small parity shapes run it too
-    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1" if encoder == "fused" else "1000000000")
+    knob(CST_FUSED_MIN_STREAMS="1" if encoder == "fused" else "1000000000")
     W, S, P = cfg
     lo, hi = (-100, 100) if P == 24 else (-60, 60)
     sym, mu, sd = workload(n_streams, n_per, lo, hi, n_streams * 13 + n_per + P)
@@ -179,12 +179,12 @@ def test_release_scratch(B):
 
 
 @pytest.mark.parametrize("P", [8, 13, 17, 18, 19, 21, 23, 24])
-def test_fused_encoder_step_variants(B, O, P, monkeypatch):
+def test_fused_encoder_step_variants(B, O, P, knob):
     """The fused Gaussian encoder codes with entries that carry 1 / p as an f64 from P = 18 on (encode_step_inv: the quotient
     from one f64 product, within 0.27 of the true one at P = 18) and with floor(2^64 / p) below: both sides of that switch,
     the precisions next to it, symbols of probability 1 / 2^P (far off the means) next to near-certain ones; words of every
     stream against the oracle."""
-    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")
+    knob(CST_FUSED_MIN_STREAMS="1")
     lo, hi = -100, 100
     n_streams, n_per = 70, 16 * 12 + 5
     rng = np.random.default_rng(P)
@@ -206,12 +206,12 @@ def test_fused_encoder_step_variants(B, O, P, monkeypatch):
 @pytest.mark.parametrize("coder", ["ans", "range"])
 @pytest.mark.parametrize("layout", ["stream_major", "symbol_major"])
 @pytest.mark.parametrize("n_per", [16, 32, 80, 96])
-def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, n_per, monkeypatch):
+def test_fused_encoder_walks_whole_tiles(B, O, coder, layout, n_per, knob):
     """Full waves (a multiple of 32 streams) over rows of whole 16-symbol tiles: the fused Gaussian encoder then walks its three
     input matrices by adding strides to one running index per lane instead of computing every item's index (the shape of the
     bench's f1 entry), and in stream-major matrices asks for the symbols of both tiles of a 128-byte line at once (one tile, one
     pair, an odd and an even number of tiles); 96 streams in both layouts and both coders, words against the oracle."""
-    monkeypatch.setenv("CST_FUSED_MIN_STREAMS", "1")
+    knob(CST_FUSED_MIN_STREAMS="1")
     lo, hi, P = -100, 100, 24
     n_streams = 96
     sym, mu, sd = workload(n_streams, n_per, lo, hi, 4242 + n_per)

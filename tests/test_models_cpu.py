@@ -155,7 +155,7 @@ def test_packed_batch_container_with_a_jump_table(tmp_path):
     lens = rng.integers(1, 9, n_streams)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     words = rng.integers(0, 2 ** 32, int(offsets[-1]), dtype=np.uint64).astype(np.uint32)
-    jump = SimpleNamespace(interval=64, pos=rng.integers(0, 9, (n_streams, k)).astype(np.int32),
+    jump = SimpleNamespace(interval=64, pos=rng.integers(0, lens[:, None] + 1, (n_streams, k)).astype(np.int32),      # (points lie within their streams)
                            state=rng.integers(0, 2 ** 63, (n_streams, k), dtype=np.int64))
     path = tmp_path / "jump.cst"
     container.save(path, words, offsets, (32, 64, 12), jump_points=jump)
@@ -179,3 +179,9 @@ def test_packed_batch_container_with_a_jump_table(tmp_path):
         container.load_with_jump_points(tmp_path / "huge.cst")
     with pytest.raises(ValueError):
         container.save(tmp_path / "bad.cst", words, offsets, (32, 64, 12), jump_points=SimpleNamespace(interval=64, pos=jump.pos[:-1], state=jump.state[:-1]))
+    # a jump point beyond its stream's words would make a packed decoder read the neighbour's: refused when the file is read
+    beyond = jump.pos.copy()
+    beyond[4, 1] = lens[4] + 1
+    container.save(tmp_path / "beyond.cst", words, offsets, (32, 64, 12), jump_points=SimpleNamespace(interval=64, pos=beyond, state=jump.state))
+    with pytest.raises(ValueError):
+        container.load_with_jump_points(tmp_path / "beyond.cst")
