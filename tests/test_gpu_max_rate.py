@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from kernel_names import with_jump  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 # (runs of the suite through the alternate kernel paths -- profiles/r05_alt_paths.txt -- do not take the kernels the tests name)
 ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED", "CST_NO_PC_WIDE"))
@@ -118,9 +120,10 @@ def test_per_stream_table_decoders_at_the_maximum_rate(B, O, frac):
         assert int(s2.abs().sum()) == 0 and np.array_equal(d2.cpu().numpy(), sym), f"k = {chunks}"
 
 
+@pytest.mark.parametrize("jp", [0, "auto"], ids=["plain", "auto_jump"])
 @pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
 @pytest.mark.parametrize("P", [12, 8])
-def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac):
+def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac, jp):
     """the loops that read / write int8 matrices themselves (cst_ans_n8.hip, ans_encode_pc_n8_kernel): 12 words per 32-symbol tile,
     refills on every phase, four tiles per pass of the decoder's statement"""
     n = 101
@@ -130,8 +133,9 @@ def test_int8_native_kernels_at_the_maximum_rate(B, O, P, frac):
     sym = high_rate_symbols(rng, 256, 2048, n, frac)
     want_words, want_n, _ = O.ans_encode_batch(sym, 0, cdf, P, 32, 64)
     d = dev(sym.astype(np.int8))
-    enc = B.ans_encode(d, model, (32, 64, P))
-    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=jp)        # (auto: max-rate words THROUGH jump points noted on the way)
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_n8_kernel", enc)
+    assert (enc.jump is not None) == (jp == "auto")
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
     for s in range(256):
@@ -317,9 +321,10 @@ def test_per_symbol_gaussian_decoders_at_the_maximum_rate_on_packed_words(B, O, 
     assert int(st.abs().sum()) == 0 and np.array_equal(dec.cpu().numpy(), sym), B.last_kernel()
 
 
+@pytest.mark.parametrize("jp", [0, "auto"], ids=["plain", "auto_jump"])
 @pytest.mark.parametrize("frac", [0.0, 0.01, 0.2])
 @pytest.mark.parametrize("n_streams", [256, "small"])
-def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
+def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac, jp):
     """the decoders that write int16 matrices themselves (two tiles per pass), one and two waves per SIMD, slabs and packed words"""
     P, n = 12, 101
     if n_streams == "small":
@@ -331,9 +336,9 @@ def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
     rng = np.random.default_rng(int(frac * 1000) + 17)
     sym = high_rate_symbols(rng, n_streams, n_per, n, frac) + 1000
     d = dev(sym.astype(np.int16))
-    enc = B.ans_encode(d, model, (32, 64, P))
-    assert ALT or B.last_kernel() == "ans_encode_pc_n16_kernel"
-    plain = B.ans_encode(dev(sym), model, (32, 64, P))
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=jp)
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_n16_kernel", enc)
+    plain = B.ans_encode(dev(sym), model, (32, 64, P), jump_points=jp)
     assert torch.equal(enc.n_words, plain.n_words) and int(enc.status.abs().sum()) == 0
     used = torch.arange(plain.words.shape[1], device="cuda")[None, :] < plain.n_words[:, None]
     assert bool(((enc.words == plain.words) | ~used).all()), "the int16 encoder's words differ from the int32 encoder's"
@@ -346,10 +351,11 @@ def test_int16_native_decoders_at_the_maximum_rate(B, O, n_streams, frac):
     assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
 
 
+@pytest.mark.parametrize("jp", [0, "auto"], ids=["plain", "auto_jump"])
 @pytest.mark.parametrize("frac", [0.0, 0.01, 0.05, 0.2])
 @pytest.mark.parametrize("P", [24, 16])
 @pytest.mark.parametrize("dtype", ["int8", "int16"])
-def test_narrow_high_precision_kernels_at_the_maximum_rate(B, O, dtype, P, frac):
+def test_narrow_high_precision_kernels_at_the_maximum_rate(B, O, dtype, P, frac, jp):
     """ans_decode_b16_narrow_kernel at 24 words per 32-symbol tile (P = 24: every symbol of probability 2^-24), slabs and packed words;
     the tails also take the statement's out-of-line walk over the cdf table on nearly every step"""
     n = 101
@@ -359,9 +365,9 @@ def test_narrow_high_precision_kernels_at_the_maximum_rate(B, O, dtype, P, frac)
     sym = high_rate_symbols(rng, 200, 2048, n, frac)
     dt = torch.int8 if dtype == "int8" else torch.int16
     d = dev(sym).to(dt)
-    enc = B.ans_encode(dev(sym), model, (32, 64, P))
-    narrow = B.ans_encode(d, model, (32, 64, P))            # ... and the narrow encoder (its storer moves two word groups per tile)
-    assert ALT or B.last_kernel() == "ans_encode_pc_n%d_kernel<wide>" % (8 * d.element_size())
+    enc = B.ans_encode(dev(sym), model, (32, 64, P), jump_points=jp)
+    narrow = B.ans_encode(d, model, (32, 64, P), jump_points=jp)            # ... and the narrow encoder (its storer moves two word groups per tile)
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_n%d_kernel<wide>" % (8 * d.element_size()), narrow)
     assert torch.equal(narrow.n_words, enc.n_words) and int(narrow.status.abs().sum()) == 0
     wa, na, _ = enc.to_numpy()
     wb, _, _ = narrow.to_numpy()

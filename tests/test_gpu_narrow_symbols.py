@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from kernel_names import with_jump  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 # (runs of the suite through the alternate kernel paths -- profiles/r05_alt_paths.txt -- do not take the kernels the tests name)
 ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED", "CST_NO_PC_WIDE"))
@@ -82,10 +84,11 @@ def _aligned_i8(host):
     return t
 
 
+@pytest.mark.parametrize("jp", [0, "auto"], ids=["plain", "auto_jump"])
 @pytest.mark.parametrize("P", [8, 10, 12])
 @pytest.mark.parametrize("support", [(-50, 50), (-128, 127), (5, 60), (-128, -100), (0, 0 + 1)], ids=lambda s: "%d..%d" % s)
 @pytest.mark.parametrize("n_streams,n_per", [(256, 128), (256, 256), (512, 384), (256, 4096), (768, 1152)])
-def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n_per):
+def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n_per, jp):
     """the kernels that read / write the int8 matrix themselves: words, counts and status of the CPU oracle on the widened values
     (every stream), decoded symbols = the input.  Shapes: one line per row (no previous group to store, no second line to stage),
     two lines, an odd number of lines, the headline row length, several workgroups."""
@@ -97,8 +100,8 @@ def test_int8_native_kernels_code_like_the_oracle(B, O, P, support, n_streams, n
     sym = O.synth_symbols(1000 + P, 0, n_streams, n_per, lo, cdf, P)
     want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
     d = _aligned_i8(sym)
-    enc = B.ans_encode(d, model, (32, 64, P))
-    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    enc = B.ans_encode(d, model, (32, 64, P), jump_points=jp)
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_n8_kernel", enc)
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
@@ -125,7 +128,7 @@ def test_int8_native_kernels_report_what_int32_reports(B, O):
     bad = sym.copy()
     bad[3, 10] = 51; bad[69, 0] = -128; bad[70, 255] = 127; bad[255, 128] = -51
     enc = B.ans_encode(_aligned_i8(bad), model, (32, 64, P))
-    assert ALT or B.last_kernel() == "ans_encode_pc_n8_kernel"
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_n8_kernel", enc)
     torch.cuda.synchronize()
     words, n_words, st = enc.to_numpy()
     flagged = [3, 69, 70, 255]
@@ -403,7 +406,7 @@ def test_int16_native_encoder_codes_like_the_oracle(B, O, P, support, n_streams,
         assert ALT or B.last_kernel() == _pc_name(2, P, True)
     else:
         enc = B.ans_encode(d, model, (32, 64, P))
-        assert ALT or B.last_kernel() == _pc_name(2, P)
+        assert ALT or B.last_kernel() == with_jump(_pc_name(2, P), enc)
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert status.tolist() == want_st.tolist()
@@ -460,7 +463,7 @@ def test_narrow_kernels_at_high_precision(B, O, dtype, P, n_streams, n_per):
     d = torch.from_numpy(sym).to(dtype).cuda()
     enc = B.ans_encode(d, model, (32, 64, P))
     if d.data_ptr() % 128 == 0 and n_per % (128 // d.element_size()) == 0:
-        assert ALT or B.last_kernel() == _pc_name(d.element_size(), P)
+        assert ALT or B.last_kernel() == with_jump(_pc_name(d.element_size(), P), enc)
     torch.cuda.synchronize()
     want_words, want_n, _ = O.ans_encode_batch(sym, lo, cdf, P)
     words, n_words, status = enc.to_numpy()

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from kernel_names import with_jump  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -49,8 +51,9 @@ def _aligned_symbols(sym):
 
 
 @pytest.mark.parametrize("P", [8, 11, 12, 13, 16, 24])          # (12 < P <= 24, round 5: the wide step in the coder waves, two word groups per tile)
+@pytest.mark.parametrize("jp", [0, "auto"], ids=["plain", "auto_jump"])
 @pytest.mark.parametrize("n_streams,n_per", [(256, 64), (256, 96), (512, 160), (1024, 992), (768, 4096), (300, 128)])
-def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per):
+def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per, jp):
     lo, hi = -60, 60
     cdf = O.GaussianModel(lo, hi, 2.5, 7.0 if P > 8 else 9.0, P, 32).cdf_table()
     model = B.Model.from_cdf(cdf, lo, P)
@@ -60,8 +63,8 @@ def test_pc_encoder_matches_the_oracle(B, O, P, n_streams, n_per):
     sym[200, 0] = 2 ** 30
     sym[255, n_per // 2] = -2 ** 31
     want_words, want_n, want_status = O.ans_encode_batch(sym, lo, cdf, P)
-    enc = B.ans_encode(_aligned_symbols(sym), model, (32, 64, P))
-    assert ALT or B.last_kernel() == ("ans_encode_pc_kernel<wide>" if P > 12 else "ans_encode_pc_kernel")
+    enc = B.ans_encode(_aligned_symbols(sym), model, (32, 64, P), jump_points=jp)
+    assert ALT or B.last_kernel() == with_jump("ans_encode_pc_kernel<wide>" if P > 12 else "ans_encode_pc_kernel", enc)
     torch.cuda.synchronize()
     words, n_words, status = enc.to_numpy()
     assert status.tolist() == want_status.tolist() and sorted(np.flatnonzero(status).tolist()) == [3, 70, 200, 255]
