@@ -280,13 +280,17 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
         enc = enc_fn(symbols, model, cfg, stride=stride, **kw)      # stride "tuned": batched.tuned_stride, like the headline batch
     decoded = torch.empty_like(symbols)
     enc_ms = event_ms(lambda: enc_fn(symbols, model, cfg, out=enc, **kw), reps)
+    enc_kernel = B.last_kernel()
     dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded, **kw), reps)
+    dec_kernel = B.last_kernel()
     total_words = enc.total_words()
     n_sym = n_streams * n_per
     byts = 4 * n_sym + (cfg[0] // 8) * total_words       # algorithmic: W-bit words (16-bit words sit in 32-bit slots: the TRAFFIC is larger)
     entry = {
         "workload": name, "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per,
-        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
+        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "encode_kernel": enc_kernel, "decode_kernel": dec_kernel,
+        # the calls above are the DEFAULT calls (jump_points="auto"): how many jump points per stream the library took for this batch
+        "jump_points": int(enc.jump.pos.shape[1]) if enc.jump is not None else 0,
         "Msymbols_per_s": round(n_sym / (enc_ms + dec_ms) / 1e3, 1), "words_per_stream": round(total_words / n_streams, 2),
         "slab_stride_words": int(enc.words.shape[1]),
         "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -294,8 +298,22 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
     }
     if cdf_host is not None and np.asarray(cdf_host).ndim == 1:
         entry.update(rate_report(total_words, n_sym, cfg[0], model_entropy_bits(cdf_host, cfg[2])))
+    plain_ok = True
+    if enc.jump is not None:
+        # for the record: the same batch WITHOUT jump points (jump_points=0: what the default call was before round 6); same words
+        plain = enc_fn(symbols, model, cfg, stride=int(enc.words.shape[1]), jump_points=0, **kw)
+        plain_dec = torch.empty_like(symbols)
+        pe = event_ms(lambda: enc_fn(symbols, model, cfg, out=plain, jump_points=0, **kw), reps)
+        pd = event_ms(lambda: dec_fn(plain, model, n_per, out=plain_dec, **kw), reps)
+        entry["without_jump_points"] = {"encode_ms": round(pe, 4), "decode_ms": round(pd, 4), "decode_kernel": B.last_kernel(),
+                                        "decode_speedup_of_the_default": round(pd / dec_ms, 3)}
+        if check:
+            used = torch.arange(plain.words.shape[1], device=symbols.device)[None, :] < plain.n_words[:, None]
+            plain_ok = bool(torch.equal(plain_dec, symbols)) and bool(torch.equal(plain.n_words, enc.n_words)) and \
+                bool(((plain.words == enc.words) | ~used).all())
+        del plain, plain_dec
     if check:
-        ok = bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
+        ok = plain_ok and bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
         if ok and cdf_host is not None:
             words, n_words, _ = enc.to_numpy()
             host_sym = symbols.cpu().numpy() if layout == "stream_major" else np.ascontiguousarray(symbols.cpu().numpy().T)
@@ -316,7 +334,7 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
     ans = coder == "ans"
     enc_ck = B.ans_encode_checkpointed if ans else B.range_encode_checkpointed
     dec_ck = B.ans_decode_checkpointed if ans else B.range_decode_checkpointed
-    plain = (B.ans_encode if ans else B.range_encode)(symbols, model, cfg)
+    plain = (B.ans_encode if ans else B.range_encode)(symbols, model, cfg, jump_points=0)
     decoded = torch.empty_like(symbols)
     plain_dec_ms = event_ms(lambda: (B.ans_decode if ans else B.range_decode)(plain, model, n_per, out=decoded), reps)
     plain_kernel = B.last_kernel()
@@ -378,6 +396,7 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
     cfg = cfg or (W, S, P)
     narrow = symbols.to(dtype)
     nb = narrow.element_size()
+    from constriction_amd import _native
     enc = B.ans_encode(narrow, model, cfg)
     enc_kernel = B.last_kernel()
     decoded = torch.empty_like(narrow)
@@ -391,21 +410,30 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
     entry = {"workload": f"{name} with {str(dtype).replace('torch.', '')} symbol matrices " +
                          ("(read / written by the coder loops themselves)" if native else "(widened / narrowed on the device next to the coder call)"),
              "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
-             "encode_kernel": enc_kernel, "decode_kernel": dec_kernel,
+             "encode_kernel": enc_kernel, "decode_kernel": dec_kernel, "jump_points": int(enc.jump.pos.shape[1]) if enc.jump is not None else 0,
              "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_streams * n_per / (enc_ms + dec_ms) / 1e3, 1),
              "slab_stride_words": int(enc.words.shape[1]),
              "algorithmic_bytes_per_symbol": round(byts / (n_streams * n_per), 3),
              "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if native:
         entry["bound"] = "instruction issue of one wave per SIMD (not HBM): see DESIGN.md 4.13"
+    if enc.jump is not None:
+        plain8 = B.ans_encode(narrow, model, cfg, jump_points=0)
+        pe = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=plain8, jump_points=0), reps)
+        pd = event_ms(lambda: B.ans_decode(plain8, model, n_per, out=decoded), reps)
+        entry["without_jump_points"] = {"encode_ms": round(pe, 4), "decode_ms": round(pd, 4), "decode_kernel": B.last_kernel(),
+                                        "decode_speedup_of_the_default": round(pd / dec_ms, 3)}
+        del plain8
+        B.ans_decode(enc, model, n_per, out=decoded)
     if check:
-        plain = B.ans_encode(symbols, model, cfg)
+        plain = B.ans_encode(symbols, model, cfg, jump_points=0)
         used = torch.arange(plain.words.shape[1], device=symbols.device)[None, :] < plain.n_words[:, None]
         entry["bit_exact"] = bool(torch.equal(decoded, narrow)) and bool(torch.equal(enc.n_words, plain.n_words)) and \
             bool(((enc.words == plain.words) | ~used).all()) and int(enc.status.abs().sum().item()) == 0
         entry["bit_exact_scope"] = "words and counts of every stream vs the int32 call's (compared with the CPU oracle in the headline check), decoded symbols vs input"
     if native:
         os.environ["CST_NO_N8"] = "1"
+        _native.reload_knobs()           # (the library reads its debug switches once, when it is loaded)
         try:
             c_enc = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
             ck = B.last_kernel()
@@ -414,6 +442,7 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
                                         "Msymbols_per_s": round(n_streams * n_per / (c_enc + c_dec) / 1e3, 1)}
         finally:
             del os.environ["CST_NO_N8"]
+            _native.reload_knobs()
     return entry
 
 
@@ -450,26 +479,32 @@ def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100,
              "words_per_stream": round(total_words / n_streams, 2), "algorithmic_bytes_per_symbol": round(byts / n_sym, 3),
              "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-    # the same batch decoded through two jump points per stream (cst_ans_*_gaussian_batch_ckpt: the fused encoder notes them, the
-    # small-geometry lane decoder runs two waves per SIMD on the 131 072 (stream, chunk) pairs); words are the plain call's
+    entry["jump_points"] = int(enc.jump.pos.shape[1]) if enc.jump is not None else 0
+    entry["encode_kernel"], entry["decode_kernel"] = "", ""
+    B.ans_encode_gaussian(sym, lo, hi, mu, sd, cfg, out=enc); entry["encode_kernel"] = B.last_kernel()
+    B.ans_decode_gaussian(enc, lo, hi, mu, sd, out=decoded); entry["decode_kernel"] = B.last_kernel()
+    # the calls above are the DEFAULT calls: the fused encoder notes two jump points per stream on its way and the small-geometry lane
+    # decoder runs two waves per SIMD on the 131 072 (stream, chunk) pairs.  For the record, the same batch without (jump_points=0:
+    # the default before round 6); the words are the same
     jump_ok = True
-    try:
-        pair = B.ans_encode_gaussian_checkpointed(sym, lo, hi, mu, sd, n_per // 2, cfg)
-        st2 = torch.empty((n_streams, 2), dtype=torch.int32, device=dev)
-        dec2 = torch.zeros_like(sym)
-        je = event_ms(lambda: B.ans_encode_gaussian_checkpointed(sym, lo, hi, mu, sd, n_per // 2, cfg, out=pair), reps)
-        jd = event_ms(lambda: B.ans_decode_gaussian_checkpointed(pair[0], pair[1], lo, hi, mu, sd, out=dec2, status=st2), reps)
-        entry["with_2_jump_points"] = {"encode_ms": round(je, 4), "decode_ms": round(jd, 4), "decode_speedup": round(dec_ms / jd, 3),
-                                       "decode_frac": round(byts / (jd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-        if check:
-            used = torch.arange(min(512, int(enc.words.shape[1])), device=dev)[None, :] < enc.n_words[:, None]
-            w = used.shape[1]
-            jump_ok = bool(torch.equal(dec2, sym)) and int(st2.abs().sum().item()) == 0 and bool(torch.equal(pair[0].n_words, enc.n_words)) and \
-                bool(((pair[0].words[:, :w] == enc.words[:, :w]) | ~used).all())
-        del pair, st2, dec2
-    except Exception as exc:      # noqa: BLE001
-        entry["with_2_jump_points"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-        jump_ok = False
+    if enc.jump is not None:
+        try:
+            plain = B.ans_encode_gaussian(sym, lo, hi, mu, sd, cfg, jump_points=0)
+            dec2 = torch.zeros_like(sym)
+            pe = event_ms(lambda: B.ans_encode_gaussian(sym, lo, hi, mu, sd, cfg, out=plain, jump_points=0), reps)
+            pd = event_ms(lambda: B.ans_decode_gaussian(plain, lo, hi, mu, sd, out=dec2), reps)
+            entry["without_jump_points"] = {"encode_ms": round(pe, 4), "decode_ms": round(pd, 4), "decode_kernel": B.last_kernel(),
+                                            "decode_speedup_of_the_default": round(pd / dec_ms, 3),
+                                            "decode_frac": round(byts / (pd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            if check:
+                used = torch.arange(min(512, int(enc.words.shape[1])), device=dev)[None, :] < enc.n_words[:, None]
+                w = used.shape[1]
+                jump_ok = bool(torch.equal(dec2, sym)) and bool(torch.equal(plain.n_words, enc.n_words)) and \
+                    bool(((plain.words[:, :w] == enc.words[:, :w]) | ~used).all())
+            del plain, dec2
+        except Exception as exc:      # noqa: BLE001
+            entry["without_jump_points"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            jump_ok = False
     if check:
         ok = bool(torch.equal(decoded, sym)) and int(enc.status.abs().sum().item()) == 0 and jump_ok
         if ok:

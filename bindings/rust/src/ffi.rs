@@ -533,6 +533,16 @@ extern "C" {
 
     pub fn cst_ckpt_scratch_bytes(n_streams: usize, n_per_stream: usize, ckpt_interval: usize) -> usize;
 
+    /// ABI 5: the per-chunk status of a *_decode_batch_ckpt call as one status per stream (the worst of its chunks: what the plain
+    /// decoder of the whole stream reports in d_status[s]).  d_chunk_status[n_streams][n_chunks] -> d_stream_status[n_streams].
+    pub fn cst_ckpt_status_per_stream(
+        d_chunk_status: *const i32,
+        n_streams: usize,
+        n_chunks: usize,
+        d_stream_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     pub fn cst_ans_decode_batch_ckpt(
         model: *const CstModel,
         cfg: CstCoderConfig,

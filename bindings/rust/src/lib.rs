@@ -471,6 +471,19 @@ pub struct DecodedBatch {
     pub status: DeviceBuffer<i32>,
 }
 
+impl DecodedBatch {
+    /// The per-chunk status of a `*_from_checkpoints` decode (`n_streams * n_chunks` entries) as one status per stream -- the worst of
+    /// its chunks, what the plain decoder of the whole stream reports (`cst_ckpt_status_per_stream`).
+    pub fn status_per_stream(&self, n_streams: usize, n_chunks: usize, stream: &Stream) -> Result<DeviceBuffer<i32>> {
+        if n_chunks == 0 || self.status.len() < n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)? {
+            return Err(Error::InvalidArgument);
+        }
+        let mut out: DeviceBuffer<i32> = DeviceBuffer::new(n_streams)?;
+        check(unsafe { ffi::cst_ckpt_status_per_stream(self.status.as_ptr(), n_streams, n_chunks, out.as_mut_ptr(), stream.as_raw()) })?;
+        Ok(out)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ANS: many `AnsCoder<Word, State>` at once
 // ---------------------------------------------------------------------------------------------------------------------

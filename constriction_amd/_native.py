@@ -81,6 +81,7 @@ SIGNATURES = {
     "cst_ans_decode_batch": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp]),
     "cst_ans_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
+    "cst_ckpt_status_per_stream": (_i32, [_vp, _z, _z, _vp, _vp]),
     "cst_ans_decode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_ans_encode_batch_ckpt_sym": (_i32, [_vp, CoderConfig, _vp, _i32, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_ckpt_sym_scratch_bytes": (_z, [_z, _z, _z, _i32]),

@@ -494,7 +494,7 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
         # the batch carries jump points for exactly this decode (ans_encode, jump_points): every part of a stream on a lane of its
         # own.  (A prefix of the streams, n_per_stream < what was encoded, is a plain decode: the table's rows have another stride.)
         dec, part_status = ans_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype if out is None else out.dtype)
-        return dec, part_status.amax(dim=1)
+        return dec, _status_per_stream(part_status)
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
         stride = words.shape[1]
@@ -809,7 +809,7 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
             n_per_stream == jump.interval * jump.pos.shape[1] and jump.pos.shape[0] == n_streams:
         # the batch carries jump points for exactly this decode: every part of a stream on a lane of its own
         wide, part_status = range_decode_checkpointed(encoded, jump, model, n_per_stream, out=out)
-        status = part_status.amax(dim=1)
+        status = _status_per_stream(part_status)
         return (_narrowed(wide, model, narrow_out, dtype), status) if dtype != torch.int32 else (wide, status)
     if out is None:
         shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
@@ -983,7 +983,7 @@ def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="st
     if isinstance(jump, Checkpoints) and offsets is None and layout == "stream_major" and means.dim() == 2 and \
             tuple(means.shape) == (jump.pos.shape[0], jump.interval * jump.pos.shape[1]) and jump.pos.shape[0] == encoded.n_words.numel():
         dec, part_status = ans_decode_gaussian_checkpointed(encoded, jump, min_symbol, max_symbol, means, stds, out=out)
-        return dec, part_status.amax(dim=1)
+        return dec, _status_per_stream(part_status)
     return _decode_gaussian("cst_ans_decode_gaussian_batch", True, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)
 
 
@@ -1053,6 +1053,14 @@ def _ckpt_scratch(kind, dev, nbytes):
     if buf is None or buf.numel() < nbytes:
         buf = _scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return buf
+
+
+def _status_per_stream(part_status: torch.Tensor) -> torch.Tensor:
+    """[n_streams, n_chunks] -> [n_streams]: a stream's status is the worst of its chunks' (cst_ckpt_status_per_stream)"""
+    n_streams, n_chunks = part_status.shape
+    out = torch.empty(n_streams, dtype=torch.int32, device=part_status.device)
+    N.check(N.lib().cst_ckpt_status_per_stream(_ptr(part_status), n_streams, n_chunks, _ptr(out), _stream_ptr()), "cst_ckpt_status_per_stream")
+    return out
 
 
 def _check_jump_shape(checkpoints, n_per_stream: int) -> None:

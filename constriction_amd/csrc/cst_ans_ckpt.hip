@@ -77,13 +77,23 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ckpt_kernel(const CkptEncod
     a.n_words[s] = (status == CST_STREAM_OK) ? n_words : 0u;
 }
 
-// offsets of the virtual streams: every chunk of stream s reads stream s's words
+// the virtual streams' offsets (every chunk of stream s reads stream s's words) and states (the raw decode updates its state array:
+// a copy) -- one launch in front of the decoder
 __global__ void ckpt_offsets_kernel(const uint64_t* __restrict__ offsets, size_t stride_words, size_t n_streams, size_t n_chunks,
-                                    uint64_t* __restrict__ out) {
+                                    const uint64_t* __restrict__ state_in, uint64_t* __restrict__ out, uint64_t* __restrict__ state_out) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_streams * n_chunks) return;
     const size_t s = v / n_chunks;
     out[v] = offsets ? offsets[s] : s * stride_words;
+    state_out[v] = state_in[v];
+}
+
+__global__ void ckpt_status_per_stream_kernel(const int32_t* __restrict__ chunk_status, size_t n_streams, size_t n_chunks, int32_t* __restrict__ out) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    int32_t worst = 0;
+    for (size_t j = 0; j < n_chunks; ++j) worst = max(worst, chunk_status[s * n_chunks + j]);
+    out[s] = worst;
 }
 
 // decoding WITHOUT the jump points (the words are the plain encoder's): chunk 0's jump point is the whole stream --
@@ -209,9 +219,9 @@ cst_status cst_ans_decode_batch_ckpt(const cst_model* model, cst_coder_config cf
     }
     uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
     uint64_t* v_state = v_offsets + n_virtual;
-    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);
+    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks,
+                       d_ckpt_state, v_offsets, v_state);
     CST_HIP_TRY(hipGetLastError());
-    CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));   // (the raw decode updates its state array)
     // every virtual stream's slice [off(s), off(s) + pos) is checked against the buffer (slab form: against all slabs)
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
     const cst_status rc = cst_ans_decode_batch(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, n_virtual, ckpt_interval,
@@ -252,6 +262,15 @@ cst_status cst_ans_encode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
                                      d_ckpt_state, d_status, stream);
 }
 
+cst_status cst_ckpt_status_per_stream(const int32_t* d_chunk_status, size_t n_streams, size_t n_chunks, int32_t* d_stream_status, void* stream) {
+    if (n_streams == 0) return CST_OK;
+    if (!d_chunk_status || !d_stream_status || n_chunks == 0) return CST_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(ckpt_status_per_stream_kernel, dim3((unsigned)((n_streams + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_chunk_status, n_streams,
+                       n_chunks, d_stream_status);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
 size_t cst_ckpt_sym_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval, int32_t symbol_bytes) {
     return cst_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) + cst_symbols_scratch_bytes(n_streams, n_per_stream, symbol_bytes) + 16;
 }
@@ -283,9 +302,9 @@ cst_status cst_ans_decode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
     hipStream_t hs = (hipStream_t)stream;
     uint64_t* v_offsets = reinterpret_cast<uint64_t*>(d_scratch);
     uint64_t* v_state = v_offsets + n_virtual;
-    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks, v_offsets);
+    hipLaunchKernelGGL(ckpt_offsets_kernel, dim3((unsigned)((n_virtual + 255) / 256)), dim3(256), 0, hs, d_offsets, stride_words, n_streams, n_chunks,
+                       d_ckpt_state, v_offsets, v_state);
     CST_HIP_TRY(hipGetLastError());
-    CST_HIP_TRY(hipMemcpyAsync(v_state, d_ckpt_state, 8 * n_virtual, hipMemcpyDeviceToDevice, hs));
     const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
     const cst_status rc = cst_ans_decode_batch_sym(model, cfg, d_words, v_offsets, 0, capacity, d_ckpt_pos, d_symbols, symbol_bytes, n_virtual, ckpt_interval,
                                                    CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, conv_scratch, stream);

@@ -969,7 +969,13 @@ __global__ __launch_bounds__(LaneGeo<SMALL>::kThreads) void decode_gaussian_lane
 
     // ---- parameter tiles: item w = it * 64 + lane of a tile is (stream j, symbol tl), consecutive lanes on consecutive
     // addresses in either layout ----
-    double mu_r[kParTile], sd_r[kParTile];
+    // SMALL geometry, stream-major: a tile is 8 symbols = HALF a 128-byte line of doubles per stream.  Requested tile by tile, every
+    // line of means and stds came in twice, ~16 000 cycles apart (round 5's counters: 10.24 GB per launch against 5.49 GB
+    // algorithmic).  So a request there covers a PAIR of tiles -- whole lines, the big geometry's item mapping -- and the second
+    // tile's half waits in the registers it arrived in: landed when its tile begins (mode 1 -> 2 -> 0 below).
+    constexpr int kReqTile = 16;                              // symbols a request can cover (= kParTile of the big geometry)
+    double mu_r[kReqTile], sd_r[kReqTile];
+    int mode = 0;                                             // (wave-uniform) 0: the registers hold ONE tile (or nothing); 1 / 2: a pair, its first / second half lands next
     // item `it` of a tile that lies wholly inside the matrix: element base_e + t0 * t_stride + it * item_stride (stream-major:
     // stream s0 + lane / 16 + 4 it, symbol t0 + lane % 16; symbol-major: symbol t0 + it, stream s0 + lane), LDS slot
     // base_l + it * l_stride -- pointer increments; tiles that stick out (last streams, last symbols) take the general form
@@ -977,7 +983,21 @@ __global__ __launch_bounds__(LaneGeo<SMALL>::kThreads) void decode_gaussian_lane
     const size_t t_stride = symbol_major ? a.n_streams : 1, item_stride = symbol_major ? a.n_streams : (size_t)(kWave / kParTile) * N;
     const int base_l = symbol_major ? lane : (lane % kParTile) * kParStride + lane / kParTile;
     const int l_stride = symbol_major ? kParStride : kWave / kParTile;
+    const bool pairs = SMALL && !symbol_major && s0 + kWave <= a.n_streams;
     auto par_request = [&](size_t t0) {
+        if (SMALL && pairs && t0 % kReqTile == 0 && t0 + kReqTile <= N) {
+            const size_t e = (s0 + (size_t)(lane / kReqTile)) * N + (size_t)(lane % kReqTile) + t0;
+            const double* pm = a.means + e;
+            const double* ps = a.stds + e;
+#pragma unroll
+            for (int it = 0; it < kReqTile; ++it) {
+                mu_r[it] = __builtin_nontemporal_load(pm + (size_t)it * (size_t)(kWave / kReqTile) * N);
+                sd_r[it] = __builtin_nontemporal_load(ps + (size_t)it * (size_t)(kWave / kReqTile) * N);
+            }
+            mode = 1;
+            return;
+        }
+        mode = 0;
         if (s0 + kWave <= a.n_streams && t0 + kParTile <= N) {
             const double* pm = a.means + base_e + t0 * t_stride;
             const double* ps = a.stds + base_e + t0 * t_stride;
@@ -1001,6 +1021,19 @@ __global__ __launch_bounds__(LaneGeo<SMALL>::kThreads) void decode_gaussian_lane
         }
     };
     auto par_land = [&]() {
+        if (SMALL && mode != 0) {
+            // half (mode - 1) of the pair: the lanes that hold symbols 8 (mode - 1) .. + 7 of the sixteen write theirs
+            const int sub = (lane % kReqTile) - kParTile * (mode - 1);
+            if (sub >= 0 && sub < kParTile) {
+#pragma unroll
+                for (int it = 0; it < kReqTile; ++it) {
+                    par_mu[sub * kParStride + lane / kReqTile + (kWave / kReqTile) * it] = mu_r[it];
+                    par_sd[sub * kParStride + lane / kReqTile + (kWave / kReqTile) * it] = sd_r[it];
+                }
+            }
+            mode = mode == 1 ? 2 : 0;
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < kParTile; ++it) {
             par_mu[base_l + it * l_stride] = mu_r[it];
@@ -1042,7 +1075,7 @@ __global__ __launch_bounds__(LaneGeo<SMALL>::kThreads) void decode_gaussian_lane
         wave_lds_fence();                                     // (the previous tile's parameters have been read)
         par_land();
         win_land();
-        if (t0 + kParTile < N) par_request(t0 + kParTile);
+        if (t0 + kParTile < N && mode != 2) par_request(t0 + kParTile);      // (mode 2: the next tile's parameters are here already)
         win_request(window_of(1));                            // (the words one tile further: used from the next tile on)
         wave_lds_fence();
         const int n_here = (int)(N - t0 < (size_t)kParTile ? N - t0 : (size_t)kParTile);

@@ -367,6 +367,10 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model *model, cst_coder_config cf
                                      size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
                                      uint32_t *d_ckpt_pos, uint64_t *d_ckpt_state, int32_t *d_status, void *stream);
 size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval);
+/* ABI 5: the per-chunk status of a *_decode_batch_ckpt call as one status per stream (the worst of its chunks: what the plain
+ * decoder of the whole stream reports in d_status[s]).  d_chunk_status[n_streams][n_chunks] -> d_stream_status[n_streams]. */
+cst_status cst_ckpt_status_per_stream(const int32_t *d_chunk_status, size_t n_streams, size_t n_chunks,
+                                      int32_t *d_stream_status, void *stream);
 cst_status cst_ans_decode_batch_ckpt(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
                                      const uint64_t *d_offsets, size_t stride_words, size_t words_capacity, size_t ckpt_interval,
                                      const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_state, int32_t *d_symbols,
