@@ -844,6 +844,62 @@ def other_configs(B, rank, world, dist, args, reps=5):
     return out
 
 
+def headline_side_legs(B, args, world, model, symbols, enc, decoded):
+    """what the line reports beside the timed step, on the same batch: compaction, the host -> device -> host leg, the same two
+    kernels after cache flushes.  Returns (compact_ms, end_to_end or None, after_cache_flush)."""
+    packed, offsets = B.compact(enc)
+    compact_ms = event_ms(lambda: B.compact(enc, out=(packed, offsets)), 5)
+    e2e = None
+    if world == 1 and not args.no_end_to_end:
+        try:
+            e2e = end_to_end(B, model, symbols)
+        except Exception as exc:      # noqa: BLE001
+            e2e = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        try:      # the same with int8 symbol matrices (the alphabet has 101 symbols): a quarter of the symbol bytes on the link
+            e2e["int8_symbols"] = end_to_end(B, model, symbols, dtype=torch.int8)
+        except Exception as exc:      # noqa: BLE001
+            e2e["int8_symbols"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
+    # The timed steps decode what the encoder has just written.  For the record, the same two kernels after a 1-GiB fill
+    # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):
+    flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+
+    def after_flush_ms(fn, reps=3, clean=False):
+        total = 0.0
+        for _ in range(reps):
+            if clean:
+                flush.view(torch.int32).sum()      # a 1-GiB READ: the caches end up full of clean lines
+            else:
+                flush.fill_(1)                     # a 1-GiB fill: ... of DIRTY lines, whose write-back the launch then shares HBM with
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            total += e0.elapsed_time(e1)
+        return total / reps
+    # words WITHOUT provenance: the same buffers as a caller holds them who got the words from the host, a peer or a file (the
+    # library then decides for itself: batched._words_are_cold)
+    foreign = B.EncodedBatch(enc.words, enc.n_words, enc.status, enc.config)
+    cold = {"encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc)), 4),
+            "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded)), 4),
+            "decode_kernel": B.last_kernel(),
+            "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False)), 4),
+            "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True)), 4),
+            "what": "same batch, a 1-GiB fill before every launch (nothing of it left in L2 or the Infinity Cache).  decode_ms: the default "
+                    "call on words whose provenance the library does not know (as they arrive from the host, a peer, a file): it takes the "
+                    "lane-quad decoder (cst_ans_dq.hip) by itself; decode_chunk_loads_ms: the decoder of the timed steps forced (cold=False); "
+                    "decode_cold_words_hint_ms: CST_FLAG_COLD_WORDS passed explicitly"}
+    cold["hint_bit_exact"] = bool(torch.equal(decoded, symbols))
+    cold["after_a_1GiB_read_instead"] = {
+        "encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc), clean=True), 4),
+        "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded), clean=True), 4),
+        "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False), clean=True), 4),
+        "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True), clean=True), 4),
+        "what": "the same with the caches full of clean lines (a fill leaves 288 MiB of dirty lines whose write-back competes with the launch)"}
+    del flush
+
+    return compact_ms, e2e, cold
+
+
 # ---- the output contract: ONE small last line, everything else beside it ----
 LINE_LIMIT = 4096          # bytes; round 5's 21-KB line was not parsed by the driver (BENCH_r05.json: parsed null)
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -944,6 +1000,9 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host -> device -> host leg (pinned buffers, chunked over HIP streams)")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` block")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed step and nothing else on the GPU: no configs, no end-to-end leg, no cache-flush legs, no compaction, no CPU "
+                         "baseline -- the run whose rocprofv3 kernel trace holds ONLY the headline pair's hot launches (scripts/profile_round.sh)")
     ap.add_argument("--graph", action="store_true", help="replay the timed step as a HIP graph instead of launching eagerly")
     ap.add_argument("--slab-stride", default="tuned",
                     help="words between the headline batch's slabs: 'tuned' (batched.tuned_stride measures it before the warmup), "
@@ -956,6 +1015,8 @@ def main():
                          "variable-length gather of per-stream words to rank 0, max-over-ranks timing) on host tensors -- "
                          "what tests/test_dist_cpu.py drives with --backend gloo in the CPU-only build container")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_configs = args.no_end_to_end = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # start our own ranks: one process per GPU on this node, rendezvous on 127.0.0.1
@@ -1076,55 +1137,10 @@ def main():
             scope = f"all {n_streams} streams of rank 0: words and counts vs CPU oracle; decoded symbols vs input on every rank"
             del words
 
-    packed, offsets = B.compact(enc)
-    compact_ms = event_ms(lambda: B.compact(enc, out=(packed, offsets)), 5)
+    compact_ms, cold = None, None
     e2e = None
-    if world == 1 and not args.no_end_to_end:
-        try:
-            e2e = end_to_end(B, model, symbols)
-        except Exception as exc:      # noqa: BLE001
-            e2e = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-        try:      # the same with int8 symbol matrices (the alphabet has 101 symbols): a quarter of the symbol bytes on the link
-            e2e["int8_symbols"] = end_to_end(B, model, symbols, dtype=torch.int8)
-        except Exception as exc:      # noqa: BLE001
-            e2e["int8_symbols"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-
-    # The timed steps decode what the encoder has just written.  For the record, the same two kernels after a 1-GiB fill
-    # (nothing of the batch left in L2 or the 256-MiB Infinity Cache; DESIGN.md 3.8 "working sets beyond the caches"):
-    flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-
-    def after_flush_ms(fn, reps=3, clean=False):
-        total = 0.0
-        for _ in range(reps):
-            if clean:
-                flush.view(torch.int32).sum()      # a 1-GiB READ: the caches end up full of clean lines
-            else:
-                flush.fill_(1)                     # a 1-GiB fill: ... of DIRTY lines, whose write-back the launch then shares HBM with
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); fn(); e1.record()
-            torch.cuda.synchronize()
-            total += e0.elapsed_time(e1)
-        return total / reps
-    # words WITHOUT provenance: the same buffers as a caller holds them who got the words from the host, a peer or a file (the
-    # library then decides for itself: batched._words_are_cold)
-    foreign = B.EncodedBatch(enc.words, enc.n_words, enc.status, enc.config)
-    cold = {"encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc)), 4),
-            "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded)), 4),
-            "decode_kernel": B.last_kernel(),
-            "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False)), 4),
-            "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True)), 4),
-            "what": "same batch, a 1-GiB fill before every launch (nothing of it left in L2 or the Infinity Cache).  decode_ms: the default "
-                    "call on words whose provenance the library does not know (as they arrive from the host, a peer, a file): it takes the "
-                    "lane-quad decoder (cst_ans_dq.hip) by itself; decode_chunk_loads_ms: the decoder of the timed steps forced (cold=False); "
-                    "decode_cold_words_hint_ms: CST_FLAG_COLD_WORDS passed explicitly"}
-    cold["hint_bit_exact"] = bool(torch.equal(decoded, symbols))
-    cold["after_a_1GiB_read_instead"] = {
-        "encode_ms": round(after_flush_ms(lambda: B.ans_encode(symbols, model, (W, S, P), out=enc), clean=True), 4),
-        "decode_ms": round(after_flush_ms(lambda: B.ans_decode(foreign, model, N_PER, out=decoded), clean=True), 4),
-        "decode_chunk_loads_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=False), clean=True), 4),
-        "decode_cold_words_hint_ms": round(after_flush_ms(lambda: B.ans_decode(enc, model, N_PER, out=decoded, cold=True), clean=True), 4),
-        "what": "the same with the caches full of clean lines (a fill leaves 288 MiB of dirty lines whose write-back competes with the launch)"}
-    del flush
+    if not args.headline_only:
+        compact_ms, e2e, cold = headline_side_legs(B, args, world, model, symbols, enc, decoded)
 
     # N > 1: every rank's own kernel times and how many ranks RCCL really connected (a scaling run diagnoses itself)
     per_rank, ranks_seen = None, None
@@ -1156,7 +1172,7 @@ def main():
                 traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this command, scripts/pmc_all.sh)"
             except Exception:
                 traffic = None
-        dom_cold_ms = cold["encode_ms"] if dominant == enc_kernel else cold["decode_ms"]
+        dom_cold_ms = None if cold is None else (cold["encode_ms"] if dominant == enc_kernel else cold["decode_ms"])
         line = {
             "metric": "Msymbols/s encode+decode, 64k x 4k-symbol streams, bit-exact vs CPU",
             "value": round(world * n_sym * args.steps / elapsed / 1e6, 1),
@@ -1170,12 +1186,12 @@ def main():
                                    "encode into slabs + decode; u64 coder state, u32 words, i32 symbols", "streams_per_gpu": n_streams, "symbols_per_stream": N_PER,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "bit_exact": ok, "bit_exact_scope": scope, "launch": launch_mode,
-            "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": round(compact_ms, 4), "after_cache_flush": cold,
+            "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "compact_ms": None if compact_ms is None else round(compact_ms, 4), "after_cache_flush": cold,
             "words_per_stream": round(total_words / n_streams, 2), "rate": rate_report(total_words, n_sym, W, model_entropy_bits(cdf, P)),
             "slab_stride_words": int(enc.words.shape[1]), "slab_stride_source": args.slab_stride,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "frac_cold": round(bytes_per_launch / (dom_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "frac_cold": None if dom_cold_ms is None else round(bytes_per_launch / (dom_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(dom_ms, 4),
                          "encode_GBps": round(bytes_per_launch / (enc_ms * 1e-3) / 1e9, 1),

@@ -102,6 +102,30 @@ for r in ours:
     med = f" / {statistics.median(durations[k]):.1f}" if durations.get(k) else ""
     lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f}{med} | {fk:.0f} | {2 * fk * 1024 / 2**30:.3f} | {wk:.0f} | "
                  f"{hbm:.3e} | {alg} | {'' if not h else f'{h / (h + m):.3f}'} |")
+# ---- the timed loop's own rows: the kernel trace of `bench.py --headline-only` (nothing but hot launches of the headline pair) ----
+hl = g / f"{tag}_headline"
+if (hl / "bench_kernel_trace.csv").exists():
+    hl_lines = [json.loads(l) for l in (hl / "bench.json").read_text().splitlines() if l.startswith("{")]
+    hb = next((l["bench_detail"] for l in hl_lines if "bench_detail" in l), hl_lines[-1])
+    alg = hb["roofline"]["algorithmic_bytes_per_launch"]
+    rows_h = collections.defaultdict(list)
+    for r in csv.DictReader(open(hl / "bench_kernel_trace.csv")):
+        if "cst::" in r["Kernel_Name"]:
+            rows_h[(r["Kernel_Name"], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    lines += ["", f"## The timed loop alone: `python bench.py --steps 20 --warmup 3 --headline-only --no-check` under `rocprofv3 --kernel-trace`", "",
+              f"Only hot launches of the headline pair (ramp, warmup, 20 timed steps, 20 event-timed steps, the tuner's launches come from the stride cache).  "
+              f"The run's own line: encode {hb['encode_ms']} ms, decode {hb['decode_ms']} ms (HIP events), value {hb['value']} Msym/s; algorithmic bytes per launch {alg}.", "",
+              "| kernel | grid | calls | avg us | median us | min | max | algorithmic / avg (GB/s) | of 8 TB/s | line's ms / avg |", "|---|---|---|---|---|---|---|---|---|---|"]
+    with open(out / f"{tag}_headline_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Grid_Size_X", "Calls", "AverageUs", "MedianUs", "MinUs", "MaxUs", "AlgorithmicGBps", "FracOf8TBps"])
+        for (k, gs), v in sorted(rows_h.items(), key=lambda kv: -sum(kv[1])):
+            avg = sum(v) / len(v)
+            short = k.split("(")[0].replace("void cst::", "")
+            line_ms = hb["encode_ms"] if "encode" in short else hb["decode_ms"] if "decode" in short else None
+            agree = "" if line_ms is None else f"{line_ms * 1e3 / avg:.3f}"
+            w.writerow([short, gs, len(v), round(avg, 1), round(statistics.median(v), 1), round(min(v), 1), round(max(v), 1), round(alg / avg / 1e3, 1), round(alg / avg / 1e3 / 8000, 4)])
+            lines.append(f"| `{short}` | {gs} | {len(v)} | {avg:.1f} | {statistics.median(v):.1f} | {min(v):.1f} | {max(v):.1f} | {alg / avg / 1e3:.0f} | {alg / avg / 1e3 / 8000:.3f} | {agree} |")
 (out / f"{tag}_pmc_summary.md").write_text("\n".join(lines) + "\n")
 (out / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
 print("\n".join(lines))

@@ -16,6 +16,11 @@ rm -f $CST_STRIDE_CACHE
 $B > gpurun_out/${tag}_unprofiled_bench.json 2>/dev/null
 mkdir -p gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_l2
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o bench -- $B > gpurun_out/${tag}_stats/bench.json 2> gpurun_out/${tag}_stats/err.log
+# the timed loop alone (round 6): `--headline-only` launches nothing but the headline pair, hot -- its trace rows are what the bench
+# line's encode_ms / decode_ms must agree with (the full run's rows also hold the flush legs, foreign-words legs and plain_decode calls)
+mkdir -p gpurun_out/${tag}_headline
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_headline -o bench -- $B --headline-only --no-check > gpurun_out/${tag}_headline/bench.json 2> gpurun_out/${tag}_headline/err.log
+find gpurun_out/${tag}_headline -mindepth 2 -name "*.csv" -exec mv {} gpurun_out/${tag}_headline/ \;
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_fetch -o pmc -- $B > /dev/null 2> gpurun_out/${tag}_fetch/err.log
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_write -o pmc -- $B > /dev/null 2> gpurun_out/${tag}_write/err.log
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${tag}_l2 -o pmc -- $B > /dev/null 2> gpurun_out/${tag}_l2/err.log
