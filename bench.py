@@ -384,7 +384,7 @@ def jump_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None,
     return entry
 
 
-def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, name="C2"):
+def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, name="C2", coder="ans"):
     """C2 with a NARROW symbol matrix (the reference's Symbol type is generic, quantize.rs:229-255; C2's alphabet fits int8).
     int8 / int16 (round 5): the hand-scheduled loops read / write the narrow matrix themselves (ans_encode_pc_n8_kernel / ans_decode_n8_kernel
     and their n16 forms: cst_ans_pc.hip, cst_ans_n8.hip) -- algorithmic bytes 1 or 2 B per symbol + 4 B per word each way, and that is the traffic; the
@@ -392,24 +392,25 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
     construction.  `conversion_path`: the same call with CST_NO_N8=1 -- widened / narrowed by a streaming kernel next to the int32
     coder kernels (what the shapes the native kernels do not take -- symbol-major, other presets, rows that are not whole lines -- still use)."""
     import os
+    enc_fn, dec_fn = (B.ans_encode, B.ans_decode) if coder == "ans" else (B.range_encode, B.range_decode)      # (C4: round 6, cst_range_*_batch_sym)
     n_streams, n_per = symbols.shape
     cfg = cfg or (W, S, P)
     narrow = symbols.to(dtype)
     nb = narrow.element_size()
     from constriction_amd import _native
-    enc = B.ans_encode(narrow, model, cfg)
+    enc = enc_fn(narrow, model, cfg)
     enc_kernel = B.last_kernel()
     decoded = torch.empty_like(narrow)
-    B.ans_decode(enc, model, n_per, out=decoded)
+    dec_fn(enc, model, n_per, out=decoded)
     dec_kernel = B.last_kernel()
-    enc_ms = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
-    dec_ms = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
+    enc_ms = event_ms(lambda: enc_fn(narrow, model, cfg, out=enc), reps)
+    dec_ms = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded), reps)
     total_words = enc.total_words()
     byts = nb * n_streams * n_per + 4 * total_words
     native = "n8_kernel" in enc_kernel or "n16_kernel" in enc_kernel
     entry = {"workload": f"{name} with {str(dtype).replace('torch.', '')} symbol matrices " +
                          ("(read / written by the coder loops themselves)" if native else "(widened / narrowed on the device next to the coder call)"),
-             "coder": "ans", "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
+             "coder": coder, "config": list(cfg), "streams": n_streams, "symbols_per_stream": n_per, "symbol_bytes": nb,
              "encode_kernel": enc_kernel, "decode_kernel": dec_kernel, "jump_points": int(enc.jump.pos.shape[1]) if enc.jump is not None else 0,
              "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_streams * n_per / (enc_ms + dec_ms) / 1e3, 1),
              "slab_stride_words": int(enc.words.shape[1]),
@@ -418,15 +419,15 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
     if native:
         entry["bound"] = "instruction issue of one wave per SIMD (not HBM): see DESIGN.md 4.13"
     if enc.jump is not None:
-        plain8 = B.ans_encode(narrow, model, cfg, jump_points=0)
-        pe = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=plain8, jump_points=0), reps)
-        pd = event_ms(lambda: B.ans_decode(plain8, model, n_per, out=decoded), reps)
+        plain8 = enc_fn(narrow, model, cfg, jump_points=0)
+        pe = event_ms(lambda: enc_fn(narrow, model, cfg, out=plain8, jump_points=0), reps)
+        pd = event_ms(lambda: dec_fn(plain8, model, n_per, out=decoded), reps)
         entry["without_jump_points"] = {"encode_ms": round(pe, 4), "decode_ms": round(pd, 4), "decode_kernel": B.last_kernel(),
                                         "decode_speedup_of_the_default": round(pd / dec_ms, 3)}
         del plain8
-        B.ans_decode(enc, model, n_per, out=decoded)
+        dec_fn(enc, model, n_per, out=decoded)
     if check:
-        plain = B.ans_encode(symbols, model, cfg, jump_points=0)
+        plain = enc_fn(symbols, model, cfg, jump_points=0)
         used = torch.arange(plain.words.shape[1], device=symbols.device)[None, :] < plain.n_words[:, None]
         entry["bit_exact"] = bool(torch.equal(decoded, narrow)) and bool(torch.equal(enc.n_words, plain.n_words)) and \
             bool(((enc.words == plain.words) | ~used).all()) and int(enc.status.abs().sum().item()) == 0
@@ -435,9 +436,9 @@ def narrow_config(B, model, symbols, reps, check, dtype=torch.int8, cfg=None, na
         os.environ["CST_NO_N8"] = "1"
         _native.reload_knobs()           # (the library reads its debug switches once, when it is loaded)
         try:
-            c_enc = event_ms(lambda: B.ans_encode(narrow, model, cfg, out=enc), reps)
+            c_enc = event_ms(lambda: enc_fn(narrow, model, cfg, out=enc), reps)
             ck = B.last_kernel()
-            c_dec = event_ms(lambda: B.ans_decode(enc, model, n_per, out=decoded), reps)
+            c_dec = event_ms(lambda: dec_fn(enc, model, n_per, out=decoded), reps)
             entry["conversion_path"] = {"encode_ms": round(c_enc, 4), "decode_ms": round(c_dec, 4), "coder_kernels": [ck, B.last_kernel()],
                                         "Msymbols_per_s": round(n_streams * n_per / (c_enc + c_dec) / 1e3, 1)}
         finally:
@@ -760,6 +761,11 @@ def other_configs(B, rank, world, dist, args, reps=5):
             out.append({"workload": "C2 at P = 24 with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         add("C4 range coder, P = 12", "range", (32, 64, 12), m12, sym12, reps, check, cdf12)
         add("C4 range coder, P = 24", "range", (32, 64, 24), m24, sym24, reps, check, cdf24)
+        for mN, symN, PN in ((m12, sym12, 12), (m24, sym24, 24)):      # round 6: the range coder's loops read / write int8 themselves
+            try:
+                out.append(narrow_config(B, mN, symN, reps, check, dtype=torch.int8, cfg=(32, 64, PN), name=f"C4 range coder, P = {PN},", coder="range"))
+            except Exception as exc:      # noqa: BLE001
+                out.append({"workload": f"C4 range coder, P = {PN}, with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         jump("C2 decode with k jump points per stream (small-footprint decoder on 65 536 k virtual streams; the producer / consumer encoder "
              "notes the jump points on its way)", "ans", (32, 64, 12), m12, sym12, reps, check, cdf12)
         jump("C2 with int8 symbol matrices: decode with k jump points per stream (the loops read / write int8 themselves; 65 536 k virtual "

@@ -992,6 +992,101 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// ABI 5: NARROW symbol matrices for the range coder -- the reference's RangeEncoder / RangeDecoder are generic over the symbol type
+    /// (src/stream/queue.rs:612, 968; src/stream/model/quantize.rs:229-255).  The four calls below are cst_range_{en,de}code_batch[_ckpt] with
+    /// the matrix given as symbol_bytes = 1 (int8), 2 (int16) or 4 (int32: the plain call); words, counts, status and jump points are
+    /// those of the int32 call on the widened values.  An int8 matrix of stream-major rows of whole 32-symbol tiles at (32,64),
+    /// 8 <= P <= 24, is read by the hand-scheduled encoder itself ("range_encode_n8_kernel" / "range_encode_ckpt_n8_kernel": a quarter of the
+    /// symbol bytes, one more instruction per symbol) and written by the sub-lane decoder itself ("range_decode_n8_kernel" /
+    /// "range_decode_sub_n8_kernel": its byte tiles hold the symbols); every other shape converts next to the int32 call
+    /// (cst_symbols_widen / cst_symbols_narrow).  The decoders want a support that fits the type.
+    /// d_scratch: cst_range_sym_scratch_bytes(n_streams, n_per_stream, ckpt_interval or 0, symbol_bytes) bytes, contents irrelevant.
+    pub fn cst_range_sym_scratch_bytes(
+        n_streams: usize,
+        n_per_stream: usize,
+        ckpt_interval: usize,
+        symbol_bytes: i32,
+    ) -> usize;
+
+    pub fn cst_range_encode_batch_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_decode_batch_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_rstate: *mut CstRangeState,
+        d_status: *mut i32,
+        flags: u32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_encode_batch_ckpt_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_lower: *mut u64,
+        d_ckpt_range: *mut u64,
+        d_status: *mut i32,
+        d_scratch: *mut c_void,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_decode_batch_ckpt_sym(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *const u32,
+        d_ckpt_lower: *const u64,
+        d_ckpt_range: *const u64,
+        d_symbols: *mut c_void,
+        symbol_bytes: i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     /// Per-symbol-model variants of the range coder (same argument meaning as the cst_ans_* twins).
     pub fn cst_range_encode_cp_batch(
         cfg: CstCoderConfig,

@@ -1397,6 +1397,98 @@ impl BatchedRangeEncoder {
         Ok((out, ckpt))
     }
 
+    /// `encode_iid_symbols` for a NARROW symbol type (`i8` / `i16`: `RangeEncoder` is generic over the symbol type,
+    /// src/stream/queue.rs:612; ABI 5 `cst_range_encode_batch_sym`).  An `i8` matrix of stream-major rows of whole 32-symbol tiles is
+    /// read by the hand-scheduled encoder itself; other shapes are widened on the device next to the `i32` call.  Words, counts and
+    /// status are those of the `i32` call on the widened values.
+    pub fn encode_iid_symbols_narrow<T: NarrowSymbol>(
+        &self,
+        symbols: &DeviceBuffer<T>,
+        n_streams: usize,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<EncodedBatch> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if symbols.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_range_sym_scratch_bytes(n_streams, n_per_stream, 0, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_range_encode_batch_sym(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr() as *const c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                core::ptr::null_mut(),
+                out.status.as_mut_ptr(),
+                ffi::CST_FLAG_NONE,
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(out)
+    }
+
+    /// `encode_iid_symbols_with_checkpoints` for a NARROW symbol type (`cst_range_encode_batch_ckpt_sym`): `RangeEncoder::pos()` in front of
+    /// every `interval` symbols, noted by the `i8` encoder loop on its way where the chunks are whole tiles.
+    pub fn encode_iid_symbols_with_checkpoints_narrow<T: NarrowSymbol>(
+        &self,
+        symbols: &DeviceBuffer<T>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch, RangeCheckpoints)> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if interval == 0 || symbols.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_chunks = (n_per_stream + interval - 1) / interval;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut ckpt = RangeCheckpoints {
+            pos: DeviceBuffer::new(n_points)?,
+            lower: DeviceBuffer::new(n_points)?,
+            range: DeviceBuffer::new(n_points)?,
+            interval,
+        };
+        let mut scratch: DeviceBuffer<u8> =
+            DeviceBuffer::new(unsafe { ffi::cst_range_sym_scratch_bytes(n_streams, n_per_stream, interval, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_range_encode_batch_ckpt_sym(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr() as *const c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.lower.as_mut_ptr(),
+                ckpt.range.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok((out, ckpt))
+    }
+
     /// Per stream: `encode_symbols(symbols[s].zip(models))` with one quantized Gaussian per symbol (Python
     /// `RangeEncoder.encode(symbols, QuantizedGaussian(lo, hi), means, stds)`, src/pybindings/stream/queue.rs:343-410).
     pub fn encode_symbols(
@@ -1482,6 +1574,95 @@ pub struct BatchedRangeDecoder {
 impl BatchedRangeDecoder {
     pub fn new(config: CoderConfig) -> Self {
         BatchedRangeDecoder { config, layout: Layout::StreamMajor }
+    }
+
+    /// `decode_iid_symbols` into a NARROW symbol type (`cst_range_decode_batch_sym`; `RangeDecoder` is generic over the symbol type,
+    /// src/stream/queue.rs:968).  The model's support must fit the type.  `i8` stream-major matrices are written by the decoder itself.
+    pub fn decode_iid_symbols_narrow<T: NarrowSymbol>(
+        &self,
+        encoded: &EncodedBatch,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(DeviceBuffer<T>, DeviceBuffer<i32>)> {
+        let n_streams = encoded.n_streams;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        let mut symbols: DeviceBuffer<T> = DeviceBuffer::new(count)?;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams)?;
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_range_sym_scratch_bytes(n_streams, n_per_stream, 0, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_range_decode_batch_sym(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                symbols.as_mut_ptr() as *mut c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                core::ptr::null_mut(),
+                status.as_mut_ptr(),
+                ffi::CST_FLAG_NONE,
+                scratch.as_mut_ptr() as *mut c_void,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?;
+        Ok((symbols, status))
+    }
+
+    /// `decode_iid_symbols_from_checkpoints` into a NARROW symbol type (`cst_range_decode_batch_ckpt_sym`): every chunk on a lane of its
+    /// own, `i8` matrices written by the sub-lane decoder itself.  Returns the symbols and one status per (stream, chunk).
+    pub fn decode_iid_symbols_from_checkpoints_narrow<T: NarrowSymbol>(
+        &self,
+        encoded: &EncodedBatch,
+        checkpoints: &RangeCheckpoints,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(DeviceBuffer<T>, DeviceBuffer<i32>)> {
+        let n_streams = encoded.n_streams;
+        if checkpoints.interval == 0 || n_per_stream % checkpoints.interval != 0 {
+            return Err(Error::InvalidArgument); // whole chunks only: the C call indexes [n_streams][n_per_stream / interval]
+        }
+        let n_chunks = n_per_stream / checkpoints.interval;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        let n_points = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        if checkpoints.pos.len() < n_points || checkpoints.lower.len() < n_points || checkpoints.range.len() < n_points {
+            return Err(Error::InvalidArgument);
+        }
+        let mut symbols: DeviceBuffer<T> = DeviceBuffer::new(count)?;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_points)?;
+        let mut scratch: DeviceBuffer<u8> =
+            DeviceBuffer::new(unsafe { ffi::cst_range_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, T::BYTES) })?;
+        check(unsafe {
+            ffi::cst_range_decode_batch_ckpt_sym(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                checkpoints.interval,
+                checkpoints.pos.as_ptr(),
+                checkpoints.lower.as_ptr(),
+                checkpoints.range.as_ptr(),
+                symbols.as_mut_ptr() as *mut c_void,
+                T::BYTES,
+                n_streams,
+                n_per_stream,
+                scratch.as_mut_ptr() as *mut c_void,
+                status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?;
+        Ok((symbols, status))
     }
 
     /// Per stream: `RangeDecoder::from_compressed(words[s])?.decode_iid_symbols(n_per_stream, &model)`

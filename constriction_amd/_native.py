@@ -96,6 +96,11 @@ SIGNATURES = {
     "cst_ans_decode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_range_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_range_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
+    "cst_range_sym_scratch_bytes": (_z, [_z, _z, _z, _i32]),
+    "cst_range_encode_batch_sym": (_i32, [_vp, CoderConfig, _vp, _i32, _z, _z, _i32, _vp, _z, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "cst_range_decode_batch_sym": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _i32, _z, _z, _i32, _vp, _vp, _u32, _vp, _vp]),
+    "cst_range_encode_batch_ckpt_sym": (_i32, [_vp, CoderConfig, _vp, _i32, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cst_range_decode_batch_ckpt_sym": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _i32, _z, _z, _vp, _vp, _vp]),
     "cst_jump_points_auto": (_z, [_vp, CoderConfig, _i32, _i32, _vp, _z, _z, _i32, _vp, _z]),
     "cst_jump_points_auto_gaussian": (_z, [CoderConfig, _i32, _z, _z, _i32]),
     "cst_debug_reload_knobs": (None, []),

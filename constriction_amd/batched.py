@@ -740,48 +740,37 @@ def range_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layou
         if stride != "tuned":
             raise ValueError("stride must be a number of words or 'tuned'")
         stride = tuned_stride(symbols, model, config, layout, coder="range") if out is None else None
-    if symbols.dtype in (torch.int8, torch.int16):
-        symbols = _widened(symbols, model)                 # (the range coder's kernels take int32: cst_symbols_widen in front of them)
-    given = _require_cuda(symbols, torch.int32, "symbols")
-    symbols = _to_indices(model, given)
+    narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
+    if narrow != 4:
+        # int8 / int16 matrices (the reference's Symbol is generic, queue.rs:612; cst_range_encode_batch[_ckpt]_sym): int8 rows of whole
+        # 32-symbol tiles at (32, 64) are read by the encoder loop itself (round 6), every other shape is widened next to the int32 call
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
+        given = symbols = _require_cuda(symbols, symbols.dtype, "symbols")
+    else:
+        given = _require_cuda(symbols, torch.int32, "symbols")
+        symbols = _to_indices(model, given)
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         out = _new_batch(n_streams, stride or range_max_words(n_per, config), symbols.device, config)
     L = N.lib()
     interval = 0 if model.n_tables != 1 else _jump_interval(jump_points, n_per, lambda: L.cst_jump_points_auto(
-        model._h, _cfg(*config), N.CODER_RANGE, 4, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
+        model._h, _cfg(*config), N.CODER_RANGE, narrow, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
     if interval:
         ck = _jump_table(out, RangeCheckpoints, interval, n_streams, n_per, symbols.device)
         range_encode_checkpointed(given, model, interval, config, layout, out=(out, ck))
         out.jump = ck
         return out
     out.jump = None
+    if narrow != 4:
+        scratch = _ckpt_scratch("range_sym", symbols.device, L.cst_range_sym_scratch_bytes(n_streams, n_per, 0, narrow))
+        N.check(L.cst_range_encode_batch_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words),
+                                             out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE, _ptr(scratch),
+                                             _stream_ptr()), "cst_range_encode_batch_sym")
+        return out
     N.check(L.cst_range_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
                                      out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), N.FLAG_NONE,
                                      _stream_ptr()), "cst_range_encode_batch")
-    return out
-
-
-def _widened(symbols: torch.Tensor, model: Model) -> torch.Tensor:
-    """an int8 / int16 symbol matrix as int32, on the current stream (cst_symbols_widen; the reference's Symbol is generic,
-    quantize.rs:229-255 -- the ANS calls read such matrices themselves, the other coders' kernels take int32)"""
-    if model.noncontiguous:
-        raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
-    symbols = _require_cuda(symbols, symbols.dtype, "symbols")
-    wide = torch.empty(symbols.shape, dtype=torch.int32, device=symbols.device)
-    N.check(N.lib().cst_symbols_widen(_ptr(symbols), _SYMBOL_BYTES[symbols.dtype], symbols.numel(), _ptr(wide), _stream_ptr()), "cst_symbols_widen")
-    return wide
-
-
-def _narrowed(wide: torch.Tensor, model: Model, out: Optional[torch.Tensor], dtype) -> torch.Tensor:
-    """decoded int32 symbols as int8 / int16 (cst_symbols_narrow); the model's support must fit the type, as for cst_ans_decode_batch_sym"""
-    if model.noncontiguous:
-        raise ValueError("narrow symbol matrices: contiguous alphabets only")
-    info = torch.iinfo(dtype)
-    if model.min_symbol < info.min or model.min_symbol + model.n_symbols - 1 > info.max:
-        raise ValueError(f"the model's support does not fit {dtype}")
-    out = torch.empty(wide.shape, dtype=dtype, device=wide.device) if out is None else out
-    N.check(N.lib().cst_symbols_narrow(_ptr(wide), wide.numel(), _ptr(out), _SYMBOL_BYTES[dtype], _stream_ptr()), "cst_symbols_narrow")
     return out
 
 
@@ -801,26 +790,36 @@ def range_decode(encoded, model: Model, n_per_stream: int, layout="stream_major"
     dtype = out.dtype if out is not None else dtype
     if dtype not in _SYMBOL_BYTES:
         raise TypeError("decoded symbols are int32, int16 or int8")
-    narrow_out = None
-    if dtype != torch.int32:
-        narrow_out, out = out, None
+    narrow = _SYMBOL_BYTES[dtype]
+    if narrow != 4:
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only")
+        info = torch.iinfo(dtype)
+        if model.min_symbol < info.min or model.min_symbol + model.n_symbols - 1 > info.max:
+            raise ValueError(f"the model's support does not fit {dtype}")
     jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
     if isinstance(jump, RangeCheckpoints) and offsets is None and layout == "stream_major" and \
             n_per_stream == jump.interval * jump.pos.shape[1] and jump.pos.shape[0] == n_streams:
         # the batch carries jump points for exactly this decode: every part of a stream on a lane of its own
-        wide, part_status = range_decode_checkpointed(encoded, jump, model, n_per_stream, out=out)
-        status = _status_per_stream(part_status)
-        return (_narrowed(wide, model, narrow_out, dtype), status) if dtype != torch.int32 else (wide, status)
+        dec, part_status = range_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype)
+        return dec, _status_per_stream(part_status)
     if out is None:
         shape = (n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams)
-        out = torch.empty(shape, dtype=torch.int32, device=dev)
+        out = torch.empty(shape, dtype=dtype, device=dev)
     lay = N.LAYOUT_STREAM_MAJOR if layout == "stream_major" else N.LAYOUT_SYMBOL_MAJOR
     status = torch.empty(n_streams, dtype=torch.int32, device=dev)
-    N.check(N.lib().cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
-                                           _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
-                                           _stream_ptr()), "cst_range_decode_batch")
-    if dtype != torch.int32:
-        return _narrowed(out, model, narrow_out, dtype), status
+    L = N.lib()
+    if narrow != 4:
+        # (cst_range_decode_batch_sym: int8 stream-major matrices are written by the sub-lane decoder itself, one lane per stream;
+        #  every other shape is narrowed on the device behind the int32 decoder)
+        scratch = _ckpt_scratch("range_sym", dev, L.cst_range_sym_scratch_bytes(n_streams, n_per_stream, 0, narrow))
+        N.check(L.cst_range_decode_batch_sym(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
+                                             _ptr(out), narrow, n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE, _ptr(scratch),
+                                             _stream_ptr()), "cst_range_decode_batch_sym")
+        return out, status
+    N.check(L.cst_range_decode_batch(model._h, _cfg(*config), _ptr(words), _ptr(offsets), stride, words.numel(), _ptr(n_words),
+                                     _ptr(out), n_streams, n_per_stream, lay, None, _ptr(status), N.FLAG_NONE,
+                                     _stream_ptr()), "cst_range_decode_batch")
     return _to_symbols(model, out), status
 
 
@@ -1129,7 +1128,13 @@ def range_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int
                               stride: Optional[int] = None, out=None):
     """range_encode + a jump point in front of every `interval` symbols.  Returns (EncodedBatch, RangeCheckpoints); the words
     are those of range_encode."""
-    symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
+    narrow = _SYMBOL_BYTES.get(symbols.dtype, 4) if symbols.dtype in _SYMBOL_BYTES else 4
+    if narrow != 4:        # int8 / int16 matrices (round 6: cst_range_encode_batch_ckpt_sym; int8 tiles are read by the encoder loop itself)
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only (map the symbols to indices first)")
+        symbols = _require_cuda(symbols, symbols.dtype, "symbols")
+    else:
+        symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     dev = symbols.device
     n_chunks = (n_per + interval - 1) // interval
@@ -1145,6 +1150,13 @@ def range_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int
                            torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config))
         ck = RangeCheckpoints(int(interval), *(torch.zeros((n_streams, n_chunks), dtype=dt, device=dev)
                                                for dt in (torch.int32, torch.int64, torch.int64)))
+    if narrow != 4:
+        L = N.lib()
+        scratch = _ckpt_scratch("range_sym", dev, L.cst_range_sym_scratch_bytes(n_streams, n_per, int(interval), narrow))
+        N.check(L.cst_range_encode_batch_ckpt_sym(model._h, _cfg(*config), _ptr(symbols), narrow, n_streams, n_per, lay, _ptr(out.words), stride,
+                                                  _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.lower), _ptr(ck.range),
+                                                  _ptr(out.status), _ptr(scratch), _stream_ptr()), "cst_range_encode_batch_ckpt_sym")
+        return out, ck
     N.check(N.lib().cst_range_encode_batch_ckpt(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), stride,
                                                 _ptr(out.n_words), int(interval), _ptr(ck.pos), _ptr(ck.lower), _ptr(ck.range),
                                                 _ptr(out.status), _stream_ptr()), "cst_range_encode_batch_ckpt")
@@ -1152,7 +1164,7 @@ def range_encode_checkpointed(symbols: torch.Tensor, model: Model, interval: int
 
 
 def range_decode_checkpointed(encoded, checkpoints: RangeCheckpoints, model: Model, n_per_stream: int, out=None, status=None,
-                              offsets: Optional[torch.Tensor] = None, config=None):
+                              offsets: Optional[torch.Tensor] = None, config=None, dtype=torch.int32):
     """Every chunk on its own lane: RangeDecoder.seek(pos, (lower, range)) + `interval` symbols per chunk.
     Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks]).  `encoded`: an EncodedBatch, or (packed words, n_words)
     with `offsets` (int64 [n_streams + 1]) and `config` for the words of compact() / container.load() / a gather."""
@@ -1170,10 +1182,23 @@ def range_decode_checkpointed(encoded, checkpoints: RangeCheckpoints, model: Mod
     if checkpoints.pos.shape[0] != n_streams:
         raise ValueError("jump points of another batch: one row per stream")
     if out is None:
-        out = torch.empty((n_streams, n_per_stream), dtype=torch.int32, device=dev)
+        out = torch.empty((n_streams, n_per_stream), dtype=dtype, device=dev)
     if status is None:
         status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
     L = N.lib()
+    narrow = _SYMBOL_BYTES.get(out.dtype)
+    if narrow is None:
+        raise TypeError("decoded symbols are int32, int16 or int8")
+    if narrow != 4:        # (round 6: int8 matrices are written by the sub-lane decoder itself, cst_range_decode_batch_ckpt_sym)
+        if model.noncontiguous:
+            raise ValueError("narrow symbol matrices: contiguous alphabets only")
+        scratch = _ckpt_scratch("range_sym", dev, L.cst_range_sym_scratch_bytes(n_streams, n_per_stream, checkpoints.interval, narrow))
+        N.check(L.cst_range_decode_batch_ckpt_sym(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets),
+                                                  encoded.words.shape[1] if stride_arg is None else stride_arg, encoded.words.numel(), _ptr(encoded.n_words),
+                                                  checkpoints.interval, _ptr(checkpoints.pos), _ptr(checkpoints.lower), _ptr(checkpoints.range), _ptr(out),
+                                                  narrow, n_streams, n_per_stream, _ptr(scratch), _ptr(status), _stream_ptr()),
+                "cst_range_decode_batch_ckpt_sym")
+        return out, status
     scratch = _ckpt_scratch("range_ckpt", dev, L.cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval))
     N.check(L.cst_range_decode_batch_ckpt(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(offsets),
                                           encoded.words.shape[1] if stride_arg is None else stride_arg, encoded.words.numel(), _ptr(encoded.n_words), checkpoints.interval, _ptr(checkpoints.pos),

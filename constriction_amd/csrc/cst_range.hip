@@ -496,4 +496,174 @@ cst_status cst_range_decode_batch_ckpt(const cst_model* model, cst_coder_config 
     return CST_OK;
 }
 
+// ---- narrow symbol matrices (ABI 5): the reference's coders are generic over the symbol type (queue.rs:612, 968; quantize.rs:229-255) ----
+//
+// int8 matrices of stream-major rows of whole 32-symbol tiles are read by the hand-scheduled encoder itself and written by the sub-lane
+// decoder itself (cst_range_fast.hip, round 6); every other shape converts next to the int32 call (cst_symbols_widen / _narrow), as
+// cst_ans_*_batch_sym do.  Scratch layout: [jump-point scratch of the int32 calls][one jump point per stream for the plain calls]
+// [the widened matrix].
+
+static size_t range_sym_plain_table_bytes(size_t n_streams) { return ((20 * n_streams + 15) & ~(size_t)15) + 16; }
+
+size_t cst_range_sym_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval, int32_t symbol_bytes) {
+    const size_t ck = ckpt_interval ? cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) : 0;
+    return ((ck + 15) & ~(size_t)15) + range_sym_plain_table_bytes(n_streams) + cst_symbols_scratch_bytes(n_streams, n_per_stream, symbol_bytes) + 32;
+}
+
+namespace {
+struct SymScratch { unsigned char* ck; uint32_t* pos; uint64_t* lower; uint64_t* range; void* conv; };
+SymScratch split_scratch(void* d_scratch, size_t n_streams, size_t n_per_stream, size_t ckpt_interval) {
+    SymScratch x{};
+    unsigned char* b = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
+    x.ck = b;
+    b += ((ckpt_interval ? cst_range_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) : 0) + 15) & ~(size_t)15;
+    x.lower = reinterpret_cast<uint64_t*>(b);
+    x.range = x.lower + n_streams;
+    x.pos = reinterpret_cast<uint32_t*>(x.range + n_streams);
+    x.conv = b + range_sym_plain_table_bytes(n_streams);
+    return x;
+}
+bool narrow_model_ok(const cst_model* model, cst_coder_config cfg) {
+    return model && !model->per_stream && !model->d_symbol_of_index && config_supported(cfg) && cfg.precision == model->precision &&
+           cfg.word_bits == 32 && cfg.state_bits == 64;
+}
+} // namespace
+
+cst_status cst_range_encode_batch_ckpt_sym(const cst_model* model, cst_coder_config cfg, const void* d_symbols, int32_t symbol_bytes, size_t n_streams,
+                                           size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                           size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_lower, uint64_t* d_ckpt_range,
+                                           int32_t* d_status, void* d_scratch, void* stream) {
+    if (symbol_bytes == 4)
+        return cst_range_encode_batch_ckpt(model, cfg, reinterpret_cast<const int32_t*>(d_symbols), n_streams, n_per_stream, layout, d_words, stride_words,
+                                           d_n_words, ckpt_interval, d_ckpt_pos, d_ckpt_lower, d_ckpt_range, d_status, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range ||
+        ckpt_interval == 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    hipStream_t hs = (hipStream_t)stream;
+    if (symbol_bytes == 1 && narrow_model_ok(model, cfg)) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        RangeEncodeArgs a{};
+        a.symbols = reinterpret_cast<const int32_t*>(d_symbols); a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+        a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+        a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
+        if (range_encode_n8_usable(a, layout, ckpt_interval)) {
+            RangeCkptOut ck{d_ckpt_pos, d_ckpt_lower, d_ckpt_range, ckpt_interval, n_per_stream / ckpt_interval};
+            return note_kernel("range_encode_ckpt_n8_kernel", range_encode_ckpt_n8(a, ck, hs));
+        }
+    }
+    if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
+    const SymScratch x = split_scratch(d_scratch, n_streams, n_per_stream, ckpt_interval);
+    int32_t* wide = reinterpret_cast<int32_t*>(x.conv);
+    const cst_status rc = cst_symbols_widen(d_symbols, symbol_bytes, n_streams * n_per_stream, wide, stream);
+    if (rc != CST_OK) return rc;
+    return cst_range_encode_batch_ckpt(model, cfg, wide, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, ckpt_interval, d_ckpt_pos,
+                                       d_ckpt_lower, d_ckpt_range, d_status, stream);
+}
+
+cst_status cst_range_encode_batch_sym(const cst_model* model, cst_coder_config cfg, const void* d_symbols, int32_t symbol_bytes, size_t n_streams,
+                                      size_t n_per_stream, cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                      cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, void* d_scratch, void* stream) {
+    if (symbol_bytes == 4)
+        return cst_range_encode_batch(model, cfg, reinterpret_cast<const int32_t*>(d_symbols), n_streams, n_per_stream, layout, d_words, stride_words,
+                                      d_n_words, d_rstate, d_status, flags, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (!d_scratch) return CST_ERR_INVALID_ARGUMENT;
+    const SymScratch x = split_scratch(d_scratch, n_streams, n_per_stream, 0);
+    if (symbol_bytes == 1 && flags == CST_FLAG_NONE && narrow_model_ok(model, cfg) && n_per_stream >= (size_t)cst::kTileSyms) {
+        // the jump-point-noting encoder with ONE chunk: its only jump point is the start of the stream (noted into the scratch, unused)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        RangeEncodeArgs a{};
+        a.symbols = reinterpret_cast<const int32_t*>(d_symbols); a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+        a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+        a.words = d_words; a.stride_words = stride_words; a.n_words = d_n_words; a.status = d_status;
+        if (range_encode_n8_usable(a, layout, n_per_stream)) {
+            RangeCkptOut ck{x.pos, x.lower, x.range, n_per_stream, 1};
+            return note_kernel("range_encode_n8_kernel", range_encode_ckpt_n8(a, ck, (hipStream_t)stream));
+        }
+    }
+    int32_t* wide = reinterpret_cast<int32_t*>(x.conv);
+    const cst_status rc = cst_symbols_widen(d_symbols, symbol_bytes, n_streams * n_per_stream, wide, stream);
+    if (rc != CST_OK) return rc;
+    return cst_range_encode_batch(model, cfg, wide, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_rstate, d_status, flags, stream);
+}
+
+cst_status cst_range_decode_batch_ckpt_sym(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                           size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t ckpt_interval,
+                                           const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_lower, const uint64_t* d_ckpt_range, void* d_symbols,
+                                           int32_t symbol_bytes, size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status, void* stream) {
+    if (symbol_bytes == 4)
+        return cst_range_decode_batch_ckpt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, ckpt_interval, d_ckpt_pos, d_ckpt_lower,
+                                           d_ckpt_range, reinterpret_cast<int32_t*>(d_symbols), n_streams, n_per_stream, d_scratch, d_status, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_n_words || !d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range || !d_scratch || !d_status ||
+        ckpt_interval == 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream % ckpt_interval != 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    if (!d_symbols || !d_words) return CST_ERR_INVALID_ARGUMENT;
+    if (symbol_bytes == 1 && narrow_model_ok(model, cfg)) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        const size_t n_chunks = n_per_stream / ckpt_interval;
+        RangeDecodeArgs a{};
+        a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = reinterpret_cast<int32_t*>(d_symbols);
+        a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
+        a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
+        a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
+        a.words_capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+        a.ckpt_pos = d_ckpt_pos; a.ckpt_lower = d_ckpt_lower; a.ckpt_range = d_ckpt_range; a.interval = ckpt_interval; a.n_chunks = n_chunks;
+        if (n_streams * n_chunks <= 0x7fffffffull && range_decode_sub_n8_usable(a))
+            return note_kernel("range_decode_sub_n8_kernel", range_decode_sub_n8(a, (hipStream_t)stream));
+    }
+    const SymScratch x = split_scratch(d_scratch, n_streams, n_per_stream, ckpt_interval);
+    int32_t* wide = reinterpret_cast<int32_t*>(x.conv);
+    const cst_status rc = cst_range_decode_batch_ckpt(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, ckpt_interval, d_ckpt_pos,
+                                                      d_ckpt_lower, d_ckpt_range, wide, n_streams, n_per_stream, x.ck, d_status, stream);
+    if (rc != CST_OK) return rc;
+    return cst_symbols_narrow(wide, n_streams * n_per_stream, d_symbols, symbol_bytes, stream);
+}
+
+cst_status cst_range_decode_batch_sym(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,
+                                      size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, void* d_symbols, int32_t symbol_bytes,
+                                      size_t n_streams, size_t n_per_stream, cst_layout layout, cst_range_state* d_rstate, int32_t* d_status,
+                                      uint32_t flags, void* d_scratch, void* stream) {
+    if (symbol_bytes == 4)
+        return cst_range_decode_batch(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, reinterpret_cast<int32_t*>(d_symbols),
+                                      n_streams, n_per_stream, layout, d_rstate, d_status, flags, stream);
+    if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    if (!d_scratch || !d_words) return CST_ERR_INVALID_ARGUMENT;
+    const SymScratch x = split_scratch(d_scratch, n_streams, n_per_stream, 0);
+    hipStream_t hs = (hipStream_t)stream;
+    if (symbol_bytes == 1 && flags == CST_FLAG_NONE && layout == CST_LAYOUT_STREAM_MAJOR && narrow_model_ok(model, cfg)) {
+        // the sub-lane decoder with ONE lane per stream: its jump point is the start of the stream, (pos, lower, range) = (0, 0, 2^64 - 1)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        RangeDecodeArgs a{};
+        a.words = d_words; a.offsets = d_offsets; a.stride_words = stride_words; a.n_words = d_n_words; a.symbols = reinterpret_cast<int32_t*>(d_symbols);
+        a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.dec_cp = model->d_dec_cp; a.dec_idx = model->d_dec_idx;
+        a.cdf = model->d_cdf; a.bucket = model->d_bucket; a.bucket_bits = model->bucket_bits; a.n_symbols = model->n_symbols;
+        a.min_symbol = model->min_symbol; a.precision = model->precision; a.status = d_status;
+        a.words_capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+        a.ckpt_pos = x.pos; a.ckpt_lower = x.lower; a.ckpt_range = x.range; a.interval = n_per_stream; a.n_chunks = 1;
+        if (n_streams <= 0x7fffffffull && range_decode_sub_n8_usable(a)) {
+            CST_HIP_TRY(hipMemsetAsync(x.lower, 0, 8 * n_streams, hs));
+            CST_HIP_TRY(hipMemsetAsync(x.range, 0xff, 8 * n_streams, hs));
+            CST_HIP_TRY(hipMemsetAsync(x.pos, 0, 4 * n_streams, hs));
+            return note_kernel("range_decode_n8_kernel", range_decode_sub_n8(a, hs));
+        }
+    }
+    int32_t* wide = reinterpret_cast<int32_t*>(x.conv);
+    const cst_status rc = cst_range_decode_batch(model, cfg, d_words, d_offsets, stride_words, words_capacity, d_n_words, wide, n_streams, n_per_stream, layout,
+                                                 d_rstate, d_status, flags, stream);
+    if (rc != CST_OK) return rc;
+    return cst_symbols_narrow(wide, n_streams * n_per_stream, d_symbols, symbol_bytes, stream);
+}
+
 } // extern "C"

@@ -9,6 +9,8 @@
 // situation is tracked.  A carry that must travel further than the held word (a run of two or more held words) is
 // handled by RangeEncHeld::carry_back on words in the ring or already in HBM; the asm main loop only flags it and the
 // wave repeats its streams with the C++ step.  scripts/gen_range_encode_loop.py has the instruction-level account.
+#include <type_traits>
+
 #include "cst_range_kernels.hpp"
 
 namespace cst {
@@ -686,8 +688,28 @@ __device__ __forceinline__ void range_encode_tiles_loop_ck(uint32_t& lo0, uint32
     }
 }
 
+// ... over an int8 symbol matrix (round 6, scripts/gen_range_encode_loop.py GEN_RANGE_N8): a tile is 32 bytes of a row
 template <int FLUSHES>
+__device__ __forceinline__ void range_encode_tiles_loop_ck_n8(uint32_t& lo0, uint32_t& lo1, uint32_t& rg0, uint32_t& rg1, uint32_t& lw,
+                                                              uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax, uint32_t& slow,
+                                                              uint32_t& ck_index, const uint32_t (&tile_row_addr)[2],
+                                                              const uint32_t (&tile_tr_addr)[2], uint32_t ring_lane_addr, uint32_t cap,
+                                                              uint32_t slab_off, uint32_t table_addr_biased, uint32_t P, const void* words_base,
+                                                              uint64_t symbols_base, uint32_t n_tiles, const void* ck_pos_base,
+                                                              const void* ck_lower_base, const void* ck_range_base, uint32_t ck_tiles,
+                                                              const uint32_t (&goff)[8]) {
+    if constexpr (FLUSHES == 1) {
+#include "cst_range_encode_loop_ck_n8.inc"
+    } else {
+#include "cst_range_encode_loop_2f_ck_n8.inc"
+    }
+}
+
+// SB = bytes per symbol of the matrix behind a.symbols: 4 (int32) or 1 (int8: RangeEncodeArgs::symbols is then a const int8_t*)
+template <int FLUSHES, int SB = 4>
 __global__ __launch_bounds__(kBlock) void range_encode_ckpt_kernel(const RangeEncodeArgs a, const RangeCkptOut ck) {
+    using SymT = typename std::conditional<SB == 1, int8_t, int32_t>::type;
+    const SymT* symbols = reinterpret_cast<const SymT*>(a.symbols);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -723,8 +745,8 @@ __global__ __launch_bounds__(kBlock) void range_encode_ckpt_kernel(const RangeEn
         const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
         uint32_t goff[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
-        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N);
+        for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * SB);
+        const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + s0 * N);
         const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
         const uint32_t tr_off = (uint32_t)(((lane >> 3) * kTileStride + 4 * (lane & 7)) * 4);
@@ -735,6 +757,12 @@ __global__ __launch_bounds__(kBlock) void range_encode_ckpt_kernel(const RangeEn
         uint32_t ck_index = (uint32_t)(se * ck.n_chunks);
         int32_t smin = a.min_symbol, smax = a.min_symbol;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+        if constexpr (SB == 1)
+            range_encode_tiles_loop_ck_n8<FLUSHES>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, ck_index, row_addr, tr_addr, L.out.lane_addr,
+                                                   cap, (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
+                                                   symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms)), ck.pos, ck.lower,
+                                                   ck.range, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ck.interval / kTileSyms)), goff);
+        else
         range_encode_tiles_loop_ck<FLUSHES>(lo0, lo1, rg0, rg1, lw, wr, flushed, smin, smax, slow, ck_index, row_addr, tr_addr, L.out.lane_addr,
                                             cap, (uint32_t)slab_off, lds_addr(table) - 8u * (uint32_t)a.min_symbol, (uint32_t)P, a.words,
                                             symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(N / kTileSyms)), ck.pos, ck.lower,
@@ -752,13 +780,13 @@ __global__ __launch_bounds__(kBlock) void range_encode_ckpt_kernel(const RangeEn
     }
     if (!done) {
         // any other shape: symbol by symbol (correct, slow)
-        const int32_t* row = a.symbols + se * N;
+        const SymT* row = symbols + se * N;
         for (size_t t = 0; t < N; ++t) {
             if (active && t % ck.interval == 0) {
                 const size_t k = s * ck.n_chunks + t / ck.interval;
                 ck.pos[k] = (uint32_t)((int32_t)L.out.wr + 1); ck.lower[k] = L.lower; ck.range[k] = L.range;
             }
-            const CumProb e = table[enc_index(row[t], a.min_symbol, nsym, L.bad)];
+            const CumProb e = table[enc_index((int32_t)row[t], a.min_symbol, nsym, L.bad)];
             L.step(e.c, e.p, P);
             if ((t & 7) == 7) L.flush();
         }
@@ -788,6 +816,30 @@ cst_status range_encode_ckpt_fast(const RangeEncodeArgs& a, const RangeCkptOut& 
     return a.precision <= 16 ? go(range_encode_ckpt_kernel<1>) : go(range_encode_ckpt_kernel<2>);
 }
 
+// int8 symbol matrices read by the loop itself (round 6): a.symbols is a const int8_t* in disguise; rows of whole 32-symbol tiles whose
+// chunks are whole tiles run the statement, anything else the kernel's exact symbol-by-symbol path (both read int8)
+bool range_encode_n8_usable(const RangeEncodeArgs& a, cst_layout layout, size_t interval) {
+    if (knobs().no_n8) return false;                                  // (A/B runs: the conversion path)
+    if (layout != CST_LAYOUT_STREAM_MAJOR || !range_encode_fast_usable(a, layout)) return false;      // (16-byte aligned matrix, rows of whole dwords)
+    if (a.n_per_stream % kTileSyms != 0 || interval == 0 || interval % kTileSyms != 0 || a.n_per_stream % interval != 0) return false;
+    if (a.n_streams * (a.n_per_stream / interval) >= (1u << 28)) return false;
+    return a.min_symbol >= -128 && a.min_symbol + a.n_symbols - 1 <= 127;
+}
+
+cst_status range_encode_ckpt_n8(const RangeEncodeArgs& a, const RangeCkptOut& ck, hipStream_t hs) {
+    const size_t table_bytes = (((size_t)a.n_symbols * sizeof(CumProb)) + 15) & ~(size_t)15;
+    const size_t lds = kFastRingBytes + table_bytes + 2 * kFastTileBytes;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, ck);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 16 ? go(range_encode_ckpt_kernel<1, 1>) : go(range_encode_ckpt_kernel<2, 1>);
+}
+
 // ---- sub-lane decoder ----
 constexpr int kRsThreads = 512;
 constexpr int kRsWaves = kRsThreads / kWave;
@@ -796,7 +848,7 @@ constexpr int kRsTileRow = 36;                                                  
 constexpr size_t kRsTileBytes = (size_t)kWave * kRsTileRow;                     // 2304 B per wave and buffer
 constexpr size_t kRsDumpBytes = 4 * kWave * 4;                                  // ONE landing area for unused chunk slots (never read)
 
-template <bool ENDS, bool B16>
+template <bool ENDS, bool B16, bool N8 = false>
 __device__ __forceinline__ void range_decode_tiles_loop_sub(uint32_t& x0, uint32_t& x1, uint32_t& rg0, uint32_t& rg1, uint32_t& pos,
                                                             uint32_t& hi_issued, uint32_t& row_cur, uint32_t& row_prev, uint32_t& tr_cur,
                                                             uint32_t& tr_prev, uint32_t& tiles, uint32_t& ginc, uint32_t& bad,
@@ -807,6 +859,21 @@ __device__ __forceinline__ void range_decode_tiles_loop_sub(uint32_t& x0, uint32
                                                             [[maybe_unused]] uint32_t cdf_addr, int32_t min_symbol,
                                                             [[maybe_unused]] uint32_t c_field_mask, [[maybe_unused]] uint32_t index_shift,
                                                             bool plain_stores) {
+    if constexpr (N8) {       // int8 symbol matrices (round 6): the byte tile leaves as it is, four symbols per store
+#define CST_STORE_MOD ""
+        if constexpr (B16 && ENDS) {
+#include "cst_range_decode_loop_b16_sub_n8_ends.inc"
+        } else if constexpr (B16) {
+#include "cst_range_decode_loop_b16_sub_n8.inc"
+        } else if constexpr (ENDS) {
+#include "cst_range_decode_loop_sub_n8_ends.inc"
+        } else {
+#include "cst_range_decode_loop_sub_n8.inc"
+        }
+#undef CST_STORE_MOD
+        (void)plain_stores;
+        return;
+    }
     if constexpr (B16 && ENDS) {
         if (plain_stores) {
 #define CST_STORE_MOD ""
@@ -852,8 +919,12 @@ __device__ __forceinline__ void range_decode_tiles_loop_sub(uint32_t& x0, uint32
 
 // LDS layout: [word rings, 8 KiB per wave][tables][byte tiles A, 2304 B per wave][byte tiles B][dump 1 KiB]
 // P <= 12: cp[q] = c | p << 16 at +0, the symbol INDEX of quantile q (int32) at +16384; B16: cdf, bucket entries, second level
-template <bool B16>
+// SB = bytes per symbol of the matrix behind a.symbols: 4 (int32) or 1 (int8, round 6: the byte tiles hold the symbols themselves)
+template <bool B16, int SB = 4>
 __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const RangeDecodeArgs a) {
+    using SymT = typename std::conditional<SB == 1, int8_t, int32_t>::type;
+    SymT* symbols = reinterpret_cast<SymT*>(a.symbols);
+    const int32_t tile_bias = SB == 1 ? a.min_symbol : 0;             // what the byte tile holds: index (int32 matrix) or symbol (int8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -873,7 +944,7 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
     } else {
         for (size_t q = threadIdx.x; q < n_q; q += blockDim.x) {
             lut[q] = a.dec_cp[q];
-            idxt[q] = (int32_t)a.dec_idx[q];
+            idxt[q] = (int32_t)a.dec_idx[q] + tile_bias;
         }
     }
     unsigned char* tile = smem + kRsRingBytes + table_bytes + (size_t)wave_in_block * kRsTileBytes;
@@ -924,7 +995,7 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
         } else {
             const uint32_t cp = lut[q];
             c = cp & 0xffffu; p = cp >> 16;
-            sym = a.min_symbol + idxt[q];
+            sym = a.min_symbol + idxt[q] - tile_bias;
         }
         const uint32_t w = L.in.peek();
         L.in.pos += L.advance(c, p, P, w, L.in.pos < L.in.len) ? 1u : 0u;
@@ -932,16 +1003,17 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
     };
 
     bool tiles_done = false;
-    int32_t* out_row = a.symbols + s * N + chunk * K;
+    SymT* out_row = symbols + s * N + chunk * K;
     {
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)my_len + 8) < 0x80000000ull;
-        if (n_full > 0 && K % kTileSyms == 0 && N < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && !__any(!off_ok)) {
+        if (n_full > 0 && K % kTileSyms == 0 && N < (1u << 24) && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0 && (N * SB) % 4 == 0 &&
+            !__any(!off_ok)) {
             const size_t last_row = min((size_t)kWave, a.n_streams - s0) - 1;
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * 4);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((min((size_t)(lane >> 3) + 8 * k, last_row) * N + 4 * (size_t)(lane & 7)) * SB);
             auto leave_offsets = [&](uint32_t row_cur_addr) {      // the statements read their store offsets from the lane's row
                 uint32_t* cur = reinterpret_cast<uint32_t*>((row_cur_addr == lds_addr(tile + lane * kRsTileRow) ? tile : tile_b) + lane * kRsTileRow);
 #pragma unroll
@@ -958,7 +1030,7 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
             uint32_t row_cur = lds_addr(tile + lane * kRsTileRow), row_prev = lds_addr(tile_b + lane * kRsTileRow);
             uint32_t tr_cur = lds_addr(tile) + tr_off, tr_prev = lds_addr(tile_b) + tr_off;
             uint32_t tiles = (uint32_t)n_full, ginc = 0, bad = 0, bad2 = 0;
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols + s0 * N + chunk * K);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols + s0 * N + chunk * K);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
             const bool plain_stores = __builtin_amdgcn_readfirstlane((int)((((N * 4) % 128 != 0 || (sb & 127) != 0)) ? 1 : 0)) != 0;
@@ -968,7 +1040,7 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
             const uint32_t cdf_addr = B16 ? lds_addr(cdf) : 0u;
             const uint32_t idx_shift = B16 ? (uint32_t)blut.idx_shift : 24u, idx_mask = (1u << idx_shift) - 1u;
             leave_offsets(row_cur);
-            range_decode_tiles_loop_sub<false, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
+            range_decode_tiles_loop_sub<false, B16, SB == 1>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad, lut_addr,
                                                     qmax, (uint32_t)P, ring_mask, words_base, delta_hi, store_base, lens, endr,
                                                     lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
                                                     (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), cdf_addr, a.min_symbol, idx_mask, idx_shift,
@@ -976,9 +1048,9 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
             tiles = (uint32_t)__builtin_amdgcn_readfirstlane(tiles);
             if (tiles > 0) {
                 const uint32_t done = (uint32_t)n_full - tiles;
-                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * 4) : 0);
+                const uint64_t base2 = store_base + (done > 0 ? (uint64_t)(done - 1) * (kTileSyms * SB) : 0);
                 leave_offsets(row_cur);
-                range_decode_tiles_loop_sub<true, B16>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
+                range_decode_tiles_loop_sub<true, B16, SB == 1>(x0, x1, rg0, rg1, pos, hi_issued, row_cur, row_prev, tr_cur, tr_prev, tiles, ginc, bad2,
                                                        lut_addr, qmax, (uint32_t)P, ring_mask, words_base, delta_hi, base2, lens, endr,
                                                        lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
                                                        (uint32_t)__builtin_amdgcn_readfirstlane(bucket_shift), cdf_addr, a.min_symbol, idx_mask,
@@ -992,6 +1064,10 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
                 for (int k = 0; k < 8; ++k) {
                     const size_t R = min((size_t)(lane >> 3) + 8 * k, last_row);
                     const uint32_t pk = *reinterpret_cast<const uint32_t*>(last + ((lane >> 3) + 8 * k) * kRsTileRow + 4 * (lane & 7));
+                    if constexpr (SB == 1) {      // the bytes are the symbols
+                        *reinterpret_cast<uint32_t*>(symbols + (s0 + R) * N + chunk * K + (n_full - 1) * kTileSyms + 4 * (lane & 7)) = pk;
+                        continue;
+                    }
                     v4i t;
                     t.x = a.min_symbol + (int32_t)(pk & 0xffu); t.y = a.min_symbol + (int32_t)((pk >> 8) & 0xffu);
                     t.z = a.min_symbol + (int32_t)((pk >> 16) & 0xffu); t.w = a.min_symbol + (int32_t)(pk >> 24);
@@ -1010,7 +1086,7 @@ __global__ __launch_bounds__(kRsThreads) void range_decode_sub_kernel(const Rang
     if (!tiles_done) {
         for (size_t t = 0; t < K; ++t) {          // shapes the statements do not take, and the exact repeat: symbol by symbol
             const int32_t sym = step();
-            if (active) out_row[t] = sym;
+            if (active) out_row[t] = (SymT)sym;
             if ((t & 3) == 3) { L.in.fill_blocking(); wave_lds_fence(); }
         }
     }
@@ -1043,6 +1119,27 @@ cst_status range_decode_sub(const RangeDecodeArgs& a, hipStream_t hs) {
         return CST_OK;
     };
     return a.precision <= 12 ? go(range_decode_sub_kernel<false>) : go(range_decode_sub_kernel<true>);
+}
+
+// ... writing an int8 symbol matrix (a.symbols is an int8_t* in disguise): the support must fit the type
+bool range_decode_sub_n8_usable(const RangeDecodeArgs& a) {
+    if (knobs().no_n8) return false;                                  // (A/B runs: the conversion path)
+    return range_decode_sub_usable(a) && a.min_symbol >= -128 && a.min_symbol + a.n_symbols - 1 <= 127 && a.interval % 4 == 0 &&
+           a.n_per_stream % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols) & 15) == 0;
+}
+
+cst_status range_decode_sub_n8(const RangeDecodeArgs& a, hipStream_t hs) {
+    const size_t lds = range_decode_sub_lds(a);
+    const size_t blocks = ((a.n_streams + kWave - 1) / kWave * a.n_chunks + kRsWaves - 1) / kRsWaves;
+    RangeDecodeArgs b = a;
+    if (knobs().sub_order_flat) b.flags |= 0x100u;
+    auto go = [&](auto kernel) -> cst_status {
+        CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kRsThreads), lds, hs, b);
+        CST_HIP_TRY(hipGetLastError());
+        return CST_OK;
+    };
+    return a.precision <= 12 ? go(range_decode_sub_kernel<false, 1>) : go(range_decode_sub_kernel<true, 1>);
 }
 
 } // namespace cst

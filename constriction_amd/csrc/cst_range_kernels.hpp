@@ -64,6 +64,11 @@ bool range_encode_ckpt_fast_usable(const RangeEncodeArgs& a, cst_layout layout);
 cst_status range_encode_ckpt_fast(const RangeEncodeArgs& a, const RangeCkptOut& ck, hipStream_t hs);
 bool range_decode_sub_usable(const RangeDecodeArgs& a);
 cst_status range_decode_sub(const RangeDecodeArgs& a, hipStream_t hs);
+// ... over int8 symbol matrices (round 6): `symbols` of the argument structs is then an int8_t pointer in disguise
+bool range_encode_n8_usable(const RangeEncodeArgs& a, cst_layout layout, size_t interval);
+cst_status range_encode_ckpt_n8(const RangeEncodeArgs& a, const RangeCkptOut& ck, hipStream_t hs);
+bool range_decode_sub_n8_usable(const RangeDecodeArgs& a);
+cst_status range_decode_sub_n8(const RangeDecodeArgs& a, hipStream_t hs);
 
 // Forward-reading counterpart of RingReader (queue semantics).
 template <int SLOTS = kRingSlots, int AHEAD = kAhead>

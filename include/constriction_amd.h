@@ -606,6 +606,38 @@ cst_status cst_range_decode_batch(const cst_model *model, cst_coder_config cfg, 
                                   int32_t *d_symbols, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                   cst_range_state *d_rstate, int32_t *d_status, uint32_t flags, void *stream);
 
+/* ABI 5: NARROW symbol matrices for the range coder -- the reference's RangeEncoder / RangeDecoder are generic over the symbol type
+ * (src/stream/queue.rs:612, 968; src/stream/model/quantize.rs:229-255).  The four calls below are cst_range_{en,de}code_batch[_ckpt] with
+ * the matrix given as symbol_bytes = 1 (int8), 2 (int16) or 4 (int32: the plain call); words, counts, status and jump points are
+ * those of the int32 call on the widened values.  An int8 matrix of stream-major rows of whole 32-symbol tiles at (32,64),
+ * 8 <= P <= 24, is read by the hand-scheduled encoder itself ("range_encode_n8_kernel" / "range_encode_ckpt_n8_kernel": a quarter of the
+ * symbol bytes, one more instruction per symbol) and written by the sub-lane decoder itself ("range_decode_n8_kernel" /
+ * "range_decode_sub_n8_kernel": its byte tiles hold the symbols); every other shape converts next to the int32 call
+ * (cst_symbols_widen / cst_symbols_narrow).  The decoders want a support that fits the type.
+ * d_scratch: cst_range_sym_scratch_bytes(n_streams, n_per_stream, ckpt_interval or 0, symbol_bytes) bytes, contents irrelevant. */
+size_t cst_range_sym_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval, int32_t symbol_bytes);
+cst_status cst_range_encode_batch_sym(const cst_model *model, cst_coder_config cfg, const void *d_symbols, int32_t symbol_bytes,
+                                      size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                      size_t stride_words, uint32_t *d_n_words, cst_range_state *d_rstate, int32_t *d_status,
+                                      uint32_t flags, void *d_scratch, void *stream);
+cst_status cst_range_decode_batch_sym(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                      const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
+                                      const uint32_t *d_n_words, void *d_symbols, int32_t symbol_bytes, size_t n_streams,
+                                      size_t n_per_stream, cst_layout layout, cst_range_state *d_rstate, int32_t *d_status,
+                                      uint32_t flags, void *d_scratch, void *stream);
+cst_status cst_range_encode_batch_ckpt_sym(const cst_model *model, cst_coder_config cfg, const void *d_symbols, int32_t symbol_bytes,
+                                           size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                           size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval, uint32_t *d_ckpt_pos,
+                                           uint64_t *d_ckpt_lower, uint64_t *d_ckpt_range, int32_t *d_status, void *d_scratch,
+                                           void *stream);
+cst_status cst_range_decode_batch_ckpt_sym(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                           const uint64_t *d_offsets, size_t stride_words, size_t words_capacity,
+                                           const uint32_t *d_n_words, size_t ckpt_interval, const uint32_t *d_ckpt_pos,
+                                           const uint64_t *d_ckpt_lower, const uint64_t *d_ckpt_range, void *d_symbols,
+                                           int32_t symbol_bytes, size_t n_streams, size_t n_per_stream, void *d_scratch,
+                                           int32_t *d_status, void *stream);
+
+
 /* Per-symbol-model variants of the range coder (same argument meaning as the cst_ans_* twins). */
 cst_status cst_range_encode_cp_batch(cst_coder_config cfg, const uint32_t *d_left, const uint32_t *d_prob,
                                      size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,

@@ -39,6 +39,13 @@ from asmgen import Asm  # noqa: E402
 # Written to cst_range_decode_loop{,_b16}_sub{,_ends}.inc (stream-major only).
 SUB = bool(os.environ.get("GEN_RANGE_SUB"))
 SUB_ROW = 36
+# GEN_RANGE_N8=1 (round 6, with GEN_RANGE_SUB): the sub-lane decoder that writes an INT8 symbol matrix itself (the reference's Symbol
+# is generic: queue.rs:968, quantize.rs:229-255).  The byte tile then holds the symbols themselves (index + min_symbol, low byte:
+# P <= 12 through a biased index table, the bucket-entry form through the step's add), the previous tile's four bytes leave as they
+# are -- one global_store_dword per quad instead of four SDWA adds and a 16-byte store -- and a tile is 32 bytes of a row.
+# Written to cst_range_decode_loop{,_b16}_sub_n8{,_ends}.inc.
+N8 = bool(os.environ.get("GEN_RANGE_N8"))
+assert not N8 or SUB
 CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
 OUT = {(False, False): CSRC / "cst_range_decode_loop.inc", (False, True): CSRC / "cst_range_decode_loop_ends.inc",
        (True, False): CSRC / "cst_range_decode_loop_b16.inc", (True, True): CSRC / "cst_range_decode_loop_b16_ends.inc"}
@@ -217,7 +224,7 @@ def gen(ends):
         if B16:
             a.i(f"v_lshrrev_b32 {IDX}, %[ishift], {E0}", "symbol index = i0 + (q >= e1) + (q >= e2)   (off the chain)")
             a.i(f"v_addc_co_u32_e64 {IDX}, {SD}, 0, {IDX}, {V1}")
-            if SUB:
+            if SUB and not N8:
                 a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, 0, {IDX}, {V2}", "the decoded symbol's index")
             else:
                 a.i(f"v_addc_co_u32_e64 {SYM[(quad % 2) * 4 + pos]}, {SD}, %[minsym], {IDX}, {V2}", "the decoded symbol (min_symbol in a VGPR: one scalar operand per instruction)")
@@ -230,11 +237,14 @@ def gen(ends):
             a.ds(f"ds_read_b128 {XT}, %[trprev] offset:{1152 * quad}", "x", f"previous tile, rows (lane>>3)+{8 * quad}")
         if pos == 2:
             # XT / XB was read in step pos 1 and is covered by this step's lgkmcnt(0)
-            if SUB:
-                for b in range(4):
-                    a.i(f"v_add_u32_sdwa v{172 + b}, %[minsym], {XB} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{b}",
-                        "index -> int32 symbol" if b == 0 else None)
-            a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
+            if N8:
+                a.vmem(f"global_store_dword {GOFF[quad]}, {XB}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}", "four int8 symbols of a row")
+            else:
+                if SUB:
+                    for b in range(4):
+                        a.i(f"v_add_u32_sdwa v{172 + b}, %[minsym], {XB} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{b}",
+                            "index -> int32 symbol" if b == 0 else None)
+                a.vmem(f"global_store_dwordx4 {GOFF[quad]}, {XT}, s[80:81] \" CST_STORE_MOD \"", f"store{quad}")
         if pos == 3 and SUB:
             base = 160 + (quad % 2) * 4
             for b in range(4):
@@ -251,7 +261,7 @@ def gen(ends):
     a.i("v_swap_b32 %[trcur], %[trprev]")
     a.i("s_add_u32 s80, s80, s83")
     a.i("s_addc_u32 s81, s81, 0")
-    a.i("s_mov_b32 s83, %[tilestep]" if SYMBOL_MAJOR else "s_movk_i32 s83, 0x80")
+    a.i("s_mov_b32 s83, %[tilestep]" if SYMBOL_MAJOR else "s_movk_i32 s83, 0x20" if N8 else "s_movk_i32 s83, 0x80")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.wait_lds_all("landed chunks visible to the next tile")
@@ -357,7 +367,10 @@ def main():
                    "    : " + ", ".join(f'"{c}"' for c in CLOBBERS) + ");"]
             out = OUT[(b16, ends)]
             if SUB:
-                out = out.with_name(out.name.replace("_ends.inc", "_sub_ends.inc") if ends else out.name.replace(".inc", "_sub.inc"))
+                tag = "_sub_n8" if N8 else "_sub"
+                out = out.with_name(out.name.replace("_ends.inc", tag + "_ends.inc") if ends else out.name.replace(".inc", tag + ".inc"))
+                if N8:
+                    header[1] = header[1].replace(": see", ", int8 symbol matrix: see")
             if sm:
                 out = out.with_name(out.name.replace(".inc", "_sm.inc"))
                 header[1] = header[1].replace(": see", ", symbols[t][stream]: see")

@@ -34,6 +34,13 @@ from asmgen import Asm  # noqa: E402
 # countdown and a branch at the top of every tile, four instructions + three stores k times per stream.  The held word counts:
 # pos = wr + 1 (wr is -1 until the first word exists).  Written to cst_range_encode_loop{,_2f}_ck.inc; the words are the plain loop's.
 CKPT = bool(os.environ.get("GEN_RANGE_CK"))
+# GEN_RANGE_N8=1 (round 6, with GEN_RANGE_CK): the same loops over an INT8 symbol matrix (the reference's Symbol is generic:
+# queue.rs:612, quantize.rs:229-255).  A tile is 32 BYTES of a row: a lane requests four symbols with one global_load_dword into the last
+# register of its quad, and sign-extends them into the quad (three v_bfe_i32 and a shift) in front of the transposed ds_write_b128 --
+# one more VALU instruction per symbol, a quarter of the symbol bytes.  Written to cst_range_encode_loop{,_2f}_ck_n8.inc; the kernel
+# that runs them (range_encode_ckpt_kernel<FLUSHES, 1>) also serves the plain call (one chunk: the jump point is the start).
+N8 = bool(os.environ.get("GEN_RANGE_N8"))
+assert not N8 or CKPT
 CSRC = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc")
 OUT = {(1, False): CSRC / "cst_range_encode_loop.inc", (2, False): CSRC / "cst_range_encode_loop_2f.inc",
        (1, True): CSRC / "cst_range_encode_loop_sm.inc", (2, True): CSRC / "cst_range_encode_loop_2f_sm.inc"}
@@ -115,7 +122,7 @@ def fold_minmax(a, g):
 def advance_base(a):
     """s[80:81] -> symbols of the next tile to request; stays on the last tile once every tile has been requested"""
     a.i("s_cmp_lg_u32 s83, 0")
-    a.i("s_cselect_b32 s88, %[tilestep], 0" if SYMBOL_MAJOR else "s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s88, %[tilestep], 0" if SYMBOL_MAJOR else "s_cselect_b32 s88, 0x20, 0" if N8 else "s_cselect_b32 s88, 0x80, 0")
     a.i("s_cselect_b32 s89, 1, 0")
     a.i("s_add_u32 s80, s80, s88")
     a.i("s_addc_u32 s81, s81, 0")
@@ -132,11 +139,19 @@ def stage_one(a, name, buf, k):
         for c in range(4):
             a.ds(f"ds_write_b32 {TR[buf]}, v{base + 4 * k + c} offset:{(16 * (k >> 1) + c) * 144 + 64 * (k & 1)}", "tl")
         return
+    if N8:
+        b = {"A": 100, "B": 132}[name] + 4 * k
+        for c in range(3):
+            a.i(f"v_bfe_i32 v{b + c}, v{b + 3}, {8 * c}, 8", "four int8 symbols -> the quad" if c == 0 else None)
+        a.i(f"v_ashrrev_i32 v{b + 3}, 24, v{b + 3}")
     a.ds(f"ds_write_b128 {TR[buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
 
 def load_one(a, name, k):
-    a.vmem(f"global_load_dwordx4 {R[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
+    if N8:
+        a.vmem(f"global_load_dword v{ {'A': 100, 'B': 132}[name] + 4 * k + 3}, %[goff{k}], s[80:81] nt", f"ld{name}")
+    else:
+        a.vmem(f"global_load_dwordx4 {R[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
     if k == 7:
         advance_base(a)
 
@@ -304,7 +319,9 @@ def emit(flushes, symbol_major=False):
         header[1] = header[1].replace(": see", ", symbols[t][stream]: see")
     out = OUT[(flushes, symbol_major)]
     if CKPT:
-        out = out.with_name(out.name.replace(".inc", "_ck.inc"))
+        out = out.with_name(out.name.replace(".inc", "_ck_n8.inc" if N8 else "_ck.inc"))
+        if N8:
+            header[1] = header[1].replace(": see", ", int8 symbol matrix: see")
     out.write_text(a.render(header, ops))
     print(f"wrote {out} ({a.n_instr()} instructions incl. prologue)")
     for n in notes:

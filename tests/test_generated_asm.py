@@ -215,6 +215,21 @@ def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):
     for name in ("cst_range_decode_loop_sub.inc", "cst_range_decode_loop_sub_ends.inc", "cst_range_decode_loop_b16_sub.inc",
                  "cst_range_decode_loop_b16_sub_ends.inc"):
         assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
+    # round 6: the same two generators over INT8 symbol matrices (GEN_RANGE_N8 on top of GEN_RANGE_SUB / GEN_RANGE_CK)
+    monkeypatch.setenv("GEN_RANGE_N8", "1")
+    mod = _load("gen_range_decode_loop")
+    mod.OUT = {key: tmp_path / path.name for key, path in mod.OUT.items()}
+    mod.main()
+    for name in ("cst_range_decode_loop_sub_n8.inc", "cst_range_decode_loop_sub_n8_ends.inc", "cst_range_decode_loop_b16_sub_n8.inc",
+                 "cst_range_decode_loop_b16_sub_n8_ends.inc"):
+        assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
+    monkeypatch.delenv("GEN_RANGE_SUB")
+    monkeypatch.setenv("GEN_RANGE_CK", "1")
+    mod = _load("gen_range_encode_loop")
+    mod.OUT = {key: tmp_path / path.name for key, path in mod.OUT.items()}
+    mod.main()
+    for name in ("cst_range_encode_loop_ck_n8.inc", "cst_range_encode_loop_2f_ck_n8.inc"):
+        assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
 
 
 def test_packed_w16_loops_are_in_sync(tmp_path, monkeypatch):

@@ -114,6 +114,12 @@ def test_c4_range_coder(B, c2, P):
     assert enc.jump.pos.shape == (N_STREAMS, 2)
     _roundtrip(B, lambda: B.range_encode(sym, model, (32, 64, P), jump_points=0), lambda e: B.range_decode(e, model, N_PER),
                "range_encode_fast_kernel", "range_decode_fast_kernel", sym)
+    d = sym.to(torch.int8)                                               # round 6: int8 matrices inside the range coder's loops
+    enc = _roundtrip(B, lambda: B.range_encode(d, model, (32, 64, P)), lambda e: B.range_decode(e, model, N_PER, dtype=torch.int8),
+                     "range_encode_ckpt_n8_kernel", "range_decode_sub_n8_kernel", d)
+    assert enc.jump.pos.shape == (N_STREAMS, 2)
+    _roundtrip(B, lambda: B.range_encode(d, model, (32, 64, P), jump_points=0), lambda e: B.range_decode(e, model, N_PER, dtype=torch.int8),
+               "range_encode_n8_kernel", "range_decode_n8_kernel", d)
 
 
 def test_c5_shard_runs_the_small_footprint_pair(B, bench, c2):
