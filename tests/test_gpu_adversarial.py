@@ -226,9 +226,11 @@ def test_compaction_beyond_4_gib(B):
     torch.cuda.synchronize()
     want = torch.zeros(n_streams + 1, dtype=torch.int64)
     want[1:] = torch.cumsum(n_words.cpu().to(torch.int64), 0)
-    assert int(want[-1]) > (1 << 30) + (1 << 26) and int(want[1_048_577]) >= (1 << 30), "the prefix must pass 4 GiB (2^30 words)"
+    beyond = int((want >= (1 << 30)).nonzero()[0])             # the first stream that starts behind 4 GiB of packed words
+    assert int(want[-1]) > (1 << 30) + (1 << 26) and beyond < n_streams - 100_000, "the prefix must pass 4 GiB (2^30 words)"
     assert torch.equal(offsets.cpu(), want)
-    for s in (0, 4, 5, 6, 77_777, 77_778, 1_048_575, 1_048_576, 1_048_577, 1_100_000, n_streams - 3, n_streams - 2, n_streams - 1):
+    for s in (0, 4, 5, 6, 77_777, 77_778, 1_048_575, 1_048_576, 1_048_577, beyond - 1, beyond, beyond + 1, 1_100_000, n_streams - 3, n_streams - 2,
+              n_streams - 1):
         k, o = int(n_words[s]), int(want[s])
         got = packed[o: o + k].cpu().numpy().view(np.uint32)
         exp = ((s * stride + np.arange(k, dtype=np.int64)) & 0xFFFFFFFF).astype(np.uint32)
