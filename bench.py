@@ -797,6 +797,10 @@ def other_configs(B, rank, world, dist, args, reps=5):
         sym3 = synth_symbols_per_stream(SEED, rank * N_STREAMS, N_PER, -127, m3.cdfs_device(), 12)
         cdfs = cpu_tables(-127, 127, mu, sigma, 12) if check else None
         add("C3 per-stream (mean, std) tables, support -127..127", "ans", (32, 64, 12), m3, sym3, reps, check, cdfs, lo=-127)
+        try:      # round 6: C3's support fits int8 -- the compact-row encoder and the sub-lane decoder read / write the int8 matrix themselves
+            out.append(narrow_config(B, m3, sym3, reps, check, dtype=torch.int8, cfg=(32, 64, 12), name="C3 per-stream (mean, std) tables"))
+        except Exception as exc:      # noqa: BLE001
+            out.append({"workload": "C3 with int8 symbol matrices", "error": f"{type(exc).__name__}: {exc}"[:200], "bit_exact": False})
         jump("C3: decode with k jump points per stream (sub-lane decoder: the lanes of a stream share its table in LDS)", "ans", (32, 64, 12),
              m3, sym3, reps, check, cdfs, lo=-127, ks=(2, 4, 8))
         del sym3, m3, cdfs

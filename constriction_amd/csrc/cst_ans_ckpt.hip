@@ -242,6 +242,14 @@ cst_status cst_ans_encode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
     if (!model || (symbol_bytes != 1 && symbol_bytes != 2) || !d_words || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0)
         return CST_ERR_INVALID_ARGUMENT;
     if (n_streams == 0) return CST_OK;
+    if (d_symbols && symbol_bytes == 1 && model->per_stream && config_supported(cfg) && cfg.precision == model->precision) {
+        // one table per stream, int8 matrix (round 6): the compact-row encoder reads the int8 tiles itself
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        if (pt_n8_encode_usable(model, cfg, layout, d_symbols, n_streams, n_per_stream, ckpt_interval))
+            return note_kernel("ans_encode_pt_n8_kernel<ckpt>", ans_encode_pt_ckpt_n8(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words,
+                                                                                       ckpt_interval, d_ckpt_pos, d_ckpt_state, d_status, (hipStream_t)stream));
+    }
     if (d_symbols && !model->per_stream && !model->d_symbol_of_index && config_supported(cfg) && cfg.precision == model->precision) {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
@@ -289,7 +297,16 @@ cst_status cst_ans_decode_batch_ckpt_sym(const cst_model* model, cst_coder_confi
     const size_t ck_bytes = (cst_ckpt_scratch_bytes(n_streams, n_per_stream, ckpt_interval) + 15) & ~(size_t)15;
     void* conv_scratch = reinterpret_cast<unsigned char*>(d_scratch) + ck_bytes;
     if (model->per_stream) {
-        // one table per stream: the sub-lane decoders write int32 -- decode into the wide matrix, narrow behind them
+        if (symbol_bytes == 1 && d_symbols && config_supported(cfg) && cfg.precision == model->precision && model->n_tables == n_streams &&
+            n_per_stream / ckpt_interval >= 2 && pt_sub_n8_usable(model, cfg, n_streams, n_per_stream, ckpt_interval, d_symbols)) {
+            // int8 matrix (round 6): the sub-lane decoder's byte tiles hold the symbols and leave as they are
+            int dev = -1;
+            if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+            return note_kernel("ans_decode_pt_sub_n8_kernel", ans_decode_pt_sub(model, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos,
+                                                                                 d_ckpt_state, reinterpret_cast<int32_t*>(d_symbols), n_streams, n_per_stream,
+                                                                                 d_status, (hipStream_t)stream, 1));
+        }
+        // any other shape: the sub-lane decoders write int32 -- decode into the wide matrix, narrow behind them
         int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(conv_scratch) + 15) & ~(uintptr_t)15);
         const cst_status rc = cst_ans_decode_batch_ckpt(model, cfg, d_words, d_offsets, stride_words, words_capacity, ckpt_interval, d_ckpt_pos, d_ckpt_state,
                                                         wide, n_streams, n_per_stream, d_scratch, d_status, stream);

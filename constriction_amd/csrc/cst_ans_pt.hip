@@ -17,6 +17,8 @@
 //           further in a wave-uniform loop (buckets that hold more than four bins: the narrow bins next to the unit runs).
 // Shapes this file does not take (P > 12 or P < 8, more than 256 symbols, the 16-bit word preset, symbol-major
 // matrices, blocks whose rows do not fit in LDS) stay on the full-row kernels of cst_ans_ps.hip.
+#include <type_traits>
+
 #include "cst_ans_kernels.hpp"
 
 namespace cst {
@@ -103,6 +105,40 @@ __device__ __forceinline__ void pt_encode_tiles_loop_ck(uint32_t& lo, uint32_t& 
 #include "cst_pt_encode_loop_ck.inc"
 }
 
+// ... over an INT8 symbol matrix (round 6, GEN_PT_N8=1 on top of GEN_PT_CK): a tile is 32 bytes of a row
+__device__ __forceinline__ void pt_encode_tiles_loop_ck_n8(uint32_t& lo, uint32_t& hi, uint32_t& wr, uint32_t& flushed, int32_t& smin,
+                                                           int32_t& smax, uint32_t& ck_index, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                           uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off, uint32_t sym_lo,
+                                                           uint32_t sym_hi, uint32_t row_addr_biased, uint32_t recip_addr, int32_t min_symbol,
+                                                           uint32_t P, uint32_t ring_mask, const void* words_base, uint64_t symbols_base,
+                                                           uint32_t n_tiles, const void* ck_pos_base, const void* ck_state_base,
+                                                           uint32_t ck_tiles, const uint32_t (&goff)[8]) {
+#include "cst_pt_encode_loop_ck_n8.inc"
+}
+
+// Main loops of the SUB-LANE decoder writing an INT8 matrix (round 6, GEN_PT_N8=1 on top of GEN_PT_SUB): a packed add of min_symbol
+__device__ __forceinline__ void pt_decode_tiles_loop_sub_n8(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
+                                                            uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
+                                                            uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
+                                                            uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                            uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                            const uint32_t (&goff)[8]) {
+#define CST_STORE_MOD ""
+#include "cst_pt_decode_loop_sub_n8.inc"
+#undef CST_STORE_MOD
+}
+
+__device__ __forceinline__ void pt_decode_tiles_loop_sub16_n8(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
+                                                              uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
+                                                              uint64_t store_base, uint32_t n_tiles, uint32_t l1_lane_addr, uint32_t row_addr,
+                                                              uint32_t shift_minus_1, uint32_t ring_lane_addr, uint32_t dump_addr,
+                                                              uint32_t words_off, uint32_t tile_row_addr, uint32_t tile_tr_addr,
+                                                              const uint32_t (&goff)[8]) {
+#define CST_STORE_MOD ""
+#include "cst_pt_decode_loop_sub16_n8.inc"
+#undef CST_STORE_MOD
+}
+
 // Main loop of the SUB-LANE decoder (GEN_PT_SUB=1 of scripts/gen_pt_decode_loop.py): the same chain, the symbol tile in bytes
 __device__ __forceinline__ void pt_decode_tiles_loop_sub(uint32_t& lo, uint32_t& hi, uint32_t& rd, uint32_t& lo_issued, uint32_t bucket_mask,
                                                          uint32_t ring_mask, uint32_t P, int32_t min_symbol, const void* words_base,
@@ -146,8 +182,12 @@ __device__ __forceinline__ void pt_stage_rows(uint32_t* rows_l, const uint32_t* 
 
 // LDS layout: [word rings, 8 KiB per wave][reciprocals 8 B x 2^P][symbol tiles][rows]
 // CK: note a jump point in front of every chunk of a.interval symbols (a.ckpt_pos / a.ckpt_state)
-template <bool CK>
+// SB = bytes per symbol of the matrix behind a.symbols_in: 4, or 1 (int8, round 6: CK only -- the plain call is the one-chunk case)
+template <bool CK, int SB = 4>
 __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
+    static_assert(SB == 4 || (SB == 1 && CK), "int8 matrices: the checkpointing form");
+    using SymT = typename std::conditional<SB == 1, int8_t, int32_t>::type;
+    const SymT* symbols_in = reinterpret_cast<const SymT*>(a.symbols_in);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
         return EncEntry{(e & 0xffffu) + (i - t), p, (uint32_t)m, (uint32_t)(m >> 32)};
     };
 
-    const int32_t* my = a.symbols_in + (active ? s : 0) * N;
+    const SymT* my = symbols_in + (active ? s : 0) * N;
     // (jump points lie on tile boundaries or the tiles are not used: chunks of 32 k symbols are the fast case)
     const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.symbols_in) & 15) == 0) && (!CK || a.interval % kTileSyms == 0);
     const size_t n_full = vec ? N / kTileSyms : 0;
@@ -208,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
     // ragged top part [32 * n_full, N): direct reads
     for (size_t t = N; t > n_full * kTileSyms;) {
         --t;
-        const int32_t v = active ? my[t] : a.min_symbol;
+        const int32_t v = active ? (int32_t)my[t] : a.min_symbol;
         L.template step<true>(entry_of(v), P);
         L.flush_chunks();
         note_jump_point(t);
@@ -222,8 +262,8 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
         if (!__any(!ok)) {
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols_in + s0 * N + (n_full - 1) * kTileSyms);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * SB);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols_in + s0 * N + (n_full - 1) * kTileSyms);
             // wave-uniform base in SGPRs (readfirstlane returns int: go through uint32_t)
             const uint64_t symbols_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
@@ -233,6 +273,13 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
             if constexpr (CK) {
                 uint32_t ck_index = (uint32_t)(s * a.n_chunks + a.n_chunks - 1);        // the last chunk's jump point comes first
+                if constexpr (SB == 1)
+                    pt_encode_tiles_loop_ck_n8(lo, hi, L.out.wr, L.out.flushed, smin, smax, ck_index, lds_addr(tile + lane * kTileStride),
+                                               lds_addr(tile) + tr_off, L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A,
+                                               lds_addr(recip), a.min_symbol, (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out,
+                                               symbols_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), a.ckpt_pos, a.ckpt_state,
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a.interval / kTileSyms)), goff);
+                else
                 pt_encode_tiles_loop_ck(lo, hi, L.out.wr, L.out.flushed, smin, smax, ck_index, lds_addr(tile + lane * kTileStride),
                                         lds_addr(tile) + tr_off, L.out.lane_addr, L.out.cap, (uint32_t)slab_off, A, B, row_addr - 2u * A,
                                         lds_addr(recip), a.min_symbol, (uint32_t)P, (uint32_t)((kPtRingSlots - 1) * kWave * 4), a.words_out,
@@ -250,6 +297,16 @@ __global__ __launch_bounds__(kBlock) void ans_encode_pt_kernel(const PtArgs a) {
             done = true;
         }
     }
+    if constexpr (SB == 1) {
+        if (n_full > 0 && !done) {      // (a partial last wave, slabs the statement does not take: symbol by symbol, straight from the int8 rows)
+            for (size_t t = n_full * kTileSyms; t-- > 0;) {
+                const int32_t v = active ? (int32_t)my[t] : a.min_symbol;
+                L.template step<true>(entry_of(v), P);
+                L.flush_chunks();
+                note_jump_point(t);
+            }
+        }
+    } else
     if (n_full > 0 && !done) {
         int32_t r[kTileSyms];
         tile_fetch<true>(a.symbols_in, a.n_streams, N, s0, (n_full - 1) * kTileSyms, lane, r);
@@ -465,8 +522,12 @@ constexpr int kSubTileRow = 36;                                                 
 constexpr size_t kSubTileBytes = (size_t)kWave * kSubTileRow;                          // 2304 B per wave
 constexpr size_t kSubDumpBytes = 4 * kWave * 4;                                        // ONE landing area (never read)
 
-template <int WAVES, bool RING16>
+// SB = bytes per symbol of the matrix behind a.symbols_out: 4, or 1 (int8, round 6: the four index bytes of a tile piece get min_symbol
+// added byte by byte and leave with one 4-byte store)
+template <int WAVES, bool RING16, int SB = 4>
 __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const PtArgs a) {
+    using SymT = typename std::conditional<SB == 1, int8_t, int32_t>::type;
+    SymT* symbols_out = reinterpret_cast<SymT*>(a.symbols_out);
     constexpr int kSubWaves = WAVES, kSlots = SubGeo<WAVES, RING16>::kSlots;
     constexpr size_t kSubRingBytes = SubGeo<WAVES, RING16>::kRingBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -572,10 +633,11 @@ __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const 
         return a.min_symbol + (int32_t)idx;
     };
 
-    int32_t* row = a.symbols_out + s * N + (size_t)chunk * K;
+    SymT* row = symbols_out + s * N + (size_t)chunk * K;
     const size_t n_full = K / kTileSyms;
     size_t t_done = 0;
-    if (P == 12 && n_full > 0 && s0 + kWave <= a.n_streams && K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0 && N < (1u << 24)) {
+    if (P == 12 && n_full > 0 && s0 + kWave <= a.n_streams && K % 4 == 0 && N % 4 == 0 && (reinterpret_cast<uintptr_t>(a.symbols_out) & 15) == 0 &&
+        N < (1u << 24)) {
         const unsigned char* words_base = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(a.words_in) & ~(uintptr_t)15);
         const uint64_t w_off = (uint64_t)(reinterpret_cast<const unsigned char*>(L.in.base16) - words_base);
         const bool off_ok = w_off + 4ull * ((uint64_t)L.in.rd + 8) < 0x80000000ull;
@@ -583,14 +645,24 @@ __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const 
         if (!__any(!off_ok)) {
             uint32_t goff[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * 4);
+            for (int k = 0; k < 8; ++k) goff[k] = (uint32_t)((((size_t)(lane >> 3) + 8 * k) * N + 4 * (size_t)(lane & 7)) * SB);
             const uint32_t tr_off = (uint32_t)((lane >> 3) * kSubTileRow + 4 * (lane & 7));
-            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(a.symbols_out + s0 * N + (size_t)chunk * K);
+            const uint64_t sb = (uint64_t)reinterpret_cast<uintptr_t>(symbols_out + s0 * N + (size_t)chunk * K);
             const uint64_t store_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32)) << 32) |
                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb);
             const bool plain_stores = __builtin_amdgcn_readfirstlane((int)(((N * 4) % 128 != 0 || (sb & 127) != 0) ? 1 : 0)) != 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
-            if constexpr (RING16)
+            if constexpr (SB == 1 && RING16)
+                pt_decode_tiles_loop_sub16_n8(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kSlots - 1) * kWave * 4), (uint32_t)P,
+                                              a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                              lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                              lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff);
+            else if constexpr (SB == 1)
+                pt_decode_tiles_loop_sub_n8(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kSlots - 1) * kWave * 4), (uint32_t)P,
+                                            a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
+                                            lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
+                                            lds_addr(tile + lane * kSubTileRow), lds_addr(tile) + tr_off, goff);
+            else if constexpr (RING16)
                 pt_decode_tiles_loop_sub16(lo, hi, L.in.rd, L.in.lo_issued, bucket_mask, (uint32_t)((kSlots - 1) * kWave * 4), (uint32_t)P,
                                            a.min_symbol, words_base, store_base, (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full),
                                            lds_addr(l1p), row_addr, L.in.shift - 1u, lds_addr(ring + lane), lds_addr(dump), (uint32_t)w_off,
@@ -605,7 +677,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const 
     }
     for (size_t t = t_done; t < K; ++t) {          // shapes the statement does not take: symbol by symbol (correct, slow)
         const int32_t sym = decode_one();
-        if (active) row[t] = sym;
+        if (active) row[t] = (SymT)sym;
         L.in.advance_window();
     }
     if (!active) return;
@@ -663,6 +735,28 @@ cst_status ans_encode_pt_ckpt(const cst_model* model, const int32_t* d_symbols, 
     return pt_launch(ans_encode_pt_kernel<true>, a, pt_lds_bytes(model, true), hs);
 }
 
+// int8 symbol matrices inside the loops (round 6): rows of whole tiles in chunks of whole tiles, a support inside int8
+bool pt_n8_encode_usable(const cst_model* m, cst_coder_config cfg, cst_layout layout, const void* d_symbols, size_t n_streams, size_t n_per_stream,
+                         size_t interval) {
+    if (knobs().no_n8 || !pt_usable(m, cfg, layout, n_per_stream) || m->n_tables != n_streams) return false;
+    if (interval == 0 || interval % kTileSyms != 0 || n_per_stream % interval != 0 || n_per_stream >= (1u << 24)) return false;
+    if ((reinterpret_cast<uintptr_t>(d_symbols) & 15) != 0 || n_streams * (n_per_stream / interval) >= (1u << 28)) return false;
+    return m->min_symbol >= -128 && m->min_symbol + m->n_symbols - 1 <= 127;
+}
+
+cst_status ans_encode_pt_ckpt_n8(const cst_model* model, const void* d_symbols8, size_t n_streams, size_t n_per_stream, uint32_t* d_words,
+                                 size_t stride_words, uint32_t* d_n_words, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
+                                 int32_t* d_status, hipStream_t hs) {
+    if (model->n_tables != n_streams) return CST_ERR_INVALID_ARGUMENT;
+    PtArgs a{};
+    a.symbols_in = reinterpret_cast<const int32_t*>(d_symbols8); a.n_streams = n_streams; a.n_per_stream = n_per_stream;
+    a.precision = model->precision; a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol;
+    a.meta = model->d_pt_meta; a.rows_enc = model->d_pt_enc; a.block_base = model->d_pt_block_base; a.recip = model->d_recip;
+    a.words_out = d_words; a.stride_words = stride_words; a.n_words_out_enc = d_n_words; a.status = d_status;
+    a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.interval = interval; a.n_chunks = n_per_stream / interval;
+    return pt_launch(ans_encode_pt_kernel<true, 1>, a, pt_lds_bytes(model, true), hs);
+}
+
 // rows of the S = max(waves / k, 1) * 64 streams of a workgroup: at most S / 64 times the largest 64-stream group (pt_max_dec64),
 // and never more than the largest block of kBlock streams
 static size_t pt_sub_rows_bytes(const cst_model* m, int waves, int sub_shift) {
@@ -706,7 +800,7 @@ bool pt_sub_usable(const cst_model* m, cst_coder_config cfg, size_t n_streams, s
 
 cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
                              size_t words_capacity, size_t interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
-                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs) {
+                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs, int symbol_bytes) {
     PtArgs a{};
     const size_t k = n_per_stream / interval;
     const int ks = pt_sub_shift(k);
@@ -728,8 +822,19 @@ cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, co
         CST_HIP_TRY(hipGetLastError());
         return CST_OK;
     };
+    if (symbol_bytes == 1) {
+        if (geo.waves == 16) return go(ans_decode_pt_sub_kernel<16, true, 1>);
+        return geo.ring16 ? go(ans_decode_pt_sub_kernel<8, true, 1>) : go(ans_decode_pt_sub_kernel<8, false, 1>);
+    }
     if (geo.waves == 16) return go(ans_decode_pt_sub_kernel<16, true>);
     return geo.ring16 ? go(ans_decode_pt_sub_kernel<8, true>) : go(ans_decode_pt_sub_kernel<8, false>);
+}
+
+// ... writing an int8 matrix itself: the sub-lane shapes whose support fits the type (P = 12: the statement's precision)
+bool pt_sub_n8_usable(const cst_model* m, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval, const void* d_symbols) {
+    if (knobs().no_n8 || !pt_sub_usable(m, cfg, n_streams, n_per_stream, interval)) return false;
+    if (interval % 4 != 0 || n_per_stream % 4 != 0 || (reinterpret_cast<uintptr_t>(d_symbols) & 15) != 0) return false;
+    return m->min_symbol >= -128 && m->min_symbol + m->n_symbols - 1 <= 127;
 }
 
 cst_status ans_decode_pt(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_offsets,

@@ -98,7 +98,9 @@ size_t cst_jump_points_auto(const cst_model* model, cst_coder_config cfg, int32_
 
     if (model->per_stream) {
         // one table per stream: the sub-lane decoder shares a stream's table among its lanes -- eight of them where the tables fit
-        if (symbol_bytes != 4 || model->n_tables != n_streams || !pt_usable(model, cfg, layout, n_per_stream)) return 0;
+        // (int8 matrices are read / written by the same kernels' int8 forms: round 6; int16 would convert -- no points for it)
+        if ((symbol_bytes != 4 && symbol_bytes != 1) || model->n_tables != n_streams || !pt_usable(model, cfg, layout, n_per_stream)) return 0;
+        if (symbol_bytes == 1 && (model->min_symbol < -128 || model->min_symbol + model->n_symbols - 1 > 127)) return 0;
         size_t k = fill < 8 ? 8 : fill;
         if (k > 16) k = 16;
         for (; k >= 2; k >>= 1) {

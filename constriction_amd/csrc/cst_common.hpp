@@ -219,9 +219,17 @@ cst_status ans_encode_pt_ckpt(const cst_model* model, const int32_t* d_symbols, 
                               size_t stride_words, uint32_t* d_n_words, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
                               int32_t* d_status, hipStream_t hs);
 bool pt_sub_usable(const cst_model* model, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval);
+// (symbol_bytes = 1: d_symbols is an int8_t matrix in disguise and pt_sub_n8_usable has said yes)
 cst_status ans_decode_pt_sub(const cst_model* model, const uint32_t* d_words, const uint64_t* d_offsets, size_t stride_words,
                              size_t words_capacity, size_t interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_state,
-                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs);
+                             int32_t* d_symbols, size_t n_streams, size_t n_per_stream, int32_t* d_status, hipStream_t hs, int symbol_bytes = 4);
+// int8 symbol matrices inside the per-stream-table loops (round 6)
+bool pt_n8_encode_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, const void* d_symbols, size_t n_streams, size_t n_per_stream,
+                         size_t interval);
+cst_status ans_encode_pt_ckpt_n8(const cst_model* model, const void* d_symbols8, size_t n_streams, size_t n_per_stream, uint32_t* d_words,
+                                 size_t stride_words, uint32_t* d_n_words, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state,
+                                 int32_t* d_status, hipStream_t hs);
+bool pt_sub_n8_usable(const cst_model* model, cst_coder_config cfg, size_t n_streams, size_t n_per_stream, size_t interval, const void* d_symbols);
 
 // (16,32) with packed words (CST_FLAG_PACKED_W16, cst_ans_w16pk.hip): two 16-bit words per 32-bit slot, every count in 16-bit words
 struct AnsEncodeArgs;

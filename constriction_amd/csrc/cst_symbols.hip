@@ -145,6 +145,19 @@ cst_status cst_ans_encode_batch_sym(const cst_model* model, cst_coder_config cfg
     }
     if (!d_scratch && n_streams * n_per_stream > 0) return CST_ERR_INVALID_ARGUMENT;
     int32_t* wide = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
+    if (symbol_bytes == 1 && model->per_stream && flags == CST_FLAG_NONE && d_symbols && d_words && d_n_words && d_status && n_streams > 0 &&
+        n_per_stream >= 32 && config_supported(cfg) && cfg.precision == model->precision) {
+        // one table per stream (config C3), int8 matrix (round 6): the jump-point-noting encoder reads int8 tiles itself -- run it with
+        // ONE chunk (its only jump point, the end of the stream, goes to the scratch and is not used)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+        if (pt_n8_encode_usable(model, cfg, layout, d_symbols, n_streams, n_per_stream, n_per_stream)) {
+            uint64_t* jump_state = reinterpret_cast<uint64_t*>(wide);
+            uint32_t* jump_pos = reinterpret_cast<uint32_t*>(jump_state + n_streams);
+            return note_kernel("ans_encode_pt_n8_kernel", ans_encode_pt_ckpt_n8(model, d_symbols, n_streams, n_per_stream, d_words, stride_words, d_n_words,
+                                                                                 n_per_stream, jump_pos, jump_state, d_status, (hipStream_t)stream));
+        }
+    }
     const cst_status rc = cst_symbols_widen(d_symbols, symbol_bytes, n_streams * n_per_stream, wide, stream);
     if (rc != CST_OK) return rc;
     return cst_ans_encode_batch(model, cfg, wide, n_streams, n_per_stream, layout, d_words, stride_words, d_n_words, d_state, d_status, flags, stream);

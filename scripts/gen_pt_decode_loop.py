@@ -41,8 +41,16 @@ SUB = bool(os.environ.get("GEN_PT_SUB"))
 SUB16 = os.environ.get("GEN_PT_SUB") == "2"
 REG_SHIFT = 52 if SUB16 else 0
 SUB_ROW = 36          # bytes between the rows of the byte tile (9 dwords: the lanes' quad writes hit 64 different banks)
+# GEN_PT_N8=1 (round 6, with GEN_PT_SUB): the sub-lane decoders writing an INT8 symbol matrix themselves.  A four-byte piece of the byte
+# tile (four symbol INDICES) becomes four int8 symbols by ONE packed add of min_symbol to every byte (carries between the bytes
+# suppressed: five VALU instructions instead of four SDWA adds) and leaves with one global_store_dword; a tile is 32 bytes of a row.
+# (Adding min_symbol to the index bytes of the staged rows instead would be free -- and wrong: the search compares whole entries, and a
+# run mark 0xfff with index byte 0xff exceeds the key's 0xffffe.)
+N8 = bool(os.environ.get("GEN_PT_N8"))
+assert not N8 or SUB
 OUT = Path(os.environ.get("GEN_CSRC") or Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc") / \
-    ("cst_pt_decode_loop_sub16.inc" if SUB16 else "cst_pt_decode_loop_sub.inc" if SUB else "cst_pt_decode_loop.inc")
+    (("cst_pt_decode_loop_sub16_n8.inc" if SUB16 else "cst_pt_decode_loop_sub_n8.inc") if N8 else
+     "cst_pt_decode_loop_sub16.inc" if SUB16 else "cst_pt_decode_loop_sub.inc" if SUB else "cst_pt_decode_loop.inc")
 
 K_CHUNKS = 2 if SUB16 else 3      # window chunks requested per tile (32 symbols * 12 bits = 12 words = 3 chunks) / per half tile
 AHEAD_M1 = 11 if SUB16 else 23    # kPtAhead - 1
@@ -71,7 +79,7 @@ PEND = [(f"v[{152 + 4 * k}:{155 + 4 * k}]", [f"v{152 + 4 * k + j}" for j in rang
 LAND = [f"v{164 + k}" for k in range(K_CHUNKS)]
 WANT, TMP, TADDR, TOFF = "v167", "v168", "v169", "v170"
 SD, SAVE, M2, MORE, RUN, M3, M4 = "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s[92:93]", "s[76:77]", "s[78:79]"
-CLOBBERS = [f"v{r}" for r in range(100, 178)] + [f"s{r}" for r in range(76, 94)] + ["vcc", "scc", "memory"]
+CLOBBERS = [f"v{r}" for r in range(100, 178)] + [f"s{r}" for r in range(74 if N8 else 76, 94)] + ["vcc", "scc", "memory"]
 
 
 def wait_if_pending(a, tag, comment=None):
@@ -216,6 +224,10 @@ def step(a, j):
 def gen():
     a = Asm()
     a.i("v_mov_b32 v103, 0")
+    if N8:
+        a.i("s_and_b32 s74, %[minsym], 0xff")
+        a.i("s_mul_i32 s74, s74, 0x01010101", "min_symbol in every byte")
+        a.i("s_and_b32 s75, s74, 0x7f7f7f7f")
     a.i("s_mov_b64 s[80:81], %[gbase]", "store base of the current tile, bumped by 128 B per iteration")
     a.i("s_mov_b32 s82, %[ntiles]")
     # first bucket read and the off-chain values of step 0
@@ -277,6 +289,15 @@ def gen():
                     a.events.append(("wait_lds", None, n_after))
                     a.lds = a.lds[len(a.lds) - n_after:] if n_after else []
                     a.i(f"s_waitcnt lgkmcnt({n_after})", f"piece {k} is back")
+                if N8:
+                    t, u = f"v{136 + 4 * k}", f"v{137 + 4 * k}"
+                    a.i(f"v_and_b32 {t}, 0x7f7f7f7f, {XB[k]}", "four indices + min_symbol, byte by byte (mod 256): the low seven bits add ...")
+                    a.i(f"v_xor_b32 {u}, s74, {XB[k]}")
+                    a.i(f"v_add_u32 {t}, s75, {t}")
+                    a.i(f"v_and_b32 {u}, 0x80808080, {u}", "... the top bits by xor: no carry crosses a byte")
+                    a.i(f"v_xor_b32 {t}, {t}, {u}")
+                    a.vmem(f"global_store_dword %[goff{4 * half + k}], {t}, s[80:81] \" CST_STORE_MOD \"", "store", "four int8 symbols of a row")
+                    continue
                 for b in range(4):
                     a.i(f"v_add_u32_sdwa v{136 + 4 * k + b}, %[minsym], {XB[k]} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_{b}",
                         "index -> int32 symbol" if b == 0 else None)
@@ -284,7 +305,7 @@ def gen():
                 a.wait_lds("xo")
             a.vmem(f"global_store_dwordx4 %[goff{4 * half + k}], {XO[k]}, s[80:81] \" CST_STORE_MOD \"", "store")
     window_landing("the chunk loads are older than this tile's stores")
-    a.i("s_add_u32 s80, s80, 0x80")
+    a.i("s_add_u32 s80, s80, 0x20" if N8 else "s_add_u32 s80, s80, 0x80")
     a.i("s_addc_u32 s81, s81, 0")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
@@ -303,7 +324,7 @@ def gen():
 def main():
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_pt_decode_loop.py -- do not edit by hand (edit the generator and re-run it).",
-              "// Main loop of the hand-scheduled per-stream-table ANS decoder: see pt_decode_tiles_loop in cst_ans_pt.hip."]
+              "// Main loop of the hand-scheduled per-stream-table ANS decoder" + (", int8 symbol matrix" if N8 else "") + ": see pt_decode_tiles_loop in cst_ans_pt.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [rd] "+v"(rd), [lo_issued] "+v"(lo_issued)',
            '    : [bmask] "s"(bucket_mask), [cmask] "s"(ring_mask), [P] "s"(P), [fffe] "s"(0xffffeu), [fff] "s"(0xfffu), [minsym] "s"(min_symbol),',
            '      [wbase] "s"(words_base), [gbase] "s"(store_base), [ntiles] "s"(n_tiles),',

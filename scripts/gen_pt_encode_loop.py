@@ -28,7 +28,13 @@ import os
 # vmcnt(0) (they are not in the generator's book: waiting for MORE than the book knows is always safe) and cost nothing
 # measurable.  The compressed words are those of the plain loop.
 CKPT = bool(os.environ.get("GEN_PT_CK"))
-OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / ("cst_pt_encode_loop_ck.inc" if CKPT else "cst_pt_encode_loop.inc")
+# GEN_PT_N8=1 (round 6, with GEN_PT_CK): the same loop over an INT8 symbol matrix (C3's support -127 .. 127 fits the type; the reference's
+# Symbol is generic, quantize.rs:229-255).  A tile is 32 BYTES of a row: one global_load_dword per lane and quad into the quad's last
+# register, sign-extended into the quad (three v_bfe_i32 and a shift) in front of the transposed ds_write_b128.  cst_pt_encode_loop_ck_n8.inc
+N8 = bool(os.environ.get("GEN_PT_N8"))
+assert not N8 or CKPT
+OUT = Path(__file__).resolve().parent.parent / "constriction_amd" / "csrc" / \
+    ("cst_pt_encode_loop_ck_n8.inc" if N8 else "cst_pt_encode_loop_ck.inc" if CKPT else "cst_pt_encode_loop.inc")
 
 
 def regs(base, n=4):
@@ -128,16 +134,24 @@ def stage_b(a, g):
 def advance_base(a):
     """s[80:81] -> symbols of the next tile to request; stays on tile 0 once every tile has been requested"""
     a.i("s_cmp_lg_u32 s83, 0")
-    a.i("s_cselect_b32 s88, 0x80, 0")
+    a.i("s_cselect_b32 s88, 0x20, 0" if N8 else "s_cselect_b32 s88, 0x80, 0")
     a.i("s_cselect_b32 s89, 1, 0")
     a.i("s_sub_u32 s80, s80, s88")
     a.i("s_subb_u32 s81, s81, 0")
     a.i("s_sub_u32 s83, s83, s89")
 
 
+def _quad_base(name, k):
+    """first register of quad k of symbol set `name` (R[name][k] = "v[b:b+3]")"""
+    return int(R[name][k][2:].split(":")[0])
+
+
 def load_set(a, name):
     for k in range(8):
-        a.vmem(f"global_load_dwordx4 {R[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
+        if N8:
+            a.vmem(f"global_load_dword v{_quad_base(name, k) + 3}, %[goff{k}], s[80:81] nt", f"ld{name}")
+        else:
+            a.vmem(f"global_load_dwordx4 {R[name][k]}, %[goff{k}], s[80:81] nt", f"ld{name}")
     advance_base(a)
 
 
@@ -149,6 +163,11 @@ def stage_set(a, name, buf):
     if os.environ.get("GEN_NO_VMWAIT") and len(a.lines) > 100:      # timing experiment only: results are wrong
         a.lines.pop()
     for k in range(8):
+        if N8:
+            b = _quad_base(name, k)
+            for c in range(3):
+                a.i(f"v_bfe_i32 v{b + c}, v{b + 3}, {8 * c}, 8", "four int8 symbols -> the quad" if c == 0 else None)
+            a.i(f"v_ashrrev_i32 v{b + 3}, 24, v{b + 3}")
         a.ds(f"ds_write_b128 {TR[buf]}, {R[name][k]} offset:{1152 * k}", "tl")
 
 
@@ -274,7 +293,7 @@ def gen():
 def main():
     a, notes = gen()
     header = ["// GENERATED by scripts/gen_pt_encode_loop.py -- do not edit by hand (edit the generator and re-run it).",
-              "// Main loop of the hand-scheduled per-stream-table ANS encoder: see pt_encode_tiles_loop in cst_ans_pt.hip."]
+              "// Main loop of the hand-scheduled per-stream-table ANS encoder" + (", int8 symbol matrix" if N8 else "") + ": see pt_encode_tiles_loop in cst_ans_pt.hip."]
     ops = ['    : [lo] "+v"(lo), [hi] "+v"(hi), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)' +
            (', [ckidx] "+v"(ck_index)' if CKPT else ""),
            '    : [row0] "v"(tile_row_addr), [tr0] "v"(tile_tr_addr),',

@@ -215,6 +215,18 @@ def test_jump_point_and_sub_lane_variants_are_in_sync(tmp_path, monkeypatch):
     for name in ("cst_range_decode_loop_sub.inc", "cst_range_decode_loop_sub_ends.inc", "cst_range_decode_loop_b16_sub.inc",
                  "cst_range_decode_loop_b16_sub_ends.inc"):
         assert (tmp_path / name).read_text() == (csrc / name).read_text(), name
+    # round 6: the per-stream-table generators over INT8 symbol matrices (GEN_PT_N8 on top of GEN_PT_CK / GEN_PT_SUB)
+    monkeypatch.delenv("GEN_RANGE_SUB")
+    monkeypatch.setenv("GEN_PT_N8", "1")
+    monkeypatch.setenv("GEN_PT_CK", "1")
+    assert _regenerate(_load("gen_pt_encode_loop"), tmp_path, "cst_pt_encode_loop_ck_n8.inc") == (csrc / "cst_pt_encode_loop_ck_n8.inc").read_text()
+    monkeypatch.delenv("GEN_PT_CK")
+    for mode, name in (("1", "cst_pt_decode_loop_sub_n8.inc"), ("2", "cst_pt_decode_loop_sub16_n8.inc")):
+        monkeypatch.setenv("GEN_PT_SUB", mode)
+        assert _regenerate(_load("gen_pt_decode_loop"), tmp_path, name) == (csrc / name).read_text(), name
+    monkeypatch.delenv("GEN_PT_SUB")
+    monkeypatch.delenv("GEN_PT_N8")
+    monkeypatch.setenv("GEN_RANGE_SUB", "1")
     # round 6: the same two generators over INT8 symbol matrices (GEN_RANGE_N8 on top of GEN_RANGE_SUB / GEN_RANGE_CK)
     monkeypatch.setenv("GEN_RANGE_N8", "1")
     mod = _load("gen_range_decode_loop")

@@ -104,6 +104,10 @@ def test_c3_tables_per_stream(B, bench):
     assert enc.jump.pos.shape == (N_STREAMS, 8)
     _roundtrip(B, lambda: B.ans_encode(sym, model, (32, 64, 12), jump_points=0), lambda e: B.ans_decode(e, model, N_PER),
                "ans_encode_pt_kernel", "ans_decode_pt_kernel", sym)
+    d = sym.to(torch.int8)                                               # round 6: the int8 matrix inside the same loops
+    enc = _roundtrip(B, lambda: B.ans_encode(d, model, (32, 64, 12)), lambda e: B.ans_decode(e, model, N_PER, dtype=torch.int8),
+                     "ans_encode_pt_n8_kernel<ckpt>", "ans_decode_pt_sub_n8_kernel", d)
+    assert enc.jump.pos.shape == (N_STREAMS, 8)
 
 
 @pytest.mark.parametrize("P", [12, 24])
