@@ -557,17 +557,30 @@ def ragged_config(B, reps, check, n_docs=100_000, n_sym=64, precision=24):
     decoded, status = B.ans_decode_ragged(enc, model, off_d)
     enc_ms = event_ms(lambda: B.ans_encode_ragged(flat, off_d, model, cfg), reps)
     dec_ms = event_ms(lambda: B.ans_decode_ragged(enc, model, off_d, out=decoded), reps)
+    dec_kernel = B.last_kernel()
     total_words = int(enc.n_words.sum().item())
     byts = 4 * n_total + 4 * total_words + 16 * n_docs
+    # the calls above are the DEFAULT calls: the encoder notes a jump point every batched.RAGGED_JUMP_EVERY symbols of every document on
+    # its way and the decoder runs the chunks side by side (round 6) -- a launch lasts as long as its longest CHAIN.  For the record,
+    # the same batch without (jump_every=0: the default before round 6; same words):
+    plain = B.ans_encode_ragged(flat, off_d, model, cfg, jump_every=0)
+    plain_dec = torch.empty_like(flat)
+    pe = event_ms(lambda: B.ans_encode_ragged(flat, off_d, model, cfg, jump_every=0), reps)
+    pd = event_ms(lambda: B.ans_decode_ragged(plain, model, off_d, out=plain_dec), reps)
+    plain_ok = bool(torch.equal(plain_dec, flat)) and bool(torch.equal(plain.n_words, enc.n_words)) and bool(torch.equal(plain.words, enc.words))
     entry = {"workload": f"many small coders (tests/issue52.rs pattern): {n_docs} documents of 20..2000 symbols in one launch, {n_sym}-symbol categorical model",
              "coder": "ans", "config": list(cfg), "streams": n_docs, "symbols_total": n_total,
+             "jump_every": enc.jump.interval if enc.jump is not None else 0, "decode_kernel": dec_kernel,
+             "jump_table_bytes_per_symbol": round(12 * int(enc.jump.chunk_offsets[-1].item()) / n_total, 4) if enc.jump is not None else 0,
+             "without_jump_points": {"encode_ms": round(pe, 4), "decode_ms": round(pd, 4), "decode_speedup_of_the_default": round(pd / dec_ms, 3),
+                                     "same_words_and_symbols": plain_ok},
              "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "Msymbols_per_s": round(n_total / (enc_ms + dec_ms) / 1e3, 1),
              "ns_per_document": [round(enc_ms * 1e6 / n_docs, 2), round(dec_ms * 1e6 / n_docs, 2)],
              "words_per_stream": round(total_words / n_docs, 2),
              "encode_frac": round(byts / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
              "decode_frac": round(byts / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if check:
-        ok = bool(torch.equal(decoded, flat)) and int(enc.status.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
+        ok = plain_ok and bool(torch.equal(decoded, flat)) and int(enc.status.abs().sum().item()) == 0 and int(status.abs().sum().item()) == 0
         if ok:
             h_flat, n_words = flat.cpu().numpy(), enc.n_words.cpu().numpy()
             h_words, h_woff = enc.words.cpu().numpy().view(np.uint32), enc.word_offsets.cpu().numpy()

@@ -443,6 +443,57 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// ABI 5: jump points for ragged batches.  A launch of many small coders lasts as long as its LONGEST document's chain (100 000
+    /// documents of 20 .. 2000 symbols decode in 0.61 ms however few they are: 2000 dependent steps).  The reference's own remedy is the jump
+    /// table of Pos / Seek (src/stream/stack.rs:1107-1139): the encoder notes AnsCoder::pos() -- (words in the bulk, coder state) -- in front
+    /// of every chunk of `jump_interval` symbols of every stream (a multiple of 8) on its way, the words are those of cst_ans_encode_ragged,
+    /// and the decoder runs every chunk as a coder of its own (AnsCoder::seek + at most jump_interval symbols): the longest chain is
+    /// jump_interval steps.  Chunk j of stream s is entry d_chunk_offsets[s] + j of d_jump_pos / d_jump_state, with
+    /// d_chunk_offsets[n_streams + 1] the exclusive prefix sum of ceil(length / jump_interval) (n_chunks_total = its last entry).  The
+    /// decoder writes one status per STREAM (the worst of its chunks'; a table that does not describe its stream, or a jump point with more
+    /// words than the stream has, reports CST_STREAM_INVALID_DATA).  d_scratch: cst_ragged_jump_scratch_bytes(n_chunks_total) bytes.
+    pub fn cst_ragged_jump_scratch_bytes(n_chunks_total: usize) -> usize;
+
+    pub fn cst_ans_encode_ragged_jump(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        d_order: *const u32,
+        d_words: *mut u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        jump_interval: usize,
+        d_chunk_offsets: *const u64,
+        d_jump_pos: *mut u32,
+        d_jump_state: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_ans_decode_ragged_jump(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_words: *const u32,
+        d_word_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        d_symbols: *mut i32,
+        d_sym_offsets: *const u64,
+        n_streams: usize,
+        jump_interval: usize,
+        d_chunk_offsets: *const u64,
+        n_chunks_total: usize,
+        d_jump_pos: *const u32,
+        d_jump_state: *const u64,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     /// The same three calls with a SCHEDULE: lane slot i of the launch codes stream d_order[i] (uint32 [n_streams], a permutation of
     /// 0 .. n_streams - 1; NULL = the identity, i.e. the calls above).  A wave of 64 slots runs as long as its longest stream, so a
     /// batch whose lengths differ by orders of magnitude should put streams of similar length side by side, longest first:

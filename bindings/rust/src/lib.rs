@@ -1087,6 +1087,111 @@ impl BatchedAnsCoder {
         Ok(status)
     }
 
+    /// `encode_ragged` that also notes `AnsCoder::pos()` in front of every `jump_interval` symbols of every stream (ABI 5,
+    /// `cst_ans_encode_ragged_jump`; `Pos`, src/stream/stack.rs:1107-1116): chunk `j` of stream `s` is entry `chunk_offsets[s] + j` of
+    /// the returned `(pos, state)` arrays, `chunk_offsets[n_streams + 1]` the exclusive prefix sum of `ceil(length / jump_interval)`
+    /// (device memory, `n_chunks_total` its last entry).  The words are those of `encode_ragged`.
+    ///
+    /// # Safety
+    /// As for `encode_ragged`; `chunk_offsets` must be that prefix sum.
+    pub unsafe fn encode_ragged_with_jump_points(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        sym_offsets: &DeviceBuffer<u64>,
+        word_offsets: &DeviceBuffer<u64>,
+        words: &mut DeviceBuffer<u32>,
+        jump_interval: usize,
+        chunk_offsets: &DeviceBuffer<u64>,
+        n_chunks_total: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(DeviceBuffer<u32>, DeviceBuffer<i32>, DeviceBuffer<u32>, DeviceBuffer<u64>)> {
+        if sym_offsets.is_empty() || word_offsets.len() != sym_offsets.len() || chunk_offsets.len() != sym_offsets.len() || jump_interval == 0 || jump_interval % 8 != 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_streams = sym_offsets.len() - 1;
+        let mut n_words: DeviceBuffer<u32> = DeviceBuffer::new(n_streams)?;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams)?;
+        let mut pos: DeviceBuffer<u32> = DeviceBuffer::new(n_chunks_total.max(1))?;
+        let mut state: DeviceBuffer<u64> = DeviceBuffer::new(n_chunks_total.max(1))?;
+        check(unsafe {
+            ffi::cst_ans_encode_ragged_jump(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr(),
+                sym_offsets.as_ptr(),
+                n_streams,
+                core::ptr::null(),
+                words.as_mut_ptr(),
+                word_offsets.as_ptr(),
+                0,
+                n_words.as_mut_ptr(),
+                jump_interval,
+                chunk_offsets.as_ptr(),
+                pos.as_mut_ptr(),
+                state.as_mut_ptr(),
+                status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        Ok((n_words, status, pos, state))
+    }
+
+    /// The decoder of `encode_ragged_with_jump_points`: every chunk of every stream as a coder of its own (`AnsCoder::seek` + at most
+    /// `jump_interval` symbols), so that a launch lasts as long as a chunk, not as its longest document.  One status per stream.
+    ///
+    /// # Safety
+    /// As for `decode_ragged`.  The jump table is checked against the lengths on the device.
+    pub unsafe fn decode_ragged_from_jump_points(
+        &self,
+        words: &DeviceBuffer<u32>,
+        word_offsets: &DeviceBuffer<u64>,
+        n_words: &DeviceBuffer<u32>,
+        sym_offsets: &DeviceBuffer<u64>,
+        symbols: &mut DeviceBuffer<i32>,
+        jump_interval: usize,
+        chunk_offsets: &DeviceBuffer<u64>,
+        pos: &DeviceBuffer<u32>,
+        state: &DeviceBuffer<u64>,
+        n_chunks_total: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<DeviceBuffer<i32>> {
+        if sym_offsets.is_empty() || word_offsets.len() < sym_offsets.len() - 1 || n_words.len() < sym_offsets.len() - 1 {
+            return Err(Error::InvalidArgument);
+        }
+        if chunk_offsets.len() != sym_offsets.len() || pos.len() < n_chunks_total || state.len() < n_chunks_total || jump_interval == 0 || jump_interval % 8 != 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_streams = sym_offsets.len() - 1;
+        let mut status: DeviceBuffer<i32> = DeviceBuffer::new(n_streams)?;
+        let mut scratch: DeviceBuffer<u8> = DeviceBuffer::new(unsafe { ffi::cst_ragged_jump_scratch_bytes(n_chunks_total) })?;
+        check(unsafe {
+            ffi::cst_ans_decode_ragged_jump(
+                model.as_raw(),
+                self.config,
+                words.as_ptr(),
+                word_offsets.as_ptr(),
+                0,
+                words.len(),
+                n_words.as_ptr(),
+                symbols.as_mut_ptr(),
+                sym_offsets.as_ptr(),
+                n_streams,
+                jump_interval,
+                chunk_offsets.as_ptr(),
+                n_chunks_total,
+                pos.as_ptr(),
+                state.as_ptr(),
+                scratch.as_mut_ptr() as *mut c_void,
+                status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(status)
+    }
+
     /// Encoding with jump tables: what `AnsCoder::pos()` returns in front of every chunk of `interval` symbols
     /// (`Pos`, src/stream/stack.rs:1107-1116); the words are those of `encode_iid_symbols_reverse`.
     pub fn encode_iid_symbols_reverse_with_checkpoints(

@@ -111,6 +111,9 @@ SIGNATURES = {
     "cst_ans_encode_ragged_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _vp, _z, _vp, _vp, _vp]),
     "cst_ans_decode_ragged_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _vp, _vp, _vp]),
     "cst_ans_count_until_ordered": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _z, _vp, _i32, _z, _vp, _vp, _vp]),
+    "cst_ragged_jump_scratch_bytes": (_z, [_z]),
+    "cst_ans_encode_ragged_jump": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _vp, _vp, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
+    "cst_ans_decode_ragged_jump": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_compact_scratch_bytes": (_z, [_z]),
     "cst_compact_words": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
     "cst_words_reverse": (_i32, [_vp, _vp, _z, _vp, _z, _vp, _vp, _z, _vp]),

@@ -547,11 +547,25 @@ class RaggedBatch:
     status: torch.Tensor         # int32 [n_streams]
     config: tuple
     order: Optional[torch.Tensor] = None   # int32 [n_streams]: the schedule the encoder ran with (the decoders reuse it)
+    jump: Optional["RaggedJump"] = None    # jump points the encoder noted (ans_encode_ragged, jump_every): ans_decode_ragged decodes the chunks side by side
 
     def stream(self, s: int) -> np.ndarray:
         """get_compressed() of stream s (uint32, host)."""
         lo, n = int(self.word_offsets[s].item()), int(self.n_words[s].item())
         return self.words[lo: lo + n].cpu().numpy().view(np.uint32)
+
+
+@dataclass
+class RaggedJump:
+    """AnsCoder.pos() in front of every `interval` symbols of every stream of a RaggedBatch (stack.rs:1107-1139): chunk j of stream s is
+    entry chunk_offsets[s] + j of pos (words in the bulk) / state (the coder state there)."""
+    interval: int
+    chunk_offsets: torch.Tensor   # int64 [n_streams + 1]: exclusive prefix sum of ceil(length / interval)
+    pos: torch.Tensor             # int32 [>= total chunks]
+    state: torch.Tensor           # int64 [>= total chunks]
+
+
+RAGGED_JUMP_EVERY = 256            # jump_every="auto": symbols between the jump points of a ragged batch
 
 
 def ragged(sequences, device="cuda"):
@@ -587,11 +601,16 @@ def _ragged_order(order, n_streams, keys):
     return order
 
 
-def ans_encode_ragged(symbols: torch.Tensor, sym_offsets: torch.Tensor, model: Model, config=(32, 64, 24), order="auto") -> RaggedBatch:
+def ans_encode_ragged(symbols: torch.Tensor, sym_offsets: torch.Tensor, model: Model, config=(32, 64, 24), order="auto",
+                      jump_every="auto") -> RaggedBatch:
     """One AnsCoder per stream, streams of different lengths (`symbols` flat, stream s = symbols[sym_offsets[s]:sym_offsets[s+1]]):
     encode_iid_symbols_reverse + into_compressed per stream (stack.rs:835-849, 891-895) in ONE launch.  `order`: see
     _ragged_order (big batches of very different lengths run 1.5 - 3x faster with their streams sorted by length; the
-    results do not depend on it)."""
+    results do not depend on it).
+    jump_every: the encoder also notes AnsCoder.pos() in front of every jump_every symbols of every stream (a multiple of 8; the words
+    are unchanged) and the batch carries the table as `.jump`: ans_decode_ragged then decodes all chunks side by side -- a launch
+    lasts as long as its longest CHAIN, and a 2000-symbol document among short ones is 2000 dependent steps without jump points.
+    "auto" (default): every RAGGED_JUMP_EVERY symbols if the streams average more than a quarter of that; 0: none."""
     symbols = _to_indices(model, _require_cuda(symbols, torch.int32, "symbols"))
     sym_offsets = _require_cuda(sym_offsets, torch.int64, "sym_offsets")
     n_streams = sym_offsets.numel() - 1
@@ -611,6 +630,26 @@ def ans_encode_ragged(symbols: torch.Tensor, sym_offsets: torch.Tensor, model: M
     out = RaggedBatch(torch.empty(max(total, 4), dtype=torch.int32, device=dev), word_offsets,
                       torch.empty(n_streams, dtype=torch.int32, device=dev), torch.empty(n_streams, dtype=torch.int32, device=dev), tuple(config),
                       order)
+    if isinstance(jump_every, str):
+        if jump_every != "auto":
+            raise ValueError("jump_every: 'auto', 0 or a multiple of 8")
+        jump_every = RAGGED_JUMP_EVERY if n_streams > 0 and symbols.numel() * 4 > n_streams * RAGGED_JUMP_EVERY else 0
+    jump_every = int(jump_every or 0)
+    if jump_every < 0 or jump_every % 8 != 0:
+        raise ValueError("jump_every: 'auto', 0 or a multiple of 8")
+    if jump_every and n_streams > 0:
+        chunk_offsets = torch.zeros(n_streams + 1, dtype=torch.int64, device=dev)
+        torch.cumsum((lengths + (jump_every - 1)) // jump_every, 0, out=chunk_offsets[1:])
+        # (no read-back of the total: sum(ceil(len / I)) <= total / I + n_streams bounds it, entries behind the last chunk stay unused)
+        n_chunks = symbols.numel() // jump_every + n_streams
+        jump = RaggedJump(jump_every, chunk_offsets, torch.empty(max(n_chunks, 1), dtype=torch.int32, device=dev),
+                          torch.empty(max(n_chunks, 1), dtype=torch.int64, device=dev))
+        N.check(N.lib().cst_ans_encode_ragged_jump(model._h, _cfg(*config), _ptr(symbols), _ptr(sym_offsets), n_streams,
+                                                   _ptr(order) if order is not None else None, _ptr(out.words), _ptr(word_offsets), 0,
+                                                   _ptr(out.n_words), jump_every, _ptr(chunk_offsets), _ptr(jump.pos), _ptr(jump.state),
+                                                   _ptr(out.status), _stream_ptr()), "cst_ans_encode_ragged_jump")
+        out.jump = jump
+        return out
     N.check(N.lib().cst_ans_encode_ragged_ordered(model._h, _cfg(*config), _ptr(symbols), _ptr(sym_offsets), n_streams,
                                                   _ptr(order) if order is not None else None, _ptr(out.words), _ptr(word_offsets), 0,
                                                   _ptr(out.n_words), _ptr(out.status), _stream_ptr()), "cst_ans_encode_ragged_ordered")
@@ -624,6 +663,9 @@ def ans_decode_ragged(encoded: RaggedBatch, model: Model, sym_offsets: torch.Ten
     streams on."""
     sym_offsets = _require_cuda(sym_offsets, torch.int64, "sym_offsets")
     n_streams = sym_offsets.numel() - 1
+    # a batch with jump points decodes its chunks side by side (they are all at most `interval` symbols long: no schedule needed) --
+    # unless the caller hands in a schedule of their own, which is then honoured on the whole streams
+    take_jump = encoded.jump is not None and (order is None or (isinstance(order, str) and order == "auto"))
     if isinstance(order, str) and order == "auto" and encoded.order is not None and encoded.order.numel() == n_streams:
         order = encoded.order
     order = _ragged_order(order, n_streams, encoded.n_words)
@@ -632,6 +674,18 @@ def ans_decode_ragged(encoded: RaggedBatch, model: Model, sym_offsets: torch.Ten
     if out is None:
         out = torch.empty(total, dtype=torch.int32, device=dev)
     status = torch.empty(max(n_streams, 0), dtype=torch.int32, device=dev)
+    jump = encoded.jump
+    if take_jump and n_streams > 0 and jump.chunk_offsets.numel() == n_streams + 1:
+        # the batch carries jump points: every chunk of every stream on a lane of its own (the table is checked against the lengths on
+        # the device: a stream it does not describe reports INVALID_DATA)
+        L = N.lib()
+        n_chunks = int(jump.pos.numel())              # (an upper bound of the chunks is enough: entries behind the last chunk are empty streams)
+        scratch = _ckpt_scratch("ragged_jump", dev, L.cst_ragged_jump_scratch_bytes(n_chunks))
+        N.check(L.cst_ans_decode_ragged_jump(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(encoded.word_offsets), 0, encoded.words.numel(),
+                                             _ptr(encoded.n_words), _ptr(out), _ptr(sym_offsets), n_streams, jump.interval, _ptr(jump.chunk_offsets),
+                                             n_chunks, _ptr(jump.pos), _ptr(jump.state), _ptr(scratch), _ptr(status), _stream_ptr()),
+                "cst_ans_decode_ragged_jump")
+        return _to_symbols(model, out), status
     N.check(N.lib().cst_ans_decode_ragged_ordered(model._h, _cfg(*encoded.config), _ptr(encoded.words), _ptr(encoded.word_offsets), 0,
                                                   encoded.words.numel(), _ptr(encoded.n_words), _ptr(out), _ptr(sym_offsets), n_streams,
                                                   _ptr(order) if order is not None else None, _ptr(status), _stream_ptr()),

@@ -44,6 +44,15 @@ struct RaggedArgs {
     int32_t* status;
     uint64_t words_capacity;
     const uint32_t* order;           // null, or [n_streams]: lane slot i codes stream order[i] (streams of similar length side by side)
+    // Jump points (round 6; the reference's Pos / Seek, stack.rs:1107-1139): AnsCoder::pos() in front of every chunk of `jump_interval`
+    // symbols of every stream -- chunk j of stream s is entry jump_chunk_offsets[s] + j of jump_pos / jump_state -- noted by the encoder
+    // on its way (the words are unchanged).  The decoder of such a batch runs every chunk as a stream of its own, its coder state
+    // taken from `state_in` instead of the end of its words.
+    uint32_t jump_interval;                 // 0 = none; a multiple of kRaggedGroup
+    const uint64_t* jump_chunk_offsets;     // [n_streams + 1]
+    uint32_t* jump_pos;
+    uint64_t* jump_state;
+    const uint64_t* state_in;               // decoder: [n_streams] raw coder states, or null (read_initial_state)
 };
 
 // lane slot -> stream: the slot itself, or order[slot] (an entry that is not a stream leaves its lane idle)
@@ -108,6 +117,26 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
     auto entry = [&](int32_t v) { return table[enc_index(v, a.min_symbol, nsym, L.bad)]; };
     // encode_iid_symbols_reverse: last symbol first (stack.rs:835-849).  The (len mod 8) symbols at the END of the row one by
     // one (all their loads in flight at once), so that what remains is whole groups
+    // AnsCoder::pos() once the symbols [start, len) are encoded, whenever a chunk starts at `start`.  No division in the loop: the
+    // lane counts groups down to its next chunk boundary (`to_jump`) and walks the table backwards (`next_chunk`).
+    const bool jumps = a.jump_interval != 0 && active && len > 0;
+    const uint32_t groups_per_chunk = a.jump_interval ? a.jump_interval / (uint32_t)kRaggedGroup : 1u;
+    const uint32_t ng0 = len / kRaggedGroup;
+    uint32_t to_jump = ng0 % groups_per_chunk;                   // whole groups above the highest chunk boundary at or below 8 ng0
+    uint64_t next_chunk = jumps ? a.jump_chunk_offsets[s] + ng0 / groups_per_chunk : 0;       // the chunk that starts at that boundary
+    // A jump point is NOTED where it occurs and STORED at the next group's memory point, next to the word chunks (the kernel's rule:
+    // one memory point per group -- the 64 lanes of a wave reach their chunk boundaries in different groups, so a store right behind
+    // the steps would sit in front of nearly every group's wait for its symbols).
+    bool jp_pending = false;
+    uint32_t jp_pos = 0;
+    uint64_t jp_state = 0, jp_chunk = 0;
+    auto note_here = [&]() {
+        jp_pos = L.out.wr; jp_state = (uint64_t)L.state; jp_chunk = next_chunk; jp_pending = true;
+        --next_chunk;
+    };
+    auto store_jump_point = [&]() {
+        if (jp_pending) { a.jump_pos[jp_chunk] = jp_pos; a.jump_state[jp_chunk] = jp_state; jp_pending = false; }
+    };
     const uint32_t pre = len & (uint32_t)(kRaggedGroup - 1);
     if (__any(pre != 0)) {
         int32_t v[kRaggedGroup - 1];
@@ -116,7 +145,9 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
 #pragma unroll
         for (int j = 0; j < kRaggedGroup - 1; ++j)
             if ((uint32_t)j < pre) L.template step<FAST>(entry(v[j]), P);
+        if (jumps && pre != 0 && to_jump == 0) note_here();     // the ragged top part IS a chunk (8 ng0 is a multiple of the interval)
     }
+    if (jumps && to_jump == 0) { to_jump = groups_per_chunk; if (pre == 0) --next_chunk; }      // (no chunk starts at len itself)
     const uint32_t ng = len / kRaggedGroup;                     // whole groups, coded from the last one down
     const uint32_t mxg = wave_max_u32(ng);
     const rv4i_unaligned* g4 = reinterpret_cast<const rv4i_unaligned*>(row);        // group g = pieces 2g, 2g + 1
@@ -127,13 +158,16 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
         const rv4i c0 = n0, c1 = n1;
         if (g + 1 < ng) { n0 = g4[2 * (ng - g) - 4].v; n1 = g4[2 * (ng - g) - 3].v; }
         L.flush_chunks();                   // complete 16-byte chunks of the words of earlier groups: ring -> slab (at most 3)
+        store_jump_point();                 // (a jump point noted by the previous group)
         if (g < ng) {
             const EncEntry e7 = entry(c1.w), e6 = entry(c1.z), e5 = entry(c1.y), e4 = entry(c1.x);
             const EncEntry e3 = entry(c0.w), e2 = entry(c0.z), e1 = entry(c0.y), e0 = entry(c0.x);
             L.template step<FAST>(e7, P); L.template step<FAST>(e6, P); L.template step<FAST>(e5, P); L.template step<FAST>(e4, P);
             L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
+            if (jumps && --to_jump == 0) { note_here(); to_jump = groups_per_chunk; }
         }
     }
+    store_jump_point();
     uint32_t n_words = 0;
     int32_t status = L.finish(true, nsym, n_words);
     if (too_long) status = CST_STREAM_CAPACITY;
@@ -205,7 +239,8 @@ struct RaggedDecoder {
     __device__ __forceinline__ void start(const RaggedArgs& a, uint32_t* ring) {
         ws = active ? word_slice(a.word_offsets, a.stride_words, a.n_words_in, s, a.words_capacity) : WordSlice{0, 0u, false};
         L.init(a.words_in + ws.off, ws.n, ring, lane);
-        L.read_initial_state();
+        if (a.state_in) L.state = (active && !ws.bad) ? a.state_in[s] : 0;      // AnsCoder::seek(pos, state): the words in front of the jump point
+        else L.read_initial_state();
         L.in.prime();
         wave_lds_fence();
     }
@@ -379,6 +414,91 @@ cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const u
     const uint32_t eof_index = (uint32_t)eof_symbol - (uint32_t)model->min_symbol;
     const uint64_t mx = (uint64_t)max_symbols;
     CST_RAGGED_DISPATCH(ans_count_until_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model), eof_index, mx, d_lengths);
+}
+
+// ---- jump points (round 6) ----
+// the chunks of a batch as streams of their own: chunk c = jump_chunk_offsets[s] + j of stream s decodes symbols
+// [sym_offsets[s] + j I, min(.. + I, sym_offsets[s + 1])) from stream s's words in front of its jump point
+__global__ void ragged_jump_virtual_kernel(const uint64_t* __restrict__ sym_offsets, const uint64_t* __restrict__ word_offsets, size_t stride_words,
+                                           const uint64_t* __restrict__ chunk_offsets, size_t n_streams, size_t n_chunks_total, uint32_t interval,
+                                           uint64_t* __restrict__ v_sym_offsets, uint64_t* __restrict__ v_word_offsets) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // entries behind the last chunk (n_chunks_total may be an upper bound of the chunks): empty streams at the end of the symbols
+    if (s <= n_chunks_total && s >= chunk_offsets[n_streams]) { v_sym_offsets[s] = sym_offsets[n_streams]; if (s < n_chunks_total) v_word_offsets[s] = 0; }
+    if (s >= n_streams) return;
+    const uint64_t lo = sym_offsets[s], hi = sym_offsets[s + 1];
+    const uint64_t c0 = chunk_offsets[s], c1 = chunk_offsets[s + 1];
+    const uint64_t w = word_offsets ? word_offsets[s] : (uint64_t)s * stride_words;
+    for (uint64_t c = c0; c < c1 && c < n_chunks_total; ++c) {
+        const uint64_t start = lo + (c - c0) * interval;
+        v_sym_offsets[c] = start < hi ? start : hi;              // (a table with too many chunks for its stream: empty ones)
+        v_word_offsets[c] = w;
+    }
+}
+
+// a stream's status: the worst of its chunks'; a table that does not describe the stream (chunks != ceil(len / I)), or a jump point
+// with more words than the stream has, is caller data gone wrong: CST_STREAM_INVALID_DATA
+__global__ void ragged_jump_status_kernel(const int32_t* __restrict__ chunk_status, const uint64_t* __restrict__ sym_offsets,
+                                          const uint64_t* __restrict__ chunk_offsets, const uint32_t* __restrict__ jump_pos,
+                                          const uint32_t* __restrict__ n_words, size_t n_streams, size_t n_chunks_total, uint32_t interval,
+                                          int32_t* __restrict__ status) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const uint64_t len = sym_offsets[s + 1] - sym_offsets[s];
+    const uint64_t c0 = chunk_offsets[s], c1 = chunk_offsets[s + 1];
+    int32_t worst = CST_STREAM_OK;
+    if (c1 < c0 || c1 > n_chunks_total || c1 - c0 != (len + interval - 1) / interval) worst = CST_STREAM_INVALID_DATA;
+    else
+        for (uint64_t c = c0; c < c1; ++c) {
+            worst = max(worst, chunk_status[c]);
+            if (jump_pos[c] > n_words[s]) worst = CST_STREAM_INVALID_DATA;
+        }
+    status[s] = worst;
+}
+
+cst_status ans_encode_ragged_jump(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                                  size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words, uint32_t* d_n_words,
+                                  int32_t* d_status, const uint32_t* d_order, uint32_t interval, const uint64_t* d_chunk_offsets,
+                                  uint32_t* d_jump_pos, uint64_t* d_jump_state, hipStream_t hs) {
+    RaggedArgs a{};
+    a.order = d_order;
+    a.symbols_in = d_symbols; a.sym_offsets = d_sym_offsets; a.n_streams = n_streams; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words_out = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_out = d_n_words; a.status = d_status;
+    a.jump_interval = interval; a.jump_chunk_offsets = d_chunk_offsets; a.jump_pos = d_jump_pos; a.jump_state = d_jump_state;
+    CST_RAGGED_DISPATCH(ans_encode_ragged_kernel, kRaggedRingBytes, ragged_encode_table_bytes(model));
+}
+
+static cst_status decode_ragged_virtual(const cst_model* model, cst_coder_config cfg, const RaggedArgs& a, hipStream_t hs) {
+    CST_RAGGED_DISPATCH(ans_decode_ragged_kernel, kRaggedDecRingBytes, ragged_decode_table_bytes(model));
+}
+
+cst_status ans_decode_ragged_jump(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                                  size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                                  const uint64_t* d_sym_offsets, size_t n_streams, uint32_t interval, const uint64_t* d_chunk_offsets,
+                                  size_t n_chunks_total, const uint32_t* d_jump_pos, const uint64_t* d_jump_state, void* d_scratch,
+                                  int32_t* d_status, hipStream_t hs) {
+    unsigned char* b = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
+    uint64_t* v_sym = reinterpret_cast<uint64_t*>(b);
+    uint64_t* v_word = v_sym + n_chunks_total + 2;
+    int32_t* v_status = reinterpret_cast<int32_t*>(v_word + n_chunks_total + 1);
+    const unsigned grid = (unsigned)((n_streams + 255) / 256);
+    const size_t v_threads = n_streams > n_chunks_total + 1 ? n_streams : n_chunks_total + 1;
+    hipLaunchKernelGGL(ragged_jump_virtual_kernel, dim3((unsigned)((v_threads + 255) / 256)), dim3(256), 0, hs, d_sym_offsets, d_word_offsets, stride_words, d_chunk_offsets, n_streams,
+                       n_chunks_total, interval, v_sym, v_word);
+    CST_HIP_TRY(hipGetLastError());
+    if (n_chunks_total > 0) {
+        // every chunk's slice [word offset of its stream, + pos) is checked against the buffer like any stream's (slab form: against all slabs)
+        RaggedArgs a = ragged_decode_args(model, d_words, v_word, 0, words_capacity ? words_capacity : (d_word_offsets ? 0 : n_streams * stride_words),
+                                          d_jump_pos, n_chunks_total, v_status, nullptr);
+        a.symbols_out = d_symbols; a.sym_offsets = v_sym; a.state_in = d_jump_state;
+        const cst_status rc = decode_ragged_virtual(model, cfg, a, hs);
+        if (rc != CST_OK) return rc;
+    }
+    hipLaunchKernelGGL(ragged_jump_status_kernel, dim3(grid), dim3(256), 0, hs, v_status, d_sym_offsets, d_chunk_offsets, d_jump_pos, d_n_words, n_streams,
+                       n_chunks_total, interval, d_status);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 #undef CST_RAGGED_DISPATCH
 

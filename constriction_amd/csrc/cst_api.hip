@@ -366,8 +366,8 @@ cst_status cst_ans_encode_ragged_ordered(const cst_model* model, cst_coder_confi
     if (n_streams == 0) return CST_OK;
     if (!d_sym_offsets || !d_words || !d_n_words || !d_status || !ragged_order_ok(d_order, n_streams)) return CST_ERR_INVALID_ARGUMENT;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
-    return ans_encode_ragged(model, cfg, d_symbols, d_sym_offsets, n_streams, d_words, d_word_offsets, stride_words, d_n_words, d_status,
-                             d_order, (hipStream_t)stream);
+    return note_kernel("ans_encode_ragged_kernel", ans_encode_ragged(model, cfg, d_symbols, d_sym_offsets, n_streams, d_words, d_word_offsets, stride_words,
+                                                                     d_n_words, d_status, d_order, (hipStream_t)stream));
 }
 
 cst_status cst_ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
@@ -386,8 +386,8 @@ cst_status cst_ans_decode_ragged_ordered(const cst_model* model, cst_coder_confi
     if (n_streams == 0) return CST_OK;
     if (!d_sym_offsets || !d_n_words || !d_status || !ragged_order_ok(d_order, n_streams)) return CST_ERR_INVALID_ARGUMENT;
     if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
-    return ans_decode_ragged(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols, d_sym_offsets,
-                             n_streams, d_status, d_order, (hipStream_t)stream);
+    return note_kernel("ans_decode_ragged_kernel", ans_decode_ragged(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols,
+                                                                     d_sym_offsets, n_streams, d_status, d_order, (hipStream_t)stream));
 }
 
 cst_status cst_ans_decode_ragged(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
@@ -395,6 +395,40 @@ cst_status cst_ans_decode_ragged(const cst_model* model, cst_coder_config cfg, c
                                  const uint64_t* d_sym_offsets, size_t n_streams, int32_t* d_status, void* stream) {
     return cst_ans_decode_ragged_ordered(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words, d_symbols,
                                          d_sym_offsets, n_streams, nullptr, d_status, stream);
+}
+
+// ---- ABI 5: jump points for ragged batches ----
+size_t cst_ragged_jump_scratch_bytes(size_t n_chunks_total) { return 20 * n_chunks_total + 128; }
+
+cst_status cst_ans_encode_ragged_jump(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                                      size_t n_streams, const uint32_t* d_order, uint32_t* d_words, const uint64_t* d_word_offsets,
+                                      size_t stride_words, uint32_t* d_n_words, size_t jump_interval, const uint64_t* d_chunk_offsets,
+                                      uint32_t* d_jump_pos, uint64_t* d_jump_state, int32_t* d_status, void* stream) {
+    if (!model || !config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (jump_interval == 0 || jump_interval % 8 != 0 || jump_interval > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (!d_sym_offsets || !d_words || !d_n_words || !d_status || !d_chunk_offsets || !d_jump_pos || !d_jump_state || !ragged_order_ok(d_order, n_streams))
+        return CST_ERR_INVALID_ARGUMENT;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    return note_kernel("ans_encode_ragged_kernel<jump>", ans_encode_ragged_jump(model, cfg, d_symbols, d_sym_offsets, n_streams, d_words, d_word_offsets,
+                                                                                 stride_words, d_n_words, d_status, d_order, (uint32_t)jump_interval,
+                                                                                 d_chunk_offsets, d_jump_pos, d_jump_state, (hipStream_t)stream));
+}
+
+cst_status cst_ans_decode_ragged_jump(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                                      size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                                      const uint64_t* d_sym_offsets, size_t n_streams, size_t jump_interval, const uint64_t* d_chunk_offsets,
+                                      size_t n_chunks_total, const uint32_t* d_jump_pos, const uint64_t* d_jump_state, void* d_scratch,
+                                      int32_t* d_status, void* stream) {
+    if (!model || !config_supported(cfg) || cfg.precision != model->precision || model->per_stream) return CST_ERR_INVALID_ARGUMENT;
+    if (jump_interval == 0 || jump_interval % 8 != 0 || jump_interval > 0x7fffffffull || n_chunks_total > 0xffffffffull) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    if (!d_sym_offsets || !d_n_words || !d_status || !d_chunk_offsets || !d_jump_pos || !d_jump_state || !d_scratch) return CST_ERR_INVALID_ARGUMENT;
+    if (!on_model_device(model)) return CST_ERR_INVALID_ARGUMENT;
+    return note_kernel("ans_decode_ragged_kernel<jump>", ans_decode_ragged_jump(model, cfg, d_words, d_word_offsets, stride_words, words_capacity, d_n_words,
+                                                                                 d_symbols, d_sym_offsets, n_streams, (uint32_t)jump_interval, d_chunk_offsets,
+                                                                                 n_chunks_total, d_jump_pos, d_jump_state, d_scratch, d_status,
+                                                                                 (hipStream_t)stream));
 }
 
 cst_status cst_ans_count_until_ordered(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,

@@ -204,6 +204,17 @@ cst_status ans_count_until(const cst_model* model, cst_coder_config cfg, const u
                            size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, size_t n_streams, int32_t eof_symbol,
                            size_t max_symbols, uint64_t* d_lengths, int32_t* d_status, const uint32_t* d_order, hipStream_t hs);
 
+// ... with jump points in front of every `interval` symbols of every stream (round 6): chunk j of stream s = entry d_chunk_offsets[s] + j
+cst_status ans_encode_ragged_jump(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
+                                  size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words, uint32_t* d_n_words,
+                                  int32_t* d_status, const uint32_t* d_order, uint32_t interval, const uint64_t* d_chunk_offsets,
+                                  uint32_t* d_jump_pos, uint64_t* d_jump_state, hipStream_t hs);
+cst_status ans_decode_ragged_jump(const cst_model* model, cst_coder_config cfg, const uint32_t* d_words, const uint64_t* d_word_offsets,
+                                  size_t stride_words, size_t words_capacity, const uint32_t* d_n_words, int32_t* d_symbols,
+                                  const uint64_t* d_sym_offsets, size_t n_streams, uint32_t interval, const uint64_t* d_chunk_offsets,
+                                  size_t n_chunks_total, const uint32_t* d_jump_pos, const uint64_t* d_jump_state, void* d_scratch,
+                                  int32_t* d_status, hipStream_t hs);
+
 // trimmed-packed-row coder launches (cst_ans_pt.hip); return CST_ERR_INVALID_ARGUMENT if the shape is not theirs
 bool pt_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, size_t n_per_stream);
 cst_status ans_encode_pt(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams,

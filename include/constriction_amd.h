@@ -325,6 +325,28 @@ cst_status cst_ans_count_until(const cst_model *model, cst_coder_config cfg, con
                                const uint32_t *d_n_words, size_t n_streams, int32_t eof_symbol, size_t max_symbols,
                                uint64_t *d_lengths, int32_t *d_status, void *stream);
 
+/* ABI 5: jump points for ragged batches.  A launch of many small coders lasts as long as its LONGEST document's chain (100 000
+ * documents of 20 .. 2000 symbols decode in 0.61 ms however few they are: 2000 dependent steps).  The reference's own remedy is the jump
+ * table of Pos / Seek (src/stream/stack.rs:1107-1139): the encoder notes AnsCoder::pos() -- (words in the bulk, coder state) -- in front
+ * of every chunk of `jump_interval` symbols of every stream (a multiple of 8) on its way, the words are those of cst_ans_encode_ragged,
+ * and the decoder runs every chunk as a coder of its own (AnsCoder::seek + at most jump_interval symbols): the longest chain is
+ * jump_interval steps.  Chunk j of stream s is entry d_chunk_offsets[s] + j of d_jump_pos / d_jump_state, with
+ * d_chunk_offsets[n_streams + 1] the exclusive prefix sum of ceil(length / jump_interval) (n_chunks_total = its last entry).  The
+ * decoder writes one status per STREAM (the worst of its chunks'; a table that does not describe its stream, or a jump point with more
+ * words than the stream has, reports CST_STREAM_INVALID_DATA).  d_scratch: cst_ragged_jump_scratch_bytes(n_chunks_total) bytes. */
+size_t cst_ragged_jump_scratch_bytes(size_t n_chunks_total);
+cst_status cst_ans_encode_ragged_jump(const cst_model *model, cst_coder_config cfg, const int32_t *d_symbols,
+                                      const uint64_t *d_sym_offsets, size_t n_streams, const uint32_t *d_order, uint32_t *d_words,
+                                      const uint64_t *d_word_offsets, size_t stride_words, uint32_t *d_n_words,
+                                      size_t jump_interval, const uint64_t *d_chunk_offsets, uint32_t *d_jump_pos,
+                                      uint64_t *d_jump_state, int32_t *d_status, void *stream);
+cst_status cst_ans_decode_ragged_jump(const cst_model *model, cst_coder_config cfg, const uint32_t *d_words,
+                                      const uint64_t *d_word_offsets, size_t stride_words, size_t words_capacity,
+                                      const uint32_t *d_n_words, int32_t *d_symbols, const uint64_t *d_sym_offsets,
+                                      size_t n_streams, size_t jump_interval, const uint64_t *d_chunk_offsets,
+                                      size_t n_chunks_total, const uint32_t *d_jump_pos, const uint64_t *d_jump_state,
+                                      void *d_scratch, int32_t *d_status, void *stream);
+
 /* The same three calls with a SCHEDULE: lane slot i of the launch codes stream d_order[i] (uint32 [n_streams], a permutation of
  * 0 .. n_streams - 1; NULL = the identity, i.e. the calls above).  A wave of 64 slots runs as long as its longest stream, so a
  * batch whose lengths differ by orders of magnitude should put streams of similar length side by side, longest first:

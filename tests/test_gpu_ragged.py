@@ -222,3 +222,71 @@ def test_ragged_schedule_does_not_change_results(B, O):
     off = offsets.cpu().numpy()
     assert (dec[off[3]: off[4]] == -7).all() and (dec[off[10]: off[11]] == -7).all()
     assert torch.equal(dec[off[11]:], flat[off[11]:]) and torch.equal(dec[: off[3]], flat[: off[3]])
+
+
+# ---- jump points for ragged batches (round 6: cst_ans_{encode,decode}_ragged_jump) ----
+
+@pytest.mark.parametrize("cfg", [(32, 64, 24), (32, 64, 12), (16, 32, 12)], ids=lambda c: "W%dS%dP%d" % c)
+@pytest.mark.parametrize("every", [8, 64, 256, 1024])
+def test_ragged_jump_points(B, O, cfg, every):
+    """AnsCoder.pos() in front of every `every` symbols of every document, noted by the encoder on its way: the words are the plain
+    call's, the table is the CPU oracle's for each document alone, and the decoder that runs the chunks side by side returns the
+    documents (empty documents, documents shorter than a chunk, lengths that are not multiples of anything)."""
+    W, S, P = cfg
+    rng = np.random.default_rng(P + every)
+    n_sym, lo = 90, -17
+    cdf = O.categorical_fast_cdf(rng.dirichlet(np.ones(n_sym) * 0.4), P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    lengths = np.concatenate([rng.integers(0, 200, 400), rng.integers(200, 3000, 60), [0, 1, 7, 8, 9, every - 1, every, every + 1, 2 * every, 2047]])
+    rng.shuffle(lengths)
+    docs = [O.synth_symbols(int(k), 0, 1, int(n), lo, cdf, P)[0] if n else np.zeros(0, np.int32) for k, n in enumerate(lengths)]
+    flat, offsets = B.ragged(docs)
+    plain = B.ans_encode_ragged(flat, offsets, model, cfg, jump_every=0)
+    enc = B.ans_encode_ragged(flat, offsets, model, cfg, jump_every=every)
+    assert B.last_kernel() == "ans_encode_ragged_kernel<jump>"
+    assert plain.jump is None and enc.jump is not None and enc.jump.interval == every
+    assert torch.equal(enc.n_words, plain.n_words) and torch.equal(enc.status, plain.status) and int(enc.status.abs().sum()) == 0
+    for s in range(0, len(docs), 5):
+        assert enc.stream(s).tolist() == plain.stream(s).tolist(), f"stream {s}"
+    co = enc.jump.chunk_offsets.cpu().numpy()
+    assert co.tolist() == np.concatenate([[0], np.cumsum((lengths + every - 1) // every)]).tolist()
+    pos, state = enc.jump.pos.cpu().numpy().view(np.uint32), enc.jump.state.cpu().numpy().view(np.uint64)
+    for s in list(range(0, len(docs), 9)) + [int(np.argmax(lengths))]:
+        if len(docs[s]) == 0:
+            continue
+        wp, ws = O.ans_jump_table(docs[s][None, :], lo, cdf, P, every, W, S)
+        assert pos[co[s]: co[s + 1]].tolist() == wp[0].tolist() and state[co[s]: co[s + 1]].tolist() == ws[0].tolist(), f"stream {s} ({len(docs[s])} symbols)"
+    dec, status = B.ans_decode_ragged(enc, model, offsets)
+    assert B.last_kernel() == "ans_decode_ragged_kernel<jump>"
+    assert int(status.abs().sum()) == 0 and torch.equal(dec, flat)
+    dec2, status2 = B.ans_decode_ragged(plain, model, offsets)
+    assert torch.equal(dec2, flat) and torch.equal(status2, status)
+
+
+def test_ragged_jump_points_are_checked(B, O):
+    """a table that does not describe its streams, a jump point beyond its stream's words: INVALID_DATA for that stream, the others
+    decode; no access outside the buffers (guarded output)"""
+    P, lo = 12, 0
+    cdf = O.categorical_fast_cdf(np.ones(40) / 40, P)
+    model = B.Model.from_cdf(cdf, lo, P)
+    rng = np.random.default_rng(2)
+    lengths = rng.integers(300, 900, 200)
+    docs = [O.synth_symbols(int(k), 0, 1, int(n), lo, cdf, P)[0] for k, n in enumerate(lengths)]
+    flat, offsets = B.ragged(docs)
+    enc = B.ans_encode_ragged(flat, offsets, model, (32, 64, P), jump_every=64)
+    co = enc.jump.chunk_offsets.cpu().numpy()
+    enc.jump.pos[int(co[17]) + 2] = 1 << 30                       # a jump point beyond everything
+    guard = torch.full((flat.numel() + 4096,), 77, dtype=torch.int32, device="cuda")
+    dec, status = B.ans_decode_ragged(enc, model, offsets, out=guard[: flat.numel()])
+    st = status.cpu().numpy()
+    assert st[17] == 3 and st.sum() == 3
+    assert bool((guard[flat.numel():] == 77).all())
+    off = offsets.cpu().numpy()
+    ok = np.ones(flat.numel(), bool); ok[off[17]: off[18]] = False
+    assert torch.equal(dec[torch.from_numpy(ok).cuda()], flat[torch.from_numpy(ok).cuda()])
+    # a table made for other lengths: one chunk too few for stream 5
+    bad = enc.jump.chunk_offsets.clone(); bad[6:] -= 1
+    enc2 = B.ans_encode_ragged(flat, offsets, model, (32, 64, P), jump_every=64)
+    enc2.jump.chunk_offsets = bad
+    _, status = B.ans_decode_ragged(enc2, model, offsets)
+    assert int(status[5]) == 3
