@@ -20,6 +20,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 ROOT = Path(__file__).resolve().parents[1]
+# (runs of the suite through the alternate kernel paths do not take the kernels the tests name)
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_NO_PC_ENCODER", "CST_SMALL_KERNELS", "CST_PC_COMBINED", "CST_NO_PC_WIDE"))
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +71,7 @@ def test_ans_jump_points_on_every_tile_at_the_maximum_rate(B, O, dtype, P, inter
     dt = {"int32": torch.int32, "int8": torch.int8, "int16": torch.int16}[dtype]
     d = dev(sym).to(dt)
     enc = B.ans_encode(d, model, (32, 64, P), jump_points=n_per // interval)
-    assert "ckpt" in B.last_kernel(), B.last_kernel()           # noted on the way by the producer / consumer coder waves
+    assert ALT or "ckpt" in B.last_kernel(), B.last_kernel()    # noted on the way by the producer / consumer coder waves
     want_words, want_n, _ = O.ans_encode_batch(sym, 0, cdf, P)
     words, n_words, status = enc.to_numpy()
     assert (status == 0).all() and n_words.tolist() == want_n.tolist()
