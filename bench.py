@@ -525,6 +525,43 @@ def per_symbol_config(B, reps, check, n_streams=N_STREAMS, n_per=N_PER, lo=-100,
                 ok = all(pool.map(work, _blocks(n_streams, 8 * cores)))
             entry["bit_exact_scope"] = f"all {n_streams} streams: words and counts vs CPU oracle, decoded symbols vs input"
         entry["bit_exact"] = ok
+    # the same batch through the RANGE coder's per-symbol calls (round 6: they carry jump points by default too)
+    try:
+        renc = B.range_encode_gaussian(sym, lo, hi, mu, sd, cfg)
+        rdec = torch.empty_like(sym)
+        re_ms = event_ms(lambda: B.range_encode_gaussian(sym, lo, hi, mu, sd, cfg, out=renc), reps)
+        rek = B.last_kernel()
+        rd_ms = event_ms(lambda: B.range_decode_gaussian(renc, lo, hi, mu, sd, out=rdec), reps)
+        r = {"encode_ms": round(re_ms, 4), "decode_ms": round(rd_ms, 4), "encode_kernel": rek, "decode_kernel": B.last_kernel(),
+             "jump_points": int(renc.jump.pos.shape[1]) if renc.jump is not None else 0}
+        if check:
+            r["bit_exact"] = bool(torch.equal(rdec, sym)) and int(renc.status.abs().sum().item()) == 0
+        if renc.jump is not None:
+            rplain = B.range_encode_gaussian(sym, lo, hi, mu, sd, cfg, jump_points=0)
+            rpd = event_ms(lambda: B.range_decode_gaussian(rplain, lo, hi, mu, sd, out=rdec), reps)
+            used = torch.arange(min(512, int(renc.words.shape[1])), device=dev)[None, :] < renc.n_words[:, None]
+            w = used.shape[1]
+            r["without_jump_points"] = {"decode_ms": round(rpd, 4), "decode_speedup_of_the_default": round(rpd / rd_ms, 3)}
+            if check:
+                r["bit_exact"] = r["bit_exact"] and bool(torch.equal(rdec, sym)) and bool(torch.equal(rplain.n_words, renc.n_words)) and \
+                    bool(((rplain.words[:, :w] == renc.words[:, :w]) | ~used).all())
+            del rplain
+        if check and r["bit_exact"]:
+            h_sym, h_mu, h_sd = sym[:48].cpu().numpy(), mu[:48].cpu().numpy(), sd[:48].cpu().numpy()
+            for s_ in range(0, 48, 4):      # a dozen streams against the CPU oracle (the ANS entry above compares all of them)
+                c = O.RangeEncoder()
+                c.encode(h_sym[s_], [O.GaussianModel(lo, hi, float(m), float(v), 24, 32) for m, v in zip(h_mu[s_], h_sd[s_])], 24)
+                if renc.stream(s_).tolist() != c.get_compressed().tolist():
+                    r["bit_exact"] = False
+            r["bit_exact_scope"] = "decoded symbols vs input (all streams), words vs the plain call's, twelve streams' words vs the CPU oracle"
+        entry["range_coder"] = r
+        if check:
+            entry["bit_exact"] = bool(entry.get("bit_exact", True)) and r["bit_exact"]
+        del renc, rdec
+    except Exception as exc:      # noqa: BLE001
+        entry["range_coder"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        if check:
+            entry["bit_exact"] = False
     B.release_scratch()
     return entry
 

@@ -1195,6 +1195,58 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// ABI 5: jump points for the per-symbol Gaussian calls of the RANGE coder (RangeEncoder::pos / RangeDecoder::seek, src/stream/queue.rs:172-196,
+    /// 900-926), as cst_ans_{encode,decode}_gaussian_batch_ckpt are for ANS: the fused encoder notes (words emitted including held-back ones,
+    /// lower, range) in front of every chunk of ckpt_interval symbols (a multiple of 16 that divides n_per_stream; stream-major), the decoder
+    /// runs every (stream, chunk) pair as a decoder of its own -- chunk j of stream s codes row s * n_chunks + j of the three matrices viewed
+    /// as [n_streams * n_chunks][interval] -- and writes n_streams * n_chunks status entries.  The words are those of
+    /// cst_range_encode_gaussian_batch.  d_scratch: cst_range_gaussian_ckpt_scratch_bytes(...).
+    pub fn cst_range_encode_gaussian_batch_ckpt(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_symbols: *const i32,
+        d_means: *const f64,
+        d_stds: *const f64,
+        n_streams: usize,
+        n_per_stream: usize,
+        layout: CstLayout,
+        d_words: *mut u32,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_lower: *mut u64,
+        d_ckpt_range: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
+    pub fn cst_range_gaussian_ckpt_scratch_bytes(n_streams: usize, n_per_stream: usize, ckpt_interval: usize) -> usize;
+
+    pub fn cst_range_decode_gaussian_batch_ckpt(
+        cfg: CstCoderConfig,
+        min_symbol: i32,
+        max_symbol: i32,
+        d_words: *const u32,
+        d_offsets: *const u64,
+        stride_words: usize,
+        words_capacity: usize,
+        d_n_words: *const u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *const u32,
+        d_ckpt_lower: *const u64,
+        d_ckpt_range: *const u64,
+        d_means: *const f64,
+        d_stds: *const f64,
+        d_symbols: *mut i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_scratch: *mut c_void,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     pub fn cst_range_decode_rows_batch(
         cfg: CstCoderConfig,
         d_words: *const u32,

@@ -1634,6 +1634,62 @@ impl BatchedRangeEncoder {
         Ok(out)
     }
 
+    /// `encode_symbols` that also notes `RangeEncoder::pos()` in front of every chunk of `interval` symbols (ABI 5,
+    /// `cst_range_encode_gaussian_batch_ckpt`; src/stream/queue.rs:172-196): a multiple of 16 that divides `n_per_stream`, stream-major.
+    /// The words are those of `encode_symbols`.  `auto_jump_interval_gaussian` is the library's own choice of `interval`.
+    pub fn encode_symbols_with_checkpoints(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        support: RangeInclusive<i32>,
+        means: &DeviceBuffer<f64>,
+        stds: &DeviceBuffer<f64>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch, RangeCheckpoints)> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if interval == 0 || n_per_stream % interval != 0 || symbols.len() < count || means.len() < count || stds.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_points = n_streams.checked_mul(n_per_stream / interval).ok_or(Error::InvalidArgument)?;
+        let mut out = EncodedBatch::allocate(n_streams, self.max_words(n_per_stream), self.config)?;
+        let mut ckpt = RangeCheckpoints {
+            pos: DeviceBuffer::new(n_points)?,
+            lower: DeviceBuffer::new(n_points)?,
+            range: DeviceBuffer::new(n_points)?,
+            interval,
+        };
+        check(unsafe {
+            ffi::cst_range_encode_gaussian_batch_ckpt(
+                self.config,
+                *support.start(),
+                *support.end(),
+                symbols.as_ptr(),
+                means.as_ptr(),
+                stds.as_ptr(),
+                n_streams,
+                n_per_stream,
+                self.layout.raw(),
+                out.words.as_mut_ptr(),
+                out.stride_words,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.lower.as_mut_ptr(),
+                ckpt.range.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        Ok((out, ckpt))
+    }
+
+    /// The library's own choice of jump points for `encode_symbols_with_checkpoints` (`cst_jump_points_auto_gaussian`), or 0.
+    pub fn auto_jump_interval_gaussian(&self, n_streams: usize, n_per_stream: usize) -> usize {
+        unsafe { ffi::cst_jump_points_auto_gaussian(self.config, ffi::CST_CODER_RANGE, n_streams, n_per_stream, self.layout.raw()) }
+    }
+
     /// `encode_symbols` with explicit `(left_cumulative, probability)` per symbol.
     pub fn encode_symbols_with_cp(
         &self,
@@ -1835,6 +1891,58 @@ impl BatchedRangeDecoder {
                 checkpoints.pos.as_ptr(),
                 checkpoints.lower.as_ptr(),
                 checkpoints.range.as_ptr(),
+                out.symbols.as_mut_ptr(),
+                n_streams,
+                n_per_stream,
+                scratch.as_mut_ptr() as *mut c_void,
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the scratch buffer is dropped on return)
+        Ok(out)
+    }
+
+    /// `RangeDecoder::seek` + `decode_symbols` of one chunk's models, for every chunk at once (`cst_range_decode_gaussian_batch_ckpt`): two
+    /// resident waves per SIMD where the plain per-symbol decoder of a 65 536-stream batch has one.  One status per (stream, chunk).
+    pub fn decode_symbols_from_checkpoints(
+        &self,
+        encoded: &EncodedBatch,
+        checkpoints: &RangeCheckpoints,
+        support: RangeInclusive<i32>,
+        means: &DeviceBuffer<f64>,
+        stds: &DeviceBuffer<f64>,
+        n_per_stream: usize,
+        stream: &Stream,
+    ) -> Result<DecodedBatch> {
+        let n_streams = encoded.n_streams;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if checkpoints.interval == 0 || n_per_stream % checkpoints.interval != 0 || means.len() < count || stds.len() < count {
+            return Err(Error::InvalidArgument);
+        }
+        let n_points = n_streams.checked_mul(n_per_stream / checkpoints.interval).ok_or(Error::InvalidArgument)?;
+        if checkpoints.pos.len() < n_points || checkpoints.lower.len() < n_points || checkpoints.range.len() < n_points {
+            return Err(Error::InvalidArgument);
+        }
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_points)? };
+        let mut scratch: DeviceBuffer<u8> =
+            DeviceBuffer::new(unsafe { ffi::cst_range_gaussian_ckpt_scratch_bytes(n_streams, n_per_stream, checkpoints.interval) })?;
+        check(unsafe {
+            ffi::cst_range_decode_gaussian_batch_ckpt(
+                self.config,
+                *support.start(),
+                *support.end(),
+                encoded.words.as_ptr(),
+                core::ptr::null(),
+                encoded.stride_words,
+                encoded.words.len(),
+                encoded.n_words.as_ptr(),
+                checkpoints.interval,
+                checkpoints.pos.as_ptr(),
+                checkpoints.lower.as_ptr(),
+                checkpoints.range.as_ptr(),
+                means.as_ptr(),
+                stds.as_ptr(),
                 out.symbols.as_mut_ptr(),
                 n_streams,
                 n_per_stream,

@@ -94,6 +94,9 @@ SIGNATURES = {
     "cst_ans_decode_batch_sym": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _vp, _vp, _i32, _z, _z, _i32, _vp, _vp, _vp, _u32, _vp, _vp]),
     "cst_ans_encode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_ans_decode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
+    "cst_range_encode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
+    "cst_range_gaussian_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
+    "cst_range_decode_gaussian_batch_ckpt": (_i32, [CoderConfig, _i32, _i32, _vp, _vp, _z, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp, _vp, _z, _z, _vp, _vp, _vp]),
     "cst_range_encode_batch_ckpt": (_i32, [_vp, CoderConfig, _vp, _z, _z, _i32, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp, _vp]),
     "cst_range_ckpt_scratch_bytes": (_z, [_z, _z, _z]),
     "cst_range_sym_scratch_bytes": (_z, [_z, _z, _z, _i32]),

@@ -937,9 +937,25 @@ def ans_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32
 
 
 def range_encode_gaussian(symbols, min_symbol, max_symbol, means, stds, config=(32, 64, 24), layout="stream_major",
-                          stride: Optional[int] = None, out: Optional[EncodedBatch] = None) -> EncodedBatch:
+                          stride: Optional[int] = None, out: Optional[EncodedBatch] = None, jump_points="auto") -> EncodedBatch:
     """One RangeEncoder per stream: encode(symbols[s], QuantizedGaussian(min, max), means[s], stds[s]) + get_compressed
-    (src/pybindings/stream/queue.rs:343-410)."""
+    (src/pybindings/stream/queue.rs:343-410).  jump_points: as for ans_encode_gaussian (RangeEncoder.pos(), queue.rs:172-196)."""
+    n_streams, n_per, lay = _layout_shape(symbols, layout)
+    interval = _jump_interval(jump_points, n_per, lambda: N.lib().cst_jump_points_auto_gaussian(_cfg(*config), N.CODER_RANGE, n_streams, n_per, lay))
+    if interval:
+        if layout != "stream_major":
+            raise ValueError("jump_points: stream-major batches only")
+        symbols = _require_cuda(symbols, torch.int32, "symbols")
+        means, stds = _gaussian_args(symbols.shape, means, stds)
+        if out is None:
+            out = _new_batch(n_streams, stride or range_max_words(n_per, config), symbols.device, config)
+        ck = _jump_table(out, RangeCheckpoints, interval, n_streams, n_per, symbols.device)
+        N.check(N.lib().cst_range_encode_gaussian_batch_ckpt(_cfg(*config), int(min_symbol), int(max_symbol), _ptr(symbols), _ptr(means), _ptr(stds),
+                                                             n_streams, n_per, lay, _ptr(out.words), out.words.shape[1], _ptr(out.n_words), interval,
+                                                             _ptr(ck.pos), _ptr(ck.lower), _ptr(ck.range), _ptr(out.status), _stream_ptr()),
+                "cst_range_encode_gaussian_batch_ckpt")
+        out.jump = ck
+        return out
     out = _encode_gaussian("cst_range_encode_gaussian_batch", range_max_words, symbols, min_symbol, max_symbol, means, stds,
                            config, layout, stride, out)
     out.jump = None
@@ -1041,7 +1057,25 @@ def ans_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="st
 
 
 def range_decode_gaussian(encoded, min_symbol, max_symbol, means, stds, layout="stream_major", offsets=None, out=None, config=None):
-    """One RangeDecoder per stream: RangeDecoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s])."""
+    """One RangeDecoder per stream: RangeDecoder(words[s]).decode(QuantizedGaussian(min, max), means[s], stds[s]).  A batch that carries
+    jump points for exactly this shape (range_encode_gaussian, jump_points) decodes every part of a stream on a lane of its own."""
+    jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
+    if isinstance(jump, RangeCheckpoints) and offsets is None and layout == "stream_major" and means.dim() == 2 and \
+            tuple(means.shape) == (jump.pos.shape[0], jump.interval * jump.pos.shape[1]) and jump.pos.shape[0] == encoded.n_words.numel():
+        n_streams, n_per = means.shape
+        means, stds = _gaussian_args(means.shape, means, stds)
+        dev = encoded.words.device
+        if out is None:
+            out = torch.empty((n_streams, n_per), dtype=torch.int32, device=dev)
+        part_status = torch.empty(tuple(jump.pos.shape), dtype=torch.int32, device=dev)
+        L = N.lib()
+        scratch = _ckpt_scratch("range_gaussian_ckpt", dev, L.cst_range_gaussian_ckpt_scratch_bytes(n_streams, n_per, jump.interval))
+        N.check(L.cst_range_decode_gaussian_batch_ckpt(_cfg(*encoded.config), int(min_symbol), int(max_symbol), _ptr(encoded.words), None,
+                                                       encoded.words.shape[1], encoded.words.numel(), _ptr(encoded.n_words), jump.interval,
+                                                       _ptr(jump.pos), _ptr(jump.lower), _ptr(jump.range), _ptr(means), _ptr(stds), _ptr(out),
+                                                       n_streams, n_per, _ptr(scratch), _ptr(part_status), _stream_ptr()),
+                "cst_range_decode_gaussian_batch_ckpt")
+        return out, _status_per_stream(part_status)
     return _decode_gaussian("cst_range_decode_gaussian_batch", False, encoded, min_symbol, max_symbol, means, stds, layout, offsets, out, config)
 
 

@@ -132,7 +132,7 @@ size_t cst_jump_points_auto(const cst_model* model, cst_coder_config cfg, int32_
 }
 
 size_t cst_jump_points_auto_gaussian(cst_coder_config cfg, int32_t coder, size_t n_streams, size_t n_per_stream, cst_layout layout) {
-    if (!knobs().auto_jump || coder != CST_CODER_ANS || layout != CST_LAYOUT_STREAM_MAJOR) return 0;
+    if (!knobs().auto_jump || (coder != CST_CODER_ANS && coder != CST_CODER_RANGE) || layout != CST_LAYOUT_STREAM_MAJOR) return 0;
     if (n_streams < knobs().fused_min_streams || n_streams < 16384 || n_per_stream < 2 * kMinInterval) return 0;     // (the fused encoder notes the points)
     if (!config_supported(cfg)) return 0;
     int cus = 256;

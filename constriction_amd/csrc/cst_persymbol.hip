@@ -293,9 +293,12 @@ struct GaussianFusedArgs {
     cst_range_state* rstate;
     int32_t* status;
     uint32_t flags;
-    // ANS jump points (Pos, stack.rs:1130-1139), [n_streams][n_chunks], noted where a chunk of `interval` symbols starts; or null
+    // jump points (Pos: stack.rs:1130-1139, queue.rs:182-196), [n_streams][n_chunks], noted where a chunk of `interval` symbols starts; or
+    // null.  ANS: (words in the bulk, state).  Range coder (round 6): (words emitted incl. held-back ones, lower, range).
     uint32_t* ckpt_pos;
     uint64_t* ckpt_state;
+    uint64_t* ckpt_lower;
+    uint64_t* ckpt_range;
     size_t interval, n_chunks;
 };
 
@@ -507,6 +510,14 @@ __global__ __launch_bounds__(kFuBlock) void encode_gaussian_fused_kernel(const G
         // ---- phase B: every stream's lane over its row ----
         const size_t t0 = k * kFuTile;
         const int n_here = (int)(N - t0 < (size_t)kFuTile ? N - t0 : (size_t)kFuTile);
+        if constexpr (KIND == kRange) {
+            // RangeEncoder::pos() in front of a chunk (a queue: BEFORE the chunk's first symbol is encoded; chunks are whole tiles)
+            if (a.ckpt_pos && active && t0 % a.interval == 0) {
+                a.ckpt_pos[s * a.n_chunks + t0 / a.interval] = LR.out.wr + LR.inv_n;
+                a.ckpt_lower[s * a.n_chunks + t0 / a.interval] = (uint64_t)LR.lower;
+                a.ckpt_range[s * a.n_chunks + t0 / a.interval] = (uint64_t)LR.range;
+            }
+        }
         if (active) {
             if constexpr (KIND == kAns) {
                 constexpr bool FAST = W == 32 && S == 64;            // the 32-bit-halves step (8 <= P)
@@ -1569,13 +1580,14 @@ static cst_status encode_gaussian_fused(cst_coder_config cfg, int32_t min_symbol
                                         const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream, cst_layout layout,
                                         uint32_t* d_words, size_t stride_words, uint32_t* d_n_words, uint64_t* d_state,
                                         cst_range_state* d_rstate, int32_t* d_status, uint32_t flags, hipStream_t hs,
-                                        size_t ckpt_interval = 0, uint32_t* d_ckpt_pos = nullptr, uint64_t* d_ckpt_state = nullptr) {
+                                        size_t ckpt_interval = 0, uint32_t* d_ckpt_pos = nullptr, uint64_t* d_ckpt_state = nullptr,
+                                        uint64_t* d_ckpt_lower = nullptr, uint64_t* d_ckpt_range = nullptr) {
     if (cst_status st = check_common(cfg, layout)) return st;
     if (!d_words || !d_n_words || !d_status) return CST_ERR_INVALID_ARGUMENT;
     if ((flags & CST_FLAG_RAW_STATE) && (KIND == kAns ? (void*)d_state : (void*)d_rstate) == nullptr) return CST_ERR_INVALID_ARGUMENT;
     GaussianFusedArgs a{};
     if (ckpt_interval) {
-        a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.interval = ckpt_interval;
+        a.ckpt_pos = d_ckpt_pos; a.ckpt_state = d_ckpt_state; a.ckpt_lower = d_ckpt_lower; a.ckpt_range = d_ckpt_range; a.interval = ckpt_interval;
         a.n_chunks = (n_per_stream + ckpt_interval - 1) / ckpt_interval;
     }
     a.symbols = d_symbols; a.means = d_means; a.stds = d_stds; a.n_streams = n_streams; a.n_per_stream = n_per_stream;
@@ -1847,6 +1859,102 @@ cst_status cst_ans_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_
                                                         n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR, v_state, nullptr, d_status, CST_FLAG_RAW_STATE, stream);
     if (rc != CST_OK) return rc;
     return flag_bad_jump_points(d_ckpt_pos, n_streams, n_chunks, d_offsets ? 0 : stride_words, d_status, (hipStream_t)stream);
+}
+
+// ... and for the range coder (round 6): the fused encoder notes RangeEncoder::pos() in front of every chunk, the decoder builds the
+// RangeDecoder::seek states of the (stream, chunk) pairs (point re-read at the jump point: range_ckpt_virtual_state) and runs them as
+// streams of their own -- the small-geometry lane decoder, two waves per SIMD, where the plain decoder of 65 536 streams has one
+cst_status cst_range_encode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,
+                                                const double* d_means, const double* d_stds, size_t n_streams, size_t n_per_stream,
+                                                cst_layout layout, uint32_t* d_words, size_t stride_words, uint32_t* d_n_words,
+                                                size_t ckpt_interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_lower, uint64_t* d_ckpt_range,
+                                                int32_t* d_status, void* stream) {
+    if (n_per_stream > 0 && (!d_symbols || !d_means || !d_stds)) return CST_ERR_INVALID_ARGUMENT;
+    if (!d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range || ckpt_interval == 0 || ckpt_interval % kFuTile != 0 || n_per_stream % ckpt_interval != 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (max_symbol <= min_symbol || (int64_t)max_symbol - min_symbol + 1 > ((int64_t)1 << cfg.precision)) return CST_ERR_MODEL;
+    if (n_streams == 0) return CST_OK;
+    return note_kernel("range_encode_gaussian_fused_kernel<ckpt>",
+                       encode_gaussian_fused<kRange>(cfg, min_symbol, max_symbol, d_symbols, d_means, d_stds, n_streams, n_per_stream, layout, d_words,
+                                                     stride_words, d_n_words, nullptr, nullptr, d_status, CST_FLAG_NONE, (hipStream_t)stream, ckpt_interval,
+                                                     d_ckpt_pos, nullptr, d_ckpt_lower, d_ckpt_range));
+}
+
+size_t cst_range_gaussian_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval) {
+    if (ckpt_interval == 0) return 0;
+    return (sizeof(cst_range_state) + 16) * n_streams * ((n_per_stream + ckpt_interval - 1) / ckpt_interval) + 64;
+}
+
+} // extern "C"  (kernels and templates have C++ linkage)
+
+// virtual stream v = (stream v / k, chunk v % k): where its words lie, and the decoder state RangeDecoder::seek leaves (queue.rs:911-926)
+template <int W, int S>
+__global__ void gaussian_range_virtual_kernel(const uint32_t* __restrict__ words, const uint64_t* __restrict__ offsets, size_t stride_words,
+                                              uint64_t capacity, const uint32_t* __restrict__ n_words, const uint32_t* __restrict__ ckpt_pos,
+                                              const uint64_t* __restrict__ ckpt_lower, const uint64_t* __restrict__ ckpt_range, size_t n_streams,
+                                              size_t n_chunks, uint64_t* __restrict__ v_offsets, uint32_t* __restrict__ v_n,
+                                              cst_range_state* __restrict__ v_state) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    const size_t s = v / n_chunks;
+    const WordSlice ws = word_slice(offsets, stride_words, n_words, s, capacity);
+    const uint32_t pos0 = ckpt_pos[v] < ws.n ? ckpt_pos[v] : ws.n;
+    uint64_t pt = 0;
+    uint32_t pos = pos0;
+    int num_read = 0;
+    const uint64_t mask = S == 64 ? ~0ull : ((1ull << (S % 64)) - 1ull);
+    while (pos < ws.n) {                                          // read_point, queue.rs:847-868
+        pt = ((pt << (W % 64)) | (uint64_t)words[ws.off + pos++]) & mask;
+        if (++num_read == S / W) break;
+    }
+    if (num_read < S / W && num_read != 0) pt = (pt << (S - num_read * W)) & mask;
+    cst_range_state r{};
+    r.lower = ckpt_lower[v]; r.range = ckpt_range[v]; r.point = pt; r.position = pos;
+    v_state[v] = r;
+    v_offsets[v] = offsets ? offsets[s] : (uint64_t)s * stride_words;   // (the decoder checks the slice again: a bad one stays bad)
+    v_n[v] = n_words[s];
+}
+
+__global__ void gaussian_range_flag_kernel(const uint32_t* __restrict__ n_words, const uint32_t* __restrict__ ckpt_pos, size_t n_streams, size_t n_chunks,
+                                           int32_t* __restrict__ status) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_streams * n_chunks) return;
+    if (ckpt_pos[v] > n_words[v / n_chunks]) status[v] = CST_STREAM_INVALID_DATA;      // a jump point beyond its stream's words
+}
+
+extern "C" {
+
+cst_status cst_range_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const uint32_t* d_words,
+                                                const uint64_t* d_offsets, size_t stride_words, size_t words_capacity, const uint32_t* d_n_words,
+                                                size_t ckpt_interval, const uint32_t* d_ckpt_pos, const uint64_t* d_ckpt_lower,
+                                                const uint64_t* d_ckpt_range, const double* d_means, const double* d_stds, int32_t* d_symbols,
+                                                size_t n_streams, size_t n_per_stream, void* d_scratch, int32_t* d_status, void* stream) {
+    if (!d_n_words || !d_ckpt_pos || !d_ckpt_lower || !d_ckpt_range || !d_scratch || !d_status || ckpt_interval == 0 || n_per_stream % ckpt_interval != 0)
+        return CST_ERR_INVALID_ARGUMENT;
+    if (cfg.word_bits != 32 && cfg.word_bits != 16) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0 || n_per_stream == 0) return CST_OK;
+    if (!d_words) return CST_ERR_INVALID_ARGUMENT;
+    const size_t n_chunks = n_per_stream / ckpt_interval, n_virtual = n_streams * n_chunks;
+    if (n_virtual > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    hipStream_t hs = (hipStream_t)stream;
+    const size_t capacity = words_capacity ? words_capacity : (d_offsets ? 0 : n_streams * stride_words);
+    cst_range_state* v_state = reinterpret_cast<cst_range_state*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15);
+    uint64_t* v_offsets = reinterpret_cast<uint64_t*>(v_state + n_virtual);
+    uint32_t* v_n = reinterpret_cast<uint32_t*>(v_offsets + n_virtual);
+    const dim3 grid((unsigned)((n_virtual + 255) / 256));
+    if (cfg.word_bits == 32)
+        hipLaunchKernelGGL((gaussian_range_virtual_kernel<32, 64>), grid, dim3(256), 0, hs, d_words, d_offsets, stride_words, capacity, d_n_words, d_ckpt_pos,
+                           d_ckpt_lower, d_ckpt_range, n_streams, n_chunks, v_offsets, v_n, v_state);
+    else
+        hipLaunchKernelGGL((gaussian_range_virtual_kernel<16, 32>), grid, dim3(256), 0, hs, d_words, d_offsets, stride_words, capacity, d_n_words, d_ckpt_pos,
+                           d_ckpt_lower, d_ckpt_range, n_streams, n_chunks, v_offsets, v_n, v_state);
+    CST_HIP_TRY(hipGetLastError());
+    const cst_status rc = cst_range_decode_gaussian_batch(cfg, min_symbol, max_symbol, d_words, v_offsets, 0, capacity, v_n, d_means, d_stds, d_symbols,
+                                                          n_virtual, ckpt_interval, CST_LAYOUT_STREAM_MAJOR, v_state, d_status, CST_FLAG_RAW_STATE, stream);
+    if (rc != CST_OK) return rc;
+    hipLaunchKernelGGL(gaussian_range_flag_kernel, grid, dim3(256), 0, hs, d_n_words, d_ckpt_pos, n_streams, n_chunks, d_status);
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
 }
 
 cst_status cst_range_encode_gaussian_batch(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol, const int32_t* d_symbols,

@@ -679,6 +679,27 @@ cst_status cst_range_decode_gaussian_batch(cst_coder_config cfg, int32_t min_sym
                                            cst_layout layout, cst_range_state *d_rstate, int32_t *d_status,
                                            uint32_t flags, void *stream);
 
+/* ABI 5: jump points for the per-symbol Gaussian calls of the RANGE coder (RangeEncoder::pos / RangeDecoder::seek, src/stream/queue.rs:172-196,
+ * 900-926), as cst_ans_{encode,decode}_gaussian_batch_ckpt are for ANS: the fused encoder notes (words emitted including held-back ones,
+ * lower, range) in front of every chunk of ckpt_interval symbols (a multiple of 16 that divides n_per_stream; stream-major), the decoder
+ * runs every (stream, chunk) pair as a decoder of its own -- chunk j of stream s codes row s * n_chunks + j of the three matrices viewed
+ * as [n_streams * n_chunks][interval] -- and writes n_streams * n_chunks status entries.  The words are those of
+ * cst_range_encode_gaussian_batch.  d_scratch: cst_range_gaussian_ckpt_scratch_bytes(...). */
+cst_status cst_range_encode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                                const int32_t *d_symbols, const double *d_means, const double *d_stds,
+                                                size_t n_streams, size_t n_per_stream, cst_layout layout, uint32_t *d_words,
+                                                size_t stride_words, uint32_t *d_n_words, size_t ckpt_interval,
+                                                uint32_t *d_ckpt_pos, uint64_t *d_ckpt_lower, uint64_t *d_ckpt_range,
+                                                int32_t *d_status, void *stream);
+size_t cst_range_gaussian_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval);
+cst_status cst_range_decode_gaussian_batch_ckpt(cst_coder_config cfg, int32_t min_symbol, int32_t max_symbol,
+                                                const uint32_t *d_words, const uint64_t *d_offsets, size_t stride_words,
+                                                size_t words_capacity, const uint32_t *d_n_words, size_t ckpt_interval,
+                                                const uint32_t *d_ckpt_pos, const uint64_t *d_ckpt_lower,
+                                                const uint64_t *d_ckpt_range, const double *d_means, const double *d_stds,
+                                                int32_t *d_symbols, size_t n_streams, size_t n_per_stream, void *d_scratch,
+                                                int32_t *d_status, void *stream);
+
 cst_status cst_range_decode_rows_batch(cst_coder_config cfg, const uint32_t *d_words, const uint64_t *d_offsets,
                                        size_t stride_words, size_t words_capacity, const uint32_t *d_n_words, const uint32_t *d_cdf_rows,
                                        int32_t n_symbols, int32_t min_symbol, int32_t *d_symbols, size_t n_streams,

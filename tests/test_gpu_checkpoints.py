@@ -185,6 +185,44 @@ def test_per_symbol_gaussian_jump_points(B, O, n_streams, n_per, interval, knob)
     assert (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
 
 
+@pytest.mark.parametrize("n_streams,n_per,interval", [(64, 64, 16), (130, 96, 32), (70, 128, 64), (256, 48, 48)], ids=lambda v: str(v))
+def test_per_symbol_gaussian_jump_points_range_coder(B, O, n_streams, n_per, interval, knob):
+    """round 6: the same for the range coder (cst_range_{encode,decode}_gaussian_batch_ckpt): RangeEncoder.pos() in front of every chunk
+    (queue.rs:182-196) from the CPU oracle coding the stream's prefix alone, the words of the plain call, every chunk decoded through its
+    jump point"""
+    knob(CST_FUSED_MIN_STREAMS="1")
+    rng = np.random.default_rng(n_streams + n_per + 1)
+    mu = rng.uniform(-30, 30, (n_streams, n_per)); sd = np.exp(rng.uniform(-1, 3, (n_streams, n_per)))
+    sym = np.clip(np.rint(mu + sd * rng.standard_normal((n_streams, n_per))), -100, 100).astype(np.int32)
+    enc = B.range_encode_gaussian(dev(sym), -100, 100, dev(mu), dev(sd), jump_points=n_per // interval)
+    assert B.last_kernel() == "range_encode_gaussian_fused_kernel<ckpt>" and enc.jump.pos.shape == (n_streams, n_per // interval)
+    plain = B.range_encode_gaussian(dev(sym), -100, 100, dev(mu), dev(sd), jump_points=0)
+    torch.cuda.synchronize()
+    assert plain.jump is None and (enc.status.cpu().numpy() == 0).all() and torch.equal(enc.n_words, plain.n_words)
+    pos = enc.jump.pos.cpu().numpy().view(np.uint32)
+    lower, rng_ = enc.jump.lower.cpu().numpy().view(np.uint64), enc.jump.range.cpu().numpy().view(np.uint64)
+    for s in (0, n_streams // 2, n_streams - 1):
+        assert enc.stream(s).tolist() == plain.stream(s).tolist()
+        models = [O.GaussianModel(-100, 100, float(m), float(v), 24, 32) for m, v in zip(mu[s], sd[s])]
+        for j in range(n_per // interval):
+            c = O.RangeEncoder()
+            c.encode(sym[s, : j * interval], models[: j * interval], 24)
+            want = c.pos()
+            assert (int(pos[s, j]), (int(lower[s, j]), int(rng_[s, j]))) == want, (s, j)
+        c = O.RangeEncoder()
+        c.encode(sym[s], models, 24)
+        assert enc.stream(s).tolist() == c.get_compressed().tolist()
+    dec, dstatus = B.range_decode_gaussian(enc, -100, 100, dev(mu), dev(sd))
+    torch.cuda.synchronize()
+    assert dstatus.shape == (n_streams,) and (dstatus.cpu().numpy() == 0).all() and np.array_equal(dec.cpu().numpy(), sym)
+    dec2, st2 = B.range_decode_gaussian(plain, -100, 100, dev(mu), dev(sd))
+    assert np.array_equal(dec2.cpu().numpy(), sym)
+    enc.jump.pos[3, -1] = 1 << 28                                  # a jump point beyond its stream: flagged, nothing read out of bounds
+    _, st3 = B.range_decode_gaussian(enc, -100, 100, dev(mu), dev(sd))
+    st3 = st3.cpu().numpy()
+    assert st3[3] == 3 and st3.sum() == 3
+
+
 # ---- round 5: jump points at the speed of the plain encoder (producer / consumer encoder), and int8 matrices through them ----
 
 @pytest.mark.parametrize("dtype", ["int32", "int8"])

@@ -149,3 +149,7 @@ def test_f1_per_symbol_gaussians(B):
     assert B.last_kernel() == "ans_encode_gaussian_fused_kernel" and plain.jump is None
     dec, st = B.ans_decode_gaussian(plain, lo, hi, mu, sd)
     assert B.last_kernel() == "ans_decode_gaussian_lane_kernel" and torch.equal(dec, sym)
+    renc = B.range_encode_gaussian(sym, lo, hi, mu, sd)                  # round 6: the range coder's per-symbol calls take them too
+    assert B.last_kernel() == "range_encode_gaussian_fused_kernel<ckpt>" and renc.jump.pos.shape == (n_streams, 2)
+    dec, st = B.range_decode_gaussian(renc, lo, hi, mu, sd)
+    assert B.last_kernel() == "range_decode_gaussian_lane_kernel<small>" and int(st.abs().sum()) == 0 and torch.equal(dec, sym)
