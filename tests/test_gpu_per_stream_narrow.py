@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_PT_SUB_WAVES"))
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_PT_SUB_WAVES", "CST_AUTO_JUMP"))
 torch = pytest.importorskip("torch")
 
 
@@ -136,7 +136,7 @@ def test_c3_int8_round_trip_at_full_size_without_conversion_kernels(B, O):
     d = sym.to(torch.int8)
     enc = B.ans_encode(d, model, (32, 64, 12))
     assert ALT or B.last_kernel() == "ans_encode_pt_n8_kernel<ckpt>"
-    assert enc.jump is not None and enc.jump.pos.shape == (n, 8)
+    assert ALT or (enc.jump is not None and enc.jump.pos.shape == (n, 8))
     plain = B.ans_encode(sym, model, (32, 64, 12), jump_points=0)
     used = torch.arange(plain.words.shape[1], device="cuda")[None, :] < plain.n_words[:, None]
     assert torch.equal(enc.n_words, plain.n_words) and bool(((enc.words == plain.words) | ~used).all())

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-ALT = any(os.environ.get(k) for k in ("CST_NO_N8",))
+ALT = any(os.environ.get(k) for k in ("CST_NO_N8", "CST_AUTO_JUMP"))
 torch = pytest.importorskip("torch")
 
 
@@ -155,7 +155,7 @@ def test_int8_range_round_trip_at_full_size_without_conversion_kernels(B, O):
     d = sym.to(torch.int8)
     enc = B.range_encode(d, model, (32, 64, P))
     assert ALT or B.last_kernel() == "range_encode_ckpt_n8_kernel"
-    assert enc.jump is not None and enc.jump.pos.shape == (65536, 2)
+    assert ALT or (enc.jump is not None and enc.jump.pos.shape == (65536, 2))
     plain = B.range_encode(sym, model, (32, 64, P), jump_points=0)
     used = torch.arange(plain.words.shape[1], device="cuda")[None, :] < plain.n_words[:, None]
     assert torch.equal(enc.n_words, plain.n_words) and bool(((enc.words == plain.words) | ~used).all())
