@@ -11,10 +11,14 @@
 //           symbol: i -> t = clamp(i, a, b), two 16-bit LDS reads (c[t], c[t+1]),
 //           c = c[t] + (i - t), p = c[t+1] - c[t]; m = floor(2^64 / p) from a reciprocal table shared by the workgroup.
 //   decode  (stack.rs:1070-1100)   entries  c << 20 | (p-1) << 8 | index  sorted by c, every run of unit probabilities
-//           folded into ONE entry; quantile q -> l1[q >> (P-7)] = the aligned pair of entries that holds the first
-//           candidate, six consecutive entries from there (two aligned LDS reads): the answer is the last of the first
-//           five that is <= q << 20 | 0xffffe, provided the sixth is larger; otherwise the lane continues four entries
-//           further in a wave-uniform loop (buckets that hold more than four bins: the narrow bins next to the unit runs).
+//           folded into ONE entry; quantile q -> l1[q >> (P-7)] = the 16-byte aligned quad of entries that holds the first
+//           candidate, EIGHT consecutive entries from there (two ds_read_b128): the answer is the entry of the smallest wrapping
+//           distance (q << 20 | 0xffffe) - entry among the first seven, provided the eighth lies above the key; otherwise the lane
+//           continues four entries further in a wave-uniform loop (the narrow bins next to the unit runs).
+//           (Round 6: until then six entries from the aligned PAIR -- ds_read2_b64 + ds_read_b64.  A wave's LDS read with random
+//           lane addresses costs ~13 LDS cycles per CU whatever its width, ds_read2_b64 29: the six entries cost 37 cycles, the
+//           eight 23 -- scripts/microbench/lds_tput.hip -- and the sub-lane decoder, LDS-bound at sixteen waves, went from 0.41 to
+//           0.35 ms on C3.)
 // Shapes this file does not take (P > 12 or P < 8, more than 256 symbols, the 16-bit word preset, symbol-major
 // matrices, blocks whose rows do not fit in LDS) stay on the full-row kernels of cst_ans_ps.hip.
 #include <type_traits>
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
     const uint32_t qmask = (1u << P) - 1u;
     const uint32_t bucket_mask = (uint32_t)(kPtBuckets - 1) << bshift;
     const PtMeta mt = active ? a.meta[s] : PtMeta{0u, 0u, 0, 1, 1, 0};
-    const uint32_t* rowp = rows_l + mt.dec_off;                 // 8-byte aligned
+    const uint32_t* rowp = rows_l + mt.dec_off;                 // 16-byte aligned
     const uint32_t row_addr = lds_addr(rowp);
     const uint8_t* l1p = l1_l + (((threadIdx.x >> bshift) * kPtBuckets) << bshift) + (threadIdx.x & ((1u << bshift) - 1u));
 
@@ -405,19 +409,20 @@ __global__ __launch_bounds__(kBlock) void ans_decode_pt_kernel(const PtArgs a) {
         const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
         uint32_t r0 = l1p[q & bucket_mask];
         const uint32_t qk = (q << 20) | 0xffffeu;
-        uint32_t e;
+        // eight entries from the 16-byte aligned quad that holds the first candidate (r0 = a quarter of its position): the bin is
+        // the entry of the smallest wrapping distance qk - entry among the first seven (entries above the key wrap to huge
+        // distances, the sentinels behind a row to qk + 1), unless the eighth is at or below the key too: then four entries further
+        uint32_t dmin = 0xffffffffu;
         for (int guard = 0;; ++guard) {
-            // six entries from the 8-byte aligned pair that holds the first candidate (r0 = half its position)
-            const uint2* pr = reinterpret_cast<const uint2*>(rowp) + r0;
-            const uint2 x01 = pr[0], x23 = pr[1], x45 = pr[2];
-            e = x01.y <= qk ? x01.y : x01.x;
-            e = x23.x <= qk ? x23.x : e;
-            e = x23.y <= qk ? x23.y : e;
-            e = x45.x <= qk ? x45.x : e;
-            const bool more = x45.y <= qk;               // the bin lies behind the fifth entry
+            const uint4* pr = reinterpret_cast<const uint4*>(rowp) + r0;
+            const uint4 xa = pr[0], xb = pr[1];
+            dmin = min(dmin, min(min(qk - xa.x, qk - xa.y), min(qk - xa.z, qk - xa.w)));
+            dmin = min(dmin, min(min(qk - xb.x, qk - xb.y), qk - xb.z));
+            const bool more = xb.w <= qk;
             if (!__any(more) || guard > 64) break;
-            r0 += more ? 2u : 0u;
+            r0 += more ? 1u : 0u;
         }
+        const uint32_t e = qk - dmin;
         const uint32_t pm1 = (e >> 8) & 0xfffu;
         const bool run = pm1 == kPtRunMark;               // a run of unit probabilities: symbol index + (q - c), (c, p) = (q, 1)
         const uint32_t d = q - (e >> 20);
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const 
     const uint32_t qmask = (1u << P) - 1u;
     const uint32_t bucket_mask = (uint32_t)(kPtBuckets - 1) << bshift;
     const PtMeta mt = a.meta[s];
-    const uint32_t* rowp = rows_l + (mt.dec_off - first_off);        // 8-byte aligned
+    const uint32_t* rowp = rows_l + (mt.dec_off - first_off);        // 16-byte aligned
     const uint32_t row_addr = lds_addr(rowp);
     const uint8_t* l1p = l1_l + (((ls >> bshift) * kPtBuckets) << bshift) + (ls & ((1u << bshift) - 1u));
 
@@ -604,18 +609,20 @@ __global__ __launch_bounds__(WAVES * kWave) void ans_decode_pt_sub_kernel(const 
         const uint32_t next_word = *L.in.slot(L.in.rd - 1u + L.in.shift);
         uint32_t r0 = l1p[q & bucket_mask];
         const uint32_t qk = (q << 20) | 0xffffeu;
-        uint32_t e;
+        // eight entries from the 16-byte aligned quad that holds the first candidate (r0 = a quarter of its position): the bin is
+        // the entry of the smallest wrapping distance qk - entry among the first seven (entries above the key wrap to huge
+        // distances, the sentinels behind a row to qk + 1), unless the eighth is at or below the key too: then four entries further
+        uint32_t dmin = 0xffffffffu;
         for (int guard = 0;; ++guard) {
-            const uint2* pr = reinterpret_cast<const uint2*>(rowp) + r0;
-            const uint2 x01 = pr[0], x23 = pr[1], x45 = pr[2];
-            e = x01.y <= qk ? x01.y : x01.x;
-            e = x23.x <= qk ? x23.x : e;
-            e = x23.y <= qk ? x23.y : e;
-            e = x45.x <= qk ? x45.x : e;
-            const bool more = x45.y <= qk;
+            const uint4* pr = reinterpret_cast<const uint4*>(rowp) + r0;
+            const uint4 xa = pr[0], xb = pr[1];
+            dmin = min(dmin, min(min(qk - xa.x, qk - xa.y), min(qk - xa.z, qk - xa.w)));
+            dmin = min(dmin, min(min(qk - xb.x, qk - xb.y), qk - xb.z));
+            const bool more = xb.w <= qk;
             if (!__any(more) || guard > 64) break;
-            r0 += more ? 2u : 0u;
+            r0 += more ? 1u : 0u;
         }
+        const uint32_t e = qk - dmin;
         const uint32_t pm1 = (e >> 8) & 0xfffu;
         const bool run = pm1 == kPtRunMark;
         const uint32_t d = q - (e >> 20);

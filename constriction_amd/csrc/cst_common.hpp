@@ -82,7 +82,7 @@ __host__ __device__ inline bool bucket16_usable(int n_symbols, int P) {
 //   decoder row (32-bit entries sorted by c, searched by quantile): one entry per symbol,
 //       c << 20 | (p - 1) << 8 | index,  except that every maximal run of >= 2 unit probabilities is ONE entry
 //       c << 20 | 0xfff << 8 | first index  (quantile q of the run is symbol index + (q - c), with (c, p) = (q, 1));
-//       kPtRowPad sentinels 0xffffffff behind the row.  P <= 12, n <= 256.
+//       kPtRowPad sentinels 0xffffffff behind the row (more up to a whole quad of entries: rows start on 16 bytes).  P <= 12, n <= 256.
 // Rows of different lengths lie back to back, blocks of kBlock streams are contiguous.
 struct PtMeta {
     uint32_t enc_off;   // first 16-bit entry of the encoder row, relative to its block
@@ -93,9 +93,9 @@ struct PtMeta {
     uint16_t pad;
 };
 constexpr int kPtBucketBits = 7, kPtBuckets = 1 << kPtBucketBits;
-constexpr int kPtRowPad = 5;          // sentinel entries behind every decoder row: the decoder reads SIX entries at a time from the
-                                      // aligned pair that holds its first candidate (scripts/gen_pt_decode_loop.py, WINDOW = 6; the
-                                      // measured-and-not-adopted GEN_PT_WINDOW=8 needs 7 here)
+constexpr int kPtRowPad = 7;          // sentinel entries behind every decoder row: the decoder reads EIGHT entries at a time from the
+                                      // 16-byte aligned quad that holds its first candidate (two ds_read_b128: scripts/gen_pt_decode_loop.py);
+                                      // rows start on 16 bytes (their length is rounded up to whole quads)
 constexpr uint32_t kPtRunMark = 0xfffu;
 
 } // namespace cst

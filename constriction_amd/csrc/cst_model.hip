@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void pt_offsets_kernel(PtMeta* __restrict__ me
     __shared__ uint32_t se[256], sd[256];
     const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t le = s < n_tables ? (uint32_t)meta[s].m + 1u : 0u;
-    const uint32_t ld = s < n_tables ? ((uint32_t)meta[s].m_dec + kPtRowPad + 1u) & ~1u : 0u;   // rows start on 8 bytes
+    const uint32_t ld = s < n_tables ? ((uint32_t)meta[s].m_dec + kPtRowPad + 3u) & ~3u : 0u;   // rows start on 16 bytes
     se[threadIdx.x] = le; sd[threadIdx.x] = ld;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
@@ -113,9 +113,10 @@ __global__ void pt_fill_kernel(const uint32_t* __restrict__ cdf, size_t n_tables
     const PtMeta mt = meta[s];
     uint16_t* e = enc + (size_t)enc_base[s / kBlock] + mt.enc_off;
     for (uint32_t j = 0; j <= mt.m; ++j) e[j] = (uint16_t)row[mt.a + j];
-    // decoder row and, alongside, the bucket index: bucket k = quantiles [k * w, (k + 1) * w) -> HALF the position of
-    // the entry that holds k * w (the decoder reads four entries from an 8-byte aligned address: misaligned LDS reads
-    // are 5x slower, scripts/microbench/lds_tput.hip)
+    // decoder row and, alongside, the bucket index: bucket k = quantiles [k * w, (k + 1) * w) -> a QUARTER of the position of
+    // the entry that holds k * w (the decoder reads eight entries from a 16-byte aligned address with two ds_read_b128:
+    // misaligned LDS reads are 5x slower, and two aligned 16-byte reads cost 23 LDS cycles where ds_read2_b64 + ds_read_b64
+    // of six entries cost 37 -- scripts/microbench/lds_tput.hip)
     uint32_t* d = dec + (size_t)dec_base[s / kBlock] + mt.dec_off;
     uint8_t* b = l1 + s * kPtBuckets;
     const int shift = P - kPtBucketBits;
@@ -131,11 +132,11 @@ __global__ void pt_fill_kernel(const uint32_t* __restrict__ cdf, size_t n_tables
             d[pos] = (c << 20) | ((p - 1u) << 8) | (uint32_t)i;
         }
         const uint32_t c_end = row[j];                        // quantiles [c, c_end) belong to this entry
-        while (k < (uint32_t)kPtBuckets && (k << shift) < c_end) b[k++] = (uint8_t)(pos >> 1);
+        while (k < (uint32_t)kPtBuckets && (k << shift) < c_end) b[k++] = (uint8_t)(pos >> 2);
         ++pos;
         i = j;
     }
-    for (uint32_t j = pos; j < ((pos + kPtRowPad + 1u) & ~1u); ++j) d[j] = 0xffffffffu;   // kPtRowPad or one more sentinel: even row length
+    for (uint32_t j = pos; j < ((pos + kPtRowPad + 3u) & ~3u); ++j) d[j] = 0xffffffffu;   // kPtRowPad sentinels or up to three more: whole quads
 }
 
 // Builds the compact image of a per-stream model (8 <= P <= 12, n <= 256).  Failure to allocate only leaves pt_ok

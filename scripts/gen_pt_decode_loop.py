@@ -3,10 +3,11 @@
 with ONE TABLE PER STREAM in its compact form (cst_ans_pt.hip, BASELINE config C3), (W,S,P) = (32,64,12).
 
 One asm statement decodes all full 32-symbol tiles of a wave's 64 streams.  Per symbol the serial chain is
-    q -> bucket index (ds_read_u8) -> six packed entries (ds_read2_b64 + ds_read_b64 from the 8-byte aligned pair that
-         holds the first candidate: a misaligned LDS read costs 5x, scripts/microbench/lds_tput.hip)
-      -> last of the first five entries <= q << 20 | 0xffffe   [the sixth decides whether the lane must look further:
-         0.2 extra rounds per wave step on the C3 tables, a wave-uniform loop that is branched around]
+    q -> bucket index (ds_read_u8) -> EIGHT packed entries (two ds_read_b128 from the 16-byte aligned quad that holds the first
+         candidate: a misaligned LDS read costs 5x, and a read with random lane addresses ~13 LDS cycles whatever its width --
+         scripts/microbench/lds_tput.hip; until round 6: six entries by ds_read2_b64 + ds_read_b64, 37 cycles against 23)
+      -> the entry of the smallest wrapping distance (q << 20 | 0xffffe) - entry among the first seven   [the eighth decides whether
+         the lane must look further: a wave-uniform loop that is branched around]
       -> (c, p, index) -> N = (state >> P) * p + (q - c) -> refill? -> state' -> q'
 i.e. two dependent LDS round trips and 24 issue slots; everything else of a step (ring read of the next candidate
 word, shifted state halves, read-position update, symbol index -> symbol) is issued in the shadow of the bucket read.
@@ -59,14 +60,15 @@ HALVES = (0, 16) if SUB16 else (0,)
 N0, N1 = "v100", "v101"            # v[100:101] = N
 DD = "v102"                        # v[102:103] = [q - c (0 for a run), 0]
 PR, T0, T1, TT, R0, WD, RA, R1, QK, RA2 = (f"v{r}" for r in range(104, 114))
-# GEN_PT_WINDOW=8 (round 4, measured and NOT adopted): EIGHT consecutive entries per look -- seven candidates + the one that
-# says "further on" -- with the answer taken as the entry of the SMALLEST wrapping distance key - entry (entries above the key
-# wrap to huge distances, the 0xffffffff sentinels behind a row to key + 1, more than any real distance): 7 subtractions + 3
-# v_min3_u32 instead of compare / select pairs, and the distance itself is (q - c) << 20 | ..., so the step's v_sub for q - c is
-# gone.  The continuation rounds of the six-entry window cost 17 % of the kernel (0.22 rounds per wave step on the C3 tables,
-# DESIGN.md 3.8), but the lanes that need them sit in the crowded tails of wide models (8 - 16 entries per bucket), where
-# seven candidates fall short as five do: 0.716 - 0.719 ms against 0.710 ms at 65 536 x 4096 (same box, alternating runs).
-WINDOW = int(os.environ.get("GEN_PT_WINDOW", "6"))
+# WINDOW = 8 (the default since round 6): EIGHT consecutive entries per look -- seven candidates + the one that says "further on" --
+# with the answer taken as the entry of the SMALLEST wrapping distance key - entry (entries above the key wrap to huge distances,
+# the 0xffffffff sentinels behind a row to key + 1, more than any real distance): 7 subtractions + 3 v_min3_u32 instead of compare /
+# select pairs, and the distance itself is (q - c) << 20 | ..., so the step's v_sub for q - c is gone.  Round 4 measured it with
+# 2 x ds_read2_b64 from the aligned PAIR and did not adopt it (0.716 against 0.710 ms on the plain kernel); with rows that start on
+# 16 bytes and the bucket index counting QUADS the eight entries are two ds_read_b128 -- 23 LDS cycles per wave instead of the 37
+# of ds_read2_b64 + ds_read_b64 -- and the LDS-bound sub-lane decoder gains 15 % (C3: 0.410 -> 0.349 ms; plain kernel 0.713 -> 0.637).
+# GEN_PT_WINDOW=6: the six-entry form of rounds 2 - 5 (needs the pair-aligned rows of those rounds: kept for the record).
+WINDOW = int(os.environ.get("GEN_PT_WINDOW", "8"))
 X = ["v116", "v117", "v118", "v119", "v126", "v127"] if WINDOW == 6 else ["v116", "v117", "v118", "v119", "v172", "v173", "v174", "v175"]
 X_T, X45_T = "v[116:119]", ("v[126:127]" if WINDOW == 6 else "v[172:175]")
 DM, DM2 = "v176", "v177"
@@ -120,10 +122,10 @@ def step(a, j):
         a.wait_lds("l1", f"---- step {j}: first candidate is back")
     else:
         a.i(f"; ---- step {j}: (the landing's wait covered the bucket read)")
-    a.i(f"v_lshl_add_u32 {RA2}, {R0}, 3, %[rowaddr]")
+    a.i(f"v_lshl_add_u32 {RA2}, {R0}, {4 if WINDOW == 8 else 3}, %[rowaddr]")
     if WINDOW == 8:
-        a.ds(f"ds_read2_b64 {X_T}, {RA2} offset1:1", "x", "eight consecutive entries from the aligned pair that holds the first candidate")
-        a.ds(f"ds_read2_b64 {X45_T}, {RA2} offset0:2 offset1:3", "x")
+        a.ds(f"ds_read_b128 {X_T}, {RA2}", "x", "eight consecutive entries from the 16-byte aligned quad that holds the first candidate")
+        a.ds(f"ds_read_b128 {X45_T}, {RA2} offset:16", "x")
         if pos == 0 and j > 0:
             base = ((quad - 1) % 2) * 4
             if SUB:
@@ -141,10 +143,10 @@ def step(a, j):
         a.i("s_branch 4f" if os.environ.get("GEN_NO_MORE") else "s_cbranch_scc0 4f")      # (GEN_NO_MORE: timing experiment only)
         # wave-uniform continuation for the lanes in MORE (the others re-read their eight entries and keep their distance)
         a.i("3:")
-        a.i(f"v_cndmask_b32_e64 {TS}, 0, 24, {MORE}")
-        a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the seventh entry (8-byte aligned)")
-        a.i(f"ds_read2_b64 {X_T}, {RA2} offset1:1")
-        a.i(f"ds_read2_b64 {X45_T}, {RA2} offset0:2 offset1:3")
+        a.i(f"v_cndmask_b32_e64 {TS}, 0, 16, {MORE}")
+        a.i(f"v_add_u32 {RA2}, {RA2}, {TS}", "continue from the fifth entry (the next quad)")
+        a.i(f"ds_read_b128 {X_T}, {RA2}")
+        a.i(f"ds_read_b128 {X45_T}, {RA2} offset:16")
         a.i("s_waitcnt lgkmcnt(0)")
         a.i(f"v_cmp_le_u32_e64 {M2}, {X[7]}, {QK}")
         for i in range(7):

@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void k(uint32_t* sink, int iters, uint32_t see
             else if (KIND == 3) { uint64_t v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a)); acc ^= (uint32_t)v; }
             else if (KIND == 4 || KIND == 5) { __uint128_t v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); acc ^= (uint32_t)v; }
             else if (KIND == 6) { asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(h)); }
+            else if (KIND == 8) { __uint128_t v; asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(v) : "v"(a | 8)); acc ^= (uint32_t)v; }
+            else if (KIND == 9) { __uint128_t v; uint64_t w; asm volatile("ds_read2_b64 %0, %2 offset1:1\n\tds_read_b64 %1, %2 offset:16" : "=&v"(v), "=&v"(w) : "v"(a | 8)); acc ^= (uint32_t)v ^ (uint32_t)w; }
+            else if (KIND == 10) { __uint128_t v, w; asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(v), "=&v"(w) : "v"(a)); acc ^= (uint32_t)v ^ (uint32_t)w; }
             else if (KIND == 7) { uint32_t v; asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(a | (h & 3))); acc ^= v; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -60,5 +63,8 @@ int main() {
     run<4>("ds_read_b128 16-byte aligned, random");
     run<5>("ds_read_b128 4-byte aligned, random");
     run<6>("ds_write_b32, random");
+    run<8>("ds_read2_b64 adjacent, 8-byte aligned (16 B at 8 mod 16)");
+    run<9>("ds_read2_b64 + ds_read_b64: 24 B at 8 mod 16 (two instructions)");
+    run<10>("2 x ds_read_b128: 32 B 16-byte aligned (two instructions)");
     return 0;
 }
