@@ -5,7 +5,7 @@ int32 / int8 matrices, per-symbol Gaussians on both coders, ragged batches -- on
 streams than the chip has lanes), data (model-distributed, uniform, rarest symbols only) and impossible symbols.  Checked per case:
 the default call's words / counts / status = the jump_points=0 call's = the CPU oracle's (a sample of streams), its jump table = the
 oracle's Pos at those symbols, decode through the table = decode without = the input.  Not part of the suite: minutes of GPU time.
-usage: python tests/stress/stress_auto.py [seconds] [seed]"""
+usage: python tests/stress/stress_auto.py [seconds] [seed] [family: ans | range | per_stream | gaussian | ragged]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -217,6 +217,8 @@ def ragged_case():
 while time.time() < t_end:
     r = rng.random()
     fam = "ans" if r < 0.35 else "range" if r < 0.6 else "per_stream" if r < 0.75 else "gaussian" if r < 0.85 else "ragged"
+    if len(sys.argv) > 3:
+        fam = sys.argv[3]
     n, jumped = {"ans": lambda: table_case("ans"), "range": lambda: table_case("range"), "per_stream": per_stream_case,
                  "gaussian": gaussian_case, "ragged": ragged_case}[fam]()
     count[fam] += 1
