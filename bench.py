@@ -312,6 +312,36 @@ def run_config(B, name, coder, cfg, model, symbols, reps, check, cdf_host=None, 
             plain_ok = bool(torch.equal(plain_dec, symbols)) and bool(torch.equal(plain.n_words, enc.n_words)) and \
                 bool(((plain.words == enc.words) | ~used).all())
         del plain, plain_dec
+    if coder == "ans" and (packed16 or layout != "stream_major"):
+        # Pos / Seek on the two batch forms whose fast encoders do not note jump points on their way (round 6): the table comes from the
+        # generic checkpointing encoder (one lane per stream; for packed words: run beside the packed encoder), decode = the plain
+        # batched decoder on the chunks as streams of their own.  Asked for explicitly -- "auto" takes none here; the words are the same
+        try:
+            ej = enc_fn(symbols, model, cfg, jump_points=2, **({"packed16": True} if packed16 else kw))
+            jdec = torch.empty_like(symbols)
+            je = event_ms(lambda: enc_fn(symbols, model, cfg, out=ej, jump_points=2, **kw), max(2, reps // 4))
+            jek = B.last_kernel()
+            jd = event_ms(lambda: dec_fn(ej, model, n_per, out=jdec, **kw), reps)
+            sub = {"encode_ms": round(je, 4), "decode_ms": round(jd, 4), "encode_kernel": jek, "decode_kernel": B.last_kernel(),
+                   "what": "explicit jump_points=2 (random access, stack.rs:1107-1139): the jump table from the generic checkpointing encoder"
+                           + (" run beside the packed encoder" if packed16 else "") + ", decode = the plain batched decoder on the chunks with raw states"}
+            if check:
+                used = torch.arange(min(ej.words.shape[1], enc.words.shape[1]), device=symbols.device)[None, :] < ej.n_words[:, None]
+                w = used.shape[1]
+                jok = bool(torch.equal(jdec, symbols)) and bool(torch.equal(ej.n_words, enc.n_words)) and bool(((ej.words[:, :w] == enc.words[:, :w]) | ~used).all())
+                if jok and cdf_host is not None:
+                    from oracle import oracle as O
+                    rows = [0, 1, n_streams // 2, n_streams - 1]
+                    hs = symbols[rows].cpu().numpy() if layout == "stream_major" else np.ascontiguousarray(symbols[:, rows].cpu().numpy().T)
+                    wp, ws = O.ans_jump_table(hs, lo, np.asarray(cdf_host, dtype=np.uint32), cfg[2], n_per // 2, W=cfg[0], S=cfg[1])
+                    jok = np.array_equal(ej.jump.pos[rows].cpu().numpy().view(np.uint32), wp) and np.array_equal(ej.jump.state[rows].cpu().numpy().view(np.uint64), ws)
+                sub["bit_exact"] = bool(jok)
+                plain_ok = plain_ok and bool(jok)
+            entry["with_2_jump_points"] = sub
+            del ej, jdec
+        except Exception as exc:      # noqa: BLE001
+            entry["with_2_jump_points"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            plain_ok = False
     if check:
         ok = plain_ok and bool(torch.equal(decoded, symbols)) and int(enc.status.abs().sum().item()) == 0
         if ok and cdf_host is not None:

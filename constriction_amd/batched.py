@@ -400,6 +400,8 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
     int32 symbols with one table of P <= 12 at 65 536 streams or more); an integer k: k points per stream (k divides the rows);
     0: none.
     stride: words per slab (default max_words), or "tuned" for the stride measured fastest for this shape (tuned_stride).
+    On packed 16-bit words and symbol-major matrices "auto" notes none; an explicit k does (the generic checkpointing encoder supplies the
+    table -- slower -- and ans_decode decodes the chunks through the plain decoder with raw states: random access, not speed).
     packed16 (the (16,32) preset only): the words two per 32-bit slot, as the reference's Vec<u16> (CST_FLAG_PACKED_W16) -- the
     batch's `words` is then an int16 tensor; ans_decode and compact recognise it.
     out: an EncodedBatch of an earlier call with the same shapes, to code into the same buffers (its jump table is reused,
@@ -422,11 +424,23 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
     n_streams, n_per, lay = _layout_shape(symbols, layout)
     if out is None:
         out = _new_batch(n_streams, stride or max_words(n_per, config), symbols.device, config, packed16)
-    if out.packed16 and not (isinstance(jump_points, str) or not jump_points):
-        raise ValueError("jump_points: unpacked words only")
     L = N.lib()
-    interval = 0 if out.packed16 else _jump_interval(jump_points, n_per, lambda: L.cst_jump_points_auto(
+    # (packed 16-bit words: "auto" notes none -- the packed decoder's LDS image leaves one workgroup per CU, more lanes would only
+    #  queue; an explicit k is honoured for what the reference's Pos / Seek is FOR, random access, see below)
+    interval = _jump_interval(0 if out.packed16 and isinstance(jump_points, str) else jump_points, n_per, lambda: L.cst_jump_points_auto(
         model._h, _cfg(*config), N.CODER_ANS, narrow, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
+    packed_jump = None
+    if interval and out.packed16:
+        # AnsCoder::pos() does not depend on how the words are stored (stack.rs:1107-1139: words in the bulk + state).  No packed
+        # encoder notes the points on its way yet: the WORDS come from the packed encoder below, the TABLE from the checkpointing
+        # encoder of the unpacked preset run beside it into a scratch slab (same recurrence, same counts: a count of 16-bit words)
+        if narrow != 4:
+            raise ValueError("packed16 with jump points: int32 symbols")
+        tmp = _new_batch(n_streams, max_words(n_per, config), symbols.device, config, False)
+        packed_jump = _jump_table(out, Checkpoints, interval, n_streams, n_per, symbols.device)
+        ans_encode_checkpointed(given, model, interval, config, layout, out=(tmp, packed_jump))
+        del tmp
+        interval = 0
     if interval:
         ck = _jump_table(out, Checkpoints, interval, n_streams, n_per, symbols.device)
         ans_encode_checkpointed(given, model, interval, config, layout, out=(out, ck))
@@ -444,6 +458,7 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         N.check(L.cst_ans_encode_batch(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, lay, _ptr(out.words),
                                        out.words.shape[1], _ptr(out.n_words), None, _ptr(out.status), flags,
                                        _stream_ptr()), "cst_ans_encode_batch")
+    out.jump = packed_jump
     _stamp_fresh(out)
     return out
 
@@ -489,11 +504,12 @@ def ans_decode(encoded, model: Model, n_per_stream: int, layout="stream_major", 
     if `encoded` is the EncodedBatch that the last ans_encode on this HIP stream filled (and small enough to have stayed in the
     caches); words that came from the host, a peer or a file -- plain tensors, packed + offsets -- are cold."""
     jump = encoded.jump if isinstance(encoded, EncodedBatch) else None
-    if isinstance(jump, Checkpoints) and offsets is None and layout == "stream_major" and not encoded.packed16 and \
+    if isinstance(jump, Checkpoints) and offsets is None and \
             n_per_stream == jump.interval * jump.pos.shape[1] and jump.pos.shape[0] == encoded.n_words.numel():
         # the batch carries jump points for exactly this decode (ans_encode, jump_points): every part of a stream on a lane of its
         # own.  (A prefix of the streams, n_per_stream < what was encoded, is a plain decode: the table's rows have another stride.)
-        dec, part_status = ans_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype if out is None else out.dtype)
+        dec, part_status = ans_decode_checkpointed(encoded, jump, model, n_per_stream, out=out, dtype=dtype if out is None else out.dtype,
+                                                   layout=layout)
         return dec, _status_per_stream(part_status)
     if isinstance(encoded, EncodedBatch):
         words, n_words, config = encoded.words, encoded.n_words, config or encoded.config
@@ -1161,8 +1177,44 @@ def _check_jump_shape(checkpoints, n_per_stream: int) -> None:
             raise ValueError("jump points: tensors of different shapes")
 
 
+def _decode_jump_composed(encoded: EncodedBatch, ck: Checkpoints, model: Model, n_per_stream: int, out, status, layout: str):
+    """AnsCoder.seek + decode of every chunk for the two batch forms cst_ans_decode_batch_ckpt does not take, composed of the plain
+    batched decode (raw states, counts = the jump points' word counts):
+      packed 16-bit words (stream-major): the n_streams * k chunks are streams of their own at their stream's slab (offsets in
+        16-bit words) and rows of the matrix [n_streams * k][interval] -- ONE launch;
+      symbol-major: chunk j of all streams is the symbol-major matrix [interval][n_streams] behind row j * interval -- k launches.
+    A jump point with more words than its stream holds is caller data gone wrong: CST_STREAM_INVALID_DATA, nothing is read."""
+    n_streams, k = ck.pos.shape
+    interval = ck.interval
+    dev = encoded.words.device
+    L = N.lib()
+    words = encoded.words
+    stride = words.shape[1]
+    flags = N.FLAG_RAW_STATE | (N.FLAG_PACKED_W16 if encoded.packed16 else N.FLAG_NONE)
+    bad = (ck.pos.view(torch.int32) < 0) | (ck.pos > encoded.n_words.view(-1, 1)) | (ck.pos > stride)
+    pos = torch.where(bad, torch.zeros_like(ck.pos), ck.pos)
+    if layout == "stream_major":
+        v_off = (torch.arange(n_streams, device=dev, dtype=torch.int64) * stride).view(-1, 1).expand(n_streams, k).contiguous()
+        v_n, v_state = pos.contiguous().view(-1), ck.state.clone().view(-1)     # (CST_FLAG_RAW_STATE: the state array is in AND out)
+        part = torch.empty(n_streams * k, dtype=torch.int32, device=dev)
+        N.check(L.cst_ans_decode_batch(model._h, _cfg(*encoded.config), _ptr(words), _ptr(v_off), 0, words.numel(), _ptr(v_n), _ptr(out),
+                                       n_streams * k, interval, N.LAYOUT_STREAM_MAJOR, _ptr(v_state), None, _ptr(part), flags, _stream_ptr()),
+                "cst_ans_decode_batch")
+        status.copy_(part.view(n_streams, k))
+    else:
+        part = torch.empty(n_streams, dtype=torch.int32, device=dev)
+        for j in range(k):
+            n_j, st_j = pos[:, j].contiguous(), ck.state[:, j].clone()
+            N.check(L.cst_ans_decode_batch(model._h, _cfg(*encoded.config), _ptr(words), None, stride, words.numel(), _ptr(n_j),
+                                           _ptr(out[j * interval:(j + 1) * interval]), n_streams, interval, N.LAYOUT_SYMBOL_MAJOR, _ptr(st_j), None,
+                                           _ptr(part), flags, _stream_ptr()), "cst_ans_decode_batch")
+            status[:, j] = part
+    status.masked_fill_(bad, N.STREAM_INVALID_DATA)
+    return _to_symbols(model, out), status
+
+
 def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_per_stream: int, out=None, status=None,
-                            dtype=torch.int32, offsets: Optional[torch.Tensor] = None, config=None):
+                            dtype=torch.int32, offsets: Optional[torch.Tensor] = None, config=None, layout="stream_major"):
     """Decodes every chunk on its own lane (AnsCoder.seek(pos, state) + `interval` symbols per chunk).
     Returns (symbols [n_streams, n_per_stream], status [n_streams, n_chunks]).  dtype (or the dtype of `out`): int32, or int16 / int8 for
     a narrow symbol matrix (cst_ans_decode_batch_ckpt_sym: int8 chunks of whole 128-symbol lines are written by the decoder loops).
@@ -1178,14 +1230,20 @@ def ans_decode_checkpointed(encoded, checkpoints: Checkpoints, model: Model, n_p
     dev = encoded.words.device
     n_chunks = checkpoints.pos.shape[1]
     _check_jump_shape(checkpoints, n_per_stream)
+    if layout not in ("stream_major", "symbol_major"):
+        raise ValueError("layout")
     if out is None:
-        out = torch.empty((n_streams, n_per_stream), dtype=dtype, device=dev)
+        out = torch.empty((n_streams, n_per_stream) if layout == "stream_major" else (n_per_stream, n_streams), dtype=dtype, device=dev)
     if status is None:
         status = torch.empty((n_streams, n_chunks), dtype=torch.int32, device=dev)
     L = N.lib()
     narrow = _SYMBOL_BYTES.get(out.dtype)
     if narrow is None:
         raise TypeError("decoded symbols are int32, int16 or int8")
+    if encoded.packed16 or layout == "symbol_major":
+        if offsets is not None or narrow != 4:
+            raise ValueError("jump points of packed 16-bit or symbol-major batches: slabs and int32 symbols")
+        return _decode_jump_composed(encoded, checkpoints, model, n_per_stream, out, status, layout)
     if narrow != 4:
         if model.noncontiguous:
             raise ValueError("narrow symbol matrices: contiguous alphabets only")

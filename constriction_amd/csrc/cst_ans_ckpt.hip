@@ -178,7 +178,7 @@ cst_status cst_ans_encode_batch_ckpt(const cst_model* model, cst_coder_config cf
         hipLaunchKernelGGL((ans_encode_ckpt_kernel<16, 32>), dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
     }
     CST_HIP_TRY(hipGetLastError());
-    return CST_OK;
+    return note_kernel("ans_encode_ckpt_kernel", CST_OK);
 }
 
 size_t cst_ckpt_scratch_bytes(size_t n_streams, size_t n_per_stream, size_t ckpt_interval) {

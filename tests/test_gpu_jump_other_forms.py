@@ -1,0 +1,104 @@
+"""Jump points (the reference's Pos / Seek, src/stream/stack.rs:1107-1139) on the two batch forms the checkpointing kernels do not
+take themselves: the (16,32) preset with PACKED words (the reference's Vec<u16>) and SYMBOL-MAJOR symbol matrices.  AnsCoder::pos()
+is (words in the bulk, state) whatever the word type or the matrix layout: the table is the oracle's, the words are those of the
+plain call, and decoding from the jump points (batched.ans_decode / ans_decode_checkpointed: the plain batched decoder on the
+chunks as streams of their own, raw states) gives the input back -- chunk by chunk, too, which is what Seek is for."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def B():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from constriction_amd import batched
+    return batched
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _model(B, O, P, W):
+    lo, hi = -50, 50
+    cdf = O.GaussianModel(lo, hi, 3.2, 9.6, P, 32 if W == 32 else 16).cdf_table()
+    return B.Model.from_cdf(cdf, lo, P), cdf, lo
+
+
+@pytest.mark.parametrize("k", [2, 4, 16])
+@pytest.mark.parametrize("n_streams,n_per,P", [(256, 1024, 12), (300, 2048, 12), (77, 512, 8), (1024, 4096, 12)])
+def test_packed16_jump_points(B, O, n_streams, n_per, P, k):
+    model, cdf, lo = _model(B, O, P, 16)
+    sym = O.synth_symbols(31 + k, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(sym)
+    cfg = (16, 32, P)
+    plain = B.ans_encode(d, model, cfg, packed16=True)
+    assert plain.jump is None                                   # "auto" notes none on the packed preset
+    enc = B.ans_encode(d, model, cfg, packed16=True, jump_points=k)
+    assert enc.packed16 and enc.jump is not None and enc.jump.pos.shape == (n_streams, k) and enc.jump.interval == n_per // k
+    assert torch.equal(enc.n_words, plain.n_words) and torch.equal(enc.status, plain.status)
+    used = torch.arange(enc.words.shape[1], device="cuda")[None, :] < enc.n_words[:, None]
+    assert bool(((enc.words == plain.words) | ~used).all())
+    wp, ws = O.ans_jump_table(sym, lo, cdf, P, n_per // k, W=16, S=32)
+    assert np.array_equal(enc.jump.pos.cpu().numpy().view(np.uint32), wp)
+    assert np.array_equal(enc.jump.state.cpu().numpy().view(np.uint64), ws)
+    for s in (0, n_streams - 1):                                # the words are the oracle's
+        want_words, want_n, _ = O.ans_encode_batch(sym[s: s + 1], lo, cdf, P, W=16, S=32)
+        assert enc.stream(s).tolist() == want_words[0, : want_n[0]].tolist()
+    dec, st = B.ans_decode(enc, model, n_per)                   # finds the table on the batch
+    assert st.shape == (n_streams,) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    dec, st = B.ans_decode_checkpointed(enc, enc.jump, model, n_per)
+    assert st.shape == (n_streams, k) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    dec, st = B.ans_decode(plain, model, n_per)
+    assert torch.equal(dec, d)
+
+
+def test_packed16_bad_jump_point_is_flagged(B, O):
+    model, cdf, lo = _model(B, O, 12, 16)
+    n_streams, n_per, k = 200, 1024, 4
+    d = dev(O.synth_symbols(5, 0, n_streams, n_per, lo, cdf, 12))
+    enc = B.ans_encode(d, model, (16, 32, 12), packed16=True, jump_points=k)
+    bad = B.Checkpoints(enc.jump.interval, enc.jump.pos.clone(), enc.jump.state.clone())
+    bad.pos[7, 2] = 1 << 29
+    bad.pos[9, 0] = int(enc.n_words[9]) + 1
+    dec, st = B.ans_decode_checkpointed(enc, bad, model, n_per)
+    assert int(st[7, 2]) != 0 and int(st[9, 0]) != 0 and int((st != 0).sum()) == 2
+    ok = st == 0
+    assert torch.equal(dec.view(n_streams, k, -1)[ok], d.view(n_streams, k, -1)[ok])
+
+
+@pytest.mark.parametrize("k", [2, 8])
+@pytest.mark.parametrize("n_streams,n_per,W,P", [(256, 1024, 32, 12), (320, 2048, 32, 24), (256, 512, 16, 12), (1000, 1024, 32, 12)])
+def test_symbol_major_jump_points(B, O, n_streams, n_per, W, P, k):
+    model, cdf, lo = _model(B, O, P, W)
+    cfg = (W, 2 * W, P)
+    sym = O.synth_symbols(77 + k, 0, n_streams, n_per, lo, cdf, P)
+    d = dev(np.ascontiguousarray(sym.T))                        # [n_per][n_streams]
+    plain = B.ans_encode(d, model, cfg, layout="symbol_major")
+    assert plain.jump is None
+    enc = B.ans_encode(d, model, cfg, layout="symbol_major", jump_points=k)
+    assert enc.jump is not None and enc.jump.pos.shape == (n_streams, k)
+    assert torch.equal(enc.n_words, plain.n_words)
+    used = torch.arange(enc.words.shape[1], device="cuda")[None, :] < enc.n_words[:, None]
+    assert bool(((enc.words == plain.words) | ~used).all())
+    wp, ws = O.ans_jump_table(sym, lo, cdf, P, n_per // k, W=W, S=2 * W)
+    assert np.array_equal(enc.jump.pos.cpu().numpy().view(np.uint32), wp)
+    assert np.array_equal(enc.jump.state.cpu().numpy().view(np.uint64), ws)
+    dec, st = B.ans_decode(enc, model, n_per, layout="symbol_major")
+    assert dec.shape == (n_per, n_streams) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    dec, st = B.ans_decode_checkpointed(enc, enc.jump, model, n_per, layout="symbol_major")
+    assert st.shape == (n_streams, k) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
+    # Seek: ONE chunk of all streams, from its jump point alone (the plain decoder with raw states on the chunk's rows)
+    j, K = k - 1, n_per // k
+    one = B.Checkpoints(K, enc.jump.pos[:, j: j + 1].contiguous(), enc.jump.state[:, j: j + 1].contiguous())
+    part, st = B.ans_decode_checkpointed(enc, one, model, K, layout="symbol_major")
+    assert int(st.abs().sum()) == 0 and torch.equal(part, d[j * K:(j + 1) * K])
