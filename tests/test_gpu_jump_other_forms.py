@@ -102,3 +102,45 @@ def test_symbol_major_jump_points(B, O, n_streams, n_per, W, P, k):
     one = B.Checkpoints(K, enc.jump.pos[:, j: j + 1].contiguous(), enc.jump.state[:, j: j + 1].contiguous())
     part, st = B.ans_decode_checkpointed(enc, one, model, K, layout="symbol_major")
     assert int(st.abs().sum()) == 0 and torch.equal(part, d[j * K:(j + 1) * K])
+
+
+def test_decoding_never_changes_a_jump_table(B, O):
+    """CST_FLAG_RAW_STATE makes the decoders' state array in AND out: every path that decodes from jump points must hand them a copy.
+    Decode every family twice from the same batch; the table is what it was."""
+    lo, P, n, N = -50, 12, 512, 2048
+    cdf = O.GaussianModel(lo, 50, 3.2, 9.6, P, 32).cdf_table()
+    model = B.Model.from_cdf(cdf, lo, P)
+    cdf16 = O.GaussianModel(lo, 50, 3.2, 9.6, P, 16).cdf_table()
+    model16 = B.Model.from_cdf(cdf16, lo, P)
+    d = dev(O.synth_symbols(3, 0, n, N, lo, cdf, P))
+    d16 = dev(O.synth_symbols(3, 0, n, N, lo, cdf16, P))
+
+    def twice(enc, decode, want):
+        assert enc.jump is not None
+        before = {k: v.clone() for k, v in vars(enc.jump).items() if isinstance(v, torch.Tensor)}
+        a, _ = decode(enc)
+        b, _ = decode(enc)
+        assert torch.equal(a, want) and torch.equal(b, want)
+        assert all(torch.equal(v, getattr(enc.jump, k)) for k, v in before.items())
+
+    for dt in (torch.int32, torch.int8):
+        x = d.to(dt)
+        twice(B.ans_encode(x, model, (32, 64, P)), lambda e: B.ans_decode(e, model, N, dtype=dt), x)
+        twice(B.range_encode(x, model, (32, 64, P)), lambda e: B.range_decode(e, model, N, dtype=dt), x)
+    twice(B.ans_encode(d16, model16, (16, 32, P), jump_points=2), lambda e: B.ans_decode(e, model16, N), d16)
+    twice(B.ans_encode(d16, model16, (16, 32, P), packed16=True, jump_points=4), lambda e: B.ans_decode(e, model16, N), d16)
+    dt_ = d.t().contiguous()
+    twice(B.ans_encode(dt_, model, (32, 64, P), layout="symbol_major", jump_points=2), lambda e: B.ans_decode(e, model, N, layout="symbol_major"), dt_)
+    rng = np.random.default_rng(1)
+    mu, sd = rng.uniform(-10, 10, n), np.exp(rng.uniform(np.log(0.5), np.log(16.0), n))
+    pt = B.Model.quantized_gaussian_per_stream(-127, 127, dev(mu), dev(sd), 12)
+    u = torch.randint(0, 4096, (n, N), device="cuda")
+    sp = (torch.searchsorted(pt.cdfs_device().to(torch.int64), u, right=True) - 1 - 127).to(torch.int32)
+    twice(B.ans_encode(sp, pt, (32, 64, 12)), lambda e: B.ans_decode(e, pt, N), sp)
+    ns, ng = 16384, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mu = (torch.rand((ns, ng), generator=g, device="cuda", dtype=torch.float64) - 0.5) * 60
+    sg = torch.exp(torch.rand((ns, ng), generator=g, device="cuda", dtype=torch.float64) * 4 - 1)
+    sy = torch.clamp(torch.round(mu + sg * torch.randn((ns, ng), generator=g, device="cuda", dtype=torch.float64)), -100, 100).to(torch.int32)
+    twice(B.ans_encode_gaussian(sy, -100, 100, mu, sg), lambda e: B.ans_decode_gaussian(e, -100, 100, mu, sg), sy)
+    twice(B.range_encode_gaussian(sy, -100, 100, mu, sg), lambda e: B.range_decode_gaussian(e, -100, 100, mu, sg), sy)
