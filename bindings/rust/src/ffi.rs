@@ -836,6 +836,31 @@ extern "C" {
         stream: *mut c_void,
     ) -> CstStatus;
 
+    /// cst_ans_encode_batch with CST_FLAG_PACKED_W16 + a jump point in front of every ckpt_interval symbols (ABI 5, round 6):
+    /// `AnsCoder::pos()` (src/stream/stack.rs:1107-1139) of the (16,32) preset whose words lie as the reference holds them, a
+    /// Vec<u16> -- d_ckpt_pos[s * n_chunks + j] = 16-bit words in the bulk in front of chunk j, d_ckpt_state[...] = the coder state
+    /// there (its low 32 bits; n_chunks = n_per_stream / ckpt_interval).  The packed encoder notes them on its way at the plain call's
+    /// speed; the words are the plain call's.  Stream-major, shared table, 8 <= P <= 12, chunks of whole 32-symbol tiles that divide
+    /// the rows -- other shapes: CST_ERR_INVALID_ARGUMENT (note the points with cst_ans_encode_batch_ckpt into a scratch slab
+    /// instead).  Decode from the points: cst_ans_decode_batch on the n_streams * n_chunks chunks as streams of their own --
+    /// d_offsets[v] = s * stride_words (16-bit words), d_n_words[v] = pos, d_state = A COPY of the states (CST_FLAG_RAW_STATE makes
+    /// that array in AND out), flags CST_FLAG_RAW_STATE | CST_FLAG_PACKED_W16; symbols as the matrix [n_streams * n_chunks][interval].
+    pub fn cst_ans_encode_batch_ckpt_packed16(
+        model: *const CstModel,
+        cfg: CstCoderConfig,
+        d_symbols: *const i32,
+        n_streams: usize,
+        n_per_stream: usize,
+        d_words16: *mut u16,
+        stride_words: usize,
+        d_n_words: *mut u32,
+        ckpt_interval: usize,
+        d_ckpt_pos: *mut u32,
+        d_ckpt_state: *mut u64,
+        d_status: *mut i32,
+        stream: *mut c_void,
+    ) -> CstStatus;
+
     /// Every stream's words in REVERSED order: out[s][i] = in[s][n_words[s] - 1 - i].  The reference reads an ANS stream from
     /// its END (a stack); `AnsCoder::from_reversed_compressed` (src/stream/stack.rs:734-748) and `Cursor::into_reversed`
     /// (src/backends.rs:1424-1448; docs :774-803) are its coders over words stored last-written-first, the order in which a decoder

@@ -613,6 +613,54 @@ impl BatchedAnsCoder {
         Ok(out)
     }
 
+    /// `encode_iid_symbols_reverse_packed16` + `AnsCoder::pos()` (`Pos`, src/stream/stack.rs:1107-1139) in front of every chunk of
+    /// `interval` symbols: positions count 16-bit words, the words are those of the plain call (chunks of whole 32-symbol tiles that
+    /// divide the rows).  Decode from the points = `cst_ans_decode_batch` on the chunks as streams of their own with raw states
+    /// (hand it a COPY of the states).
+    pub fn encode_iid_symbols_reverse_packed16_with_checkpoints(
+        &self,
+        symbols: &DeviceBuffer<i32>,
+        n_streams: usize,
+        n_per_stream: usize,
+        interval: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<(EncodedBatch16, Checkpoints)> {
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        if symbols.len() < count || self.config.word_bits != 16 || interval == 0 || n_per_stream % interval != 0 {
+            return Err(Error::InvalidArgument);
+        }
+        let n_points = n_streams.checked_mul(n_per_stream / interval).ok_or(Error::InvalidArgument)?;
+        let stride = self.max_words(n_per_stream);
+        let mut out = EncodedBatch16 {
+            words: DeviceBuffer::new(n_streams.checked_mul(stride).ok_or(Error::InvalidArgument)?)?,
+            n_words: DeviceBuffer::new(n_streams)?,
+            status: DeviceBuffer::new(n_streams)?,
+            n_streams,
+            stride_words: stride,
+            config: self.config,
+        };
+        let mut ckpt = Checkpoints { pos: DeviceBuffer::new(n_points)?, state: DeviceBuffer::new(n_points)?, interval };
+        check(unsafe {
+            ffi::cst_ans_encode_batch_ckpt_packed16(
+                model.as_raw(),
+                self.config,
+                symbols.as_ptr(),
+                n_streams,
+                n_per_stream,
+                out.words.as_mut_ptr(),
+                stride,
+                out.n_words.as_mut_ptr(),
+                interval,
+                ckpt.pos.as_mut_ptr(),
+                ckpt.state.as_mut_ptr(),
+                out.status.as_mut_ptr(),
+                stream.as_raw(),
+            )
+        })?;
+        Ok((out, ckpt))
+    }
+
     /// The decoder of `encode_iid_symbols_reverse_packed16`.
     pub fn decode_iid_symbols_packed16(&self, encoded: &EncodedBatch16, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;

@@ -87,6 +87,7 @@ SIGNATURES = {
     "cst_ckpt_sym_scratch_bytes": (_z, [_z, _z, _z, _i32]),
     "cst_ans_decode_batch_ckpt_sym": (_i32, [_vp, CoderConfig, _vp, _vp, _z, _z, _z, _vp, _vp, _vp, _i32, _z, _z, _vp, _vp, _vp]),
     "cst_compact_words16": (_i32, [_vp, _z, _vp, _z, _vp, _vp, _z, _vp, _vp]),
+    "cst_ans_encode_batch_ckpt_packed16": (_i32, [_vp, CoderConfig, _vp, _z, _z, _vp, _z, _vp, _z, _vp, _vp, _vp, _vp]),
     "cst_symbols_widen": (_i32, [_vp, _i32, _z, _vp, _vp]),
     "cst_symbols_narrow": (_i32, [_vp, _z, _vp, _i32, _vp]),
     "cst_symbols_scratch_bytes": (_z, [_z, _z, _i32]),

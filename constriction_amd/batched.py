@@ -431,13 +431,21 @@ def ans_encode(symbols: torch.Tensor, model: Model, config=(32, 64, 12), layout=
         model._h, _cfg(*config), N.CODER_ANS, narrow, _ptr(symbols), n_streams, n_per, lay, _ptr(out.words), out.words.shape[1]))
     packed_jump = None
     if interval and out.packed16:
-        # AnsCoder::pos() does not depend on how the words are stored (stack.rs:1107-1139: words in the bulk + state).  No packed
-        # encoder notes the points on its way yet: the WORDS come from the packed encoder below, the TABLE from the checkpointing
-        # encoder of the unpacked preset run beside it into a scratch slab (same recurrence, same counts: a count of 16-bit words)
+        # AnsCoder::pos() does not depend on how the words are stored (stack.rs:1107-1139: words in the bulk + state).  Chunks of whole
+        # tiles: the packed encoder notes them itself.  Other intervals: the WORDS come from the packed encoder below, the TABLE from
+        # the checkpointing encoder of the unpacked preset run beside it into a scratch slab (same recurrence, same counts)
         if narrow != 4:
             raise ValueError("packed16 with jump points: int32 symbols")
-        tmp = _new_batch(n_streams, max_words(n_per, config), symbols.device, config, False)
         packed_jump = _jump_table(out, Checkpoints, interval, n_streams, n_per, symbols.device)
+        if interval % 32 == 0 and layout == "stream_major" and 8 <= config[2] <= 12 and not model.noncontiguous:
+            # chunks of whole tiles: the packed encoder notes the points on its way (cst_ans_encode_batch_ckpt_packed16)
+            N.check(L.cst_ans_encode_batch_ckpt_packed16(model._h, _cfg(*config), _ptr(symbols), n_streams, n_per, _ptr(out.words), out.words.shape[1],
+                                                         _ptr(out.n_words), interval, _ptr(packed_jump.pos), _ptr(packed_jump.state), _ptr(out.status),
+                                                         _stream_ptr()), "cst_ans_encode_batch_ckpt_packed16")
+            out.jump = packed_jump
+            _stamp_fresh(out)
+            return out
+        tmp = _new_batch(n_streams, max_words(n_per, config), symbols.device, config, False)
         ans_encode_checkpointed(given, model, interval, config, layout, out=(tmp, packed_jump))
         del tmp
         interval = 0

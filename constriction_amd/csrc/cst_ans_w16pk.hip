@@ -25,6 +25,17 @@ __device__ __forceinline__ void ans_encode_w16pk_tiles_loop(uint32_t& st, uint32
 #include "cst_encode_loop_w16_pk.inc"
 }
 
+// ... the same with jump points (GEN_W16_CK=1 of the generator, round 6): every ck_tiles tiles the lanes store (wr, state) at element
+// ck_index of the two jump arrays and step to the chunk in front
+__device__ __forceinline__ void ans_encode_w16pk_tiles_loop_ck(uint32_t& st, uint32_t& wr, uint32_t& flushed, int32_t& smin, int32_t& smax, uint32_t& ck_index,
+                                                               const uint32_t (&tile_row_addr)[2], const uint32_t (&tile_tr_addr)[2],
+                                                               uint32_t ring_lane_addr, uint32_t cap, uint32_t slab_off, uint32_t table_addr_biased,
+                                                               uint32_t P, const void* words_base, uint64_t symbols_base, uint32_t n_tiles,
+                                                               const void* ck_pos_base, const void* ck_state_base, uint32_t ck_tiles,
+                                                               const uint32_t (&goff)[8]) {
+#include "cst_encode_loop_w16_pk_ck.inc"
+}
+
 __device__ __forceinline__ void ans_decode_w16pk_tiles_loop(uint32_t& st, uint32_t& rd, uint32_t& lo_issued, uint32_t& row_cur, uint32_t& row_prev,
                                                             uint32_t& tr_cur, uint32_t& tr_prev, uint32_t lut_addr, uint32_t mask, uint32_t P,
                                                             uint32_t ring_mask, const void* words_base, uint64_t store_base,
@@ -44,8 +55,13 @@ __device__ __forceinline__ void ans_decode_w16pk_tiles_loop(uint32_t& st, uint32
 constexpr size_t kPkEncRingBytes = (size_t)(kBlock / kWave) * kRingWords * 4;                // 64 slots x 64 lanes x 4 B per wave
 constexpr size_t kPkEncTileBytes = (size_t)(kBlock / kWave) * kWave * kTileStride * 4;
 
+// jump points (Pos, stack.rs:1107-1139): [n_streams][n_chunks] (16-bit words in the bulk, state) in front of every chunk of `interval`
+// symbols; n_per_stream = interval * n_chunks, interval a multiple of the tile (the launcher checks)
+struct PkJumpArgs { uint32_t* pos; uint64_t* state; uint32_t interval, n_chunks; };
+
 // LDS layout: [word rings, 16 KiB per wave][table][symbol tiles A][symbol tiles B]
-__global__ __launch_bounds__(kBlock) void ans_encode_w16pk_kernel(const AnsEncodeArgs a) {
+template <bool CK>
+__global__ __launch_bounds__(kBlock) void ans_encode_w16pk_kernel(const AnsEncodeArgs a, const PkJumpArgs jp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = threadIdx.x >> 6;
@@ -94,6 +110,13 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16pk_kernel(const AnsEncod
         const uint32_t tr_addr[2] = {lds_addr(tile) + tr_off, lds_addr(tile_b) + tr_off};
         int32_t smin = a.min_symbol, smax = a.min_symbol;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the statement keeps its own book from here
+        if constexpr (CK) {
+            uint32_t ck_index = (uint32_t)(se * jp.n_chunks + jp.n_chunks - 1);       // the last chunk's point is noted first
+            ans_encode_w16pk_tiles_loop_ck(st, wr, flushed, smin, smax, ck_index, row_addr, tr_addr, lds_addr(ring + lane), cap, (uint32_t)slab_off,
+                                           lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), jp.pos, jp.state,
+                                           (uint32_t)__builtin_amdgcn_readfirstlane(jp.interval / (uint32_t)kTileSyms), goff);
+        } else
         ans_encode_w16pk_tiles_loop(st, wr, flushed, smin, smax, row_addr, tr_addr, lds_addr(ring + lane), cap, (uint32_t)slab_off,
                                     lds_addr(table) - 16u * (uint32_t)a.min_symbol, (uint32_t)P, a.words, symbols_base,
                                     (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)n_full), goff);
@@ -114,6 +137,9 @@ __global__ __launch_bounds__(kBlock) void ans_encode_w16pk_kernel(const AnsEncod
                 st >>= 16;
             }
             st = ((st / e.p) << P) + e.c + st % e.p;
+            if constexpr (CK) {
+                if (active && t % jp.interval == 0) { jp.pos[s * jp.n_chunks + t / jp.interval] = wr; jp.state[s * jp.n_chunks + t / jp.interval] = st; }
+            }
         }
     }
     // into_compressed: the state's words, least significant first, zero high words dropped (lib.rs:719-731)
@@ -340,8 +366,25 @@ cst_status ans_encode_w16pk(const AnsEncodeArgs& a, hipStream_t hs) {
     const size_t lds = kPkEncRingBytes + (size_t)a.n_symbols * sizeof(W16PkEntry) + 2 * kPkEncTileBytes;
     const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
-    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_w16pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ans_encode_w16pk_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a);
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_w16pk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ans_encode_w16pk_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a, PkJumpArgs{nullptr, nullptr, 0u, 0u});
+    CST_HIP_TRY(hipGetLastError());
+    return CST_OK;
+}
+
+// ... noting jump points on its way: chunks of whole tiles that divide the rows; 32-bit indices into the jump arrays
+bool w16pk_ckpt_usable(const cst_model* m, cst_coder_config cfg, cst_layout layout, size_t n_streams, size_t n_per_stream, size_t interval) {
+    if (!w16pk_usable(m, cfg, layout) || interval == 0 || interval % kTileSyms != 0 || n_per_stream % interval != 0) return false;
+    return interval < (1u << 24) && n_streams * (n_per_stream / interval) < (1u << 28);
+}
+
+cst_status ans_encode_w16pk_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs) {
+    const size_t lds = kPkEncRingBytes + (size_t)a.n_symbols * sizeof(W16PkEntry) + 2 * kPkEncTileBytes;
+    const size_t blocks = (a.n_streams + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffull) return CST_ERR_INVALID_ARGUMENT;
+    CST_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ans_encode_w16pk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ans_encode_w16pk_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, hs, a,
+                       PkJumpArgs{d_ckpt_pos, d_ckpt_state, (uint32_t)interval, (uint32_t)(a.n_per_stream / interval)});
     CST_HIP_TRY(hipGetLastError());
     return CST_OK;
 }
@@ -360,6 +403,24 @@ cst_status ans_decode_w16pk(const AnsDecodeArgs& a, hipStream_t hs) {
 using namespace cst;
 
 extern "C" {
+
+cst_status cst_ans_encode_batch_ckpt_packed16(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, size_t n_streams, size_t n_per_stream,
+                                              uint16_t* d_words16, size_t stride_words, uint32_t* d_n_words, size_t ckpt_interval,
+                                              uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, int32_t* d_status, void* stream) {
+    if (!model || !d_words16 || !d_n_words || !d_status || !d_ckpt_pos || !d_ckpt_state || ckpt_interval == 0) return CST_ERR_INVALID_ARGUMENT;
+    if (n_per_stream > 0 && !d_symbols) return CST_ERR_INVALID_ARGUMENT;
+    if (!config_supported(cfg) || cfg.precision != model->precision || model->d_symbol_of_index) return CST_ERR_INVALID_ARGUMENT;
+    if (n_streams == 0) return CST_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != model->device) return CST_ERR_INVALID_ARGUMENT;
+    if (!w16pk_ckpt_usable(model, cfg, CST_LAYOUT_STREAM_MAJOR, n_streams, n_per_stream, ckpt_interval)) return CST_ERR_INVALID_ARGUMENT;
+    AnsEncodeArgs a{};
+    a.symbols = d_symbols; a.n_streams = n_streams; a.n_per_stream = n_per_stream; a.enc = model->d_enc;
+    a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
+    a.words = reinterpret_cast<uint32_t*>(d_words16); a.stride_words = stride_words; a.n_words = d_n_words; a.state = nullptr; a.status = d_status;
+    a.flags = CST_FLAG_PACKED_W16;
+    return note_kernel("ans_encode_w16pk_kernel<ckpt>", ans_encode_w16pk_ckpt(a, ckpt_interval, d_ckpt_pos, d_ckpt_state, (hipStream_t)stream));
+}
 
 cst_status cst_compact_words16(const uint16_t* d_words16, size_t stride_words, const uint32_t* d_n_words, size_t n_streams, uint64_t* d_offsets,
                                uint16_t* d_packed16, size_t packed_capacity, void* d_scratch, void* stream) {

@@ -248,6 +248,8 @@ struct AnsDecodeArgs;
 bool w16pk_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout);
 cst_status ans_encode_w16pk(const AnsEncodeArgs& a, hipStream_t hs);
 cst_status ans_decode_w16pk(const AnsDecodeArgs& a, hipStream_t hs);
+bool w16pk_ckpt_usable(const cst_model* model, cst_coder_config cfg, cst_layout layout, size_t n_streams, size_t n_per_stream, size_t interval);
+cst_status ans_encode_w16pk_ckpt(const AnsEncodeArgs& a, size_t interval, uint32_t* d_ckpt_pos, uint64_t* d_ckpt_state, hipStream_t hs);
 
 // Where stream s's compressed words lie in the caller's buffer -- CHECKED.  The reference's decoder cannot read out of
 // bounds (its backend is a Vec: src/backends.rs:495-507); here the counts and offsets are caller data, so a slice

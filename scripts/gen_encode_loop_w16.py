@@ -29,7 +29,14 @@ from asmgen import Asm  # noqa: E402
 # and stores 32 bytes at quad 5 and 32 at quad 2.  A chunk read late is never overwritten: word flushed + 4 c is written again
 # when wr reaches flushed + 64 + 4 c, and wr - flushed stays below 55 + 12.  Written to cst_encode_loop_w16_pk.inc.
 PACKED = bool(os.environ.get("GEN_W16_PACKED"))
-OUT = G.CSRC / ("cst_encode_loop_w16_pk.inc" if PACKED else "cst_encode_loop_w16.inc")
+# GEN_W16_CK=1 (round 6, with GEN_W16_PACKED): the same loop with JUMP POINTS -- the reference's Pos side information (stack.rs:1107-1139:
+# words in the bulk, state), which depends on neither the word type nor how the words are stored: after the last step of every
+# ck_tiles-th tile the lanes store (wr, state) at element ck_index of the two jump arrays and step to the chunk in front (as
+# gen_pt_encode_loop.py's GEN_PT_CK does).  Written to cst_encode_loop_w16_pk_ck.inc.
+CKPT = bool(os.environ.get("GEN_W16_CK"))
+assert not CKPT or PACKED
+OUT = G.CSRC / ("cst_encode_loop_w16_pk_ck.inc" if CKPT else "cst_encode_loop_w16_pk.inc" if PACKED else "cst_encode_loop_w16.inc")
+CKST, CKZ, CKA, CKCNT = "v218", "v219", "v220", "s92"          # v[218:219] = [state, 0]: the jump table holds 64-bit states
 A_, SH, QE, R_, T_, CKS = (f"v{r}" for r in range(212, 218))
 RA, NCH, LIM, FADDR, FOFF, FD, SAVE = G.RA, G.NCH, G.LIM, G.FADDR, G.FOFF, G.FD, G.SAVE
 
@@ -149,9 +156,30 @@ def half(a, h, g0):
             G.load_set(a, other)
 
 
+def checkpoint(a, label):
+    """after the last step of a tile: is this tile the first of a chunk?  then (wr, state) is that chunk's jump point"""
+    if not CKPT:
+        return
+    a.i(f"s_sub_u32 {CKCNT}, {CKCNT}, 1")
+    a.i(f"s_cmp_lg_u32 {CKCNT}, 0")
+    a.i(f"s_cbranch_scc1 {label}f")
+    a.i(f"v_lshlrev_b32 {CKA}, 2, %[ckidx]")
+    a.i(f"global_store_dword {CKA}, %[wr], %[ckpos]", "pos: 16-bit words in the bulk")
+    a.i(f"v_mov_b32 {CKST}, %[st]")
+    a.i(f"v_lshlrev_b32 {CKA}, 3, %[ckidx]")
+    a.i(f"global_store_dwordx2 {CKA}, v[218:219], %[ckstate]", "the coder state there")
+    a.i("v_add_u32 %[ckidx], -1, %[ckidx]", "the chunk in front of this one is next")
+    a.i(f"s_mov_b32 {CKCNT}, %[cktiles]")
+    a.i("s_waitcnt vmcnt(0)")
+    a.i(f"{label}:")
+
+
 def gen():
     G.SINGLE = False
     a = Asm()
+    if CKPT:
+        a.i(f"v_mov_b32 {CKZ}, 0")
+        a.i(f"s_mov_b32 {CKCNT}, %[cktiles]", "tiles until the next jump point")
     a.i("s_mov_b64 s[80:81], %[sbase]", "symbols of the LAST full tile of stream s0")
     a.i("s_mov_b32 s82, %[ntiles]", "tiles left to encode")
     a.i("s_sub_u32 s83, %[ntiles], 1", "tiles left to request")
@@ -166,10 +194,12 @@ def gen():
     a.i("1:")
     first = len(a.events)
     half(a, 0, 0)
+    checkpoint(a, "5")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_eq_u32 s82, 0")
     a.i("s_cbranch_scc1 2f")
     half(a, 1, 8)
+    checkpoint(a, "6")
     a.i("s_sub_u32 s82, s82, 1")
     a.i("s_cmp_lg_u32 s82, 0")
     a.i("s_cbranch_scc1 1b")
@@ -199,11 +229,12 @@ def emit(out, symbol_major):
     G.SYMBOL_MAJOR = False
     header = ["// GENERATED by scripts/gen_encode_loop_w16.py -- do not edit by hand (edit the generator and re-run it).",
               "// Main loop of the hand-scheduled (16,32) ANS encoder: see cst_ans_w16.hip."]
-    ops = ['    : [st] "+v"(st), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)',
+    ops = ['    : [st] "+v"(st), [wr] "+v"(wr), [flushed] "+v"(flushed), [smin] "+v"(smin), [smax] "+v"(smax)' + (', [ckidx] "+v"(ck_index)' if CKPT else ""),
            '    : [row0] "v"(tile_row_addr[0]), [row1] "v"(tile_row_addr[1]), [tr0] "v"(tile_tr_addr[0]), [tr1] "v"(tile_tr_addr[1]),',
            '      [lanebase] "v"(ring_lane_addr), [cap] "v"(cap), [slaboff] "v"(slab_off),',
            '      [tbl] "s"(table_addr_biased), [P] "s"(P), [c3f00] "s"(0x3f00u), [wbase] "s"(words_base),',
-           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else ''),
+           '      [sbase] "s"(symbols_base), [ntiles] "s"(n_tiles),' + (' [tilestep] "s"(tile_step_bytes),' if symbol_major else '')
+           + (' [ckpos] "s"(ck_pos_base), [ckstate] "s"(ck_state_base), [cktiles] "s"(ck_tiles),' if CKPT else ''),
            '      ' + ", ".join(f'[goff{k}] "v"(goff[{k}])' for k in range(8)),
            "    : " + ", ".join(f'"{c}"' for c in G.CLOBBERS) + ");"]
     out.write_text(a.render(header, ops))

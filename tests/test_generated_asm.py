@@ -252,6 +252,8 @@ def test_packed_w16_loops_are_in_sync(tmp_path, monkeypatch):
     monkeypatch.setenv("GEN_W16_PACKED", "1")
     assert _regenerate(_load("gen_decode_loop_w16"), tmp_path, "cst_decode_loop_w16_pk.inc") == (csrc / "cst_decode_loop_w16_pk.inc").read_text()
     assert _regenerate(_load("gen_encode_loop_w16"), tmp_path, "cst_encode_loop_w16_pk.inc") == (csrc / "cst_encode_loop_w16_pk.inc").read_text()
+    monkeypatch.setenv("GEN_W16_CK", "1")                 # round 6: the packed encoder noting jump points on its way
+    assert _regenerate(_load("gen_encode_loop_w16"), tmp_path, "cst_encode_loop_w16_pk_ck.inc") == (csrc / "cst_encode_loop_w16_pk_ck.inc").read_text()
 
 
 def test_every_loop_head_is_pinned_to_a_cache_line():

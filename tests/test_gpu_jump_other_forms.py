@@ -44,6 +44,7 @@ def test_packed16_jump_points(B, O, n_streams, n_per, P, k):
     plain = B.ans_encode(d, model, cfg, packed16=True)
     assert plain.jump is None                                   # "auto" notes none on the packed preset
     enc = B.ans_encode(d, model, cfg, packed16=True, jump_points=k)
+    assert B.last_kernel() == "ans_encode_w16pk_kernel<ckpt>"           # chunks of whole tiles: the packed encoder notes them on its way
     assert enc.packed16 and enc.jump is not None and enc.jump.pos.shape == (n_streams, k) and enc.jump.interval == n_per // k
     assert torch.equal(enc.n_words, plain.n_words) and torch.equal(enc.status, plain.status)
     used = torch.arange(enc.words.shape[1], device="cuda")[None, :] < enc.n_words[:, None]
@@ -60,6 +61,32 @@ def test_packed16_jump_points(B, O, n_streams, n_per, P, k):
     assert st.shape == (n_streams, k) and int(st.abs().sum()) == 0 and torch.equal(dec, d)
     dec, st = B.ans_decode(plain, model, n_per)
     assert torch.equal(dec, d)
+
+
+@pytest.mark.parametrize("n_streams,n_per,interval", [(256, 1024, 32), (100, 640, 64), (65, 96, 96), (3, 2048, 16), (40, 1000, 250), (256, 1056, 48)])
+def test_packed16_jump_points_every_tile_at_the_maximum_word_rate(B, O, n_streams, n_per, interval):
+    """every symbol costs P bits (the rarest symbols only) and a jump point sits on every tile (or on odd chunks: the scratch-slab
+    path): words and tables against the oracle, every chunk decodes from its point"""
+    P, lo = 12, 0
+    p = np.full(64, 1, dtype=np.int64); p[0] = (1 << P) - 63
+    cdf = np.concatenate([[0], np.cumsum(p)]).astype(np.uint32)
+    model = B.Model.from_cdf(cdf, lo, P)
+    rng = np.random.default_rng(n_streams + n_per)
+    sym = rng.integers(1, 64, (n_streams, n_per)).astype(np.int32)
+    d = dev(sym)
+    k = n_per // interval
+    enc = B.ans_encode(d, model, (16, 32, P), packed16=True, jump_points=k)
+    fast = interval % 32 == 0
+    assert (B.last_kernel() == "ans_encode_w16pk_kernel<ckpt>") == fast
+    want_words, want_n, want_st = O.ans_encode_batch(sym, lo, cdf, P, W=16, S=32)
+    words, n_words, status = enc.to_numpy()
+    assert (status == 0).all() and n_words.tolist() == want_n.tolist()
+    for s in range(n_streams):
+        assert np.array_equal(words[s, : n_words[s]], want_words[s, : want_n[s]].astype(np.uint16)), f"stream {s}"
+    wp, ws = O.ans_jump_table(sym, lo, cdf, P, interval, W=16, S=32)
+    assert np.array_equal(enc.jump.pos.cpu().numpy().view(np.uint32), wp) and np.array_equal(enc.jump.state.cpu().numpy().view(np.uint64), ws)
+    dec, st = B.ans_decode_checkpointed(enc, enc.jump, model, n_per)
+    assert int(st.abs().sum()) == 0 and torch.equal(dec, d)
 
 
 def test_packed16_bad_jump_point_is_flagged(B, O):
