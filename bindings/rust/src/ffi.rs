@@ -791,7 +791,7 @@ extern "C" {
     ///   CST_DQ_DECODER=1         the lane-quad decoder without CST_FLAG_COLD_WORDS CST_PT_SUB_WAVES=8 sub-lane decoder: never sixteen waves
     ///   CST_SUB_ORDER=0          range sub-lane decoder: chunks side by side      CST_LANE_GEO=big|small   per-symbol lane decoder geometry
     ///   CST_FUSED_MIN_STREAMS=n  from how many streams the fused per-symbol encoder runs
-    ///   CST_AUTO_JUMP=0          cst_jump_points_auto* answer 0
+    ///   CST_AUTO_JUMP=0          cst_jump_points_auto* answer 0                  CST_RAGGED_GROUP=8|16|32   ragged encoder: symbols per memory point
     /// (CST_RCCL_LIB=<path>, read at the first collective call, names the RCCL library to open.)
     /// cst_debug_reload_knobs re-reads them: for tests that drive several paths inside one process; not thread-safe against
     /// concurrent coder calls.

@@ -84,8 +84,12 @@ __device__ __forceinline__ void consume(rv4i& a, rv4i& b) {
 }
 
 // FAST (W = 32, P >= 8): the hand-scheduled coder steps of the other kernels (32-bit halves, cst_ans_asm.hpp)
-template <int W, int S, bool STAGED, bool FAST>
+// G = symbols per memory point: 8, or 16 / 32 (round 6) -- a lane's next group is requested one group ahead, and eight steps (~800
+// cycles) do not cover a gather's round trip under load: the LONGEST stream of a batch is a chain of len / G such waits, and with
+// G = 8 it set every batch's time (2000 symbols: 0.30 ms whether the batch held 2 000 or 100 000 documents)
+template <int W, int S, bool STAGED, bool FAST, int G = 8>
 __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedArgs a) {
+    constexpr int kRaggedGroup = G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * kRingWords;
@@ -150,20 +154,37 @@ __global__ __launch_bounds__(kBlock) void ans_encode_ragged_kernel(const RaggedA
     if (jumps && to_jump == 0) { to_jump = groups_per_chunk; if (pre == 0) --next_chunk; }      // (no chunk starts at len itself)
     const uint32_t ng = len / kRaggedGroup;                     // whole groups, coded from the last one down
     const uint32_t mxg = wave_max_u32(ng);
-    const rv4i_unaligned* g4 = reinterpret_cast<const rv4i_unaligned*>(row);        // group g = pieces 2g, 2g + 1
-    rv4i n0 = {0, 0, 0, 0}, n1 = {0, 0, 0, 0};
-    if (ng > 0) { n0 = g4[2 * ng - 2].v; n1 = g4[2 * ng - 1].v; }
+    constexpr int Q = G / 4;                                                        // 16-byte pieces per group
+    const rv4i_unaligned* g4 = reinterpret_cast<const rv4i_unaligned*>(row);        // group g = pieces Q g .. Q g + Q - 1
+    rv4i nx[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) nx[q] = rv4i{0, 0, 0, 0};
+    if (ng > 0) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) nx[q] = g4[Q * (ng - 1) + q].v;
+    }
     for (uint32_t g = 0; g < mxg; ++g) {
-        consume(n0, n1);                    // group g's symbols (requested a group ago) -- and every older store
-        const rv4i c0 = n0, c1 = n1;
-        if (g + 1 < ng) { n0 = g4[2 * (ng - g) - 4].v; n1 = g4[2 * (ng - g) - 3].v; }
-        L.flush_chunks();                   // complete 16-byte chunks of the words of earlier groups: ring -> slab (at most 3)
+#pragma unroll
+        for (int q = 0; q < Q; q += 2) consume(nx[q], nx[q + 1]);      // group g's symbols (requested a group ago) -- and every older store
+        rv4i cur[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) cur[q] = nx[q];
+        if (g + 1 < ng) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nx[q] = g4[Q * (ng - g - 2) + q].v;
+        }
+        L.flush_chunks();                   // complete 16-byte chunks of the words of earlier groups: ring -> slab (at most 5)
+        if constexpr (G > 16) L.flush_chunks();
         store_jump_point();                 // (a jump point noted by the previous group)
         if (g < ng) {
-            const EncEntry e7 = entry(c1.w), e6 = entry(c1.z), e5 = entry(c1.y), e4 = entry(c1.x);
-            const EncEntry e3 = entry(c0.w), e2 = entry(c0.z), e1 = entry(c0.y), e0 = entry(c0.x);
-            L.template step<FAST>(e7, P); L.template step<FAST>(e6, P); L.template step<FAST>(e5, P); L.template step<FAST>(e4, P);
-            L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
+#pragma unroll
+            for (int q = Q - 1; q >= 0; q -= 2) {                       // eight steps at a time, the group's last symbols first
+                const rv4i c0 = cur[q - 1], c1 = cur[q];
+                const EncEntry e7 = entry(c1.w), e6 = entry(c1.z), e5 = entry(c1.y), e4 = entry(c1.x);
+                const EncEntry e3 = entry(c0.w), e2 = entry(c0.z), e1 = entry(c0.y), e0 = entry(c0.x);
+                L.template step<FAST>(e7, P); L.template step<FAST>(e6, P); L.template step<FAST>(e5, P); L.template step<FAST>(e4, P);
+                L.template step<FAST>(e3, P); L.template step<FAST>(e2, P); L.template step<FAST>(e1, P); L.template step<FAST>(e0, P);
+            }
             if (jumps && --to_jump == 0) { note_here(); to_jump = groups_per_chunk; }
         }
     }
@@ -377,6 +398,31 @@ static cst_status ragged_launch(K kernel, const RaggedArgs& a, size_t ring_bytes
                        : ragged_launch(KERNEL<32, 64, false, false>, a, RING_BYTES, t_, hs, ##__VA_ARGS__);                          \
     } while (0)
 
+// the encoder's kernels by symbols per memory point (G): 16 by default, 8 where a jump interval is not a multiple of 16
+// (CST_RAGGED_GROUP=8|16|32 forces one that divides the interval)
+#define CST_RAGGED_ENC_KERNEL(G)                                                                                                      \
+    do {                                                                                                                             \
+        const size_t tb_ = ragged_encode_table_bytes(model);                                                                         \
+        const bool staged_ = tb_ <= kRaggedStageLimit && kRaggedRingBytes + tb_ <= device_lds_limit();                               \
+        const size_t t_ = staged_ ? tb_ : 0;                                                                                         \
+        if (cfg.word_bits != 32)                                                                                                     \
+            return staged_ ? ragged_launch(ans_encode_ragged_kernel<16, 32, true, false, G>, a, kRaggedRingBytes, t_, hs)            \
+                           : ragged_launch(ans_encode_ragged_kernel<16, 32, false, false, G>, a, kRaggedRingBytes, t_, hs);          \
+        if (model->precision >= 8)                                                                                                   \
+            return staged_ ? ragged_launch(ans_encode_ragged_kernel<32, 64, true, true, G>, a, kRaggedRingBytes, t_, hs)             \
+                           : ragged_launch(ans_encode_ragged_kernel<32, 64, false, true, G>, a, kRaggedRingBytes, t_, hs);           \
+        return staged_ ? ragged_launch(ans_encode_ragged_kernel<32, 64, true, false, G>, a, kRaggedRingBytes, t_, hs)                \
+                       : ragged_launch(ans_encode_ragged_kernel<32, 64, false, false, G>, a, kRaggedRingBytes, t_, hs);              \
+    } while (0)
+
+static cst_status encode_ragged_dispatch(const cst_model* model, cst_coder_config cfg, const RaggedArgs& a, hipStream_t hs) {
+    int g = knobs().ragged_group;
+    if (a.jump_interval != 0 && a.jump_interval % (uint32_t)g != 0) g = a.jump_interval % 16 == 0 ? 16 : 8;
+    if (g == 32) CST_RAGGED_ENC_KERNEL(32);
+    if (g == 16) CST_RAGGED_ENC_KERNEL(16);
+    CST_RAGGED_ENC_KERNEL(8);
+}
+
 cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const int32_t* d_symbols, const uint64_t* d_sym_offsets,
                              size_t n_streams, uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
                              uint32_t* d_n_words, int32_t* d_status, const uint32_t* d_order, hipStream_t hs) {
@@ -385,7 +431,7 @@ cst_status ans_encode_ragged(const cst_model* model, cst_coder_config cfg, const
     a.symbols_in = d_symbols; a.sym_offsets = d_sym_offsets; a.n_streams = n_streams; a.enc = model->d_enc;
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_out = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_out = d_n_words; a.status = d_status;
-    CST_RAGGED_DISPATCH(ans_encode_ragged_kernel, kRaggedRingBytes, ragged_encode_table_bytes(model));
+    return encode_ragged_dispatch(model, cfg, a, hs);
 }
 
 static RaggedArgs ragged_decode_args(const cst_model* model, const uint32_t* d_words, const uint64_t* d_word_offsets, size_t stride_words,
@@ -466,7 +512,7 @@ cst_status ans_encode_ragged_jump(const cst_model* model, cst_coder_config cfg, 
     a.n_symbols = model->n_symbols; a.min_symbol = model->min_symbol; a.precision = model->precision;
     a.words_out = d_words; a.word_offsets = d_word_offsets; a.stride_words = stride_words; a.n_words_out = d_n_words; a.status = d_status;
     a.jump_interval = interval; a.jump_chunk_offsets = d_chunk_offsets; a.jump_pos = d_jump_pos; a.jump_state = d_jump_state;
-    CST_RAGGED_DISPATCH(ans_encode_ragged_kernel, kRaggedRingBytes, ragged_encode_table_bytes(model));
+    return encode_ragged_dispatch(model, cfg, a, hs);
 }
 
 static cst_status decode_ragged_virtual(const cst_model* model, cst_coder_config cfg, const RaggedArgs& a, hipStream_t hs) {

@@ -37,6 +37,7 @@ static Knobs read_knobs() {
     if (const char* e = env("CST_LANE_GEO")) k.lane_geo = e[0] == 's' ? 2 : e[0] == 'b' ? 1 : 0;
     if (const char* e = env("CST_FUSED_MIN_STREAMS")) k.fused_min_streams = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = env("CST_AUTO_JUMP")) k.auto_jump = e[0] == '0' ? 0 : 1;
+    if (const char* e = env("CST_RAGGED_GROUP")) k.ragged_group = e[0] == '8' ? 8 : e[0] == '3' ? 32 : 16;
     return k;
 }
 

@@ -155,6 +155,7 @@ struct Knobs {
     int lane_geo = 0;                 // CST_LANE_GEO=big|small: 1 / 2 forces a geometry of the per-symbol lane decoder (0: by shape)
     size_t fused_min_streams = 16384; // CST_FUSED_MIN_STREAMS: from how many streams the fused per-symbol encoder runs
     int auto_jump = 1;                // CST_AUTO_JUMP=0: cst_jump_points_auto answers 0 (the plain decoders everywhere)
+    int ragged_group = 16;            // CST_RAGGED_GROUP=8|16|32: symbols per memory point of the ragged encoder (cst_ans_ragged.hip)
 };
 const Knobs& knobs();
 
