@@ -63,6 +63,12 @@ K_PRED = bool(os.environ.get("GEN_KPRED"))
 # ... bit-exact, and 4.7 % SLOWER (0.265 against 0.253 ms, gpurun_out/r04_elig.txt): the two instructions it adds behind the lookup's issue
 # cost more than the one it removes in front of it -- the shadow of the lookup is full.  Kept as an experiment (GEN_ELIG=1).
 EARLY_ELIG = not K_PRED and bool(os.environ.get("GEN_ELIG"))
+# LAZY_SYM (experiment, GEN_LAZY_SYM=1): the wait in front of the refill select covers the candidate WORD only -- lgkmcnt(1) or more instead of
+# lgkmcnt(0): the symbol read issued behind it (a second random read: ~13 LDS cycles per wave, scripts/microbench/lds_tput.hip) and the
+# transposing tile reads are off the chain; their consumers (the quad's tile write, the tile stores) wait for them by name
+# ... bit-exact and NO faster (0.2537 / 0.2571 against 0.2536 / 0.2531 ms, alternating runs on one box): the five instructions between the entry's
+# arrival and that wait already cover the symbol read -- the LDS pipe's 70 % load does not lengthen the chain.  Kept as an experiment.
+LAZY_SYM = bool(os.environ.get("GEN_LAZY_SYM"))
 ABL_R1 = bool(os.environ.get("GEN_ABL_R1"))      # timing experiment: no min(rd, 1) per step (right only while no stream runs out of words)
 
 
@@ -178,7 +184,10 @@ def gen():
             if not EARLY_ELIG:
                 a.i(f"v_mad_u32_u24 {N1}, {T1}, {PR}, {N1}")
             a.i(f"v_cmp_lt_u32 vcc, {N1}, {R1}", "refill <=> N < 2^32 and words remain")
-            a.wait_lds_all("candidate word (and everything older) is back")
+            if LAZY_SYM:
+                a.wait_lds("w", "candidate word is back (the symbol read behind it may still fly)")
+            else:
+                a.wait_lds_all("candidate word (and everything older) is back")
             a.i(f"v_cndmask_b32 %[lo], {N0}, {WD}, vcc")
             a.i(f"v_and_b32 {Q}, %[mask], %[lo]")
             a.i(f"v_lshl_add_u32 {LA}, {Q}, 2, %[lut]")
@@ -229,12 +238,16 @@ def gen():
                 a.vmem(f"global_store_dwordx4 %[goff{k}], {X2 if k % 2 else X}, s[80:81] {STORE_MOD}".rstrip(), f"store{k}")
         elif pos == 2:
             # x was issued in step pos 1 and is covered by this step's lgkmcnt(0)
+            if LAZY_SYM and "x" in a.lds:
+                a.wait_lds("x", "the previous tile's piece is back")
             if NO_STORE:
                 a.vm.append(f"store{quad}")
             else:
                 a.vmem(f"global_store_dwordx4 %[goff{quad}], {X}, s[80:81] {os.environ['GEN_STORE_MOD'].replace('+', ' ') if 'GEN_STORE_MOD' in os.environ else STORE_MOD}".rstrip(), f"store{quad}")
         if pos == 3:
             base = (quad % 2) * 4
+            if LAZY_SYM and f"sym{j}" in a.lds:
+                a.wait_lds(f"sym{j}", "the quad's last symbol is back")
             a.ds(f"ds_write_b128 %[rowcur], v[{134 + base}:{137 + base}] offset:{16 * quad}", "tile", f"symbols {4 * quad}..{4 * quad + 3}")
 
     a.wait_lds_all("---- end of tile")
