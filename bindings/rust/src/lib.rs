@@ -661,6 +661,63 @@ impl BatchedAnsCoder {
         Ok((out, ckpt))
     }
 
+    /// `AnsCoder::seek(pos, state)` + `interval` symbols for every chunk of an `EncodedBatch16` (src/stream/stack.rs:1117-1128): the
+    /// chunks are decoded as `n_streams * n_chunks` streams of their own by the plain batched decoder -- word offsets (in 16-bit words)
+    /// = their stream's slab, counts = the jump points' word counts, raw states.  The states are COPIED first: with
+    /// `CST_FLAG_RAW_STATE` the decoder leaves its final states in that array, and a jump table is side information that outlives
+    /// a decode.  `status` has one entry per chunk (`DecodedBatch::status_per_stream` folds them); a jump point that claims more
+    /// words than its stream holds is refused up front (`InvalidArgument` after a host read of the counts).
+    pub fn decode_iid_symbols_packed16_from_checkpoints(
+        &self,
+        encoded: &EncodedBatch16,
+        checkpoints: &Checkpoints,
+        n_per_stream: usize,
+        model: &DeviceModel,
+        stream: &Stream,
+    ) -> Result<DecodedBatch> {
+        let n_streams = encoded.n_streams;
+        let n_chunks = checkpoints.chunks_for(n_streams, n_per_stream)?;
+        let n_virtual = n_streams.checked_mul(n_chunks).ok_or(Error::InvalidArgument)?;
+        let count = n_streams.checked_mul(n_per_stream).ok_or(Error::InvalidArgument)?;
+        stream.synchronize()?;
+        let pos = checkpoints.pos.to_vec_prefix(n_virtual)?;
+        let n_words = encoded.n_words.to_vec_prefix(n_streams)?;
+        let mut offsets: Vec<u64> = Vec::with_capacity(n_virtual);
+        for s in 0..n_streams {
+            for j in 0..n_chunks {
+                if pos[s * n_chunks + j] > n_words[s] || pos[s * n_chunks + j] as usize > encoded.stride_words {
+                    return Err(Error::InvalidArgument);
+                }
+                offsets.push((s * encoded.stride_words) as u64);
+            }
+        }
+        let d_offsets = DeviceBuffer::from_slice(&offsets)?;
+        let mut states = DeviceBuffer::from_slice(&checkpoints.state.to_vec_prefix(n_virtual)?)?; // a COPY: in and out
+        let mut out = DecodedBatch { symbols: DeviceBuffer::new(count)?, status: DeviceBuffer::new(n_virtual)? };
+        check(unsafe {
+            ffi::cst_ans_decode_batch(
+                model.as_raw(),
+                self.config,
+                encoded.words.as_ptr() as *const u32,
+                d_offsets.as_ptr(),
+                0,
+                encoded.words.len(),
+                checkpoints.pos.as_ptr(),
+                out.symbols.as_mut_ptr(),
+                n_virtual,
+                checkpoints.interval,
+                ffi::CST_LAYOUT_STREAM_MAJOR,
+                states.as_mut_ptr(),
+                core::ptr::null_mut(),
+                out.status.as_mut_ptr(),
+                ffi::CST_FLAG_PACKED_W16 | ffi::CST_FLAG_RAW_STATE,
+                stream.as_raw(),
+            )
+        })?;
+        stream.synchronize()?; // (the offsets and the copied states are dropped on return)
+        Ok(out)
+    }
+
     /// The decoder of `encode_iid_symbols_reverse_packed16`.
     pub fn decode_iid_symbols_packed16(&self, encoded: &EncodedBatch16, n_per_stream: usize, model: &DeviceModel, stream: &Stream) -> Result<DecodedBatch> {
         let n_streams = encoded.n_streams;
