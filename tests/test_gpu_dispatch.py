@@ -92,6 +92,10 @@ def test_c2_small_preset_plain_and_packed(B, c2):
     enc = _roundtrip(B, lambda: B.ans_encode(sym, model, (16, 32, 12), packed16=True), lambda e: B.ans_decode(e, model, N_PER),
                      "ans_encode_w16pk_kernel", "ans_decode_w16pk_kernel", sym)
     assert enc.packed16 and enc.jump is None
+    # asked for explicitly (random access): the packed encoder notes the points on its way, the chunks decode as streams of their own
+    enc = _roundtrip(B, lambda: B.ans_encode(sym, model, (16, 32, 12), packed16=True, jump_points=2), lambda e: B.ans_decode(e, model, N_PER),
+                     "ans_encode_w16pk_kernel<ckpt>", "ans_decode_w16pk_kernel", sym)
+    assert enc.jump.pos.shape == (N_STREAMS, 2)
 
 
 def test_c3_tables_per_stream(B, bench):
